@@ -1,0 +1,263 @@
+"""Host-side processors: tokenisation/left-padding, image-tag merging and the
+HD image transform.  Drop-in for the reference's `Phi3FProcessor`,
+`Phi3VProcessor` and `Phi3VImageProcessor` (reference phi.py:228-372): same
+call signatures, same dictionary keys, same values.
+
+Outputs are NumPy arrays (the model object moves them to the GPU); with
+``return_mx`` kept only for signature compatibility.
+
+`Phi3VImageProcessor` reproduces the reference bit for bit, including the
+degenerate two-tap "bicubic" global crop -- but the
+reference's 4-deep Python loop over 336x336x3 pixels (phi.py:365-371, ~5.6 s
+per image) is evaluated as four vectorised gathers with the identical
+floating-point association, see `interpolate_336`.
+"""
+import os
+import re
+
+import numpy as np
+
+IMAGE_TAG = r"<\|image_\d+\|>"
+
+
+# ---------------------------------------------------------------------------
+# Tokenizers
+# ---------------------------------------------------------------------------
+class _Enc:
+    def __init__(self, input_ids):
+        self.input_ids = input_ids
+
+    def __getitem__(self, k):
+        return getattr(self, k)
+
+
+class ByteTokenizer:
+    """Fallback tokenizer for synthetic model directories (no tokenizer files).
+
+    Mimics the observable behaviour of the Llama-style Phi-3 tokenizer that the
+    reference relies on: a BOS (id 1) is prepended to every encoded string
+    (Q6), a dummy-prefix token precedes the text (so that
+    ``encode(text, add_special_tokens=False)[1:]`` drops it exactly as
+    reference phi_3_vision_mlx.py:538 expects), the chat markers are single
+    ids (``<|end|>`` = 32007, ``<|assistant|>`` = 32001), pad id is 0 and text
+    is byte-level (ids 3..258)."""
+    BOS, PAD, PREFIX = 1, 0, 29871
+    SPECIALS = {"<|endoftext|>": 32000, "<|assistant|>": 32001, "<|system|>": 32006,
+                "<|end|>": 32007, "<|user|>": 32010}
+
+    def __init__(self):
+        self._inv = {v: k for k, v in self.SPECIALS.items()}
+        self._split = re.compile("(" + "|".join(re.escape(k) for k in self.SPECIALS) + ")")
+
+    def encode(self, text, add_special_tokens=True):
+        ids = [self.BOS] if add_special_tokens else []
+        ids.append(self.PREFIX)
+        for part in self._split.split(text):
+            if part in self.SPECIALS:
+                ids.append(self.SPECIALS[part])
+            else:
+                ids.extend(3 + b for b in part.encode("utf-8"))
+        return ids
+
+    def __call__(self, texts, add_special_tokens=True):
+        if isinstance(texts, str):
+            return _Enc(self.encode(texts, add_special_tokens))
+        return _Enc([self.encode(t, add_special_tokens) for t in texts])
+
+    def decode(self, ids, skip_special_tokens=False):
+        out, buf = [], bytearray()
+
+        def flush():
+            if buf:
+                out.append(buf.decode("utf-8", errors="replace"))
+                buf.clear()
+        for i in (int(t) for t in ids):
+            if 3 <= i <= 258:
+                buf.append(i - 3)
+                continue
+            flush()
+            if i == self.PREFIX or i in (self.BOS, self.PAD):
+                continue
+            out.append(self._inv[i] if i in self._inv else f"<{i}>")
+        flush()
+        return "".join(out)
+
+    def batch_decode(self, seqs, skip_special_tokens=False):
+        return [self.decode(s, skip_special_tokens) for s in seqs]
+
+
+def load_tokenizer(local_dir):
+    """`AutoTokenizer.from_pretrained(local_dir)` as the reference does
+    (phi.py:230) when tokenizer files exist; otherwise the byte fallback."""
+    has_files = local_dir is not None and any(
+        os.path.exists(os.path.join(local_dir, f)) for f in ("tokenizer.json", "tokenizer.model", "tokenizer_config.json"))
+    if has_files:
+        from transformers import AutoTokenizer
+        return AutoTokenizer.from_pretrained(local_dir)
+    return ByteTokenizer()
+
+
+# ---------------------------------------------------------------------------
+# Text processor
+# ---------------------------------------------------------------------------
+class Phi3FProcessor:
+    """reference phi.py:228-250."""
+
+    def __init__(self, local_dir=None, return_mx=True, tokenizer=None):
+        self.tokenizer = tokenizer if tokenizer is not None else load_tokenizer(local_dir)
+        self.return_mx = return_mx
+
+    def _tokenize(self, texts):
+        if isinstance(texts, str):
+            return {"input_ids": np.asarray(self.tokenizer(texts).input_ids, dtype=np.int64)[None]}
+        ids = self.tokenizer(texts).input_ids
+        width = max(len(s) for s in ids)
+        # left pad: token 0, position id 1, mask 0 (phi.py:238-240)
+        pids = [[1] * (width - len(s)) + list(range(len(s))) for s in ids]
+        mask = [[0] * (width - len(s)) + [1] * len(s) for s in ids]
+        ids = [[0] * (width - len(s)) + list(s) for s in ids]
+        return {"input_ids": np.asarray(ids, dtype=np.int64), "pids": np.asarray(pids, dtype=np.int64),
+                "mask": np.asarray(mask, dtype=np.int64)}
+
+    def __call__(self, texts, images=None):
+        if images is not None:
+            print("WARNING: You are using phi3_mini_128k. Use phi3_v for VLM tasks.")
+        return self._tokenize(texts)
+
+
+class Phi3VProcessor(Phi3FProcessor):
+    """reference phi.py:252-281."""
+
+    def __init__(self, local_dir=None, return_mx=True, tokenizer=None):
+        super().__init__(local_dir, return_mx, tokenizer)
+        self.img_processor = Phi3VImageProcessor()
+
+    def __call__(self, texts, images=None):
+        if images is None:
+            return self._tokenize(texts)
+        return self._merge(self.img_processor(images), texts)
+
+    def _merge(self, images, texts):
+        # Each text chunk is tokenised on its own, so whatever the tokenizer
+        # prepends (BOS) re-appears after the image slots (Q6) -- kept.
+        chunks = self.tokenizer(re.split(IMAGE_TAG, texts)).input_ids
+        n_tok = images["num_img_tokens"]
+        tags = re.findall(IMAGE_TAG, texts)
+        image_ids = [int(t.split("|")[1].split("_")[-1]) for t in tags]
+        pads = [[-iid] * n_tok[iid - 1] for iid in image_ids]
+        if len(chunks) > len(pads):
+            pads = pads + [[]]
+        input_ids = []
+        for chunk, pad in zip(chunks, pads):
+            input_ids.extend(chunk)
+            input_ids.extend(pad)
+        input_ids = np.asarray(input_ids, dtype=np.int64)[None]
+        return {"input_ids": input_ids,
+                "pixel_values": images["pixel_values"],
+                "image_sizes": np.asarray(images["image_sizes"], dtype=np.int64),
+                "positions": np.argwhere(input_ids < 0)}
+
+
+# ---------------------------------------------------------------------------
+# Image processor
+# ---------------------------------------------------------------------------
+def _cubic(x):
+    """Keys cubic (a=-0.5) on a NumPy float64 scalar -- scalar arithmetic on
+    purpose: the reference evaluates it per element on scalars (phi.py:334-340)
+    and scalar vs SIMD `pow` may differ in the last bit."""
+    ax = np.abs(x)
+    ax2 = ax ** 2
+    ax3 = ax ** 3
+    return ((1.5 * ax3 - 2.5 * ax2 + 1) * (ax <= 1) +
+            (-0.5 * ax3 + 2.5 * ax2 - 4 * ax + 2) * ((ax > 1) & (ax <= 2)))
+
+
+def _taps(scale, out_size, in_size):
+    """Four-tap weights (fp32) and source indices per output coordinate
+    (reference `get_weights_and_indices`, phi.py:333-359).  Only taps 0,1 are
+    ever filled; taps 2,3 keep weight 0 and index 0, exactly as there."""
+    oc = np.linspace(0, in_size - 1, out_size)
+    ic = oc / scale
+    left = np.floor(ic - 0.5).astype(np.int32)
+    right = left + 1
+    left = np.clip(left, 0, in_size - 1)
+    right = np.clip(right, 0, in_size - 1)
+    w = np.zeros((out_size, 4), dtype=np.float32)
+    idx = np.zeros((out_size, 4), dtype=np.int32)
+    idx[:, 0], idx[:, 1] = left, right
+    for i in range(out_size):
+        w[i, 0] = _cubic(ic[i] - left[i])
+        w[i, 1] = _cubic(right[i] - ic[i])
+        s = w[i].sum()
+        if s != 0:
+            w[i] /= s
+    return w, idx
+
+
+class Phi3VImageProcessor:
+    """reference phi.py:283-372."""
+
+    def __init__(self):
+        self.num_crops = 16
+        self.image_mean = np.array([0.48145466, 0.4578275, 0.40821073])
+        self.image_std = np.array([0.26862954, 0.26130258, 0.27577711])
+
+    def hd_transform(self, img):
+        """`HD_transform` (phi.py:290-310): RGB -> (transpose if portrait) ->
+        bilinear resize to (scale*336, .) -> white-pad height to a multiple of
+        336 -> normalise -> CHW float64."""
+        from PIL import Image, ImageOps
+        img = img.convert("RGB")
+        w, h = img.size
+        portrait = w < h
+        if portrait:
+            img = img.transpose(Image.TRANSPOSE)
+            w, h = img.size
+        scale = int(np.sqrt(self.num_crops * w / h))
+        img = img.resize([int(scale * 336), int(scale * 336 * h / w)], Image.BILINEAR)
+        hh = img.size[1]
+        diff = int(np.ceil(hh / 336) * 336) - hh
+        top = int(diff / 2)
+        img = ImageOps.expand(img, border=(0, top, 0, diff - top), fill=(255, 255, 255))
+        if portrait:
+            img = img.transpose(Image.TRANSPOSE)
+        return ((np.array(img) / 255.0 - self.image_mean) / self.image_std).transpose(2, 0, 1)
+
+    @staticmethod
+    def interpolate_336(x):
+        """Reference `interpolate_336` (phi.py:331-372), vectorised over pixels.
+
+        out[i,j] = np.sum(hw[i][:,None] * ww[j] * x[hi[i]][:, wi[j]]) over a 4x4
+        window.  The weight product is rounded to fp32 before it meets the
+        float64 pixels, and the 16 doubles e[0..15] are added in the order
+        NumPy's add-reduce uses (see the comment at the summation below).
+        All 16 terms are kept (12 of them are signed zeros) so that even the
+        sign of a zero result matches the reference bit for bit."""
+        N, C, H, W = x.shape
+        hw, hi = _taps(336 / H, 336, H)
+        ww, wi = _taps(336 / W, 336, W)
+        e = []
+        for a in range(4):
+            xa = x[:, :, hi[:, a], :]
+            for b in range(4):
+                wab = hw[:, a][:, None] * ww[:, b][None, :]          # fp32 x fp32 -> fp32
+                e.append(wab * xa[:, :, :, wi[:, b]])                 # fp32 x fp64 -> fp64
+        # np.sum of the contiguous 4x4 = identity (+0.0) + NumPy's unrolled pairwise
+        # sum: r[k] = e[k] + e[k+8]; ((r0+r1)+(r2+r3)) + ((r4+r5)+(r6+r7)).  The
+        # leading +0.0 matters: an all-(-0.0) window sums to +0.0 in the reference.
+        r = [e[k] + e[k + 8] for k in range(8)]
+        out = 0.0 + (((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7])))
+        return out.astype(x.dtype, copy=False)
+
+    def __call__(self, images):
+        hd = [self.hd_transform(im) for im in images]
+        shapes = [[im.shape[1], im.shape[2]] for im in hd]
+        num_img_tokens = [int((h // 336 * w // 336 + 1) * 144 + 1 + (h // 336 + 1) * 12) for h, w in shapes]
+        glb = [self.interpolate_336(im[None]) for im in hd]
+        crops = [im.reshape(1, 3, h // 336, 336, w // 336, 336).transpose(0, 2, 4, 1, 3, 5).reshape(-1, 3, 336, 336)
+                 for im, (h, w) in zip(hd, shapes)]
+        crops = [np.concatenate([g, c], axis=0) for g, c in zip(glb, crops)]
+        out = np.zeros((len(crops), 17, 3, 336, 336))
+        for i, c in enumerate(crops):
+            out[i, :c.shape[0]] = c                         # zero-pad to 17 crop slots (phi.py:311-316)
+        return {"pixel_values": out, "image_sizes": shapes, "num_img_tokens": num_img_tokens}

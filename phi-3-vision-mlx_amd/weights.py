@@ -1,0 +1,151 @@
+"""Weight tables for the hot path: names/shapes in the HF layout the reference
+loads (reference phi_3_vision_mlx.py:371-374), a seeded
+synthetic generator that is bit-identical on CPU and GPU, and a safetensors
+directory loader.
+
+The synthetic generator is counter-based (a 32-bit integer hash of the element
+index, four hashed bytes summed -> Irwin-Hall(4) ~ normal), written with exact
+integer/fp32 torch ops only so the same values come out on any device.  It is
+data generation for tests/bench, not part of the compute path.
+"""
+import glob
+import zlib
+
+import torch
+
+from .config import is_vision
+
+_M32 = 0xFFFFFFFF
+
+
+def _hash32(x):
+    """lowbias32 on int64 tensors holding uint32 values."""
+    x = x ^ (x >> 16)
+    x = (x * 0x7FEB352D) & _M32
+    x = x ^ (x >> 15)
+    x = (x * 0x846CA68B) & _M32
+    x = x ^ (x >> 16)
+    return x
+
+
+def synth_values(n, seed, std, mean=0.0, device="cpu", dtype=torch.bfloat16, chunk=1 << 24):
+    """n pseudo-normal values with the given std/mean; deterministic in (seed, index)."""
+    out = torch.empty(n, dtype=dtype, device=device)
+    base = (int(seed) * 0x9E3779B1) & _M32
+    for s in range(0, n, chunk):
+        e = min(n, s + chunk)
+        idx = torch.arange(s, e, dtype=torch.int64, device=device)
+        h = _hash32((idx + base) & _M32)
+        b = (h & 0xFF) + ((h >> 8) & 0xFF) + ((h >> 16) & 0xFF) + ((h >> 24) & 0xFF)
+        v = (b.to(torch.float32) - 510.0) * (float(std) / 147.80054127) + float(mean)
+        out[s:e] = v.to(dtype)
+    return out
+
+
+def weight_specs(cfg):
+    """[(name, shape, kind)] in HF naming; kind in {matrix, norm, bias, embed, gn}."""
+    H, I, V = cfg.hidden_size, cfg.intermediate_size, cfg.vocab_size
+    nh, nkv = cfg.num_attention_heads, cfg.num_key_value_heads
+    hd = H // nh
+    specs = [("model.embed_tokens.weight", (V, H), "embed")]
+    for i in range(cfg.num_hidden_layers):
+        p = f"model.layers.{i}."
+        specs += [
+            (p + "input_layernorm.weight", (H,), "norm"),
+            (p + "self_attn.qkv_proj.weight", ((nh + 2 * nkv) * hd, H), "matrix"),
+            (p + "self_attn.o_proj.weight", (H, nh * hd), "matrix"),
+            (p + "post_attention_layernorm.weight", (H,), "norm"),
+            (p + "mlp.gate_up_proj.weight", (2 * I, H), "matrix"),
+            (p + "mlp.down_proj.weight", (H, I), "matrix"),
+        ]
+    specs += [("model.norm.weight", (H,), "norm"), ("lm_head.weight", (V, H), "matrix")]
+    if is_vision(cfg):
+        c = cfg.clip
+        D, DI, P, C = c["hidden_size"], c["intermediate_size"], c["patch_size"], c["num_channels"]
+        npos = (c["image_size"] // P) ** 2 + 1
+        v = "model.vision_embed_tokens.img_processor.vision_model."
+        specs += [
+            (v + "embeddings.class_embedding", (D,), "bias"),
+            (v + "embeddings.patch_embedding.weight", (D, C, P, P), "matrix"),
+            (v + "embeddings.position_embedding.weight", (npos, D), "matrix"),
+            (v + "pre_layrnorm.weight", (D,), "norm"),
+            (v + "pre_layrnorm.bias", (D,), "bias"),
+        ]
+        for j in range(c["num_hidden_layers"]):
+            q = v + f"encoder.layers.{j}."
+            for nm in ("q_proj", "k_proj", "v_proj", "out_proj"):
+                specs += [(q + f"self_attn.{nm}.weight", (D, D), "matrix"),
+                          (q + f"self_attn.{nm}.bias", (D,), "bias")]
+            specs += [
+                (q + "layer_norm1.weight", (D,), "norm"), (q + "layer_norm1.bias", (D,), "bias"),
+                (q + "mlp.fc1.weight", (DI, D), "matrix"), (q + "mlp.fc1.bias", (DI,), "bias"),
+                (q + "mlp.fc2.weight", (D, DI), "matrix"), (q + "mlp.fc2.bias", (D,), "bias"),
+                (q + "layer_norm2.weight", (D,), "norm"), (q + "layer_norm2.bias", (D,), "bias"),
+            ]
+        specs += [(v + "post_layernorm.weight", (D,), "norm"), (v + "post_layernorm.bias", (D,), "bias")]
+        e = "model.vision_embed_tokens."
+        Do = cfg.img_processor["image_dim_out"]
+        specs += [
+            (e + "glb_GN", (1, 1, 4 * Do), "gn"), (e + "sub_GN", (1, 1, 1, 4 * Do), "gn"),
+            (e + "img_projection.0.weight", (H, 4 * Do), "matrix"), (e + "img_projection.0.bias", (H,), "bias"),
+            (e + "img_projection.2.weight", (H, H), "matrix"), (e + "img_projection.2.bias", (H,), "bias"),
+        ]
+    return specs
+
+
+_KIND = {  # kind -> (std, mean)
+    "matrix": (0.02, 0.0), "embed": (0.02, 0.0), "bias": (0.02, 0.0),
+    "gn": (0.02, 0.0), "norm": (0.05, 1.0),
+}
+
+
+def synth_tensor(name, shape, kind, seed=0, device="cpu", std_scale=1.0):
+    n = 1
+    for s in shape:
+        n *= s
+    std, mean = _KIND[kind]
+    if kind in ("matrix", "embed"):
+        std = std * std_scale
+    sd = (zlib.crc32(name.encode()) ^ (seed * 0x85EBCA6B)) & _M32
+    return synth_values(n, sd, std, mean, device=device).reshape(shape)
+
+
+def synth_weights(cfg, seed=0, device="cpu", std_scale=1.0):
+    """Seeded synthetic bf16 weights for every tensor of `weight_specs(cfg)`.
+
+    std_scale > 1 sharpens the logits of tiny test models (wider top-2 margins)."""
+    return {n: synth_tensor(n, s, k, seed, device, std_scale) for n, s, k in weight_specs(cfg)}
+
+
+def load_safetensors_dir(model_path, cfg, device="cpu"):
+    """Read every ``*.safetensors`` under `model_path` (reference `_get_wt`,
+    phi_3_vision_mlx.py:371-374).  The conv weight stays in HF ``[O,C,kh,kw]``
+    order (the patch-embed kernel unfolds patches in the matching (c,ky,kx)
+    order); a 'sanitized' MLX re-save (``[O,kh,kw,C]``) is permuted back."""
+    from safetensors import safe_open
+    out = {}
+    files = sorted(glob.glob(f"{model_path}/*.safetensors"))
+    if not files:
+        raise FileNotFoundError(f"no *.safetensors under {model_path}")
+    for wf in files:
+        with safe_open(wf, framework="pt", device="cpu") as f:
+            for k in f.keys():
+                t = f.get_tensor(k)
+                if "patch_embedding.weight" in k and getattr(cfg, "sanitized", False):
+                    t = t.permute(0, 3, 1, 2).contiguous()
+                out[k] = t.to(torch.bfloat16).to(device)
+    missing = [n for n, _, _ in weight_specs(cfg) if n not in out]
+    if missing:
+        raise KeyError(f"weights missing from {model_path}: {missing[:4]}{'...' if len(missing) > 4 else ''}")
+    return out
+
+
+def save_safetensors_dir(weights, cfg_dict, model_path):
+    """Write a model dir (config.json + model.safetensors) in the HF layout."""
+    import json
+    import os
+    from safetensors.torch import save_file
+    os.makedirs(model_path, exist_ok=True)
+    save_file({k: v.detach().cpu().contiguous() for k, v in weights.items()}, f"{model_path}/model.safetensors")
+    with open(f"{model_path}/config.json", "w") as f:
+        json.dump(cfg_dict, f, indent=1)
