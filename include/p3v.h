@@ -1,0 +1,180 @@
+/* p3v.h -- C ABI of the MI355X (gfx950) Phi-3-Vision hot path.
+ *
+ * The reference (JosefAlbers/Phi-3-Vision-MLX) has no native layer: every
+ * tensor op on its hot path is a call into the third-party `mlx` wheel.  Each
+ * entry point below therefore replaces one MLX call site (or a fused group of
+ * them) in the reference's `phi.py` / `phi_3_vision_mlx.py`; the call site is
+ * cited as file:line next to each declaration.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; all pointers are DEVICE pointers unless
+ *     marked `host`; bf16 travels as uint16_t;
+ *   - `stream` is a hipStream_t passed as void*; launches are stream-ordered,
+ *     never synchronise and never allocate (callers pass workspaces);
+ *   - return 0 on success, a negative P3V_ERR_* code otherwise; nothing throws;
+ *   - re-entrant across streams.  Weights are [out_features, in_features]
+ *     row-major (the HF layout the reference loads).
+ */
+#ifndef P3V_H
+#define P3V_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define P3V_VERSION 100
+#define P3V_OK 0
+#define P3V_ERR_ARG (-22)         /* bad shape / null pointer / unsupported size */
+#define P3V_ERR_LAUNCH (-5)       /* hipGetLastError() != hipSuccess after launch */
+#define P3V_ERR_UNSUPPORTED (-95) /* combination not implemented */
+#define P3V_ERR_HIP (-14)         /* a HIP runtime call failed */
+
+typedef struct {
+  int cu_count, lds_per_cu, wave_size, clock_khz, mem_clock_khz, mem_bus_bits;
+  int64_t hbm_bytes;
+  char arch[32];
+} p3v_props_t;
+
+int p3v_version(void);
+int p3v_device_props(int device, p3v_props_t* out /* host */);
+const char* p3v_strerror(int code);
+
+/* ---- embedding gather: nn.Embedding, phi.py:568,577.  Negative ids (image
+ * slots, phi.py:270) are clamped to 0; their rows are overwritten later. */
+int p3v_embed_gather(const int32_t* ids, const uint16_t* table, uint16_t* out,
+                     int n_tok, int hidden, int vocab, void* stream);
+
+/* ---- nn.RMSNorm, phi.py:478-479,571: y = x*rsqrt(mean(x^2)+eps)*w, bf16 io, fp32 math */
+int p3v_rmsnorm(const uint16_t* x, const uint16_t* w, uint16_t* y, int rows, int hidden, float eps, void* stream);
+
+/* ---- nn.LayerNorm, phi.py:165,167,212: fp32 in (ViT residual stream); bf16 out (feeds a
+ * projection) or fp32 out (pre_layrnorm, which IS the residual stream; may be in place) */
+int p3v_layernorm(const float* x, const uint16_t* w, const uint16_t* b, void* y, int out_f32,
+                  int rows, int hidden, float eps, void* stream);
+
+/* ---- dense projection  C[M,N] = A[M,K] * W[N,K]^T (+ epilogue), bf16 MFMA, fp32 accumulate.
+ * Replaces every nn.Linear on the path (phi.py:140-149,154-159,391,437-438,
+ * 465-466,604) and the k=14,s=14 patch conv (phi.py:186-192,199). */
+enum {
+  P3V_EPI_NONE = 0,        /* out bf16 = acc                                              */
+  P3V_EPI_BIAS = 1,        /* out bf16 = acc + bias                                       */
+  P3V_EPI_BIAS_QGELU = 2,  /* out bf16 = g(acc+bias), g(x)=x*sigmoid(1.702x)  phi.py:154  */
+  P3V_EPI_BIAS_GELU = 3,   /* out bf16 = gelu_erf(acc+bias)                   phi.py:391  */
+  P3V_EPI_BIAS_RESID_F32 = 4, /* out f32  = resid_f32 + acc + bias            phi.py:170-171 */
+  P3V_EPI_RESID_BF16 = 5,  /* out bf16 = resid + bf16(acc)                    phi.py:460,483-485 */
+  P3V_EPI_SILU_MUL = 6,    /* W = [gate;up] (2N rows): out bf16[M,N] = silu(g)*u  phi.py:469-471 */
+  P3V_EPI_PATCH = 7,       /* out f32 row (m/P)*(P+1)+1+m%P = acc + pos[1+m%P]   phi.py:199-205 */
+  P3V_EPI_F32 = 8          /* out f32 = acc (+ bias if given)                               */
+};
+typedef struct {
+  const uint16_t* A;   /* [M, lda] bf16 */
+  const uint16_t* W;   /* [N or 2N, ldw] bf16 */
+  void* out;           /* bf16 or f32, row stride ldo elements */
+  const uint16_t* bias;  /* [N] bf16 or null */
+  const void* resid;   /* bf16 or f32 [M, ldo] or null; may alias out */
+  const uint16_t* pos; /* P3V_EPI_PATCH: position embedding [(P+1), N] bf16 */
+  int M, N, K;         /* K % 64 == 0 */
+  int lda, ldw, ldo;
+  int epilogue;
+  int patches_per_img; /* P3V_EPI_PATCH: P (=576) */
+} p3v_gemm_args_t;
+int p3v_gemm(const p3v_gemm_args_t* args /* host */, void* stream);
+
+/* ---- skinny projection for decode: y[M,N] = x[M,K] * W[N,K]^T, M <= 16, weight-streaming.
+ * Same call sites as p3v_gemm when L*B is small.  Optional fused RMSNorm of x
+ * (norm_w != null: x is normalised with norm_w/eps before use, phi.py:482,484).
+ * Epilogues: NONE, RESID_BF16, SILU_MUL (W = [gate;up]), F32. */
+typedef struct {
+  const uint16_t* x;      /* [M, K] bf16 */
+  const uint16_t* W;      /* [N or 2N, K] bf16 */
+  void* out;              /* [M, N] bf16 (or f32 for P3V_EPI_F32) */
+  const uint16_t* resid;  /* [M, N] bf16 or null; may alias out */
+  const uint16_t* norm_w; /* [K] bf16 or null */
+  float norm_eps;
+  int M, N, K;            /* M <= 8, K % 8 == 0, M*K*2 bytes must fit LDS */
+  int epilogue;
+} p3v_gemv_args_t;
+int p3v_gemv(const p3v_gemv_args_t* args /* host */, void* stream);
+
+/* ---- SuRoPE tables, phi.py:487-504: cos/sin[n_pos, half] = {cos,sin}(pos*inv_freq)*scale (fp32) */
+int p3v_rope_table(const float* pos, const float* inv_freq, float scale, float* cos_out, float* sin_out,
+                   int n_pos, int half_dim, void* stream);
+
+/* ---- split + RoPE + KV append, phi.py:443-452 and 542-548.
+ * qkv [B*L, (nh+2*nkv)*hd] bf16 -> q_out [B, nh, L, hd] bf16 (rotated),
+ * K (rotated) / V -> k_dst/v_dst[b, h, dst_off + l, :] with row stride hd and
+ * head stride dst_t*hd, batch stride nkv*dst_t*hd.
+ * cos/sin tables are [B/tab_div, tab_t, hd/2]; position of (b,l) is past+l.
+ * cos_t == sin_t == NULL: no rotation, plain head split (CLIP q/k/v, phi.py:147).
+ * `d_past` (device int32, may be null) overrides `past` -- used under graph replay. */
+int p3v_rope_kv_append(const uint16_t* qkv, const float* cos_t, const float* sin_t,
+                       uint16_t* q_out, uint16_t* k_dst, uint16_t* v_dst,
+                       int B, int L, int n_heads, int n_kv, int hd,
+                       int past, const int32_t* d_past, int dst_t, int dst_off_is_past,
+                       int tab_t, int tab_div, void* stream);
+
+/* ---- attention, phi.py:454-457 (decoder, causal + left-pad, Mask4D phi.py:550-563)
+ * and phi.py:148 (CLIP, no mask).  q [B, nh, L, hd]; keys/values come from two
+ * segments: positions [0,past) from (k_past,v_past) batch row b/past_div
+ * (head stride past_t*hd), positions [past,past+L) from (k_new,v_new) batch
+ * row b (head stride new_t*hd).  out [B, L, nh*hd] bf16.
+ * Query i sees key t iff (!causal || t <= past+i) && t >= pad_len[b]; a query
+ * that is itself padding outputs 0.  hd in {64, 96}. */
+typedef struct {
+  const uint16_t* q;
+  const uint16_t* k_past; const uint16_t* v_past;
+  const uint16_t* k_new;  const uint16_t* v_new;
+  uint16_t* out;
+  const int32_t* pad_len;   /* [B/past_div... indexed by b/pad_div] or null */
+  const int32_t* d_past;    /* device override of `past` or null */
+  float* ws;                /* split-KV workspace (decode path) or null */
+  int B, L, n_heads, n_kv, hd;
+  int past, past_t, past_div, new_t, pad_div;
+  int causal;
+  float scale;
+  int n_split;              /* decode path: KV splits (0 = auto) */
+} p3v_attn_args_t;
+int p3v_attention(const p3v_attn_args_t* args /* host */, void* stream);
+/* bytes of workspace p3v_attention needs for the decode (L<=P3V_DECODE_MAX_L) path */
+int64_t p3v_attention_ws_bytes(int B, int L, int n_heads, int hd, int n_split);
+#define P3V_DECODE_MAX_L 16
+
+/* ---- CLIP patch unfold: pixel_values [N,3,S,S] f32 -> patches [N*P, kpad] bf16, (c,ky,kx) order, zero padded */
+int p3v_im2col_patches(const float* pix, uint16_t* patches, int n_img, int img, int patch, int kpad, void* stream);
+/* ---- CLS rows: x[n, 0, :] = class_emb + pos[0]  (phi.py:202-205); x [N, P+1, D] f32 */
+int p3v_clip_cls_rows(float* x, const uint16_t* cls, const uint16_t* pos, int n_img, int tokens, int dim, void* stream);
+
+/* ---- HD merge, phi.py:403-407: ViT features [n_crops, P+1, C] f32 (CLS at row 0 skipped)
+ * -> rows [n_out, 4C] bf16 in the reference's order: sub crops (h*12 rows of
+ * w*12 tokens, each row followed by sub_GN), glb_GN, global crop (12 rows of 12 + sub_GN). */
+int p3v_hd_merge(const float* feats, const uint16_t* sub_gn, const uint16_t* glb_gn, uint16_t* out,
+                 int h_crops, int w_crops, int grid /* 24 */, int C, void* stream);
+
+/* ---- argmax over the last axis of bf16 logits (first maximum wins), phi_3_vision_mlx.py:386,392 */
+int p3v_argmax(const uint16_t* logits, int32_t* out, int rows, int n, int64_t row_stride, void* stream);
+/* ---- nn.log_softmax, phi_3_vision_mlx.py:92,476,511,541: bf16 io, fp32 math */
+int p3v_log_softmax(const uint16_t* x, uint16_t* y, int rows, int n, void* stream);
+/* ---- top-k (k<=8) by (-value, index), replaces mx.argpartition phi_3_vision_mlx.py:507 */
+int p3v_topk(const uint16_t* x, int32_t* idx_out, int rows, int n, int k, int64_t row_stride, void* stream);
+
+/* ---- decode-step helpers (device-resident loop state for graph replay) */
+int p3v_add_i32(int32_t* x, int n, int delta, void* stream);
+int p3v_store_token(const int32_t* tok, int32_t* history, const int32_t* d_step, int B, int max_steps, void* stream);
+
+/* ---- hipGraph helpers: capture a sequence of the launches above and replay it */
+int p3v_graph_begin(void* stream);
+int p3v_graph_end(void* stream, void** graph_exec_out /* host */);
+int p3v_graph_launch(void* graph_exec, void* stream);
+int p3v_graph_destroy(void* graph_exec);
+
+/* ---- timing with HIP events on a given stream (bench.py roofline leg) */
+int p3v_event_create(void** ev /* host */);
+int p3v_event_record(void* ev, void* stream);
+int p3v_event_elapsed_ms(void* start, void* stop, float* ms /* host */);
+int p3v_event_destroy(void* ev);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* P3V_H */

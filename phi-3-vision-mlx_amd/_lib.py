@@ -1,0 +1,99 @@
+"""ctypes binding of the C ABI in ``include/p3v.h`` (``libp3v.so``).
+
+The library is the product: there is NO fallback.  If it is missing or fails to
+load, every op raises -- a silent PyTorch path would void the parity claims.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libp3v.so")
+
+P3V_OK = 0
+(EPI_NONE, EPI_BIAS, EPI_BIAS_QGELU, EPI_BIAS_GELU, EPI_BIAS_RESID_F32, EPI_RESID_BF16, EPI_SILU_MUL, EPI_PATCH,
+ EPI_F32) = range(9)
+DECODE_MAX_L = 16
+
+vp, i32, i64, f32 = C.c_void_p, C.c_int, C.c_int64, C.c_float
+
+
+class Props(C.Structure):
+    _fields_ = [("cu_count", i32), ("lds_per_cu", i32), ("wave_size", i32), ("clock_khz", i32),
+                ("mem_clock_khz", i32), ("mem_bus_bits", i32), ("hbm_bytes", i64), ("arch", C.c_char * 32)]
+
+
+class GemmArgs(C.Structure):
+    _fields_ = [("A", vp), ("W", vp), ("out", vp), ("bias", vp), ("resid", vp), ("pos", vp),
+                ("M", i32), ("N", i32), ("K", i32), ("lda", i32), ("ldw", i32), ("ldo", i32),
+                ("epilogue", i32), ("patches_per_img", i32)]
+
+
+class GemvArgs(C.Structure):
+    _fields_ = [("x", vp), ("W", vp), ("out", vp), ("resid", vp), ("norm_w", vp), ("norm_eps", f32),
+                ("M", i32), ("N", i32), ("K", i32), ("epilogue", i32)]
+
+
+class AttnArgs(C.Structure):
+    _fields_ = [("q", vp), ("k_past", vp), ("v_past", vp), ("k_new", vp), ("v_new", vp), ("out", vp),
+                ("pad_len", vp), ("d_past", vp), ("ws", vp),
+                ("B", i32), ("L", i32), ("n_heads", i32), ("n_kv", i32), ("hd", i32),
+                ("past", i32), ("past_t", i32), ("past_div", i32), ("new_t", i32), ("pad_div", i32),
+                ("causal", i32), ("scale", f32), ("n_split", i32)]
+
+
+# name -> (restype, argtypes); must list every symbol include/p3v.h declares
+SIGNATURES = {
+    "p3v_version": (i32, []),
+    "p3v_device_props": (i32, [i32, C.POINTER(Props)]),
+    "p3v_strerror": (C.c_char_p, [i32]),
+    "p3v_embed_gather": (i32, [vp, vp, vp, i32, i32, i32, vp]),
+    "p3v_rmsnorm": (i32, [vp, vp, vp, i32, i32, f32, vp]),
+    "p3v_layernorm": (i32, [vp, vp, vp, vp, i32, i32, i32, f32, vp]),
+    "p3v_gemm": (i32, [C.POINTER(GemmArgs), vp]),
+    "p3v_gemv": (i32, [C.POINTER(GemvArgs), vp]),
+    "p3v_rope_table": (i32, [vp, vp, f32, vp, vp, i32, i32, vp]),
+    "p3v_rope_kv_append": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, i32, i32, i32, i32, vp]),
+    "p3v_attention": (i32, [C.POINTER(AttnArgs), vp]),
+    "p3v_attention_ws_bytes": (i64, [i32, i32, i32, i32, i32]),
+    "p3v_im2col_patches": (i32, [vp, vp, i32, i32, i32, i32, vp]),
+    "p3v_clip_cls_rows": (i32, [vp, vp, vp, i32, i32, i32, vp]),
+    "p3v_hd_merge": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp]),
+    "p3v_argmax": (i32, [vp, vp, i32, i32, i64, vp]),
+    "p3v_log_softmax": (i32, [vp, vp, i32, i32, vp]),
+    "p3v_topk": (i32, [vp, vp, i32, i32, i32, i64, vp]),
+    "p3v_add_i32": (i32, [vp, i32, i32, vp]),
+    "p3v_store_token": (i32, [vp, vp, vp, i32, i32, vp]),
+    "p3v_graph_begin": (i32, [vp]),
+    "p3v_graph_end": (i32, [vp, C.POINTER(vp)]),
+    "p3v_graph_launch": (i32, [vp, vp]),
+    "p3v_graph_destroy": (i32, [vp]),
+    "p3v_event_create": (i32, [C.POINTER(vp)]),
+    "p3v_event_record": (i32, [vp, vp]),
+    "p3v_event_elapsed_ms": (i32, [vp, vp, C.POINTER(f32)]),
+    "p3v_event_destroy": (i32, [vp]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load libp3v.so once; raise loudly when it is not there."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: the HIP extension is not built. Run "
+                "`python -c 'import __graft_entry__ as g; g.build()'` (or csrc/build.sh). "
+                "There is no CPU/PyTorch fallback for the hot path.")
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)          # AttributeError if the ABI and the header drift apart
+            fn.restype, fn.argtypes = res, args
+        _lib = l
+    return _lib
+
+
+def check(code, what=""):
+    if code != P3V_OK:
+        msg = lib().p3v_strerror(code).decode()
+        raise RuntimeError(f"p3v call {what} failed: {code} ({msg})")

@@ -1,0 +1,533 @@
+"""Public inference API -- the drop-in boundary.
+
+Same names, signatures, defaults, return types and error behaviour as the
+reference's `load / generate / choose / constrain / benchmark`
+(reference phi_3_vision_mlx.py:1178-1487) and the decoding loops underneath
+(`_generate :376-409`, `_choose_from :466-487`, `_constrain :500-619`,
+`Streamer / LogitStopper / TokenStopper :45-117`, `_apply_chat_template :341-357`).
+Host code stays Python; everything that touches the device goes through
+`model(...)` (model.py) and `model_ops` (ops.py), i.e. hand-written HIP kernels.
+
+Not carried over (out of scope): LoRA adapters
+(`use_adapter=True` raises NotImplementedError), the `<|api_input|>` tool hook,
+HF-hub download (`_setup`): a model directory must exist locally, or pass
+`synthetic=...` to `load()` for seeded random weights of the real architecture.
+"""
+import json
+import math
+import os
+import time
+from io import BytesIO
+from pathlib import Path
+
+import numpy as np
+import torch
+
+from . import ops as model_ops
+from .config import is_vision, load_config, make_config, phi3v_config_dict, tiny_config_dict
+from .processor import Phi3FProcessor, Phi3VProcessor
+from .weights import load_safetensors_dir, synth_weights
+
+PATH_ADAPTERS = "adapters"
+PATH_ORIGINAL_PHI3_VISION = "models/phi3_v"
+PATH_QUANTIZED_PHI3_VISION = "models/phi3_v_Q"
+PATH_ORIGINAL_PHI3_BLIND = "models/phi3_mini_128k"
+PATH_QUANTIZED_PHI3_BLIND = "models/phi3_mini_128k_Q"
+ID_EOS = 32007
+ID_ASS = 32001
+
+
+class Tic:
+    """reference phi.py:16-24."""
+
+    def __init__(self):
+        self.last_time = time.perf_counter()
+
+    def __call__(self):
+        now = time.perf_counter()
+        dt, self.last_time = now - self.last_time, now
+        return dt
+
+
+def _rows(token):
+    """token: int tensor [B,1] / [B] or nested list -> list[int] per row (one D2H copy)."""
+    if torch.is_tensor(token):
+        return token.reshape(-1).tolist()
+    return np.asarray(token).reshape(-1).tolist()
+
+
+class Streamer:
+    """reference phi_3_vision_mlx.py:45-77."""
+
+    def __init__(self, processor, stream, mute):
+        self.tokenizer = processor.tokenizer
+        self.mute = mute
+        self.stream = stream and (not mute)
+        self.list_tokens = []
+        self.idx_sofar = 0
+
+    def __call__(self, token):
+        rows = _rows(token)
+        if not self.stream:
+            self.list_tokens.append(rows)
+            return None
+        if len(rows) > 1:
+            self.list_tokens.append(rows)
+            self.stream = False
+            return None
+        self.list_tokens.append(rows[0])
+        txt = self.tokenizer.decode(self.list_tokens)
+        idx_split = txt.rfind(" ", self.idx_sofar)
+        if idx_split > 0:
+            print(txt[self.idx_sofar:idx_split], end="", flush=True)
+            self.idx_sofar = idx_split
+
+    def end(self):
+        if self.stream:
+            txt = self.tokenizer.decode(self.list_tokens)
+            print(txt[self.idx_sofar:], "\n", flush=True)
+            return txt, len(self.list_tokens)
+        steps = [s if isinstance(s, list) else [s] for s in self.list_tokens]
+        per_row = [list(r) for r in zip(*steps)]                  # [B][n_steps]
+        list_txt = self.tokenizer.batch_decode([(r[:r.index(ID_EOS) + 1] if ID_EOS in r else r) for r in per_row])
+        if not self.mute:
+            for i, gen in enumerate(list_txt):
+                print(f"\n< Generated text for prompt #{i} >\n{gen}")
+        return list_txt, sum(len(r) for r in per_row)
+
+
+class LogitStopper:
+    """Early-stop heuristic, B=1 only (reference phi_3_vision_mlx.py:79-104)."""
+
+    def __init__(self, max_tokens, early_stop):
+        self.step = 0
+        self.early_stop = early_stop if isinstance(early_stop, int) and not isinstance(early_stop, bool) \
+            and (early_stop < max_tokens) else False
+        self.log_prob_sum = 0.0
+        self.best_eos_sofar = -math.inf
+        self.log_prob_sum_at_best_eos = 0.0
+
+    def __call__(self, logits):
+        if not self.early_stop:
+            return False
+        if logits.shape[0] > 1:
+            self.early_stop = False
+            return False
+        log_prob = model_ops.log_softmax(logits[:, -1, :].contiguous())
+        log_prob_best = log_prob.float().max().item()
+        log_prob_eos = log_prob[0, ID_EOS].float().item()
+        if log_prob_eos > self.best_eos_sofar:
+            self.log_prob_sum_since_last_best_eos = self.log_prob_sum - self.log_prob_sum_at_best_eos
+            if (self.log_prob_sum_since_last_best_eos < self.best_eos_sofar) and (self.step > self.early_stop):
+                return True
+            self.best_eos_sofar = log_prob_eos
+            self.log_prob_sum_at_best_eos = self.log_prob_sum
+        self.log_prob_sum += log_prob_best
+        self.step += 1
+        return False
+
+
+class TokenStopper:
+    """Stop when every row has emitted EOS (reference phi_3_vision_mlx.py:105-117)."""
+
+    def __init__(self, processor, batch_size):
+        self.tokenizer = processor.tokenizer
+        self.eos_id = ID_EOS
+        self.batch_size = batch_size
+        self.eos_rows = [1] * batch_size
+
+    def __call__(self, token):
+        rows = _rows(token)
+        if self.eos_id in rows:
+            self.eos_rows = [a * int(t != self.eos_id) for a, t in zip(self.eos_rows, rows)]
+            if sum(self.eos_rows) < 1:
+                return True
+        return False
+
+
+# ----------------------------------------------------------------------------- loading
+def _load_image(image_source):
+    """reference phi_3_vision_mlx.py:307-326 (PIL images are passed through)."""
+    from PIL import Image
+    if isinstance(image_source, Image.Image):
+        return image_source
+    if isinstance(image_source, BytesIO):
+        try:
+            return Image.open(image_source)
+        except IOError as e:
+            raise ValueError(f"Failed to load image from BytesIO with error: {e}")
+    elif image_source.startswith(("http://", "https://")):
+        try:
+            import requests
+            response = requests.get(image_source, stream=True)
+            response.raise_for_status()
+            return Image.open(response.raw)
+        except Exception as e:
+            raise ValueError(f"Failed to load image from URL: {image_source} with error {e}")
+    elif Path(image_source).is_file():
+        try:
+            return Image.open(image_source)
+        except IOError as e:
+            raise ValueError(f"Failed to load image {image_source} with error: {e}")
+    else:
+        raise ValueError(f"The image {image_source} must be a valid URL or existing file.")
+
+
+def _apply_chat_template(prompt, images, verbose, apply_chat_template=True):
+    """reference phi_3_vision_mlx.py:341-357."""
+    if apply_chat_template is False:
+        print(f"*** Prompt ***\n{prompt}\n*** Images ***\n{images}\n*** Output ***") if verbose else None
+        return prompt, images
+    if images is not None:
+        images = [_load_image(i) for i in images] if isinstance(images, list) else [_load_image(images)]
+        img_prompt = "\n".join([f"<|image_{i+1}|>" for i in range(len(images))]) + "\n"
+    else:
+        img_prompt = ""
+    prompt = [prompt] if isinstance(prompt, str) else prompt
+    prompt = [f"<|user|>\n{img_prompt}{i.strip()}<|end|>\n<|assistant|>\n" for i in prompt]
+    if verbose:
+        prompt_str = "\n".join(map(str.strip, prompt)).strip()
+        images_str = "\n".join(map(str, images)) if images else "None"
+        print(f"*** Prompt ***\n{prompt_str}\n*** Images ***\n{images_str}\n*** Output ***")
+    prompt = prompt[0] if len(prompt) == 1 else prompt
+    return prompt, images
+
+
+def _get_cfg(json_path, **kwargs):
+    return load_config(json_path, **kwargs)
+
+
+def _make_processor(cfg, model_path, return_mx=True):
+    cls = Phi3VProcessor if is_vision(cfg) else Phi3FProcessor
+    return cls(model_path, return_mx=return_mx)
+
+
+def _load(model_path=PATH_ORIGINAL_PHI3_VISION, adapter_path=None, return_mx=True, device=None, **kwargs):
+    """reference phi_3_vision_mlx.py:257-274: config -> model class by `architectures[0]`,
+    HF safetensors -> device weights."""
+    from .model import Phi3VModel
+    if adapter_path:
+        raise NotImplementedError("LoRA adapters are outside the inference hot path of this build")
+    cfg = _get_cfg(f"{model_path}/config.json", **kwargs)
+    if getattr(cfg, "quantized", False):
+        raise NotImplementedError("MLX int4 checkpoints are not supported (SURVEY.md section 8f item 4)")
+    if getattr(cfg, "use_quantized_cache", False):
+        raise NotImplementedError("quantize_cache=True (int8 KV, BASELINE config 5) is not implemented in this round")
+    processor = _make_processor(cfg, model_path, return_mx)
+    device = device or f"cuda:{torch.cuda.current_device()}"
+    model = Phi3VModel(cfg, load_safetensors_dir(model_path, cfg, device="cpu"), device=device)
+    return model, processor
+
+
+def load_synthetic(blind_model=False, tiny=False, seed=0, device=None, std_scale=1.0, **kwargs):
+    """Seeded random weights of the real (or tiny) architecture -- no checkpoint needed."""
+    from .model import Phi3VModel
+    d = tiny_config_dict(vision=not blind_model) if tiny else phi3v_config_dict(vision=not blind_model)
+    cfg = make_config(d, **kwargs)
+    device = device or f"cuda:{torch.cuda.current_device()}"
+    model = Phi3VModel(cfg, synth_weights(cfg, seed=seed, device=device, std_scale=std_scale), device=device)
+    return model, _make_processor(cfg, None)
+
+
+def load(blind_model=False, quantize_model=False, quantize_cache=False, use_adapter=False, **kwargs):
+    """reference phi_3_vision_mlx.py:1279-1322.  Extra: `synthetic=True|'tiny'` builds seeded
+    random weights instead of reading `models/...` (there is no hub access here)."""
+    synthetic = kwargs.pop("synthetic", None)
+    if use_adapter:
+        raise NotImplementedError("use_adapter=True: LoRA is outside the inference hot path of this build")
+    if quantize_model:
+        raise NotImplementedError("quantize_model=True (fp8 weights, BASELINE config 5) is not implemented in this round")
+    if quantize_cache:
+        raise NotImplementedError("quantize_cache=True (int8 KV, BASELINE config 5) is not implemented in this round")
+    if synthetic:
+        return load_synthetic(blind_model=blind_model, tiny=(synthetic == "tiny"), **kwargs)
+    model_path = kwargs.pop("model_path", None) or (PATH_ORIGINAL_PHI3_BLIND if blind_model else PATH_ORIGINAL_PHI3_VISION)
+    if not os.path.exists(model_path):
+        raise FileNotFoundError(
+            f"model directory {model_path!r} not found and this build cannot download checkpoints; "
+            "place HF-layout safetensors + config.json there, or use load(synthetic=True)")
+    return _load(model_path=model_path, use_quantized_cache=quantize_cache, adapter_path=None, **kwargs)
+
+
+# ----------------------------------------------------------------------------- generate
+def _last_logits(logits):
+    return logits[:, -1, :].contiguous()
+
+
+def _generate(model, processor, prompt, images=None, max_tokens=512, verbose=True, return_tps=False, early_stop=False,
+              stream=True, mute=False):
+    """Greedy decoding loop (reference phi_3_vision_mlx.py:376-409)."""
+    if images is not None and isinstance(prompt, list):
+        raise ValueError("Images cannot be provided when prompt is a list")
+    logit_stopper = LogitStopper(max_tokens, early_stop)
+    streamer = Streamer(processor, stream, mute)
+    dict_input = processor(prompt, images)
+    mask, pids = dict_input.get("mask", None), dict_input.get("pids", None)
+    token_stopper = TokenStopper(processor, dict_input["input_ids"].shape[0])
+    tic = Tic()
+    logits, cache = model(**dict_input, max_tokens=max_tokens)
+    token = model_ops.argmax(_last_logits(logits))[:, None]
+    streamer(token)                                             # D2H copy = the per-token sync the reference has (mx.eval)
+    prompt_time = tic()
+    for i in range(max_tokens - 1):
+        logits, cache = model(input_ids=token, cache=cache, mask=mask, pids=pids)
+        token = model_ops.argmax(_last_logits(logits))[:, None]
+        streamer(token)
+        if logit_stopper(logits):
+            break
+        if token_stopper(token):
+            break
+    result, gen_len = streamer.end()
+    gen_time = tic()
+    prompt_len = dict_input["input_ids"].size
+    prompt_tps = prompt_len / prompt_time
+    gen_tps = (gen_len - 1) / gen_time
+    if verbose:
+        print(f"\nPrompt: {prompt_tps:.2f} tokens-per-sec ({prompt_len} tokens / {prompt_time:.1f} sec)")
+        print(f"Generate: {gen_tps:.2f} tokens-per-sec ({gen_len} tokens / {gen_time:.1f} sec)")
+    if return_tps:
+        return prompt_tps, gen_tps
+    return result
+
+
+def generate(prompt, images=None, preload=None, blind_model=False, quantize_model=False, quantize_cache=False,
+             use_adapter=False, max_tokens=512, verbose=True, return_tps=False, early_stop=False, stream=True,
+             apply_chat_template=True, enable_api=False):
+    """reference phi_3_vision_mlx.py:1324-1374."""
+    if "<|api_input|>" in prompt and enable_api:
+        raise NotImplementedError("the <|api_input|> tool hook is outside the inference hot path of this build")
+    if preload is None:
+        preload = load(blind_model=blind_model, quantize_model=quantize_model, quantize_cache=quantize_cache, use_adapter=use_adapter)
+    return _generate(*preload, *_apply_chat_template(prompt, images, verbose, apply_chat_template), max_tokens=max_tokens,
+                     verbose=verbose, return_tps=return_tps, early_stop=early_stop, stream=stream)
+
+
+# ----------------------------------------------------------------------------- choose
+def _choose_from(model, processor, prompt, choices="ABCDE", mute=False):
+    """Option scoring with one prefill (reference phi_3_vision_mlx.py:466-487)."""
+    def _ord(s):
+        return processor([f" {i}" for i in s])["input_ids"][:, -1]
+    _was_prompt_str = isinstance(prompt, str)
+    options = torch.as_tensor(np.asarray(_ord(choices)), dtype=torch.long)
+    dict_input = processor(prompt)
+    logits, _ = model(**dict_input, max_tokens=0)
+    logp = model_ops.log_softmax(_last_logits(logits))
+    picked = logp[:, options.to(logp.device)].float().cpu()
+    indices = torch.argmax(picked, dim=-1).tolist()              # first maximum, 5-wide host argmax
+    output = [choices[i] for i in indices]
+    if not mute:
+        if _was_prompt_str:
+            print(output[0])
+        else:
+            for i, o in enumerate(output):
+                print(f"\n< Chosen option for prompt #{i} >\n{o}")
+    if _was_prompt_str:
+        output = output[0]
+    return output
+
+
+def choose(prompt, choices="ABCDE", images=None, preload=None, blind_model=False, quantize_model=False,
+           quantize_cache=False, use_adapter=False, verbose=True, apply_chat_template=True):
+    """reference phi_3_vision_mlx.py:1376-1423."""
+    if preload is None:
+        preload = load(blind_model=blind_model, quantize_model=quantize_model, quantize_cache=quantize_cache, use_adapter=use_adapter)
+    if apply_chat_template:
+        prompt, _ = _apply_chat_template(prompt, images, verbose)
+    return _choose_from(*preload, prompt=prompt, choices=choices)
+
+
+# ----------------------------------------------------------------------------- constrain
+def _preprocess(s):
+    """reference phi_3_vision_mlx.py:489-493."""
+    for i in ["<|system|>", "<|user|>", "<|end|>"]:
+        s = s.replace(f"{i} ", f"{i}\n").replace(f"{i}\n\n", f"{i}\n")
+    s = s.replace("<|end|><|assistant|>", "<|end|>\n<|assistant|>")
+    return s
+
+
+BF16 = torch.bfloat16
+
+
+def _sum_last(x):
+    return x.float().sum(-1).to(x.dtype)
+
+
+def _div(x, n):
+    return (x.float() / n).to(x.dtype)
+
+
+def _already(a2, a1):
+    """reference phi_3_vision_mlx.py:495-498: 1 where the row does NOT yet end with a1."""
+    if a2.shape[1] < a1.shape[0]:
+        return torch.ones(a2.shape[0])
+    return (~torch.all(a2[:, -len(a1):] == a1, dim=1)).float()
+
+
+def constrain_tokens(model, dict_input, constraint, id_constraint, use_beam=False, log_norm=False):
+    """One (max_new, text) constraint of the reference's `_constrain`
+    (phi_3_vision_mlx.py:537-601).  Vocabulary-wide work (log-softmax, argmax,
+    top-3) runs in HIP kernels; the [B, C]-sized score bookkeeping is host-side
+    on CPU tensors in the logits dtype, like the reference keeps it in bf16.
+    Returns (synth_sofar [B, *] int64 padded with ID_EOS, score_sofar [B])."""
+    dev = model.device
+    ar = torch.arange
+
+    def _log_mean(x):
+        return _div(_sum_last(x), math.log(x.shape[-1]) if log_norm else x.shape[-1])
+
+    def lsm(logits):                                          # [B, L, V] -> log-probs, same shape (device)
+        return model_ops.log_softmax(logits.contiguous())
+
+    def pick(lp, pos_idx, tok):                               # lp[b, pos_idx[j], tok[b, j]] -> host [B, J]
+        tok = torch.as_tensor(tok).to(dev).long()
+        return lp[ar(lp.shape[0], device=dev)[:, None], torch.as_tensor(pos_idx).to(dev)[None, :], tok].cpu()
+
+    def amax(lp, pos):                                        # host int64 [B]
+        return model_ops.argmax(lp[:, pos, :].contiguous()).long().cpu()
+
+    idc = torch.as_tensor(np.asarray(id_constraint)).long()
+    C_ = idc.shape[0]
+    Bn = np.asarray(dict_input["input_ids"]).shape[0]
+    synth_pad = torch.full((Bn, 1), ID_EOS, dtype=torch.long)
+    tiled = idc[None].expand(Bn, -1)
+
+    def _get_beam(lp, cache, beam_idx=0, n_beam=3):
+        token = amax(lp, beam_idx)
+        arg_beam = model_ops.topk(lp[:, beam_idx, :].contiguous(), n_beam).long().cpu()      # (-value, index) order, Q9
+        beam = torch.cat([arg_beam.reshape(-1)[:, None], idc[None].expand(Bn * n_beam, -1)], dim=-1)
+        bl, _ = model(input_ids=beam, cache=cache, n_beam=n_beam, advance_offset=0)
+        bl = lsm(bl)
+        s0 = lp[ar(Bn, device=dev)[:, None], beam_idx, arg_beam.to(dev)].cpu().reshape(-1)[:, None]
+        s1 = pick(bl, ar(C_), beam[:, 1:])
+        score_all = torch.cat([s0, s1], dim=1)
+        mean = _div(_sum_last(score_all), score_all.shape[1])
+        am = torch.argmax(mean.reshape(-1, n_beam).float(), dim=-1)
+        return token, arg_beam[ar(Bn), am], score_all.reshape(Bn, n_beam, -1)[ar(Bn), am]
+
+    logits, cache = model(**dict_input, max_tokens=constraint[0] + C_ + 10)
+    lp = lsm(logits)                                          # [B, 1, V] (last prompt position)
+    score_0 = pick(lp, torch.tensor([lp.shape[1] - 1]), idc[0].expand(Bn)[:, None])[:, 0]
+    lr, _ = model(input_ids=tiled, cache=cache, advance_offset=0)
+    lr = lsm(lr)
+    score_1 = pick(lr, ar(C_ - 1), tiled[:, 1:])
+    running_score = lp[:, -1, :].float().max(dim=-1).values.to(lp.dtype).cpu()[:, None]
+    pre_score = _log_mean(torch.cat([score_0[:, None], score_1], dim=1))
+    pre_synth = torch.cat([tiled, synth_pad], dim=1)
+    if use_beam and constraint[0] > 0:
+        token, beam_token, beam_score = _get_beam(lp, cache, -1)
+        post_score = _log_mean(beam_score)
+        post_synth = torch.cat([beam_token[:, None], tiled], dim=1)
+        win = pre_score > post_score
+        score_sofar = torch.where(win, pre_score, post_score)
+        synth_sofar = torch.where(win[:, None], pre_synth, post_synth)
+    else:
+        token = amax(lp, -1)
+        score_sofar, synth_sofar = pre_score, pre_synth
+    token = token[:, None]
+    tokens = []
+    finished = torch.ones(Bn)
+    for _ in range(constraint[0]):
+        tokens.append(token)
+        token_plus = torch.cat([token, tiled], dim=1)
+        logits, cache = model(input_ids=token_plus, cache=cache, advance_offset=1)
+        lp = lsm(logits)
+        g = pick(lp, ar(C_), token_plus[:, 1:])
+        pre_score = _log_mean(torch.cat([running_score, g], dim=1))
+        pre_synth = torch.cat(tokens + [tiled, synth_pad], dim=1)
+        if use_beam:
+            token, beam_token, beam_score = _get_beam(lp, cache)
+            post_score = _log_mean(torch.cat([running_score, beam_score], dim=1))
+            post_synth = torch.cat(tokens + [beam_token[:, None], tiled], dim=1)
+            win = pre_score > post_score
+            score = torch.where(win, pre_score, post_score)
+            synth = torch.where(win[:, None], pre_synth, post_synth)
+        else:
+            token = amax(lp, 0)
+            score, synth = pre_score, pre_synth
+        synth_sofar = torch.cat([synth_sofar, synth_pad], dim=1)
+        finished = finished * _already(torch.cat(tokens, dim=1), idc)
+        upd = (score > score_sofar).float() * finished
+        synth_sofar = torch.where(upd[:, None] > 0, synth, synth_sofar)
+        score_sofar = torch.where(upd > 0, score, score_sofar)
+        running_score = torch.cat([running_score, pick(lp, torch.tensor([0]), token[:, None])], dim=1)
+        finished = finished * (token != ID_EOS).float()
+        if finished.sum() < 1:
+            break
+        token = token[:, None]
+    return synth_sofar, score_sofar
+
+
+def _constrain(model, processor, prompt, constraints, return_full_text=False, mute=False, use_beam=False, verbose=True,
+               log_norm=False):
+    """reference phi_3_vision_mlx.py:500-619."""
+    _was_prompt_str = isinstance(prompt, str)
+    if _was_prompt_str:
+        prompt = [prompt]
+    tic = Tic()
+    constrain_time = 0
+    prompt = [_preprocess(s) for s in prompt]
+    len_ps = [len(p) for p in prompt]
+    output = prompt
+    for constraint in constraints:
+        if isinstance(constraint, str):
+            _output = _choose_from(model, processor, prompt, constraint, True)
+            output = [" ".join([p, o]) for p, o in zip(prompt, _output)]
+            prompt = output
+            continue
+        id_constraint = processor.tokenizer.encode(constraint[1], add_special_tokens=False)[1:]
+        dict_input = processor(prompt)
+        synth_sofar, _ = constrain_tokens(model, dict_input, constraint, id_constraint, use_beam, log_norm)
+        constrain_time += tic()
+        ids = np.asarray(dict_input["input_ids"])
+        output = np.concatenate([ids, synth_sofar.numpy()], axis=1).tolist()
+        S = ids.shape[1]
+        output = [(i[:i.index(ID_EOS, S)] if ID_EOS in i[S:] else i) for i in output]
+        output = [[num for num in sublist if num not in (0, 1)] for sublist in output]
+        output = processor.tokenizer.batch_decode(output)
+        output = [_preprocess(s) for s in output]
+        prompt = output
+    if not return_full_text:
+        output = [o[l:] for o, l in zip(output, len_ps)]
+    if not mute:
+        if _was_prompt_str:
+            print(output[0])
+        else:
+            for i, o in enumerate(output):
+                print(f"\n< Constrained text for prompt #{i} >\n{o}")
+    if verbose:
+        print(f"Constrain: {constrain_time:.2f} sec")
+    if _was_prompt_str:
+        output = output[0]
+    return output
+
+
+def constrain(prompt, constraints=[(0, "\nThe"), (100, " The correct answer is"), "ABCDE"], images=None, preload=None,
+              blind_model=False, quantize_model=False, quantize_cache=False, use_adapter=False, verbose=True,
+              apply_chat_template=True, use_beam=False):
+    """reference phi_3_vision_mlx.py:1425-1487."""
+    if preload is None:
+        preload = load(blind_model=blind_model, quantize_model=quantize_model, quantize_cache=quantize_cache, use_adapter=use_adapter)
+    if apply_chat_template:
+        prompt = _apply_chat_template(prompt, None, verbose)[0]
+    return _constrain(*preload, prompt=prompt, constraints=constraints, use_beam=use_beam, verbose=verbose)
+
+
+# ----------------------------------------------------------------------------- benchmark
+def benchmark(blind_model=False, json_path="benchmark.json", preload=None, max_tokens=100):
+    """reference phi_3_vision_mlx.py:1178-1277, 'vanilla' column only (quantised / LoRA
+    variants are not part of this build).  Prompts: text, [image+text if vision], batched text."""
+    prompts = [("Write a mystery horror.",)]
+    if not blind_model:
+        from PIL import Image
+        rng = np.random.default_rng(0)
+        prompts.append(("What is shown in this image?", Image.fromarray(rng.integers(0, 256, (336, 336, 3), dtype=np.uint8))))
+    prompts.append((["Write an executive summary for a startup.", "Write a poem about the sea.", "Explain attention.",
+                     "Say hi."],))
+    preload = preload or load(blind_model=blind_model)
+    results = {"vanilla": []}
+    for i, pr in enumerate(prompts):
+        prompt_tps, gen_tps = generate(*pr, preload=preload, max_tokens=max_tokens, return_tps=True, verbose=False)
+        results["vanilla"].append([i, prompt_tps, gen_tps])
+    with open(json_path, "w") as f:
+        json.dump(results, f, indent=4)
+    return results

@@ -1,0 +1,8 @@
+#!/bin/bash
+# Build libp3v.so (all HIP kernels + the C ABI) for gfx950, in-tree.
+set -e
+cd "$(dirname "$0")"
+OUT=../libp3v.so
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result"
+hipcc $FLAGS -shared p3v_elementwise.hip p3v_gemm.hip p3v_gemv.hip p3v_attention.hip p3v_runtime.hip -o $OUT "$@"
+echo "built $(realpath $OUT)"

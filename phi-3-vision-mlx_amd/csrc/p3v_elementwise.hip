@@ -1,0 +1,421 @@
+// HBM-bound row kernels of the hot path: gather, norms, RoPE/KV append, HD merge,
+// patch unfold, argmax / log-softmax / top-k.  All loads are 16-byte vectors
+// (8 bf16 or 4 f32 per lane), reductions use 64-lane shuffles.
+#include "p3v_common.h"
+
+// ---------------------------------------------------------------- embed gather
+__global__ void __launch_bounds__(128) k_embed_gather(const int32_t* __restrict__ ids, const u32x4_t* __restrict__ table,
+                                                      u32x4_t* __restrict__ out, int chunks, int vocab) {
+  const int t = blockIdx.x;
+  int id = ids[t];
+  id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+  const u32x4_t* src = table + (size_t)id * chunks;
+  u32x4_t* dst = out + (size_t)t * chunks;
+  for (int c = threadIdx.x; c < chunks; c += blockDim.x) dst[c] = src[c];
+}
+
+extern "C" int p3v_embed_gather(const int32_t* ids, const uint16_t* table, uint16_t* out, int n_tok, int hidden, int vocab,
+                                void* stream) {
+  if (!ids || !table || !out || n_tok < 0 || hidden % 8 || vocab <= 0) return P3V_ERR_ARG;
+  if (n_tok == 0) return P3V_OK;
+  hipLaunchKernelGGL(k_embed_gather, dim3(n_tok), dim3(128), 0, (hipStream_t)stream, ids, (const u32x4_t*)table,
+                     (u32x4_t*)out, hidden / 8, vocab);
+  P3V_CHECK_LAUNCH();
+  return P3V_OK;
+}
+
+// ---------------------------------------------------------------- RMSNorm (one wave per row)
+__global__ void __launch_bounds__(256) k_rmsnorm(const u32x4_t* __restrict__ x, const u32x4_t* __restrict__ w,
+                                                 u32x4_t* __restrict__ y, int rows, int chunks, float inv_h, float eps) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const u32x4_t* xr = x + (size_t)row * chunks;
+  float ss = 0.f;
+  for (int c = lane; c < chunks; c += 64) {
+    u32x4_t v = xr[c];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float a = bf16lo(v[j]), b = bf16hi(v[j]);
+      ss += a * a + b * b;
+    }
+  }
+  ss = wave_sum(ss);
+  const float r = rsqrtf(ss * inv_h + eps);
+  u32x4_t* yr = y + (size_t)row * chunks;
+  for (int c = lane; c < chunks; c += 64) {
+    u32x4_t v = xr[c], g = w[c], o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = pack_bf16x2(bf16lo(v[j]) * r * bf16lo(g[j]), bf16hi(v[j]) * r * bf16hi(g[j]));
+    yr[c] = o;
+  }
+}
+
+extern "C" int p3v_rmsnorm(const uint16_t* x, const uint16_t* w, uint16_t* y, int rows, int hidden, float eps, void* stream) {
+  if (!x || !w || !y || rows < 0 || hidden <= 0 || hidden % 8) return P3V_ERR_ARG;
+  if (rows == 0) return P3V_OK;
+  hipLaunchKernelGGL(k_rmsnorm, dim3(p3v_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, (const u32x4_t*)x,
+                     (const u32x4_t*)w, (u32x4_t*)y, rows, hidden / 8, 1.0f / hidden, eps);
+  P3V_CHECK_LAUNCH();
+  return P3V_OK;
+}
+
+// ---------------------------------------------------------------- LayerNorm f32 -> bf16 (one wave per row)
+template <bool OUT_F32>
+__global__ void __launch_bounds__(256) k_layernorm(const float4* __restrict__ x, const u32x2_t* __restrict__ w,
+                                                   const u32x2_t* __restrict__ b, void* __restrict__ yv, int rows,
+                                                   int chunks, float inv_h, float eps) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const float4* xr = x + (size_t)row * chunks;
+  float s = 0.f;
+  for (int c = lane; c < chunks; c += 64) {
+    float4 v = xr[c];
+    s += (v.x + v.y) + (v.z + v.w);
+  }
+  const float mu = wave_sum(s) * inv_h;
+  float q = 0.f;
+  for (int c = lane; c < chunks; c += 64) {
+    float4 v = xr[c];
+    float d0 = v.x - mu, d1 = v.y - mu, d2 = v.z - mu, d3 = v.w - mu;
+    q += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+  }
+  const float r = rsqrtf(wave_sum(q) * inv_h + eps);
+  for (int c = lane; c < chunks; c += 64) {
+    float4 v = xr[c];
+    u32x2_t g = w[c], be = b[c];
+    float4 t;
+    t.x = (v.x - mu) * r * bf16lo(g[0]) + bf16lo(be[0]);
+    t.y = (v.y - mu) * r * bf16hi(g[0]) + bf16hi(be[0]);
+    t.z = (v.z - mu) * r * bf16lo(g[1]) + bf16lo(be[1]);
+    t.w = (v.w - mu) * r * bf16hi(g[1]) + bf16hi(be[1]);
+    if (OUT_F32) {
+      ((float4*)yv)[(size_t)row * chunks + c] = t;
+    } else {
+      u32x2_t o;
+      o[0] = pack_bf16x2(t.x, t.y);
+      o[1] = pack_bf16x2(t.z, t.w);
+      ((u32x2_t*)yv)[(size_t)row * chunks + c] = o;
+    }
+  }
+}
+
+extern "C" int p3v_layernorm(const float* x, const uint16_t* w, const uint16_t* b, void* y, int out_f32, int rows,
+                             int hidden, float eps, void* stream) {
+  if (!x || !w || !b || !y || rows < 0 || hidden <= 0 || hidden % 4) return P3V_ERR_ARG;
+  if (rows == 0) return P3V_OK;
+  if (out_f32)
+    hipLaunchKernelGGL(k_layernorm<true>, dim3(p3v_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, (const float4*)x,
+                       (const u32x2_t*)w, (const u32x2_t*)b, y, rows, hidden / 4, 1.0f / hidden, eps);
+  else
+    hipLaunchKernelGGL(k_layernorm<false>, dim3(p3v_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, (const float4*)x,
+                       (const u32x2_t*)w, (const u32x2_t*)b, y, rows, hidden / 4, 1.0f / hidden, eps);
+  P3V_CHECK_LAUNCH();
+  return P3V_OK;
+}
+
+// ---------------------------------------------------------------- SuRoPE tables
+__global__ void k_rope_table(const float* __restrict__ pos, const float* __restrict__ inv_freq, float scale,
+                             float* __restrict__ c, float* __restrict__ s, int n_pos, int half) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_pos * half) return;
+  const float e = pos[i / half] * inv_freq[i % half];
+  c[i] = cosf(e) * scale;
+  s[i] = sinf(e) * scale;
+}
+
+extern "C" int p3v_rope_table(const float* pos, const float* inv_freq, float scale, float* cos_out, float* sin_out,
+                              int n_pos, int half_dim, void* stream) {
+  if (!pos || !inv_freq || !cos_out || !sin_out || n_pos < 0 || half_dim <= 0) return P3V_ERR_ARG;
+  if (n_pos == 0) return P3V_OK;
+  const long n = (long)n_pos * half_dim;
+  hipLaunchKernelGGL(k_rope_table, dim3(p3v_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, pos, inv_freq, scale,
+                     cos_out, sin_out, n_pos, half_dim);
+  P3V_CHECK_LAUNCH();
+  return P3V_OK;
+}
+
+// ---------------------------------------------------------------- split + RoPE + KV append
+// one block per token (b,l); work item = 8 consecutive dims of the low half paired with the
+// same 8 dims of the high half (q and k heads), or one 8-wide chunk of v.
+__global__ void __launch_bounds__(256) k_rope_kv_append(const bf16_t* __restrict__ qkv, const float* __restrict__ cos_t,
+                                                        const float* __restrict__ sin_t, bf16_t* __restrict__ q_out,
+                                                        bf16_t* __restrict__ k_dst, bf16_t* __restrict__ v_dst, int L,
+                                                        int nh, int nkv, int hd, int past, const int32_t* d_past,
+                                                        int dst_t, int dst_off_is_past, int tab_t, int tab_div) {
+  const int tok = blockIdx.x, b = tok / L, l = tok % L;
+  if (d_past) past = *d_past;
+  const int half = hd >> 1, hc = half >> 3;          // 8-wide chunks per half
+  const int pos = past + l;
+  const bool rot = cos_t != nullptr;          // null tables: plain head split (CLIP q/k/v, phi.py:147)
+  const float* ct = rot ? cos_t + ((size_t)(b / tab_div) * tab_t + pos) * half : nullptr;
+  const float* st = rot ? sin_t + ((size_t)(b / tab_div) * tab_t + pos) * half : nullptr;
+  const bf16_t* row = qkv + (size_t)tok * (nh + 2 * nkv) * hd;
+  const int dpos = (dst_off_is_past ? past : 0) + l;
+  const int n_rot = (nh + nkv) * hc;
+  const int n_v = nkv * (hd >> 3);
+  for (int it = threadIdx.x; it < n_rot + n_v; it += blockDim.x) {
+    if (it < n_rot) {
+      const int head = it / hc, c = it % hc;
+      const bf16_t* src = row + (size_t)head * hd + c * 8;
+      u32x4_t lo = *(const u32x4_t*)src, hi = *(const u32x4_t*)(src + half);
+      u32x4_t olo = lo, ohi = hi;
+      float cs[8], sn[8];
+      if (rot) {
+        const float4 c0 = *(const float4*)(ct + c * 8), c1 = *(const float4*)(ct + c * 8 + 4);
+        const float4 s0 = *(const float4*)(st + c * 8), s1 = *(const float4*)(st + c * 8 + 4);
+        cs[0] = c0.x; cs[1] = c0.y; cs[2] = c0.z; cs[3] = c0.w; cs[4] = c1.x; cs[5] = c1.y; cs[6] = c1.z; cs[7] = c1.w;
+        sn[0] = s0.x; sn[1] = s0.y; sn[2] = s0.z; sn[3] = s0.w; sn[4] = s1.x; sn[5] = s1.y; sn[6] = s1.z; sn[7] = s1.w;
+      }
+#pragma unroll
+      for (int j = 0; j < 4 && rot; ++j) {
+        const float a0 = bf16lo(lo[j]), a1 = bf16hi(lo[j]), b0 = bf16lo(hi[j]), b1 = bf16hi(hi[j]);
+        olo[j] = pack_bf16x2(a0 * cs[2 * j] - b0 * sn[2 * j], a1 * cs[2 * j + 1] - b1 * sn[2 * j + 1]);
+        ohi[j] = pack_bf16x2(b0 * cs[2 * j] + a0 * sn[2 * j], b1 * cs[2 * j + 1] + a1 * sn[2 * j + 1]);
+      }
+      bf16_t* dst;
+      if (head < nh) dst = q_out + (((size_t)b * nh + head) * L + l) * hd + c * 8;
+      else dst = k_dst + (((size_t)b * nkv + (head - nh)) * dst_t + dpos) * hd + c * 8;
+      *(u32x4_t*)dst = olo;
+      *(u32x4_t*)(dst + half) = ohi;
+    } else {
+      const int j = it - n_rot, head = j / (hd >> 3), c = j % (hd >> 3);
+      const u32x4_t v = *(const u32x4_t*)(row + (size_t)(nh + nkv + head) * hd + c * 8);
+      *(u32x4_t*)(v_dst + (((size_t)b * nkv + head) * dst_t + dpos) * hd + c * 8) = v;
+    }
+  }
+}
+
+extern "C" int p3v_rope_kv_append(const uint16_t* qkv, const float* cos_t, const float* sin_t, uint16_t* q_out,
+                                  uint16_t* k_dst, uint16_t* v_dst, int B, int L, int n_heads, int n_kv, int hd, int past,
+                                  const int32_t* d_past, int dst_t, int dst_off_is_past, int tab_t, int tab_div,
+                                  void* stream) {
+  if (!qkv || !q_out || !k_dst || !v_dst || (!cos_t) != (!sin_t)) return P3V_ERR_ARG;
+  if (B < 0 || L < 0 || hd % 16 || n_heads <= 0 || n_kv <= 0 || tab_div <= 0) return P3V_ERR_ARG;
+  if (B * L == 0) return P3V_OK;
+  hipLaunchKernelGGL(k_rope_kv_append, dim3(B * L), dim3(256), 0, (hipStream_t)stream, qkv, cos_t, sin_t, q_out, k_dst,
+                     v_dst, L, n_heads, n_kv, hd, past, d_past, dst_t, dst_off_is_past, tab_t, tab_div);
+  P3V_CHECK_LAUNCH();
+  return P3V_OK;
+}
+
+// ---------------------------------------------------------------- CLIP patch unfold + CLS rows
+__global__ void k_im2col(const float* __restrict__ pix, bf16_t* __restrict__ out, int img, int patch, int grid, int kpad,
+                         long total) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int k = (int)(i % kpad);
+  const long r = i / kpad;
+  const int pp = patch * patch;
+  float v = 0.f;
+  if (k < 3 * pp) {
+    const int c = k / pp, ky = (k % pp) / patch, kx = k % patch;
+    const int px = (int)(r % grid), py = (int)((r / grid) % grid);
+    const long n = r / ((long)grid * grid);
+    v = pix[((n * 3 + c) * img + (py * patch + ky)) * (long)img + px * patch + kx];
+  }
+  out[i] = f32_to_bf16(v);
+}
+
+extern "C" int p3v_im2col_patches(const float* pix, uint16_t* patches, int n_img, int img, int patch, int kpad,
+                                  void* stream) {
+  if (!pix || !patches || n_img < 0 || img % patch || kpad < 3 * patch * patch) return P3V_ERR_ARG;
+  const int grid = img / patch;
+  const long total = (long)n_img * grid * grid * kpad;
+  if (total == 0) return P3V_OK;
+  hipLaunchKernelGGL(k_im2col, dim3(p3v_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, pix, patches, img, patch,
+                     grid, kpad, total);
+  P3V_CHECK_LAUNCH();
+  return P3V_OK;
+}
+
+__global__ void k_clip_cls(float* __restrict__ x, const bf16_t* __restrict__ cls, const bf16_t* __restrict__ pos,
+                           int tokens, int dim) {
+  const int n = blockIdx.x;
+  for (int d = threadIdx.x; d < dim; d += blockDim.x)
+    x[(size_t)n * tokens * dim + d] = bf16_to_f32(cls[d]) + bf16_to_f32(pos[d]);
+}
+
+extern "C" int p3v_clip_cls_rows(float* x, const uint16_t* cls, const uint16_t* pos, int n_img, int tokens, int dim,
+                                 void* stream) {
+  if (!x || !cls || !pos || n_img < 0) return P3V_ERR_ARG;
+  if (n_img == 0) return P3V_OK;
+  hipLaunchKernelGGL(k_clip_cls, dim3(n_img), dim3(256), 0, (hipStream_t)stream, x, cls, pos, tokens, dim);
+  P3V_CHECK_LAUNCH();
+  return P3V_OK;
+}
+
+// ---------------------------------------------------------------- HD merge (pure index math)
+// one block per output token; 4C channels = [dy][dx][C].
+__global__ void __launch_bounds__(256) k_hd_merge(const float* __restrict__ feats, const bf16_t* __restrict__ sub_gn,
+                                                  const bf16_t* __restrict__ glb_gn, bf16_t* __restrict__ out, int h,
+                                                  int w, int grid, int C) {
+  const int g2 = grid / 2;                       // 12
+  const int sub_w = w * g2 + 1;
+  const int n_sub = h * g2 * sub_w;
+  const int t = blockIdx.x;
+  bf16_t* o = out + (size_t)t * 4 * C;
+  const bf16_t* gn = nullptr;
+  int crop = 0, i = 0, j = 0;
+  if (t < n_sub) {
+    const int line = t / sub_w, col = t % sub_w;
+    if (col == w * g2) gn = sub_gn;
+    else {
+      const int q = line * (w * g2) + col;       // crop-major token index (reference quirk Q4)
+      crop = 1 + q / (g2 * g2);
+      i = (q % (g2 * g2)) / g2;
+      j = q % g2;
+    }
+  } else if (t == n_sub) {
+    gn = glb_gn;
+  } else {
+    const int u = t - n_sub - 1, line = u / (g2 + 1), col = u % (g2 + 1);
+    if (col == g2) gn = sub_gn;
+    else { crop = 0; i = line; j = col; }
+  }
+  if (gn) {
+    for (int c = threadIdx.x; c < 4 * C; c += blockDim.x) o[c] = gn[c];
+    return;
+  }
+  const size_t tok_stride = C, crop_stride = (size_t)(grid * grid + 1) * C;
+  for (int c4 = threadIdx.x; c4 < C; c4 += blockDim.x) {   // c4 indexes 4-wide f32 chunks over [dy][dx][C]
+    const int e = c4 * 4, dy = e / (2 * C), dx = (e / C) & 1, c = e % C;
+    const int p = (2 * i + dy) * grid + (2 * j + dx);
+    const float4 v = *(const float4*)(feats + crop * crop_stride + (size_t)(p + 1) * tok_stride + c);
+    u32x2_t r;
+    r[0] = pack_bf16x2(v.x, v.y);
+    r[1] = pack_bf16x2(v.z, v.w);
+    *(u32x2_t*)(o + e) = r;
+  }
+}
+
+extern "C" int p3v_hd_merge(const float* feats, const uint16_t* sub_gn, const uint16_t* glb_gn, uint16_t* out, int h_crops,
+                            int w_crops, int grid, int C, void* stream) {
+  if (!feats || !sub_gn || !glb_gn || !out || h_crops <= 0 || w_crops <= 0 || grid % 2 || C % 4) return P3V_ERR_ARG;
+  const int g2 = grid / 2;
+  const int n_out = h_crops * g2 * (w_crops * g2 + 1) + 1 + g2 * (g2 + 1);
+  hipLaunchKernelGGL(k_hd_merge, dim3(n_out), dim3(256), 0, (hipStream_t)stream, feats, sub_gn, glb_gn, out, h_crops,
+                     w_crops, grid, C);
+  P3V_CHECK_LAUNCH();
+  return P3V_OK;
+}
+
+// ---------------------------------------------------------------- argmax / log-softmax / top-k over the vocab
+struct ValIdx { float v; int i; };
+__device__ __forceinline__ ValIdx better(ValIdx a, ValIdx b) {   // larger value, then smaller index
+  return (b.v > a.v || (b.v == a.v && b.i < a.i)) ? b : a;
+}
+__device__ __forceinline__ ValIdx block_argmax(ValIdx m, ValIdx* red) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    ValIdx t;
+    t.v = __shfl_xor(m.v, o, 64);
+    t.i = __shfl_xor(m.i, o, 64);
+    m = better(m, t);
+  }
+  const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[w] = m;
+  __syncthreads();
+  ValIdx r = red[0];
+  for (int k = 1; k < nw; ++k) r = better(r, red[k]);
+  return r;
+}
+
+__global__ void __launch_bounds__(1024) k_argmax(const bf16_t* __restrict__ x, int32_t* __restrict__ out, int n,
+                                                 int64_t stride) {
+  __shared__ ValIdx red[16];
+  const bf16_t* r = x + (size_t)blockIdx.x * stride;
+  ValIdx m = {-INFINITY, 0x7fffffff};
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const float v = bf16_to_f32(r[i]);
+    if (v > m.v || (v == m.v && i < m.i) || m.i == 0x7fffffff) { m.v = v; m.i = i; }
+  }
+  m = block_argmax(m, red);
+  if (threadIdx.x == 0) out[blockIdx.x] = m.i;
+}
+
+extern "C" int p3v_argmax(const uint16_t* logits, int32_t* out, int rows, int n, int64_t row_stride, void* stream) {
+  if (!logits || !out || rows < 0 || n <= 0) return P3V_ERR_ARG;
+  if (rows == 0) return P3V_OK;
+  hipLaunchKernelGGL(k_argmax, dim3(rows), dim3(1024), 0, (hipStream_t)stream, logits, out, n, row_stride);
+  P3V_CHECK_LAUNCH();
+  return P3V_OK;
+}
+
+__global__ void __launch_bounds__(1024) k_log_softmax(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, int n) {
+  __shared__ float red[16];
+  const bf16_t* r = x + (size_t)blockIdx.x * n;
+  bf16_t* o = y + (size_t)blockIdx.x * n;
+  float m = -INFINITY;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) m = fmaxf(m, bf16_to_f32(r[i]));
+  m = block_max(m, red);
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) s += expf(bf16_to_f32(r[i]) - m);
+  s = block_sum(s, red);
+  const float lse = m + logf(s);
+  for (int i = threadIdx.x; i < n; i += blockDim.x) o[i] = f32_to_bf16(bf16_to_f32(r[i]) - lse);
+}
+
+extern "C" int p3v_log_softmax(const uint16_t* x, uint16_t* y, int rows, int n, void* stream) {
+  if (!x || !y || rows < 0 || n <= 0) return P3V_ERR_ARG;
+  if (rows == 0) return P3V_OK;
+  hipLaunchKernelGGL(k_log_softmax, dim3(rows), dim3(1024), 0, (hipStream_t)stream, x, y, n);
+  P3V_CHECK_LAUNCH();
+  return P3V_OK;
+}
+
+__global__ void __launch_bounds__(1024) k_topk(const bf16_t* __restrict__ x, int32_t* __restrict__ out, int n, int k,
+                                               int64_t stride) {
+  __shared__ ValIdx red[16];
+  __shared__ int picked[8];
+  const bf16_t* r = x + (size_t)blockIdx.x * stride;
+  for (int round = 0; round < k; ++round) {
+    ValIdx m = {-INFINITY, 0x7fffffff};
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+      bool skip = false;
+      for (int p = 0; p < round; ++p) skip |= (picked[p] == i);
+      if (skip) continue;
+      const float v = bf16_to_f32(r[i]);
+      if (v > m.v || (v == m.v && i < m.i) || m.i == 0x7fffffff) { m.v = v; m.i = i; }
+    }
+    m = block_argmax(m, red);
+    if (threadIdx.x == 0) { picked[round] = m.i; out[blockIdx.x * k + round] = m.i; }
+    __syncthreads();
+  }
+}
+
+extern "C" int p3v_topk(const uint16_t* x, int32_t* idx_out, int rows, int n, int k, int64_t row_stride, void* stream) {
+  if (!x || !idx_out || rows < 0 || n <= 0 || k <= 0 || k > 8 || k > n) return P3V_ERR_ARG;
+  if (rows == 0) return P3V_OK;
+  hipLaunchKernelGGL(k_topk, dim3(rows), dim3(1024), 0, (hipStream_t)stream, x, idx_out, n, k, row_stride);
+  P3V_CHECK_LAUNCH();
+  return P3V_OK;
+}
+
+// ---------------------------------------------------------------- device-resident loop state
+__global__ void k_add_i32(int32_t* x, int n, int delta) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) x[i] += delta;
+}
+extern "C" int p3v_add_i32(int32_t* x, int n, int delta, void* stream) {
+  if (!x || n <= 0) return P3V_ERR_ARG;
+  hipLaunchKernelGGL(k_add_i32, dim3(p3v_cdiv(n, 64)), dim3(64), 0, (hipStream_t)stream, x, n, delta);
+  P3V_CHECK_LAUNCH();
+  return P3V_OK;
+}
+
+__global__ void k_store_token(const int32_t* tok, int32_t* hist, const int32_t* d_step, int B, int max_steps) {
+  const int b = threadIdx.x;
+  const int s = *d_step;
+  if (b < B && s < max_steps) hist[(size_t)b * max_steps + s] = tok[b];
+}
+extern "C" int p3v_store_token(const int32_t* tok, int32_t* history, const int32_t* d_step, int B, int max_steps,
+                               void* stream) {
+  if (!tok || !history || !d_step || B <= 0 || B > 1024) return P3V_ERR_ARG;
+  hipLaunchKernelGGL(k_store_token, dim3(1), dim3(p3v_cdiv(B, 64) * 64), 0, (hipStream_t)stream, tok, history, d_step, B,
+                     max_steps);
+  P3V_CHECK_LAUNCH();
+  return P3V_OK;
+}

@@ -1,0 +1,157 @@
+// Skinny projection for decode:  y[M,N] = x[M,K] * W[N,K]^T,  M <= 8.
+//
+// Pure weight streaming (HBM-bound: 2*N*K bytes of W per call, read once):
+//   * x (optionally RMS-normalised on the fly -- the pre-norm of the decoder
+//     layer is fused here, phi.py:482,484) is staged once per block in LDS as
+//     bf16, M*K*2 bytes;
+//   * each wave owns output rows two at a time (for SiLU*up the pair is
+//     gate row n / up row n+N, phi.py:469-471), lanes stride over K in 16-byte
+//     chunks (8 bf16), so every global load is a fully coalesced 1 KiB
+//     wave-load straight to VGPRs (no LDS round trip for W: it is used once);
+//   * fp32 accumulate, 64-lane shuffle reduction, fused epilogue.
+// Algorithmic bytes per launch: 2*N*K (+ M*K*2 for x per block from L2).
+#include "p3v_common.h"
+
+struct GemvP {
+  const bf16_t* x; const bf16_t* W; void* out; const bf16_t* resid; const bf16_t* norm_w;
+  float eps;
+  int M, N, K, epi, units;
+};
+
+__device__ __forceinline__ float dot8(u32x4_t w, u32x4_t x, float acc) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    acc = fmaf(bf16lo(w[j]), bf16lo(x[j]), acc);
+    acc = fmaf(bf16hi(w[j]), bf16hi(x[j]), acc);
+  }
+  return acc;
+}
+
+template <int MT>
+__global__ void __launch_bounds__(256) k_gemv(GemvP p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ float red[16];
+  u32x4_t* xs = (u32x4_t*)smem;                       // [MT][chunks]
+  const int chunks = p.K >> 3;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+  // ---- stage x (+ fused RMSNorm) into LDS
+  for (int m = 0; m < MT; ++m) {
+    const bool live = m < p.M;
+    const u32x4_t* xr = (const u32x4_t*)(p.x + (size_t)(live ? m : 0) * p.K);
+    if (p.norm_w) {
+      float ss = 0.f;
+      for (int c = tid; c < chunks; c += 256) {
+        const u32x4_t v = xr[c];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const float a = bf16lo(v[j]), b = bf16hi(v[j]); ss += a * a + b * b; }
+      }
+      const float r = rsqrtf(block_sum(ss, red) / (float)p.K + p.eps);
+      const u32x4_t* g = (const u32x4_t*)p.norm_w;
+      for (int c = tid; c < chunks; c += 256) {
+        const u32x4_t v = xr[c], gw = g[c];
+        u32x4_t o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          o[j] = pack_bf16x2(bf16lo(v[j]) * r * bf16lo(gw[j]), bf16hi(v[j]) * r * bf16hi(gw[j]));
+        xs[m * chunks + c] = live ? o : (u32x4_t){0, 0, 0, 0};
+      }
+    } else {
+      for (int c = tid; c < chunks; c += 256) xs[m * chunks + c] = live ? xr[c] : (u32x4_t){0, 0, 0, 0};
+    }
+  }
+  __syncthreads();
+
+  const bool silu = p.epi == P3V_EPI_SILU_MUL;
+  const int n_waves = gridDim.x * 4;
+  for (int u = blockIdx.x * 4 + wave; u < p.units; u += n_waves) {
+    const int r0 = silu ? u : 2 * u;
+    int r1 = silu ? u + p.N : 2 * u + 1;
+    const bool has1 = silu || r1 < p.N;
+    if (!has1) r1 = r0;
+    const u32x4_t* w0 = (const u32x4_t*)(p.W + (size_t)r0 * p.K);
+    const u32x4_t* w1 = (const u32x4_t*)(p.W + (size_t)r1 * p.K);
+    float a0[MT], a1[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) a0[m] = a1[m] = 0.f;
+    int c = lane;
+    for (; c + 64 < chunks; c += 128) {             // two chunks per row in flight per iteration
+      const u32x4_t wa = w0[c], wb = w1[c], wc = w0[c + 64], wd = w1[c + 64];
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        const u32x4_t xa = xs[m * chunks + c], xb = xs[m * chunks + c + 64];
+        a0[m] = dot8(wa, xa, a0[m]);
+        a1[m] = dot8(wb, xa, a1[m]);
+        a0[m] = dot8(wc, xb, a0[m]);
+        a1[m] = dot8(wd, xb, a1[m]);
+      }
+    }
+    for (; c < chunks; c += 64) {
+      const u32x4_t wa = w0[c], wb = w1[c];
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        const u32x4_t xa = xs[m * chunks + c];
+        a0[m] = dot8(wa, xa, a0[m]);
+        a1[m] = dot8(wb, xa, a1[m]);
+      }
+    }
+#pragma unroll
+    for (int m = 0; m < MT; ++m) { a0[m] = wave_sum(a0[m]); a1[m] = wave_sum(a1[m]); }
+    if (lane == 0) {
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        if (m >= p.M) break;
+        if (silu) {
+          const float g = bf16_round(a0[m]), up = bf16_round(a1[m]);
+          const float s = bf16_round(g * bf16_round(1.f / (1.f + __expf(-g))));
+          ((bf16_t*)p.out)[(size_t)m * p.N + u] = f32_to_bf16(s * up);
+        } else {
+          for (int h = 0; h < (has1 ? 2 : 1); ++h) {
+            const float v = h ? a1[m] : a0[m];
+            const size_t o = (size_t)m * p.N + (h ? r1 : r0);
+            if (p.epi == P3V_EPI_F32) ((float*)p.out)[o] = v;
+            else if (p.epi == P3V_EPI_RESID_BF16)
+              ((bf16_t*)p.out)[o] = f32_to_bf16(bf16_to_f32(p.resid[o]) + bf16_round(v));
+            else ((bf16_t*)p.out)[o] = f32_to_bf16(v);
+          }
+        }
+      }
+    }
+  }
+}
+
+template <int MT>
+static int launch_gemv(const GemvP& p, hipStream_t s) {
+  const size_t lds = (size_t)MT * p.K * 2;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)k_gemv<MT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256) != hipSuccess)
+      return P3V_ERR_HIP;
+    attr_set = true;
+  }
+  int blocks = p3v_cdiv(p.units, 4);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(k_gemv<MT>, dim3(blocks), dim3(256), lds, s, p);
+  P3V_CHECK_LAUNCH();
+  return P3V_OK;
+}
+
+extern "C" int p3v_gemv(const p3v_gemv_args_t* a, void* stream) {
+  if (!a || !a->x || !a->W || !a->out) return P3V_ERR_ARG;
+  if (a->M <= 0 || a->M > 8 || a->N <= 0 || a->K <= 0 || a->K % 8) return P3V_ERR_ARG;
+  if (a->epilogue != P3V_EPI_NONE && a->epilogue != P3V_EPI_RESID_BF16 && a->epilogue != P3V_EPI_SILU_MUL &&
+      a->epilogue != P3V_EPI_F32)
+    return P3V_ERR_UNSUPPORTED;
+  if (a->epilogue == P3V_EPI_RESID_BF16 && !a->resid) return P3V_ERR_ARG;
+  const int mt = a->M <= 1 ? 1 : a->M <= 2 ? 2 : a->M <= 4 ? 4 : 8;
+  if ((size_t)mt * a->K * 2 > 160 * 1024 - 256) return P3V_ERR_UNSUPPORTED;
+  GemvP p = {a->x, a->W, a->out, a->resid, a->norm_w, a->norm_eps, a->M, a->N, a->K, a->epilogue,
+             a->epilogue == P3V_EPI_SILU_MUL ? a->N : (a->N + 1) / 2};
+  hipStream_t s = (hipStream_t)stream;
+  switch (mt) {
+    case 1: return launch_gemv<1>(p, s);
+    case 2: return launch_gemv<2>(p, s);
+    case 4: return launch_gemv<4>(p, s);
+    default: return launch_gemv<8>(p, s);
+  }
+}

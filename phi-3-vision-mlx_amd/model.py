@@ -1,0 +1,276 @@
+"""Phi-3-Vision / Phi-3-mini-128K on MI355X: the model object behind
+`generate()/choose()/constrain()`.
+
+Drop-in for the reference's `Phi3VForCausalLM` / `Phi3ForCausalLM`
+(reference phi.py:565-617): same call signature and return contract
+
+    model(input_ids, pixel_values=None, image_sizes=None, positions=None, cache=None,
+          pids=None, mask=None, max_tokens=0, advance_offset=None, n_beam=1) -> (logits, cache)
+
+but every tensor op is a hand-written gfx950 kernel from ``csrc/`` (see ops.py).
+This module only owns device buffers and sequences launches.
+
+HBM layout
+  weights      bf16 [out, in] row-major (HF layout, K contiguous = MFMA fragment order)
+  KV cache     per layer K,V bf16 [B, n_kv, T, hd]  (T = prompt + max_tokens, allocated once)
+  RoPE tables  fp32 cos/sin [B, T, hd/2] built once per prompt (one short/long choice, Q2)
+  residual     decoder: bf16 [B*L, H]; ViT: fp32 [crops, 577, 1024]
+Dtype flow differs from the reference only where stated in DESIGN.md
+(bf16 K cache / bf16 MFMA operands instead of fp32 attention), within the
+tolerance the parity tests state.
+"""
+import math
+
+import numpy as np
+import torch
+
+from . import ops
+from .config import head_dim, is_vision, rope_scaling_factor
+from .ops import (BF16, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_QGELU, EPI_BIAS_RESID_F32, EPI_NONE, EPI_PATCH,
+                  EPI_RESID_BF16, EPI_SILU_MUL, F32, I32)
+
+V_PREFIX = "model.vision_embed_tokens.img_processor.vision_model."
+E_PREFIX = "model.vision_embed_tokens."
+
+
+class CacheState:
+    """All layers' KV cache + per-prompt RoPE tables / pad lengths.
+
+    Mirrors reference KVCache (phi.py:509-548) semantics: `offset` auto-advances
+    by L, can be rewound (`advance_offset`), `max_tokens < 1` disables caching,
+    `n_beam > 1` reads the cache without writing it."""
+
+    def __init__(self, cfg, B, S, max_tokens, device):
+        self.B, self.S, self.max_tokens = B, S, max_tokens
+        self.T = S + max(max_tokens, 0)
+        nl, nkv, hd = cfg.num_hidden_layers, cfg.num_key_value_heads, head_dim(cfg)
+        self.k = torch.empty((nl, B, nkv, self.T, hd), dtype=BF16, device=device)
+        self.v = torch.empty((nl, B, nkv, self.T, hd), dtype=BF16, device=device)
+        self.offset = 0
+        self.cos = self.sin = self.pad_len = None
+        self.graphs = {}
+
+
+class LayerCache:
+    """`cache[i]` view with the reference's `.offset` attribute."""
+
+    def __init__(self, state, i):
+        self.state, self.i = state, i
+
+    @property
+    def offset(self):
+        return self.state.offset
+
+    @offset.setter
+    def offset(self, v):
+        self.state.offset = int(v)
+
+
+class Phi3VModel:
+    def __init__(self, cfg, weights, device="cuda:0"):
+        if not torch.cuda.is_available():
+            raise RuntimeError("Phi3VModel needs a GPU: the hot path is HIP-only (no CPU fallback)")
+        ops.L.lib()                                  # fail loudly if libp3v.so is missing
+        self.cfg, self.device = cfg, torch.device(device)
+        self.vision = is_vision(cfg)
+        self.w = {k: v.to(self.device, BF16).contiguous() for k, v in weights.items()}
+        self.hd = head_dim(cfg)
+        if self.hd != 96:
+            raise ValueError(f"decoder head_dim must be 96 (got {self.hd})")
+        self._state = None
+        if self.vision:
+            self._prep_vision()
+
+    # ------------------------------------------------------------------ vision tower
+    def _prep_vision(self):
+        c = self.cfg.clip
+        D, P = c["hidden_size"], c["patch_size"]
+        if D // c["num_attention_heads"] != 64:
+            raise ValueError("CLIP head_dim must be 64")
+        kk = 3 * P * P
+        self.kpad = (kk + 63) // 64 * 64
+        wp = torch.zeros((D, self.kpad), dtype=BF16, device=self.device)
+        wp[:, :kk] = self.w[V_PREFIX + "embeddings.patch_embedding.weight"].reshape(D, kk)
+        self.w_patch = wp
+        self.clip_qkv = []
+        for j in range(c["num_hidden_layers"] - 1):          # the last layer never runs (phi.py:219)
+            q = V_PREFIX + f"encoder.layers.{j}.self_attn."
+            wq = torch.cat([self.w[q + f"{n}_proj.weight"] for n in "qkv"], dim=0).contiguous()
+            bq = torch.cat([self.w[q + f"{n}_proj.bias"] for n in "qkv"], dim=0).contiguous()
+            self.clip_qkv.append((wq, bq))
+
+    def clip_forward(self, pix):
+        """ClipModel.__call__ (phi.py:216-221) on live crops; pix f32 [n,3,336,336] -> f32 [n,577,D]
+        (row 0 = CLS, which the caller skips)."""
+        c, w = self.cfg.clip, self.w
+        n, D, P = pix.shape[0], c["hidden_size"], c["patch_size"]
+        G = c["image_size"] // P
+        T, nh, eps = G * G + 1, c["num_attention_heads"], c["layer_norm_eps"]
+        e = V_PREFIX + "embeddings."
+        patches = ops.im2col_patches(pix, P, self.kpad)
+        x = torch.empty((n, T, D), dtype=F32, device=self.device)
+        pos = w[e + "position_embedding.weight"]
+        ops.gemm(patches, self.w_patch, EPI_PATCH, out=x, n_out=D, pos=pos, patches_per_img=G * G, ldo=D)
+        ops.clip_cls_rows(x, w[e + "class_embedding"], pos)
+        x2 = x.view(n * T, D)
+        ops.layernorm(x2, w[V_PREFIX + "pre_layrnorm.weight"], w[V_PREFIX + "pre_layrnorm.bias"], 1e-5, out_f32=True, out=x2)
+        q = torch.empty((n, nh, T, 64), dtype=BF16, device=self.device)
+        k, v = torch.empty_like(q), torch.empty_like(q)
+        o = torch.empty((n * T, D), dtype=BF16, device=self.device)
+        for j in range(c["num_hidden_layers"] - 1):
+            lp = V_PREFIX + f"encoder.layers.{j}."
+            h = ops.layernorm(x2, w[lp + "layer_norm1.weight"], w[lp + "layer_norm1.bias"], eps)
+            wq, bq = self.clip_qkv[j]
+            qkv = ops.gemm(h, wq, EPI_BIAS, bias=bq)
+            ops.rope_kv_append(qkv, None, None, q, k, v, n, T, nh, nh, 64, 0, T, False)
+            ops.attention(q, k, v, o, n, T, nh, nh, 64, 64 ** -0.5, False, new_t=T)
+            ops.gemm(o, w[lp + "self_attn.out_proj.weight"], EPI_BIAS_RESID_F32, bias=w[lp + "self_attn.out_proj.bias"],
+                     resid=x2, out=x2)
+            h = ops.layernorm(x2, w[lp + "layer_norm2.weight"], w[lp + "layer_norm2.bias"], eps)
+            f = ops.gemm(h, w[lp + "mlp.fc1.weight"], EPI_BIAS_QGELU, bias=w[lp + "mlp.fc1.bias"])
+            ops.gemm(f, w[lp + "mlp.fc2.weight"], EPI_BIAS_RESID_F32, bias=w[lp + "mlp.fc2.bias"], resid=x2, out=x2)
+        return x
+
+    def vision_embed(self, x, pixel_values, image_sizes, positions, L):
+        """Phi3ImageEmbedding.__call__ (phi.py:393-416): ViT on the live crops
+        (dead zero-padded crop slots are skipped, Q5), HD merge, projector, and
+        the projector's second GEMM writes straight into the text embeddings."""
+        w = self.w
+        pv = torch.as_tensor(np.asarray(pixel_values), dtype=F32)          # f64 -> f32 as mx.array does
+        sizes = (np.asarray(image_sizes) // 336).tolist()
+        positions = np.asarray(positions).tolist()
+        live = [h * ww + 1 for h, ww in sizes]
+        pix = torch.cat([pv[i, :n] for i, n in enumerate(live)], dim=0).contiguous().to(self.device)
+        feats = self.clip_forward(pix)
+        C_ = self.cfg.img_processor["image_dim_out"]
+        G = self.cfg.clip["image_size"] // self.cfg.clip["patch_size"]
+        H = self.cfg.hidden_size
+        idx, crop0 = 0, 0
+        for i, (h, ww) in enumerate(sizes):
+            merged = ops.hd_merge(feats[crop0:crop0 + live[i]], w[E_PREFIX + "sub_GN"], w[E_PREFIX + "glb_GN"], h, ww, G, C_)
+            t = ops.gemm(merged, w[E_PREFIX + "img_projection.0.weight"], EPI_BIAS_GELU, bias=w[E_PREFIX + "img_projection.0.bias"])
+            r, c0 = positions[idx]
+            cnt = merged.shape[0]
+            dst = x[r * L + c0: r * L + c0 + cnt]
+            ops.gemm(t, w[E_PREFIX + "img_projection.2.weight"], EPI_BIAS, bias=w[E_PREFIX + "img_projection.2.bias"], out=dst)
+            idx += cnt
+            crop0 += live[i]
+        return x
+
+    # ------------------------------------------------------------------ per-prompt state
+    def _new_state(self, B, S, max_tokens, pids, mask):
+        cfg = self.cfg
+        st = CacheState(cfg, B, S, max_tokens, self.device)
+        L_all = S + max_tokens                                  # reference sizes tables with max_tokens as given
+        half = self.hd // 2
+        su = cfg.rope_scaling["long_factor"] if L_all > cfg.original_max_position_embeddings else cfg.rope_scaling["short_factor"]
+        inv_freq = 1.0 / (torch.tensor(su, dtype=F32) * (torch.tensor(float(cfg.rope_theta), dtype=F32)
+                                                        ** (torch.arange(0, self.hd, 2, dtype=F32) / self.hd)))
+        T = st.T
+        if pids is None:
+            pos = torch.arange(T, dtype=F32)[None].expand(B, T)
+        else:
+            p = torch.as_tensor(np.asarray(pids)).to(F32)
+            ext = p[:, -1:] + 1 + torch.arange(T - p.shape[1], dtype=F32)[None]
+            pos = torch.cat([p, ext], dim=1)
+        pos = pos.contiguous().to(self.device)
+        cos, sin = ops.rope_table(pos.view(-1), inv_freq.to(self.device), rope_scaling_factor(cfg))
+        st.cos, st.sin = cos.view(B, T, half), sin.view(B, T, half)
+        if mask is not None:
+            m = np.asarray(mask)
+            st.pad_len = torch.as_tensor((m == 0).sum(axis=1).astype(np.int32)).to(self.device)
+        return st
+
+    # ------------------------------------------------------------------ decoder stack
+    def _layers(self, x, st, B, L, past, n_beam):
+        cfg, w = self.cfg, self.w
+        nh, nkv, hd, eps = cfg.num_attention_heads, cfg.num_key_value_heads, self.hd, cfg.rms_norm_eps
+        M = B * L
+        scale = hd ** -0.5
+        q = torch.empty((B, nh, L, hd), dtype=BF16, device=self.device)
+        o = torch.empty((M, nh * hd), dtype=BF16, device=self.device)
+        Bc = B // n_beam
+        if n_beam > 1:                                          # beams: K/V of this call go to a scratch, cache is read-only
+            k_new = torch.empty((B, nkv, L, hd), dtype=BF16, device=self.device)
+            v_new = torch.empty_like(k_new)
+        n_split, ws = 0, None
+        if L <= ops.L.DECODE_MAX_L:
+            n_split = max(1, min(64, 1024 // max(1, B * nh)))
+            if n_split > 1:
+                ws = torch.empty(ops.attention_ws_bytes(B, L, nh, hd, n_split) // 4, dtype=F32, device=self.device)
+        for i in range(cfg.num_hidden_layers):
+            p = f"model.layers.{i}."
+            if M <= 8:
+                qkv = ops.gemv(x, w[p + "self_attn.qkv_proj.weight"], norm_w=w[p + "input_layernorm.weight"], norm_eps=eps)
+            else:
+                h = ops.rmsnorm(x, w[p + "input_layernorm.weight"], eps)
+                qkv = ops.gemm(h, w[p + "self_attn.qkv_proj.weight"])
+            if n_beam > 1:
+                ops.rope_kv_append(qkv, st.cos, st.sin, q, k_new, v_new, B, L, nh, nkv, hd, past, L, False, st.T, n_beam)
+                ops.attention(q, k_new, v_new, o, B, L, nh, nkv, hd, scale, True, new_t=L, past=past, k_past=st.k[i],
+                              v_past=st.v[i], past_t=st.T, past_div=n_beam, pad_len=st.pad_len, pad_div=n_beam, ws=ws,
+                              n_split=n_split)
+            else:
+                ops.rope_kv_append(qkv, st.cos, st.sin, q, st.k[i], st.v[i], B, L, nh, nkv, hd, past, st.T, True, st.T, 1)
+                kn, vn = st.k[i][:, :, past:], st.v[i][:, :, past:]          # views: same strides, offset by `past` rows
+                ops.attention(q, kn, vn, o, B, L, nh, nkv, hd, scale, True, new_t=st.T, past=past, k_past=st.k[i],
+                              v_past=st.v[i], past_t=st.T, pad_len=st.pad_len, ws=ws, n_split=n_split)
+            x = ops.linear(o, w[p + "self_attn.o_proj.weight"], EPI_RESID_BF16, resid=x, out=x)
+            if M <= 8:
+                a = ops.gemv(x, w[p + "mlp.gate_up_proj.weight"], EPI_SILU_MUL, norm_w=w[p + "post_attention_layernorm.weight"],
+                             norm_eps=eps)
+            else:
+                h = ops.rmsnorm(x, w[p + "post_attention_layernorm.weight"], eps)
+                a = ops.gemm(h, w[p + "mlp.gate_up_proj.weight"], EPI_SILU_MUL)
+            x = ops.linear(a, w[p + "mlp.down_proj.weight"], EPI_RESID_BF16, resid=x, out=x)
+        return x
+
+    def __call__(self, input_ids, pixel_values=None, image_sizes=None, positions=None, cache=None, pids=None, mask=None,
+                 max_tokens=0, advance_offset=None, n_beam=1, full_logits=None):
+        """Phi3ForCausalLM.__call__ (phi.py:606-608) + Phi3F.__call__ (phi.py:576-592).
+
+        Returns (logits bf16 [B, L', V], cache).  On a prefill call (cache is None)
+        only the last position is projected through lm_head (L' = 1) unless
+        `full_logits=True`: every caller in the reference reads `logits[:, -1]`
+        of a prefill only; cached calls return all L rows."""
+        cfg, w = self.cfg, self.w
+        if torch.is_tensor(input_ids):
+            ids = input_ids.to(self.device, I32)
+        else:
+            ids = torch.as_tensor(np.asarray(input_ids).astype(np.int32)).to(self.device)
+        if ids.dim() == 1:
+            ids = ids[None]
+        ids = ids.contiguous()
+        B, L = ids.shape
+        H = cfg.hidden_size
+        x = ops.embed_gather(ids.view(-1), w["model.embed_tokens.weight"])
+        if pixel_values is not None and self.vision:
+            self.vision_embed(x, pixel_values, image_sizes, positions, L)
+        prefill = cache is None
+        if prefill:
+            st = self._new_state(B, L, max_tokens, pids, mask)
+            cache = [LayerCache(st, i) for i in range(cfg.num_hidden_layers)]
+            self._state = st
+        else:
+            st = cache[0].state
+        past = st.offset
+        if n_beam == 1 and past + L > st.T:
+            raise ValueError(f"KV cache overflow: {past}+{L} > {st.T} (prompt + max_tokens)")
+        x = self._layers(x, st, B, L, past, n_beam)
+        if n_beam == 1:
+            st.offset = past + L                                 # KVCache.__call__ auto-advance (phi.py:544-547)
+        if advance_offset is not None:
+            st.offset = past + advance_offset                    # phi.py:589-591
+        if full_logits is None:
+            full_logits = not prefill
+        if not full_logits:
+            x = x.view(B, L, H)[:, -1, :].contiguous()
+        if x.shape[0] <= 8:
+            logits = ops.gemv(x, w["lm_head.weight"], norm_w=w["model.norm.weight"], norm_eps=cfg.rms_norm_eps)
+        else:
+            logits = ops.gemm(ops.rmsnorm(x, w["model.norm.weight"], cfg.rms_norm_eps), w["lm_head.weight"])
+        return logits.view(B, -1, cfg.vocab_size), cache
+
+    @property
+    def layers(self):
+        return range(self.cfg.num_hidden_layers)

@@ -1,0 +1,235 @@
+"""Operator layer: torch tensors in, HIP kernels (via the C ABI) underneath.
+
+torch is used for device memory and the current stream only; every function
+here launches a hand-written gfx950 kernel from ``csrc/`` and nothing else.
+Each op names the MLX call site of the reference it replaces.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+from ._lib import (EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_QGELU, EPI_BIAS_RESID_F32, EPI_F32, EPI_NONE,  # noqa: F401
+                   EPI_PATCH, EPI_RESID_BF16, EPI_SILU_MUL)
+
+BF16, F32, I32 = torch.bfloat16, torch.float32, torch.int32
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def _chk(t, dtype, name):
+    if not t.is_cuda:
+        raise RuntimeError(f"{name}: expected a device tensor (the hot path has no CPU fallback)")
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name}: expected a contiguous tensor")
+    return t
+
+
+def embed_gather(ids, table, out=None):
+    """nn.Embedding (phi.py:577); ids int32 [n], table bf16 [V,H] -> bf16 [n,H]."""
+    _chk(ids, I32, "ids"), _chk(table, BF16, "table")
+    n, (V, H) = ids.numel(), table.shape
+    out = torch.empty((n, H), dtype=BF16, device=table.device) if out is None else out
+    L.check(L.lib().p3v_embed_gather(_p(ids), _p(table), _p(out), n, H, V, _stream()), "embed_gather")
+    return out
+
+
+def rmsnorm(x, w, eps, out=None):
+    """nn.RMSNorm (phi.py:478-479,571)."""
+    _chk(x, BF16, "x"), _chk(w, BF16, "w")
+    rows, H = x.numel() // x.shape[-1], x.shape[-1]
+    out = torch.empty_like(x) if out is None else out
+    L.check(L.lib().p3v_rmsnorm(_p(x), _p(w), _p(out), rows, H, float(eps), _stream()), "rmsnorm")
+    return out
+
+
+def layernorm(x, w, b, eps, out_f32=False, out=None):
+    """nn.LayerNorm (phi.py:165,167,212): fp32 rows -> bf16 (or fp32, may be in place)."""
+    _chk(x, F32, "x"), _chk(w, BF16, "w"), _chk(b, BF16, "b")
+    rows, H = x.numel() // x.shape[-1], x.shape[-1]
+    if out is None:
+        out = torch.empty(x.shape, dtype=F32 if out_f32 else BF16, device=x.device)
+    L.check(L.lib().p3v_layernorm(_p(x), _p(w), _p(b), _p(out), int(out_f32), rows, H, float(eps), _stream()), "layernorm")
+    return out
+
+
+def gemm(a, w, epilogue=EPI_NONE, bias=None, resid=None, out=None, n_out=None, pos=None, patches_per_img=0, ldo=None):
+    """nn.Linear / patch conv: out[M,N] = a[M,K] @ w[N,K]^T (+ epilogue), bf16 MFMA."""
+    _chk(a, BF16, "a"), _chk(w, BF16, "w")
+    M, K = a.shape
+    N = n_out if n_out is not None else (w.shape[0] // 2 if epilogue == EPI_SILU_MUL else w.shape[0])
+    if w.shape[1] != K:
+        raise ValueError(f"gemm: K mismatch {a.shape} x {w.shape}")
+    f32_out = epilogue in (EPI_BIAS_RESID_F32, EPI_PATCH, EPI_F32)
+    if out is None:
+        out = torch.empty((M, N), dtype=F32 if f32_out else BF16, device=a.device)
+    args = L.GemmArgs(_p(a), _p(w), _p(out), _p(bias), _p(resid), _p(pos), M, N, K, a.stride(0), w.stride(0),
+                      ldo if ldo is not None else N, epilogue, patches_per_img)
+    L.check(L.lib().p3v_gemm(C.byref(args), _stream()), "gemm")
+    return out
+
+
+def gemv(x, w, epilogue=EPI_NONE, resid=None, norm_w=None, norm_eps=0.0, out=None):
+    """Skinny nn.Linear for decode (M<=8) with optional fused RMSNorm / epilogue."""
+    _chk(x, BF16, "x"), _chk(w, BF16, "w")
+    M, K = x.shape
+    N = w.shape[0] // 2 if epilogue == EPI_SILU_MUL else w.shape[0]
+    if out is None:
+        out = torch.empty((M, N), dtype=F32 if epilogue == EPI_F32 else BF16, device=x.device)
+    args = L.GemvArgs(_p(x), _p(w), _p(out), _p(resid), _p(norm_w), float(norm_eps), M, N, K, epilogue)
+    L.check(L.lib().p3v_gemv(C.byref(args), _stream()), "gemv")
+    return out
+
+
+def linear(x, w, epilogue=EPI_NONE, resid=None, out=None):
+    """Dispatch a projection to the weight-streaming GEMV (M<=8) or the MFMA GEMM."""
+    if x.shape[0] <= 8 and epilogue in (EPI_NONE, EPI_RESID_BF16, EPI_SILU_MUL, EPI_F32):
+        return gemv(x, w, epilogue, resid=resid, out=out)
+    return gemm(x, w, epilogue, resid=resid, out=out)
+
+
+def rope_table(pos, inv_freq, scale):
+    """SuRoPE tables (phi.py:494-504): pos [n] f32, inv_freq [half] f32 -> cos, sin [n, half] f32."""
+    _chk(pos, F32, "pos"), _chk(inv_freq, F32, "inv_freq")
+    n, half = pos.numel(), inv_freq.numel()
+    cos = torch.empty((n, half), dtype=F32, device=pos.device)
+    sin = torch.empty_like(cos)
+    L.check(L.lib().p3v_rope_table(_p(pos), _p(inv_freq), float(scale), _p(cos), _p(sin), n, half, _stream()), "rope_table")
+    return cos, sin
+
+
+def rope_kv_append(qkv, cos_t, sin_t, q_out, k_dst, v_dst, B, Lq, nh, nkv, hd, past, dst_t, dst_off_is_past, tab_t=0,
+                   tab_div=1, d_past=None):
+    """split + _rotate_half + KVCache append (phi.py:443-452, 542-548)."""
+    L.check(L.lib().p3v_rope_kv_append(_p(qkv), _p(cos_t), _p(sin_t), _p(q_out), _p(k_dst), _p(v_dst), B, Lq, nh, nkv, hd,
+                                       int(past), _p(d_past), dst_t, int(dst_off_is_past), tab_t, tab_div, _stream()),
+            "rope_kv_append")
+
+
+def attention(q, k_new, v_new, out, B, Lq, nh, nkv, hd, scale, causal, new_t, past=0, k_past=None, v_past=None, past_t=0,
+              past_div=1, pad_len=None, pad_div=1, d_past=None, ws=None, n_split=0):
+    """softmax((q*scale) k^T + mask) v (phi.py:454-457 / phi.py:148), mask never materialised."""
+    args = L.AttnArgs(_p(q), _p(k_past), _p(v_past), _p(k_new), _p(v_new), _p(out), _p(pad_len), _p(d_past), _p(ws),
+                      B, Lq, nh, nkv, hd, int(past), past_t, past_div, new_t, pad_div, int(causal), float(scale), n_split)
+    L.check(L.lib().p3v_attention(C.byref(args), _stream()), "attention")
+    return out
+
+
+def attention_ws_bytes(B, Lq, nh, hd, n_split):
+    return int(L.lib().p3v_attention_ws_bytes(B, Lq, nh, hd, n_split))
+
+
+def im2col_patches(pix, patch, kpad):
+    _chk(pix, F32, "pix")
+    n, _, S, _ = pix.shape
+    out = torch.empty((n * (S // patch) ** 2, kpad), dtype=BF16, device=pix.device)
+    L.check(L.lib().p3v_im2col_patches(_p(pix), _p(out), n, S, patch, kpad, _stream()), "im2col")
+    return out
+
+
+def clip_cls_rows(x, cls, pos):
+    n, T, D = x.shape
+    L.check(L.lib().p3v_clip_cls_rows(_p(x), _p(cls), _p(pos), n, T, D, _stream()), "clip_cls_rows")
+
+
+def hd_merge(feats, sub_gn, glb_gn, h, w, grid, C_):
+    """Phi3ImageEmbedding reshape/concat (phi.py:403-407) as one gather."""
+    _chk(feats, F32, "feats")
+    g2 = grid // 2
+    n_out = h * g2 * (w * g2 + 1) + 1 + g2 * (g2 + 1)
+    out = torch.empty((n_out, 4 * C_), dtype=BF16, device=feats.device)
+    L.check(L.lib().p3v_hd_merge(_p(feats), _p(sub_gn), _p(glb_gn), _p(out), h, w, grid, C_, _stream()), "hd_merge")
+    return out
+
+
+def argmax(logits2d, out=None):
+    """mx.argmax(logits[:, -1, :]) (phi_3_vision_mlx.py:386): bf16 rows, first max wins."""
+    _chk(logits2d, BF16, "logits")
+    rows, n = logits2d.shape
+    out = torch.empty((rows,), dtype=I32, device=logits2d.device) if out is None else out
+    L.check(L.lib().p3v_argmax(_p(logits2d), _p(out), rows, n, n, _stream()), "argmax")
+    return out
+
+
+def log_softmax(x):
+    """nn.log_softmax over the last axis, bf16 in/out, fp32 math."""
+    _chk(x, BF16, "x")
+    n = x.shape[-1]
+    y = torch.empty_like(x)
+    L.check(L.lib().p3v_log_softmax(_p(x), _p(y), x.numel() // n, n, _stream()), "log_softmax")
+    return y
+
+
+def topk(x2d, k):
+    """k largest per row ordered by (-value, index); replaces mx.argpartition (Q9)."""
+    _chk(x2d, BF16, "x")
+    rows, n = x2d.shape
+    out = torch.empty((rows, k), dtype=I32, device=x2d.device)
+    L.check(L.lib().p3v_topk(_p(x2d), _p(out), rows, n, k, n, _stream()), "topk")
+    return out
+
+
+def add_i32(x, delta):
+    L.check(L.lib().p3v_add_i32(_p(x), x.numel(), int(delta), _stream()), "add_i32")
+
+
+def store_token(tok, history, d_step):
+    B, max_steps = history.shape
+    L.check(L.lib().p3v_store_token(_p(tok), _p(history), _p(d_step), B, max_steps, _stream()), "store_token")
+
+
+class Graph:
+    """hipGraph capture/replay of a launch sequence on the current stream."""
+
+    def __init__(self):
+        self.exec = C.c_void_p()
+
+    def begin(self):
+        L.check(L.lib().p3v_graph_begin(_stream()), "graph_begin")
+
+    def end(self):
+        L.check(L.lib().p3v_graph_end(_stream(), C.byref(self.exec)), "graph_end")
+
+    def launch(self):
+        L.check(L.lib().p3v_graph_launch(self.exec, _stream()), "graph_launch")
+
+    def __del__(self):
+        try:
+            if self.exec:
+                L.lib().p3v_graph_destroy(self.exec)
+        except Exception:
+            pass
+
+
+class Event:
+    def __init__(self):
+        self.h = C.c_void_p()
+        L.check(L.lib().p3v_event_create(C.byref(self.h)), "event_create")
+
+    def record(self):
+        L.check(L.lib().p3v_event_record(self.h, _stream()), "event_record")
+
+    def elapsed_ms(self, stop):
+        ms = C.c_float()
+        L.check(L.lib().p3v_event_elapsed_ms(self.h, stop.h, C.byref(ms)), "event_elapsed")
+        return ms.value
+
+    def __del__(self):
+        try:
+            L.lib().p3v_event_destroy(self.h)
+        except Exception:
+            pass
+
+
+def device_props(device=0):
+    p = L.Props()
+    L.check(L.lib().p3v_device_props(device, C.byref(p)), "device_props")
+    return {f: (getattr(p, f).decode() if f == "arch" else getattr(p, f)) for f, _ in L.Props._fields_}

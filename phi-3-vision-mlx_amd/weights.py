@@ -28,8 +28,10 @@ def _hash32(x):
     return x
 
 
-def synth_values(n, seed, std, mean=0.0, device="cpu", dtype=torch.bfloat16, chunk=1 << 24):
+def synth_values(n, seed, std, mean=0.0, device="cpu", dtype=torch.bfloat16, chunk=None):
     """n pseudo-normal values with the given std/mean; deterministic in (seed, index)."""
+    if chunk is None:      # CPU: stay cache-resident (8 MB temporaries); GPU: amortise launches
+        chunk = (1 << 20) if str(device) == "cpu" else (1 << 24)
     out = torch.empty(n, dtype=dtype, device=device)
     base = (int(seed) * 0x9E3779B1) & _M32
     for s in range(0, n, chunk):

@@ -1,0 +1,286 @@
+"""Per-kernel parity: each HIP kernel (called through the C ABI) against the
+oracle's restatement of the same reference op on the same seeded inputs.
+
+Tolerances: bf16 outputs are compared with rtol 2^-7 (one bf16 ulp is 2^-8
+relative) plus a small atol for cancellation; index outputs are exact."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+BF16, F32 = torch.bfloat16, torch.float32
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from phi_3_vision_mlx_amd import ops as o
+    o.L.lib()
+    return o
+
+
+@pytest.fixture(scope="module")
+def orc():
+    import phi3v_oracle
+    return phi3v_oracle
+
+
+def g(shape, seed, std=1.0, dtype=BF16):
+    gen = torch.Generator().manual_seed(seed)
+    return (torch.randn(shape, generator=gen) * std).to(dtype)
+
+
+def close(a, b, rtol=2 ** -7, atol=1e-2):
+    a, b = a.float().cpu(), b.float().cpu()
+    err = (a - b).abs()
+    tol = atol + rtol * b.abs()
+    bad = (err > tol).sum().item()
+    assert bad == 0, f"{bad}/{a.numel()} mismatches; max err {err.max().item():.5f} at |ref| {b.abs().max().item():.3f}"
+
+
+def test_device_props(ops):
+    p = ops.device_props(0)
+    assert p["arch"].startswith("gfx950"), p
+    assert p["wave_size"] == 64 and p["cu_count"] >= 200
+
+
+@pytest.mark.parametrize("n,H", [(1, 3072), (7, 192), (300, 3072)])
+def test_embed_gather(ops, n, H):
+    table = g((1000, H), 1)
+    ids = torch.randint(-5, 1000, (n,), dtype=torch.int32)
+    out = ops.embed_gather(ids.cuda(), table.cuda())
+    ref = table[ids.long().clamp_min(0)]
+    assert torch.equal(out.cpu(), ref)                     # pure copy: bit exact
+
+
+@pytest.mark.parametrize("rows,H", [(1, 3072), (5, 192), (257, 3072)])
+def test_rmsnorm(ops, orc, rows, H):
+    x, w = g((rows, H), 2, 3.0), g((H,), 3, 0.1) + 1
+    out = ops.rmsnorm(x.cuda(), w.cuda(), 1e-5)
+    close(out, orc.rms_norm(x, w, 1e-5), atol=1e-3)
+
+
+@pytest.mark.parametrize("rows,H,f32", [(3, 1024, False), (577, 1024, True), (9, 128, False)])
+def test_layernorm(ops, orc, rows, H, f32):
+    x = g((rows, H), 4, 2.0, F32) + 0.5
+    w, b = g((H,), 5, 0.1) + 1, g((H,), 6, 0.1)
+    out = ops.layernorm(x.cuda(), w.cuda(), b.cuda(), 1e-5, out_f32=f32)
+    ref = orc.layer_norm(x, w, b, 1e-5)
+    if f32:
+        close(out, ref, rtol=1e-5, atol=1e-5)
+    else:
+        close(out, ref.to(BF16), atol=1e-3)
+
+
+EPI_CASES = [
+    ("none", 200, 256, 192), ("none", 128, 128, 64), ("none", 1, 9216, 3072), ("none", 333, 32064, 192),
+    ("bias", 577, 3072, 1024), ("qgelu", 130, 4096, 1024), ("gelu", 77, 3072, 4096),
+    ("resid_f32", 577, 1024, 4096), ("resid_bf16", 300, 3072, 8192), ("silu", 300, 8192, 3072),
+    ("silu", 20, 256, 192), ("f32", 65, 192, 128),
+]
+
+
+@pytest.mark.parametrize("epi,M,N,K", EPI_CASES)
+def test_gemm(ops, epi, M, N, K):
+    a = g((M, K), 10)
+    nw = 2 * N if epi == "silu" else N
+    w = g((nw, K), 11, 1.0 / math.sqrt(K))
+    bias = g((N,), 12, 0.5)
+    af, wf = a.float(), w.float()
+    acc = af @ wf.t()
+    if epi == "none":
+        out, ref = ops.gemm(a.cuda(), w.cuda()), acc.to(BF16)
+    elif epi == "bias":
+        out, ref = ops.gemm(a.cuda(), w.cuda(), ops.EPI_BIAS, bias=bias.cuda()), (acc + bias.float()).to(BF16)
+    elif epi == "qgelu":
+        v = acc + bias.float()
+        out, ref = ops.gemm(a.cuda(), w.cuda(), ops.EPI_BIAS_QGELU, bias=bias.cuda()), (v * torch.sigmoid(1.702 * v)).to(BF16)
+    elif epi == "gelu":
+        v = acc + bias.float()
+        out, ref = ops.gemm(a.cuda(), w.cuda(), ops.EPI_BIAS_GELU, bias=bias.cuda()), torch.nn.functional.gelu(v).to(BF16)
+    elif epi == "resid_f32":
+        r = g((M, N), 13, 1.0, F32)
+        rc = r.cuda()
+        out = ops.gemm(a.cuda(), w.cuda(), ops.EPI_BIAS_RESID_F32, bias=bias.cuda(), resid=rc, out=rc)
+        ref = r + acc + bias.float()
+        close(out, ref, rtol=1e-3, atol=2e-3)
+        return
+    elif epi == "resid_bf16":
+        r = g((M, N), 13)
+        rc = r.cuda()
+        out = ops.gemm(a.cuda(), w.cuda(), ops.EPI_RESID_BF16, resid=rc, out=rc)
+        ref = (r.float() + acc.to(BF16).float()).to(BF16)
+    elif epi == "silu":
+        gate, up = acc[:, :N].to(BF16), acc[:, N:].to(BF16)
+        out, ref = ops.gemm(a.cuda(), w.cuda(), ops.EPI_SILU_MUL), (gate * torch.sigmoid(gate)) * up
+    elif epi == "f32":
+        out = ops.gemm(a.cuda(), w.cuda(), ops.EPI_F32)
+        close(out, acc, rtol=1e-3, atol=2e-3)
+        return
+    close(out, ref, rtol=2 ** -6, atol=2e-2)
+
+
+def test_gemm_asymmetric_identity(ops):
+    """A = I against an asymmetric W: catches a transposed C write (guide rule 16)."""
+    K = 128
+    a = torch.eye(K, dtype=BF16)
+    w = (torch.arange(192 * K, dtype=F32).reshape(192, K) % 251 / 16).to(BF16)
+    out = ops.gemm(a.cuda(), w.cuda())
+    assert torch.equal(out.cpu(), w.t().contiguous())
+
+
+@pytest.mark.parametrize("M,N,K,epi", [(1, 9216, 3072, "none"), (1, 3072, 8192, "resid"), (1, 8192, 3072, "silu"),
+                                       (3, 576, 192, "none"), (8, 3072, 8192, "resid"), (5, 256, 192, "silu"),
+                                       (1, 32064, 3072, "norm"), (8, 9216, 3072, "norm"), (2, 101, 192, "none")])
+def test_gemv(ops, orc, M, N, K, epi):
+    x = g((M, K), 20)
+    nw = 2 * N if epi == "silu" else N
+    w = g((nw, K), 21, 1.0 / math.sqrt(K))
+    acc = x.float() @ w.float().t()
+    if epi == "none":
+        out, ref = ops.gemv(x.cuda(), w.cuda()), acc.to(BF16)
+    elif epi == "resid":
+        r = g((M, N), 22)
+        rc = r.cuda()
+        out = ops.gemv(x.cuda(), w.cuda(), ops.EPI_RESID_BF16, resid=rc, out=rc)
+        ref = (r.float() + acc.to(BF16).float()).to(BF16)
+    elif epi == "silu":
+        gate, up = acc[:, :N].to(BF16), acc[:, N:].to(BF16)
+        out, ref = ops.gemv(x.cuda(), w.cuda(), ops.EPI_SILU_MUL), (gate * torch.sigmoid(gate)) * up
+    elif epi == "norm":
+        nw_ = g((K,), 23, 0.1) + 1
+        out = ops.gemv(x.cuda(), w.cuda(), norm_w=nw_.cuda(), norm_eps=1e-5)
+        ref = (orc.rms_norm(x, nw_, 1e-5).float() @ w.float().t()).to(BF16)
+    close(out, ref, rtol=2 ** -6, atol=2e-2)
+
+
+def test_rope_table_and_append(ops, orc):
+    from phi_3_vision_mlx_amd.config import make_config, rope_scaling_factor
+    cfg = make_config()
+    B, L, T, nh, nkv, hd, past = 2, 5, 40, 4, 4, 96, 7
+    pids = torch.stack([torch.arange(T), torch.cat([torch.ones(3, dtype=torch.long), torch.arange(T - 3)])])
+    cos_ref, sin_ref = orc.su_rope_tables(cfg, T, pids[:, :12])
+    inv = 1.0 / (torch.tensor(cfg.rope_scaling["short_factor"], dtype=F32) * (10000.0 ** (torch.arange(0, hd, 2, dtype=F32) / hd)))
+    cos, sin = ops.rope_table(pids.float().reshape(-1).cuda(), inv.cuda(), rope_scaling_factor(cfg))
+    close(cos.view(B, T, 48), cos_ref[:, 0, :, :48], rtol=1e-5, atol=2e-5)
+    close(sin.view(B, T, 48), sin_ref[:, 0, :, :48], rtol=1e-5, atol=2e-5)
+    qkv = g((B * L, (nh + 2 * nkv) * hd), 30)
+    q = torch.zeros((B, nh, L, hd), dtype=BF16).cuda()
+    kc = torch.zeros((B, nkv, T, hd), dtype=BF16).cuda()
+    vc = torch.zeros_like(kc)
+    ops.rope_kv_append(qkv.cuda(), cos, sin, q, kc, vc, B, L, nh, nkv, hd, past, T, True, T, 1)
+    x = qkv.view(B, L, nh + 2 * nkv, hd).transpose(1, 2)                     # [B, heads, L, hd]
+    cs, sn = cos_ref[:, :, past:past + L], sin_ref[:, :, past:past + L]
+    close(q, orc.rotate_half(x[:, :nh], cs, sn).to(BF16), atol=1e-2)
+    close(kc[:, :, past:past + L], orc.rotate_half(x[:, nh:nh + nkv], cs, sn).to(BF16), atol=1e-2)
+    assert torch.equal(vc[:, :, past:past + L].cpu(), x[:, nh + nkv:].contiguous())
+    assert kc[:, :, :past].abs().sum().item() == 0 and kc[:, :, past + L:].abs().sum().item() == 0
+
+
+def _attn_ref(orc, q, k, v, scale, allowed):
+    w = (q.float() * scale) @ k.float().transpose(-1, -2)
+    return (orc.masked_softmax(w, allowed) @ v.float())
+
+
+@pytest.mark.parametrize("B,L,past,hd,nh,causal,pads", [
+    (1, 130, 0, 96, 2, True, None), (2, 70, 0, 96, 3, True, [0, 9]), (2, 577, 0, 64, 2, False, None),
+    (1, 1, 300, 96, 4, True, None), (3, 1, 77, 96, 2, True, [0, 5, 70]), (2, 6, 130, 96, 2, True, [3, 0]),
+    (1, 16, 64, 96, 2, True, None), (1, 33, 100, 96, 1, True, None)])
+def test_attention(ops, orc, B, L, past, hd, nh, causal, pads):
+    T = past + L
+    q, k, v = g((B, nh, L, hd), 40), g((B, nh, T, hd), 41), g((B, nh, T, hd), 42)
+    pad = torch.tensor(pads if pads else [0] * B, dtype=torch.int32)
+    out = torch.empty((B, L, nh * hd), dtype=BF16).cuda()
+    kc, vc = k.cuda(), v.cuda()
+    n_split, ws = 0, None
+    if L <= 16:
+        n_split = 4
+        ws = torch.empty(ops.attention_ws_bytes(B, L, nh, hd, n_split) // 4, dtype=F32).cuda()
+    ops.attention(q.cuda(), kc[:, :, past:], vc[:, :, past:], out, B, L, nh, nh, hd, hd ** -0.5, causal, new_t=T, past=past,
+                  k_past=kc, v_past=vc, past_t=T, pad_len=pad.cuda() if pads else None, ws=ws, n_split=n_split)
+    t = torch.arange(T)[None, None, None, :]
+    qpos = (past + torch.arange(L))[None, None, :, None]
+    allowed = (t >= pad[:, None, None, None]) & (qpos >= pad[:, None, None, None])
+    if causal:
+        allowed = allowed & (t <= qpos)
+    allowed = allowed.expand(B, 1, L, T)
+    ref = _attn_ref(orc, q, k, v, hd ** -0.5, allowed).transpose(1, 2).reshape(B, L, nh * hd)
+    close(out, ref, rtol=2 ** -6, atol=2e-2)
+
+
+def test_attention_beam_view(ops, orc):
+    """n_beam: keys [0,past) come from cache row b//n_beam, new keys from a scratch (phi.py:523-527)."""
+    Bc, nb, L, past, nh, hd = 2, 3, 4, 50, 2, 96
+    B, T = Bc * nb, 64
+    q = g((B, nh, L, hd), 50)
+    kc, vc = g((Bc, nh, T, hd), 51), g((Bc, nh, T, hd), 52)
+    kn, vn = g((B, nh, L, hd), 53), g((B, nh, L, hd), 54)
+    out = torch.empty((B, L, nh * hd), dtype=BF16).cuda()
+    ws = torch.empty(ops.attention_ws_bytes(B, L, nh, hd, 2) // 4, dtype=F32).cuda()
+    ops.attention(q.cuda(), kn.cuda(), vn.cuda(), out, B, L, nh, nh, hd, hd ** -0.5, True, new_t=L, past=past,
+                  k_past=kc.cuda(), v_past=vc.cuda(), past_t=T, past_div=nb, ws=ws, n_split=2)
+    kf = torch.cat([kc[:, :, :past].repeat_interleave(nb, dim=0), kn], dim=2)
+    vf = torch.cat([vc[:, :, :past].repeat_interleave(nb, dim=0), vn], dim=2)
+    allowed = (torch.arange(past + L)[None, :] <= (past + torch.arange(L))[:, None])[None, None].expand(B, 1, L, past + L)
+    ref = _attn_ref(orc, q, kf, vf, hd ** -0.5, allowed).transpose(1, 2).reshape(B, L, nh * hd)
+    close(out, ref, rtol=2 ** -6, atol=2e-2)
+
+
+def test_im2col_cls_hd_merge(ops, orc):
+    n, D = 3, 128
+    pix = g((n, 3, 336, 336), 60, 1.0, F32)
+    pat = ops.im2col_patches(pix.cuda(), 14, 640)
+    ref = torch.nn.functional.unfold(pix, 14, stride=14).transpose(1, 2).reshape(n * 576, 588)
+    assert torch.equal(pat[:, :588].cpu(), ref.to(BF16)) and pat[:, 588:].abs().sum().item() == 0
+    # HD merge vs the oracle's reshape/transpose/concat (phi.py:403-407)
+    from phi_3_vision_mlx_amd.config import make_config, tiny_config_dict
+    cfg = make_config(tiny_config_dict())
+    C_ = cfg.img_processor["image_dim_out"]
+    for h, w in [(1, 1), (2, 3), (4, 4), (3, 4)]:
+        nc = h * w + 1
+        feats = g((nc, 577, C_), 61, 1.0, F32)
+        sub, glb = g((1, 1, 1, 4 * C_), 62), g((1, 1, 4 * C_), 63)
+        out = ops.hd_merge(feats.cuda(), sub.cuda(), glb.cuda(), h, w, 24, C_)
+        o = orc.OraclePhi3V.__new__(orc.OraclePhi3V)
+        f = feats[:, 1:]                                            # drop CLS
+        def rc(img, shape, tile):
+            t = img.reshape(shape).permute(0, 1, 3, 2, 4, 5).reshape(tile)
+            return torch.cat([t, sub.float().expand(1, tile[1], 1, -1)], dim=2).reshape(1, -1, 4 * C_)
+        g_ = rc(f[:1], (1, 12, 2, 12, 2, C_), (1, 12, 12, 4 * C_))
+        s_ = rc(f[1:], (h * w, 12, 2, 12, 2, C_), (1, h * 12, w * 12, 4 * C_))
+        ref = torch.cat([s_, glb.float(), g_], dim=1)[0]
+        assert out.shape[0] == (h * w + 1) * 144 + 1 + (h + 1) * 12
+        assert torch.equal(out.cpu(), ref.to(BF16))
+
+
+def test_argmax_logsoftmax_topk(ops, orc):
+    x = g((5, 32064), 70, 2.0)
+    x[1, 100] = x[1, 31000] = x[1].float().max() + 1            # tie -> first index
+    x[2, :] = -1.5
+    xc = x.cuda()
+    assert ops.argmax(xc).cpu().tolist() == torch.argmax(x.float(), dim=-1).tolist()
+    assert ops.argmax(xc).cpu().tolist()[1] == 100 and ops.argmax(xc).cpu().tolist()[2] == 0
+    close(ops.log_softmax(xc), orc.log_softmax(x), rtol=2 ** -7, atol=1e-2)
+    tk = ops.topk(xc, 3).cpu()
+    assert tk.tolist() == orc.top3_candidates(x, 3).tolist()
+
+
+def test_graph_replay(ops):
+    """hipGraph capture of a launch sequence replays with updated inputs."""
+    x, w = g((4, 192), 80).cuda(), (g((192,), 81, 0.1) + 1).cuda()
+    y = torch.empty_like(x)
+    ops.rmsnorm(x, w, 1e-5, out=y)
+    torch.cuda.synchronize()
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        gr = ops.Graph()
+        gr.begin()
+        ops.rmsnorm(x, w, 1e-5, out=y)
+        gr.end()
+        x.copy_(g((4, 192), 82))
+        gr.launch()
+    s.synchronize()
+    import phi3v_oracle as orc_
+    close(y, orc_.rms_norm(x.cpu(), w.cpu(), 1e-5), atol=1e-3)
