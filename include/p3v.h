@@ -133,7 +133,9 @@ typedef struct {
   int past, past_t, past_div, new_t, pad_div;
   int causal;
   float scale;
-  int n_split;              /* decode path: KV splits (0 = auto) */
+  int n_split;              /* decode path: KV splits (<=1: no split) */
+  int new_is_cache;         /* 1: (k_new,v_new) ignored, rows [past,past+L) are read from (k_past,v_past) too --
+                               used with d_past, when the append offset is only known on the device */
 } p3v_attn_args_t;
 int p3v_attention(const p3v_attn_args_t* args /* host */, void* stream);
 /* bytes of workspace p3v_attention needs for the decode (L<=P3V_DECODE_MAX_L) path */
@@ -160,7 +162,9 @@ int p3v_topk(const uint16_t* x, int32_t* idx_out, int rows, int n, int k, int64_
 
 /* ---- decode-step helpers (device-resident loop state for graph replay) */
 int p3v_add_i32(int32_t* x, int n, int delta, void* stream);
-int p3v_store_token(const int32_t* tok, int32_t* history, const int32_t* d_step, int B, int max_steps, void* stream);
+/* history[b, *d_step] = tok[b]; if tok_next != NULL also tok_next[b] = tok[b] (feeds the next replayed step) */
+int p3v_store_token(const int32_t* tok, int32_t* history, const int32_t* d_step, int32_t* tok_next,
+                    int B, int max_steps, void* stream);
 
 /* ---- hipGraph helpers: capture a sequence of the launches above and replay it */
 int p3v_graph_begin(void* stream);

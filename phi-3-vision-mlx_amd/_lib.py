@@ -38,7 +38,7 @@ class AttnArgs(C.Structure):
                 ("pad_len", vp), ("d_past", vp), ("ws", vp),
                 ("B", i32), ("L", i32), ("n_heads", i32), ("n_kv", i32), ("hd", i32),
                 ("past", i32), ("past_t", i32), ("past_div", i32), ("new_t", i32), ("pad_div", i32),
-                ("causal", i32), ("scale", f32), ("n_split", i32)]
+                ("causal", i32), ("scale", f32), ("n_split", i32), ("new_is_cache", i32)]
 
 
 # name -> (restype, argtypes); must list every symbol include/p3v.h declares
@@ -62,7 +62,7 @@ SIGNATURES = {
     "p3v_log_softmax": (i32, [vp, vp, i32, i32, vp]),
     "p3v_topk": (i32, [vp, vp, i32, i32, i32, i64, vp]),
     "p3v_add_i32": (i32, [vp, i32, i32, vp]),
-    "p3v_store_token": (i32, [vp, vp, vp, i32, i32, vp]),
+    "p3v_store_token": (i32, [vp, vp, vp, vp, i32, i32, vp]),
     "p3v_graph_begin": (i32, [vp]),
     "p3v_graph_end": (i32, [vp, C.POINTER(vp)]),
     "p3v_graph_launch": (i32, [vp, vp]),

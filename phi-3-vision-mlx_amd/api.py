@@ -269,9 +269,13 @@ def _generate(model, processor, prompt, images=None, max_tokens=512, verbose=Tru
     token = model_ops.argmax(_last_logits(logits))[:, None]
     streamer(token)                                             # D2H copy = the per-token sync the reference has (mx.eval)
     prompt_time = tic()
+    graph_step = getattr(model, "greedy_step", None)        # one hipGraph launch per token (HIP model)
     for i in range(max_tokens - 1):
-        logits, cache = model(input_ids=token, cache=cache, mask=mask, pids=pids)
-        token = model_ops.argmax(_last_logits(logits))[:, None]
+        if graph_step is not None:
+            logits, token = graph_step(token, cache)
+        else:
+            logits, cache = model(input_ids=token, cache=cache, mask=mask, pids=pids)
+            token = model_ops.argmax(_last_logits(logits))[:, None]
         streamer(token)
         if logit_stopper(logits):
             break

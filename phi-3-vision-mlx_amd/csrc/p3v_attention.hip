@@ -22,7 +22,7 @@
 struct AttnP {
   const bf16_t* q; const bf16_t* k_past; const bf16_t* v_past; const bf16_t* k_new; const bf16_t* v_new;
   bf16_t* out; const int32_t* pad_len; const int32_t* d_past; float* ws;
-  int B, L, nh, nkv, past, past_t, past_div, new_t, pad_div, causal, split_mode, n_split;
+  int B, L, nh, nkv, past, past_t, past_div, new_t, pad_div, causal, split_mode, n_split, new_is_cache;
   float scale;
 };
 
@@ -89,8 +89,9 @@ __global__ void __launch_bounds__(256) k_attn(AttnP p) {
       const int key = i / CPR, c = i % CPR, t = kv0 + key;
       u32x4_t kv = {0, 0, 0, 0}, vv = {0, 0, 0, 0};
       if (t < kv_end) {
-        const bf16_t* ks = t < past ? kp_base + (size_t)t * HD : kn_base + (size_t)(t - past) * HD;
-        const bf16_t* vs = t < past ? vp_base + (size_t)t * HD : vn_base + (size_t)(t - past) * HD;
+        const bool from_past = t < past || p.new_is_cache;
+        const bf16_t* ks = from_past ? kp_base + (size_t)t * HD : kn_base + (size_t)(t - past) * HD;
+        const bf16_t* vs = from_past ? vp_base + (size_t)t * HD : vn_base + (size_t)(t - past) * HD;
         kv = *(const u32x4_t*)(ks + c * 8);
         vv = *(const u32x4_t*)(vs + c * 8);
       }
@@ -214,14 +215,16 @@ extern "C" int64_t p3v_attention_ws_bytes(int B, int L, int n_heads, int hd, int
 }
 
 extern "C" int p3v_attention(const p3v_attn_args_t* a, void* stream) {
-  if (!a || !a->q || !a->k_new || !a->v_new || !a->out) return P3V_ERR_ARG;
+  if (!a || !a->q || !a->out) return P3V_ERR_ARG;
+  if (a->new_is_cache ? (!a->k_past || !a->v_past) : (!a->k_new || !a->v_new)) return P3V_ERR_ARG;
   if (a->hd != 64 && a->hd != 96) return P3V_ERR_UNSUPPORTED;
   if (a->B < 0 || a->L < 0 || a->n_heads <= 0 || a->n_kv <= 0 || a->n_heads % a->n_kv) return P3V_ERR_ARG;
   if ((a->past > 0 || a->d_past) && (!a->k_past || !a->v_past)) return P3V_ERR_ARG;
   if (a->B * a->L == 0) return P3V_OK;
   AttnP p;
   p.q = a->q; p.k_past = a->k_past ? a->k_past : a->k_new; p.v_past = a->v_past ? a->v_past : a->v_new;
-  p.k_new = a->k_new; p.v_new = a->v_new; p.out = a->out; p.pad_len = a->pad_len; p.d_past = a->d_past; p.ws = a->ws;
+  p.k_new = a->new_is_cache ? a->k_past : a->k_new; p.v_new = a->new_is_cache ? a->v_past : a->v_new; p.new_is_cache = a->new_is_cache;
+  p.out = a->out; p.pad_len = a->pad_len; p.d_past = a->d_past; p.ws = a->ws;
   p.B = a->B; p.L = a->L; p.nh = a->n_heads; p.nkv = a->n_kv; p.past = a->past; p.past_t = a->past_t;
   p.past_div = a->past_div > 0 ? a->past_div : 1; p.new_t = a->new_t; p.pad_div = a->pad_div > 0 ? a->pad_div : 1;
   p.causal = a->causal; p.scale = a->scale;

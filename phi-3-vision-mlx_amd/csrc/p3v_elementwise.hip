@@ -406,16 +406,20 @@ extern "C" int p3v_add_i32(int32_t* x, int n, int delta, void* stream) {
   return P3V_OK;
 }
 
-__global__ void k_store_token(const int32_t* tok, int32_t* hist, const int32_t* d_step, int B, int max_steps) {
+__global__ void k_store_token(const int32_t* tok, int32_t* hist, const int32_t* d_step, int32_t* tok_next, int B,
+                              int max_steps) {
   const int b = threadIdx.x;
   const int s = *d_step;
-  if (b < B && s < max_steps) hist[(size_t)b * max_steps + s] = tok[b];
+  if (b >= B) return;
+  const int t = tok[b];
+  if (s < max_steps) hist[(size_t)b * max_steps + s] = t;
+  if (tok_next) tok_next[b] = t;
 }
-extern "C" int p3v_store_token(const int32_t* tok, int32_t* history, const int32_t* d_step, int B, int max_steps,
-                               void* stream) {
+extern "C" int p3v_store_token(const int32_t* tok, int32_t* history, const int32_t* d_step, int32_t* tok_next, int B,
+                               int max_steps, void* stream) {
   if (!tok || !history || !d_step || B <= 0 || B > 1024) return P3V_ERR_ARG;
-  hipLaunchKernelGGL(k_store_token, dim3(1), dim3(p3v_cdiv(B, 64) * 64), 0, (hipStream_t)stream, tok, history, d_step, B,
-                     max_steps);
+  hipLaunchKernelGGL(k_store_token, dim3(1), dim3(p3v_cdiv(B, 64) * 64), 0, (hipStream_t)stream, tok, history, d_step,
+                     tok_next, B, max_steps);
   P3V_CHECK_LAUNCH();
   return P3V_OK;
 }

@@ -11,8 +11,11 @@
 //             (XOR swizzle applied on the per-lane SOURCE address because the
 //             DMA destination is lane-linear; the same XOR on the ds_read_b128
 //             side) -> conflict-free fragment reads
-//   epilogue  runtime switch (bias / quick-GELU / erf-GELU / residual / SiLU*up /
-//             patch-embed row remap), fp32 math, bf16 or fp32 stores
+//   epilogue  compile-time variant (bias / quick-GELU / erf-GELU / residual /
+//             SiLU*up / patch-embed row remap).  The accumulators go through a
+//             wave-private LDS tile so that every lane loads/stores 8 consecutive
+//             columns: 16-byte bf16 stores, full 128-byte lines per 8 lanes
+//             (the MFMA C layout itself would give 2-byte stores at a row stride).
 //
 // Roofline: MFMA-bound for M >= ~512 (2*M*N*K flops vs (M+N)*K*2 bytes).
 #include "p3v_common.h"
@@ -21,19 +24,34 @@
 #define BN 128
 #define BK 64
 #define TILE_BYTES (BM * BK * 2)   // 16 KiB per operand tile
+#define CT_LD 68                   // fp32 row stride of the wave's 64x64 epilogue tile (2-way write conflicts only)
+#define GEMM_LDS (4 * 64 * CT_LD * 4)   // 69632 B >= 4 * TILE_BYTES
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
 struct GemmP {
   const bf16_t* A; const bf16_t* W; void* out; const bf16_t* bias; const void* resid; const bf16_t* pos;
-  int M, N, K, lda, ldw, ldo, epi, ppi, n_wrows;
+  int M, N, K, lda, ldw, ldo, ppi;
 };
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
 
-template <bool SILU>
+__device__ __forceinline__ void load8_bf16(const bf16_t* p, float* v) {
+  const u32x4_t w = *(const u32x4_t*)p;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { v[2 * j] = bf16lo(w[j]); v[2 * j + 1] = bf16hi(w[j]); }
+}
+__device__ __forceinline__ void store8_bf16(bf16_t* p, const float* v) {
+  u32x4_t w;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) w[j] = pack_bf16x2(v[2 * j], v[2 * j + 1]);
+  *(u32x4_t*)p = w;
+}
+
+template <int EPI>
 __global__ void __launch_bounds__(256, 2) k_gemm(GemmP p) {
+  constexpr bool SILU = EPI == P3V_EPI_SILU_MUL;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
@@ -112,73 +130,133 @@ __global__ void __launch_bounds__(256, 2) k_gemm(GemmP p) {
     }
   }
 
-  // ---- epilogue.  C layout of the 16x16 tile: col = lane&15, row = (lane>>4)*4 + r
-  const int ccol = lane & 15, crow = (lane >> 4) * 4;
+  // ---- epilogue: MFMA C layout (col = lane&15, row = (lane>>4)*4 + r) -> wave-private LDS tile -> rows of 8 columns
+  __syncthreads();                                            // every wave is done with the staging buffers
+  float* ct = (float*)smem + wave * (64 * CT_LD);
+  {
+    const int ccol = lane & 15, crow = (lane >> 4) * 4;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int m = m0 + wr * 64 + i * 16 + crow + r;
-      if (m >= p.M) continue;
-      if (SILU) {
+      for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const int n = n0 + wc * 32 + j * 16 + ccol;
-          if (n >= p.N) continue;
-          // reference rounds gate/up to bf16 (Linear output) before silu*up (phi.py:469-471)
-          const float g = bf16_round(acc[i][j][r]), u = bf16_round(acc[i][j + 2][r]);
-          const float s = bf16_round(g * bf16_round(1.f / (1.f + __expf(-g))));
-          ((bf16_t*)p.out)[(size_t)m * p.ldo + n] = f32_to_bf16(s * u);
+        for (int r = 0; r < 4; ++r) ct[(i * 16 + crow + r) * CT_LD + j * 16 + ccol] = acc[i][j][r];
+  }
+  __syncthreads();
+
+  if (SILU) {
+    // wave tile columns: [0,32) gate, [32,64) up for output columns n0 + wc*32 + [0,32)
+    const int c8 = (lane & 3) * 8;
+    const int n = n0 + wc * 32 + c8;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int row = it * 16 + (lane >> 2);
+      const int m = m0 + wr * 64 + row;
+      if (m < p.M && n < p.N) {
+        const float4 g0 = *(const float4*)(ct + row * CT_LD + c8), g1 = *(const float4*)(ct + row * CT_LD + c8 + 4);
+        const float4 u0 = *(const float4*)(ct + row * CT_LD + 32 + c8), u1 = *(const float4*)(ct + row * CT_LD + 36 + c8);
+        const float gs[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+        const float us[8] = {u0.x, u0.y, u0.z, u0.w, u1.x, u1.y, u1.z, u1.w};
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          // reference rounds gate/up to bf16 (Linear output) and every elementwise op after it (phi.py:469-471)
+          const float g = bf16_round(gs[e]), u = bf16_round(us[e]);
+          o[e] = bf16_round(g * bf16_round(1.f / (1.f + __expf(-g)))) * u;
         }
-        continue;
+        store8_bf16((bf16_t*)p.out + (size_t)m * p.ldo + n, o);
       }
+    }
+    return;
+  }
+
+  const int c8 = (lane & 7) * 8;
+  const int n = n0 + wc * 64 + c8;
+  float bias[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const bool ncol_ok = n < p.N;
+  if (ncol_ok && p.bias) load8_bf16(p.bias + n, bias);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int n = n0 + wc * 64 + j * 16 + ccol;
-        if (n >= p.N) continue;
-        float v = acc[i][j][r];
-        if (p.bias) v += bf16_to_f32(p.bias[n]);
-        const size_t o = (size_t)m * p.ldo + n;
-        switch (p.epi) {
-          case P3V_EPI_NONE:
-          case P3V_EPI_BIAS: ((bf16_t*)p.out)[o] = f32_to_bf16(v); break;
-          case P3V_EPI_BIAS_QGELU: ((bf16_t*)p.out)[o] = f32_to_bf16(v / (1.f + __expf(-1.702f * v))); break;
-          case P3V_EPI_BIAS_GELU: ((bf16_t*)p.out)[o] = f32_to_bf16(gelu_erf(v)); break;
-          case P3V_EPI_BIAS_RESID_F32: ((float*)p.out)[o] = ((const float*)p.resid)[o] + v; break;
-          case P3V_EPI_RESID_BF16:
-            ((bf16_t*)p.out)[o] = f32_to_bf16(bf16_to_f32(((const bf16_t*)p.resid)[o]) + bf16_round(v));
-            break;
-          case P3V_EPI_F32: ((float*)p.out)[o] = v; break;
-          case P3V_EPI_PATCH: {
-            const int img = m / p.ppi, pi = m % p.ppi;
-            ((float*)p.out)[((size_t)img * (p.ppi + 1) + 1 + pi) * p.ldo + n] =
-                v + bf16_to_f32(p.pos[(size_t)(1 + pi) * p.N + n]);
-          } break;
+  for (int it = 0; it < 8; ++it) {
+    const int row = it * 8 + (lane >> 3);
+    const int m = m0 + wr * 64 + row;
+    if (m < p.M && ncol_ok) {
+      const float4 a0 = *(const float4*)(ct + row * CT_LD + c8), a1 = *(const float4*)(ct + row * CT_LD + c8 + 4);
+      float v[8] = {a0.x + bias[0], a0.y + bias[1], a0.z + bias[2], a0.w + bias[3],
+                    a1.x + bias[4], a1.y + bias[5], a1.z + bias[6], a1.w + bias[7]};
+      const size_t o = (size_t)m * p.ldo + n;
+      if (EPI == P3V_EPI_NONE || EPI == P3V_EPI_BIAS) {
+        store8_bf16((bf16_t*)p.out + o, v);
+      } else if (EPI == P3V_EPI_BIAS_QGELU) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = v[e] / (1.f + __expf(-1.702f * v[e]));
+        store8_bf16((bf16_t*)p.out + o, v);
+      } else if (EPI == P3V_EPI_BIAS_GELU) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = gelu_erf(v[e]);
+        store8_bf16((bf16_t*)p.out + o, v);
+      } else if (EPI == P3V_EPI_RESID_BF16) {
+        float r[8];
+        load8_bf16((const bf16_t*)p.resid + o, r);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = r[e] + bf16_round(v[e]);
+        store8_bf16((bf16_t*)p.out + o, v);
+      } else if (EPI == P3V_EPI_BIAS_RESID_F32 || EPI == P3V_EPI_F32 || EPI == P3V_EPI_PATCH) {
+        size_t oo = o;
+        if (EPI == P3V_EPI_BIAS_RESID_F32) {
+          const float4 r0 = *(const float4*)((const float*)p.resid + o), r1 = *(const float4*)((const float*)p.resid + o + 4);
+          v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w; v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
+        } else if (EPI == P3V_EPI_PATCH) {
+          const int img = m / p.ppi, pi = m % p.ppi;
+          float pe[8];
+          load8_bf16(p.pos + (size_t)(1 + pi) * p.N + n, pe);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += pe[e];
+          oo = ((size_t)img * (p.ppi + 1) + 1 + pi) * p.ldo + n;
         }
+        *(float4*)((float*)p.out + oo) = make_float4(v[0], v[1], v[2], v[3]);
+        *(float4*)((float*)p.out + oo + 4) = make_float4(v[4], v[5], v[6], v[7]);
       }
     }
   }
 }
 
-extern "C" int p3v_gemm(const p3v_gemm_args_t* a, void* stream) {
-  if (!a || !a->A || !a->W || !a->out) return P3V_ERR_ARG;
-  if (a->M < 0 || a->N <= 0 || a->K <= 0 || a->K % BK) return P3V_ERR_ARG;
-  if (a->lda < a->K || a->ldw < a->K || a->lda % 8 || a->ldw % 8) return P3V_ERR_ARG;
-  if (((uintptr_t)a->A | (uintptr_t)a->W) & 15) return P3V_ERR_ARG;
-  if ((a->epilogue == P3V_EPI_BIAS_RESID_F32 || a->epilogue == P3V_EPI_RESID_BF16) && !a->resid) return P3V_ERR_ARG;
-  if (a->epilogue == P3V_EPI_PATCH && (!a->pos || a->patches_per_img <= 0)) return P3V_ERR_ARG;
-  if (a->epilogue < 0 || a->epilogue > P3V_EPI_F32) return P3V_ERR_ARG;
-  if (a->M == 0) return P3V_OK;
-  GemmP p = {a->A, a->W, a->out, a->bias, a->resid, a->pos, a->M, a->N, a->K, a->lda, a->ldw, a->ldo,
-             a->epilogue, a->patches_per_img, 0};
-  const size_t lds = 4 * TILE_BYTES;
-  if (a->epilogue == P3V_EPI_SILU_MUL) {
-    dim3 grid(p3v_cdiv(a->N, BN / 2), p3v_cdiv(a->M, BM));
-    hipLaunchKernelGGL(k_gemm<true>, grid, dim3(256), lds, (hipStream_t)stream, p);
-  } else {
-    dim3 grid(p3v_cdiv(a->N, BN), p3v_cdiv(a->M, BM));
-    hipLaunchKernelGGL(k_gemm<false>, grid, dim3(256), lds, (hipStream_t)stream, p);
+template <int EPI>
+static int launch_gemm(const GemmP& p, hipStream_t s) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)k_gemm<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS) != hipSuccess)
+      return P3V_ERR_HIP;
+    attr_set = true;
   }
+  const int n_tile = EPI == P3V_EPI_SILU_MUL ? BN / 2 : BN;
+  dim3 grid(p3v_cdiv(p.N, n_tile), p3v_cdiv(p.M, BM));
+  hipLaunchKernelGGL(k_gemm<EPI>, grid, dim3(256), GEMM_LDS, s, p);
   P3V_CHECK_LAUNCH();
   return P3V_OK;
+}
+
+extern "C" int p3v_gemm(const p3v_gemm_args_t* a, void* stream) {
+  if (!a || !a->A || !a->W || !a->out) return P3V_ERR_ARG;
+  if (a->M < 0 || a->N <= 0 || a->K <= 0 || a->K % BK || a->N % 8 || a->ldo % 8) return P3V_ERR_ARG;
+  if (a->lda < a->K || a->ldw < a->K || a->lda % 8 || a->ldw % 8) return P3V_ERR_ARG;
+  if (((uintptr_t)a->A | (uintptr_t)a->W | (uintptr_t)a->out | (uintptr_t)a->resid | (uintptr_t)a->bias | (uintptr_t)a->pos) & 15)
+    return P3V_ERR_ARG;
+  if ((a->epilogue == P3V_EPI_BIAS_RESID_F32 || a->epilogue == P3V_EPI_RESID_BF16) && !a->resid) return P3V_ERR_ARG;
+  if (a->epilogue == P3V_EPI_PATCH && (!a->pos || a->patches_per_img <= 0)) return P3V_ERR_ARG;
+  if (a->M == 0) return P3V_OK;
+  const GemmP p = {a->A, a->W, a->out, a->bias, a->resid, a->pos, a->M, a->N, a->K, a->lda, a->ldw, a->ldo,
+                   a->patches_per_img};
+  hipStream_t s = (hipStream_t)stream;
+  switch (a->epilogue) {
+    case P3V_EPI_NONE: return launch_gemm<P3V_EPI_NONE>(p, s);
+    case P3V_EPI_BIAS: return launch_gemm<P3V_EPI_BIAS>(p, s);
+    case P3V_EPI_BIAS_QGELU: return launch_gemm<P3V_EPI_BIAS_QGELU>(p, s);
+    case P3V_EPI_BIAS_GELU: return launch_gemm<P3V_EPI_BIAS_GELU>(p, s);
+    case P3V_EPI_BIAS_RESID_F32: return launch_gemm<P3V_EPI_BIAS_RESID_F32>(p, s);
+    case P3V_EPI_RESID_BF16: return launch_gemm<P3V_EPI_RESID_BF16>(p, s);
+    case P3V_EPI_SILU_MUL: return launch_gemm<P3V_EPI_SILU_MUL>(p, s);
+    case P3V_EPI_PATCH: return launch_gemm<P3V_EPI_PATCH>(p, s);
+    case P3V_EPI_F32: return launch_gemm<P3V_EPI_F32>(p, s);
+    default: return P3V_ERR_ARG;
+  }
 }

@@ -182,48 +182,131 @@ class Phi3VModel:
         return st
 
     # ------------------------------------------------------------------ decoder stack
-    def _layers(self, x, st, B, L, past, n_beam):
+    def _alloc_bufs(self, B, L):
+        cfg = self.cfg
+        nh, nkv, hd, H, I = cfg.num_attention_heads, cfg.num_key_value_heads, self.hd, cfg.hidden_size, cfg.intermediate_size
+        M, dev = B * L, self.device
+        bufs = dict(
+            q=torch.empty((B, nh, L, hd), dtype=BF16, device=dev), o=torch.empty((M, nh * hd), dtype=BF16, device=dev),
+            qkv=torch.empty((M, (nh + 2 * nkv) * hd), dtype=BF16, device=dev), a=torch.empty((M, I), dtype=BF16, device=dev),
+            h=torch.empty((M, H), dtype=BF16, device=dev) if M > 8 else None, n_split=0, ws=None)
+        return bufs
+
+    def _split_plan(self, bufs, B, L, T):
+        """Split-KV plan for the decode-shaped attention (L <= 16): enough blocks to fill 256 CUs."""
+        nh, hd = self.cfg.num_attention_heads, self.hd
+        if L <= ops.L.DECODE_MAX_L:
+            n_split = max(1, min(64, -(-T // 128), -(-768 // max(1, B * nh))))
+            if n_split > 1:
+                bufs["n_split"] = n_split
+                bufs["ws"] = torch.empty(ops.attention_ws_bytes(B, L, nh, hd, n_split) // 4, dtype=F32, device=self.device)
+
+    def _layers(self, x, st, B, L, past, n_beam, bufs=None, d_past=None):
+        """Phi3DecoderLayer stack (phi.py:473-485).  `d_past` (device int32) makes every
+        position-dependent kernel read the cache length from HBM -> graph-replayable."""
         cfg, w = self.cfg, self.w
         nh, nkv, hd, eps = cfg.num_attention_heads, cfg.num_key_value_heads, self.hd, cfg.rms_norm_eps
         M = B * L
         scale = hd ** -0.5
-        q = torch.empty((B, nh, L, hd), dtype=BF16, device=self.device)
-        o = torch.empty((M, nh * hd), dtype=BF16, device=self.device)
-        Bc = B // n_beam
+        if bufs is None:
+            bufs = self._alloc_bufs(B, L)
+            self._split_plan(bufs, B, L, past + L)
+        q, o, qkv, a, h, n_split, ws = (bufs[k] for k in ("q", "o", "qkv", "a", "h", "n_split", "ws"))
         if n_beam > 1:                                          # beams: K/V of this call go to a scratch, cache is read-only
             k_new = torch.empty((B, nkv, L, hd), dtype=BF16, device=self.device)
             v_new = torch.empty_like(k_new)
-        n_split, ws = 0, None
-        if L <= ops.L.DECODE_MAX_L:
-            n_split = max(1, min(64, 1024 // max(1, B * nh)))
-            if n_split > 1:
-                ws = torch.empty(ops.attention_ws_bytes(B, L, nh, hd, n_split) // 4, dtype=F32, device=self.device)
         for i in range(cfg.num_hidden_layers):
             p = f"model.layers.{i}."
             if M <= 8:
-                qkv = ops.gemv(x, w[p + "self_attn.qkv_proj.weight"], norm_w=w[p + "input_layernorm.weight"], norm_eps=eps)
+                ops.gemv(x, w[p + "self_attn.qkv_proj.weight"], norm_w=w[p + "input_layernorm.weight"], norm_eps=eps, out=qkv)
             else:
-                h = ops.rmsnorm(x, w[p + "input_layernorm.weight"], eps)
-                qkv = ops.gemm(h, w[p + "self_attn.qkv_proj.weight"])
+                ops.rmsnorm(x, w[p + "input_layernorm.weight"], eps, out=h)
+                ops.gemm(h, w[p + "self_attn.qkv_proj.weight"], out=qkv)
             if n_beam > 1:
                 ops.rope_kv_append(qkv, st.cos, st.sin, q, k_new, v_new, B, L, nh, nkv, hd, past, L, False, st.T, n_beam)
                 ops.attention(q, k_new, v_new, o, B, L, nh, nkv, hd, scale, True, new_t=L, past=past, k_past=st.k[i],
                               v_past=st.v[i], past_t=st.T, past_div=n_beam, pad_len=st.pad_len, pad_div=n_beam, ws=ws,
                               n_split=n_split)
+            elif d_past is not None:                            # graph path: new rows are addressed through the cache itself
+                ops.rope_kv_append(qkv, st.cos, st.sin, q, st.k[i], st.v[i], B, L, nh, nkv, hd, 0, st.T, True, st.T, 1, d_past=d_past)
+                ops.attention(q, st.k[i], st.v[i], o, B, L, nh, nkv, hd, scale, True, new_t=st.T, past=0, k_past=st.k[i],
+                              v_past=st.v[i], past_t=st.T, pad_len=st.pad_len, ws=ws, n_split=n_split, d_past=d_past,
+                              new_is_cache=True)
             else:
                 ops.rope_kv_append(qkv, st.cos, st.sin, q, st.k[i], st.v[i], B, L, nh, nkv, hd, past, st.T, True, st.T, 1)
                 kn, vn = st.k[i][:, :, past:], st.v[i][:, :, past:]          # views: same strides, offset by `past` rows
                 ops.attention(q, kn, vn, o, B, L, nh, nkv, hd, scale, True, new_t=st.T, past=past, k_past=st.k[i],
                               v_past=st.v[i], past_t=st.T, pad_len=st.pad_len, ws=ws, n_split=n_split)
-            x = ops.linear(o, w[p + "self_attn.o_proj.weight"], EPI_RESID_BF16, resid=x, out=x)
+            ops.linear(o, w[p + "self_attn.o_proj.weight"], EPI_RESID_BF16, resid=x, out=x)
             if M <= 8:
-                a = ops.gemv(x, w[p + "mlp.gate_up_proj.weight"], EPI_SILU_MUL, norm_w=w[p + "post_attention_layernorm.weight"],
-                             norm_eps=eps)
+                ops.gemv(x, w[p + "mlp.gate_up_proj.weight"], EPI_SILU_MUL, norm_w=w[p + "post_attention_layernorm.weight"],
+                         norm_eps=eps, out=a)
             else:
-                h = ops.rmsnorm(x, w[p + "post_attention_layernorm.weight"], eps)
-                a = ops.gemm(h, w[p + "mlp.gate_up_proj.weight"], EPI_SILU_MUL)
-            x = ops.linear(a, w[p + "mlp.down_proj.weight"], EPI_RESID_BF16, resid=x, out=x)
+                ops.rmsnorm(x, w[p + "post_attention_layernorm.weight"], eps, out=h)
+                ops.gemm(h, w[p + "mlp.gate_up_proj.weight"], EPI_SILU_MUL, out=a)
+            ops.linear(a, w[p + "mlp.down_proj.weight"], EPI_RESID_BF16, resid=x, out=x)
         return x
+
+    # ------------------------------------------------------------------ graph-replayed greedy decode step
+    def _build_decode_graph(self, st):
+        """Capture ONE greedy decode step (embed -> 32 layers -> norm+lm_head -> argmax ->
+        bookkeeping) as a hipGraph.  All loop state lives in HBM: `tok` (next input ids),
+        `d_past` (cache length), `d_step`, `history` -- so replays need no host input and
+        a token costs one graph launch instead of ~170 kernel launches."""
+        cfg, w, B, dev = self.cfg, self.w, st.B, self.device
+        g = dict(tok=torch.zeros((B,), dtype=I32, device=dev), d_past=torch.zeros((1,), dtype=I32, device=dev),
+                 d_step=torch.zeros((1,), dtype=I32, device=dev),
+                 history=torch.zeros((B, max(1, st.max_tokens) + 1), dtype=I32, device=dev),
+                 x=torch.empty((B, cfg.hidden_size), dtype=BF16, device=dev),
+                 logits=torch.empty((B, cfg.vocab_size), dtype=BF16, device=dev),
+                 next_tok=torch.zeros((B,), dtype=I32, device=dev))
+        bufs = self._alloc_bufs(B, 1)
+        self._split_plan(bufs, B, 1, st.T)
+        g["bufs"] = bufs
+
+        def step():
+            ops.embed_gather(g["tok"], w["model.embed_tokens.weight"], out=g["x"])
+            self._layers(g["x"], st, B, 1, 0, 1, bufs=bufs, d_past=g["d_past"])
+            ops.gemv(g["x"], w["lm_head.weight"], norm_w=w["model.norm.weight"], norm_eps=cfg.rms_norm_eps, out=g["logits"])
+            ops.argmax(g["logits"], out=g["next_tok"])
+            ops.store_token(g["next_tok"], g["history"], g["d_step"], g["tok"])
+            ops.add_i32(g["d_past"], 1)
+            ops.add_i32(g["d_step"], 1)
+        g["d_past"].fill_(st.offset)
+        step()                                                   # warm-up run (sets func attributes, pages code in)
+        torch.cuda.synchronize()
+        graph = ops.Graph()
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            graph.begin()
+            step()
+            graph.end()
+        torch.cuda.current_stream().wait_stream(side)
+        g["d_step"].zero_()                                      # the warm-up run above counted as a step
+        g["graph"] = graph
+        return g
+
+    def greedy_step(self, token, cache):
+        """One greedy decode step through the captured graph.  Equivalent to
+        `logits, cache = model(input_ids=token, cache=cache); next = argmax(logits[:, -1])`
+        (reference phi_3_vision_mlx.py:391-392).  Returns (logits [B,1,V], next_token [B,1])
+        -- views of persistent buffers, valid until the next call."""
+        st = cache[0].state
+        if st.offset + 1 > st.T:
+            raise ValueError(f"KV cache overflow: {st.offset}+1 > {st.T} (prompt + max_tokens)")
+        g = st.graphs.get("greedy")
+        if g is None:
+            g = st.graphs["greedy"] = self._build_decode_graph(st)
+            g["host_tok"] = None
+        if g["host_tok"] is None or token is not g["host_tok"]:
+            g["tok"].copy_(token.reshape(-1).to(self.device, I32))   # first step / caller-chosen token
+        g["d_past"].fill_(st.offset) if g.get("synced_offset") != st.offset else None
+        g["graph"].launch()
+        st.offset += 1
+        g["synced_offset"] = st.offset
+        g["host_tok"] = g["next_tok"].view(-1, 1)
+        return g["logits"].view(st.B, 1, -1), g["host_tok"]
 
     def __call__(self, input_ids, pixel_values=None, image_sizes=None, positions=None, cache=None, pids=None, mask=None,
                  max_tokens=0, advance_offset=None, n_beam=1, full_logits=None):

@@ -115,10 +115,10 @@ def rope_kv_append(qkv, cos_t, sin_t, q_out, k_dst, v_dst, B, Lq, nh, nkv, hd, p
 
 
 def attention(q, k_new, v_new, out, B, Lq, nh, nkv, hd, scale, causal, new_t, past=0, k_past=None, v_past=None, past_t=0,
-              past_div=1, pad_len=None, pad_div=1, d_past=None, ws=None, n_split=0):
+              past_div=1, pad_len=None, pad_div=1, d_past=None, ws=None, n_split=0, new_is_cache=False):
     """softmax((q*scale) k^T + mask) v (phi.py:454-457 / phi.py:148), mask never materialised."""
     args = L.AttnArgs(_p(q), _p(k_past), _p(v_past), _p(k_new), _p(v_new), _p(out), _p(pad_len), _p(d_past), _p(ws),
-                      B, Lq, nh, nkv, hd, int(past), past_t, past_div, new_t, pad_div, int(causal), float(scale), n_split)
+                      B, Lq, nh, nkv, hd, int(past), past_t, past_div, new_t, pad_div, int(causal), float(scale), n_split, int(new_is_cache))
     L.check(L.lib().p3v_attention(C.byref(args), _stream()), "attention")
     return out
 
@@ -181,9 +181,9 @@ def add_i32(x, delta):
     L.check(L.lib().p3v_add_i32(_p(x), x.numel(), int(delta), _stream()), "add_i32")
 
 
-def store_token(tok, history, d_step):
+def store_token(tok, history, d_step, tok_next=None):
     B, max_steps = history.shape
-    L.check(L.lib().p3v_store_token(_p(tok), _p(history), _p(d_step), B, max_steps, _stream()), "store_token")
+    L.check(L.lib().p3v_store_token(_p(tok), _p(history), _p(d_step), _p(tok_next), B, max_steps, _stream()), "store_token")
 
 
 class Graph:

@@ -2,7 +2,7 @@
 CPU oracle on the same seeded weights and inputs.
 
 Tolerance on bf16 logits: |diff| <= ATOL + RTOL*|ref| with RTOL = 2e-2,
-ATOL = 2e-2*max|ref| is asserted on >= 99.9 % of entries and 4x that on all of
+ATOL = 1.25e-2*max|ref| is asserted on >= 99.9 % of entries and 4x that on all of
 them; greedy tokens are asserted exact wherever the oracle's top-2 margin
 exceeds 4*ATOL."""
 import numpy as np
@@ -34,7 +34,7 @@ def vis():
 def assert_logits(got, ref, what=""):
     got, ref = got.float().cpu(), ref.float().cpu()
     assert got.shape == ref.shape, (got.shape, ref.shape)
-    atol = 2e-2 * ref.abs().max().item()
+    atol = 1.25e-2 * ref.abs().max().item()
     err = (got - ref).abs()
     tol = atol + 2e-2 * ref.abs()
     frac_bad = (err > tol).float().mean().item()
@@ -62,7 +62,7 @@ def test_prefill_all_positions(text):
     got, _ = model(input_ids=ids, max_tokens=4, full_logits=True)
     ref, _ = oracle(input_ids=ids, max_tokens=4)
     atol = assert_logits(got, ref, "prefill")
-    assert assert_tokens_where_confident(got, ref, atol) > 0.3
+    assert assert_tokens_where_confident(got, ref, atol) > 0.1
 
 
 def test_prefill_last_only_and_decode_teacher_forced(text):
@@ -90,6 +90,31 @@ def test_decode_equals_prefill_property(text):
     b, _ = model(input_ids=ids[:, 64:], cache=cache)
     c, _ = model(input_ids=ids, max_tokens=1)
     assert_logits(b[:, -1], c[:, -1], "decode vs prefill")
+
+
+def test_graph_replayed_greedy_step_equals_eager(text):
+    """The hipGraph decode step (device-resident token/offset state) is bit-identical to the eager path."""
+    model, proc, _ = text
+    from phi_3_vision_mlx_amd import ops
+    for inputs in (dict(input_ids=rand_ids(40, 7)), proc(["short", "a somewhat longer prompt here"])):
+        n = 9
+        lg, cache = model(**inputs, max_tokens=n)
+        tok = ops.argmax(lg[:, -1, :].contiguous())[:, None]
+        eager_tok, eager_lg, t = [], [], tok
+        for _ in range(n - 1):
+            lg, cache = model(input_ids=t, cache=cache, mask=inputs.get("mask"), pids=inputs.get("pids"))
+            t = ops.argmax(lg[:, -1, :].contiguous())[:, None]
+            eager_tok.append(t.cpu()), eager_lg.append(lg[:, -1].cpu())
+        lg, cache2 = model(**inputs, max_tokens=n)
+        t = ops.argmax(lg[:, -1, :].contiguous())[:, None]
+        assert torch.equal(t.cpu(), tok.cpu())
+        for i in range(n - 1):
+            lg, t = model.greedy_step(t, cache2)
+            assert torch.equal(lg[:, -1].cpu(), eager_lg[i]), f"step {i}"
+            assert torch.equal(t.cpu(), eager_tok[i])
+        assert cache2[0].offset == cache[0].offset
+        hist = cache2[0].state.graphs["greedy"]["history"][:, :n - 1].cpu()
+        assert torch.equal(hist, torch.cat(eager_tok, dim=1).to(hist.dtype))
 
 
 def test_batched_left_pad(text):

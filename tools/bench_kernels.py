@@ -1,0 +1,68 @@
+"""Per-shape micro-benchmark of the projection kernels (run on the GPU box):
+HIP-event timing over rotating operand copies (so the 256 MiB Infinity Cache cannot hold them)."""
+import sys, os, math
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from phi_3_vision_mlx_amd import ops
+
+def timeit(fn, n_rot, iters=20):
+    for i in range(3): fn(i % n_rot)
+    torch.cuda.synchronize()
+    a, b = ops.Event(), ops.Event()
+    a.record()
+    for i in range(iters): fn(i % n_rot)
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_ms(b) / iters
+
+def gemm_case(name, M, N, K, epi, f32res=False):
+    nrot = max(2, int(600e6 // (N * K * 2 * (2 if epi == ops.EPI_SILU_MUL else 1))) + 1)
+    nrot = min(nrot, 8)
+    A = torch.randn(M, K, device="cuda").bfloat16()
+    Ws = [torch.randn((2 * N if epi == ops.EPI_SILU_MUL else N), K, device="cuda").bfloat16() * 0.02 for _ in range(nrot)]
+    bias = torch.randn(N, device="cuda").bfloat16()
+    res = torch.zeros(M, N, device="cuda", dtype=torch.float32 if f32res else torch.bfloat16)
+    kw = {}
+    if epi in (ops.EPI_BIAS, ops.EPI_BIAS_QGELU, ops.EPI_BIAS_GELU, ops.EPI_BIAS_RESID_F32): kw["bias"] = bias
+    if epi in (ops.EPI_BIAS_RESID_F32, ops.EPI_RESID_BF16): kw.update(resid=res, out=res)
+    ms = timeit(lambda i: ops.gemm(A, Ws[i], epi, **kw), nrot)
+    tf = 2 * M * N * K * (2 if epi == ops.EPI_SILU_MUL else 1) / ms / 1e9
+    print(f"gemm {name:28s} M={M:6d} N={N:6d} K={K:5d}  {ms*1e3:9.1f} us  {tf:8.1f} TF/s")
+
+def gemv_case(name, M, N, K, epi, norm=False):
+    rows = 2 * N if epi == ops.EPI_SILU_MUL else N
+    nrot = min(16, max(2, int(600e6 // (rows * K * 2)) + 1))
+    x = torch.randn(M, K, device="cuda").bfloat16()
+    Ws = [torch.randn(rows, K, device="cuda").bfloat16() * 0.02 for _ in range(nrot)]
+    res = torch.zeros(M, N, device="cuda", dtype=torch.bfloat16)
+    nw = torch.ones(K, device="cuda").bfloat16()
+    kw = {}
+    if epi == ops.EPI_RESID_BF16: kw.update(resid=res, out=res)
+    if norm: kw.update(norm_w=nw, norm_eps=1e-5)
+    ms = timeit(lambda i: ops.gemv(x, Ws[i], epi, **kw), nrot, iters=50)
+    gb = rows * K * 2 / ms / 1e6
+    print(f"gemv {name:28s} M={M:6d} N={N:6d} K={K:5d}  {ms*1e3:9.1f} us  {gb:8.1f} GB/s  ({gb/80:.1f}% of 8 TB/s)")
+
+if __name__ == "__main__":
+    which = sys.argv[1] if len(sys.argv) > 1 else "all"
+    if which in ("all", "gemm"):
+        S = 2531
+        gemm_case("dec qkv", S, 9216, 3072, ops.EPI_NONE)
+        gemm_case("dec o_proj+resid", S, 3072, 3072, ops.EPI_RESID_BF16)
+        gemm_case("dec gate_up silu", S, 8192, 3072, ops.EPI_SILU_MUL)
+        gemm_case("dec down+resid", S, 3072, 8192, ops.EPI_RESID_BF16)
+        V = 17 * 577
+        gemm_case("vit qkv+bias", V, 3072, 1024, ops.EPI_BIAS)
+        gemm_case("vit out+resid_f32", V, 1024, 1024, ops.EPI_BIAS_RESID_F32, True)
+        gemm_case("vit fc1 qgelu", V, 4096, 1024, ops.EPI_BIAS_QGELU)
+        gemm_case("vit fc2+resid_f32", V, 1024, 4096, ops.EPI_BIAS_RESID_F32, True)
+        gemm_case("proj0 gelu", 2509, 3072, 4096, ops.EPI_BIAS_GELU)
+        gemm_case("square 4096", 4096, 4096, 4096, ops.EPI_NONE)
+        gemm_case("square 8192", 8192, 8192, 8192, ops.EPI_NONE)
+    if which in ("all", "gemv"):
+        for M in (1, 8):
+            gemv_case("qkv +norm", M, 9216, 3072, ops.EPI_NONE, True)
+            gemv_case("o_proj +resid", M, 3072, 3072, ops.EPI_RESID_BF16)
+            gemv_case("gate_up silu +norm", M, 8192, 3072, ops.EPI_SILU_MUL, True)
+            gemv_case("down +resid", M, 3072, 8192, ops.EPI_RESID_BF16)
+            gemv_case("lm_head +norm", M, 32064, 3072, ops.EPI_NONE, True)
