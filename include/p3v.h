@@ -103,8 +103,9 @@ int p3v_rope_table(const float* pos, const float* inv_freq, float scale, float* 
 
 /* ---- split + RoPE + KV append, phi.py:443-452 and 542-548.
  * qkv [B*L, (nh+2*nkv)*hd] bf16 -> q_out [B, nh, L, hd] bf16 (rotated),
- * K (rotated) / V -> k_dst/v_dst[b, h, dst_off + l, :] with row stride hd and
- * head stride dst_t*hd, batch stride nkv*dst_t*hd.
+ * K (rotated) -> k_dst[b, h, dst_off + l, :]   (K   layout [B, nkv, dst_t, hd]),
+ * V           -> v_dst[b, h, :, dst_off + l]   (V^T layout [B, nkv, hd, dst_t]: the PV product
+ * then reads 8 consecutive keys per lane with one 16-byte load, like QK^T does for K).
  * cos/sin tables are [B/tab_div, tab_t, hd/2]; position of (b,l) is past+l.
  * cos_t == sin_t == NULL: no rotation, plain head split (CLIP q/k/v, phi.py:147).
  * `d_past` (device int32, may be null) overrides `past` -- used under graph replay. */
@@ -117,8 +118,11 @@ int p3v_rope_kv_append(const uint16_t* qkv, const float* cos_t, const float* sin
 /* ---- attention, phi.py:454-457 (decoder, causal + left-pad, Mask4D phi.py:550-563)
  * and phi.py:148 (CLIP, no mask).  q [B, nh, L, hd]; keys/values come from two
  * segments: positions [0,past) from (k_past,v_past) batch row b/past_div
- * (head stride past_t*hd), positions [past,past+L) from (k_new,v_new) batch
- * row b (head stride new_t*hd).  out [B, L, nh*hd] bf16.
+ * (K [.., past_t, hd], V^T [.., hd, past_t]), positions [past,past+L) from
+ * (k_new,v_new) batch row b (K [.., new_t, hd], V^T [.., hd, new_t]) -- or, with
+ * new_is_cache, from (k_past,v_past) as well (the normal case: rows were just
+ * appended to the cache).  V^T columns beyond the valid keys must hold finite values.
+ * out [B, L, nh*hd] bf16.
  * Query i sees key t iff (!causal || t <= past+i) && t >= pad_len[b]; a query
  * that is itself padding outputs 0.  hd in {64, 96}. */
 typedef struct {
@@ -141,6 +145,27 @@ int p3v_attention(const p3v_attn_args_t* args /* host */, void* stream);
 /* bytes of workspace p3v_attention needs for the decode (L<=P3V_DECODE_MAX_L) path */
 int64_t p3v_attention_ws_bytes(int B, int L, int n_heads, int hd, int n_split);
 #define P3V_DECODE_MAX_L 16
+
+/* ---- fused decode-step attention (L <= P3V_DECODE_MAX_L new tokens, no beams): head split +
+ * _rotate_half + KVCache append + split-KV attention + merge in one call (phi.py:443-457, 542-548).
+ * qkv [B*L, (nh+2*nkv)*hd] is the raw projection; positions [past, past+L) of the caches
+ * (K [B, nkv, cache_t, hd], V^T [B, nkv, hd, cache_t], cache_t % 64 == 0) are written,
+ * positions [0, past) read.  cos_t/sin_t point at the rows of the NEW positions: row
+ * (b, r) = b*rope_bstride + r, r in [0, L) (either a view into the prompt tables at `past`, or
+ * the compact buffers p3v_stage_rope fills when `past` only lives on the device);
+ * ws >= p3v_attention_ws_bytes(B, L, nh, hd, n_split) even when n_split == 1.  hd == 96.
+ * Key ranges of the splits are a static function of cache_t, so loads start before d_past arrives. */
+typedef struct {
+  const uint16_t* qkv; const float* cos_t; const float* sin_t;
+  uint16_t* k_cache; uint16_t* v_cache; uint16_t* out;
+  const int32_t* pad_len; const int32_t* d_past; float* ws;
+  int B, L, n_heads, n_kv, hd, past, cache_t, rope_bstride, n_split;
+  float scale;
+} p3v_attn_decode_args_t;
+int p3v_attention_decode(const p3v_attn_decode_args_t* args /* host */, void* stream);
+/* cos/sin rows of positions [past, past+L) of each batch row ([B, tab_t, half] tables) -> [B, L, half] */
+int p3v_stage_rope(const float* cos_t, const float* sin_t, int past, const int32_t* d_past,
+                   float* cos_out, float* sin_out, int B, int L, int tab_t, int half_dim, void* stream);
 
 /* ---- CLIP patch unfold: pixel_values [N,3,S,S] f32 -> patches [N*P, kpad] bf16, (c,ky,kx) order, zero padded */
 int p3v_im2col_patches(const float* pix, uint16_t* patches, int n_img, int img, int patch, int kpad, void* stream);

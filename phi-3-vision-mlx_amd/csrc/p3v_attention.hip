@@ -17,6 +17,8 @@
 //   decode   L <= 16: grid (n_split, heads, B): the KV range is split across
 //            blocks (HBM-bound: reads 2*T*hd*2 bytes per head once); partial
 //            (m, l, O) go to a workspace and `k_attn_combine` merges them.
+#include <stdlib.h>
+
 #include "p3v_common.h"
 
 struct AttnP {
@@ -29,7 +31,7 @@ struct AttnP {
 template <int HD>
 __global__ void __launch_bounds__(256) k_attn(AttnP p) {
   constexpr int KSTR = HD * 2 + 16;        // bytes per K row in LDS (padded: conflict-free b128 fragment reads)
-  constexpr int VSTR = 64 * 2 + 8;         // bytes per V^T row in LDS
+  constexpr int VSTR = 64 * 2 + 16;        // bytes per V^T row in LDS (16-B aligned rows, conflict-free b64 reads)
   constexpr int NKS = HD / 32;             // k-steps of QK^T
   constexpr int NDT = HD / 16;             // 16-wide d tiles of O^T
   constexpr int CPR = HD / 8;              // 16-byte chunks per K/V row
@@ -74,9 +76,9 @@ __global__ void __launch_bounds__(256) k_attn(AttnP p) {
   const int qpos = past + qrow;                    // absolute position of this lane's query
 
   const bf16_t* kp_base = p.k_past + ((size_t)(b / p.past_div) * p.nkv + kvh) * (size_t)p.past_t * HD;
-  const bf16_t* vp_base = p.v_past + ((size_t)(b / p.past_div) * p.nkv + kvh) * (size_t)p.past_t * HD;
+  const bf16_t* vp_base = p.v_past + ((size_t)(b / p.past_div) * p.nkv + kvh) * (size_t)HD * p.past_t;   // V^T: [hd][past_t]
   const bf16_t* kn_base = p.k_new + ((size_t)b * p.nkv + kvh) * (size_t)p.new_t * HD;
-  const bf16_t* vn_base = p.v_new + ((size_t)b * p.nkv + kvh) * (size_t)p.new_t * HD;
+  const bf16_t* vn_base = p.v_new + ((size_t)b * p.nkv + kvh) * (size_t)HD * p.new_t;
 
   float m_run = -INFINITY, l_run = 0.f;
   f32x4_t o[NDT];
@@ -85,22 +87,34 @@ __global__ void __launch_bounds__(256) k_attn(AttnP p) {
 
   for (int kv0 = kv_begin; kv0 < kv_end; kv0 += 64) {
     __syncthreads();
-    for (int i = tid; i < 64 * CPR; i += 256) {
+    for (int i = tid; i < 64 * CPR; i += 256) {               // K tile: 64 key rows x CPR 16-byte chunks
       const int key = i / CPR, c = i % CPR, t = kv0 + key;
-      u32x4_t kv = {0, 0, 0, 0}, vv = {0, 0, 0, 0};
+      u32x4_t kv = {0, 0, 0, 0};
       if (t < kv_end) {
         const bool from_past = t < past || p.new_is_cache;
         const bf16_t* ks = from_past ? kp_base + (size_t)t * HD : kn_base + (size_t)(t - past) * HD;
-        const bf16_t* vs = from_past ? vp_base + (size_t)t * HD : vn_base + (size_t)(t - past) * HD;
         kv = *(const u32x4_t*)(ks + c * 8);
-        vv = *(const u32x4_t*)(vs + c * 8);
       }
       *(u32x4_t*)(Ks + key * KSTR + c * 16) = kv;
+    }
+    for (int i = tid; i < HD * 8; i += 256) {                 // V^T tile: HD rows x 8 chunks of 8 keys
+      const int d = i >> 3, c = i & 7, t0 = kv0 + c * 8;
+      u32x4_t vv = {0, 0, 0, 0};
+      if (t0 < kv_end) {
+        if (t0 + 8 <= past || p.new_is_cache) {
+          vv = *(const u32x4_t*)(vp_base + (size_t)d * p.past_t + t0);
+        } else {                                              // chunk touches the separate "new" segment (beam path)
+          bf16_t e[8];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        *(bf16_t*)(Vt + (c * 8 + 2 * j) * VSTR + key * 2) = (bf16_t)(vv[j] & 0xffff);
-        *(bf16_t*)(Vt + (c * 8 + 2 * j + 1) * VSTR + key * 2) = (bf16_t)(vv[j] >> 16);
+          for (int j = 0; j < 8; ++j) {
+            const int t = t0 + j;
+            e[j] = t < past ? vp_base[(size_t)d * p.past_t + t] : (t < kv_end ? vn_base[(size_t)d * p.new_t + (t - past)] : (bf16_t)0);
+          }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) vv[j] = (uint32_t)e[2 * j] | ((uint32_t)e[2 * j + 1] << 16);
+        }
       }
+      *(u32x4_t*)(Vt + d * VSTR + c * 16) = vv;
     }
     __syncthreads();
     if (!active) continue;
@@ -186,31 +200,10 @@ __global__ void __launch_bounds__(256) k_attn(AttnP p) {
   }
 }
 
-// merge the split-KV partials: one block per (b, head, query)
-__global__ void __launch_bounds__(128) k_attn_combine(const float* __restrict__ ws, bf16_t* __restrict__ out, int L, int nh,
-                                                      int hd, int n_split) {
-  const int qi = blockIdx.x % L, head = (blockIdx.x / L) % nh, b = blockIdx.x / (L * nh);
-  const float* base = ws + (((size_t)b * nh + head) * n_split * 16 + qi) * (hd + 2);
-  const size_t sstr = (size_t)16 * (hd + 2);
-  float M = -INFINITY;
-  for (int s = 0; s < n_split; ++s) M = fmaxf(M, base[s * sstr + hd]);
-  const int d = threadIdx.x;
-  if (d >= hd) return;
-  float acc = 0.f, l = 0.f;
-  if (M > -INFINITY) {
-    for (int s = 0; s < n_split; ++s) {
-      const float m = base[s * sstr + hd];
-      if (m == -INFINITY) continue;
-      const float wgt = __expf(m - M);
-      acc += wgt * base[s * sstr + d];
-      l += wgt * base[s * sstr + hd + 1];
-    }
-  }
-  out[((size_t)b * L + qi) * (size_t)(nh * hd) + head * hd + d] = f32_to_bf16(l > 0.f ? acc / l : 0.f);
-}
+__global__ void k_attn_combine2(const float* __restrict__ ws, bf16_t* __restrict__ out, int L, int nh, int hd, int n_split);
 
 extern "C" int64_t p3v_attention_ws_bytes(int B, int L, int n_heads, int hd, int n_split) {
-  if (L > P3V_DECODE_MAX_L || n_split <= 1) return 0;
+  if (L > P3V_DECODE_MAX_L || n_split < 1) return 0;
   return (int64_t)B * n_heads * n_split * 16 * (hd + 2) * 4;
 }
 
@@ -238,9 +231,302 @@ extern "C" int p3v_attention(const p3v_attn_args_t* a, void* stream) {
   else hipLaunchKernelGGL(k_attn<64>, grid, dim3(256), 0, s, p);
   P3V_CHECK_LAUNCH();
   if (p.split_mode) {
-    hipLaunchKernelGGL(k_attn_combine, dim3(a->B * a->n_heads * a->L), dim3(128), 0, s, a->ws, a->out, a->L, a->n_heads,
+    hipLaunchKernelGGL(k_attn_combine2, dim3(a->B * a->n_heads * a->L), dim3(256), 0, s, a->ws, a->out, a->L, a->n_heads,
                        a->hd, p.n_split);
     P3V_CHECK_LAUNCH();
   }
+  return P3V_OK;
+}
+
+// =====================================================================================
+// Fused decode step attention (L <= 16 new tokens, n_beam == 1):
+//   split(qkv) + _rotate_half + KV append + split-KV attention   (phi.py:443-457, 542-548)
+// in ONE launch, one WAVE per workgroup (no block barriers), grid (n_split, heads, B).
+//   * Q is rotated in registers straight into MFMA B fragments;
+//   * keys/values of positions < past stream from the cache (bf16, 16-byte loads,
+//     24 in flight per lane per 64-key tile); the L new positions are rotated from
+//     the qkv row on the fly by the one workgroup whose key range covers them, which
+//     also appends them to the cache (so no other workgroup ever reads rows that are
+//     written in this launch);
+//   * partial (m, l, O) per split go to `ws`; `k_attn_combine2` merges them.
+// HBM-bound: algorithmic bytes = 2 * past * n_kv * hd * 2 per (batch row, layer).
+struct AttnDecP {
+  const bf16_t* qkv; const float* cos_t; const float* sin_t; bf16_t* k_cache; bf16_t* v_cache;
+  const int32_t* pad_len; const int32_t* d_past; float* ws;
+  int B, L, nh, nkv, past, cache_t, rope_bstride, n_split;   // cos/sin row of (b, new position r) = b*rope_bstride + r
+  float scale;
+};
+
+__device__ __forceinline__ u32x4_t rope_chunk(const bf16_t* head_row, int c, const float* ct, const float* st) {
+  // rotated 8-wide chunk c (0..11) of a 96-wide head: low half pairs with +48, high half with -48
+  constexpr int HALF = 48;
+  const int d0 = c * 8, lo = d0 < HALF;
+  const u32x4_t x0 = *(const u32x4_t*)(head_row + d0);
+  const u32x4_t x1 = *(const u32x4_t*)(head_row + (lo ? d0 + HALF : d0 - HALF));
+  const int tb = lo ? d0 : d0 - HALF;
+  const float4 c0 = *(const float4*)(ct + tb), c1 = *(const float4*)(ct + tb + 4);
+  const float4 s0 = *(const float4*)(st + tb), s1 = *(const float4*)(st + tb + 4);
+  const float cs[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+  const float sn[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+  const float sg = lo ? -1.f : 1.f;
+  u32x4_t o;
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    o[j] = pack_bf16x2(bf16lo(x0[j]) * cs[2 * j] + sg * bf16lo(x1[j]) * sn[2 * j],
+                       bf16hi(x0[j]) * cs[2 * j + 1] + sg * bf16hi(x1[j]) * sn[2 * j + 1]);
+  return o;
+}
+
+template <int TK>   // keys per tile (32 or 64): one tile per wave-iteration
+__global__ void __launch_bounds__(64) k_attn_decode(AttnDecP p) {
+  constexpr int HD = 96, KSTR = HD * 2 + 16, VSTR = TK * 2 + 16, NKS = 3, NDT = 6, CPR = 12;
+  constexpr int KIT = TK * CPR / 64, VCH = TK / 8, VIT = HD * VCH / 64;   // 16-byte loads per lane: K, V^T
+  __shared__ __attribute__((aligned(16))) unsigned char Ks[TK * KSTR];
+  __shared__ __attribute__((aligned(16))) unsigned char Vt[HD * VSTR];
+  const int lane = threadIdx.x, g = lane >> 4, qi = lane & 15;
+  const int b = blockIdx.z, head = blockIdx.y, kvh = head / (p.nh / p.nkv);
+  const bool kv_writer = head % (p.nh / p.nkv) == 0;
+  const int row_w = (p.nh + 2 * p.nkv) * HD;                  // qkv row width
+  const bf16_t* kc = p.k_cache + ((size_t)b * p.nkv + kvh) * (size_t)p.cache_t * HD;
+  bf16_t* vc = p.v_cache + ((size_t)b * p.nkv + kvh) * (size_t)HD * p.cache_t;          // V^T: [hd][cache_t]
+  // The key range of a split is STATIC (a function of the cache capacity, not of the current length):
+  // its first tile can be requested before the cache length `past` has even arrived from HBM.
+  const int chunk = ((p.cache_t + p.n_split - 1) / p.n_split + TK - 1) & ~(TK - 1);
+  const int kv_lo = blockIdx.x * chunk, kv_hi = min(p.cache_t, kv_lo + chunk);
+
+  // ---- tile registers: K TK rows x 12 chunks, V^T 96 rows x TK/8 chunks, all requested before anything is
+  //      used.  Rows beyond the live length are read too (allocated, finite V^T / masked K) and ignored.
+  u32x4_t kreg[KIT], vreg[VIT];
+  auto load_tile = [&](int kv0) {
+#pragma unroll
+    for (int it = 0; it < KIT; ++it) {
+      const int i = it * 64 + lane;
+      kreg[it] = __builtin_nontemporal_load((const u32x4_t*)(kc + (size_t)(kv0 + i / CPR) * HD + (i % CPR) * 8));
+    }
+#pragma unroll
+    for (int it = 0; it < VIT; ++it) {
+      const int i = it * 64 + lane;
+      vreg[it] = __builtin_nontemporal_load((const u32x4_t*)(vc + (size_t)(i / VCH) * p.cache_t + kv0 + (i % VCH) * 8));
+    }
+  };
+  if (kv_lo < kv_hi) load_tile(kv_lo);                         // cache_t % TK == 0: the tile is always in bounds
+
+  const int past = p.d_past ? *p.d_past : p.past;
+  const int total = past + p.L;
+  const int pad = p.pad_len ? p.pad_len[b] : 0;
+  int kv_begin = kv_lo;
+  const int kv_end = min(total, kv_hi);
+  if (pad > kv_begin) kv_begin = pad & ~(TK - 1);
+  const float* cos_b = p.cos_t + (size_t)b * p.rope_bstride * (HD / 2);
+  const float* sin_b = p.sin_t + (size_t)b * p.rope_bstride * (HD / 2);
+
+  // positions [past, total) that fall in this tile: K rotated from the qkv row, V copied -- written straight into
+  // the LDS tile (after the bulk register->LDS store) and appended to the cache by the writer block.  Rolled
+  // loops on purpose: this is the rare path (one tile per head) and must not cost registers.
+  auto patch_new = [&](int kv0) {
+    const int n0 = max(past, kv0), n1 = min(kv_end, kv0 + TK), n_new = n1 - n0;
+#pragma unroll 1
+    for (int w = lane; w < n_new * CPR; w += 64) {
+      const int t = n0 + w / CPR, c = w % CPR, r = t - past;
+      const bf16_t* row = p.qkv + ((size_t)b * p.L + r) * row_w;
+      const u32x4_t kn = rope_chunk(row + (p.nh + kvh) * HD, c, cos_b + r * (HD / 2), sin_b + r * (HD / 2));
+      *(u32x4_t*)(Ks + (t - kv0) * KSTR + c * 16) = kn;
+      if (kv_writer) *(u32x4_t*)(p.k_cache + (((size_t)b * p.nkv + kvh) * p.cache_t + t) * HD + c * 8) = kn;   // phi.py:545
+    }
+#pragma unroll 1
+    for (int w = lane; w < n_new * HD; w += 64) {
+      const int t = n0 + w / HD, d = w % HD, r = t - past;
+      const bf16_t val = p.qkv[((size_t)b * p.L + r) * row_w + (p.nh + p.nkv + kvh) * HD + d];
+      *(bf16_t*)(Vt + d * VSTR + (t - kv0) * 2) = val;
+      if (kv_writer) vc[(size_t)d * p.cache_t + t] = val;                                                   // phi.py:546
+    }
+  };
+  if (kv_begin > kv_lo && kv_begin < kv_end) load_tile(kv_begin);   // left padding skipped whole tiles: reload
+
+
+  const bool qvalid = qi < p.L;
+  const int qpos = past + qi;
+  bf16x8_t qf[NKS];
+  {
+    const bf16_t* qrow = p.qkv + ((size_t)b * p.L + (qvalid ? qi : 0)) * row_w + head * HD;
+    const float* ct = cos_b + (qvalid ? qi : 0) * (HD / 2);
+    const float* st = sin_b + (qvalid ? qi : 0) * (HD / 2);
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+      u32x4_t v = rope_chunk(qrow, 4 * ks + g, ct, st);
+      if (!qvalid) v = (u32x4_t){0, 0, 0, 0};
+      qf[ks] = __builtin_bit_cast(bf16x8_t, v);
+    }
+  }
+
+  float m_run = -INFINITY, l_run = 0.f;
+  f32x4_t o[NDT];
+#pragma unroll
+  for (int d = 0; d < NDT; ++d) o[d] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  for (int kv0 = kv_begin; kv0 < kv_end; kv0 += TK) {
+#pragma unroll
+    for (int it = 0; it < KIT; ++it) {
+      const int i = it * 64 + lane;
+      *(u32x4_t*)(Ks + (i / CPR) * KSTR + (i % CPR) * 16) = kreg[it];
+    }
+#pragma unroll
+    for (int it = 0; it < VIT; ++it) {
+      const int i = it * 64 + lane;
+      *(u32x4_t*)(Vt + (i / VCH) * VSTR + (i % VCH) * 16) = vreg[it];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // this wave's LDS writes have landed (single-wave block)
+    if (kv0 + TK > past) {                                     // wave-uniform: only the tile(s) holding new positions
+      patch_new(kv0);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    if (kv0 + TK < kv_end) load_tile(kv0 + TK);                // next tile streams in under the MFMAs below
+
+    f32x4_t s[TK / 16];
+#pragma unroll
+    for (int st = 0; st < TK / 16; ++st) {
+      s[st] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks) {
+        const bf16x8_t kf = *(const bf16x8_t*)(Ks + (16 * st + qi) * KSTR + (32 * ks + 8 * g) * 2);
+        s[st] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], s[st], 0, 0, 0);
+      }
+    }
+    float m_t = -INFINITY;
+#pragma unroll
+    for (int st = 0; st < TK / 16; ++st)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int t = kv0 + 16 * st + 4 * g + r;
+        const bool vis = t < kv_end && t >= pad && t <= qpos && qpos >= pad;
+        const float v = vis ? s[st][r] * p.scale : -INFINITY;
+        s[st][r] = v;
+        m_t = fmaxf(m_t, v);
+      }
+    m_t = fmaxf(m_t, __shfl_xor(m_t, 16, 64));
+    m_t = fmaxf(m_t, __shfl_xor(m_t, 32, 64));
+    const float m_new = fmaxf(m_run, m_t);
+    const float m_use = m_new == -INFINITY ? 0.f : m_new;
+    const float alpha = __expf(m_run - m_use);
+    float l_t = 0.f;
+#pragma unroll
+    for (int st = 0; st < TK / 16; ++st)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float e = __expf(s[st][r] - m_use);
+        s[st][r] = e;
+        l_t += e;
+      }
+    l_t += __shfl_xor(l_t, 16, 64);
+    l_t += __shfl_xor(l_t, 32, 64);
+    l_run = l_run * alpha + l_t;
+    m_run = m_new;
+#pragma unroll
+    for (int d = 0; d < NDT; ++d) o[d] *= alpha;
+#pragma unroll
+    for (int st = 0; st < TK / 32; ++st) {
+      u32x4_t pw;
+      pw[0] = pack_bf16x2(s[2 * st][0], s[2 * st][1]);
+      pw[1] = pack_bf16x2(s[2 * st][2], s[2 * st][3]);
+      pw[2] = pack_bf16x2(s[2 * st + 1][0], s[2 * st + 1][1]);
+      pw[3] = pack_bf16x2(s[2 * st + 1][2], s[2 * st + 1][3]);
+      const bf16x8_t pf = __builtin_bit_cast(bf16x8_t, pw);
+#pragma unroll
+      for (int d = 0; d < NDT; ++d) {
+        const unsigned char* vr = Vt + (16 * d + qi) * VSTR + (32 * st + 4 * g) * 2;
+        const u32x2_t a0 = *(const u32x2_t*)vr, a1 = *(const u32x2_t*)(vr + 32);
+        const u32x4_t aw = {a0[0], a0[1], a1[0], a1[1]};
+        o[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, aw), pf, o[d], 0, 0, 0);
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // LDS reads of this tile precede the next tile's writes
+  }
+  if (!qvalid) return;
+  float* w = p.ws + ((((size_t)b * p.nh + head) * p.n_split + blockIdx.x) * 16 + qi) * (HD + 2);
+#pragma unroll
+  for (int d = 0; d < NDT; ++d) *(f32x4_t*)(w + 16 * d + 4 * g) = o[d];
+  if (g == 0) { w[HD] = m_run; w[HD + 1] = l_run; }
+}
+
+// merge split-KV partials: one 256-thread block per (b, head, query), ONE memory round trip: thread
+// (grp, d) loads (m, l, o[d]) of its quarter of the splits at once, reduces them against its own running
+// max, and the four groups are merged through LDS.
+__global__ void __launch_bounds__(256) k_attn_combine2(const float* __restrict__ ws, bf16_t* __restrict__ out, int L,
+                                                       int nh, int hd, int n_split) {
+  __shared__ float pm[4], pl[4];
+  __shared__ float part[4][128];
+  const int qi = blockIdx.x % L, head = (blockIdx.x / L) % nh, b = blockIdx.x / (L * nh);
+  const float* base = ws + (((size_t)b * nh + head) * n_split * 16 + qi) * (hd + 2);
+  const size_t sstr = (size_t)16 * (hd + 2);
+  const int t = threadIdx.x, grp = t >> 6, d0 = t & 63;       // 4 groups x 64 lanes; lane handles d0 and d0+64
+  const int per = (n_split + 3) >> 2, s0 = grp * per, s1 = min(n_split, s0 + per);
+  const bool two = d0 + 64 < hd;
+  float m = -INFINITY, l = 0.f, a0 = 0.f, a1 = 0.f;
+#pragma unroll 4
+  for (int s = s0; s < s1; ++s) {
+    const float ms = base[s * sstr + hd], ls = base[s * sstr + hd + 1];
+    const float o0 = base[s * sstr + d0], o1 = two ? base[s * sstr + d0 + 64] : 0.f;
+    const float mn = fmaxf(m, ms);
+    const float mu = mn == -INFINITY ? 0.f : mn;
+    const float ca = __expf(m - mu), cb = __expf(ms - mu);    // exp(-inf) = 0 covers empty partials
+    l = l * ca + ls * cb;
+    a0 = a0 * ca + o0 * cb;
+    a1 = a1 * ca + o1 * cb;
+    m = mn;
+  }
+  if (d0 == 0) { pm[grp] = m; pl[grp] = l; }
+  part[grp][d0] = a0;
+  if (two) part[grp][d0 + 64] = a1;
+  __syncthreads();
+  if (t < hd) {
+    const float M = fmaxf(fmaxf(pm[0], pm[1]), fmaxf(pm[2], pm[3]));
+    const float Mu = M == -INFINITY ? 0.f : M;
+    float acc = 0.f, lsum = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float c = __expf(pm[k] - Mu);
+      acc += c * part[k][t];
+      lsum += c * pl[k];
+    }
+    out[((size_t)b * L + qi) * (size_t)(nh * hd) + head * hd + t] = f32_to_bf16(lsum > 0.f ? acc / lsum : 0.f);
+  }
+}
+
+// cos/sin rows of the L positions [past, past+L) of every batch row -> compact [B, L, half] buffers, so that
+// the decode attention of all layers reads them at addresses that do not depend on the device-side cache length
+__global__ void k_stage_rope(const float* __restrict__ cos_t, const float* __restrict__ sin_t, const int32_t* d_past,
+                             int past, float* __restrict__ cos_o, float* __restrict__ sin_o, int L, int tab_t, int half) {
+  if (d_past) past = *d_past;
+  const int b = blockIdx.x / L, r = blockIdx.x % L;
+  for (int i = threadIdx.x; i < half; i += blockDim.x) {
+    cos_o[((size_t)b * L + r) * half + i] = cos_t[((size_t)b * tab_t + past + r) * half + i];
+    sin_o[((size_t)b * L + r) * half + i] = sin_t[((size_t)b * tab_t + past + r) * half + i];
+  }
+}
+
+extern "C" int p3v_stage_rope(const float* cos_t, const float* sin_t, int past, const int32_t* d_past, float* cos_out,
+                              float* sin_out, int B, int L, int tab_t, int half_dim, void* stream) {
+  if (!cos_t || !sin_t || !cos_out || !sin_out || B <= 0 || L <= 0) return P3V_ERR_ARG;
+  hipLaunchKernelGGL(k_stage_rope, dim3(B * L), dim3(64), 0, (hipStream_t)stream, cos_t, sin_t, d_past, past, cos_out,
+                     sin_out, L, tab_t, half_dim);
+  P3V_CHECK_LAUNCH();
+  return P3V_OK;
+}
+
+extern "C" int p3v_attention_decode(const p3v_attn_decode_args_t* a, void* stream) {
+  if (!a || !a->qkv || !a->cos_t || !a->sin_t || !a->k_cache || !a->v_cache || !a->out || !a->ws) return P3V_ERR_ARG;
+  if (a->hd != 96) return P3V_ERR_UNSUPPORTED;
+  if (a->B <= 0 || a->L <= 0 || a->L > P3V_DECODE_MAX_L || a->n_heads % a->n_kv) return P3V_ERR_ARG;
+  if (a->n_split < 1 || a->n_split > 128 || a->cache_t % 64) return P3V_ERR_ARG;
+  AttnDecP p = {a->qkv, a->cos_t, a->sin_t, a->k_cache, a->v_cache, a->pad_len, a->d_past, a->ws,
+                a->B, a->L, a->n_heads, a->n_kv, a->past, a->cache_t, a->rope_bstride, a->n_split, a->scale};
+  hipStream_t s = (hipStream_t)stream;
+  static const int tk = getenv("P3V_ATTN_TK") ? atoi(getenv("P3V_ATTN_TK")) : 64;
+  if (tk == 64) hipLaunchKernelGGL(k_attn_decode<64>, dim3(a->n_split, a->n_heads, a->B), dim3(64), 0, s, p);
+  else hipLaunchKernelGGL(k_attn_decode<32>, dim3(a->n_split, a->n_heads, a->B), dim3(64), 0, s, p);
+  P3V_CHECK_LAUNCH();
+  hipLaunchKernelGGL(k_attn_combine2, dim3(a->B * a->n_heads * a->L), dim3(256), 0, s, a->ws, a->out, a->L, a->n_heads,
+                     a->hd, a->n_split);
+  P3V_CHECK_LAUNCH();
   return P3V_OK;
 }

@@ -182,7 +182,12 @@ __global__ void __launch_bounds__(256) k_rope_kv_append(const bf16_t* __restrict
     } else {
       const int j = it - n_rot, head = j / (hd >> 3), c = j % (hd >> 3);
       const u32x4_t v = *(const u32x4_t*)(row + (size_t)(nh + nkv + head) * hd + c * 8);
-      *(u32x4_t*)(v_dst + (((size_t)b * nkv + head) * dst_t + dpos) * hd + c * 8) = v;
+      bf16_t* vd = v_dst + (((size_t)b * nkv + head) * hd + c * 8) * (size_t)dst_t + dpos;    // V^T: [hd][dst_t]
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        vd[(size_t)(2 * jj) * dst_t] = (bf16_t)(v[jj] & 0xffff);
+        vd[(size_t)(2 * jj + 1) * dst_t] = (bf16_t)(v[jj] >> 16);
+      }
     }
   }
 }

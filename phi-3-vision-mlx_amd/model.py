@@ -12,7 +12,9 @@ This module only owns device buffers and sequences launches.
 
 HBM layout
   weights      bf16 [out, in] row-major (HF layout, K contiguous = MFMA fragment order)
-  KV cache     per layer K,V bf16 [B, n_kv, T, hd]  (T = prompt + max_tokens, allocated once)
+  KV cache     per layer K bf16 [B, n_kv, Tp, hd] and V TRANSPOSED bf16 [B, n_kv, hd, Tp]
+               (Tp = prompt + max_tokens rounded up to 64, allocated once): both are then
+               k-contiguous MFMA operands for QK^T and PV with plain 16-byte loads
   RoPE tables  fp32 cos/sin [B, T, hd/2] built once per prompt (one short/long choice, Q2)
   residual     decoder: bf16 [B*L, H]; ViT: fp32 [crops, 577, 1024]
 Dtype flow differs from the reference only where stated in DESIGN.md
@@ -20,6 +22,7 @@ Dtype flow differs from the reference only where stated in DESIGN.md
 tolerance the parity tests state.
 """
 import math
+import os
 
 import numpy as np
 import torch
@@ -43,9 +46,10 @@ class CacheState:
     def __init__(self, cfg, B, S, max_tokens, device):
         self.B, self.S, self.max_tokens = B, S, max_tokens
         self.T = S + max(max_tokens, 0)
+        self.Tp = (self.T + 63) // 64 * 64                     # row/column stride of the caches (64-key tiles)
         nl, nkv, hd = cfg.num_hidden_layers, cfg.num_key_value_heads, head_dim(cfg)
-        self.k = torch.empty((nl, B, nkv, self.T, hd), dtype=BF16, device=device)
-        self.v = torch.empty((nl, B, nkv, self.T, hd), dtype=BF16, device=device)
+        self.k = torch.empty((nl, B, nkv, self.Tp, hd), dtype=BF16, device=device)    # K   [.., t, hd]
+        self.v = torch.zeros((nl, B, nkv, hd, self.Tp), dtype=BF16, device=device)    # V^T [.., hd, t] (zero: tail keys stay finite)
         self.offset = 0
         self.cos = self.sin = self.pad_len = None
         self.graphs = {}
@@ -114,16 +118,18 @@ class Phi3VModel:
         ops.clip_cls_rows(x, w[e + "class_embedding"], pos)
         x2 = x.view(n * T, D)
         ops.layernorm(x2, w[V_PREFIX + "pre_layrnorm.weight"], w[V_PREFIX + "pre_layrnorm.bias"], 1e-5, out_f32=True, out=x2)
+        Tp = (T + 63) // 64 * 64
         q = torch.empty((n, nh, T, 64), dtype=BF16, device=self.device)
-        k, v = torch.empty_like(q), torch.empty_like(q)
+        k = torch.empty((n, nh, Tp, 64), dtype=BF16, device=self.device)
+        v = torch.zeros((n, nh, 64, Tp), dtype=BF16, device=self.device)                 # V^T, zero tail
         o = torch.empty((n * T, D), dtype=BF16, device=self.device)
         for j in range(c["num_hidden_layers"] - 1):
             lp = V_PREFIX + f"encoder.layers.{j}."
             h = ops.layernorm(x2, w[lp + "layer_norm1.weight"], w[lp + "layer_norm1.bias"], eps)
             wq, bq = self.clip_qkv[j]
             qkv = ops.gemm(h, wq, EPI_BIAS, bias=bq)
-            ops.rope_kv_append(qkv, None, None, q, k, v, n, T, nh, nh, 64, 0, T, False)
-            ops.attention(q, k, v, o, n, T, nh, nh, 64, 64 ** -0.5, False, new_t=T)
+            ops.rope_kv_append(qkv, None, None, q, k, v, n, T, nh, nh, 64, 0, Tp, False)
+            ops.attention(q, o, n, T, nh, nh, 64, 64 ** -0.5, False, k_past=k, v_past=v, past_t=Tp, new_is_cache=True)
             ops.gemm(o, w[lp + "self_attn.out_proj.weight"], EPI_BIAS_RESID_F32, bias=w[lp + "self_attn.out_proj.bias"],
                      resid=x2, out=x2)
             h = ops.layernorm(x2, w[lp + "layer_norm2.weight"], w[lp + "layer_norm2.bias"], eps)
@@ -196,10 +202,12 @@ class Phi3VModel:
         """Split-KV plan for the decode-shaped attention (L <= 16): enough blocks to fill 256 CUs."""
         nh, hd = self.cfg.num_attention_heads, self.hd
         if L <= ops.L.DECODE_MAX_L:
-            n_split = max(1, min(64, -(-T // 128), -(-768 // max(1, B * nh))))
-            if n_split > 1:
-                bufs["n_split"] = n_split
-                bufs["ws"] = torch.empty(ops.attention_ws_bytes(B, L, nh, hd, n_split) // 4, dtype=F32, device=self.device)
+            # single-wave workgroups of 64-key tiles; ~768 workgroups = one resident round on 256 CUs
+            n_split = max(1, min(128, -(-T // 64), -(-768 // max(1, B * nh))))
+            if os.environ.get("P3V_ATTN_NSPLIT"):
+                n_split = int(os.environ["P3V_ATTN_NSPLIT"])
+            bufs["n_split"] = n_split
+            bufs["ws"] = torch.empty(ops.attention_ws_bytes(B, L, nh, hd, n_split) // 4, dtype=F32, device=self.device)
 
     def _layers(self, x, st, B, L, past, n_beam, bufs=None, d_past=None):
         """Phi3DecoderLayer stack (phi.py:473-485).  `d_past` (device int32) makes every
@@ -213,8 +221,9 @@ class Phi3VModel:
             self._split_plan(bufs, B, L, past + L)
         q, o, qkv, a, h, n_split, ws = (bufs[k] for k in ("q", "o", "qkv", "a", "h", "n_split", "ws"))
         if n_beam > 1:                                          # beams: K/V of this call go to a scratch, cache is read-only
-            k_new = torch.empty((B, nkv, L, hd), dtype=BF16, device=self.device)
-            v_new = torch.empty_like(k_new)
+            Lp = (L + 7) // 8 * 8
+            k_new = torch.empty((B, nkv, Lp, hd), dtype=BF16, device=self.device)
+            v_new = torch.zeros((B, nkv, hd, Lp), dtype=BF16, device=self.device)
         for i in range(cfg.num_hidden_layers):
             p = f"model.layers.{i}."
             if M <= 8:
@@ -223,20 +232,21 @@ class Phi3VModel:
                 ops.rmsnorm(x, w[p + "input_layernorm.weight"], eps, out=h)
                 ops.gemm(h, w[p + "self_attn.qkv_proj.weight"], out=qkv)
             if n_beam > 1:
-                ops.rope_kv_append(qkv, st.cos, st.sin, q, k_new, v_new, B, L, nh, nkv, hd, past, L, False, st.T, n_beam)
-                ops.attention(q, k_new, v_new, o, B, L, nh, nkv, hd, scale, True, new_t=L, past=past, k_past=st.k[i],
-                              v_past=st.v[i], past_t=st.T, past_div=n_beam, pad_len=st.pad_len, pad_div=n_beam, ws=ws,
-                              n_split=n_split)
-            elif d_past is not None:                            # graph path: new rows are addressed through the cache itself
-                ops.rope_kv_append(qkv, st.cos, st.sin, q, st.k[i], st.v[i], B, L, nh, nkv, hd, 0, st.T, True, st.T, 1, d_past=d_past)
-                ops.attention(q, st.k[i], st.v[i], o, B, L, nh, nkv, hd, scale, True, new_t=st.T, past=0, k_past=st.k[i],
-                              v_past=st.v[i], past_t=st.T, pad_len=st.pad_len, ws=ws, n_split=n_split, d_past=d_past,
-                              new_is_cache=True)
+                ops.rope_kv_append(qkv, st.cos, st.sin, q, k_new, v_new, B, L, nh, nkv, hd, past, Lp, False, st.T, n_beam)
+                ops.attention(q, o, B, L, nh, nkv, hd, scale, True, k_new=k_new, v_new=v_new, new_t=Lp, past=past,
+                              k_past=st.k[i], v_past=st.v[i], past_t=st.Tp, past_div=n_beam, pad_len=st.pad_len,
+                              pad_div=n_beam, ws=ws, n_split=n_split)
+            elif L <= ops.L.DECODE_MAX_L:                       # decode-shaped step: one fused launch (+ merge)
+                if d_past is not None:                          # graph replay: rows staged once per step by the caller
+                    rc, rs, rb = bufs["rope_cos"], bufs["rope_sin"], L
+                else:                                           # eager: views into the prompt tables at `past`
+                    rc, rs, rb = st.cos[:, past:], st.sin[:, past:], st.T
+                ops.attention_decode(qkv, rc, rs, rb, st.k[i], st.v[i], o, B, L, nh, nkv, hd, scale, past, st.Tp, ws, n_split,
+                                     pad_len=st.pad_len, d_past=d_past)
             else:
-                ops.rope_kv_append(qkv, st.cos, st.sin, q, st.k[i], st.v[i], B, L, nh, nkv, hd, past, st.T, True, st.T, 1)
-                kn, vn = st.k[i][:, :, past:], st.v[i][:, :, past:]          # views: same strides, offset by `past` rows
-                ops.attention(q, kn, vn, o, B, L, nh, nkv, hd, scale, True, new_t=st.T, past=past, k_past=st.k[i],
-                              v_past=st.v[i], past_t=st.T, pad_len=st.pad_len, ws=ws, n_split=n_split)
+                ops.rope_kv_append(qkv, st.cos, st.sin, q, st.k[i], st.v[i], B, L, nh, nkv, hd, past, st.Tp, True, st.T, 1)
+                ops.attention(q, o, B, L, nh, nkv, hd, scale, True, past=past, k_past=st.k[i], v_past=st.v[i],
+                              past_t=st.Tp, pad_len=st.pad_len, new_is_cache=True)
             ops.linear(o, w[p + "self_attn.o_proj.weight"], EPI_RESID_BF16, resid=x, out=x)
             if M <= 8:
                 ops.gemv(x, w[p + "mlp.gate_up_proj.weight"], EPI_SILU_MUL, norm_w=w[p + "post_attention_layernorm.weight"],
@@ -262,10 +272,13 @@ class Phi3VModel:
                  next_tok=torch.zeros((B,), dtype=I32, device=dev))
         bufs = self._alloc_bufs(B, 1)
         self._split_plan(bufs, B, 1, st.T)
+        bufs["rope_cos"] = torch.empty((B, 1, self.hd // 2), dtype=F32, device=dev)
+        bufs["rope_sin"] = torch.empty_like(bufs["rope_cos"])
         g["bufs"] = bufs
 
         def step():
             ops.embed_gather(g["tok"], w["model.embed_tokens.weight"], out=g["x"])
+            ops.stage_rope(st.cos, st.sin, bufs["rope_cos"], bufs["rope_sin"], B, 1, st.T, d_past=g["d_past"])
             self._layers(g["x"], st, B, 1, 0, 1, bufs=bufs, d_past=g["d_past"])
             ops.gemv(g["x"], w["lm_head.weight"], norm_w=w["model.norm.weight"], norm_eps=cfg.rms_norm_eps, out=g["logits"])
             ops.argmax(g["logits"], out=g["next_tok"])

@@ -114,13 +114,30 @@ def rope_kv_append(qkv, cos_t, sin_t, q_out, k_dst, v_dst, B, Lq, nh, nkv, hd, p
             "rope_kv_append")
 
 
-def attention(q, k_new, v_new, out, B, Lq, nh, nkv, hd, scale, causal, new_t, past=0, k_past=None, v_past=None, past_t=0,
-              past_div=1, pad_len=None, pad_div=1, d_past=None, ws=None, n_split=0, new_is_cache=False):
-    """softmax((q*scale) k^T + mask) v (phi.py:454-457 / phi.py:148), mask never materialised."""
+def attention(q, out, B, Lq, nh, nkv, hd, scale, causal, k_new=None, v_new=None, new_t=0, past=0, k_past=None, v_past=None,
+              past_t=0, past_div=1, pad_len=None, pad_div=1, d_past=None, ws=None, n_split=0, new_is_cache=False):
+    """softmax((q*scale) k^T + mask) v (phi.py:454-457 / phi.py:148), mask never materialised.
+    K tensors are [B, nkv, t, hd]; V tensors are TRANSPOSED [B, nkv, hd, t] (t = past_t / new_t)."""
     args = L.AttnArgs(_p(q), _p(k_past), _p(v_past), _p(k_new), _p(v_new), _p(out), _p(pad_len), _p(d_past), _p(ws),
                       B, Lq, nh, nkv, hd, int(past), past_t, past_div, new_t, pad_div, int(causal), float(scale), n_split, int(new_is_cache))
     L.check(L.lib().p3v_attention(C.byref(args), _stream()), "attention")
     return out
+
+
+def attention_decode(qkv, cos_new, sin_new, rope_bstride, k_cache, v_cache, out, B, Lq, nh, nkv, hd, scale, past, cache_t, ws,
+                     n_split, pad_len=None, d_past=None):
+    """Fused decode-step attention: head split + RoPE + KV append + split-KV attention + merge.
+    cos_new/sin_new: rows of the new positions, row (b, r) at b*rope_bstride + r."""
+    args = L.AttnDecArgs(_p(qkv), _p(cos_new), _p(sin_new), _p(k_cache), _p(v_cache), _p(out), _p(pad_len), _p(d_past), _p(ws),
+                         B, Lq, nh, nkv, hd, int(past), cache_t, rope_bstride, n_split, float(scale))
+    L.check(L.lib().p3v_attention_decode(C.byref(args), _stream()), "attention_decode")
+    return out
+
+
+def stage_rope(cos_t, sin_t, cos_out, sin_out, B, Lq, tab_t, past=0, d_past=None):
+    """Copy the cos/sin rows of positions [past, past+L) into compact [B, L, half] buffers (graph-replayed decode)."""
+    L.check(L.lib().p3v_stage_rope(_p(cos_t), _p(sin_t), int(past), _p(d_past), _p(cos_out), _p(sin_out), B, Lq, tab_t,
+                                   cos_t.shape[-1], _stream()), "stage_rope")
 
 
 def attention_ws_bytes(B, Lq, nh, hd, n_split):

@@ -169,13 +169,14 @@ def test_rope_table_and_append(ops, orc):
     qkv = g((B * L, (nh + 2 * nkv) * hd), 30)
     q = torch.zeros((B, nh, L, hd), dtype=BF16).cuda()
     kc = torch.zeros((B, nkv, T, hd), dtype=BF16).cuda()
-    vc = torch.zeros_like(kc)
+    vc = torch.zeros((B, nkv, hd, T), dtype=BF16).cuda()                     # V^T layout
     ops.rope_kv_append(qkv.cuda(), cos, sin, q, kc, vc, B, L, nh, nkv, hd, past, T, True, T, 1)
     x = qkv.view(B, L, nh + 2 * nkv, hd).transpose(1, 2)                     # [B, heads, L, hd]
     cs, sn = cos_ref[:, :, past:past + L], sin_ref[:, :, past:past + L]
     close(q, orc.rotate_half(x[:, :nh], cs, sn).to(BF16), atol=1e-2)
     close(kc[:, :, past:past + L], orc.rotate_half(x[:, nh:nh + nkv], cs, sn).to(BF16), atol=1e-2)
-    assert torch.equal(vc[:, :, past:past + L].cpu(), x[:, nh + nkv:].contiguous())
+    assert torch.equal(vc[:, :, :, past:past + L].cpu().transpose(2, 3), x[:, nh + nkv:])
+    assert vc[:, :, :, :past].abs().sum().item() == 0
     assert kc[:, :, :past].abs().sum().item() == 0 and kc[:, :, past + L:].abs().sum().item() == 0
 
 
@@ -190,16 +191,20 @@ def _attn_ref(orc, q, k, v, scale, allowed):
     (1, 16, 64, 96, 2, True, None), (1, 33, 100, 96, 1, True, None)])
 def test_attention(ops, orc, B, L, past, hd, nh, causal, pads):
     T = past + L
+    Tp = (T + 63) // 64 * 64
     q, k, v = g((B, nh, L, hd), 40), g((B, nh, T, hd), 41), g((B, nh, T, hd), 42)
     pad = torch.tensor(pads if pads else [0] * B, dtype=torch.int32)
     out = torch.empty((B, L, nh * hd), dtype=BF16).cuda()
-    kc, vc = k.cuda(), v.cuda()
+    kc = torch.zeros((B, nh, Tp, hd), dtype=BF16)
+    vc = torch.zeros((B, nh, hd, Tp), dtype=BF16)                            # V^T cache layout
+    kc[:, :, :T], vc[:, :, :, :T] = k, v.transpose(2, 3)
+    kc, vc = kc.cuda(), vc.cuda()
     n_split, ws = 0, None
     if L <= 16:
         n_split = 4
         ws = torch.empty(ops.attention_ws_bytes(B, L, nh, hd, n_split) // 4, dtype=F32).cuda()
-    ops.attention(q.cuda(), kc[:, :, past:], vc[:, :, past:], out, B, L, nh, nh, hd, hd ** -0.5, causal, new_t=T, past=past,
-                  k_past=kc, v_past=vc, past_t=T, pad_len=pad.cuda() if pads else None, ws=ws, n_split=n_split)
+    ops.attention(q.cuda(), out, B, L, nh, nh, hd, hd ** -0.5, causal, past=past, k_past=kc, v_past=vc, past_t=Tp,
+                  pad_len=pad.cuda() if pads else None, ws=ws, n_split=n_split, new_is_cache=True)
     t = torch.arange(T)[None, None, None, :]
     qpos = (past + torch.arange(L))[None, None, :, None]
     allowed = (t >= pad[:, None, None, None]) & (qpos >= pad[:, None, None, None])
@@ -208,6 +213,49 @@ def test_attention(ops, orc, B, L, past, hd, nh, causal, pads):
     allowed = allowed.expand(B, 1, L, T)
     ref = _attn_ref(orc, q, k, v, hd ** -0.5, allowed).transpose(1, 2).reshape(B, L, nh * hd)
     close(out, ref, rtol=2 ** -6, atol=2e-2)
+
+
+@pytest.mark.parametrize("B,L,past,nh,n_split,pads", [(1, 1, 300, 4, 5, None), (2, 1, 63, 2, 1, [0, 7]), (1, 6, 130, 2, 3, None),
+                                                      (3, 1, 2000, 2, 32, [0, 100, 1999]), (1, 16, 0, 2, 2, None)])
+def test_attention_decode_fused(ops, orc, B, L, past, nh, n_split, pads):
+    """Fused split + RoPE + KV append + split-KV attention vs the oracle's rotate_half / cache / softmax."""
+    from phi_3_vision_mlx_amd.config import make_config, rope_scaling_factor
+    cfg = make_config()
+    hd, T = 96, (past + L + 5 + 63) // 64 * 64
+    qkv = g((B * L, 3 * nh * hd), 45)
+    kc, vc = g((B, nh, T, hd), 46), g((B, nh, T, hd), 47)
+    cos_ref, sin_ref = orc.su_rope_tables(cfg, T, None)
+    inv = 1.0 / (torch.tensor(cfg.rope_scaling["short_factor"], dtype=F32) * (10000.0 ** (torch.arange(0, hd, 2, dtype=F32) / hd)))
+    pos = torch.arange(T, dtype=F32).repeat(B)
+    cos, sin = ops.rope_table(pos.cuda(), inv.cuda(), rope_scaling_factor(cfg))
+    pad = torch.tensor(pads if pads else [0] * B, dtype=torch.int32)
+    kcc, vcc = kc.cuda(), vc.transpose(2, 3).contiguous().cuda()         # V^T cache layout
+    out = torch.empty((B, L, nh * hd), dtype=BF16).cuda()
+    ws = torch.empty(ops.attention_ws_bytes(B, L, nh, hd, n_split) // 4, dtype=F32).cuda()
+    d_past = torch.tensor([past], dtype=torch.int32).cuda()
+    cos_s = torch.empty((B, L, hd // 2), dtype=F32).cuda()
+    sin_s = torch.empty_like(cos_s)
+    ops.stage_rope(cos.view(B, T, -1), sin.view(B, T, -1), cos_s, sin_s, B, L, T, d_past=d_past)
+    assert torch.equal(cos_s.cpu(), cos.view(B, T, -1)[:, past:past + L].cpu())
+    ops.attention_decode(qkv.cuda(), cos_s, sin_s, L, kcc, vcc, out, B, L, nh, nh, hd, hd ** -0.5, 0, T, ws, n_split,
+                         pad_len=pad.cuda() if pads else None, d_past=d_past)
+    x = qkv.view(B, L, 3 * nh, hd).transpose(1, 2)
+    cs, sn = cos_ref[:, :, past:past + L], sin_ref[:, :, past:past + L]
+    q = orc.rotate_half(x[:, :nh], cs, sn).to(BF16)
+    k_new = orc.rotate_half(x[:, nh:2 * nh], cs, sn).to(BF16)
+    v_new = x[:, 2 * nh:]
+    kf = torch.cat([kc[:, :, :past], k_new], dim=2)
+    vf = torch.cat([vc[:, :, :past], v_new], dim=2)
+    t = torch.arange(past + L)[None, None, None, :]
+    qpos = (past + torch.arange(L))[None, None, :, None]
+    allowed = ((t >= pad[:, None, None, None]) & (qpos >= pad[:, None, None, None]) & (t <= qpos)).expand(B, 1, L, past + L)
+    ref = _attn_ref(orc, q, kf, vf, hd ** -0.5, allowed).transpose(1, 2).reshape(B, L, nh * hd)
+    close(out, ref, rtol=2 ** -6, atol=2e-2)
+    close(kcc[:, :, past:past + L], k_new, atol=1e-2)                       # appended rows
+    vback = vcc.cpu().transpose(2, 3)
+    assert torch.equal(vback[:, :, past:past + L], v_new)
+    assert torch.equal(vback[:, :, :past], vc[:, :, :past]) and torch.equal(vback[:, :, past + L:], vc[:, :, past + L:])
+    assert torch.equal(kcc[:, :, :past].cpu(), kc[:, :, :past]) and torch.equal(kcc[:, :, past + L:].cpu(), kc[:, :, past + L:])
 
 
 def test_attention_beam_view(ops, orc):
@@ -219,8 +267,12 @@ def test_attention_beam_view(ops, orc):
     kn, vn = g((B, nh, L, hd), 53), g((B, nh, L, hd), 54)
     out = torch.empty((B, L, nh * hd), dtype=BF16).cuda()
     ws = torch.empty(ops.attention_ws_bytes(B, L, nh, hd, 2) // 4, dtype=F32).cuda()
-    ops.attention(q.cuda(), kn.cuda(), vn.cuda(), out, B, L, nh, nh, hd, hd ** -0.5, True, new_t=L, past=past,
-                  k_past=kc.cuda(), v_past=vc.cuda(), past_t=T, past_div=nb, ws=ws, n_split=2)
+    Lp = 8
+    knp = torch.zeros((B, nh, Lp, hd), dtype=BF16)
+    vnp = torch.zeros((B, nh, hd, Lp), dtype=BF16)
+    knp[:, :, :L], vnp[:, :, :, :L] = kn, vn.transpose(2, 3)
+    ops.attention(q.cuda(), out, B, L, nh, nh, hd, hd ** -0.5, True, k_new=knp.cuda(), v_new=vnp.cuda(), new_t=Lp, past=past,
+                  k_past=kc.cuda(), v_past=vc.transpose(2, 3).contiguous().cuda(), past_t=T, past_div=nb, ws=ws, n_split=2)
     kf = torch.cat([kc[:, :, :past].repeat_interleave(nb, dim=0), kn], dim=2)
     vf = torch.cat([vc[:, :, :past].repeat_interleave(nb, dim=0), vn], dim=2)
     allowed = (torch.arange(past + L)[None, :] <= (past + torch.arange(L))[:, None])[None, None].expand(B, 1, L, past + L)

@@ -1,0 +1,15 @@
+"""prefill + N graph-replayed greedy steps (for rocprofv3 tracing)."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from phi_3_vision_mlx_amd import ops
+from phi_3_vision_mlx_amd.api import load_synthetic
+ctx = int(sys.argv[1]) if len(sys.argv) > 1 else 2531
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+steps = int(sys.argv[3]) if len(sys.argv) > 3 else 24
+model, _ = load_synthetic(blind_model=True, device="cuda:0")
+ids = np.random.default_rng(0).integers(3, 32000, (B, ctx))
+lg, cache = model(input_ids=ids, max_tokens=steps + 4)
+t = ops.argmax(lg[:, -1].contiguous())[:, None]
+for _ in range(steps): lg, t = model.greedy_step(t, cache)
+torch.cuda.synchronize()

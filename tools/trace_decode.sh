@@ -1,0 +1,46 @@
+#!/bin/bash
+# usage: tools/trace_decode.sh <tag> [ctx] [B] [steps]  -> per-kernel in-graph durations and gaps of the decode step
+TAG=$1; shift
+export TMPDIR=/tmp
+OUT=$PWD/gpurun_out/trace_$TAG
+rm -rf $OUT; mkdir -p $OUT
+cd /tmp
+rocprofv3 --kernel-trace --output-format csv -d $OUT -o t -- python3 $GRAFT_REPO_ROOT/tools/decode_replay.py "$@" > $OUT/run.log 2>&1
+cd - > /dev/null
+python3 - "$OUT" "$TAG" <<'PY'
+import csv, sys, glob, collections
+out, tag = sys.argv[1], sys.argv[2]
+f = glob.glob(out + "/**/*kernel_trace.csv", recursive=True)[0]
+rows = list(csv.DictReader(open(f)))
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+# decode section = everything after the last k_gemm* (prefill) kernel
+last_pref = max(i for i, r in enumerate(rows) if "k_gemm" in r["Kernel_Name"])
+dec = rows[last_pref + 1:]
+# drop the first step(s): eager warm-up + first replay
+names = [r["Kernel_Name"] for r in dec]
+per_step = None
+for i, n in enumerate(names):
+    if "k_store_token" in n:
+        idx = [j for j, m in enumerate(names) if "k_store_token" in m]
+        break
+steps = [(idx[k] + 1, idx[k + 1] + 1) for k in range(len(idx) - 1)]
+steps = steps[4:]          # skip warm-up + early replays
+agg = collections.OrderedDict(); gaps = []
+tot = 0
+for a, b in steps:
+    seg = dec[a:b]
+    for k, r in enumerate(seg):
+        d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+        key = (r["Kernel_Name"].replace("void ", "").split("(")[0][:40], r["Grid_Size_X"] if "Grid_Size_X" in r else r.get("Grid_Size", ""))
+        agg.setdefault(key, []).append(d)
+        if k > 0: gaps.append((int(r["Start_Timestamp"]) - int(seg[k - 1]["End_Timestamp"])) / 1e3)
+    tot += (int(seg[-1]["End_Timestamp"]) - int(seg[0]["Start_Timestamp"])) / 1e3
+n = len(steps)
+lines = [f"decode step (in-graph, rocprofv3 kernel trace, {n} steps averaged): {tot/n:.1f} us/step, "
+         f"{len(dec[steps[0][0]:steps[0][1]])} kernels/step, mean gap {sum(gaps)/len(gaps):.2f} us, total gaps {sum(gaps)/n:.1f} us/step"]
+for (name, grid), v in agg.items():
+    lines.append(f"  {name:40s} grid {grid:>8s}  calls/step {len(v)/n:5.1f}  avg {sum(v)/len(v):8.2f} us  total/step {sum(v)/n:8.1f} us")
+open(f"{out}/../trace_{tag}_summary.txt", "w").write("\n".join(lines) + "\n")
+print("\n".join(lines))
+PY
+rm -f $(find $OUT -name '*kernel_trace.csv')
