@@ -1,0 +1,130 @@
+"""Host-side logic of the drop-in API (no GPU): template, streamer, stoppers, tokenizer,
+synthetic weights, config, loader errors -- checked against the reference's documented behaviour."""
+import io
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+
+def test_chat_template_matches_reference_format(capsys):
+    from phi_3_vision_mlx_amd.api import _apply_chat_template
+    p, im = _apply_chat_template("  What is this? ", None, verbose=False)
+    assert p == "<|user|>\nWhat is this?<|end|>\n<|assistant|>\n" and im is None
+    ps, _ = _apply_chat_template(["a", "b "], None, verbose=False)
+    assert ps == ["<|user|>\na<|end|>\n<|assistant|>\n", "<|user|>\nb<|end|>\n<|assistant|>\n"]
+    from PIL import Image
+    img = Image.new("RGB", (8, 8))
+    p, ims = _apply_chat_template("hi", [img, img], verbose=False)
+    assert p == "<|user|>\n<|image_1|>\n<|image_2|>\nhi<|end|>\n<|assistant|>\n" and len(ims) == 2
+    raw, _ = _apply_chat_template("raw", None, verbose=False, apply_chat_template=False)
+    assert raw == "raw"
+    with pytest.raises(ValueError):
+        _apply_chat_template("x", "/no/such/file.png", verbose=False)
+
+
+def test_byte_tokenizer_contract():
+    from phi_3_vision_mlx_amd.processor import ByteTokenizer
+    t = ByteTokenizer()
+    ids = t("<|user|>\nhi<|end|>").input_ids
+    assert ids[0] == 1 and 32010 in ids and ids[-1] == 32007
+    assert t.encode(" The", add_special_tokens=False)[0] == ByteTokenizer.PREFIX      # [1:] drops it (ref :538)
+    assert t.decode(t("héllo <|end|>").input_ids) == "héllo <|end|>"
+    assert t.batch_decode([[1, 3 + ord("a")], [0, 0, 3 + ord("b")]]) == ["a", "b"]
+
+
+class _P:
+    from phi_3_vision_mlx_amd.processor import ByteTokenizer
+    tokenizer = ByteTokenizer()
+
+
+def test_streamer_batch_trims_at_first_eos_inclusive():
+    from phi_3_vision_mlx_amd.api import ID_EOS, Streamer
+    s = Streamer(_P, stream=True, mute=False)
+    for step in ([[70], [71]], [[ID_EOS], [72]], [[73], [ID_EOS]]):
+        s(torch.tensor(step))
+    txt, n = s.end()
+    assert n == 6 and len(txt) == 2
+    assert txt[0].endswith("<|end|>") and "<73>" not in txt[0] and txt[1].endswith("<|end|>")
+
+
+def test_token_stopper_waits_for_all_rows():
+    from phi_3_vision_mlx_amd.api import ID_EOS, TokenStopper
+    ts = TokenStopper(_P, 2)
+    assert not ts(torch.tensor([[5], [6]]))
+    assert not ts(torch.tensor([[ID_EOS], [6]]))
+    assert not ts(torch.tensor([[7], [8]]))               # row 0 already finished, row 1 not yet
+    assert ts(torch.tensor([[9], [ID_EOS]]))
+
+
+def test_logit_stopper_only_active_for_int_below_max_tokens():
+    from phi_3_vision_mlx_amd.api import LogitStopper
+    assert LogitStopper(100, False).early_stop is False
+    assert LogitStopper(100, True).early_stop is False          # bool is not an int budget
+    assert LogitStopper(100, 200).early_stop is False
+    assert LogitStopper(100, 20).early_stop == 20
+
+
+def test_synthetic_weights_deterministic_and_complete():
+    from phi_3_vision_mlx_amd.config import make_config, tiny_config_dict
+    from phi_3_vision_mlx_amd.weights import synth_values, synth_weights, weight_specs
+    cfg = make_config(tiny_config_dict())
+    w1, w2 = synth_weights(cfg, seed=3), synth_weights(cfg, seed=3)
+    assert set(w1) == {n for n, _, _ in weight_specs(cfg)}
+    assert all(torch.equal(w1[k], w2[k]) for k in w1)
+    assert not torch.equal(w1["lm_head.weight"], synth_weights(cfg, seed=4)["lm_head.weight"])
+    v = synth_values(200000, 7, 0.02).float()
+    assert abs(v.std().item() - 0.02) < 5e-4 and abs(v.mean().item()) < 2e-4
+    # chunking must not change the stream (the GPU path uses bigger chunks)
+    assert torch.equal(synth_values(5000, 1, 0.02, chunk=64), synth_values(5000, 1, 0.02, chunk=4096))
+    full = make_config()
+    n_dec = sum(int(np.prod(s)) for n, s, _ in weight_specs(full) if n.startswith("model.layers.") or n == "lm_head.weight")
+    assert abs(n_dec * 2 / 1e9 - 7.445) < 0.01                   # 7.445 GB streamed per decoded token
+
+
+def test_safetensors_roundtrip_and_loader_errors(tmp_path):
+    from phi_3_vision_mlx_amd.config import load_config, make_config, tiny_config_dict
+    from phi_3_vision_mlx_amd.weights import load_safetensors_dir, save_safetensors_dir, synth_weights
+    d = tiny_config_dict(vision=False)
+    cfg = make_config(d)
+    w = synth_weights(cfg, seed=1)
+    save_safetensors_dir(w, d, str(tmp_path / "m"))
+    cfg2 = load_config(str(tmp_path / "m" / "config.json"), use_quantized_cache=False)
+    back = load_safetensors_dir(str(tmp_path / "m"), cfg2)
+    assert all(torch.equal(back[k], w[k]) for k in w)
+    with pytest.raises(FileNotFoundError):
+        load_config(str(tmp_path / "nope.json"))
+    (tmp_path / "bad.json").write_text("{not json")
+    with pytest.raises(ValueError):
+        load_config(str(tmp_path / "bad.json"))
+    del w["lm_head.weight"]
+    save_safetensors_dir(w, d, str(tmp_path / "m2"))
+    with pytest.raises(KeyError):
+        load_safetensors_dir(str(tmp_path / "m2"), cfg2)
+
+
+def test_load_rejects_out_of_scope_variants():
+    from phi_3_vision_mlx_amd import api
+    with pytest.raises(NotImplementedError):
+        api.load(use_adapter=True)
+    with pytest.raises(FileNotFoundError):
+        api.load(model_path="/definitely/not/here")
+
+
+def test_shim_exports_reference_api():
+    import inspect
+    import phi_3_vision_mlx_amd as m
+    ref = {"generate": ["prompt", "images", "preload", "blind_model", "quantize_model", "quantize_cache", "use_adapter",
+                        "max_tokens", "verbose", "return_tps", "early_stop", "stream", "apply_chat_template", "enable_api"],
+           "choose": ["prompt", "choices", "images", "preload", "blind_model", "quantize_model", "quantize_cache",
+                      "use_adapter", "verbose", "apply_chat_template"],
+           "constrain": ["prompt", "constraints", "images", "preload", "blind_model", "quantize_model", "quantize_cache",
+                         "use_adapter", "verbose", "apply_chat_template", "use_beam"],
+           "load": ["blind_model", "quantize_model", "quantize_cache", "use_adapter", "kwargs"]}
+    for fn, params in ref.items():
+        assert list(inspect.signature(getattr(m, fn)).parameters) == params, fn
+    assert inspect.signature(m.generate).parameters["max_tokens"].default == 512
+    assert inspect.signature(m.constrain).parameters["constraints"].default == [(0, "\nThe"), (100, " The correct answer is"), "ABCDE"]
+    assert m.ID_EOS == 32007 and m.ID_ASS == 32001

@@ -224,3 +224,93 @@ def test_public_generate_runs_and_reports(text, capsys):
         api.generate(["a", "b"], images=["x.png"], preload=(model, proc), apply_chat_template=False)
     txt = api.constrain("Pick one.", constraints=[(3, " The answer is"), "AB"], preload=(model, proc), verbose=False)
     assert isinstance(txt, str) and txt[-1] in "AB"
+
+
+# ----------------------------------------------------------------------------- committed golden fixtures
+GOLDEN = __import__("os").path.join(__import__("os").path.dirname(__import__("os").path.abspath(__file__)), "golden")
+
+
+def _check_topk(logits, topv, topi, what):
+    """HIP logits vs the fixture's top-16 (ids, values) of the oracle: values within tolerance at the oracle's
+    top ids, and the argmax agrees whenever the oracle's top-2 margin is clear."""
+    lg = logits.float().cpu()
+    ref_v, ref_i = torch.as_tensor(topv), torch.as_tensor(topi).long()
+    got_v = torch.gather(lg, -1, ref_i)
+    scale = ref_v.abs().max().item()
+    err = (got_v - ref_v).abs().max().item()
+    assert err <= 2.5e-2 * scale + 1e-2, f"{what}: top-k logit error {err:.4f} (scale {scale:.2f})"
+    margin = ref_v[..., 0] - ref_v[..., 1]
+    clear = margin > 5e-2 * scale
+    assert torch.equal(lg.argmax(-1)[clear], ref_i[..., 0][clear]), what
+    return clear
+
+
+def test_tiny_fixture_text_and_batch(text):
+    model, proc, _ = text
+    g = np.load(GOLDEN + "/tiny_oracle.npz")
+    from phi_3_vision_mlx_amd import ops
+    for key, inputs in (("text", {"input_ids": g["text_ids"]}),
+                        ("batch", proc(["<|user|>\nPick A or B.<|end|>\n<|assistant|>\n",
+                                        "<|user|>\nName a colour of the sky.<|end|>\n<|assistant|>\n"]))):
+        ref_tok = torch.as_tensor(g[f"{key}_tokens"]).long()
+        n = ref_tok.shape[1]
+        logits, cache = model(**inputs, max_tokens=n)
+        for step in range(n):                                   # teacher-forced with the fixture's tokens
+            _check_topk(logits[:, -1], g[f"{key}_topv"][:, step], g[f"{key}_topi"][:, step], f"{key} step {step}")
+            if step + 1 < n:
+                logits, cache = model(input_ids=ref_tok[:, step:step + 1], cache=cache, mask=inputs.get("mask"), pids=inputs.get("pids"))
+
+
+def test_tiny_fixture_vision(vis):
+    model, proc, _ = vis
+    from golden_inputs import make_image
+    g = np.load(GOLDEN + "/tiny_oracle.npz")
+    inputs = proc("<|user|>\n<|image_1|>\nWhat is shown?<|end|>\n<|assistant|>\n", [make_image(336, 336, "noise", 0)])
+    assert np.asarray(inputs["input_ids"]).shape[1] == int(g["vis_n_ids"][0])
+    ref_tok = torch.as_tensor(g["vis_tokens"]).long()
+    logits, cache = model(**inputs, max_tokens=4)
+    for step in range(4):
+        _check_topk(logits[:, -1], g["vis_topv"][:, step], g["vis_topi"][:, step], f"vision step {step}")
+        if step + 1 < 4:
+            logits, cache = model(input_ids=ref_tok[:, step:step + 1], cache=cache)
+
+
+def test_synthetic_weights_identical_on_gpu_and_cpu():
+    from phi_3_vision_mlx_amd.weights import synth_values
+    a, b = synth_values(300001, 12345, 0.02, device="cpu"), synth_values(300001, 12345, 0.02, device="cuda:0")
+    assert torch.equal(a, b.cpu())
+
+
+@pytest.fixture(scope="module")
+def full_text():
+    from phi_3_vision_mlx_amd.api import load_synthetic
+    model, proc = load_synthetic(blind_model=True, tiny=False, seed=0, device="cuda:0")
+    yield model, proc
+    del model
+    torch.cuda.empty_cache()
+
+
+def test_c1_fixture_full_size(full_text):
+    """BASELINE config 1 (Phi-3-mini-128K, 128-token prompt, greedy) at FULL size vs the oracle fixture
+    generated on CPU (tests/golden/gen_golden_oracle.py c1): same hash-seeded weights on both sides."""
+    model, _ = full_text
+    g = np.load(GOLDEN + "/c1_oracle.npz")
+    ref_tok = torch.as_tensor(g["tokens"]).long()
+    n = ref_tok.shape[1]
+    logits, cache = model(input_ids=g["ids"], max_tokens=n)
+    n_clear = 0
+    for step in range(n):
+        n_clear += int(_check_topk(logits[:, -1], g["topv"][:, step], g["topi"][:, step], f"C1 step {step}").sum())
+        if step + 1 < n:
+            logits, tok = model.greedy_step(ref_tok[:, step:step + 1].to("cuda:0", torch.int32), cache)
+    assert n_clear >= n // 2, "fixture has too few clear-margin steps to be meaningful"
+
+
+def test_full_size_decode_equals_prefill_property(full_text):
+    """Size-independent property at full size: (prefill S, decode 1) == (prefill S+1) on the last row."""
+    model, _ = full_text
+    ids = rand_ids(300, 9)
+    a, cache = model(input_ids=ids[:, :299], max_tokens=2)
+    b, _ = model(input_ids=ids[:, 299:], cache=cache)
+    c, _ = model(input_ids=ids, max_tokens=1)
+    assert_logits(b[:, -1], c[:, -1], "full-size decode vs prefill")
