@@ -183,32 +183,37 @@ def main():
     B = 1
     tokens_per_s = world * B * args.steps / elapsed
 
-    # ---- roofline of the dominant decode kernel (gate_up GEMV + SiLU*up): HIP events around each launch
+    # ---- roofline of the dominant decode kernel (gate_up GEMV + fused RMSNorm + SiLU*up): the 32 layers' launches
+    #      replayed as one hipGraph on the launch stream (exactly the launches of a decode step, weights of every
+    #      layer in turn so nothing is cache-resident), HIP events around the replay
     I, H, L = cfg.intermediate_size, cfg.hidden_size, cfg.num_hidden_layers
     alg_bytes = 2 * I * H * 2                                     # bf16 [2I, H] weights streamed once per launch
-    st = cache[0].state
-    st.offset -= 2                                                # re-run two already-written positions eagerly
-    evs = []
-    orig = ops.gemv
+    xb = torch.randn((1, H), device=dev).to(torch.bfloat16)
+    ab = torch.empty((1, I), dtype=torch.bfloat16, device=dev)
 
-    def timed_gemv(x, w, epilogue=ops.EPI_NONE, **kw):
-        if epilogue == ops.EPI_SILU_MUL:
-            a, b = ops.Event(), ops.Event()
-            a.record()
-            r = orig(x, w, epilogue, **kw)
-            b.record()
-            evs.append((a, b))
-            return r
-        return orig(x, w, epilogue, **kw)
-    ops.gemv = timed_gemv
-    try:
-        for _ in range(2):
-            model(input_ids=token, cache=cache)
-    finally:
-        ops.gemv = orig
-    torch.cuda.synchronize()
-    durs = [a.elapsed_ms(b) for a, b in evs][L:]                  # drop the first pass (cold)
-    k_ms = float(np.mean(durs))
+    def gate_up_all_layers():
+        for i in range(L):
+            ops.gemv(xb, model.w[f"model.layers.{i}.mlp.gate_up_proj.weight"], ops.EPI_SILU_MUL,
+                     norm_w=model.w[f"model.layers.{i}.post_attention_layernorm.weight"], norm_eps=cfg.rms_norm_eps, out=ab)
+    side = torch.cuda.Stream(device=dev)
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        gate_up_all_layers()
+        gr = ops.Graph()
+        gr.begin()
+        gate_up_all_layers()
+        gr.end()
+        gr.launch()
+        side.synchronize()
+        reps = []
+        for _ in range(5):
+            e0, e1 = ops.Event(), ops.Event()
+            e0.record()
+            gr.launch()
+            e1.record()
+            side.synchronize()
+            reps.append(e0.elapsed_ms(e1) / L)
+    k_ms = float(np.median(reps))
     achieved = alg_bytes / (k_ms * 1e-3) / 1e9
 
     kv_bytes = 2 * L * cfg.num_key_value_heads * (cfg.hidden_size // cfg.num_attention_heads) * 2 * (S + args.warmup + args.steps // 2)
@@ -226,7 +231,7 @@ def main():
         "decode_step_hbm": {"algorithmic_GB_per_token": round((w_bytes + kv_bytes) / 1e9, 3),
                             "achieved_GBps": round((w_bytes + kv_bytes) / step_s / 1e9, 1),
                             "frac_of_peak": round((w_bytes + kv_bytes) / step_s / 1e9 / HBM_PEAK_GBS, 4)},
-        "roofline": {"bound": "hbm", "kernel": "k_gemv<1> gate_up_proj+SiLU*up", "achieved": round(achieved, 1),
+        "roofline": {"bound": "hbm", "kernel": "k_gemv3<1,1,6> (RMSNorm + gate_up_proj + SiLU*up), 32 launches/step", "achieved": round(achieved, 1),
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                      "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(k_ms, 5)},
         "first_token": first, "weights_init_s": round(t_weights, 1),
