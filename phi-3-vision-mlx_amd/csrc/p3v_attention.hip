@@ -44,6 +44,7 @@ __global__ void __launch_bounds__(256) k_attn(AttnP p) {
   const int past = p.d_past ? *p.d_past : p.past;
   const int total = past + p.L;
   const int pad = p.pad_len ? p.pad_len[b / p.pad_div] : 0;
+  const float sc2 = p.scale * 1.4426950408889634f;   // scale * log2(e): softmax (and the split partials) run on exp2
 
   int q0, kv_begin, kv_end;
   bool active;
@@ -138,7 +139,7 @@ __global__ void __launch_bounds__(256) k_attn(AttnP p) {
       for (int r = 0; r < 4; ++r) {
         const int t = kv0 + 16 * st + 4 * g + r;
         const bool vis = t < kv_end && t >= pad && (!p.causal || t <= qpos) && qpos >= pad;
-        const float v = vis ? s[st][r] * p.scale : -INFINITY;
+        const float v = vis ? s[st][r] * sc2 : -INFINITY;                 // log2 domain
         s[st][r] = v;
         m_t = fmaxf(m_t, v);
       }
@@ -146,13 +147,13 @@ __global__ void __launch_bounds__(256) k_attn(AttnP p) {
     m_t = fmaxf(m_t, __shfl_xor(m_t, 32, 64));
     const float m_new = fmaxf(m_run, m_t);
     const float m_use = m_new == -INFINITY ? 0.f : m_new;
-    const float alpha = __expf(m_run - m_use);       // m_run = -inf -> 0
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);       // m_run = -inf -> 0
     float l_t = 0.f;
 #pragma unroll
     for (int st = 0; st < 4; ++st)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float e = __expf(s[st][r] - m_use);
+        const float e = __builtin_amdgcn_exp2f(s[st][r] - m_use);
         s[st][r] = e;
         l_t += e;
       }
@@ -201,6 +202,222 @@ __global__ void __launch_bounds__(256) k_attn(AttnP p) {
 }
 
 __global__ void k_attn_combine2(const float* __restrict__ ws, bf16_t* __restrict__ out, int L, int nh, int hd, int n_split);
+// =====================================================================================
+// Prefill / CLIP attention (L > 16): 128 queries per workgroup (4 waves x 2 sub-tiles of 16), 64-key tiles,
+// two LDS buffers.  The next tile's global loads are issued BEFORE the MFMAs of the current tile and written
+// to the other LDS buffer after them (split stage: HBM/L2 latency hides under the matrix work), one barrier
+// per tile.  K and V^T fragments read from LDS are shared by the wave's two query sub-tiles (48 MFMAs per
+// 24 + 24 fragment reads).  Same swapped-MFMA formulation and masks as k_attn above.
+template <int HD>
+__global__ void __launch_bounds__(256, 2) k_attn_prefill(AttnP p) {
+  constexpr int KSTR = HD * 2 + 16, VSTR = 64 * 2 + 16, NKS = HD / 32, NDT = HD / 16, CPR = HD / 8;
+  constexpr int KTILE = 64 * KSTR, VTILE = HD * VSTR, BUF = KTILE + VTILE;
+  constexpr int NLD = (64 * CPR + 255) / 256;               // 16-byte K loads per thread per tile (= V^T loads)
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, qi = lane & 15;
+  const int b = blockIdx.z, head = blockIdx.y, kvh = head / (p.nh / p.nkv);
+  const int past = p.d_past ? *p.d_past : p.past;
+  const int total = past + p.L;
+  const int pad = p.pad_len ? p.pad_len[b / p.pad_div] : 0;
+  const int qb0 = blockIdx.x * 128, q0 = qb0 + wave * 32;
+  const int kv_end = p.causal ? min(total, past + qb0 + 128) : total;
+  const int kv_begin = pad & ~63;
+  const int wave_last = p.causal ? past + q0 + 31 : total;  // last key position this wave can see
+  const float sc2 = p.scale * 1.4426950408889634f;          // scale * log2(e)
+
+  bf16x8_t qf[2][NKS];
+  int qpos[2];
+  bool qvalid[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int qrow = q0 + u * 16 + qi;
+    qvalid[u] = qrow < p.L;
+    qpos[u] = past + qrow;
+    const bf16_t* qp = p.q + (((size_t)b * p.nh + head) * p.L + (qvalid[u] ? qrow : 0)) * HD + 8 * g;
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+      u32x4_t v = *(const u32x4_t*)(qp + 32 * ks);
+      if (!qvalid[u]) v = (u32x4_t){0, 0, 0, 0};
+      qf[u][ks] = __builtin_bit_cast(bf16x8_t, v);
+    }
+  }
+  const bf16_t* kp_base = p.k_past + ((size_t)(b / p.past_div) * p.nkv + kvh) * (size_t)p.past_t * HD;
+  const bf16_t* vp_base = p.v_past + ((size_t)(b / p.past_div) * p.nkv + kvh) * (size_t)HD * p.past_t;
+  const bf16_t* kn_base = p.k_new + ((size_t)b * p.nkv + kvh) * (size_t)p.new_t * HD;
+  const bf16_t* vn_base = p.v_new + ((size_t)b * p.nkv + kvh) * (size_t)HD * p.new_t;
+
+  u32x4_t kst[NLD], vst[NLD];
+  auto stage_load = [&](int kv0) {
+#pragma unroll
+    for (int it = 0; it < NLD; ++it) {
+      const int i = it * 256 + tid;
+      kst[it] = (u32x4_t){0, 0, 0, 0};
+      vst[it] = (u32x4_t){0, 0, 0, 0};
+      if (i < 64 * CPR) {
+        const int key = i / CPR, c = i % CPR, t = kv0 + key;
+        if (t < kv_end) {
+          const bool fp = t < past || p.new_is_cache;
+          kst[it] = *(const u32x4_t*)((fp ? kp_base + (size_t)t * HD : kn_base + (size_t)(t - past) * HD) + c * 8);
+        }
+        const int d = i >> 3, c8 = i & 7, t0 = kv0 + c8 * 8;       // HD*8 == 64*CPR chunks as well
+        if (t0 < kv_end) {
+          if (t0 + 8 <= past || p.new_is_cache) {
+            vst[it] = *(const u32x4_t*)(vp_base + (size_t)d * p.past_t + t0);
+          } else {
+            bf16_t e[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              const int t = t0 + j;
+              e[j] = t < past ? vp_base[(size_t)d * p.past_t + t] : (t < kv_end ? vn_base[(size_t)d * p.new_t + (t - past)] : (bf16_t)0);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) vst[it][j] = (uint32_t)e[2 * j] | ((uint32_t)e[2 * j + 1] << 16);
+          }
+        }
+      }
+    }
+  };
+  auto stage_write = [&](int buf) {
+    unsigned char* Ks = smem + buf * BUF;
+    unsigned char* Vt = Ks + KTILE;
+#pragma unroll
+    for (int it = 0; it < NLD; ++it) {
+      const int i = it * 256 + tid;
+      if (i < 64 * CPR) {
+        *(u32x4_t*)(Ks + (i / CPR) * KSTR + (i % CPR) * 16) = kst[it];
+        *(u32x4_t*)(Vt + (i >> 3) * VSTR + (i & 7) * 16) = vst[it];
+      }
+    }
+  };
+
+  float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};
+  f32x4_t o[2][NDT];
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+#pragma unroll
+    for (int d = 0; d < NDT; ++d) o[u][d] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  if (kv_begin < kv_end) { stage_load(kv_begin); stage_write(0); }
+  __syncthreads();
+  int buf = 0;
+  for (int kv0 = kv_begin; kv0 < kv_end; kv0 += 64, buf ^= 1) {
+    const bool more = kv0 + 64 < kv_end;
+    if (more) stage_load(kv0 + 64);                         // in flight during the MFMAs below
+    if (kv0 <= wave_last) {                                 // wave-uniform: tiles above this wave's diagonal are skipped
+      const unsigned char* Ks = smem + buf * BUF;
+      const unsigned char* Vt = Ks + KTILE;
+      f32x4_t s[2][4];
+#pragma unroll
+      for (int st = 0; st < 4; ++st) {
+        s[0][st] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        s[1][st] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+          const bf16x8_t kf = *(const bf16x8_t*)(Ks + (16 * st + qi) * KSTR + (32 * ks + 8 * g) * 2);
+          s[0][st] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[0][ks], s[0][st], 0, 0, 0);
+          s[1][st] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[1][ks], s[1][st], 0, 0, 0);
+        }
+      }
+      // every key of the tile visible to every query of the wave -> no per-element mask work (wave-uniform)
+      const bool interior = kv0 + 64 <= kv_end && kv0 >= pad && past + q0 >= pad && (!p.causal || kv0 + 63 <= past + q0);
+      bf16x8_t pf[2][2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        float m_t = -INFINITY;
+        if (interior) {
+#pragma unroll
+          for (int st = 0; st < 4; ++st)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) m_t = fmaxf(m_t, s[u][st][r]);
+        } else {
+#pragma unroll
+          for (int st = 0; st < 4; ++st)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int t = kv0 + 16 * st + 4 * g + r;
+              const bool vis = t < kv_end && t >= pad && (!p.causal || t <= qpos[u]) && qpos[u] >= pad;
+              const float v = vis ? s[u][st][r] : -INFINITY;
+              s[u][st][r] = v;
+              m_t = fmaxf(m_t, v);
+            }
+        }
+        m_t = fmaxf(m_t, __shfl_xor(m_t, 16, 64));
+        m_t = fmaxf(m_t, __shfl_xor(m_t, 32, 64));
+        // running max / exponentials in the log2 domain: exp(x*scale - m) = exp2(x*c - m2), c = scale*log2(e)
+        const float m_new = fmaxf(m_run[u], m_t * sc2);
+        const float m_use = m_new == -INFINITY ? 0.f : m_new;
+        const float alpha = __builtin_amdgcn_exp2f(m_run[u] - m_use);
+        float l_t = 0.f;
+#pragma unroll
+        for (int st = 0; st < 4; ++st)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float e = __builtin_amdgcn_exp2f(fmaf(s[u][st][r], sc2, -m_use));
+            s[u][st][r] = e;
+            l_t += e;
+          }
+        l_t += __shfl_xor(l_t, 16, 64);
+        l_t += __shfl_xor(l_t, 32, 64);
+        l_run[u] = l_run[u] * alpha + l_t;
+        m_run[u] = m_new;
+        if (!__all(alpha == 1.f)) {
+#pragma unroll
+          for (int d = 0; d < NDT; ++d) o[u][d] *= alpha;
+        }
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+          u32x4_t pw;
+          pw[0] = pack_bf16x2(s[u][2 * st][0], s[u][2 * st][1]);
+          pw[1] = pack_bf16x2(s[u][2 * st][2], s[u][2 * st][3]);
+          pw[2] = pack_bf16x2(s[u][2 * st + 1][0], s[u][2 * st + 1][1]);
+          pw[3] = pack_bf16x2(s[u][2 * st + 1][2], s[u][2 * st + 1][3]);
+          pf[u][st] = __builtin_bit_cast(bf16x8_t, pw);
+        }
+      }
+#pragma unroll
+      for (int st = 0; st < 2; ++st)
+#pragma unroll
+        for (int d = 0; d < NDT; ++d) {
+          const unsigned char* vr = Vt + (16 * d + qi) * VSTR + (32 * st + 4 * g) * 2;
+          const u32x2_t a0 = *(const u32x2_t*)vr, a1 = *(const u32x2_t*)(vr + 32);
+          const u32x4_t aw = {a0[0], a0[1], a1[0], a1[1]};
+          const bf16x8_t vf = __builtin_bit_cast(bf16x8_t, aw);
+          o[0][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[0][st], o[0][d], 0, 0, 0);
+          o[1][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[1][st], o[1][d], 0, 0, 0);
+        }
+    }
+    if (more) stage_write(buf ^ 1);
+    __syncthreads();
+  }
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    if (!qvalid[u]) continue;
+    const float inv = l_run[u] > 0.f ? 1.f / l_run[u] : 0.f;
+    bf16_t* op = p.out + ((size_t)b * p.L + (q0 + u * 16 + qi)) * (size_t)(p.nh * HD) + head * HD + 4 * g;
+#pragma unroll
+    for (int d = 0; d < NDT; ++d) {
+      u32x2_t w;
+      w[0] = pack_bf16x2(o[u][d][0] * inv, o[u][d][1] * inv);
+      w[1] = pack_bf16x2(o[u][d][2] * inv, o[u][d][3] * inv);
+      *(u32x2_t*)(op + 16 * d) = w;
+    }
+  }
+}
+
+template <int HD>
+static int launch_attn_prefill(const AttnP& p, hipStream_t s) {
+  constexpr int LDS = 2 * (64 * (HD * 2 + 16) + HD * (64 * 2 + 16));
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)k_attn_prefill<HD>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
+      return P3V_ERR_HIP;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(k_attn_prefill<HD>, dim3(p3v_cdiv(p.L, 128), p.nh, p.B), dim3(256), LDS, s, p);
+  P3V_CHECK_LAUNCH();
+  return P3V_OK;
+}
+
 
 extern "C" int64_t p3v_attention_ws_bytes(int B, int L, int n_heads, int hd, int n_split) {
   if (L > P3V_DECODE_MAX_L || n_split < 1) return 0;
@@ -226,6 +443,8 @@ extern "C" int p3v_attention(const p3v_attn_args_t* a, void* stream) {
   if (p.split_mode && !a->ws) return P3V_ERR_ARG;
   if (!p.split_mode) p.n_split = 1;
   hipStream_t s = (hipStream_t)stream;
+  if (!p.split_mode && a->L > P3V_DECODE_MAX_L && !getenv("P3V_ATTN_OLD"))
+    return a->hd == 96 ? launch_attn_prefill<96>(p, s) : launch_attn_prefill<64>(p, s);
   dim3 grid(p.split_mode ? p.n_split : p3v_cdiv(a->L, 64), a->n_heads, a->B);
   if (a->hd == 96) hipLaunchKernelGGL(k_attn<96>, grid, dim3(256), 0, s, p);
   else hipLaunchKernelGGL(k_attn<64>, grid, dim3(256), 0, s, p);
@@ -286,6 +505,7 @@ __global__ void __launch_bounds__(64) k_attn_decode(AttnDecP p) {
   const int lane = threadIdx.x, g = lane >> 4, qi = lane & 15;
   const int b = blockIdx.z, head = blockIdx.y, kvh = head / (p.nh / p.nkv);
   const bool kv_writer = head % (p.nh / p.nkv) == 0;
+  const float sc2 = p.scale * 1.4426950408889634f;            // scale * log2(e): softmax runs on exp2
   const int row_w = (p.nh + 2 * p.nkv) * HD;                  // qkv row width
   const bf16_t* kc = p.k_cache + ((size_t)b * p.nkv + kvh) * (size_t)p.cache_t * HD;
   bf16_t* vc = p.v_cache + ((size_t)b * p.nkv + kvh) * (size_t)HD * p.cache_t;          // V^T: [hd][cache_t]
@@ -399,7 +619,7 @@ __global__ void __launch_bounds__(64) k_attn_decode(AttnDecP p) {
       for (int r = 0; r < 4; ++r) {
         const int t = kv0 + 16 * st + 4 * g + r;
         const bool vis = t < kv_end && t >= pad && t <= qpos && qpos >= pad;
-        const float v = vis ? s[st][r] * p.scale : -INFINITY;
+        const float v = vis ? s[st][r] * sc2 : -INFINITY;               // log2 domain: scale*log2(e) folded in
         s[st][r] = v;
         m_t = fmaxf(m_t, v);
       }
@@ -407,13 +627,13 @@ __global__ void __launch_bounds__(64) k_attn_decode(AttnDecP p) {
     m_t = fmaxf(m_t, __shfl_xor(m_t, 32, 64));
     const float m_new = fmaxf(m_run, m_t);
     const float m_use = m_new == -INFINITY ? 0.f : m_new;
-    const float alpha = __expf(m_run - m_use);
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);
     float l_t = 0.f;
 #pragma unroll
     for (int st = 0; st < TK / 16; ++st)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float e = __expf(s[st][r] - m_use);
+        const float e = __builtin_amdgcn_exp2f(s[st][r] - m_use);
         s[st][r] = e;
         l_t += e;
       }
@@ -468,7 +688,7 @@ __global__ void __launch_bounds__(256) k_attn_combine2(const float* __restrict__
     const float o0 = base[s * sstr + d0], o1 = two ? base[s * sstr + d0 + 64] : 0.f;
     const float mn = fmaxf(m, ms);
     const float mu = mn == -INFINITY ? 0.f : mn;
-    const float ca = __expf(m - mu), cb = __expf(ms - mu);    // exp(-inf) = 0 covers empty partials
+    const float ca = __builtin_amdgcn_exp2f(m - mu), cb = __builtin_amdgcn_exp2f(ms - mu);   // partial maxima are log2-domain; exp2(-inf) = 0 covers empty partials
     l = l * ca + ls * cb;
     a0 = a0 * ca + o0 * cb;
     a1 = a1 * ca + o1 * cb;
@@ -484,7 +704,7 @@ __global__ void __launch_bounds__(256) k_attn_combine2(const float* __restrict__
     float acc = 0.f, lsum = 0.f;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const float c = __expf(pm[k] - Mu);
+      const float c = __builtin_amdgcn_exp2f(pm[k] - Mu);
       acc += c * part[k][t];
       lsum += c * pl[k];
     }

@@ -23,17 +23,18 @@ typedef __attribute__((ext_vector_type(2))) uint32_t u32x2_t;
 
 __device__ __forceinline__ float bf16_to_f32(bf16_t u) { return __uint_as_float(((uint32_t)u) << 16); }
 
-// round-to-nearest-even, NaN preserved
+// round-to-nearest-even through the native conversion (v_cvt_pk_bf16_f32 on gfx950: one VALU op per PAIR,
+// where the integer formulation costs ~10 -- it was the largest VALU item of the attention softmax)
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
 __device__ __forceinline__ bf16_t f32_to_bf16(float f) {
-  uint32_t x = __float_as_uint(f);
-  if ((x & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((x >> 16) | 0x40);
-  x += 0x7fffu + ((x >> 16) & 1u);
-  return (bf16_t)(x >> 16);
+  const __bf16 h = (__bf16)f;
+  return __builtin_bit_cast(bf16_t, h);
 }
 __device__ __forceinline__ float bf16_round(float f) { return bf16_to_f32(f32_to_bf16(f)); }
 
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
-  return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+  const bf16x2_t r = {(__bf16)lo, (__bf16)hi};
+  return __builtin_bit_cast(uint32_t, r);
 }
 __device__ __forceinline__ float bf16lo(uint32_t w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float bf16hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }

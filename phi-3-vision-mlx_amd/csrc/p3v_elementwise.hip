@@ -143,7 +143,7 @@ __global__ void __launch_bounds__(256) k_rope_kv_append(const bf16_t* __restrict
                                                         const float* __restrict__ sin_t, bf16_t* __restrict__ q_out,
                                                         bf16_t* __restrict__ k_dst, bf16_t* __restrict__ v_dst, int L,
                                                         int nh, int nkv, int hd, int past, const int32_t* d_past,
-                                                        int dst_t, int dst_off_is_past, int tab_t, int tab_div) {
+                                                        int dst_t, int dst_off_is_past, int tab_t, int tab_div, int skip_v) {
   const int tok = blockIdx.x, b = tok / L, l = tok % L;
   if (d_past) past = *d_past;
   const int half = hd >> 1, hc = half >> 3;          // 8-wide chunks per half
@@ -154,7 +154,7 @@ __global__ void __launch_bounds__(256) k_rope_kv_append(const bf16_t* __restrict
   const bf16_t* row = qkv + (size_t)tok * (nh + 2 * nkv) * hd;
   const int dpos = (dst_off_is_past ? past : 0) + l;
   const int n_rot = (nh + nkv) * hc;
-  const int n_v = nkv * (hd >> 3);
+  const int n_v = skip_v ? 0 : nkv * (hd >> 3);
   for (int it = threadIdx.x; it < n_rot + n_v; it += blockDim.x) {
     if (it < n_rot) {
       const int head = it / hc, c = it % hc;
@@ -192,16 +192,60 @@ __global__ void __launch_bounds__(256) k_rope_kv_append(const bf16_t* __restrict
   }
 }
 
+// V rows of 64 tokens x one kv head -> V^T columns, transposed through LDS so that both the qkv reads (192 B
+// per token) and the cache writes (128 B per d row) are full-line vector accesses.
+__global__ void __launch_bounds__(256) k_v_transpose_append(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ v_dst, int L,
+                                                            int nh, int nkv, int hd, int past, const int32_t* d_past,
+                                                            int dst_t, int dst_off_is_past) {
+  __shared__ __attribute__((aligned(16))) bf16_t tile[64 * (96 + 8)];
+  const int ld = hd + 8, cpr = hd >> 3;
+  const int l0 = blockIdx.x * 64, head = blockIdx.y, b = blockIdx.z;
+  if (d_past) past = *d_past;
+  const int row_w = (nh + 2 * nkv) * hd;
+  for (int i = threadIdx.x; i < 64 * cpr; i += 256) {
+    const int tok = i / cpr, c = i % cpr, l = l0 + tok;
+    u32x4_t v = {0, 0, 0, 0};
+    if (l < L) v = *(const u32x4_t*)(qkv + ((size_t)b * L + l) * row_w + (size_t)(nh + nkv + head) * hd + c * 8);
+    *(u32x4_t*)(tile + tok * ld + c * 8) = v;
+  }
+  __syncthreads();
+  const int dpos0 = (dst_off_is_past ? past : 0) + l0;
+  bf16_t* base = v_dst + ((size_t)b * nkv + head) * (size_t)hd * dst_t + dpos0;
+  const bool aligned = (dpos0 & 7) == 0;
+  for (int i = threadIdx.x; i < hd * 8; i += 256) {
+    const int d = i >> 3, c = i & 7, n_ok = min(8, L - (l0 + c * 8));
+    if (n_ok <= 0) continue;
+    bf16_t e[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) e[j] = tile[(c * 8 + j) * ld + d];
+    bf16_t* dst = base + (size_t)d * dst_t + c * 8;
+    if (aligned && n_ok == 8) {
+      u32x4_t w;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) w[j] = (uint32_t)e[2 * j] | ((uint32_t)e[2 * j + 1] << 16);
+      *(u32x4_t*)dst = w;
+    } else {
+      for (int j = 0; j < n_ok; ++j) dst[j] = e[j];
+    }
+  }
+}
+
 extern "C" int p3v_rope_kv_append(const uint16_t* qkv, const float* cos_t, const float* sin_t, uint16_t* q_out,
                                   uint16_t* k_dst, uint16_t* v_dst, int B, int L, int n_heads, int n_kv, int hd, int past,
                                   const int32_t* d_past, int dst_t, int dst_off_is_past, int tab_t, int tab_div,
                                   void* stream) {
   if (!qkv || !q_out || !k_dst || !v_dst || (!cos_t) != (!sin_t)) return P3V_ERR_ARG;
-  if (B < 0 || L < 0 || hd % 16 || n_heads <= 0 || n_kv <= 0 || tab_div <= 0) return P3V_ERR_ARG;
+  if (B < 0 || L < 0 || hd % 16 || hd > 96 || n_heads <= 0 || n_kv <= 0 || tab_div <= 0) return P3V_ERR_ARG;
   if (B * L == 0) return P3V_OK;
+  const int bulk_v = L >= 32;                             // prefill-shaped: V goes through the LDS transpose kernel
   hipLaunchKernelGGL(k_rope_kv_append, dim3(B * L), dim3(256), 0, (hipStream_t)stream, qkv, cos_t, sin_t, q_out, k_dst,
-                     v_dst, L, n_heads, n_kv, hd, past, d_past, dst_t, dst_off_is_past, tab_t, tab_div);
+                     v_dst, L, n_heads, n_kv, hd, past, d_past, dst_t, dst_off_is_past, tab_t, tab_div, bulk_v);
   P3V_CHECK_LAUNCH();
+  if (bulk_v) {
+    hipLaunchKernelGGL(k_v_transpose_append, dim3(p3v_cdiv(L, 64), n_kv, B), dim3(256), 0, (hipStream_t)stream, qkv, v_dst, L,
+                       n_heads, n_kv, hd, past, d_past, dst_t, dst_off_is_past);
+    P3V_CHECK_LAUNCH();
+  }
   return P3V_OK;
 }
 

@@ -156,10 +156,11 @@ def test_gemv(ops, orc, M, N, K, epi):
     close(out, ref, rtol=2 ** -6, atol=2e-2)
 
 
-def test_rope_table_and_append(ops, orc):
+@pytest.mark.parametrize("L,T,past", [(5, 40, 7), (70, 128, 8), (100, 192, 3), (64, 64, 0)])
+def test_rope_table_and_append(ops, orc, L, T, past):
     from phi_3_vision_mlx_amd.config import make_config, rope_scaling_factor
     cfg = make_config()
-    B, L, T, nh, nkv, hd, past = 2, 5, 40, 4, 4, 96, 7
+    B, nh, nkv, hd = 2, 4, 4, 96
     pids = torch.stack([torch.arange(T), torch.cat([torch.ones(3, dtype=torch.long), torch.arange(T - 3)])])
     cos_ref, sin_ref = orc.su_rope_tables(cfg, T, pids[:, :12])
     inv = 1.0 / (torch.tensor(cfg.rope_scaling["short_factor"], dtype=F32) * (10000.0 ** (torch.arange(0, hd, 2, dtype=F32) / hd)))

@@ -43,6 +43,16 @@ def gemv_case(name, M, N, K, epi, norm=False):
     gb = rows * K * 2 / ms / 1e6
     print(f"gemv {name:28s} M={M:6d} N={N:6d} K={K:5d}  {ms*1e3:9.1f} us  {gb:8.1f} GB/s  ({gb/80:.1f}% of 8 TB/s)")
 
+def attn_case(name, B, L, nh, hd, causal):
+    Tp = (L + 63) // 64 * 64
+    q = torch.randn(B, nh, L, hd, device="cuda").bfloat16()
+    k = torch.randn(B, nh, Tp, hd, device="cuda").bfloat16()
+    v = torch.randn(B, nh, hd, Tp, device="cuda").bfloat16()
+    out = torch.empty(B, L, nh * hd, device="cuda", dtype=torch.bfloat16)
+    ms = timeit(lambda i: ops.attention(q, out, B, L, nh, nh, hd, hd ** -0.5, causal, k_past=k, v_past=v, past_t=Tp, new_is_cache=True), 1, iters=10)
+    fl = 4 * B * nh * L * L * hd * (0.5 if causal else 1.0)
+    print(f"attn {name:28s} B={B:3d} L={L:5d} heads={nh} hd={hd}  {ms*1e3:9.1f} us  {fl/ms/1e9:8.1f} TF/s")
+
 if __name__ == "__main__":
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
     if which in ("all", "gemm"):
@@ -59,6 +69,10 @@ if __name__ == "__main__":
         gemm_case("proj0 gelu", 2509, 3072, 4096, ops.EPI_BIAS_GELU)
         gemm_case("square 4096", 4096, 4096, 4096, ops.EPI_NONE)
         gemm_case("square 8192", 8192, 8192, 8192, ops.EPI_NONE)
+    if which in ("all", "attn"):
+        attn_case("decoder prefill causal", 1, 2531, 32, 96, True)
+        attn_case("decoder prefill 8k causal", 1, 8192, 32, 96, True)
+        attn_case("clip 17 crops", 17, 577, 16, 64, False)
     if which in ("all", "gemv"):
         for M in (1, 8):
             gemv_case("qkv +norm", M, 9216, 3072, ops.EPI_NONE, True)
