@@ -81,7 +81,8 @@ typedef struct {
 } p3v_gemm_args_t;
 int p3v_gemm(const p3v_gemm_args_t* args /* host */, void* stream);
 
-/* ---- skinny projection for decode: y[M,N] = x[M,K] * W[N,K]^T, M <= 16, weight-streaming.
+/* ---- skinny projection for decode: y[M,N] = x[M,K] * W[N,K]^T, M <= 16, weight-streaming
+ * (M == 1: VALU dot products; 2 <= M <= 16: the weight rows go straight from HBM into MFMA fragments).
  * Same call sites as p3v_gemm when L*B is small.  Optional fused RMSNorm of x
  * (norm_w != null: x is normalised with norm_w/eps before use, phi.py:482,484).
  * Epilogues: NONE, RESID_BF16, SILU_MUL (W = [gate;up]), F32. */
@@ -92,10 +93,12 @@ typedef struct {
   const uint16_t* resid;  /* [M, N] bf16 or null; may alias out */
   const uint16_t* norm_w; /* [K] bf16 or null */
   float norm_eps;
-  int M, N, K;            /* M <= 8, K % 8 == 0, M*K*2 bytes must fit LDS */
+  int M, N, K;            /* M <= 16, K % 8 == 0 (M > 8 needs K % 512 == 0) */
   int epilogue;
+  float* ws;              /* reserved (optional scratch, p3v_gemv_ws_bytes(M, N, K) bytes; currently 0) */
 } p3v_gemv_args_t;
 int p3v_gemv(const p3v_gemv_args_t* args /* host */, void* stream);
+int64_t p3v_gemv_ws_bytes(int M, int N, int K);
 
 /* ---- SuRoPE tables, phi.py:487-504: cos/sin[n_pos, half] = {cos,sin}(pos*inv_freq)*scale (fp32) */
 int p3v_rope_table(const float* pos, const float* inv_freq, float scale, float* cos_out, float* sin_out,

@@ -30,7 +30,7 @@ class GemmArgs(C.Structure):
 
 class GemvArgs(C.Structure):
     _fields_ = [("x", vp), ("W", vp), ("out", vp), ("resid", vp), ("norm_w", vp), ("norm_eps", f32),
-                ("M", i32), ("N", i32), ("K", i32), ("epilogue", i32)]
+                ("M", i32), ("N", i32), ("K", i32), ("epilogue", i32), ("ws", vp)]
 
 
 class AttnArgs(C.Structure):
@@ -58,6 +58,7 @@ SIGNATURES = {
     "p3v_layernorm": (i32, [vp, vp, vp, vp, i32, i32, i32, f32, vp]),
     "p3v_gemm": (i32, [C.POINTER(GemmArgs), vp]),
     "p3v_gemv": (i32, [C.POINTER(GemvArgs), vp]),
+    "p3v_gemv_ws_bytes": (i64, [i32, i32, i32]),
     "p3v_rope_table": (i32, [vp, vp, f32, vp, vp, i32, i32, vp]),
     "p3v_rope_kv_append": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, i32, i32, i32, i32, vp]),
     "p3v_attention": (i32, [C.POINTER(AttnArgs), vp]),

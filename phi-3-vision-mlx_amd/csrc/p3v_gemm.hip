@@ -56,8 +56,22 @@ __global__ void __launch_bounds__(256, 2) k_gemm(GemmP p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
   const int n_out_tile = SILU ? BN / 2 : BN;
-  const int m0 = blockIdx.y * BM;
-  const int n0 = blockIdx.x * n_out_tile;
+  // XCD-aware tile order: the dispatcher places workgroup i on XCD i % 8 (speed only, never correctness), so
+  // give each XCD a contiguous run of tiles; inside a run tiles walk N fastest within a band of 8 M-tiles,
+  // i.e. the tiles resident on one XCD share A row panels and W panels through that XCD's 4 MiB L2.
+  int m_t, n_t;
+  {
+    const int gx = gridDim.x, gy = gridDim.y, nwg = gx * gy, wid = blockIdx.y * gx + blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = wid & 7, loc = wid >> 3;
+    const int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;       // bijective for any nwg
+    constexpr int BAND = 8;
+    const int band = id / (BAND * gx), in_band = id % (BAND * gx);
+    const int rows = min(BAND, gy - band * BAND);
+    m_t = band * BAND + in_band % rows;
+    n_t = in_band / rows;
+  }
+  const int m0 = m_t * BM;
+  const int n0 = n_t * n_out_tile;
 
   // ---- staging addresses: wave w issues 4 DMA pieces per operand, piece q covers tile rows (w*4+q)*8 .. +8
   const int srow = lane >> 3, schunk = lane & 7;

@@ -320,15 +320,124 @@ static int launch_gemv3(const GemvP& p, hipStream_t s) {
   return P3V_OK;
 }
 
+// ---------------------------------------------------------------------------
+// Batched decode / constrained decoding (2 <= M <= 16 rows of x): the same weight stream, but the
+// dot products go through the matrix cores so that the cost does not grow with M:
+//   C[n, m] = W[n, :] . x[m, :]   v_mfma_f32_16x16x32_bf16 with A = 16 weight rows loaded STRAIGHT from
+//   HBM into the fragment (lane l: row l&15, 16 bytes at k = 32*ks + 8*(l>>4); two consecutive k-steps
+//   complete each 128-byte line) and B = x^T loaded straight from L2 in the same shape -- no LDS staging,
+//   no barriers in the stream.  A workgroup = 16 output rows (SiLU*up: 16 gate + the matching 16 up rows);
+//   its 4 waves split K four ways and merge their 16x16 partials (and the RMSNorm sums of squares, which
+//   ride along with the x fragments) through LDS once at the end.
+// The fused RMSNorm is applied as  (W . bf16(x*g)) * rsqrt(mean x^2 + eps)  -- the row factor commutes
+// with the dot product, so no pass over x is needed before streaming starts.
+#define GM_G 8                           // k-steps per pipeline stage (8 x 32 = 256 k)
+
+template <bool SILU>
+__global__ void __launch_bounds__(256) k_gemv_mfma(GemvP p) {
+  __shared__ float cpart[4][2][256];
+  __shared__ float sspart[4][16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, li = lane & 15;
+  const int n_base = blockIdx.x * 16;
+  const int kq = p.K >> 2, k_lo = wave * kq, n_st = kq / (32 * GM_G);          // this wave's K quarter
+  const int n_row = min(n_base + li, p.N - 1);                                  // clamped: loads stay unconditional
+  const bf16_t* w0 = p.W + (size_t)n_row * p.K + k_lo + 8 * g;
+  const bf16_t* w1 = p.W + (size_t)(n_row + p.N) * p.K + k_lo + 8 * g;          // up rows (SILU only)
+  const bf16_t* xp = p.x + (size_t)min(li, p.M - 1) * p.K + k_lo + 8 * g;
+  const bf16_t* gp = p.norm_w ? p.norm_w + k_lo + 8 * g : nullptr;
+
+  u32x4_t wa[2][GM_G], wb[2][GM_G], xa[2][GM_G], ga[2][GM_G];
+  auto issue = [&](int st, auto bufc) {
+    constexpr int buf = decltype(bufc)::value;
+#pragma unroll
+    for (int ks = 0; ks < GM_G; ++ks) {
+      const int off = (st * GM_G + ks) * 32;
+      wa[buf][ks] = __builtin_nontemporal_load((const u32x4_t*)(w0 + off));
+      if (SILU) wb[buf][ks] = __builtin_nontemporal_load((const u32x4_t*)(w1 + off));
+      xa[buf][ks] = *(const u32x4_t*)(xp + off);
+      if (gp) ga[buf][ks] = *(const u32x4_t*)(gp + off);
+    }
+  };
+  f32x4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+  float ss = 0.f;
+  auto compute = [&](auto bufc) {
+    constexpr int buf = decltype(bufc)::value;
+#pragma unroll
+    for (int ks = 0; ks < GM_G; ++ks) {
+      u32x4_t xv = xa[buf][ks];
+      if (gp) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float a = bf16lo(xv[j]), b = bf16hi(xv[j]);
+          ss += a * a + b * b;
+          xv[j] = pack_bf16x2(a * bf16lo(ga[buf][ks][j]), b * bf16hi(ga[buf][ks][j]));
+        }
+      }
+      const bf16x8_t xb = __builtin_bit_cast(bf16x8_t, xv);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wa[buf][ks]), xb, acc0, 0, 0, 0);
+      if (SILU) acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wb[buf][ks]), xb, acc1, 0, 0, 0);
+    }
+  };
+  issue(0, IC0{});
+  int st = 0;
+  while (st + 2 < n_st) {                                             // branch-free body: counted vmcnt survives
+    issue(st + 1, IC1{}); compute(IC0{});
+    issue(st + 2, IC0{}); compute(IC1{});
+    st += 2;
+  }
+  if (st + 1 < n_st) { issue(st + 1, IC1{}); compute(IC0{}); compute(IC1{}); }
+  else compute(IC0{});
+
+  // ---- merge the four K quarters.  C layout: lane holds outputs n = n_base + 4*g + r of x row m = li
+  ss += __shfl_xor(ss, 16, 64);
+  ss += __shfl_xor(ss, 32, 64);
+  if (g == 0) sspart[wave][li] = ss;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    cpart[wave][0][lane * 4 + r] = acc0[r];
+    if (SILU) cpart[wave][1][lane * 4 + r] = acc1[r];
+  }
+  __syncthreads();
+  if (wave != 0 || li >= p.M) return;
+  const float rs = gp ? rsqrtf(((sspart[0][li] + sspart[1][li]) + (sspart[2][li] + sspart[3][li])) / (float)p.K + p.eps) : 1.f;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int n = n_base + 4 * g + r, e = lane * 4 + r;
+    if (n >= p.N) continue;
+    const float v0 = ((cpart[0][0][e] + cpart[1][0][e]) + (cpart[2][0][e] + cpart[3][0][e])) * rs;
+    const size_t o = (size_t)li * p.N + n;
+    if (SILU) {
+      const float v1 = ((cpart[0][1][e] + cpart[1][1][e]) + (cpart[2][1][e] + cpart[3][1][e])) * rs;
+      const float gt = bf16_round(v0), up = bf16_round(v1);
+      ((bf16_t*)p.out)[o] = f32_to_bf16(bf16_round(gt * bf16_round(1.f / (1.f + __expf(-gt)))) * up);
+    } else if (p.epi == P3V_EPI_F32) {
+      ((float*)p.out)[o] = v0;
+    } else if (p.epi == P3V_EPI_RESID_BF16) {
+      ((bf16_t*)p.out)[o] = f32_to_bf16(bf16_to_f32(p.resid[o]) + bf16_round(v0));
+    } else {
+      ((bf16_t*)p.out)[o] = f32_to_bf16(v0);
+    }
+  }
+}
+
+extern "C" int64_t p3v_gemv_ws_bytes(int M, int N, int K) { return 0; }   // kept in the ABI; the MFMA path needs no scratch
+
+static int launch_gemv_mfma(const GemvP& p, hipStream_t s) {
+  dim3 grid(p3v_cdiv(p.N, 16));
+  if (p.epi == P3V_EPI_SILU_MUL) hipLaunchKernelGGL(k_gemv_mfma<true>, grid, dim3(256), 0, s, p);
+  else hipLaunchKernelGGL(k_gemv_mfma<false>, grid, dim3(256), 0, s, p);
+  P3V_CHECK_LAUNCH();
+  return P3V_OK;
+}
+
 extern "C" int p3v_gemv(const p3v_gemv_args_t* a, void* stream) {
   if (!a || !a->x || !a->W || !a->out) return P3V_ERR_ARG;
-  if (a->M <= 0 || a->M > 8 || a->N <= 0 || a->K <= 0 || a->K % 8) return P3V_ERR_ARG;
+  if (a->M <= 0 || a->M > 16 || a->N <= 0 || a->K <= 0 || a->K % 8) return P3V_ERR_ARG;
   if (a->epilogue != P3V_EPI_NONE && a->epilogue != P3V_EPI_RESID_BF16 && a->epilogue != P3V_EPI_SILU_MUL &&
       a->epilogue != P3V_EPI_F32)
     return P3V_ERR_UNSUPPORTED;
   if (a->epilogue == P3V_EPI_RESID_BF16 && !a->resid) return P3V_ERR_ARG;
   const int mt = a->M <= 1 ? 1 : a->M <= 2 ? 2 : a->M <= 4 ? 4 : 8;
-  if ((size_t)mt * a->K * 2 > 160 * 1024 - 256) return P3V_ERR_UNSUPPORTED;
   GemvP p = {a->x, a->W, a->out, a->resid, a->norm_w, a->norm_eps, a->M, a->N, a->K, a->epilogue,
              a->epilogue == P3V_EPI_SILU_MUL ? a->N : (a->N + 1) / 2};
   hipStream_t s = (hipStream_t)stream;
@@ -337,6 +446,8 @@ extern "C" int p3v_gemv(const p3v_gemv_args_t* a, void* stream) {
     if (a->K == 3072) return launch_gemv3<1, 1, 6>(p, s);
     return launch_gemv3<1, 4, 4>(p, s);                  // 8192 = 4 stages x 4 chunks: keeps 2 waves/SIMD resident
   }
+  if (a->M >= 2 && a->K % (4 * 32 * GM_G) == 0 && !getenv("P3V_GEMV_NO_MFMA")) return launch_gemv_mfma(p, s);
+  if (a->M > 8 || (size_t)mt * a->K * 2 > 160 * 1024 - 256) return P3V_ERR_UNSUPPORTED;
   switch (mt) {
     case 1: return launch_gemv<1>(p, s);
     case 2: return launch_gemv<2>(p, s);

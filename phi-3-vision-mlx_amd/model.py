@@ -195,7 +195,7 @@ class Phi3VModel:
         bufs = dict(
             q=torch.empty((B, nh, L, hd), dtype=BF16, device=dev), o=torch.empty((M, nh * hd), dtype=BF16, device=dev),
             qkv=torch.empty((M, (nh + 2 * nkv) * hd), dtype=BF16, device=dev), a=torch.empty((M, I), dtype=BF16, device=dev),
-            h=torch.empty((M, H), dtype=BF16, device=dev) if M > 8 else None, n_split=0, ws=None)
+            h=torch.empty((M, H), dtype=BF16, device=dev), n_split=0, ws=None)
         return bufs
 
     def _split_plan(self, bufs, B, L, T):
@@ -215,6 +215,7 @@ class Phi3VModel:
         cfg, w = self.cfg, self.w
         nh, nkv, hd, eps = cfg.num_attention_heads, cfg.num_key_value_heads, self.hd, cfg.rms_norm_eps
         M = B * L
+        skinny = M <= 8 or (M <= ops.GEMV_MAX_M and cfg.hidden_size % 512 == 0)   # weight-streaming projections
         scale = hd ** -0.5
         if bufs is None:
             bufs = self._alloc_bufs(B, L)
@@ -226,7 +227,7 @@ class Phi3VModel:
             v_new = torch.zeros((B, nkv, hd, Lp), dtype=BF16, device=self.device)
         for i in range(cfg.num_hidden_layers):
             p = f"model.layers.{i}."
-            if M <= 8:
+            if skinny:
                 ops.gemv(x, w[p + "self_attn.qkv_proj.weight"], norm_w=w[p + "input_layernorm.weight"], norm_eps=eps, out=qkv)
             else:
                 ops.rmsnorm(x, w[p + "input_layernorm.weight"], eps, out=h)
@@ -248,7 +249,7 @@ class Phi3VModel:
                 ops.attention(q, o, B, L, nh, nkv, hd, scale, True, past=past, k_past=st.k[i], v_past=st.v[i],
                               past_t=st.Tp, pad_len=st.pad_len, new_is_cache=True)
             ops.linear(o, w[p + "self_attn.o_proj.weight"], EPI_RESID_BF16, resid=x, out=x)
-            if M <= 8:
+            if skinny:
                 ops.gemv(x, w[p + "mlp.gate_up_proj.weight"], EPI_SILU_MUL, norm_w=w[p + "post_attention_layernorm.weight"],
                          norm_eps=eps, out=a)
             else:
@@ -361,7 +362,7 @@ class Phi3VModel:
             full_logits = not prefill
         if not full_logits:
             x = x.view(B, L, H)[:, -1, :].contiguous()
-        if x.shape[0] <= 8:
+        if x.shape[0] <= 8 or (x.shape[0] <= ops.GEMV_MAX_M and H % 512 == 0):
             logits = ops.gemv(x, w["lm_head.weight"], norm_w=w["model.norm.weight"], norm_eps=cfg.rms_norm_eps)
         else:
             logits = ops.gemm(ops.rmsnorm(x, w["model.norm.weight"], cfg.rms_norm_eps), w["lm_head.weight"])

@@ -77,21 +77,37 @@ def gemm(a, w, epilogue=EPI_NONE, bias=None, resid=None, out=None, n_out=None, p
     return out
 
 
+GEMV_MAX_M = 16
+_gemv_ws = {}
+
+
+def _gemv_scratch(M, N, K, device):
+    """Split-K scratch of the MFMA skinny kernel (one lazily grown buffer per device; stream-ordered reuse)."""
+    need = int(L.lib().p3v_gemv_ws_bytes(M, N, K))
+    if need == 0:
+        return None
+    buf = _gemv_ws.get(device)
+    if buf is None or buf.numel() * 4 < need:
+        buf = _gemv_ws[device] = torch.empty(max(need // 4, 1 << 20), dtype=F32, device=device)
+    return buf
+
+
 def gemv(x, w, epilogue=EPI_NONE, resid=None, norm_w=None, norm_eps=0.0, out=None):
-    """Skinny nn.Linear for decode (M<=8) with optional fused RMSNorm / epilogue."""
+    """Skinny nn.Linear for decode (M<=16) with optional fused RMSNorm / epilogue."""
     _chk(x, BF16, "x"), _chk(w, BF16, "w")
     M, K = x.shape
     N = w.shape[0] // 2 if epilogue == EPI_SILU_MUL else w.shape[0]
     if out is None:
         out = torch.empty((M, N), dtype=F32 if epilogue == EPI_F32 else BF16, device=x.device)
-    args = L.GemvArgs(_p(x), _p(w), _p(out), _p(resid), _p(norm_w), float(norm_eps), M, N, K, epilogue)
+    ws = _gemv_scratch(M, N, K, x.device) if M >= 2 else None
+    args = L.GemvArgs(_p(x), _p(w), _p(out), _p(resid), _p(norm_w), float(norm_eps), M, N, K, epilogue, _p(ws))
     L.check(L.lib().p3v_gemv(C.byref(args), _stream()), "gemv")
     return out
 
 
 def linear(x, w, epilogue=EPI_NONE, resid=None, out=None):
     """Dispatch a projection to the weight-streaming GEMV (M<=8) or the MFMA GEMM."""
-    if x.shape[0] <= 8 and epilogue in (EPI_NONE, EPI_RESID_BF16, EPI_SILU_MUL, EPI_F32):
+    if x.shape[0] <= GEMV_MAX_M and x.shape[1] % 512 == 0 or x.shape[0] <= 8 and epilogue in (EPI_NONE, EPI_RESID_BF16, EPI_SILU_MUL, EPI_F32):
         return gemv(x, w, epilogue, resid=resid, out=out)
     return gemm(x, w, epilogue, resid=resid, out=out)
 

@@ -133,7 +133,9 @@ def test_gemm_asymmetric_identity(ops):
 
 @pytest.mark.parametrize("M,N,K,epi", [(1, 9216, 3072, "none"), (1, 3072, 8192, "resid"), (1, 8192, 3072, "silu"),
                                        (3, 576, 192, "none"), (8, 3072, 8192, "resid"), (5, 256, 192, "silu"),
-                                       (1, 32064, 3072, "norm"), (8, 9216, 3072, "norm"), (2, 101, 192, "none")])
+                                       (1, 32064, 3072, "norm"), (8, 9216, 3072, "norm"), (2, 101, 192, "none"),
+                                       (16, 3072, 3072, "resid"), (16, 8192, 3072, "silu"), (12, 9216, 3072, "norm"),
+                                       (2, 3072, 8192, "resid"), (9, 32064, 3072, "norm"), (16, 1000, 1024, "none")])
 def test_gemv(ops, orc, M, N, K, epi):
     x = g((M, K), 20)
     nw = 2 * N if epi == "silu" else N

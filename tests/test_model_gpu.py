@@ -311,6 +311,31 @@ def test_c1_fixture_full_size(full_text):
     assert int(g["topi"][0, n - 1, 0]) in last
 
 
+def test_config3_long_context_32k(full_text):
+    """BASELINE config 3: 32k-token prompt (Su/LongRoPE long factors, chosen once from S+max_tokens > 4096, Q2).
+    No CPU oracle can run this size; parity is checked through size-independent properties:
+    (a) the RoPE table the model built equals the long-factor formula, (b) prefill(S)+decode(1) == prefill(S+1),
+    (c) the graph-replayed step equals the eager step bit for bit at this length."""
+    from phi_3_vision_mlx_amd.config import LONG_FACTOR, rope_scaling_factor
+    model, _ = full_text
+    S = 32768
+    ids = np.random.default_rng(4).integers(3, 32000, (1, S + 1)).astype(np.int64)
+    a, cache = model(input_ids=ids[:, :S], max_tokens=4)
+    st = cache[0].state
+    for pos in (0, 4097, S - 1):
+        e = pos / (np.asarray(LONG_FACTOR) * 10000.0 ** (np.arange(0, 96, 2) / 96))
+        ref = np.cos(e) * rope_scaling_factor(model.cfg)
+        assert np.allclose(st.cos[0, pos].cpu().numpy(), ref, atol=2e-5 + pos * 3e-7), pos
+    b, _ = model(input_ids=ids[:, S:], cache=cache)
+    st.offset = S                                               # rewind; replay the same step through the graph
+    g, _ = model.greedy_step(torch.as_tensor(ids[:, S:]).to("cuda:0", torch.int32), cache)
+    assert torch.equal(g[:, -1], b[:, -1])
+    del cache
+    torch.cuda.empty_cache()
+    c, _ = model(input_ids=ids, max_tokens=1)
+    assert_logits(b[:, -1], c[:, -1], "32k decode vs prefill", rel_atol=6e-2)
+
+
 def test_full_size_decode_equals_prefill_property(full_text):
     """Size-independent property at full size: (prefill S, decode 1) == (prefill S+1) on the last row."""
     model, _ = full_text
