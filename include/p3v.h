@@ -170,6 +170,23 @@ int p3v_attention_decode(const p3v_attn_decode_args_t* args /* host */, void* st
 int p3v_stage_rope(const float* cos_t, const float* sin_t, int past, const int32_t* d_past,
                    float* cos_out, float* sin_out, int B, int L, int tab_t, int half_dim, void* stream);
 
+/* ---- int8 KV cache (quantize_cache=True; replaces the 4-bit prompt cache of phi.py:528-540).
+ * Bytes are offset-binary u = round(x/s)+128 with one fp32 scale per (batch row, kv head, token):
+ * K8 [B*nkv, dst_t, hd], V8^T [B*nkv, hd, dst_t], scales [B*nkv, dst_t].
+ * p3v_kv_quantize converts rows [t0, t0+n_tok) of a bf16 K [BH, src_t, hd] / V^T [BH, hd, src_t] pair. */
+int p3v_kv_quantize(const uint16_t* k, const uint16_t* vt, uint8_t* k8, uint8_t* v8t, float* k_scale, float* v_scale,
+                    int BH, int hd, int src_t, int dst_t, int t0, int n_tok, void* stream);
+/* p3v_attention_decode on the int8 cache: same contract; the step's own new rows are attended exactly
+ * (bf16) and appended quantised. */
+typedef struct {
+  const uint16_t* qkv; const float* cos_t; const float* sin_t;
+  uint8_t* k8; uint8_t* v8t; float* k_scale; float* v_scale; uint16_t* out;
+  const int32_t* pad_len; const int32_t* d_past; float* ws;
+  int B, L, n_heads, n_kv, hd, past, cache_t, rope_bstride, n_split;
+  float scale;
+} p3v_attn_decode_q8_args_t;
+int p3v_attention_decode_q8(const p3v_attn_decode_q8_args_t* args /* host */, void* stream);
+
 /* ---- CLIP patch unfold: pixel_values [N,3,S,S] f32 -> patches [N*P, kpad] bf16, (c,ky,kx) order, zero padded */
 int p3v_im2col_patches(const float* pix, uint16_t* patches, int n_img, int img, int patch, int kpad, void* stream);
 /* ---- CLS rows: x[n, 0, :] = class_emb + pos[0]  (phi.py:202-205); x [N, P+1, D] f32 */

@@ -48,6 +48,13 @@ class AttnDecArgs(C.Structure):
                 ("cache_t", i32), ("rope_bstride", i32), ("n_split", i32), ("scale", f32)]
 
 
+class AttnDecQ8Args(C.Structure):
+    _fields_ = [("qkv", vp), ("cos_t", vp), ("sin_t", vp), ("k8", vp), ("v8t", vp), ("k_scale", vp), ("v_scale", vp),
+                ("out", vp), ("pad_len", vp), ("d_past", vp), ("ws", vp),
+                ("B", i32), ("L", i32), ("n_heads", i32), ("n_kv", i32), ("hd", i32), ("past", i32),
+                ("cache_t", i32), ("rope_bstride", i32), ("n_split", i32), ("scale", f32)]
+
+
 # name -> (restype, argtypes); must list every symbol include/p3v.h declares
 SIGNATURES = {
     "p3v_version": (i32, []),
@@ -63,6 +70,8 @@ SIGNATURES = {
     "p3v_rope_kv_append": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, i32, i32, i32, i32, vp]),
     "p3v_attention": (i32, [C.POINTER(AttnArgs), vp]),
     "p3v_attention_decode": (i32, [C.POINTER(AttnDecArgs), vp]),
+    "p3v_kv_quantize": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
+    "p3v_attention_decode_q8": (i32, [C.POINTER(AttnDecQ8Args), vp]),
     "p3v_stage_rope": (i32, [vp, vp, i32, vp, vp, vp, i32, i32, i32, i32, vp]),
     "p3v_attention_ws_bytes": (i64, [i32, i32, i32, i32, i32]),
     "p3v_im2col_patches": (i32, [vp, vp, i32, i32, i32, i32, vp]),

@@ -8,6 +8,7 @@ reference's `load / generate / choose / constrain / benchmark`
 Host code stays Python; everything that touches the device goes through
 `model(...)` (model.py) and `model_ops` (ops.py), i.e. hand-written HIP kernels.
 
+`quantize_cache=True` selects the int8 KV cache (the build's analogue of the reference's 4-bit prompt cache).
 Not carried over (out of scope): LoRA adapters
 (`use_adapter=True` raises NotImplementedError), the `<|api_input|>` tool hook,
 HF-hub download (`_setup`): a model directory must exist locally, or pass
@@ -211,8 +212,6 @@ def _load(model_path=PATH_ORIGINAL_PHI3_VISION, adapter_path=None, return_mx=Tru
     cfg = _get_cfg(f"{model_path}/config.json", **kwargs)
     if getattr(cfg, "quantized", False):
         raise NotImplementedError("MLX int4 checkpoints are not supported (SURVEY.md section 8f item 4)")
-    if getattr(cfg, "use_quantized_cache", False):
-        raise NotImplementedError("quantize_cache=True (int8 KV, BASELINE config 5) is not implemented in this round")
     processor = _make_processor(cfg, model_path, return_mx)
     device = device or f"cuda:{torch.cuda.current_device()}"
     model = Phi3VModel(cfg, load_safetensors_dir(model_path, cfg, device="cpu"), device=device)
@@ -237,10 +236,8 @@ def load(blind_model=False, quantize_model=False, quantize_cache=False, use_adap
         raise NotImplementedError("use_adapter=True: LoRA is outside the inference hot path of this build")
     if quantize_model:
         raise NotImplementedError("quantize_model=True (fp8 weights, BASELINE config 5) is not implemented in this round")
-    if quantize_cache:
-        raise NotImplementedError("quantize_cache=True (int8 KV, BASELINE config 5) is not implemented in this round")
     if synthetic:
-        return load_synthetic(blind_model=blind_model, tiny=(synthetic == "tiny"), **kwargs)
+        return load_synthetic(blind_model=blind_model, tiny=(synthetic == "tiny"), use_quantized_cache=quantize_cache, **kwargs)
     model_path = kwargs.pop("model_path", None) or (PATH_ORIGINAL_PHI3_BLIND if blind_model else PATH_ORIGINAL_PHI3_VISION)
     if not os.path.exists(model_path):
         raise FileNotFoundError(

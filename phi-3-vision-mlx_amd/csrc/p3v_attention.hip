@@ -750,3 +750,282 @@ extern "C" int p3v_attention_decode(const p3v_attn_decode_args_t* a, void* strea
   P3V_CHECK_LAUNCH();
   return P3V_OK;
 }
+
+// =====================================================================================
+// int8 KV cache (quantize_cache=True; BASELINE config 5; replaces the reference's 4-bit group-32 prompt
+// cache, phi.py:528-540): K rows and V^T columns are stored as offset-binary bytes
+// u = round(x / s) + 128 with one fp32 scale s per (batch row, kv head, token); halves the bytes a decode
+// step streams.  As in the reference, the PREFILL attends over the exact keys/values and only the
+// stored copy is quantised (phi.py:531-533); a decode step attends over the dequantised cache plus its
+// own exact new row.
+//
+// p3v_kv_quantize: bf16 K [B,nkv,Ts,hd] / V^T [B,nkv,hd,Ts] rows [t0, t0+n) -> u8 caches + scales.
+__global__ void __launch_bounds__(256) k_kv_quantize(const bf16_t* __restrict__ k, const bf16_t* __restrict__ vt,
+                                                     uint8_t* __restrict__ k8, uint8_t* __restrict__ v8,
+                                                     float* __restrict__ ksc, float* __restrict__ vsc, int hd, int src_t,
+                                                     int dst_t, int t0, int n_tok) {
+  __shared__ float vmax[64];
+  __shared__ bf16_t vtile[96 * 66];
+  const int bh = blockIdx.y, tt = blockIdx.x * 64, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // ---- K: one wave per token row (4 rows per pass)
+  for (int r = wave; r < 64; r += 4) {
+    const int t = t0 + tt + r;
+    if (tt + r >= n_tok) break;
+    const bf16_t* row = k + ((size_t)bh * src_t + t) * hd;
+    const float a = lane < hd / 2 ? bf16_to_f32(row[2 * lane]) : 0.f, b = lane < hd / 2 ? bf16_to_f32(row[2 * lane + 1]) : 0.f;
+    const float amax = wave_max(fmaxf(fabsf(a), fabsf(b)));
+    const float s = amax > 0.f ? amax / 127.f : 1.f, inv = 1.f / s;
+    if (lane < hd / 2) {
+      const int qa = (int)rintf(a * inv) + 128, qb = (int)rintf(b * inv) + 128;
+      *(uint16_t*)(k8 + ((size_t)bh * dst_t + t) * hd + 2 * lane) = (uint16_t)(qa | (qb << 8));
+    }
+    if (lane == 0) ksc[(size_t)bh * dst_t + t] = s;
+  }
+  // ---- V^T: tile [hd][64 tokens] through LDS, per-token amax over d
+  for (int i = tid; i < hd * 64; i += 256) {
+    const int d = i >> 6, c = i & 63;
+    vtile[d * 66 + c] = tt + c < n_tok ? vt[((size_t)bh * hd + d) * src_t + t0 + tt + c] : (bf16_t)0;
+  }
+  __syncthreads();
+  if (tid < 64) {
+    float m = 0.f;
+    for (int d = 0; d < hd; ++d) m = fmaxf(m, fabsf(bf16_to_f32(vtile[d * 66 + tid])));
+    vmax[tid] = m > 0.f ? m / 127.f : 1.f;
+    if (tt + tid < n_tok) vsc[(size_t)bh * dst_t + t0 + tt + tid] = vmax[tid];
+  }
+  __syncthreads();
+  for (int i = tid; i < hd * 64; i += 256) {
+    const int d = i >> 6, c = i & 63;
+    if (tt + c < n_tok)
+      v8[((size_t)bh * hd + d) * dst_t + t0 + tt + c] = (uint8_t)((int)rintf(bf16_to_f32(vtile[d * 66 + c]) / vmax[c]) + 128);
+  }
+}
+
+extern "C" int p3v_kv_quantize(const uint16_t* k, const uint16_t* vt, uint8_t* k8, uint8_t* v8t, float* k_scale,
+                               float* v_scale, int BH, int hd, int src_t, int dst_t, int t0, int n_tok, void* stream) {
+  if (!k || !vt || !k8 || !v8t || !k_scale || !v_scale || BH <= 0 || hd > 96 || hd % 2 || n_tok < 0) return P3V_ERR_ARG;
+  if (n_tok == 0) return P3V_OK;
+  hipLaunchKernelGGL(k_kv_quantize, dim3(p3v_cdiv(n_tok, 64), BH), dim3(256), 0, (hipStream_t)stream, k, vt, k8, v8t,
+                     k_scale, v_scale, hd, src_t, dst_t, t0, n_tok);
+  P3V_CHECK_LAUNCH();
+  return P3V_OK;
+}
+
+struct AttnDecQ8P {
+  const bf16_t* qkv; const float* cos_t; const float* sin_t; uint8_t* k8; uint8_t* v8; float* ksc; float* vsc;
+  const int32_t* pad_len; const int32_t* d_past; float* ws;
+  int B, L, nh, nkv, past, cache_t, rope_bstride, n_split;
+  float scale;
+};
+
+__device__ __forceinline__ void u8x16_to_bf16(u32x4_t w, u32x4_t& lo, u32x4_t& hi) {   // 16 offset-binary bytes -> 16 bf16
+  float f[16];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    f[4 * j + 0] = (float)((w[j] >> 0) & 0xffu) - 128.f;
+    f[4 * j + 1] = (float)((w[j] >> 8) & 0xffu) - 128.f;
+    f[4 * j + 2] = (float)((w[j] >> 16) & 0xffu) - 128.f;
+    f[4 * j + 3] = (float)((w[j] >> 24) & 0xffu) - 128.f;
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { lo[j] = pack_bf16x2(f[2 * j], f[2 * j + 1]); hi[j] = pack_bf16x2(f[8 + 2 * j], f[9 + 2 * j]); }
+}
+
+__global__ void __launch_bounds__(64) k_attn_decode_q8(AttnDecQ8P p) {
+  constexpr int HD = 96, TK = 64, KSTR = HD * 2 + 16, VSTR = TK * 2 + 16, NKS = 3, NDT = 6, NLD = 6;
+  __shared__ __attribute__((aligned(16))) unsigned char Ks[TK * KSTR];
+  __shared__ __attribute__((aligned(16))) unsigned char Vt[HD * VSTR];
+  __shared__ __attribute__((aligned(16))) float ksl[TK], vsl[TK];
+  const int lane = threadIdx.x, g = lane >> 4, qi = lane & 15;
+  const int b = blockIdx.z, head = blockIdx.y, kvh = head / (p.nh / p.nkv);
+  const bool kv_writer = head % (p.nh / p.nkv) == 0;
+  const float sc2 = p.scale * 1.4426950408889634f;
+  const int row_w = (p.nh + 2 * p.nkv) * HD;
+  const size_t bh = (size_t)b * p.nkv + kvh;
+  uint8_t* kc = p.k8 + bh * (size_t)p.cache_t * HD;
+  uint8_t* vc = p.v8 + bh * (size_t)HD * p.cache_t;
+  float* ksc = p.ksc + bh * p.cache_t;
+  float* vsc = p.vsc + bh * p.cache_t;
+  const int chunk = ((p.cache_t + p.n_split - 1) / p.n_split + TK - 1) & ~(TK - 1);
+  const int kv_lo = blockIdx.x * chunk, kv_hi = min(p.cache_t, kv_lo + chunk);
+
+  u32x4_t kreg[NLD], vreg[NLD];
+  float ks_r, vs_r;
+  auto load_tile = [&](int kv0) {
+#pragma unroll
+    for (int it = 0; it < NLD; ++it) {
+      const int i = it * 64 + lane;
+      kreg[it] = __builtin_nontemporal_load((const u32x4_t*)(kc + (size_t)(kv0 + i / 6) * HD + (i % 6) * 16));
+      vreg[it] = __builtin_nontemporal_load((const u32x4_t*)(vc + (size_t)(i >> 2) * p.cache_t + kv0 + (i & 3) * 16));
+    }
+    ks_r = ksc[kv0 + lane];
+    vs_r = vsc[kv0 + lane];
+  };
+  if (kv_lo < kv_hi) load_tile(kv_lo);
+
+  const int past = p.d_past ? *p.d_past : p.past;
+  const int total = past + p.L;
+  const int pad = p.pad_len ? p.pad_len[b] : 0;
+  int kv_begin = kv_lo;
+  const int kv_end = min(total, kv_hi);
+  if (pad > kv_begin) kv_begin = pad & ~(TK - 1);
+  const float* cos_b = p.cos_t + (size_t)b * p.rope_bstride * (HD / 2);
+  const float* sin_b = p.sin_t + (size_t)b * p.rope_bstride * (HD / 2);
+
+  auto patch_new = [&](int kv0) {                             // exact new rows into LDS (scale 1), quantised copy to the cache
+    const int n0 = max(past, kv0), n1 = min(kv_end, kv0 + TK);
+#pragma unroll 1
+    for (int t = n0; t < n1; ++t) {
+      const int r = t - past;
+      const bf16_t* row = p.qkv + ((size_t)b * p.L + r) * row_w;
+      if (lane < 12) {
+        const u32x4_t kn = rope_chunk(row + (p.nh + kvh) * HD, lane, cos_b + r * (HD / 2), sin_b + r * (HD / 2));
+        *(u32x4_t*)(Ks + (t - kv0) * KSTR + lane * 16) = kn;
+      }
+      for (int d = lane; d < HD; d += 64) *(bf16_t*)(Vt + d * VSTR + (t - kv0) * 2) = row[(p.nh + p.nkv + kvh) * HD + d];
+      if (lane == 0) { ksl[t - kv0] = 1.f; vsl[t - kv0] = 1.f; }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (kv_writer) {                                        // append the quantised row / column (phi.py:545-546)
+        const float ka = lane < 48 ? bf16_to_f32(*(const bf16_t*)(Ks + (t - kv0) * KSTR + 4 * lane)) : 0.f;
+        const float kb = lane < 48 ? bf16_to_f32(*(const bf16_t*)(Ks + (t - kv0) * KSTR + 4 * lane + 2)) : 0.f;
+        const float kmax = wave_max(fmaxf(fabsf(ka), fabsf(kb)));
+        const float s = kmax > 0.f ? kmax / 127.f : 1.f, inv = 1.f / s;
+        if (lane < 48) *(uint16_t*)(kc + (size_t)t * HD + 2 * lane) = (uint16_t)(((int)rintf(ka * inv) + 128) | (((int)rintf(kb * inv) + 128) << 8));
+        const float va = bf16_to_f32(*(const bf16_t*)(Vt + lane * VSTR + (t - kv0) * 2));
+        const float vb = lane < 32 ? bf16_to_f32(*(const bf16_t*)(Vt + (lane + 64) * VSTR + (t - kv0) * 2)) : 0.f;
+        const float vmx = wave_max(fmaxf(fabsf(va), fabsf(vb)));
+        const float sv = vmx > 0.f ? vmx / 127.f : 1.f, invv = 1.f / sv;
+        vc[(size_t)lane * p.cache_t + t] = (uint8_t)((int)rintf(va * invv) + 128);
+        if (lane < 32) vc[(size_t)(lane + 64) * p.cache_t + t] = (uint8_t)((int)rintf(vb * invv) + 128);
+        if (lane == 0) { ksc[t] = s; vsc[t] = sv; }
+      }
+    }
+  };
+  if (kv_begin > kv_lo && kv_begin < kv_end) load_tile(kv_begin);
+
+  const bool qvalid = qi < p.L;
+  const int qpos = past + qi;
+  bf16x8_t qf[NKS];
+  {
+    const bf16_t* qrow = p.qkv + ((size_t)b * p.L + (qvalid ? qi : 0)) * row_w + head * HD;
+    const float* ct = cos_b + (qvalid ? qi : 0) * (HD / 2);
+    const float* st = sin_b + (qvalid ? qi : 0) * (HD / 2);
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+      u32x4_t v = rope_chunk(qrow, 4 * ks + g, ct, st);
+      if (!qvalid) v = (u32x4_t){0, 0, 0, 0};
+      qf[ks] = __builtin_bit_cast(bf16x8_t, v);
+    }
+  }
+  float m_run = -INFINITY, l_run = 0.f;
+  f32x4_t o[NDT];
+#pragma unroll
+  for (int d = 0; d < NDT; ++d) o[d] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  for (int kv0 = kv_begin; kv0 < kv_end; kv0 += TK) {
+#pragma unroll
+    for (int it = 0; it < NLD; ++it) {                        // dequantise to the bf16 LDS images of the bf16 kernel
+      const int i = it * 64 + lane;
+      u32x4_t lo, hi;
+      u8x16_to_bf16(kreg[it], lo, hi);
+      *(u32x4_t*)(Ks + (i / 6) * KSTR + (i % 6) * 32) = lo;
+      *(u32x4_t*)(Ks + (i / 6) * KSTR + (i % 6) * 32 + 16) = hi;
+      u8x16_to_bf16(vreg[it], lo, hi);
+      *(u32x4_t*)(Vt + (i >> 2) * VSTR + (i & 3) * 32) = lo;
+      *(u32x4_t*)(Vt + (i >> 2) * VSTR + (i & 3) * 32 + 16) = hi;
+    }
+    ksl[lane] = ks_r;
+    vsl[lane] = vs_r;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (kv0 + TK > past) {
+      patch_new(kv0);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    if (kv0 + TK < kv_end) load_tile(kv0 + TK);
+
+    f32x4_t s[4];
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+      s[st] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks) {
+        const bf16x8_t kf = *(const bf16x8_t*)(Ks + (16 * st + qi) * KSTR + (32 * ks + 8 * g) * 2);
+        s[st] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], s[st], 0, 0, 0);
+      }
+    }
+    float m_t = -INFINITY;
+    f32x4_t vsv[4];
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+      const f32x4_t kk = *(const f32x4_t*)(ksl + 16 * st + 4 * g);
+      vsv[st] = *(const f32x4_t*)(vsl + 16 * st + 4 * g);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int t = kv0 + 16 * st + 4 * g + r;
+        const bool vis = t < kv_end && t >= pad && t <= qpos && qpos >= pad;
+        const float v = vis ? s[st][r] * kk[r] * sc2 : -INFINITY;
+        s[st][r] = v;
+        m_t = fmaxf(m_t, v);
+      }
+    }
+    m_t = fmaxf(m_t, __shfl_xor(m_t, 16, 64));
+    m_t = fmaxf(m_t, __shfl_xor(m_t, 32, 64));
+    const float m_new = fmaxf(m_run, m_t);
+    const float m_use = m_new == -INFINITY ? 0.f : m_new;
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);
+    float l_t = 0.f;
+#pragma unroll
+    for (int st = 0; st < 4; ++st)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float e = __builtin_amdgcn_exp2f(s[st][r] - m_use);
+        l_t += e;
+        s[st][r] = e > 0.f ? e * vsv[st][r] : 0.f;            // V scale folded into P (masked keys stay exactly 0)
+      }
+    l_t += __shfl_xor(l_t, 16, 64);
+    l_t += __shfl_xor(l_t, 32, 64);
+    l_run = l_run * alpha + l_t;
+    m_run = m_new;
+#pragma unroll
+    for (int d = 0; d < NDT; ++d) o[d] *= alpha;
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+      u32x4_t pw;
+      pw[0] = pack_bf16x2(s[2 * st][0], s[2 * st][1]);
+      pw[1] = pack_bf16x2(s[2 * st][2], s[2 * st][3]);
+      pw[2] = pack_bf16x2(s[2 * st + 1][0], s[2 * st + 1][1]);
+      pw[3] = pack_bf16x2(s[2 * st + 1][2], s[2 * st + 1][3]);
+      const bf16x8_t pf = __builtin_bit_cast(bf16x8_t, pw);
+#pragma unroll
+      for (int d = 0; d < NDT; ++d) {
+        const unsigned char* vr = Vt + (16 * d + qi) * VSTR + (32 * st + 4 * g) * 2;
+        const u32x2_t a0 = *(const u32x2_t*)vr, a1 = *(const u32x2_t*)(vr + 32);
+        const u32x4_t aw = {a0[0], a0[1], a1[0], a1[1]};
+        o[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, aw), pf, o[d], 0, 0, 0);
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+  if (!qvalid) return;
+  float* w = p.ws + ((((size_t)b * p.nh + head) * p.n_split + blockIdx.x) * 16 + qi) * (HD + 2);
+#pragma unroll
+  for (int d = 0; d < NDT; ++d) *(f32x4_t*)(w + 16 * d + 4 * g) = o[d];
+  if (g == 0) { w[HD] = m_run; w[HD + 1] = l_run; }
+}
+
+extern "C" int p3v_attention_decode_q8(const p3v_attn_decode_q8_args_t* a, void* stream) {
+  if (!a || !a->qkv || !a->cos_t || !a->sin_t || !a->k8 || !a->v8t || !a->k_scale || !a->v_scale || !a->out || !a->ws)
+    return P3V_ERR_ARG;
+  if (a->hd != 96) return P3V_ERR_UNSUPPORTED;
+  if (a->B <= 0 || a->L <= 0 || a->L > P3V_DECODE_MAX_L || a->n_heads % a->n_kv) return P3V_ERR_ARG;
+  if (a->n_split < 1 || a->n_split > 128 || a->cache_t % 64) return P3V_ERR_ARG;
+  AttnDecQ8P p = {a->qkv, a->cos_t, a->sin_t, a->k8, a->v8t, a->k_scale, a->v_scale, a->pad_len, a->d_past, a->ws,
+                  a->B, a->L, a->n_heads, a->n_kv, a->past, a->cache_t, a->rope_bstride, a->n_split, a->scale};
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_attn_decode_q8, dim3(a->n_split, a->n_heads, a->B), dim3(64), 0, s, p);
+  P3V_CHECK_LAUNCH();
+  hipLaunchKernelGGL(k_attn_combine2, dim3(a->B * a->n_heads * a->L), dim3(256), 0, s, a->ws, a->out, a->L, a->n_heads,
+                     a->hd, a->n_split);
+  P3V_CHECK_LAUNCH();
+  return P3V_OK;
+}

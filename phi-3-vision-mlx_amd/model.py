@@ -48,8 +48,19 @@ class CacheState:
         self.T = S + max(max_tokens, 0)
         self.Tp = (self.T + 63) // 64 * 64                     # row/column stride of the caches (64-key tiles)
         nl, nkv, hd = cfg.num_hidden_layers, cfg.num_key_value_heads, head_dim(cfg)
-        self.k = torch.empty((nl, B, nkv, self.Tp, hd), dtype=BF16, device=device)    # K   [.., t, hd]
-        self.v = torch.zeros((nl, B, nkv, hd, self.Tp), dtype=BF16, device=device)    # V^T [.., hd, t] (zero: tail keys stay finite)
+        self.quantized = bool(getattr(cfg, "use_quantized_cache", False))
+        if self.quantized:
+            # int8 KV (quantize_cache=True): offset-binary bytes + one fp32 scale per (layer, row, head, token);
+            # one bf16 K / V^T scratch layer holds the exact prompt keys while a layer's prefill attends (phi.py:531-533)
+            self.k8 = torch.full((nl, B, nkv, self.Tp, hd), 128, dtype=torch.uint8, device=device)
+            self.v8 = torch.full((nl, B, nkv, hd, self.Tp), 128, dtype=torch.uint8, device=device)
+            self.ks = torch.ones((nl, B, nkv, self.Tp), dtype=F32, device=device)
+            self.vs = torch.ones((nl, B, nkv, self.Tp), dtype=F32, device=device)
+            self.k_tmp = torch.empty((B, nkv, self.Tp, hd), dtype=BF16, device=device)
+            self.v_tmp = torch.zeros((B, nkv, hd, self.Tp), dtype=BF16, device=device)
+        else:
+            self.k = torch.empty((nl, B, nkv, self.Tp, hd), dtype=BF16, device=device)    # K   [.., t, hd]
+            self.v = torch.zeros((nl, B, nkv, hd, self.Tp), dtype=BF16, device=device)    # V^T [.., hd, t] (zero: tail keys stay finite)
         self.offset = 0
         self.cos = self.sin = self.pad_len = None
         self.graphs = {}
@@ -221,6 +232,10 @@ class Phi3VModel:
             bufs = self._alloc_bufs(B, L)
             self._split_plan(bufs, B, L, past + L)
         q, o, qkv, a, h, n_split, ws = (bufs[k] for k in ("q", "o", "qkv", "a", "h", "n_split", "ws"))
+        if st.quantized and n_beam > 1:
+            raise NotImplementedError("Beam Search is not yet compatible with Quantized Cache")       # as phi.py:525
+        if st.quantized and L > ops.L.DECODE_MAX_L and past > 0:
+            raise NotImplementedError("a cached call with more than 16 new tokens is not supported with the quantised cache")
         if n_beam > 1:                                          # beams: K/V of this call go to a scratch, cache is read-only
             Lp = (L + 7) // 8 * 8
             k_new = torch.empty((B, nkv, Lp, hd), dtype=BF16, device=self.device)
@@ -232,7 +247,20 @@ class Phi3VModel:
             else:
                 ops.rmsnorm(x, w[p + "input_layernorm.weight"], eps, out=h)
                 ops.gemm(h, w[p + "self_attn.qkv_proj.weight"], out=qkv)
-            if n_beam > 1:
+            if st.quantized:
+                if L <= ops.L.DECODE_MAX_L:
+                    if d_past is not None:
+                        rc, rs, rb = bufs["rope_cos"], bufs["rope_sin"], L
+                    else:
+                        rc, rs, rb = st.cos[:, past:], st.sin[:, past:], st.T
+                    ops.attention_decode_q8(qkv, rc, rs, rb, st.k8[i], st.v8[i], st.ks[i], st.vs[i], o, B, L, nh, nkv, hd, scale,
+                                            past, st.Tp, ws, n_split, pad_len=st.pad_len, d_past=d_past)
+                else:                                           # prefill: exact attention, quantised copy stored
+                    ops.rope_kv_append(qkv, st.cos, st.sin, q, st.k_tmp, st.v_tmp, B, L, nh, nkv, hd, 0, st.Tp, True, st.T, 1)
+                    ops.attention(q, o, B, L, nh, nkv, hd, scale, True, past=0, k_past=st.k_tmp, v_past=st.v_tmp,
+                                  past_t=st.Tp, pad_len=st.pad_len, new_is_cache=True)
+                    ops.kv_quantize(st.k_tmp, st.v_tmp, st.k8[i], st.v8[i], st.ks[i], st.vs[i], 0, L)
+            elif n_beam > 1:
                 ops.rope_kv_append(qkv, st.cos, st.sin, q, k_new, v_new, B, L, nh, nkv, hd, past, Lp, False, st.T, n_beam)
                 ops.attention(q, o, B, L, nh, nkv, hd, scale, True, k_new=k_new, v_new=v_new, new_t=Lp, past=past,
                               k_past=st.k[i], v_past=st.v[i], past_t=st.Tp, past_div=n_beam, pad_len=st.pad_len,

@@ -150,6 +150,22 @@ def attention_decode(qkv, cos_new, sin_new, rope_bstride, k_cache, v_cache, out,
     return out
 
 
+def kv_quantize(k, vt, k8, v8t, k_scale, v_scale, t0, n_tok):
+    """bf16 K [B,nkv,Ts,hd] / V^T [B,nkv,hd,Ts] rows [t0,t0+n) -> offset-binary u8 caches + per-token scales."""
+    B, nkv, src_t, hd = k.shape
+    L.check(L.lib().p3v_kv_quantize(_p(k), _p(vt), _p(k8), _p(v8t), _p(k_scale), _p(v_scale), B * nkv, hd, src_t,
+                                    k8.shape[2], int(t0), int(n_tok), _stream()), "kv_quantize")
+
+
+def attention_decode_q8(qkv, cos_new, sin_new, rope_bstride, k8, v8t, k_scale, v_scale, out, B, Lq, nh, nkv, hd, scale, past,
+                        cache_t, ws, n_split, pad_len=None, d_past=None):
+    """`attention_decode` on the int8 KV cache."""
+    args = L.AttnDecQ8Args(_p(qkv), _p(cos_new), _p(sin_new), _p(k8), _p(v8t), _p(k_scale), _p(v_scale), _p(out), _p(pad_len),
+                           _p(d_past), _p(ws), B, Lq, nh, nkv, hd, int(past), cache_t, rope_bstride, n_split, float(scale))
+    L.check(L.lib().p3v_attention_decode_q8(C.byref(args), _stream()), "attention_decode_q8")
+    return out
+
+
 def stage_rope(cos_t, sin_t, cos_out, sin_out, B, Lq, tab_t, past=0, d_past=None):
     """Copy the cos/sin rows of positions [past, past+L) into compact [B, L, half] buffers (graph-replayed decode)."""
     L.check(L.lib().p3v_stage_rope(_p(cos_t), _p(sin_t), int(past), _p(d_past), _p(cos_out), _p(sin_out), B, Lq, tab_t,

@@ -30,7 +30,8 @@ def test_struct_layouts_match_header_field_order():
     from phi_3_vision_mlx_amd import _lib
     h = open(os.path.join(ROOT, "include", "p3v.h")).read()
     for cname, cls in (("p3v_gemm_args_t", _lib.GemmArgs), ("p3v_gemv_args_t", _lib.GemvArgs),
-                       ("p3v_attn_args_t", _lib.AttnArgs), ("p3v_attn_decode_args_t", _lib.AttnDecArgs)):
+                       ("p3v_attn_args_t", _lib.AttnArgs), ("p3v_attn_decode_args_t", _lib.AttnDecArgs),
+                       ("p3v_attn_decode_q8_args_t", _lib.AttnDecQ8Args)):
         end = h.index("} " + cname)
         body = h[h.rindex("typedef struct {", 0, end) + len("typedef struct {"):end]
         body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
@@ -39,7 +40,7 @@ def test_struct_layouts_match_header_field_order():
             stmt = stmt.strip()
             if not stmt:
                 continue
-            decl = re.sub(r"^(const\s+)?(void|uint16_t|int32_t|float|int)\s*\*?\s*", "", stmt)
+            decl = re.sub(r"^(const\s+)?(void|uint16_t|uint8_t|int32_t|float|int)\s*\*?\s*", "", stmt)
             names += [n.strip().lstrip("*").strip() for n in decl.split(",")]
         assert names == [f for f, _ in cls._fields_], (cname, names)
 

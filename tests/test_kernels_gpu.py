@@ -261,6 +261,53 @@ def test_attention_decode_fused(ops, orc, B, L, past, nh, n_split, pads):
     assert torch.equal(kcc[:, :, :past].cpu(), kc[:, :, :past]) and torch.equal(kcc[:, :, past + L:].cpu(), kc[:, :, past + L:])
 
 
+def _dequant(u8, sc, axis):
+    return (u8.float() - 128.0) * sc.unsqueeze(axis)
+
+
+def test_kv_quantize_and_q8_decode(ops, orc):
+    """int8 KV: (a) quantiser = round(x/s)+128 with s = amax/127 per token, (b) the q8 decode attention equals the
+    bf16 oracle attention over the DEQUANTISED cache, (c) the appended row is stored quantised."""
+    from phi_3_vision_mlx_amd.config import make_config, rope_scaling_factor
+    cfg = make_config()
+    B, nh, hd, past, L, T = 2, 2, 96, 200, 1, 256
+    k, v = g((B, nh, T, hd), 90), g((B, nh, T, hd), 91)
+    k8 = torch.full((B, nh, T, hd), 128, dtype=torch.uint8).cuda()
+    v8 = torch.full((B, nh, hd, T), 128, dtype=torch.uint8).cuda()
+    ksc, vsc = torch.ones((B, nh, T)).cuda(), torch.ones((B, nh, T)).cuda()
+    ops.kv_quantize(k.cuda(), v.transpose(2, 3).contiguous().cuda(), k8, v8, ksc, vsc, 0, past)
+    for src, q8, sc, ax in ((k, k8.cpu(), ksc.cpu(), -1), (v, v8.cpu().transpose(2, 3), vsc.cpu(), -1)):
+        s_ref = src[:, :, :past].float().abs().amax(-1) / 127
+        assert torch.allclose(sc[:, :, :past], s_ref, rtol=1e-6)
+        q_ref = torch.round(src[:, :, :past].float() / s_ref[..., None]) + 128
+        assert (q8[:, :, :past].float() - q_ref).abs().max() <= 1          # ties may round either way
+        assert (q8[:, :, past:] == 128).all()
+    kd, vd = _dequant(k8.cpu(), ksc.cpu(), -1), _dequant(v8.cpu().transpose(2, 3), vsc.cpu(), -1)
+    qkv = g((B * L, 3 * nh * hd), 92)
+    inv = 1.0 / (torch.tensor(cfg.rope_scaling["short_factor"], dtype=F32) * (10000.0 ** (torch.arange(0, hd, 2, dtype=F32) / hd)))
+    cos, sin = ops.rope_table(torch.arange(T, dtype=F32).repeat(B).cuda(), inv.cuda(), rope_scaling_factor(cfg))
+    cos, sin = cos.view(B, T, -1), sin.view(B, T, -1)
+    out = torch.empty((B, L, nh * hd), dtype=BF16).cuda()
+    n_split = 3
+    ws = torch.empty(ops.attention_ws_bytes(B, L, nh, hd, n_split) // 4, dtype=F32).cuda()
+    ops.attention_decode_q8(qkv.cuda(), cos[:, past:], sin[:, past:], T, k8, v8, ksc, vsc, out, B, L, nh, nh, hd, hd ** -0.5, past,
+                            T, ws, n_split)
+    cos_ref, sin_ref = orc.su_rope_tables(cfg, T, None)
+    x = qkv.view(B, L, 3 * nh, hd).transpose(1, 2)
+    cs, sn = cos_ref[:, :, past:past + L], sin_ref[:, :, past:past + L]
+    q = orc.rotate_half(x[:, :nh], cs, sn).to(BF16)
+    k_new = orc.rotate_half(x[:, nh:2 * nh], cs, sn).to(BF16)
+    kf = torch.cat([kd[:, :, :past], k_new.float()], dim=2)
+    vf = torch.cat([vd[:, :, :past], x[:, 2 * nh:].float()], dim=2)
+    allowed = torch.ones((B, 1, L, past + L), dtype=torch.bool)
+    ref = _attn_ref(orc, q, kf, vf, hd ** -0.5, allowed).transpose(1, 2).reshape(B, L, nh * hd)
+    close(out, ref, rtol=2 ** -6, atol=2e-2)
+    s_new = k_new.float().abs().amax(-1) / 127
+    assert torch.allclose(ksc.cpu()[:, :, past:past + L], s_new, rtol=1e-6)
+    assert (k8.cpu()[:, :, past:past + L].float() - (torch.round(k_new.float() / s_new[..., None]) + 128)).abs().max() <= 1
+    assert (v8.cpu()[:, :, :, past].float() - (torch.round(x[:, 2 * nh:, 0].float() / (x[:, 2 * nh:, 0].float().abs().amax(-1, keepdim=True) / 127)) + 128)).abs().max() <= 1
+
+
 def test_attention_beam_view(ops, orc):
     """n_beam: keys [0,past) come from cache row b//n_beam, new keys from a scratch (phi.py:523-527)."""
     Bc, nb, L, past, nh, hd = 2, 3, 4, 50, 2, 96

@@ -170,6 +170,28 @@ def test_vision_tower_and_projector_stages(vis):
     assert got_x[untouched].abs().sum().item() == 0
 
 
+def test_quantized_cache_close_to_bf16_cache():
+    """quantize_cache=True (int8 KV): the prefill is exact (phi.py:531-533), decode logits stay within 3 % of max|logit|
+    of the bf16-cache run, beams raise like the reference (phi.py:525)."""
+    from phi_3_vision_mlx_amd.api import load_synthetic
+    mq, proc = load_synthetic(blind_model=True, tiny=True, seed=0, std_scale=4.0, device="cuda:0", use_quantized_cache=True)
+    mb, _ = load_synthetic(blind_model=True, tiny=True, seed=0, std_scale=4.0, device="cuda:0")
+    inputs = proc(["a short one", "a somewhat longer prompt for the second row of the batch"])
+    n = 6
+    lq, cq = mq(**inputs, max_tokens=n)
+    lb, cb = mb(**inputs, max_tokens=n)
+    assert cq[0].state.quantized and torch.equal(lq, lb)
+    tok = model_tok(lb)
+    for step in range(n - 1):
+        lq, tq = mq.greedy_step(tok, cq)
+        lb, tb = mb.greedy_step(tok, cb)
+        err = (lq.float() - lb.float()).abs().max().item()
+        assert err <= 3e-2 * lb.float().abs().max().item() + 1e-2, (step, err)
+        tok = tb.clone()
+    with pytest.raises(NotImplementedError):
+        mq(input_ids=np.zeros((6, 3), dtype=np.int64), cache=cq, n_beam=3, advance_offset=0)
+
+
 def test_generate_choose_constrain_match_oracle_loops(text):
     """The public API on the HIP model vs the oracle's restatement of the same loops."""
     import phi3v_oracle as orc
