@@ -176,8 +176,8 @@ int p3v_stage_rope(const float* cos_t, const float* sin_t, int past, const int32
  * p3v_kv_quantize converts rows [t0, t0+n_tok) of a bf16 K [BH, src_t, hd] / V^T [BH, hd, src_t] pair. */
 int p3v_kv_quantize(const uint16_t* k, const uint16_t* vt, uint8_t* k8, uint8_t* v8t, float* k_scale, float* v_scale,
                     int BH, int hd, int src_t, int dst_t, int t0, int n_tok, void* stream);
-/* p3v_attention_decode on the int8 cache: same contract; the step's own new rows are attended exactly
- * (bf16) and appended quantised. */
+/* p3v_attention_decode on the int8 cache: same contract; the step's own new rows are quantised,
+ * appended, and attended in their quantised form (one representation per key, whenever it is read). */
 typedef struct {
   const uint16_t* qkv; const float* cos_t; const float* sin_t;
   uint8_t* k8; uint8_t* v8t; float* k_scale; float* v_scale; uint16_t* out;

@@ -818,14 +818,18 @@ struct AttnDecQ8P {
   float scale;
 };
 
-__device__ __forceinline__ void u8x16_to_bf16(u32x4_t w, u32x4_t& lo, u32x4_t& hi) {   // 16 offset-binary bytes -> 16 bf16
+// 16 offset-binary bytes -> 16 bf16 holding the RAW byte values 0..255 (exact in bf16: 8 significant bits).
+// The -128 offset is not applied per element: it is folded out of the dot products,
+//   sum_d q[d]*(u-128) = sum_d q[d]*u - 128*sum_d q[d]     and     sum_t P[t]*(u-128) = sum_t P[t]*u - 128*sum_t P[t],
+// so dequantisation costs one v_cvt_f32_ubyteN per value plus the pair-wise bf16 pack.
+__device__ __forceinline__ void u8x16_to_bf16(u32x4_t w, u32x4_t& lo, u32x4_t& hi) {
   float f[16];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    f[4 * j + 0] = (float)((w[j] >> 0) & 0xffu) - 128.f;
-    f[4 * j + 1] = (float)((w[j] >> 8) & 0xffu) - 128.f;
-    f[4 * j + 2] = (float)((w[j] >> 16) & 0xffu) - 128.f;
-    f[4 * j + 3] = (float)((w[j] >> 24) & 0xffu) - 128.f;
+    asm("v_cvt_f32_ubyte0 %0, %1" : "=v"(f[4 * j + 0]) : "v"(w[j]));
+    asm("v_cvt_f32_ubyte1 %0, %1" : "=v"(f[4 * j + 1]) : "v"(w[j]));
+    asm("v_cvt_f32_ubyte2 %0, %1" : "=v"(f[4 * j + 2]) : "v"(w[j]));
+    asm("v_cvt_f32_ubyte3 %0, %1" : "=v"(f[4 * j + 3]) : "v"(w[j]));
   }
 #pragma unroll
   for (int j = 0; j < 4; ++j) { lo[j] = pack_bf16x2(f[2 * j], f[2 * j + 1]); hi[j] = pack_bf16x2(f[8 + 2 * j], f[9 + 2 * j]); }
@@ -836,6 +840,7 @@ __global__ void __launch_bounds__(64) k_attn_decode_q8(AttnDecQ8P p) {
   __shared__ __attribute__((aligned(16))) unsigned char Ks[TK * KSTR];
   __shared__ __attribute__((aligned(16))) unsigned char Vt[HD * VSTR];
   __shared__ __attribute__((aligned(16))) float ksl[TK], vsl[TK];
+  __shared__ __attribute__((aligned(16))) unsigned char Kx[HD * 2], Vx[HD * 2];   // exact new row (quantiser input)
   const int lane = threadIdx.x, g = lane >> 4, qi = lane & 15;
   const int b = blockIdx.z, head = blockIdx.y, kvh = head / (p.nh / p.nkv);
   const bool kv_writer = head % (p.nh / p.nkv) == 0;
@@ -880,25 +885,33 @@ __global__ void __launch_bounds__(64) k_attn_decode_q8(AttnDecQ8P p) {
       const bf16_t* row = p.qkv + ((size_t)b * p.L + r) * row_w;
       if (lane < 12) {
         const u32x4_t kn = rope_chunk(row + (p.nh + kvh) * HD, lane, cos_b + r * (HD / 2), sin_b + r * (HD / 2));
-        *(u32x4_t*)(Ks + (t - kv0) * KSTR + lane * 16) = kn;
+        *(u32x4_t*)(Kx + lane * 16) = kn;                     // exact copy for the quantiser below
       }
-      for (int d = lane; d < HD; d += 64) *(bf16_t*)(Vt + d * VSTR + (t - kv0) * 2) = row[(p.nh + p.nkv + kvh) * HD + d];
-      if (lane == 0) { ksl[t - kv0] = 1.f; vsl[t - kv0] = 1.f; }
+      for (int d = lane; d < HD; d += 64) *(bf16_t*)(Vx + d * 2) = row[(p.nh + p.nkv + kvh) * HD + d];
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      if (kv_writer) {                                        // append the quantised row / column (phi.py:545-546)
-        const float ka = lane < 48 ? bf16_to_f32(*(const bf16_t*)(Ks + (t - kv0) * KSTR + 4 * lane)) : 0.f;
-        const float kb = lane < 48 ? bf16_to_f32(*(const bf16_t*)(Ks + (t - kv0) * KSTR + 4 * lane + 2)) : 0.f;
-        const float kmax = wave_max(fmaxf(fabsf(ka), fabsf(kb)));
-        const float s = kmax > 0.f ? kmax / 127.f : 1.f, inv = 1.f / s;
-        if (lane < 48) *(uint16_t*)(kc + (size_t)t * HD + 2 * lane) = (uint16_t)(((int)rintf(ka * inv) + 128) | (((int)rintf(kb * inv) + 128) << 8));
-        const float va = bf16_to_f32(*(const bf16_t*)(Vt + lane * VSTR + (t - kv0) * 2));
-        const float vb = lane < 32 ? bf16_to_f32(*(const bf16_t*)(Vt + (lane + 64) * VSTR + (t - kv0) * 2)) : 0.f;
-        const float vmx = wave_max(fmaxf(fabsf(va), fabsf(vb)));
-        const float sv = vmx > 0.f ? vmx / 127.f : 1.f, invv = 1.f / sv;
-        vc[(size_t)lane * p.cache_t + t] = (uint8_t)((int)rintf(va * invv) + 128);
-        if (lane < 32) vc[(size_t)(lane + 64) * p.cache_t + t] = (uint8_t)((int)rintf(vb * invv) + 128);
+      // quantise the new row / column; the step itself attends over the SAME quantised values it stores
+      // (keeps one code path in the tile: bytes + scale), phi.py:545-546
+      const float ka = lane < 48 ? bf16_to_f32(*(const bf16_t*)(Kx + 4 * lane)) : 0.f;
+      const float kb = lane < 48 ? bf16_to_f32(*(const bf16_t*)(Kx + 4 * lane + 2)) : 0.f;
+      const float kmax = wave_max(fmaxf(fabsf(ka), fabsf(kb)));
+      const float s = kmax > 0.f ? kmax / 127.f : 1.f, inv = 1.f / s;
+      const int qa = (int)rintf(ka * inv) + 128, qb = (int)rintf(kb * inv) + 128;
+      const float va = bf16_to_f32(*(const bf16_t*)(Vx + lane * 2));
+      const float vb = lane < 32 ? bf16_to_f32(*(const bf16_t*)(Vx + (lane + 64) * 2)) : 0.f;
+      const float vmx = wave_max(fmaxf(fabsf(va), fabsf(vb)));
+      const float sv = vmx > 0.f ? vmx / 127.f : 1.f, invv = 1.f / sv;
+      const int qva = (int)rintf(va * invv) + 128, qvb = (int)rintf(vb * invv) + 128;
+      if (lane < 48) *(uint32_t*)(Ks + (t - kv0) * KSTR + 4 * lane) = pack_bf16x2((float)qa, (float)qb);
+      *(bf16_t*)(Vt + lane * VSTR + (t - kv0) * 2) = f32_to_bf16((float)qva);
+      if (lane < 32) *(bf16_t*)(Vt + (lane + 64) * VSTR + (t - kv0) * 2) = f32_to_bf16((float)qvb);
+      if (lane == 0) { ksl[t - kv0] = s; vsl[t - kv0] = sv; }
+      if (kv_writer) {
+        if (lane < 48) *(uint16_t*)(kc + (size_t)t * HD + 2 * lane) = (uint16_t)(qa | (qb << 8));
+        vc[(size_t)lane * p.cache_t + t] = (uint8_t)qva;
+        if (lane < 32) vc[(size_t)(lane + 64) * p.cache_t + t] = (uint8_t)qvb;
         if (lane == 0) { ksc[t] = s; vsc[t] = sv; }
       }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
   };
   if (kv_begin > kv_lo && kv_begin < kv_end) load_tile(kv_begin);
@@ -917,7 +930,18 @@ __global__ void __launch_bounds__(64) k_attn_decode_q8(AttnDecQ8P p) {
       qf[ks] = __builtin_bit_cast(bf16x8_t, v);
     }
   }
-  float m_run = -INFINITY, l_run = 0.f;
+  // 128 * sum_d q[d] of this lane's query (the folded K offset): the lane holds 3 x 8 of the 96 values
+  float qoff = 0.f;
+#pragma unroll
+  for (int ks = 0; ks < NKS; ++ks) {
+    const u32x4_t qw = __builtin_bit_cast(u32x4_t, qf[ks]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) qoff += bf16lo(qw[j]) + bf16hi(qw[j]);
+  }
+  qoff += __shfl_xor(qoff, 16, 64);
+  qoff += __shfl_xor(qoff, 32, 64);
+  qoff *= 128.f;
+  float m_run = -INFINITY, l_run = 0.f, p_run = 0.f;          // p_run = sum_t P'[t] (the folded V offset)
   f32x4_t o[NDT];
 #pragma unroll
   for (int d = 0; d < NDT; ++d) o[d] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
@@ -963,7 +987,7 @@ __global__ void __launch_bounds__(64) k_attn_decode_q8(AttnDecQ8P p) {
       for (int r = 0; r < 4; ++r) {
         const int t = kv0 + 16 * st + 4 * g + r;
         const bool vis = t < kv_end && t >= pad && t <= qpos && qpos >= pad;
-        const float v = vis ? s[st][r] * kk[r] * sc2 : -INFINITY;
+        const float v = vis ? (s[st][r] - qoff) * kk[r] * sc2 : -INFINITY;
         s[st][r] = v;
         m_t = fmaxf(m_t, v);
       }
@@ -973,18 +997,23 @@ __global__ void __launch_bounds__(64) k_attn_decode_q8(AttnDecQ8P p) {
     const float m_new = fmaxf(m_run, m_t);
     const float m_use = m_new == -INFINITY ? 0.f : m_new;
     const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);
-    float l_t = 0.f;
+    float l_t = 0.f, p_t = 0.f;
 #pragma unroll
     for (int st = 0; st < 4; ++st)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const float e = __builtin_amdgcn_exp2f(s[st][r] - m_use);
         l_t += e;
-        s[st][r] = e > 0.f ? e * vsv[st][r] : 0.f;            // V scale folded into P (masked keys stay exactly 0)
+        const float pv = bf16_round(e > 0.f ? e * vsv[st][r] : 0.f);   // V scale folded into P (masked keys stay exactly 0)
+        s[st][r] = pv;
+        p_t += pv;
       }
     l_t += __shfl_xor(l_t, 16, 64);
     l_t += __shfl_xor(l_t, 32, 64);
+    p_t += __shfl_xor(p_t, 16, 64);
+    p_t += __shfl_xor(p_t, 32, 64);
     l_run = l_run * alpha + l_t;
+    p_run = p_run * alpha + p_t;
     m_run = m_new;
 #pragma unroll
     for (int d = 0; d < NDT; ++d) o[d] *= alpha;
@@ -1008,8 +1037,9 @@ __global__ void __launch_bounds__(64) k_attn_decode_q8(AttnDecQ8P p) {
   }
   if (!qvalid) return;
   float* w = p.ws + ((((size_t)b * p.nh + head) * p.n_split + blockIdx.x) * 16 + qi) * (HD + 2);
+  const float voff = 128.f * p_run;
 #pragma unroll
-  for (int d = 0; d < NDT; ++d) *(f32x4_t*)(w + 16 * d + 4 * g) = o[d];
+  for (int d = 0; d < NDT; ++d) *(f32x4_t*)(w + 16 * d + 4 * g) = o[d] - voff;
   if (g == 0) { w[HD] = m_run; w[HD + 1] = l_run; }
 }
 

@@ -297,8 +297,11 @@ def test_kv_quantize_and_q8_decode(ops, orc):
     cs, sn = cos_ref[:, :, past:past + L], sin_ref[:, :, past:past + L]
     q = orc.rotate_half(x[:, :nh], cs, sn).to(BF16)
     k_new = orc.rotate_half(x[:, nh:2 * nh], cs, sn).to(BF16)
-    kf = torch.cat([kd[:, :, :past], k_new.float()], dim=2)
-    vf = torch.cat([vd[:, :, :past], x[:, 2 * nh:].float()], dim=2)
+    def qdq(t):                                                 # the step attends over the values it stores
+        sc = t.float().abs().amax(-1, keepdim=True) / 127
+        return torch.round(t.float() / sc) * sc
+    kf = torch.cat([kd[:, :, :past], qdq(k_new)], dim=2)
+    vf = torch.cat([vd[:, :, :past], qdq(x[:, 2 * nh:])], dim=2)
     allowed = torch.ones((B, 1, L, past + L), dtype=torch.bool)
     ref = _attn_ref(orc, q, kf, vf, hd ** -0.5, allowed).transpose(1, 2).reshape(B, L, nh * hd)
     close(out, ref, rtol=2 ** -6, atol=2e-2)
