@@ -100,6 +100,19 @@ typedef struct {
 int p3v_gemv(const p3v_gemv_args_t* args /* host */, void* stream);
 int64_t p3v_gemv_ws_bytes(int M, int N, int K);
 
+/* ---- fp8 (OCP e4m3fn) weight-only projections (quantize_model=True; replaces the int4 `nn.quantize` of
+ * phi_3_vision_mlx.py:264,296): W is u8 [N or 2N, K] bit patterns, w = fp8 * w_scale[row]; x, accumulation
+ * and outputs as in p3v_gemv.  K in {3072, 8192}, M <= 16.  p3v_dequant_fp8 expands rows to bf16 (prefill). */
+typedef struct {
+  const uint16_t* x; const uint8_t* W; const float* w_scale; void* out;
+  const uint16_t* resid; const uint16_t* norm_w;
+  float norm_eps;
+  int M, N, K;
+  int epilogue;
+} p3v_gemv_fp8_args_t;
+int p3v_gemv_fp8(const p3v_gemv_fp8_args_t* args /* host */, void* stream);
+int p3v_dequant_fp8(const uint8_t* w8, const float* w_scale, uint16_t* out_bf16, int rows, int K, void* stream);
+
 /* ---- SuRoPE tables, phi.py:487-504: cos/sin[n_pos, half] = {cos,sin}(pos*inv_freq)*scale (fp32) */
 int p3v_rope_table(const float* pos, const float* inv_freq, float scale, float* cos_out, float* sin_out,
                    int n_pos, int half_dim, void* stream);

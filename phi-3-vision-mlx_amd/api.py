@@ -8,7 +8,8 @@ reference's `load / generate / choose / constrain / benchmark`
 Host code stays Python; everything that touches the device goes through
 `model(...)` (model.py) and `model_ops` (ops.py), i.e. hand-written HIP kernels.
 
-`quantize_cache=True` selects the int8 KV cache (the build's analogue of the reference's 4-bit prompt cache).
+`quantize_cache=True` selects the int8 KV cache and `quantize_model=True` fp8 (e4m3) decoder weights -- the build's
+analogues of the reference's 4-bit prompt cache / int4 weights (BASELINE config 5).
 Not carried over (out of scope): LoRA adapters
 (`use_adapter=True` raises NotImplementedError), the `<|api_input|>` tool hook,
 HF-hub download (`_setup`): a model directory must exist locally, or pass
@@ -234,16 +235,15 @@ def load(blind_model=False, quantize_model=False, quantize_cache=False, use_adap
     synthetic = kwargs.pop("synthetic", None)
     if use_adapter:
         raise NotImplementedError("use_adapter=True: LoRA is outside the inference hot path of this build")
-    if quantize_model:
-        raise NotImplementedError("quantize_model=True (fp8 weights, BASELINE config 5) is not implemented in this round")
     if synthetic:
-        return load_synthetic(blind_model=blind_model, tiny=(synthetic == "tiny"), use_quantized_cache=quantize_cache, **kwargs)
+        return load_synthetic(blind_model=blind_model, tiny=(synthetic == "tiny"), use_quantized_cache=quantize_cache,
+                              quantized_fp8=quantize_model, **kwargs)
     model_path = kwargs.pop("model_path", None) or (PATH_ORIGINAL_PHI3_BLIND if blind_model else PATH_ORIGINAL_PHI3_VISION)
     if not os.path.exists(model_path):
         raise FileNotFoundError(
             f"model directory {model_path!r} not found and this build cannot download checkpoints; "
             "place HF-layout safetensors + config.json there, or use load(synthetic=True)")
-    return _load(model_path=model_path, use_quantized_cache=quantize_cache, adapter_path=None, **kwargs)
+    return _load(model_path=model_path, use_quantized_cache=quantize_cache, quantized_fp8=quantize_model, adapter_path=None, **kwargs)
 
 
 # ----------------------------------------------------------------------------- generate

@@ -105,6 +105,34 @@ def gemv(x, w, epilogue=EPI_NONE, resid=None, norm_w=None, norm_eps=0.0, out=Non
     return out
 
 
+def quantize_fp8_rows(w):
+    """bf16 [N,K] -> (u8 e4m3fn bit patterns [N,K], fp32 scale [N]); w ~ fp8 * scale.  Load-time weight prep."""
+    wf = w.float()
+    scale = (wf.abs().amax(dim=1) / 448.0).clamp_min(1e-12)
+    w8 = (wf / scale[:, None]).to(torch.float8_e4m3fn).view(torch.uint8).contiguous()
+    return w8, scale.contiguous()
+
+
+def gemv_fp8(x, w8, w_scale, epilogue=EPI_NONE, resid=None, norm_w=None, norm_eps=0.0, out=None):
+    """`gemv` on fp8 weights (half the streamed bytes)."""
+    _chk(x, BF16, "x"), _chk(w8, torch.uint8, "w8"), _chk(w_scale, F32, "w_scale")
+    M, K = x.shape
+    N = w8.shape[0] // 2 if epilogue == EPI_SILU_MUL else w8.shape[0]
+    if out is None:
+        out = torch.empty((M, N), dtype=F32 if epilogue == EPI_F32 else BF16, device=x.device)
+    args = L.GemvF8Args(_p(x), _p(w8), _p(w_scale), _p(out), _p(resid), _p(norm_w), float(norm_eps), M, N, K, epilogue)
+    L.check(L.lib().p3v_gemv_fp8(C.byref(args), _stream()), "gemv_fp8")
+    return out
+
+
+def dequant_fp8(w8, w_scale, out=None):
+    """fp8 rows -> bf16 (scratch for the prefill GEMM)."""
+    N, K = w8.shape
+    out = torch.empty((N, K), dtype=BF16, device=w8.device) if out is None else out
+    L.check(L.lib().p3v_dequant_fp8(_p(w8), _p(w_scale), _p(out), N, K, _stream()), "dequant_fp8")
+    return out
+
+
 def linear(x, w, epilogue=EPI_NONE, resid=None, out=None):
     """Dispatch a projection to the weight-streaming GEMV (M<=8) or the MFMA GEMM."""
     if x.shape[0] <= GEMV_MAX_M and x.shape[1] % 512 == 0 or x.shape[0] <= 8 and epilogue in (EPI_NONE, EPI_RESID_BF16, EPI_SILU_MUL, EPI_F32):

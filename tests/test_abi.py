@@ -31,7 +31,7 @@ def test_struct_layouts_match_header_field_order():
     h = open(os.path.join(ROOT, "include", "p3v.h")).read()
     for cname, cls in (("p3v_gemm_args_t", _lib.GemmArgs), ("p3v_gemv_args_t", _lib.GemvArgs),
                        ("p3v_attn_args_t", _lib.AttnArgs), ("p3v_attn_decode_args_t", _lib.AttnDecArgs),
-                       ("p3v_attn_decode_q8_args_t", _lib.AttnDecQ8Args)):
+                       ("p3v_attn_decode_q8_args_t", _lib.AttnDecQ8Args), ("p3v_gemv_fp8_args_t", _lib.GemvF8Args)):
         end = h.index("} " + cname)
         body = h[h.rindex("typedef struct {", 0, end) + len("typedef struct {"):end]
         body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)

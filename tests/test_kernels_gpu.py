@@ -158,6 +158,40 @@ def test_gemv(ops, orc, M, N, K, epi):
     close(out, ref, rtol=2 ** -6, atol=2e-2)
 
 
+@pytest.mark.parametrize("M,N,K,epi", [(1, 9216, 3072, "norm"), (1, 3072, 8192, "resid"), (1, 8192, 3072, "silu"),
+                                       (8, 3072, 3072, "resid"), (16, 8192, 3072, "silu"), (5, 9216, 3072, "norm"),
+                                       (2, 3072, 8192, "none"), (1, 32064, 3072, "norm")])
+def test_gemv_fp8(ops, orc, M, N, K, epi):
+    """fp8 weight-only projection == the bf16 math on the DEQUANTISED weights (the only new error is weight rounding,
+    which the reference comparison below does not see: both sides use fp8*scale)."""
+    x = g((M, K), 24)
+    rows = 2 * N if epi == "silu" else N
+    w = g((rows, K), 25, 1.0 / math.sqrt(K))
+    w8, sc = ops.quantize_fp8_rows(w.cuda())
+    wd = ops.dequant_fp8(w8, sc).cpu()
+    assert torch.equal(wd.float(), (w8.cpu().view(torch.float8_e4m3fn).float() * sc.cpu()[:, None]).to(BF16).float())
+    assert (wd.float() - w.float()).abs().max() <= w.float().abs().max() * 2 ** -3       # e4m3: 3 mantissa bits
+    wdq = w8.cpu().view(torch.float8_e4m3fn).float() * sc.cpu()[:, None]                   # exact fp32 dequant
+    kw = {}
+    xin = x
+    if epi == "norm":
+        nw_ = g((K,), 26, 0.1) + 1
+        kw = dict(norm_w=nw_.cuda(), norm_eps=1e-5)
+        xin = orc.rms_norm(x, nw_, 1e-5)
+    acc = xin.float() @ wdq.t()
+    if epi in ("none", "norm"):
+        out, ref = ops.gemv_fp8(x.cuda(), w8, sc, **kw), acc.to(BF16)
+    elif epi == "resid":
+        r = g((M, N), 27)
+        rc = r.cuda()
+        out = ops.gemv_fp8(x.cuda(), w8, sc, ops.EPI_RESID_BF16, resid=rc, out=rc)
+        ref = (r.float() + acc.to(BF16).float()).to(BF16)
+    else:
+        gate, up = acc[:, :N].to(BF16), acc[:, N:].to(BF16)
+        out, ref = ops.gemv_fp8(x.cuda(), w8, sc, ops.EPI_SILU_MUL), (gate * torch.sigmoid(gate)) * up
+    close(out, ref, rtol=2 ** -6, atol=3e-2)
+
+
 @pytest.mark.parametrize("L,T,past", [(5, 40, 7), (70, 128, 8), (100, 192, 3), (64, 64, 0)])
 def test_rope_table_and_append(ops, orc, L, T, past):
     from phi_3_vision_mlx_amd.config import make_config, rope_scaling_factor

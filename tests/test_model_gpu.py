@@ -192,6 +192,33 @@ def test_quantized_cache_close_to_bf16_cache():
         mq(input_ids=np.zeros((6, 3), dtype=np.int64), cache=cq, n_beam=3, advance_offset=0)
 
 
+def test_fp8_weights_equal_bf16_model_on_dequantised_weights():
+    """quantize_model=True: the fp8 model must equal a bf16 model that is handed the dequantised weights
+    (isolates the kernels from the quantisation error itself), and stay close to the unquantised model."""
+    from phi_3_vision_mlx_amd.api import load_synthetic
+    from phi_3_vision_mlx_amd.model import Phi3VModel
+    from phi_3_vision_mlx_amd import ops
+    mf, proc = load_synthetic(blind_model=True, tiny=True, seed=0, std_scale=4.0, device="cuda:0", quantized_fp8=True)
+    assert len(mf.w8) == 2 * 4 + 1 and "lm_head.weight" not in mf.w
+    wd = dict(mf.w)
+    for k, (w8, sc) in mf.w8.items():
+        wd[k] = ops.dequant_fp8(w8, sc)
+    mb = Phi3VModel(mf.cfg.__class__(**{**vars(mf.cfg), "quantized_fp8": False}), wd, device="cuda:0")
+    m0, _ = load_synthetic(blind_model=True, tiny=True, seed=0, std_scale=4.0, device="cuda:0")
+    inputs = proc(["fp8 check", "a second and longer row for the batch"])
+    lf, cf = mf(**inputs, max_tokens=5)
+    lb, cb = mb(**inputs, max_tokens=5)
+    l0, _ = m0(**inputs, max_tokens=5)
+    assert_logits(lf[:, -1], lb[:, -1], "fp8 vs bf16-on-dequantised prefill")
+    assert (lf.float() - l0.float()).abs().max().item() <= 0.2 * l0.float().abs().max().item()      # weight rounding, 3-bit mantissa
+    tok = model_tok(lb)
+    for step in range(4):
+        lf, _ = mf.greedy_step(tok, cf)
+        lb, tb = mb.greedy_step(tok, cb)
+        assert_logits(lf[:, -1], lb[:, -1], f"fp8 vs bf16-on-dequantised decode {step}")
+        tok = tb.clone()
+
+
 def test_generate_choose_constrain_match_oracle_loops(text):
     """The public API on the HIP model vs the oracle's restatement of the same loops."""
     import phi3v_oracle as orc

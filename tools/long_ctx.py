@@ -5,7 +5,7 @@ import numpy as np, torch
 from phi_3_vision_mlx_amd import ops
 from phi_3_vision_mlx_amd.api import load_synthetic
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 32768
-model, _ = load_synthetic(blind_model=True, device="cuda:0", use_quantized_cache=bool(os.environ.get("P3V_QCACHE")))
+model, _ = load_synthetic(blind_model=True, device="cuda:0", use_quantized_cache=bool(os.environ.get("P3V_QCACHE")), quantized_fp8=bool(os.environ.get("P3V_FP8")))
 ids = np.random.default_rng(0).integers(3, 32000, (1, S))
 for rep in range(2):
     torch.cuda.synchronize(); t0 = time.perf_counter()
