@@ -216,6 +216,14 @@ def main():
     k_ms = float(np.median(reps))
     achieved = alg_bytes / (k_ms * 1e-3) / 1e9
 
+    # HBM bytes per launch from the PMC passes (tools/pmc_gemv.sh: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
+    # runs, FETCH_SIZE x2 on gfx950); a committed measurement, not re-collected inside the timed benchmark
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_gate_up_gemv.json")) as f:
+            traffic = json.load(f)["hbm_bytes_per_launch_corrected"]
+    except Exception:
+        pass
     kv_bytes = 2 * L * cfg.num_key_value_heads * (cfg.hidden_size // cfg.num_attention_heads) * 2 * (S + args.warmup + args.steps // 2)
     w_bytes = sum(v.numel() * 2 for k, v in model.w.items() if k.startswith("model.layers.") or k == "lm_head.weight")
     step_s = elapsed / args.steps
@@ -232,7 +240,7 @@ def main():
                             "achieved_GBps": round((w_bytes + kv_bytes) / step_s / 1e9, 1),
                             "frac_of_peak": round((w_bytes + kv_bytes) / step_s / 1e9 / HBM_PEAK_GBS, 4)},
         "roofline": {"bound": "hbm", "kernel": "k_gemv3<1,1,6> (RMSNorm + gate_up_proj + SiLU*up), 32 launches/step", "achieved": round(achieved, 1),
-                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                      "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(k_ms, 5)},
         "first_token": first, "weights_init_s": round(t_weights, 1),
     }
