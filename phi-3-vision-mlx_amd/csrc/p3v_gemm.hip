@@ -18,6 +18,8 @@
 //             (the MFMA C layout itself would give 2-byte stores at a row stride).
 //
 // Roofline: MFMA-bound for M >= ~512 (2*M*N*K flops vs (M+N)*K*2 bytes).
+#include <stdlib.h>
+
 #include "p3v_common.h"
 
 #define BM 128
@@ -249,6 +251,8 @@ static int launch_gemm(const GemmP& p, hipStream_t s) {
   return P3V_OK;
 }
 
+int p3v_gemm256_try(const p3v_gemm_args_t* a, hipStream_t s);   // p3v_gemm256.hip: 256x256 tiles for prefill-sized problems
+
 extern "C" int p3v_gemm(const p3v_gemm_args_t* a, void* stream) {
   if (!a || !a->A || !a->W || !a->out) return P3V_ERR_ARG;
   if (a->M < 0 || a->N <= 0 || a->K <= 0 || a->K % BK || a->N % 8 || a->ldo % 8) return P3V_ERR_ARG;
@@ -261,6 +265,11 @@ extern "C" int p3v_gemm(const p3v_gemm_args_t* a, void* stream) {
   const GemmP p = {a->A, a->W, a->out, a->bias, a->resid, a->pos, a->M, a->N, a->K, a->lda, a->ldw, a->ldo,
                    a->patches_per_img};
   hipStream_t s = (hipStream_t)stream;
+  static const bool big_tiles = !getenv("P3V_GEMM_128");
+  if (big_tiles) {
+    const int rc = p3v_gemm256_try(a, s);
+    if (rc != P3V_ERR_UNSUPPORTED) return rc;
+  }
   switch (a->epilogue) {
     case P3V_EPI_NONE: return launch_gemm<P3V_EPI_NONE>(p, s);
     case P3V_EPI_BIAS: return launch_gemm<P3V_EPI_BIAS>(p, s);

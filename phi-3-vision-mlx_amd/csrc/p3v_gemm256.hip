@@ -1,0 +1,272 @@
+// Large-tile variant of the dense projection for prefill-sized problems (M >= 1024, N % 256 == 0, K % 64 == 0):
+//   256(M) x 256(N) x 64(K) tile, 512 threads = 8 waves as 2(M) x 4(N), each wave 128 x 64 =
+//   8 x 4 v_mfma_f32_16x16x32_bf16 accumulators (128 registers), 2.67 MFMAs per LDS fragment read
+//   (the 128x128 kernel: 2.0) and 25 % less global->LDS traffic per flop.
+//   K-tile t lives in LDS buffer t&1 (2 x 64 KiB); the four 16-KiB half-tiles of tile t+1 are requested by
+//   LDS-DMA one per PHASE of tile t (a phase = one 64x32 accumulator quadrant = 16 MFMAs), so the loads are
+//   spread under the whole tile's matrix work; one vmcnt(0) + barrier per K-tile.  No barrier inside a tile:
+//   the waves de-phase, one wave's fragment reads overlap another's MFMAs.
+//   Same XOR-swizzled LDS image and the same epilogues as p3v_gemm.hip (through a wave-private LDS tile).
+#include <stdlib.h>
+
+#include "p3v_common.h"
+
+#define TM 256
+#define TN 256
+#define TK 64
+#define HALF_BYTES (128 * TK * 2)     // 16 KiB
+#define BUF_BYTES (4 * HALF_BYTES)    // A0 A1 B0 B1
+#define CT2_LD 68
+#define GEMM256_LDS (2 * BUF_BYTES)   // 128 KiB (epilogue: 8 waves x 64x68 fp32 = 136 KiB would not fit -> two passes of 32 rows)
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+struct Gemm256P {
+  const bf16_t* A; const bf16_t* W; void* out; const bf16_t* bias; const void* resid;
+  int M, N, K, lda, ldw, ldo;
+};
+
+__device__ __forceinline__ float gelu_erf2(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+
+template <int EPI>
+__global__ void __launch_bounds__(512, 1) k_gemm256(Gemm256P p) {
+  constexpr bool SILU = EPI == P3V_EPI_SILU_MUL;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 2, wc = wave & 3;
+  constexpr int n_out_tile = SILU ? TN / 2 : TN;
+  int m_t, n_t;
+  {
+    const int gx = gridDim.x, gy = gridDim.y, nwg = gx * gy, wid = blockIdx.y * gx + blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = wid & 7, loc = wid >> 3;
+    const int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    constexpr int BAND = 4;
+    const int band = id / (BAND * gx), in_band = id % (BAND * gx);
+    const int rows = min(BAND, gy - band * BAND);
+    m_t = band * BAND + in_band % rows;
+    n_t = in_band / rows;
+  }
+  const int m0 = m_t * TM, n0 = n_t * n_out_tile;
+
+  // ---- DMA source pointers: half-tile h (128 rows), instruction q (64 rows), this thread: row tid/8, chunk tid%8
+  const int srow = tid >> 3, schunk = tid & 7;
+  const bf16_t* a_src[2][2];
+  const bf16_t* b_src[2][2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int r = h * 128 + q * 64 + srow;
+      const int sw = (schunk ^ (r & 7)) * 8;
+      const int ar = min(m0 + r, p.M - 1);
+      a_src[h][q] = p.A + (size_t)ar * p.lda + sw;
+      int br;
+      if (SILU) {                                   // wave column group wcol (64 tile rows) = 32 gate + 32 up rows
+        const int wcol = r >> 6, ni = (r & 63) >> 4, c = r & 15;
+        br = min(n0 + wcol * 32 + (ni & 1) * 16 + c, p.N - 1) + (ni >> 1) * p.N;
+      } else {
+        br = min(n0 + r, p.N - 1);
+      }
+      b_src[h][q] = p.W + (size_t)br * p.ldw + sw;
+    }
+  auto dma_half = [&](int which, int kt, int buf) {   // which: 0 A0, 1 A1, 2 B0, 3 B1
+    unsigned char* base = smem + buf * BUF_BYTES + which * HALF_BYTES + wave * 1024;
+    const int h = which & 1;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const bf16_t* src = (which < 2 ? a_src[h][q] : b_src[h][q]) + (size_t)kt * TK;
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(base + q * 8192), 16, 0, 0);
+    }
+  };
+
+  f32x4_t acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  const int frow = lane & 15, fchunk = lane >> 4;
+  const int nk = p.K / TK;
+#pragma unroll
+  for (int w4 = 0; w4 < 4; ++w4) dma_half(w4, 0, 0);
+
+  for (int kt = 0; kt < nk; ++kt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const bool more = kt + 1 < nk;
+    const int nb = (kt + 1) & 1;
+    const unsigned char* ta = smem + (kt & 1) * BUF_BYTES + wr * HALF_BYTES;                      // this wave's A half
+    const unsigned char* tb = smem + (kt & 1) * BUF_BYTES + (2 + (wc >> 1)) * HALF_BYTES + (wc & 1) * 64 * 128;  // its 64 B rows
+    bf16x8_t af[4][2], bf0[2][2], bf1[2][2];
+    auto read_a = [&](int sub) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+          const int r = sub * 64 + i * 16 + frow;
+          af[i][kk] = *(const bf16x8_t*)(ta + r * 128 + (((kk * 4 + fchunk) ^ (r & 7)) << 4));
+        }
+    };
+    auto read_b = [&](int sub, bf16x8_t (&bf)[2][2]) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+          const int r = sub * 32 + j * 16 + frow;
+          bf[j][kk] = *(const bf16x8_t*)(tb + r * 128 + (((kk * 4 + fchunk) ^ (r & 7)) << 4));
+        }
+    };
+    auto quad = [&](int asub, int bsub, bf16x8_t (&bf)[2][2]) {
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[asub * 4 + i][bsub * 2 + j] =
+                __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][kk], bf[j][kk], acc[asub * 4 + i][bsub * 2 + j], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+    };
+    // phase 0
+    if (more) dma_half(0, kt + 1, nb);
+    read_b(0, bf0);
+    read_a(0);
+    quad(0, 0, bf0);
+    // phase 1
+    if (more) dma_half(1, kt + 1, nb);
+    read_b(1, bf1);
+    quad(0, 1, bf1);
+    // phase 2
+    if (more) dma_half(2, kt + 1, nb);
+    read_a(1);
+    quad(1, 1, bf1);
+    // phase 3
+    if (more) dma_half(3, kt + 1, nb);
+    quad(1, 0, bf0);
+  }
+
+  // ---- epilogue: 128 x 64 per wave, in four passes of 32 rows through a wave-private [32][68] fp32 LDS tile
+  __syncthreads();
+  float* ct = (float*)smem + wave * (32 * CT2_LD);
+  const int ccol = lane & 15, crow = (lane >> 4) * 4;
+#pragma unroll
+  for (int pass = 0; pass < 4; ++pass) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ct[(i * 16 + crow + r) * CT2_LD + j * 16 + ccol] = acc[pass * 2 + i][j][r];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (SILU) {
+      const int c8 = (lane & 3) * 8, n = n0 + wc * 32 + c8;
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        const int row = it * 16 + (lane >> 2);
+        const int m = m0 + wr * 128 + pass * 32 + row;
+        if (m < p.M && n < p.N) {
+          const float4 g0 = *(const float4*)(ct + row * CT2_LD + c8), g1 = *(const float4*)(ct + row * CT2_LD + c8 + 4);
+          const float4 u0 = *(const float4*)(ct + row * CT2_LD + 32 + c8), u1 = *(const float4*)(ct + row * CT2_LD + 36 + c8);
+          const float gs[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+          const float us[8] = {u0.x, u0.y, u0.z, u0.w, u1.x, u1.y, u1.z, u1.w};
+          u32x4_t w;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float o2[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+              const float g = bf16_round(gs[2 * e + h]), u = bf16_round(us[2 * e + h]);
+              o2[h] = bf16_round(g * bf16_round(1.f / (1.f + __expf(-g)))) * u;
+            }
+            w[e] = pack_bf16x2(o2[0], o2[1]);
+          }
+          *(u32x4_t*)((bf16_t*)p.out + (size_t)m * p.ldo + n) = w;
+        }
+      }
+    } else {
+      const int c8 = (lane & 7) * 8, n = n0 + wc * 64 + c8;
+      const bool ncol_ok = n < p.N;
+      float bias[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (ncol_ok && p.bias) {
+        const u32x4_t bw = *(const u32x4_t*)(p.bias + n);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { bias[2 * j] = bf16lo(bw[j]); bias[2 * j + 1] = bf16hi(bw[j]); }
+      }
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int row = it * 8 + (lane >> 3);
+        const int m = m0 + wr * 128 + pass * 32 + row;
+        if (m < p.M && ncol_ok) {
+          const float4 a0 = *(const float4*)(ct + row * CT2_LD + c8), a1 = *(const float4*)(ct + row * CT2_LD + c8 + 4);
+          float v[8] = {a0.x + bias[0], a0.y + bias[1], a0.z + bias[2], a0.w + bias[3],
+                        a1.x + bias[4], a1.y + bias[5], a1.z + bias[6], a1.w + bias[7]};
+          const size_t o = (size_t)m * p.ldo + n;
+          if (EPI == P3V_EPI_BIAS_QGELU) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = v[e] / (1.f + __expf(-1.702f * v[e]));
+          } else if (EPI == P3V_EPI_BIAS_GELU) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = gelu_erf2(v[e]);
+          } else if (EPI == P3V_EPI_RESID_BF16) {
+            const u32x4_t rw = *(const u32x4_t*)((const bf16_t*)p.resid + o);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { v[2 * j] = bf16lo(rw[j]) + bf16_round(v[2 * j]); v[2 * j + 1] = bf16hi(rw[j]) + bf16_round(v[2 * j + 1]); }
+          }
+          if (EPI == P3V_EPI_BIAS_RESID_F32 || EPI == P3V_EPI_F32) {
+            if (EPI == P3V_EPI_BIAS_RESID_F32) {
+              const float4 r0 = *(const float4*)((const float*)p.resid + o), r1 = *(const float4*)((const float*)p.resid + o + 4);
+              v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w; v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
+            }
+            *(float4*)((float*)p.out + o) = make_float4(v[0], v[1], v[2], v[3]);
+            *(float4*)((float*)p.out + o + 4) = make_float4(v[4], v[5], v[6], v[7]);
+          } else {
+            u32x4_t w;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) w[j] = pack_bf16x2(v[2 * j], v[2 * j + 1]);
+            *(u32x4_t*)((bf16_t*)p.out + o) = w;
+          }
+        }
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+}
+
+template <int EPI>
+static int launch_gemm256(const Gemm256P& p, hipStream_t s) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)k_gemm256<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM256_LDS) != hipSuccess)
+      return P3V_ERR_HIP;
+    attr_set = true;
+  }
+  const int n_tile = EPI == P3V_EPI_SILU_MUL ? TN / 2 : TN;
+  dim3 grid(p3v_cdiv(p.N, n_tile), p3v_cdiv(p.M, TM));
+  hipLaunchKernelGGL(k_gemm256<EPI>, grid, dim3(512), GEMM256_LDS, s, p);
+  P3V_CHECK_LAUNCH();
+  return P3V_OK;
+}
+
+// called by p3v_gemm for the large-problem epilogues it supports; returns P3V_ERR_UNSUPPORTED to fall back
+int p3v_gemm256_try(const p3v_gemm_args_t* a, hipStream_t s) {
+  const int n_tile = a->epilogue == P3V_EPI_SILU_MUL ? TN / 2 : TN;
+  if (a->M < 1024 || a->N % n_tile || a->K % TK || a->epilogue == P3V_EPI_PATCH) return P3V_ERR_UNSUPPORTED;
+  // 1 workgroup per CU: the big tile only pays when the grid is several rounds of 256 workgroups deep (measured:
+  // +13 % at 4096^3/8192^3, but -25 % on 2531x3072x3072 = 120 workgroups) -- otherwise the 128x128 kernel runs
+  const long blocks = (long)p3v_cdiv(a->M, TM) * (a->N / n_tile);
+  if (!getenv("P3V_GEMM_256_ALWAYS") && !(blocks >= 1024 || (blocks >= 448 && a->K >= 2048))) return P3V_ERR_UNSUPPORTED;
+  const Gemm256P p = {a->A, a->W, a->out, a->bias, a->resid, a->M, a->N, a->K, a->lda, a->ldw, a->ldo};
+  switch (a->epilogue) {
+    case P3V_EPI_NONE: return launch_gemm256<P3V_EPI_NONE>(p, s);
+    case P3V_EPI_BIAS: return launch_gemm256<P3V_EPI_BIAS>(p, s);
+    case P3V_EPI_BIAS_QGELU: return launch_gemm256<P3V_EPI_BIAS_QGELU>(p, s);
+    case P3V_EPI_BIAS_GELU: return launch_gemm256<P3V_EPI_BIAS_GELU>(p, s);
+    case P3V_EPI_BIAS_RESID_F32: return launch_gemm256<P3V_EPI_BIAS_RESID_F32>(p, s);
+    case P3V_EPI_RESID_BF16: return launch_gemm256<P3V_EPI_RESID_BF16>(p, s);
+    case P3V_EPI_SILU_MUL: return launch_gemm256<P3V_EPI_SILU_MUL>(p, s);
+    case P3V_EPI_F32: return launch_gemm256<P3V_EPI_F32>(p, s);
+    default: return P3V_ERR_UNSUPPORTED;
+  }
+}

@@ -3,6 +3,8 @@ import sys
 
 import pytest
 
+os.environ.setdefault("P3V_GEMM_256_ALWAYS", "1")   # exercise the 256x256-tile GEMM on test-sized problems too
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests", "golden")):
     if p not in sys.path:

@@ -79,11 +79,16 @@ EPI_CASES = [
     ("bias", 577, 3072, 1024), ("qgelu", 130, 4096, 1024), ("gelu", 77, 3072, 4096),
     ("resid_f32", 577, 1024, 4096), ("resid_bf16", 300, 3072, 8192), ("silu", 300, 8192, 3072),
     ("silu", 20, 256, 192), ("f32", 65, 192, 128),
+    # large-tile (256x256) path: M >= 1024, N % 256 == 0 (N % 128 for silu)
+    ("none", 1100, 768, 192), ("bias", 1300, 1024, 128), ("qgelu", 1024, 512, 256), ("gelu", 1030, 256, 128),
+    ("resid_f32", 2000, 1024, 192), ("resid_bf16", 2531, 3072, 256), ("silu", 1500, 640, 192), ("f32", 1025, 256, 64),
 ]
 
 
 @pytest.mark.parametrize("epi,M,N,K", EPI_CASES)
 def test_gemm(ops, epi, M, N, K):
+    # (P3V_GEMM_256_ALWAYS is read at first use inside the library; conftest sets it so the big-tile kernel
+    #  is exercised on these small shapes too)
     a = g((M, K), 10)
     nw = 2 * N if epi == "silu" else N
     w = g((nw, K), 11, 1.0 / math.sqrt(K))
