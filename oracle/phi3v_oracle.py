@@ -205,7 +205,7 @@ class OraclePhi3V:
     def image_embedding(self, txt_embeds, pixel_values, image_sizes, positions, return_parts=False):
         """Phi3ImageEmbedding.__call__ (phi.py:393-416)."""
         e = "model.vision_embed_tokens."
-        pv = torch.as_tensor(pixel_values).to(F32)                       # mx.array(f64) -> fp32
+        pv = torch.as_tensor(pixel_values).cpu().to(F32)                 # mx.array(f64) -> fp32
         B = pv.shape[0]
         img_sizes = (torch.as_tensor(image_sizes) // 336).tolist()
         positions = torch.as_tensor(positions).tolist()

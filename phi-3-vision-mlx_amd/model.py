@@ -184,7 +184,10 @@ class Phi3VModel:
         (dead zero-padded crop slots are skipped, Q5), HD merge, projector, and
         the projector's second GEMM writes straight into the text embeddings."""
         w = self.w
-        pv = torch.as_tensor(np.asarray(pixel_values), dtype=F32)          # f64 -> f32 as mx.array does
+        if torch.is_tensor(pixel_values):                                  # processor(return_mx=True): already f32 on the GPU
+            pv = pixel_values.to(F32)
+        else:
+            pv = torch.as_tensor(np.asarray(pixel_values), dtype=F32)      # f64 -> f32 as mx.array does
         sizes = (np.asarray(image_sizes) // 336).tolist()
         positions = np.asarray(positions).tolist()
         live = [h * ww + 1 for h, ww in sizes]

@@ -137,6 +137,16 @@ class Phi3VProcessor(Phi3FProcessor):
             return self._tokenize(texts)
         return self._merge(self.img_processor(images), texts)
 
+    def _to_device(self, pixel_values):
+        """The reference hands the model `mx.array(images)` (phi.py:279): float64 -> float32 ON the device, inside
+        the processor, i.e. before the prefill timer starts.  With return_mx (default) we do the same: a float32
+        torch tensor on the current GPU (CPU tensor when there is no GPU); return_mx=False keeps the float64 array."""
+        if not self.return_mx:
+            return pixel_values
+        import torch
+        t = torch.as_tensor(np.asarray(pixel_values), dtype=torch.float32)
+        return t.cuda(non_blocking=True) if torch.cuda.is_available() else t
+
     def _merge(self, images, texts):
         # Each text chunk is tokenised on its own, so whatever the tokenizer
         # prepends (BOS) re-appears after the image slots (Q6) -- kept.
@@ -153,7 +163,7 @@ class Phi3VProcessor(Phi3FProcessor):
             input_ids.extend(pad)
         input_ids = np.asarray(input_ids, dtype=np.int64)[None]
         return {"input_ids": input_ids,
-                "pixel_values": images["pixel_values"],
+                "pixel_values": self._to_device(images["pixel_values"]),
                 "image_sizes": np.asarray(images["image_sizes"], dtype=np.int64),
                 "positions": np.argwhere(input_ids < 0)}
 

@@ -158,7 +158,7 @@ def test_vision_tower_and_projector_stages(vis):
     h, w = (np.asarray(inputs["image_sizes"])[0] // 336).tolist()
     live = h * w + 1
     feats = model.clip_forward(pv[0, :live].contiguous().cuda())[:, 1:].cpu()
-    ref_feats = oracle.clip_model(pv[0, :live])
+    ref_feats = oracle.clip_model(pv[0, :live].cpu())
     err = (feats - ref_feats).abs().max().item()
     assert err <= 0.05 * ref_feats.abs().max().item() + 0.05, (err, ref_feats.abs().max().item())
     x = torch.zeros((inputs["input_ids"].shape[1], model.cfg.hidden_size), dtype=BF16)
