@@ -113,11 +113,17 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus or world == 1, f"WORLD_SIZE={world} but --gpus {args.gpus}"
+    share = bool(os.environ.get("P3V_BENCH_SHARE_GPU"))           # debug only: all ranks on GPU 0 over gloo (1-GPU boxes)
+    if share:
+        local = 0
     torch.cuda.set_device(local)
     dev = f"cuda:{local}"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(dev))
+        if share:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(dev))
 
     from phi_3_vision_mlx_amd import ops
     from phi_3_vision_mlx_amd.api import load_synthetic
