@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libp3v.so")
+LIB_PATH = os.environ.get("P3V_LIB") or os.path.join(_HERE, "libp3v.so")     # P3V_LIB: debug builds only
 
 P3V_OK = 0
 (EPI_NONE, EPI_BIAS, EPI_BIAS_QGELU, EPI_BIAS_GELU, EPI_BIAS_RESID_F32, EPI_RESID_BF16, EPI_SILU_MUL, EPI_PATCH,

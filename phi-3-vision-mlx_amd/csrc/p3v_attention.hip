@@ -474,7 +474,35 @@ struct AttnDecP {
   const int32_t* pad_len; const int32_t* d_past; float* ws;
   int B, L, nh, nkv, past, cache_t, rope_bstride, n_split;   // cos/sin row of (b, new position r) = b*rope_bstride + r
   float scale;
+  int chunk, grp, grp_magic;   // host-side: keys per split (multiple of 64), heads per kv head and ceil(2^16 / grp)
 };
+
+// operands of one rotated 8-wide chunk, split into a load half and a math half so that the loads can be issued
+// ahead of other memory traffic and consumed later
+struct RopeRaw { u32x4_t x0, x1; float4 c0, c1, s0, s1; };
+__device__ __forceinline__ RopeRaw rope_fetch(const bf16_t* head_row, int c, const float* ct, const float* st) {
+  constexpr int HALF = 48;
+  const int d0 = c * 8, lo = d0 < HALF, tb = lo ? d0 : d0 - HALF;
+  RopeRaw r;
+  r.x0 = *(const u32x4_t*)(head_row + d0);
+  r.x1 = *(const u32x4_t*)(head_row + (lo ? d0 + HALF : d0 - HALF));
+  r.c0 = *(const float4*)(ct + tb); r.c1 = *(const float4*)(ct + tb + 4);
+  r.s0 = *(const float4*)(st + tb); r.s1 = *(const float4*)(st + tb + 4);
+  return r;
+}
+__device__ __forceinline__ u32x4_t rope_apply(const RopeRaw& r, int c, unsigned sh16 = 16, unsigned himask = 0xffff0000u) {
+  auto bf16lo = [&](unsigned x) { return __builtin_bit_cast(float, x << sh16); };
+  auto bf16hi = [&](unsigned x) { return __builtin_bit_cast(float, x & himask); };
+  const float cs[8] = {r.c0.x, r.c0.y, r.c0.z, r.c0.w, r.c1.x, r.c1.y, r.c1.z, r.c1.w};
+  const float sn[8] = {r.s0.x, r.s0.y, r.s0.z, r.s0.w, r.s1.x, r.s1.y, r.s1.z, r.s1.w};
+  const float sg = c < 6 ? -1.f : 1.f;
+  u32x4_t o;
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    o[j] = pack_bf16x2(bf16lo(r.x0[j]) * cs[2 * j] + sg * bf16lo(r.x1[j]) * sn[2 * j],
+                       bf16hi(r.x0[j]) * cs[2 * j + 1] + sg * bf16hi(r.x1[j]) * sn[2 * j + 1]);
+  return o;
+}
 
 __device__ __forceinline__ u32x4_t rope_chunk(const bf16_t* head_row, int c, const float* ct, const float* st) {
   // rotated 8-wide chunk c (0..11) of a 96-wide head: low half pairs with +48, high half with -48
@@ -496,111 +524,212 @@ __device__ __forceinline__ u32x4_t rope_chunk(const bf16_t* head_row, int c, con
   return o;
 }
 
-template <int TK>   // keys per tile (32 or 64): one tile per wave-iteration
+// cross-row all-reduce over the four 16-lane rows of a wave (lanes sharing lane & 15), on gfx950's
+// v_permlane{16,32}_swap: swap(x, x) leaves {row r, row r^1} pairs in the two results, so one max / add finishes a
+// butterfly step without the LDS crossbar latency of ds_bpermute.
+// (The two integer results pass through an empty asm before they are reinterpreted as floats: hipcc 7.2 otherwise
+// folds bitcast(result 1) into bitcast(result 0).)
+__device__ __forceinline__ void rows_swap32(float v, float& a, float& b) {
+  const unsigned u = __builtin_bit_cast(unsigned, v);
+  auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  unsigned x = r[0], y = r[1];
+  asm("" : "+v"(x), "+v"(y));
+  a = __builtin_bit_cast(float, x); b = __builtin_bit_cast(float, y);
+}
+__device__ __forceinline__ void rows_swap16(float v, float& a, float& b) {
+  const unsigned u = __builtin_bit_cast(unsigned, v);
+  auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  unsigned x = r[0], y = r[1];
+  asm("" : "+v"(x), "+v"(y));
+  a = __builtin_bit_cast(float, x); b = __builtin_bit_cast(float, y);
+}
+__device__ __forceinline__ float rows_max(float v) {
+  float a, b;
+  rows_swap32(v, a, b); v = fmaxf(a, b);
+  rows_swap16(v, a, b); return fmaxf(a, b);
+}
+__device__ __forceinline__ float rows_sum(float v) {
+  float a, b;
+  rows_swap32(v, a, b); v = a + b;
+  rows_swap16(v, a, b); return a + b;
+}
+
+typedef const __attribute__((address_space(1))) void* dec_gptr_t;
+typedef __attribute__((address_space(3))) void* dec_lptr_t;
+
+// One wave per workgroup, 64 keys per tile.  The K tile (64 rows x 192 B, contiguous in the cache) and the V^T tile
+// (96 rows x 128 B) go HBM -> LDS by LDS-DMA (global_load_lds_dwordx4): no staging registers, no ds_write pass, and
+// a prologue of ~30 instructions -- a decode workgroup runs its code exactly once, so every instruction is an
+// instruction-cache miss and the old register-staged version spent 5.5k cycles just issuing its loads.  The DMA
+// destination is lane-linear, so the bank-conflict swizzle is applied to the SOURCE chunk index and again on the
+// ds_read side:
+//   K  : 16-B chunk c (0..11) of row r lives at chunk c ^ ((r >> 2) & 3)      (192-B rows: rows r, r+4 share banks)
+//   V^T: 16-B chunk c (0..7)  of row d lives at chunk c ^ ((d >> 1) & 7)      (128-B rows: rows d, d+2 share banks)
+// SINGLE: the launcher guarantees one tile per workgroup (n_split * 64 >= cache_t): one LDS buffer, no loop.
+#ifdef P3V_ATTN_DEBUG
+__device__ unsigned long long p3v_dbg[16];
+#define DBG_T(i) do { if (blockIdx.x == 7 && blockIdx.y == 3 && threadIdx.x == 0) p3v_dbg[i] = __builtin_readcyclecounter(); } while (0)
+#else
+#define DBG_T(i)
+#endif
+template <bool SINGLE>
 __global__ void __launch_bounds__(64) k_attn_decode(AttnDecP p) {
-  constexpr int HD = 96, KSTR = HD * 2 + 16, VSTR = TK * 2 + 16, NKS = 3, NDT = 6, CPR = 12;
-  constexpr int KIT = TK * CPR / 64, VCH = TK / 8, VIT = HD * VCH / 64;   // 16-byte loads per lane: K, V^T
-  __shared__ __attribute__((aligned(16))) unsigned char Ks[TK * KSTR];
-  __shared__ __attribute__((aligned(16))) unsigned char Vt[HD * VSTR];
+  DBG_T(0);
+  constexpr int TK = 64, HD = 96, KROW = HD * 2, VROW = TK * 2, NKS = 3, NDT = 6, CPR = 12;
+  constexpr int KT_BYTES = TK * KROW, VT_BYTES = HD * VROW, NBUF = SINGLE ? 1 : 2;
+  __shared__ __attribute__((aligned(1024))) unsigned char Ks[NBUF * KT_BYTES];
+  __shared__ __attribute__((aligned(1024))) unsigned char Vt[NBUF * VT_BYTES];
   const int lane = threadIdx.x, g = lane >> 4, qi = lane & 15;
-  const int b = blockIdx.z, head = blockIdx.y, kvh = head / (p.nh / p.nkv);
-  const bool kv_writer = head % (p.nh / p.nkv) == 0;
-  const float sc2 = p.scale * 1.4426950408889634f;            // scale * log2(e): softmax runs on exp2
-  const int row_w = (p.nh + 2 * p.nkv) * HD;                  // qkv row width
-  const bf16_t* kc = p.k_cache + ((size_t)b * p.nkv + kvh) * (size_t)p.cache_t * HD;
-  bf16_t* vc = p.v_cache + ((size_t)b * p.nkv + kvh) * (size_t)HD * p.cache_t;          // V^T: [hd][cache_t]
-  // The key range of a split is STATIC (a function of the cache capacity, not of the current length):
-  // its first tile can be requested before the cache length `past` has even arrived from HBM.
-  const int chunk = ((p.cache_t + p.n_split - 1) / p.n_split + TK - 1) & ~(TK - 1);
-  const int kv_lo = blockIdx.x * chunk, kv_hi = min(p.cache_t, kv_lo + chunk);
+  const int b = blockIdx.z, head = blockIdx.y, kvh = (head * p.grp_magic) >> 16;      // head / grp without a divide
+  const bool kv_writer = head == kvh * p.grp;
 
-  // ---- tile registers: K TK rows x 12 chunks, V^T 96 rows x TK/8 chunks, all requested before anything is
-  //      used.  Rows beyond the live length are read too (allocated, finite V^T / masked K) and ignored.
-  u32x4_t kreg[KIT], vreg[VIT];
-  auto load_tile = [&](int kv0) {
-#pragma unroll
-    for (int it = 0; it < KIT; ++it) {
-      const int i = it * 64 + lane;
-      kreg[it] = __builtin_nontemporal_load((const u32x4_t*)(kc + (size_t)(kv0 + i / CPR) * HD + (i % CPR) * 8));
-    }
-#pragma unroll
-    for (int it = 0; it < VIT; ++it) {
-      const int i = it * 64 + lane;
-      vreg[it] = __builtin_nontemporal_load((const u32x4_t*)(vc + (size_t)(i / VCH) * p.cache_t + kv0 + (i % VCH) * 8));
-    }
-  };
-  if (kv_lo < kv_hi) load_tile(kv_lo);                         // cache_t % TK == 0: the tile is always in bounds
+  // ---- the cache length and this row's left padding: scalar loads issued first, consumed after everything
+  //      that does not depend on them has been put in flight
+  int past = p.past, pad = 0;
+  if (p.d_past) asm volatile("s_load_dword %0, %1, 0x0" : "=s"(past) : "s"(p.d_past) : "memory");
+  if (p.pad_len) asm volatile("s_load_dword %0, %1, 0x0" : "=s"(pad) : "s"(p.pad_len + b) : "memory");
 
-  const int past = p.d_past ? *p.d_past : p.past;
-  const int total = past + p.L;
-  const int pad = p.pad_len ? p.pad_len[b] : 0;
-  int kv_begin = kv_lo;
-  const int kv_end = min(total, kv_hi);
-  if (pad > kv_begin) kv_begin = pad & ~(TK - 1);
+  // ---- Q: raw row + rotation table rows requested first (the rotation math then overlaps the tile DMA)
+  const int row_w = (p.nh + 2 * p.nkv) * HD;                   // qkv row width
   const float* cos_b = p.cos_t + (size_t)b * p.rope_bstride * (HD / 2);
   const float* sin_b = p.sin_t + (size_t)b * p.rope_bstride * (HD / 2);
-
-  // positions [past, total) that fall in this tile: K rotated from the qkv row, V copied -- written straight into
-  // the LDS tile (after the bulk register->LDS store) and appended to the cache by the writer block.  Rolled
-  // loops on purpose: this is the rare path (one tile per head) and must not cost registers.
-  auto patch_new = [&](int kv0) {
-    const int n0 = max(past, kv0), n1 = min(kv_end, kv0 + TK), n_new = n1 - n0;
-#pragma unroll 1
-    for (int w = lane; w < n_new * CPR; w += 64) {
-      const int t = n0 + w / CPR, c = w % CPR, r = t - past;
-      const bf16_t* row = p.qkv + ((size_t)b * p.L + r) * row_w;
-      const u32x4_t kn = rope_chunk(row + (p.nh + kvh) * HD, c, cos_b + r * (HD / 2), sin_b + r * (HD / 2));
-      *(u32x4_t*)(Ks + (t - kv0) * KSTR + c * 16) = kn;
-      if (kv_writer) *(u32x4_t*)(p.k_cache + (((size_t)b * p.nkv + kvh) * p.cache_t + t) * HD + c * 8) = kn;   // phi.py:545
-    }
-#pragma unroll 1
-    for (int w = lane; w < n_new * HD; w += 64) {
-      const int t = n0 + w / HD, d = w % HD, r = t - past;
-      const bf16_t val = p.qkv[((size_t)b * p.L + r) * row_w + (p.nh + p.nkv + kvh) * HD + d];
-      *(bf16_t*)(Vt + d * VSTR + (t - kv0) * 2) = val;
-      if (kv_writer) vc[(size_t)d * p.cache_t + t] = val;                                                   // phi.py:546
-    }
-  };
-  if (kv_begin > kv_lo && kv_begin < kv_end) load_tile(kv_begin);   // left padding skipped whole tiles: reload
-
-
   const bool qvalid = qi < p.L;
-  const int qpos = past + qi;
-  bf16x8_t qf[NKS];
+  RopeRaw qraw[NKS];
   {
     const bf16_t* qrow = p.qkv + ((size_t)b * p.L + (qvalid ? qi : 0)) * row_w + head * HD;
     const float* ct = cos_b + (qvalid ? qi : 0) * (HD / 2);
     const float* st = sin_b + (qvalid ? qi : 0) * (HD / 2);
 #pragma unroll
-    for (int ks = 0; ks < NKS; ++ks) {
-      u32x4_t v = rope_chunk(qrow, 4 * ks + g, ct, st);
-      if (!qvalid) v = (u32x4_t){0, 0, 0, 0};
-      qf[ks] = __builtin_bit_cast(bf16x8_t, v);
-    }
+    for (int ks = 0; ks < NKS; ++ks) qraw[ks] = rope_fetch(qrow, 4 * ks + g, ct, st);
   }
+  __builtin_amdgcn_sched_barrier(0);
+
+  // ---- tile DMA.  The key range of a split is STATIC (a function of the cache capacity, not of the current
+  //      length), so its first tile is requested before the cache length has arrived.  K: LDS slot i = it*64 +
+  //      lane holds (row i/12, physical chunk i%12); 192 slots = 16 rows, so the source pattern has period 3 in
+  //      `it`.  V^T: slot i -> (row it*8 + lane/8, chunk lane%8).  Rows beyond the live length are fetched too
+  //      (allocated, finite) and masked.
+  const unsigned char* kc = (const unsigned char*)(p.k_cache + ((size_t)b * p.nkv + kvh) * (size_t)p.cache_t * HD);
+  bf16_t* vc = p.v_cache + ((size_t)b * p.nkv + kvh) * (size_t)HD * p.cache_t;          // V^T: [hd][cache_t]
+  const int chunk = SINGLE ? TK : p.chunk;
+  const int kv_lo = blockIdx.x * chunk, kv_hi = min(p.cache_t, kv_lo + chunk);
+  unsigned koff[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const int i = j * 64 + lane, r0 = i / CPR, pc = i % CPR;
+    koff[j] = r0 * KROW + ((pc ^ ((r0 >> 2) & 3)) << 4);
+  }
+  const size_t vrow = (size_t)p.cache_t * 2;                   // bytes per V^T row
+  const unsigned vc0 = (((lane & 7) ^ (lane >> 4)) << 4), vc1 = vc0 ^ 64;   // source chunk for even / odd `it`
+  const unsigned char* vsrc = (const unsigned char*)vc + (size_t)(lane >> 3) * vrow;
+  auto load_tile = [&](int kv0, int buf) {
+    const unsigned char* ksrc = kc + (size_t)kv0 * KROW;
+#pragma unroll
+    for (int it = 0; it < 12; ++it)
+      __builtin_amdgcn_global_load_lds((dec_gptr_t)(ksrc + koff[it % 3] + (it / 3) * 16 * KROW),
+                                       (dec_lptr_t)(Ks + buf * KT_BYTES + it * 1024), 16, 0, 0);
+    const unsigned char* vs = vsrc + (size_t)kv0 * 2;
+#pragma unroll
+    for (int it = 0; it < 12; ++it)
+      __builtin_amdgcn_global_load_lds((dec_gptr_t)(vs + (size_t)it * 8 * vrow + ((it & 1) ? vc1 : vc0)),
+                                       (dec_lptr_t)(Vt + buf * VT_BYTES + it * 1024), 16, 0, 0);
+  };
+  load_tile(min(kv_lo, p.cache_t - TK), 0);                    // unconditional (an empty split fetches a tile it never uses)
+  // The rotation math must not be scheduled above the DMA issue (it would stall on the Q loads first): its bf16
+  // unpack constants come out of an opaque asm that sits after the DMA in program order.
+  unsigned sh16, himask;
+  asm volatile("s_mov_b32 %0, 16\n\ts_mov_b32 %1, 0xffff0000" : "=s"(sh16), "=s"(himask));
+  DBG_T(9);
+
+  bf16x8_t qf[NKS];
+#pragma unroll
+  for (int ks = 0; ks < NKS; ++ks) {
+    u32x4_t v = rope_apply(qraw[ks], 4 * ks + g, sh16, himask);
+    if (!qvalid) v = (u32x4_t){0, 0, 0, 0};
+    asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]));   // ... and not below the wait for the tile
+    qf[ks] = __builtin_bit_cast(bf16x8_t, v);
+  }
+  DBG_T(2);
+
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(past), "+s"(pad)::"memory");
+  DBG_T(1);
+  const int total = past + p.L;
+  const int kv_end = min(total, kv_hi);
+  const int qpos = past + qi;
+  const float sc2 = p.scale * 1.4426950408889634f;            // scale * log2(e): softmax runs on exp2
+
+  // ---- positions [past, total) that fall in a tile: K rotated from the qkv row, V copied -- written into the LDS
+  //      tile once its DMA has landed, and appended to the cache by the writer block.  The single-token step
+  //      (L == 1) with the new position in the first tile fetches its operands NOW, under the DMA; everything
+  //      else takes rolled loops (rare, must not cost registers or code).
+  const bool fast_new = p.L == 1 && past >= kv_lo && past < kv_hi && past < kv_lo + TK;
+  RopeRaw nraw;
+  bf16_t nv0 = 0, nv1 = 0;
+  if (fast_new) {
+    const bf16_t* row = p.qkv + (size_t)b * row_w;
+    if (lane < CPR) nraw = rope_fetch(row + (p.nh + kvh) * HD, lane, cos_b, sin_b);
+    const bf16_t* vrowp = row + (p.nh + p.nkv + kvh) * HD;
+    nv0 = vrowp[lane];
+    if (lane < HD - 64) nv1 = vrowp[lane + 64];
+  }
+  auto patch_new = [&](int kv0, unsigned char* Kb, unsigned char* Vb) {
+    const int n0 = max(past, kv0), n1 = min(kv_end, kv0 + TK), n_new = n1 - n0;
+#pragma unroll 1
+    for (int w = lane; w < n_new * CPR; w += 64) {
+      const int t = n0 + w / CPR, c = w % CPR, r = t - past, rr = t - kv0;
+      const bf16_t* row = p.qkv + ((size_t)b * p.L + r) * row_w;
+      const u32x4_t kn = rope_chunk(row + (p.nh + kvh) * HD, c, cos_b + r * (HD / 2), sin_b + r * (HD / 2));
+      *(u32x4_t*)(Kb + rr * KROW + ((c ^ ((rr >> 2) & 3)) << 4)) = kn;
+      if (kv_writer) *(u32x4_t*)(p.k_cache + (((size_t)b * p.nkv + kvh) * p.cache_t + t) * HD + c * 8) = kn;   // phi.py:545
+    }
+#pragma unroll 1
+    for (int w = lane; w < n_new * HD; w += 64) {
+      const int t = n0 + w / HD, d = w % HD, r = t - past, rr = t - kv0;
+      const bf16_t val = p.qkv[((size_t)b * p.L + r) * row_w + (p.nh + p.nkv + kvh) * HD + d];
+      *(bf16_t*)(Vb + d * VROW + ((((rr >> 3) ^ (d >> 1)) & 7) << 4) + (rr & 7) * 2) = val;
+      if (kv_writer) vc[(size_t)d * p.cache_t + t] = val;                                                   // phi.py:546
+    }
+  };
+
+  // ---- fragment read offsets (swizzled as above)
+  const unsigned k_rd = qi * KROW + ((g ^ ((qi >> 2) & 3)) << 4);             // + st*16*KROW + ks*64
+  const unsigned vx = (g >> 1) ^ ((qi >> 1) & 7);
+  unsigned v_rd[4];                                                            // chunk (4 st + 2 h + g/2) ^ ((qi>>1)&7)
+#pragma unroll
+  for (int k = 0; k < 4; ++k) v_rd[k] = qi * VROW + ((vx ^ (2 * k)) << 4) + (g & 1) * 8;   // + d*16*VROW
 
   float m_run = -INFINITY, l_run = 0.f;
   f32x4_t o[NDT];
 #pragma unroll
   for (int d = 0; d < NDT; ++d) o[d] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
-  for (int kv0 = kv_begin; kv0 < kv_end; kv0 += TK) {
-#pragma unroll
-    for (int it = 0; it < KIT; ++it) {
-      const int i = it * 64 + lane;
-      *(u32x4_t*)(Ks + (i / CPR) * KSTR + (i % CPR) * 16) = kreg[it];
-    }
-#pragma unroll
-    for (int it = 0; it < VIT; ++it) {
-      const int i = it * 64 + lane;
-      *(u32x4_t*)(Vt + (i / VCH) * VSTR + (i % VCH) * 16) = vreg[it];
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // this wave's LDS writes have landed (single-wave block)
+  int buf = 0;
+  for (int kv0 = kv_lo; kv0 < kv_end; kv0 += TK) {
+    unsigned char* Kb = Ks + buf * KT_BYTES;
+    unsigned char* Vb = Vt + buf * VT_BYTES;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this tile's DMA has landed (single-wave block: no barrier)
+    DBG_T(3);
+    if (!SINGLE && kv0 + TK < kv_end) load_tile(kv0 + TK, buf ^ 1);   // next tile streams in under the MFMAs below
     if (kv0 + TK > past) {                                     // wave-uniform: only the tile(s) holding new positions
-      patch_new(kv0);
+      if (fast_new) {
+        const int rr = past - kv0;
+        if (lane < CPR) {
+          const u32x4_t kn = rope_apply(nraw, lane);
+          *(u32x4_t*)(Kb + rr * KROW + ((lane ^ ((rr >> 2) & 3)) << 4)) = kn;
+          if (kv_writer) *(u32x4_t*)(p.k_cache + (((size_t)b * p.nkv + kvh) * p.cache_t + past) * HD + lane * 8) = kn;   // phi.py:545
+        }
+        *(bf16_t*)(Vb + lane * VROW + ((((rr >> 3) ^ (lane >> 1)) & 7) << 4) + (rr & 7) * 2) = nv0;
+        if (kv_writer) vc[(size_t)lane * p.cache_t + past] = nv0;                                           // phi.py:546
+        if (lane < HD - 64) {
+          const int d = lane + 64;
+          *(bf16_t*)(Vb + d * VROW + ((((rr >> 3) ^ (d >> 1)) & 7) << 4) + (rr & 7) * 2) = nv1;
+          if (kv_writer) vc[(size_t)d * p.cache_t + past] = nv1;
+        }
+      } else {
+        patch_new(kv0, Kb, Vb);
+      }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
-    if (kv0 + TK < kv_end) load_tile(kv0 + TK);                // next tile streams in under the MFMAs below
 
     f32x4_t s[TK / 16];
 #pragma unroll
@@ -608,10 +737,11 @@ __global__ void __launch_bounds__(64) k_attn_decode(AttnDecP p) {
       s[st] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int ks = 0; ks < NKS; ++ks) {
-        const bf16x8_t kf = *(const bf16x8_t*)(Ks + (16 * st + qi) * KSTR + (32 * ks + 8 * g) * 2);
+        const bf16x8_t kf = *(const bf16x8_t*)(Kb + k_rd + st * 16 * KROW + ks * 64);
         s[st] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], s[st], 0, 0, 0);
       }
     }
+    DBG_T(4);
     float m_t = -INFINITY;
 #pragma unroll
     for (int st = 0; st < TK / 16; ++st)
@@ -623,11 +753,9 @@ __global__ void __launch_bounds__(64) k_attn_decode(AttnDecP p) {
         s[st][r] = v;
         m_t = fmaxf(m_t, v);
       }
-    m_t = fmaxf(m_t, __shfl_xor(m_t, 16, 64));
-    m_t = fmaxf(m_t, __shfl_xor(m_t, 32, 64));
+    m_t = rows_max(m_t);
     const float m_new = fmaxf(m_run, m_t);
     const float m_use = m_new == -INFINITY ? 0.f : m_new;
-    const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);
     float l_t = 0.f;
 #pragma unroll
     for (int st = 0; st < TK / 16; ++st)
@@ -637,12 +765,16 @@ __global__ void __launch_bounds__(64) k_attn_decode(AttnDecP p) {
         s[st][r] = e;
         l_t += e;
       }
-    l_t += __shfl_xor(l_t, 16, 64);
-    l_t += __shfl_xor(l_t, 32, 64);
-    l_run = l_run * alpha + l_t;
-    m_run = m_new;
+    l_t = rows_sum(l_t);
+    if (!SINGLE) {
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);
+      l_run *= alpha;
 #pragma unroll
-    for (int d = 0; d < NDT; ++d) o[d] *= alpha;
+      for (int d = 0; d < NDT; ++d) o[d] *= alpha;
+    }
+    l_run += l_t;
+    m_run = m_new;
+    DBG_T(5);
 #pragma unroll
     for (int st = 0; st < TK / 32; ++st) {
       u32x4_t pw;
@@ -653,19 +785,24 @@ __global__ void __launch_bounds__(64) k_attn_decode(AttnDecP p) {
       const bf16x8_t pf = __builtin_bit_cast(bf16x8_t, pw);
 #pragma unroll
       for (int d = 0; d < NDT; ++d) {
-        const unsigned char* vr = Vt + (16 * d + qi) * VSTR + (32 * st + 4 * g) * 2;
-        const u32x2_t a0 = *(const u32x2_t*)vr, a1 = *(const u32x2_t*)(vr + 32);
+        const u32x2_t a0 = *(const u32x2_t*)(Vb + v_rd[2 * st] + d * 16 * VROW);
+        const u32x2_t a1 = *(const u32x2_t*)(Vb + v_rd[2 * st + 1] + d * 16 * VROW);
         const u32x4_t aw = {a0[0], a0[1], a1[0], a1[1]};
         o[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, aw), pf, o[d], 0, 0, 0);
       }
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // LDS reads of this tile precede the next tile's writes
+    DBG_T(6);
+    if (SINGLE) break;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // LDS reads of this tile precede the DMA that reuses it
+    buf ^= 1;
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // no DMA may still target this workgroup's LDS at exit
   if (!qvalid) return;
   float* w = p.ws + ((((size_t)b * p.nh + head) * p.n_split + blockIdx.x) * 16 + qi) * (HD + 2);
 #pragma unroll
   for (int d = 0; d < NDT; ++d) *(f32x4_t*)(w + 16 * d + 4 * g) = o[d];
   if (g == 0) { w[HD] = m_run; w[HD + 1] = l_run; }
+  DBG_T(7);
 }
 
 // merge split-KV partials: one 256-thread block per (b, head, query), ONE memory round trip: thread
@@ -733,17 +870,26 @@ extern "C" int p3v_stage_rope(const float* cos_t, const float* sin_t, int past, 
   return P3V_OK;
 }
 
+#ifdef P3V_ATTN_DEBUG
+extern "C" int p3v_debug_read(unsigned long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(p3v_dbg), sizeof(unsigned long long) * 16) == hipSuccess ? 0 : -1;
+}
+#endif
+
 extern "C" int p3v_attention_decode(const p3v_attn_decode_args_t* a, void* stream) {
   if (!a || !a->qkv || !a->cos_t || !a->sin_t || !a->k_cache || !a->v_cache || !a->out || !a->ws) return P3V_ERR_ARG;
   if (a->hd != 96) return P3V_ERR_UNSUPPORTED;
   if (a->B <= 0 || a->L <= 0 || a->L > P3V_DECODE_MAX_L || a->n_heads % a->n_kv) return P3V_ERR_ARG;
   if (a->n_split < 1 || a->n_split > 128 || a->cache_t % 64) return P3V_ERR_ARG;
+  const int grp = a->n_heads / a->n_kv;
+  const int chunk = ((a->cache_t + a->n_split - 1) / a->n_split + 63) & ~63;
   AttnDecP p = {a->qkv, a->cos_t, a->sin_t, a->k_cache, a->v_cache, a->pad_len, a->d_past, a->ws,
-                a->B, a->L, a->n_heads, a->n_kv, a->past, a->cache_t, a->rope_bstride, a->n_split, a->scale};
+                a->B, a->L, a->n_heads, a->n_kv, a->past, a->cache_t, a->rope_bstride, a->n_split, a->scale,
+                chunk, grp, (65536 + grp - 1) / grp};
   hipStream_t s = (hipStream_t)stream;
-  static const int tk = getenv("P3V_ATTN_TK") ? atoi(getenv("P3V_ATTN_TK")) : 64;
-  if (tk == 64) hipLaunchKernelGGL(k_attn_decode<64>, dim3(a->n_split, a->n_heads, a->B), dim3(64), 0, s, p);
-  else hipLaunchKernelGGL(k_attn_decode<32>, dim3(a->n_split, a->n_heads, a->B), dim3(64), 0, s, p);
+  const dim3 grid(a->n_split, a->n_heads, a->B);
+  if (a->n_split * 64 >= a->cache_t) hipLaunchKernelGGL((k_attn_decode<true>), grid, dim3(64), 0, s, p);
+  else hipLaunchKernelGGL((k_attn_decode<false>), grid, dim3(64), 0, s, p);
   P3V_CHECK_LAUNCH();
   hipLaunchKernelGGL(k_attn_combine2, dim3(a->B * a->n_heads * a->L), dim3(256), 0, s, a->ws, a->out, a->L, a->n_heads,
                      a->hd, a->n_split);

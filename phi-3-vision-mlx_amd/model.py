@@ -247,8 +247,13 @@ class Phi3VModel:
         """Split-KV plan for the decode-shaped attention (L <= 16): enough blocks to fill 256 CUs."""
         nh, hd = self.cfg.num_attention_heads, self.hd
         if L <= ops.L.DECODE_MAX_L:
-            # single-wave workgroups of 64-key tiles; ~768 workgroups = one resident round on 256 CUs
-            n_split = max(1, min(128, -(-T // 64), -(-768 // max(1, B * nh))))
+            # single-wave workgroups of 64-key tiles.  Up to ~4096 workgroups: ONE tile each (the kernel then lasts a
+            # single tile's dependency chain); beyond that ~768 workgroups (one resident round) walking several tiles
+            tiles = -(-T // 64)
+            if tiles <= 128 and B * nh * tiles <= 4096:
+                n_split = tiles
+            else:
+                n_split = max(1, min(128, tiles, -(-768 // max(1, B * nh))))
             if os.environ.get("P3V_ATTN_NSPLIT"):
                 n_split = int(os.environ["P3V_ATTN_NSPLIT"])
             bufs["n_split"] = n_split
