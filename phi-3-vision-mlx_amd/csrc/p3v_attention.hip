@@ -557,31 +557,40 @@ __device__ __forceinline__ float rows_sum(float v) {
 typedef const __attribute__((address_space(1))) void* dec_gptr_t;
 typedef __attribute__((address_space(3))) void* dec_lptr_t;
 
-// One wave per workgroup, 64 keys per tile.  The K tile (64 rows x 192 B, contiguous in the cache) and the V^T tile
-// (96 rows x 128 B) go HBM -> LDS by LDS-DMA (global_load_lds_dwordx4): no staging registers, no ds_write pass, and
-// a prologue of ~30 instructions -- a decode workgroup runs its code exactly once, so every instruction is an
-// instruction-cache miss and the old register-staged version spent 5.5k cycles just issuing its loads.  The DMA
-// destination is lane-linear, so the bank-conflict swizzle is applied to the SOURCE chunk index and again on the
-// ds_read side:
+// Workgroup = 4 waves x one 64-key tile; wave w owns keys [16w, 16w+16) of the tile end to end: it DMAs its own K
+// slice (16 rows x 192 B, contiguous in the cache) and V^T slice (96 rows x 32 B) HBM -> LDS with
+// global_load_lds_dwordx4 (no staging registers, no ds_write pass), runs S^T = K.Q^T (3 MFMA 16x16x32), a
+// 4-value-per-lane softmax and O^T += V^T.P^T (6 MFMA 16x16x16, P straight from the S^T accumulator layout), and
+// the four wave partials are merged through LDS before one (m, l, O) partial per workgroup goes to `ws`.
+// Why 4 short waves instead of 1 long one: a lone wave issues one dependent instruction per ~8 cycles, so the
+// duration of a decode-attention launch is the instruction count of its longest wave, not its bytes.
+// The DMA destination is lane-linear, so the bank-conflict swizzle is applied to the SOURCE chunk index and again
+// on the ds_read side:
 //   K  : 16-B chunk c (0..11) of row r lives at chunk c ^ ((r >> 2) & 3)      (192-B rows: rows r, r+4 share banks)
-//   V^T: 16-B chunk c (0..7)  of row d lives at chunk c ^ ((d >> 1) & 7)      (128-B rows: rows d, d+2 share banks)
-// SINGLE: the launcher guarantees one tile per workgroup (n_split * 64 >= cache_t): one LDS buffer, no loop.
+//   V^T: 16-B chunk c (0..1)  of row d lives at chunk c ^ ((d >> 3) & 1)      (32-B rows: rows d, d+8 share banks)
+//   Q   (rotated by the first 12 L threads, [16 queries][96]): same swizzle as K.
+// SINGLE: the launcher guarantees one tile per workgroup (n_split * 64 >= cache_t): one LDS buffer per wave.
 #ifdef P3V_ATTN_DEBUG
 __device__ unsigned long long p3v_dbg[16];
 #define DBG_T(i) do { if (blockIdx.x == 7 && blockIdx.y == 3 && threadIdx.x == 0) p3v_dbg[i] = __builtin_readcyclecounter(); } while (0)
 #else
 #define DBG_T(i)
 #endif
+typedef short s16x4_t __attribute__((ext_vector_type(4)));
 template <bool SINGLE>
-__global__ void __launch_bounds__(64) k_attn_decode(AttnDecP p) {
+__global__ void __launch_bounds__(256) k_attn_decode(AttnDecP p) {
   DBG_T(0);
-  constexpr int TK = 64, HD = 96, KROW = HD * 2, VROW = TK * 2, NKS = 3, NDT = 6, CPR = 12;
-  constexpr int KT_BYTES = TK * KROW, VT_BYTES = HD * VROW, NBUF = SINGLE ? 1 : 2;
-  __shared__ __attribute__((aligned(1024))) unsigned char Ks[NBUF * KT_BYTES];
-  __shared__ __attribute__((aligned(1024))) unsigned char Vt[NBUF * VT_BYTES];
-  const int lane = threadIdx.x, g = lane >> 4, qi = lane & 15;
+  constexpr int TK = 64, WK = 16, HD = 96, KROW = HD * 2, VROW = WK * 2, NKS = 3, NDT = 6, CPR = 12;
+  constexpr int KS_BYTES = WK * KROW, VS_BYTES = HD * VROW, WREG = KS_BYTES + VS_BYTES, NBUF = SINGLE ? 1 : 2;
+  static_assert(WREG >= 16 * HD * 4, "a wave's O partial reuses its tile region");
+  __shared__ __attribute__((aligned(1024))) unsigned char KV[4 * NBUF * WREG];   // [wave][buf]{K slice | V^T slice}
+  __shared__ __attribute__((aligned(16))) unsigned char Qs[16 * KROW];
+  __shared__ float Ml[4][16][2];
+  const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, qi = lane & 15;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int b = blockIdx.z, head = blockIdx.y, kvh = (head * p.grp_magic) >> 16;      // head / grp without a divide
   const bool kv_writer = head == kvh * p.grp;
+  unsigned char* wreg = KV + wave * (NBUF * WREG);
 
   // ---- the cache length and this row's left padding: scalar loads issued first, consumed after everything
   //      that does not depend on them has been put in flight
@@ -589,26 +598,10 @@ __global__ void __launch_bounds__(64) k_attn_decode(AttnDecP p) {
   if (p.d_past) asm volatile("s_load_dword %0, %1, 0x0" : "=s"(past) : "s"(p.d_past) : "memory");
   if (p.pad_len) asm volatile("s_load_dword %0, %1, 0x0" : "=s"(pad) : "s"(p.pad_len + b) : "memory");
 
-  // ---- Q: raw row + rotation table rows requested first (the rotation math then overlaps the tile DMA)
-  const int row_w = (p.nh + 2 * p.nkv) * HD;                   // qkv row width
-  const float* cos_b = p.cos_t + (size_t)b * p.rope_bstride * (HD / 2);
-  const float* sin_b = p.sin_t + (size_t)b * p.rope_bstride * (HD / 2);
-  const bool qvalid = qi < p.L;
-  RopeRaw qraw[NKS];
-  {
-    const bf16_t* qrow = p.qkv + ((size_t)b * p.L + (qvalid ? qi : 0)) * row_w + head * HD;
-    const float* ct = cos_b + (qvalid ? qi : 0) * (HD / 2);
-    const float* st = sin_b + (qvalid ? qi : 0) * (HD / 2);
-#pragma unroll
-    for (int ks = 0; ks < NKS; ++ks) qraw[ks] = rope_fetch(qrow, 4 * ks + g, ct, st);
-  }
-  __builtin_amdgcn_sched_barrier(0);
-
   // ---- tile DMA.  The key range of a split is STATIC (a function of the cache capacity, not of the current
-  //      length), so its first tile is requested before the cache length has arrived.  K: LDS slot i = it*64 +
-  //      lane holds (row i/12, physical chunk i%12); 192 slots = 16 rows, so the source pattern has period 3 in
-  //      `it`.  V^T: slot i -> (row it*8 + lane/8, chunk lane%8).  Rows beyond the live length are fetched too
-  //      (allocated, finite) and masked.
+  //      length), so its first tile is requested before the cache length has arrived.  K: LDS slot i = j*64 + lane
+  //      holds (row i/12, physical chunk i%12).  V^T: slot i -> (row i/2, physical chunk i%2).  Rows beyond the
+  //      live length are fetched too (allocated, finite) and masked.
   const unsigned char* kc = (const unsigned char*)(p.k_cache + ((size_t)b * p.nkv + kvh) * (size_t)p.cache_t * HD);
   bf16_t* vc = p.v_cache + ((size_t)b * p.nkv + kvh) * (size_t)HD * p.cache_t;          // V^T: [hd][cache_t]
   const int chunk = SINGLE ? TK : p.chunk;
@@ -616,38 +609,59 @@ __global__ void __launch_bounds__(64) k_attn_decode(AttnDecP p) {
   unsigned koff[3];
 #pragma unroll
   for (int j = 0; j < 3; ++j) {
-    const int i = j * 64 + lane, r0 = i / CPR, pc = i % CPR;
+    const int i = j * 64 + lane, r0 = i / CPR, pc = i - r0 * CPR;
     koff[j] = r0 * KROW + ((pc ^ ((r0 >> 2) & 3)) << 4);
   }
+#ifdef P3V_VT_CONTIG_HACK
+  const size_t vrow = 128;                                     // timing experiment only: tile-contiguous V^T (wrong results)
+#else
   const size_t vrow = (size_t)p.cache_t * 2;                   // bytes per V^T row
-  const unsigned vc0 = (((lane & 7) ^ (lane >> 4)) << 4), vc1 = vc0 ^ 64;   // source chunk for even / odd `it`
-  const unsigned char* vsrc = (const unsigned char*)vc + (size_t)(lane >> 3) * vrow;
+#endif
+  const unsigned char* vsrc = (const unsigned char*)vc + (size_t)(lane >> 1) * vrow + (((lane & 1) ^ ((lane >> 4) & 1)) << 4);
   auto load_tile = [&](int kv0, int buf) {
-    const unsigned char* ksrc = kc + (size_t)kv0 * KROW;
+    const int k0 = kv0 + WK * wave;
+    unsigned char* dst = wreg + buf * WREG;
+    const unsigned char* ksrc = kc + (size_t)k0 * KROW;
 #pragma unroll
-    for (int it = 0; it < 12; ++it)
-      __builtin_amdgcn_global_load_lds((dec_gptr_t)(ksrc + koff[it % 3] + (it / 3) * 16 * KROW),
-                                       (dec_lptr_t)(Ks + buf * KT_BYTES + it * 1024), 16, 0, 0);
-    const unsigned char* vs = vsrc + (size_t)kv0 * 2;
+    for (int j = 0; j < 3; ++j)
+      __builtin_amdgcn_global_load_lds((dec_gptr_t)(ksrc + koff[j]), (dec_lptr_t)(dst + j * 1024), 16, 0, 0);
+#ifdef P3V_VT_CONTIG_HACK
+    const unsigned char* vs = vsrc + (size_t)(kv0 / 64) * 12288 + wave * 32;
+#else
+    const unsigned char* vs = vsrc + (size_t)k0 * 2;
+#endif
 #pragma unroll
-    for (int it = 0; it < 12; ++it)
-      __builtin_amdgcn_global_load_lds((dec_gptr_t)(vs + (size_t)it * 8 * vrow + ((it & 1) ? vc1 : vc0)),
-                                       (dec_lptr_t)(Vt + buf * VT_BYTES + it * 1024), 16, 0, 0);
+    for (int j = 0; j < 3; ++j)
+      __builtin_amdgcn_global_load_lds((dec_gptr_t)(vs + (size_t)j * 32 * vrow), (dec_lptr_t)(dst + KS_BYTES + j * 1024), 16, 0, 0);
   };
   load_tile(min(kv_lo, p.cache_t - TK), 0);                    // unconditional (an empty split fetches a tile it never uses)
-  // The rotation math must not be scheduled above the DMA issue (it would stall on the Q loads first): its bf16
-  // unpack constants come out of an opaque asm that sits after the DMA in program order.
-  unsigned sh16, himask;
-  asm volatile("s_mov_b32 %0, 16\n\ts_mov_b32 %1, 0xffff0000" : "=s"(sh16), "=s"(himask));
   DBG_T(9);
 
-  bf16x8_t qf[NKS];
-#pragma unroll
-  for (int ks = 0; ks < NKS; ++ks) {
-    u32x4_t v = rope_apply(qraw[ks], 4 * ks + g, sh16, himask);
-    if (!qvalid) v = (u32x4_t){0, 0, 0, 0};
-    asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]));   // ... and not below the wait for the tile
-    qf[ks] = __builtin_bit_cast(bf16x8_t, v);
+  // ---- the L new rows: thread (r, c) = tid / 12, tid % 12 < L rotates chunk c of row r, Q for this head and K
+  //      (kept in registers until the tile that holds position past + r has landed); thread tid < L * 96 also
+  //      fetches one element of the new V rows.  All of it is requested now, under the DMA.
+  const int row_w = (p.nh + 2 * p.nkv) * HD;                   // qkv row width
+  const float* cos_b = p.cos_t + (size_t)b * p.rope_bstride * (HD / 2);
+  const float* sin_b = p.sin_t + (size_t)b * p.rope_bstride * (HD / 2);
+  const int tr = tid / CPR, tc = tid - tr * CPR;
+  const bool rtask = tr < p.L;
+  RopeRaw qraw, kraw;
+  if (rtask) {
+    const bf16_t* row = p.qkv + ((size_t)b * p.L + tr) * row_w;
+    qraw = rope_fetch(row + head * HD, tc, cos_b + tr * (HD / 2), sin_b + tr * (HD / 2));
+    const bf16_t* krow = row + (p.nh + kvh) * HD;
+    kraw = qraw;
+    kraw.x0 = *(const u32x4_t*)(krow + tc * 8);
+    kraw.x1 = *(const u32x4_t*)(krow + (tc < 6 ? tc * 8 + 48 : tc * 8 - 48));
+  }
+  const bf16_t* vnew = p.qkv + (size_t)b * p.L * row_w + (p.nh + p.nkv + kvh) * HD;   // + r * row_w + d
+  const int n_vnew = p.L * HD;
+  bf16_t v_early = 0;
+  if (tid < n_vnew) { const int r = tid / HD; v_early = vnew[(size_t)r * row_w + (tid - r * HD)]; }
+  if (tid < 16 * CPR) {                                        // rotated Q (zero rows for q >= L) -> LDS
+    u32x4_t v = {0, 0, 0, 0};
+    if (rtask) v = rope_apply(qraw, tc);
+    *(u32x4_t*)(Qs + tr * KROW + ((tc ^ ((tr >> 2) & 3)) << 4)) = v;
   }
   DBG_T(2);
 
@@ -656,115 +670,81 @@ __global__ void __launch_bounds__(64) k_attn_decode(AttnDecP p) {
   const int total = past + p.L;
   const int kv_end = min(total, kv_hi);
   const int qpos = past + qi;
+  const bool qvalid = qi < p.L;
   const float sc2 = p.scale * 1.4426950408889634f;            // scale * log2(e): softmax runs on exp2
 
-  // ---- positions [past, total) that fall in a tile: K rotated from the qkv row, V copied -- written into the LDS
-  //      tile once its DMA has landed, and appended to the cache by the writer block.  The single-token step
-  //      (L == 1) with the new position in the first tile fetches its operands NOW, under the DMA; everything
-  //      else takes rolled loops (rare, must not cost registers or code).
-  const bool fast_new = p.L == 1 && past >= kv_lo && past < kv_hi && past < kv_lo + TK;
-  RopeRaw nraw;
-  bf16_t nv0 = 0, nv1 = 0;
-  if (fast_new) {
-    const bf16_t* row = p.qkv + (size_t)b * row_w;
-    if (lane < CPR) nraw = rope_fetch(row + (p.nh + kvh) * HD, lane, cos_b, sin_b);
-    const bf16_t* vrowp = row + (p.nh + p.nkv + kvh) * HD;
-    nv0 = vrowp[lane];
-    if (lane < HD - 64) nv1 = vrowp[lane + 64];
-  }
-  auto patch_new = [&](int kv0, unsigned char* Kb, unsigned char* Vb) {
-    const int n0 = max(past, kv0), n1 = min(kv_end, kv0 + TK), n_new = n1 - n0;
-#pragma unroll 1
-    for (int w = lane; w < n_new * CPR; w += 64) {
-      const int t = n0 + w / CPR, c = w % CPR, r = t - past, rr = t - kv0;
-      const bf16_t* row = p.qkv + ((size_t)b * p.L + r) * row_w;
-      const u32x4_t kn = rope_chunk(row + (p.nh + kvh) * HD, c, cos_b + r * (HD / 2), sin_b + r * (HD / 2));
-      *(u32x4_t*)(Kb + rr * KROW + ((c ^ ((rr >> 2) & 3)) << 4)) = kn;
-      if (kv_writer) *(u32x4_t*)(p.k_cache + (((size_t)b * p.nkv + kvh) * p.cache_t + t) * HD + c * 8) = kn;   // phi.py:545
-    }
-#pragma unroll 1
-    for (int w = lane; w < n_new * HD; w += 64) {
-      const int t = n0 + w / HD, d = w % HD, r = t - past, rr = t - kv0;
-      const bf16_t val = p.qkv[((size_t)b * p.L + r) * row_w + (p.nh + p.nkv + kvh) * HD + d];
-      *(bf16_t*)(Vb + d * VROW + ((((rr >> 3) ^ (d >> 1)) & 7) << 4) + (rr & 7) * 2) = val;
-      if (kv_writer) vc[(size_t)d * p.cache_t + t] = val;                                                   // phi.py:546
-    }
-  };
-
   // ---- fragment read offsets (swizzled as above)
-  const unsigned k_rd = qi * KROW + ((g ^ ((qi >> 2) & 3)) << 4);             // + st*16*KROW + ks*64
-  const unsigned vx = (g >> 1) ^ ((qi >> 1) & 7);
-  unsigned v_rd[4];                                                            // chunk (4 st + 2 h + g/2) ^ ((qi>>1)&7)
-#pragma unroll
-  for (int k = 0; k < 4; ++k) v_rd[k] = qi * VROW + ((vx ^ (2 * k)) << 4) + (g & 1) * 8;   // + d*16*VROW
+  const unsigned k_rd = qi * KROW + ((g ^ ((qi >> 2) & 3)) << 4);                         // + ks*64
+  const unsigned v_rd = KS_BYTES + qi * VROW + (((g >> 1) ^ ((qi >> 3) & 1)) << 4) + (g & 1) * 8;   // + dt*16*VROW
 
   float m_run = -INFINITY, l_run = 0.f;
   f32x4_t o[NDT];
 #pragma unroll
   for (int d = 0; d < NDT; ++d) o[d] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  bf16x8_t qf[NKS];
 
   int buf = 0;
   for (int kv0 = kv_lo; kv0 < kv_end; kv0 += TK) {
-    unsigned char* Kb = Ks + buf * KT_BYTES;
-    unsigned char* Vb = Vt + buf * VT_BYTES;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this tile's DMA has landed (single-wave block: no barrier)
+    const unsigned char* Wb = wreg + buf * WREG;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wave's slices of the tile have landed
+    const bool has_new = kv0 + TK > past;                      // workgroup-uniform: the tile holds new positions
+    if (kv0 == kv_lo || has_new) __syncthreads();              // (first tile: Qs is complete)
     DBG_T(3);
-    if (!SINGLE && kv0 + TK < kv_end) load_tile(kv0 + TK, buf ^ 1);   // next tile streams in under the MFMAs below
-    if (kv0 + TK > past) {                                     // wave-uniform: only the tile(s) holding new positions
-      if (fast_new) {
-        const int rr = past - kv0;
-        if (lane < CPR) {
-          const u32x4_t kn = rope_apply(nraw, lane);
-          *(u32x4_t*)(Kb + rr * KROW + ((lane ^ ((rr >> 2) & 3)) << 4)) = kn;
-          if (kv_writer) *(u32x4_t*)(p.k_cache + (((size_t)b * p.nkv + kvh) * p.cache_t + past) * HD + lane * 8) = kn;   // phi.py:545
-        }
-        *(bf16_t*)(Vb + lane * VROW + ((((rr >> 3) ^ (lane >> 1)) & 7) << 4) + (rr & 7) * 2) = nv0;
-        if (kv_writer) vc[(size_t)lane * p.cache_t + past] = nv0;                                           // phi.py:546
-        if (lane < HD - 64) {
-          const int d = lane + 64;
-          *(bf16_t*)(Vb + d * VROW + ((((rr >> 3) ^ (d >> 1)) & 7) << 4) + (rr & 7) * 2) = nv1;
-          if (kv_writer) vc[(size_t)d * p.cache_t + past] = nv1;
-        }
-      } else {
-        patch_new(kv0, Kb, Vb);
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (kv0 == kv_lo) {
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks) qf[ks] = *(const bf16x8_t*)(Qs + k_rd + ks * 64);
     }
-
-    f32x4_t s[TK / 16];
-#pragma unroll
-    for (int st = 0; st < TK / 16; ++st) {
-      s[st] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int ks = 0; ks < NKS; ++ks) {
-        const bf16x8_t kf = *(const bf16x8_t*)(Kb + k_rd + st * 16 * KROW + ks * 64);
-        s[st] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], s[st], 0, 0, 0);
+    if (has_new) {
+      // new positions in this tile: K rotated from the qkv row, V copied, into the LDS slices of the waves that
+      // own them, and appended to the cache by the writer workgroup (no other workgroup ever reads cache rows
+      // that are written in this launch)
+      if (rtask) {
+        const int t = past + tr, rr = t - kv0;
+        if (rr >= 0 && rr < TK && t < kv_end) {
+          const u32x4_t kn = rope_apply(kraw, tc);
+          const int row = rr & 15;
+          *(u32x4_t*)(KV + ((rr >> 4) * NBUF + buf) * WREG + row * KROW + ((tc ^ ((row >> 2) & 3)) << 4)) = kn;
+          if (kv_writer) *(u32x4_t*)(p.k_cache + (((size_t)b * p.nkv + kvh) * p.cache_t + t) * HD + tc * 8) = kn;   // phi.py:545
+        }
       }
+#pragma unroll 1
+      for (int idx = tid; idx < n_vnew; idx += 256) {
+        const int r = idx / HD, d = idx - r * HD, t = past + r, rr = t - kv0;
+        if (rr >= 0 && rr < TK && t < kv_end) {
+          const bf16_t val = idx == tid ? v_early : vnew[(size_t)r * row_w + d];
+          const int kk = rr & 15;
+          *(bf16_t*)(KV + ((rr >> 4) * NBUF + buf) * WREG + KS_BYTES + d * VROW + (((kk >> 3) ^ ((d >> 3) & 1)) << 4) + (kk & 7) * 2) = val;
+          if (kv_writer) vc[(size_t)d * p.cache_t + t] = val;                                               // phi.py:546
+        }
+      }
+      __syncthreads();
+    }
+    if (!SINGLE && kv0 + TK < kv_end) load_tile(kv0 + TK, buf ^ 1);   // next tile streams in under the MFMAs below
+
+    f32x4_t s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+      const bf16x8_t kf = *(const bf16x8_t*)(Wb + k_rd + ks * 64);
+      s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], s, 0, 0, 0);
     }
     DBG_T(4);
     float m_t = -INFINITY;
 #pragma unroll
-    for (int st = 0; st < TK / 16; ++st)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int t = kv0 + 16 * st + 4 * g + r;
-        const bool vis = t < kv_end && t >= pad && t <= qpos && qpos >= pad;
-        const float v = vis ? s[st][r] * sc2 : -INFINITY;               // log2 domain: scale*log2(e) folded in
-        s[st][r] = v;
-        m_t = fmaxf(m_t, v);
-      }
+    for (int r = 0; r < 4; ++r) {
+      const int t = kv0 + WK * wave + 4 * g + r;
+      const bool vis = t < kv_end && t >= pad && t <= qpos && qpos >= pad;
+      s[r] = vis ? s[r] * sc2 : -INFINITY;                     // log2 domain: scale*log2(e) folded in
+      m_t = fmaxf(m_t, s[r]);
+    }
     m_t = rows_max(m_t);
     const float m_new = fmaxf(m_run, m_t);
     const float m_use = m_new == -INFINITY ? 0.f : m_new;
     float l_t = 0.f;
 #pragma unroll
-    for (int st = 0; st < TK / 16; ++st)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float e = __builtin_amdgcn_exp2f(s[st][r] - m_use);
-        s[st][r] = e;
-        l_t += e;
-      }
+    for (int r = 0; r < 4; ++r) {
+      s[r] = __builtin_amdgcn_exp2f(s[r] - m_use);
+      l_t += s[r];
+    }
     l_t = rows_sum(l_t);
     if (!SINGLE) {
       const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);
@@ -775,33 +755,47 @@ __global__ void __launch_bounds__(64) k_attn_decode(AttnDecP p) {
     l_run += l_t;
     m_run = m_new;
     DBG_T(5);
+    const u32x2_t pw = {pack_bf16x2(s[0], s[1]), pack_bf16x2(s[2], s[3])};
+    const s16x4_t pf = __builtin_bit_cast(s16x4_t, pw);
 #pragma unroll
-    for (int st = 0; st < TK / 32; ++st) {
-      u32x4_t pw;
-      pw[0] = pack_bf16x2(s[2 * st][0], s[2 * st][1]);
-      pw[1] = pack_bf16x2(s[2 * st][2], s[2 * st][3]);
-      pw[2] = pack_bf16x2(s[2 * st + 1][0], s[2 * st + 1][1]);
-      pw[3] = pack_bf16x2(s[2 * st + 1][2], s[2 * st + 1][3]);
-      const bf16x8_t pf = __builtin_bit_cast(bf16x8_t, pw);
-#pragma unroll
-      for (int d = 0; d < NDT; ++d) {
-        const u32x2_t a0 = *(const u32x2_t*)(Vb + v_rd[2 * st] + d * 16 * VROW);
-        const u32x2_t a1 = *(const u32x2_t*)(Vb + v_rd[2 * st + 1] + d * 16 * VROW);
-        const u32x4_t aw = {a0[0], a0[1], a1[0], a1[1]};
-        o[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, aw), pf, o[d], 0, 0, 0);
-      }
+    for (int d = 0; d < NDT; ++d) {
+      const s16x4_t vf = *(const s16x4_t*)(Wb + v_rd + d * 16 * VROW);
+      o[d] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(vf, pf, o[d], 0, 0, 0);
     }
     DBG_T(6);
     if (SINGLE) break;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // LDS reads of this tile precede the DMA that reuses it
     buf ^= 1;
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // no DMA may still target this workgroup's LDS at exit
-  if (!qvalid) return;
-  float* w = p.ws + ((((size_t)b * p.nh + head) * p.n_split + blockIdx.x) * 16 + qi) * (HD + 2);
+
+  // ---- merge the four wave partials: each wave parks (O, m, l) of its valid queries in its own (now dead) tile
+  //      region, then thread idx < L*96 folds element (q, d) over the waves and writes the workgroup partial
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); // no DMA may still target this region / LDS at exit
+  if (qvalid) {
+    float* Ow = (float*)wreg + qi * HD;
 #pragma unroll
-  for (int d = 0; d < NDT; ++d) *(f32x4_t*)(w + 16 * d + 4 * g) = o[d];
-  if (g == 0) { w[HD] = m_run; w[HD + 1] = l_run; }
+    for (int d = 0; d < NDT; ++d) *(f32x4_t*)(Ow + 16 * d + 4 * g) = o[d];
+    if (g == 0) { Ml[wave][qi][0] = m_run; Ml[wave][qi][1] = l_run; }
+  }
+  __syncthreads();
+#pragma unroll 1
+  for (int idx = tid; idx < n_vnew; idx += 256) {
+    const int q = idx / HD, d = idx - q * HD;
+    float mk[4], M = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { mk[k] = Ml[k][q][0]; M = fmaxf(M, mk[k]); }
+    const float Mu = M == -INFINITY ? 0.f : M;
+    float acc = 0.f, lsum = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float c = __builtin_amdgcn_exp2f(mk[k] - Mu);
+      acc += c * ((const float*)(KV + k * (NBUF * WREG)))[q * HD + d];
+      lsum += c * Ml[k][q][1];
+    }
+    float* w = p.ws + ((((size_t)b * p.nh + head) * p.n_split + blockIdx.x) * 16 + q) * (HD + 2);
+    w[d] = acc;
+    if (d == 0) { w[HD] = M; w[HD + 1] = lsum; }
+  }
   DBG_T(7);
 }
 
@@ -888,8 +882,8 @@ extern "C" int p3v_attention_decode(const p3v_attn_decode_args_t* a, void* strea
                 chunk, grp, (65536 + grp - 1) / grp};
   hipStream_t s = (hipStream_t)stream;
   const dim3 grid(a->n_split, a->n_heads, a->B);
-  if (a->n_split * 64 >= a->cache_t) hipLaunchKernelGGL((k_attn_decode<true>), grid, dim3(64), 0, s, p);
-  else hipLaunchKernelGGL((k_attn_decode<false>), grid, dim3(64), 0, s, p);
+  if (a->n_split * 64 >= a->cache_t) hipLaunchKernelGGL((k_attn_decode<true>), grid, dim3(256), 0, s, p);
+  else hipLaunchKernelGGL((k_attn_decode<false>), grid, dim3(256), 0, s, p);
   P3V_CHECK_LAUNCH();
   hipLaunchKernelGGL(k_attn_combine2, dim3(a->B * a->n_heads * a->L), dim3(256), 0, s, a->ws, a->out, a->L, a->n_heads,
                      a->hd, a->n_split);
