@@ -569,7 +569,7 @@ typedef __attribute__((address_space(3))) void* dec_lptr_t;
 //   K  : 16-B chunk c (0..11) of row r lives at chunk c ^ ((r >> 2) & 3)      (192-B rows: rows r, r+4 share banks)
 //   V^T: 16-B chunk c (0..1)  of row d lives at chunk c ^ ((d >> 3) & 1)      (32-B rows: rows d, d+8 share banks)
 //   Q   (rotated by the first 12 L threads, [16 queries][96]): same swizzle as K.
-// SINGLE: the launcher guarantees one tile per workgroup (n_split * 64 >= cache_t): one LDS buffer per wave.
+// The launcher guarantees one tile per workgroup (n_split * 64 >= cache_t); longer splits take k_attn_decode_stream.
 #ifdef P3V_ATTN_DEBUG
 __device__ unsigned long long p3v_dbg[16];
 #define DBG_T(i) do { if (blockIdx.x == 7 && blockIdx.y == 3 && threadIdx.x == 0) p3v_dbg[i] = __builtin_readcyclecounter(); } while (0)
@@ -577,20 +577,19 @@ __device__ unsigned long long p3v_dbg[16];
 #define DBG_T(i)
 #endif
 typedef short s16x4_t __attribute__((ext_vector_type(4)));
-template <bool SINGLE>
 __global__ void __launch_bounds__(256) k_attn_decode(AttnDecP p) {
   DBG_T(0);
   constexpr int TK = 64, WK = 16, HD = 96, KROW = HD * 2, VROW = WK * 2, NKS = 3, NDT = 6, CPR = 12;
-  constexpr int KS_BYTES = WK * KROW, VS_BYTES = HD * VROW, WREG = KS_BYTES + VS_BYTES, NBUF = SINGLE ? 1 : 2;
+  constexpr int KS_BYTES = WK * KROW, VS_BYTES = HD * VROW, WREG = KS_BYTES + VS_BYTES;
   static_assert(WREG >= 16 * HD * 4, "a wave's O partial reuses its tile region");
-  __shared__ __attribute__((aligned(1024))) unsigned char KV[4 * NBUF * WREG];   // [wave][buf]{K slice | V^T slice}
+  __shared__ __attribute__((aligned(1024))) unsigned char KV[4 * WREG];   // [wave]{K slice | V^T slice}
   __shared__ __attribute__((aligned(16))) unsigned char Qs[16 * KROW];
   __shared__ float Ml[4][16][2];
   const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, qi = lane & 15;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int b = blockIdx.z, head = blockIdx.y, kvh = (head * p.grp_magic) >> 16;      // head / grp without a divide
   const bool kv_writer = head == kvh * p.grp;
-  unsigned char* wreg = KV + wave * (NBUF * WREG);
+  unsigned char* wreg = KV + wave * WREG;
 
   // ---- the cache length and this row's left padding: scalar loads issued first, consumed after everything
   //      that does not depend on them has been put in flight
@@ -604,37 +603,28 @@ __global__ void __launch_bounds__(256) k_attn_decode(AttnDecP p) {
   //      live length are fetched too (allocated, finite) and masked.
   const unsigned char* kc = (const unsigned char*)(p.k_cache + ((size_t)b * p.nkv + kvh) * (size_t)p.cache_t * HD);
   bf16_t* vc = p.v_cache + ((size_t)b * p.nkv + kvh) * (size_t)HD * p.cache_t;          // V^T: [hd][cache_t]
-  const int chunk = SINGLE ? TK : p.chunk;
-  const int kv_lo = blockIdx.x * chunk, kv_hi = min(p.cache_t, kv_lo + chunk);
+  const int kv_lo = blockIdx.x * TK, kv_hi = min(p.cache_t, kv_lo + TK);
   unsigned koff[3];
 #pragma unroll
   for (int j = 0; j < 3; ++j) {
     const int i = j * 64 + lane, r0 = i / CPR, pc = i - r0 * CPR;
     koff[j] = r0 * KROW + ((pc ^ ((r0 >> 2) & 3)) << 4);
   }
-#ifdef P3V_VT_CONTIG_HACK
-  const size_t vrow = 128;                                     // timing experiment only: tile-contiguous V^T (wrong results)
-#else
   const size_t vrow = (size_t)p.cache_t * 2;                   // bytes per V^T row
-#endif
   const unsigned char* vsrc = (const unsigned char*)vc + (size_t)(lane >> 1) * vrow + (((lane & 1) ^ ((lane >> 4) & 1)) << 4);
-  auto load_tile = [&](int kv0, int buf) {
+  auto load_tile = [&](int kv0) {
     const int k0 = kv0 + WK * wave;
-    unsigned char* dst = wreg + buf * WREG;
+    unsigned char* dst = wreg;
     const unsigned char* ksrc = kc + (size_t)k0 * KROW;
 #pragma unroll
     for (int j = 0; j < 3; ++j)
       __builtin_amdgcn_global_load_lds((dec_gptr_t)(ksrc + koff[j]), (dec_lptr_t)(dst + j * 1024), 16, 0, 0);
-#ifdef P3V_VT_CONTIG_HACK
-    const unsigned char* vs = vsrc + (size_t)(kv0 / 64) * 12288 + wave * 32;
-#else
     const unsigned char* vs = vsrc + (size_t)k0 * 2;
-#endif
 #pragma unroll
     for (int j = 0; j < 3; ++j)
       __builtin_amdgcn_global_load_lds((dec_gptr_t)(vs + (size_t)j * 32 * vrow), (dec_lptr_t)(dst + KS_BYTES + j * 1024), 16, 0, 0);
   };
-  load_tile(min(kv_lo, p.cache_t - TK), 0);                    // unconditional (an empty split fetches a tile it never uses)
+  load_tile(min(kv_lo, p.cache_t - TK));                    // unconditional (an empty split fetches a tile it never uses)
   DBG_T(9);
 
   // ---- the L new rows: thread (r, c) = tid / 12, tid % 12 < L rotates chunk c of row r, Q for this head and K
@@ -683,18 +673,15 @@ __global__ void __launch_bounds__(256) k_attn_decode(AttnDecP p) {
   for (int d = 0; d < NDT; ++d) o[d] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
   bf16x8_t qf[NKS];
 
-  int buf = 0;
-  for (int kv0 = kv_lo; kv0 < kv_end; kv0 += TK) {
-    const unsigned char* Wb = wreg + buf * WREG;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wave's slices of the tile have landed
-    const bool has_new = kv0 + TK > past;                      // workgroup-uniform: the tile holds new positions
-    if (kv0 == kv_lo || has_new) __syncthreads();              // (first tile: Qs is complete)
+  const int kv0 = kv_lo;
+  if (kv0 < kv_end) {
+    const unsigned char* Wb = wreg;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the DMA of this wave's slices has landed
+    __syncthreads();                                           // Qs is complete, every wave's slices are in LDS
     DBG_T(3);
-    if (kv0 == kv_lo) {
 #pragma unroll
-      for (int ks = 0; ks < NKS; ++ks) qf[ks] = *(const bf16x8_t*)(Qs + k_rd + ks * 64);
-    }
-    if (has_new) {
+    for (int ks = 0; ks < NKS; ++ks) qf[ks] = *(const bf16x8_t*)(Qs + k_rd + ks * 64);
+    if (kv0 + TK > past) {                                     // workgroup-uniform: the tile holds new positions
       // new positions in this tile: K rotated from the qkv row, V copied, into the LDS slices of the waves that
       // own them, and appended to the cache by the writer workgroup (no other workgroup ever reads cache rows
       // that are written in this launch)
@@ -703,7 +690,7 @@ __global__ void __launch_bounds__(256) k_attn_decode(AttnDecP p) {
         if (rr >= 0 && rr < TK && t < kv_end) {
           const u32x4_t kn = rope_apply(kraw, tc);
           const int row = rr & 15;
-          *(u32x4_t*)(KV + ((rr >> 4) * NBUF + buf) * WREG + row * KROW + ((tc ^ ((row >> 2) & 3)) << 4)) = kn;
+          *(u32x4_t*)(KV + (rr >> 4) * WREG + row * KROW + ((tc ^ ((row >> 2) & 3)) << 4)) = kn;
           if (kv_writer) *(u32x4_t*)(p.k_cache + (((size_t)b * p.nkv + kvh) * p.cache_t + t) * HD + tc * 8) = kn;   // phi.py:545
         }
       }
@@ -713,13 +700,12 @@ __global__ void __launch_bounds__(256) k_attn_decode(AttnDecP p) {
         if (rr >= 0 && rr < TK && t < kv_end) {
           const bf16_t val = idx == tid ? v_early : vnew[(size_t)r * row_w + d];
           const int kk = rr & 15;
-          *(bf16_t*)(KV + ((rr >> 4) * NBUF + buf) * WREG + KS_BYTES + d * VROW + (((kk >> 3) ^ ((d >> 3) & 1)) << 4) + (kk & 7) * 2) = val;
+          *(bf16_t*)(KV + (rr >> 4) * WREG + KS_BYTES + d * VROW + (((kk >> 3) ^ ((d >> 3) & 1)) << 4) + (kk & 7) * 2) = val;
           if (kv_writer) vc[(size_t)d * p.cache_t + t] = val;                                               // phi.py:546
         }
       }
       __syncthreads();
     }
-    if (!SINGLE && kv0 + TK < kv_end) load_tile(kv0 + TK, buf ^ 1);   // next tile streams in under the MFMAs below
 
     f32x4_t s = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -745,14 +731,7 @@ __global__ void __launch_bounds__(256) k_attn_decode(AttnDecP p) {
       s[r] = __builtin_amdgcn_exp2f(s[r] - m_use);
       l_t += s[r];
     }
-    l_t = rows_sum(l_t);
-    if (!SINGLE) {
-      const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);
-      l_run *= alpha;
-#pragma unroll
-      for (int d = 0; d < NDT; ++d) o[d] *= alpha;
-    }
-    l_run += l_t;
+    l_run = rows_sum(l_t);
     m_run = m_new;
     DBG_T(5);
     const u32x2_t pw = {pack_bf16x2(s[0], s[1]), pack_bf16x2(s[2], s[3])};
@@ -763,9 +742,6 @@ __global__ void __launch_bounds__(256) k_attn_decode(AttnDecP p) {
       o[d] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(vf, pf, o[d], 0, 0, 0);
     }
     DBG_T(6);
-    if (SINGLE) break;
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // LDS reads of this tile precede the DMA that reuses it
-    buf ^= 1;
   }
 
   // ---- merge the four wave partials: each wave parks (O, m, l) of its valid queries in its own (now dead) tile
@@ -789,7 +765,7 @@ __global__ void __launch_bounds__(256) k_attn_decode(AttnDecP p) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const float c = __builtin_amdgcn_exp2f(mk[k] - Mu);
-      acc += c * ((const float*)(KV + k * (NBUF * WREG)))[q * HD + d];
+      acc += c * ((const float*)(KV + k * WREG))[q * HD + d];
       lsum += c * Ml[k][q][1];
     }
     float* w = p.ws + ((((size_t)b * p.nh + head) * p.n_split + blockIdx.x) * 16 + q) * (HD + 2);
@@ -797,6 +773,180 @@ __global__ void __launch_bounds__(256) k_attn_decode(AttnDecP p) {
     if (d == 0) { w[HD] = M; w[HD + 1] = lsum; }
   }
   DBG_T(7);
+}
+
+// Multi-tile variant (contexts beyond ~8k tokens or large batches, where one tile per workgroup would need more than
+// ~4096 workgroups): ONE wave per workgroup walks the 64-key tiles of its split; the whole next tile (24 16-byte
+// loads per lane) is prefetched into registers while the current one is consumed from LDS, so ~768 resident waves
+// keep 18 MB in flight and the loop is bandwidth-bound (6.2 TB/s at 32k tokens).
+template <int TK>
+__global__ void __launch_bounds__(64) k_attn_decode_stream(AttnDecP p) {
+  constexpr int HD = 96, KSTR = HD * 2 + 16, VSTR = TK * 2 + 16, NKS = 3, NDT = 6, CPR = 12;
+  constexpr int KIT = TK * CPR / 64, VCH = TK / 8, VIT = HD * VCH / 64;   // 16-byte loads per lane: K, V^T
+  __shared__ __attribute__((aligned(16))) unsigned char Ks[TK * KSTR];
+  __shared__ __attribute__((aligned(16))) unsigned char Vt[HD * VSTR];
+  const int lane = threadIdx.x, g = lane >> 4, qi = lane & 15;
+  const int b = blockIdx.z, head = blockIdx.y, kvh = (head * p.grp_magic) >> 16;
+  const bool kv_writer = head == kvh * p.grp;
+  const float sc2 = p.scale * 1.4426950408889634f;            // scale * log2(e): softmax runs on exp2
+  const int row_w = (p.nh + 2 * p.nkv) * HD;                  // qkv row width
+  const bf16_t* kc = p.k_cache + ((size_t)b * p.nkv + kvh) * (size_t)p.cache_t * HD;
+  bf16_t* vc = p.v_cache + ((size_t)b * p.nkv + kvh) * (size_t)HD * p.cache_t;          // V^T: [hd][cache_t]
+  // The key range of a split is STATIC (a function of the cache capacity, not of the current length):
+  // its first tile can be requested before the cache length `past` has even arrived from HBM.
+  const int chunk = p.chunk;
+  const int kv_lo = blockIdx.x * chunk, kv_hi = min(p.cache_t, kv_lo + chunk);
+
+  // ---- tile registers: K TK rows x 12 chunks, V^T 96 rows x TK/8 chunks, all requested before anything is
+  //      used.  Rows beyond the live length are read too (allocated, finite V^T / masked K) and ignored.
+  u32x4_t kreg[KIT], vreg[VIT];
+  auto load_tile = [&](int kv0) {
+#pragma unroll
+    for (int it = 0; it < KIT; ++it) {
+      const int i = it * 64 + lane;
+      kreg[it] = __builtin_nontemporal_load((const u32x4_t*)(kc + (size_t)(kv0 + i / CPR) * HD + (i % CPR) * 8));
+    }
+#pragma unroll
+    for (int it = 0; it < VIT; ++it) {
+      const int i = it * 64 + lane;
+      vreg[it] = __builtin_nontemporal_load((const u32x4_t*)(vc + (size_t)(i / VCH) * p.cache_t + kv0 + (i % VCH) * 8));
+    }
+  };
+  if (kv_lo < kv_hi) load_tile(kv_lo);                         // cache_t % TK == 0: the tile is always in bounds
+
+  const int past = p.d_past ? *p.d_past : p.past;
+  const int total = past + p.L;
+  const int pad = p.pad_len ? p.pad_len[b] : 0;
+  int kv_begin = kv_lo;
+  const int kv_end = min(total, kv_hi);
+  if (pad > kv_begin) kv_begin = pad & ~(TK - 1);
+  const float* cos_b = p.cos_t + (size_t)b * p.rope_bstride * (HD / 2);
+  const float* sin_b = p.sin_t + (size_t)b * p.rope_bstride * (HD / 2);
+
+  // positions [past, total) that fall in this tile: K rotated from the qkv row, V copied -- written straight into
+  // the LDS tile (after the bulk register->LDS store) and appended to the cache by the writer block.  Rolled
+  // loops on purpose: this is the rare path (one tile per head) and must not cost registers.
+  auto patch_new = [&](int kv0) {
+    const int n0 = max(past, kv0), n1 = min(kv_end, kv0 + TK), n_new = n1 - n0;
+#pragma unroll 1
+    for (int w = lane; w < n_new * CPR; w += 64) {
+      const int t = n0 + w / CPR, c = w % CPR, r = t - past;
+      const bf16_t* row = p.qkv + ((size_t)b * p.L + r) * row_w;
+      const u32x4_t kn = rope_chunk(row + (p.nh + kvh) * HD, c, cos_b + r * (HD / 2), sin_b + r * (HD / 2));
+      *(u32x4_t*)(Ks + (t - kv0) * KSTR + c * 16) = kn;
+      if (kv_writer) *(u32x4_t*)(p.k_cache + (((size_t)b * p.nkv + kvh) * p.cache_t + t) * HD + c * 8) = kn;   // phi.py:545
+    }
+#pragma unroll 1
+    for (int w = lane; w < n_new * HD; w += 64) {
+      const int t = n0 + w / HD, d = w % HD, r = t - past;
+      const bf16_t val = p.qkv[((size_t)b * p.L + r) * row_w + (p.nh + p.nkv + kvh) * HD + d];
+      *(bf16_t*)(Vt + d * VSTR + (t - kv0) * 2) = val;
+      if (kv_writer) vc[(size_t)d * p.cache_t + t] = val;                                                   // phi.py:546
+    }
+  };
+  if (kv_begin > kv_lo && kv_begin < kv_end) load_tile(kv_begin);   // left padding skipped whole tiles: reload
+
+
+  const bool qvalid = qi < p.L;
+  const int qpos = past + qi;
+  bf16x8_t qf[NKS];
+  {
+    const bf16_t* qrow = p.qkv + ((size_t)b * p.L + (qvalid ? qi : 0)) * row_w + head * HD;
+    const float* ct = cos_b + (qvalid ? qi : 0) * (HD / 2);
+    const float* st = sin_b + (qvalid ? qi : 0) * (HD / 2);
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+      u32x4_t v = rope_chunk(qrow, 4 * ks + g, ct, st);
+      if (!qvalid) v = (u32x4_t){0, 0, 0, 0};
+      qf[ks] = __builtin_bit_cast(bf16x8_t, v);
+    }
+  }
+
+  float m_run = -INFINITY, l_run = 0.f;
+  f32x4_t o[NDT];
+#pragma unroll
+  for (int d = 0; d < NDT; ++d) o[d] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  for (int kv0 = kv_begin; kv0 < kv_end; kv0 += TK) {
+#pragma unroll
+    for (int it = 0; it < KIT; ++it) {
+      const int i = it * 64 + lane;
+      *(u32x4_t*)(Ks + (i / CPR) * KSTR + (i % CPR) * 16) = kreg[it];
+    }
+#pragma unroll
+    for (int it = 0; it < VIT; ++it) {
+      const int i = it * 64 + lane;
+      *(u32x4_t*)(Vt + (i / VCH) * VSTR + (i % VCH) * 16) = vreg[it];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // this wave's LDS writes have landed (single-wave block)
+    if (kv0 + TK > past) {                                     // wave-uniform: only the tile(s) holding new positions
+      patch_new(kv0);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    if (kv0 + TK < kv_end) load_tile(kv0 + TK);                // next tile streams in under the MFMAs below
+
+    f32x4_t s[TK / 16];
+#pragma unroll
+    for (int st = 0; st < TK / 16; ++st) {
+      s[st] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks) {
+        const bf16x8_t kf = *(const bf16x8_t*)(Ks + (16 * st + qi) * KSTR + (32 * ks + 8 * g) * 2);
+        s[st] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], s[st], 0, 0, 0);
+      }
+    }
+    float m_t = -INFINITY;
+#pragma unroll
+    for (int st = 0; st < TK / 16; ++st)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int t = kv0 + 16 * st + 4 * g + r;
+        const bool vis = t < kv_end && t >= pad && t <= qpos && qpos >= pad;
+        const float v = vis ? s[st][r] * sc2 : -INFINITY;               // log2 domain: scale*log2(e) folded in
+        s[st][r] = v;
+        m_t = fmaxf(m_t, v);
+      }
+    m_t = rows_max(m_t);
+    const float m_new = fmaxf(m_run, m_t);
+    const float m_use = m_new == -INFINITY ? 0.f : m_new;
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);
+    float l_t = 0.f;
+#pragma unroll
+    for (int st = 0; st < TK / 16; ++st)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float e = __builtin_amdgcn_exp2f(s[st][r] - m_use);
+        s[st][r] = e;
+        l_t += e;
+      }
+    l_t = rows_sum(l_t);
+    l_run = l_run * alpha + l_t;
+    m_run = m_new;
+#pragma unroll
+    for (int d = 0; d < NDT; ++d) o[d] *= alpha;
+#pragma unroll
+    for (int st = 0; st < TK / 32; ++st) {
+      u32x4_t pw;
+      pw[0] = pack_bf16x2(s[2 * st][0], s[2 * st][1]);
+      pw[1] = pack_bf16x2(s[2 * st][2], s[2 * st][3]);
+      pw[2] = pack_bf16x2(s[2 * st + 1][0], s[2 * st + 1][1]);
+      pw[3] = pack_bf16x2(s[2 * st + 1][2], s[2 * st + 1][3]);
+      const bf16x8_t pf = __builtin_bit_cast(bf16x8_t, pw);
+#pragma unroll
+      for (int d = 0; d < NDT; ++d) {
+        const unsigned char* vr = Vt + (16 * d + qi) * VSTR + (32 * st + 4 * g) * 2;
+        const u32x2_t a0 = *(const u32x2_t*)vr, a1 = *(const u32x2_t*)(vr + 32);
+        const u32x4_t aw = {a0[0], a0[1], a1[0], a1[1]};
+        o[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, aw), pf, o[d], 0, 0, 0);
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // LDS reads of this tile precede the next tile's writes
+  }
+  if (!qvalid) return;
+  float* w = p.ws + ((((size_t)b * p.nh + head) * p.n_split + blockIdx.x) * 16 + qi) * (HD + 2);
+#pragma unroll
+  for (int d = 0; d < NDT; ++d) *(f32x4_t*)(w + 16 * d + 4 * g) = o[d];
+  if (g == 0) { w[HD] = m_run; w[HD + 1] = l_run; }
 }
 
 // merge split-KV partials: one 256-thread block per (b, head, query), ONE memory round trip: thread
@@ -882,8 +1032,8 @@ extern "C" int p3v_attention_decode(const p3v_attn_decode_args_t* a, void* strea
                 chunk, grp, (65536 + grp - 1) / grp};
   hipStream_t s = (hipStream_t)stream;
   const dim3 grid(a->n_split, a->n_heads, a->B);
-  if (a->n_split * 64 >= a->cache_t) hipLaunchKernelGGL((k_attn_decode<true>), grid, dim3(256), 0, s, p);
-  else hipLaunchKernelGGL((k_attn_decode<false>), grid, dim3(256), 0, s, p);
+  if (a->n_split * 64 >= a->cache_t) hipLaunchKernelGGL(k_attn_decode, grid, dim3(256), 0, s, p);
+  else hipLaunchKernelGGL(k_attn_decode_stream<64>, grid, dim3(64), 0, s, p);
   P3V_CHECK_LAUNCH();
   hipLaunchKernelGGL(k_attn_combine2, dim3(a->B * a->n_heads * a->L), dim3(256), 0, s, a->ws, a->out, a->L, a->n_heads,
                      a->hd, a->n_split);

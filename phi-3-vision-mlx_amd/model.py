@@ -247,8 +247,9 @@ class Phi3VModel:
         """Split-KV plan for the decode-shaped attention (L <= 16): enough blocks to fill 256 CUs."""
         nh, hd = self.cfg.num_attention_heads, self.hd
         if L <= ops.L.DECODE_MAX_L:
-            # single-wave workgroups of 64-key tiles.  Up to ~4096 workgroups: ONE tile each (the kernel then lasts a
-            # single tile's dependency chain); beyond that ~768 workgroups (one resident round) walking several tiles
+            # 64-key tiles.  Up to ~4096 workgroups: ONE tile per 4-wave workgroup (the kernel then lasts a single
+            # tile's dependency chain); beyond that ~768 single-wave workgroups (one resident round, each with its
+            # next 24 KB tile in flight) walking several tiles
             tiles = -(-T // 64)
             if tiles <= 128 and B * nh * tiles <= 4096:
                 n_split = tiles
