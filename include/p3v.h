@@ -223,6 +223,15 @@ int p3v_add_i32(int32_t* x, int n, int delta, void* stream);
 /* history[b, *d_step] = tok[b]; if tok_next != NULL also tok_next[b] = tok[b] (feeds the next replayed step) */
 int p3v_store_token(const int32_t* tok, int32_t* history, const int32_t* d_step, int32_t* tok_next,
                     int B, int max_steps, void* stream);
+/* fused head of a replayed greedy step: x_out[b] = table[tok[b]] (p3v_embed_gather, phi.py:597) and the rotation
+ * rows of position *d_past -> cos_out/sin_out [B, 1, half] (p3v_stage_rope with L = 1) */
+int p3v_step_begin(const int32_t* tok, const uint16_t* table, uint16_t* x_out, const float* cos_t, const float* sin_t,
+                   const int32_t* d_past, float* cos_out, float* sin_out, int B, int hidden, int vocab, int tab_t,
+                   int half_dim, void* stream);
+/* fused tail: next_tok[b] = tok[b] = argmax(logits[b]) (phi_3_vision_mlx.py:392), history[b, *d_step] = it,
+ * then *d_step += 1 and *d_past += 1 (done once, by the last workgroup; `ticket` is a zero-initialised int32) */
+int p3v_step_end(const uint16_t* logits, int32_t* next_tok, int32_t* tok, int32_t* history, int32_t* d_step,
+                 int32_t* d_past, int32_t* ticket, int B, int n, int max_steps, void* stream);
 
 /* ---- hipGraph helpers: capture a sequence of the launches above and replay it */
 int p3v_graph_begin(void* stream);

@@ -472,3 +472,71 @@ extern "C" int p3v_store_token(const int32_t* tok, int32_t* history, const int32
   P3V_CHECK_LAUNCH();
   return P3V_OK;
 }
+
+// ---------------------------------------------------------------- fused head / tail of a graph-replayed greedy step
+// p3v_step_begin = embedding gather of the B current tokens + staging of the rotation-table rows of position
+// *d_past (one workgroup per batch row); p3v_step_end = argmax + history/tok bookkeeping + the two counters.
+// Four launches fewer per decode step than the separate entry points (a launch boundary costs ~2.4 us in-graph).
+__global__ void __launch_bounds__(128) k_step_begin(const int32_t* __restrict__ ids, const u32x4_t* __restrict__ table,
+                                                    u32x4_t* __restrict__ out, int chunks, int vocab,
+                                                    const float* __restrict__ cos_t, const float* __restrict__ sin_t,
+                                                    const int32_t* __restrict__ d_past, float* __restrict__ cos_o,
+                                                    float* __restrict__ sin_o, int tab_t, int half) {
+  const int b = blockIdx.x;
+  const int past = *d_past;
+  int id = ids[b];
+  id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+  const u32x4_t* src = table + (size_t)id * chunks;
+  u32x4_t* dst = out + (size_t)b * chunks;
+  for (int c = threadIdx.x; c < chunks; c += blockDim.x) dst[c] = src[c];
+  for (int i = threadIdx.x; i < half; i += blockDim.x) {
+    cos_o[(size_t)b * half + i] = cos_t[((size_t)b * tab_t + past) * half + i];
+    sin_o[(size_t)b * half + i] = sin_t[((size_t)b * tab_t + past) * half + i];
+  }
+}
+
+extern "C" int p3v_step_begin(const int32_t* tok, const uint16_t* table, uint16_t* x_out, const float* cos_t,
+                              const float* sin_t, const int32_t* d_past, float* cos_out, float* sin_out, int B, int hidden,
+                              int vocab, int tab_t, int half_dim, void* stream) {
+  if (!tok || !table || !x_out || !cos_t || !sin_t || !d_past || !cos_out || !sin_out) return P3V_ERR_ARG;
+  if (B <= 0 || hidden % 8 || vocab <= 0 || tab_t <= 0 || half_dim <= 0) return P3V_ERR_ARG;
+  hipLaunchKernelGGL(k_step_begin, dim3(B), dim3(128), 0, (hipStream_t)stream, tok, (const u32x4_t*)table, (u32x4_t*)x_out,
+                     hidden / 8, vocab, cos_t, sin_t, d_past, cos_out, sin_out, tab_t, half_dim);
+  P3V_CHECK_LAUNCH();
+  return P3V_OK;
+}
+
+__global__ void __launch_bounds__(1024) k_step_end(const bf16_t* __restrict__ logits, int32_t* __restrict__ next_tok,
+                                                   int32_t* __restrict__ tok, int32_t* __restrict__ hist, int32_t* d_step,
+                                                   int32_t* d_past, int32_t* ticket, int n, int max_steps) {
+  __shared__ ValIdx red[16];
+  const int b = blockIdx.x;
+  const int s = *d_step;                     // read before this workgroup takes its ticket (the last one bumps it)
+  const bf16_t* r = logits + (size_t)b * n;
+  ValIdx m = {-INFINITY, 0x7fffffff};
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const float v = bf16_to_f32(r[i]);
+    if (v > m.v || (v == m.v && i < m.i) || m.i == 0x7fffffff) { m.v = v; m.i = i; }
+  }
+  m = block_argmax(m, red);
+  if (threadIdx.x == 0) {
+    next_tok[b] = m.i;
+    tok[b] = m.i;
+    if (s < max_steps) hist[(size_t)b * max_steps + s] = m.i;
+    const int done = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    if (done == (int)gridDim.x - 1) {        // every workgroup has read *d_step by now
+      *d_step = s + 1;
+      *d_past += 1;
+      __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
+extern "C" int p3v_step_end(const uint16_t* logits, int32_t* next_tok, int32_t* tok, int32_t* history, int32_t* d_step,
+                            int32_t* d_past, int32_t* ticket, int B, int n, int max_steps, void* stream) {
+  if (!logits || !next_tok || !tok || !history || !d_step || !d_past || !ticket || B <= 0 || n <= 0) return P3V_ERR_ARG;
+  hipLaunchKernelGGL(k_step_end, dim3(B), dim3(1024), 0, (hipStream_t)stream, logits, next_tok, tok, history, d_step, d_past,
+                     ticket, n, max_steps);
+  P3V_CHECK_LAUNCH();
+  return P3V_OK;
+}

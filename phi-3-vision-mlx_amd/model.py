@@ -329,7 +329,7 @@ class Phi3VModel:
                  history=torch.zeros((B, max(1, st.max_tokens) + 1), dtype=I32, device=dev),
                  x=torch.empty((B, cfg.hidden_size), dtype=BF16, device=dev),
                  logits=torch.empty((B, cfg.vocab_size), dtype=BF16, device=dev),
-                 next_tok=torch.zeros((B,), dtype=I32, device=dev))
+                 next_tok=torch.zeros((B,), dtype=I32, device=dev), ticket=torch.zeros((1,), dtype=I32, device=dev))
         bufs = self._alloc_bufs(B, 1)
         self._split_plan(bufs, B, 1, st.T)
         bufs["rope_cos"] = torch.empty((B, 1, self.hd // 2), dtype=F32, device=dev)
@@ -337,14 +337,11 @@ class Phi3VModel:
         g["bufs"] = bufs
 
         def step():
-            ops.embed_gather(g["tok"], w["model.embed_tokens.weight"], out=g["x"])
-            ops.stage_rope(st.cos, st.sin, bufs["rope_cos"], bufs["rope_sin"], B, 1, st.T, d_past=g["d_past"])
+            ops.step_begin(g["tok"], w["model.embed_tokens.weight"], g["x"], st.cos, st.sin, g["d_past"],
+                           bufs["rope_cos"], bufs["rope_sin"])
             self._layers(g["x"], st, B, 1, 0, 1, bufs=bufs, d_past=g["d_past"])
             self._proj(g["x"], "lm_head.weight", norm_w=w["model.norm.weight"], out=g["logits"])
-            ops.argmax(g["logits"], out=g["next_tok"])
-            ops.store_token(g["next_tok"], g["history"], g["d_step"], g["tok"])
-            ops.add_i32(g["d_past"], 1)
-            ops.add_i32(g["d_step"], 1)
+            ops.step_end(g["logits"], g["next_tok"], g["tok"], g["history"], g["d_step"], g["d_past"], g["ticket"])
         g["d_past"].fill_(st.offset)
         step()                                                   # warm-up run (sets func attributes, pages code in)
         torch.cuda.synchronize()

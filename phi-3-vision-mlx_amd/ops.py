@@ -258,6 +258,20 @@ def add_i32(x, delta):
     L.check(L.lib().p3v_add_i32(_p(x), x.numel(), int(delta), _stream()), "add_i32")
 
 
+def step_begin(tok, table, x_out, cos_t, sin_t, d_past, cos_out, sin_out):
+    """Head of a replayed greedy step: embedding rows of `tok` + rotation rows of position *d_past (one launch)."""
+    B, tab_t, half = tok.numel(), cos_t.shape[-2], cos_t.shape[-1]
+    L.check(L.lib().p3v_step_begin(_p(tok), _p(table), _p(x_out), _p(cos_t), _p(sin_t), _p(d_past), _p(cos_out), _p(sin_out),
+                                   B, table.shape[1], table.shape[0], tab_t, half, _stream()), "step_begin")
+
+
+def step_end(logits, next_tok, tok, history, d_step, d_past, ticket):
+    """Tail of a replayed greedy step: argmax + history/tok bookkeeping + counters (one launch)."""
+    B, n = logits.shape[0], logits.shape[-1]
+    L.check(L.lib().p3v_step_end(_p(logits), _p(next_tok), _p(tok), _p(history), _p(d_step), _p(d_past), _p(ticket), B, n,
+                                 history.shape[1], _stream()), "step_end")
+
+
 def store_token(tok, history, d_step, tok_next=None):
     B, max_steps = history.shape
     L.check(L.lib().p3v_store_token(_p(tok), _p(history), _p(d_step), _p(tok_next), B, max_steps, _stream()), "store_token")

@@ -4,7 +4,10 @@
   c1_oracle.npz     FULL-SIZE Phi-3-mini-128K (BASELINE config 1: 128-token prompt, text-only, greedy):
                     prefill + 7 decode steps; top-16 logits per step.  (~6 min, ~25 GB RAM, run once here.)
 
-    python tests/golden/gen_golden_oracle.py [tiny|c1|all]
+  c2_oracle.npz     FULL-SIZE Phi-3-Vision (BASELINE config 2 = bench.py's rank-0 request: one seeded 336x336 image,
+                    2531-token prompt, greedy): prefill + 3 decode steps; top-16 logits per step.  (CPU, run once here.)
+
+    python tests/golden/gen_golden_oracle.py [tiny|c1|c2|all]
 """
 import os
 import sys
@@ -88,9 +91,42 @@ def c1():
     print("wrote c1_oracle.npz")
 
 
+def c2_request(img_processor):
+    """bench.py's rank-0 request, rebuilt here so that the fixture pins the benchmarked workload."""
+    from PIL import Image
+    rng = np.random.default_rng(0)
+    img = Image.fromarray(rng.integers(0, 256, (336, 336, 3), dtype=np.uint8))
+    image_inputs = img_processor([img])
+    n_img = image_inputs["num_img_tokens"][0]
+    text_ids = rng.integers(3, 32000, 20)
+    ids = np.concatenate([[1], text_ids[:8], -np.ones(n_img, dtype=np.int64), [1], text_ids[8:]])[None].astype(np.int64)
+    return {"input_ids": ids, "pixel_values": np.asarray(image_inputs["pixel_values"], dtype=np.float32),
+            "image_sizes": np.asarray(image_inputs["image_sizes"]), "positions": np.argwhere(ids < 0)}
+
+
+def c2():
+    torch.set_num_threads(8)
+    cfg = make_config(phi3v_config_dict(vision=True))
+    t0 = time.time()
+    w = synth_weights(cfg, seed=0)
+    print(f"weights {time.time()-t0:.0f}s", flush=True)
+    o = orc.OraclePhi3V(cfg, w, cache_fp32=True)
+    inp = c2_request(Phi3VProcessor(None).img_processor)
+    t0 = time.time()
+    toks, lgs = orc.greedy_generate(o, {k: (torch.from_numpy(v) if k == "pixel_values" else v) for k, v in inp.items()}, 4,
+                                    stop_on_eos=False)
+    print(f"prefill + 3 decode steps {time.time()-t0:.0f}s, tokens {toks.tolist()}", flush=True)
+    v, i = topk_pack(lgs)
+    np.savez_compressed(os.path.join(HERE, "c2_oracle.npz"), n_ids=np.asarray([inp["input_ids"].shape[1]], dtype=np.int32),
+                        tokens=toks.numpy().astype(np.int32), topv=v, topi=i, absmax=lgs.float().abs().amax(dim=-1).numpy())
+    print("wrote c2_oracle.npz")
+
+
 if __name__ == "__main__":
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
     if which in ("tiny", "all"):
         tiny()
     if which in ("c1", "all"):
         c1()
+    if which in ("c2", "all"):
+        c2()

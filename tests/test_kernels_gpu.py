@@ -430,3 +430,31 @@ def test_graph_replay(ops):
     s.synchronize()
     import phi3v_oracle as orc_
     close(y, orc_.rms_norm(x.cpu(), w.cpu(), 1e-5), atol=1e-3)
+
+
+@pytest.mark.parametrize("B", [1, 5])
+def test_step_begin_end_match_separate_kernels(ops, B):
+    """The fused head/tail of a replayed greedy step = embed_gather + stage_rope / argmax + store_token + 2 x add_i32."""
+    V, H, T, half, steps = 32064, 3072, 40, 48, 6
+    table = g((V, H), 70).cuda()
+    cos, sin = torch.rand((B, T, half), dtype=F32).cuda(), torch.rand((B, T, half), dtype=F32).cuda()
+    tok = torch.tensor([(7 * b + 3) % V for b in range(B)], dtype=torch.int32).cuda()
+    d_past = torch.tensor([11], dtype=torch.int32).cuda()
+    x = torch.empty((B, H), dtype=BF16).cuda()
+    c_o, s_o = torch.empty((B, 1, half), dtype=F32).cuda(), torch.empty((B, 1, half), dtype=F32).cuda()
+    ops.step_begin(tok, table, x, cos, sin, d_past, c_o, s_o)
+    assert torch.equal(x, table[tok.long()])
+    assert torch.equal(c_o[:, 0], cos[:, 11]) and torch.equal(s_o[:, 0], sin[:, 11])
+    hist = torch.zeros((B, steps), dtype=torch.int32).cuda()
+    d_step, ticket = torch.zeros(1, dtype=torch.int32).cuda(), torch.zeros(1, dtype=torch.int32).cuda()
+    nxt = torch.zeros(B, dtype=torch.int32).cuda()
+    want = []
+    for s in range(steps + 1):                                  # one step past the history capacity: must not write
+        lg = g((B, V), 80 + s).cuda()
+        lg[:, 5] = lg[:, 17000] = lg.float().max() + 1           # tie: the first maximum wins
+        ops.step_end(lg, nxt, tok, hist, d_step, d_past, ticket)
+        ref = ops.argmax(lg)
+        assert torch.equal(nxt, ref) and torch.equal(tok, ref) and (ref == 5).all()
+        want.append(ref.clone())
+        assert d_step.item() == s + 1 and d_past.item() == 12 + s and ticket.item() == 0
+    assert torch.equal(hist, torch.stack(want[:steps], dim=1))
