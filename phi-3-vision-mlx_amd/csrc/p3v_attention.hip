@@ -201,6 +201,12 @@ __global__ void __launch_bounds__(256) k_attn(AttnP p) {
   }
 }
 
+constexpr int CMB_G = 16;   // max 64-lane groups of the split-KV merge kernel
+static inline int combine_threads(int n_split) {              // measured at 41 splits: 8 groups beat 4 and 16
+  static const char* e = getenv("P3V_COMBINE_G");             // tuning knob (4 / 8 / 16)
+  if (e) return 64 * atoi(e);
+  return 64 * (n_split <= 8 ? 4 : 8);
+}
 __global__ void k_attn_combine2(const float* __restrict__ ws, bf16_t* __restrict__ out, int L, int nh, int hd, int n_split);
 // =====================================================================================
 // Prefill / CLIP attention (L > 16): 128 queries per workgroup (4 waves x 2 sub-tiles of 16), 64-key tiles,
@@ -450,7 +456,7 @@ extern "C" int p3v_attention(const p3v_attn_args_t* a, void* stream) {
   else hipLaunchKernelGGL(k_attn<64>, grid, dim3(256), 0, s, p);
   P3V_CHECK_LAUNCH();
   if (p.split_mode) {
-    hipLaunchKernelGGL(k_attn_combine2, dim3(a->B * a->n_heads * a->L), dim3(256), 0, s, a->ws, a->out, a->L, a->n_heads,
+    hipLaunchKernelGGL(k_attn_combine2, dim3(a->B * a->n_heads * a->L), dim3(combine_threads(a->n_split)), 0, s, a->ws, a->out, a->L, a->n_heads,
                        a->hd, p.n_split);
     P3V_CHECK_LAUNCH();
   }
@@ -949,18 +955,19 @@ __global__ void __launch_bounds__(64) k_attn_decode_stream(AttnDecP p) {
   if (g == 0) { w[HD] = m_run; w[HD + 1] = l_run; }
 }
 
-// merge split-KV partials: one 256-thread block per (b, head, query), ONE memory round trip: thread
-// (grp, d) loads (m, l, o[d]) of its quarter of the splits at once, reduces them against its own running
-// max, and the four groups are merged through LDS.
-__global__ void __launch_bounds__(256) k_attn_combine2(const float* __restrict__ ws, bf16_t* __restrict__ out, int L,
-                                                       int nh, int hd, int n_split) {
-  __shared__ float pm[4], pl[4];
-  __shared__ float part[4][128];
+// merge split-KV partials: one block of G = 4 or 8 64-lane groups per (b, head, query): thread (grp, d) loads
+// (m, l, o[d]) of its share of the splits (batches of 4 independent loads), reduces them against its own
+// running max, and the groups are merged through LDS.
+__global__ void __launch_bounds__(64 * CMB_G) k_attn_combine2(const float* __restrict__ ws, bf16_t* __restrict__ out, int L,
+                                                              int nh, int hd, int n_split) {
+  __shared__ float pm[CMB_G], pl[CMB_G];
+  __shared__ float part[CMB_G][128];
   const int qi = blockIdx.x % L, head = (blockIdx.x / L) % nh, b = blockIdx.x / (L * nh);
   const float* base = ws + (((size_t)b * nh + head) * n_split * 16 + qi) * (hd + 2);
   const size_t sstr = (size_t)16 * (hd + 2);
-  const int t = threadIdx.x, grp = t >> 6, d0 = t & 63;       // 4 groups x 64 lanes; lane handles d0 and d0+64
-  const int per = (n_split + 3) >> 2, s0 = grp * per, s1 = min(n_split, s0 + per);
+  const int t = threadIdx.x, grp = t >> 6, d0 = t & 63;       // G groups x 64 lanes; lane handles d0 and d0+64
+  const int G = blockDim.x >> 6;                              // 4, 8 or 16 (combine_threads)
+  const int per = (n_split + G - 1) / G, s0 = grp * per, s1 = min(n_split, s0 + per);
   const bool two = d0 + 64 < hd;
   float m = -INFINITY, l = 0.f, a0 = 0.f, a1 = 0.f;
 #pragma unroll 4
@@ -980,11 +987,12 @@ __global__ void __launch_bounds__(256) k_attn_combine2(const float* __restrict__
   if (two) part[grp][d0 + 64] = a1;
   __syncthreads();
   if (t < hd) {
-    const float M = fmaxf(fmaxf(pm[0], pm[1]), fmaxf(pm[2], pm[3]));
+    float M = pm[0];
+    for (int k = 1; k < G; ++k) M = fmaxf(M, pm[k]);
     const float Mu = M == -INFINITY ? 0.f : M;
     float acc = 0.f, lsum = 0.f;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
+#pragma unroll 4
+    for (int k = 0; k < G; ++k) {
       const float c = __builtin_amdgcn_exp2f(pm[k] - Mu);
       acc += c * part[k][t];
       lsum += c * pl[k];
@@ -1035,7 +1043,7 @@ extern "C" int p3v_attention_decode(const p3v_attn_decode_args_t* a, void* strea
   if (a->n_split * 64 >= a->cache_t) hipLaunchKernelGGL(k_attn_decode, grid, dim3(256), 0, s, p);
   else hipLaunchKernelGGL(k_attn_decode_stream<64>, grid, dim3(64), 0, s, p);
   P3V_CHECK_LAUNCH();
-  hipLaunchKernelGGL(k_attn_combine2, dim3(a->B * a->n_heads * a->L), dim3(256), 0, s, a->ws, a->out, a->L, a->n_heads,
+  hipLaunchKernelGGL(k_attn_combine2, dim3(a->B * a->n_heads * a->L), dim3(combine_threads(a->n_split)), 0, s, a->ws, a->out, a->L, a->n_heads,
                      a->hd, a->n_split);
   P3V_CHECK_LAUNCH();
   return P3V_OK;
@@ -1344,7 +1352,7 @@ extern "C" int p3v_attention_decode_q8(const p3v_attn_decode_q8_args_t* a, void*
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(k_attn_decode_q8, dim3(a->n_split, a->n_heads, a->B), dim3(64), 0, s, p);
   P3V_CHECK_LAUNCH();
-  hipLaunchKernelGGL(k_attn_combine2, dim3(a->B * a->n_heads * a->L), dim3(256), 0, s, a->ws, a->out, a->L, a->n_heads,
+  hipLaunchKernelGGL(k_attn_combine2, dim3(a->B * a->n_heads * a->L), dim3(combine_threads(a->n_split)), 0, s, a->ws, a->out, a->L, a->n_heads,
                      a->hd, a->n_split);
   P3V_CHECK_LAUNCH();
   return P3V_OK;

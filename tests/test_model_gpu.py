@@ -361,6 +361,32 @@ def test_c1_fixture_full_size(full_text):
     assert int(g["topi"][0, n - 1, 0]) in last
 
 
+def test_c2_fixture_full_size_vision():
+    """BASELINE config 2 = bench.py's rank-0 request (one seeded 336x336 image -> 17 CLIP crops -> 2509 image tokens,
+    2531-token prompt) at FULL size vs the oracle fixture (tests/golden/gen_golden_oracle.py c2): CLIP tower,
+    projector, HD merge, 32 decoder layers and 3 graph-replayed decode steps, same hash-seeded weights on both sides."""
+    import sys
+    sys.path.insert(0, GOLDEN)
+    from gen_golden_oracle import c2_request
+    from phi_3_vision_mlx_amd.api import load_synthetic
+    model, proc = load_synthetic(blind_model=False, tiny=False, seed=0, device="cuda:0")
+    g = np.load(GOLDEN + "/c2_oracle.npz")
+    inp = c2_request(proc.img_processor)
+    assert inp["input_ids"].shape[1] == int(g["n_ids"][0]) == 2531
+    inp["pixel_values"] = torch.from_numpy(inp["pixel_values"]).to("cuda:0")
+    ref_tok = torch.as_tensor(g["tokens"]).long()
+    n = ref_tok.shape[1]
+    logits, cache = model(**inp, max_tokens=n)
+    for step in range(n):
+        _check_topk(logits[:, -1], g["topv"][:, step], g["topi"][:, step], f"C2 step {step}", rel=6e-2)
+        top16 = logits[:, -1].float().cpu().topk(16).indices[0].tolist()
+        assert int(g["topi"][0, step, 0]) in top16, f"C2 step {step}: oracle top-1 not in the HIP top-16"
+        if step + 1 < n:
+            logits, tok = model.greedy_step(ref_tok[:, step:step + 1].to("cuda:0", torch.int32), cache)
+    del model, cache
+    torch.cuda.empty_cache()
+
+
 def test_config3_long_context_32k(full_text):
     """BASELINE config 3: 32k-token prompt (Su/LongRoPE long factors, chosen once from S+max_tokens > 4096, Q2).
     No CPU oracle can run this size; parity is checked through size-independent properties:
