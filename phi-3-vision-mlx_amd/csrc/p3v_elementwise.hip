@@ -372,15 +372,31 @@ __device__ __forceinline__ ValIdx block_argmax(ValIdx m, ValIdx* red) {
   return r;
 }
 
+// per-thread argmax over a bf16 row with 16-byte loads (all of a thread's loads are independent: one memory round
+// trip for a 32064-wide row on 1024 threads); first maximum wins
+__device__ __forceinline__ ValIdx row_argmax_partial(const bf16_t* __restrict__ r, int n) {
+  ValIdx m = {-INFINITY, 0x7fffffff};
+  auto take = [&](float v, int i) { if (v > m.v || (v == m.v && i < m.i) || m.i == 0x7fffffff) { m.v = v; m.i = i; } };
+  if ((((size_t)r) & 15) == 0) {
+    const int nv = n >> 3;
+    const u32x4_t* rv = (const u32x4_t*)r;
+#pragma unroll 4
+    for (int c = threadIdx.x; c < nv; c += blockDim.x) {
+      const u32x4_t w = rv[c];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { take(bf16lo(w[j]), 8 * c + 2 * j); take(bf16hi(w[j]), 8 * c + 2 * j + 1); }
+    }
+    for (int i = (nv << 3) + threadIdx.x; i < n; i += blockDim.x) take(bf16_to_f32(r[i]), i);
+  } else {
+    for (int i = threadIdx.x; i < n; i += blockDim.x) take(bf16_to_f32(r[i]), i);
+  }
+  return m;
+}
+
 __global__ void __launch_bounds__(1024) k_argmax(const bf16_t* __restrict__ x, int32_t* __restrict__ out, int n,
                                                  int64_t stride) {
   __shared__ ValIdx red[16];
-  const bf16_t* r = x + (size_t)blockIdx.x * stride;
-  ValIdx m = {-INFINITY, 0x7fffffff};
-  for (int i = threadIdx.x; i < n; i += blockDim.x) {
-    const float v = bf16_to_f32(r[i]);
-    if (v > m.v || (v == m.v && i < m.i) || m.i == 0x7fffffff) { m.v = v; m.i = i; }
-  }
+  ValIdx m = row_argmax_partial(x + (size_t)blockIdx.x * stride, n);
   m = block_argmax(m, red);
   if (threadIdx.x == 0) out[blockIdx.x] = m.i;
 }
@@ -512,22 +528,23 @@ __global__ void __launch_bounds__(1024) k_step_end(const bf16_t* __restrict__ lo
   __shared__ ValIdx red[16];
   const int b = blockIdx.x;
   const int s = *d_step;                     // read before this workgroup takes its ticket (the last one bumps it)
-  const bf16_t* r = logits + (size_t)b * n;
-  ValIdx m = {-INFINITY, 0x7fffffff};
-  for (int i = threadIdx.x; i < n; i += blockDim.x) {
-    const float v = bf16_to_f32(r[i]);
-    if (v > m.v || (v == m.v && i < m.i) || m.i == 0x7fffffff) { m.v = v; m.i = i; }
-  }
+  ValIdx m = row_argmax_partial(logits + (size_t)b * n, n);
   m = block_argmax(m, red);
   if (threadIdx.x == 0) {
     next_tok[b] = m.i;
     tok[b] = m.i;
     if (s < max_steps) hist[(size_t)b * max_steps + s] = m.i;
-    const int done = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-    if (done == (int)gridDim.x - 1) {        // every workgroup has read *d_step by now
+    // The counters may only move once every workgroup has READ *d_step: the read above has returned (its value was
+    // used), so a relaxed ticket is enough -- no cache write-back / invalidate (an agent-scope release costs ~20 us).
+    bool last = gridDim.x == 1;
+    if (!last) {
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      last = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1;
+    }
+    if (last) {
       *d_step = s + 1;
       *d_past += 1;
-      __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (gridDim.x > 1) __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
 }

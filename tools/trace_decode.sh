@@ -20,8 +20,8 @@ dec = rows[last_pref + 1:]
 names = [r["Kernel_Name"] for r in dec]
 per_step = None
 for i, n in enumerate(names):
-    if "k_store_token" in n:
-        idx = [j for j, m in enumerate(names) if "k_store_token" in m]
+    if "k_step_end" in n or "k_store_token" in n:
+        idx = [j for j, m in enumerate(names) if "k_step_end" in m or "k_store_token" in m]
         break
 steps = [(idx[k] + 1, idx[k + 1] + 1) for k in range(len(idx) - 1)]
 steps = steps[4:]          # skip warm-up + early replays
