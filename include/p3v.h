@@ -218,6 +218,17 @@ int p3v_log_softmax(const uint16_t* x, uint16_t* y, int rows, int n, void* strea
 /* ---- top-k (k<=8) by (-value, index), replaces mx.argpartition phi_3_vision_mlx.py:507 */
 int p3v_topk(const uint16_t* x, int32_t* idx_out, int rows, int n, int k, int64_t row_stride, void* stream);
 
+/* ---- LoRA adapter inference, LoRALinear.__call__ (phi.py:129-133):
+ *   y = linear(x); z = (x @ lora_a) @ lora_b; out = (y + scale*z).astype(bf16),  scale = cfg.scale * alpha / rank (phi.py:120)
+ * lora_a [K, r] and lora_b [r, N] are the fp32 tensors of adapters.safetensors, r <= 64.
+ * p3v_lora_down: t[M, r] (f32) = x[M, K] (bf16) @ lora_a.
+ * p3v_lora_up:   v = bf16(y + scale * (t @ lora_b)) with y[M, N] the frozen projection's plain bf16 output, then the
+ *   epilogue that projection would have carried: P3V_EPI_NONE out[M,N] = v; P3V_EPI_RESID_BF16 out = resid + v;
+ *   P3V_EPI_SILU_MUL (N = 2*I, gate rows first) out[M, I] = silu(v[:, :I]) * v[:, I:]. */
+int p3v_lora_down(const uint16_t* x, const float* lora_a, float* t, int M, int K, int r, void* stream);
+int p3v_lora_up(const uint16_t* y, const float* t, const float* lora_b, float scale, int epilogue,
+                const uint16_t* resid, uint16_t* out, int M, int N, int r, void* stream);
+
 /* ---- decode-step helpers (device-resident loop state for graph replay) */
 int p3v_add_i32(int32_t* x, int n, int delta, void* stream);
 /* history[b, *d_step] = tok[b]; if tok_next != NULL also tok_next[b] = tok[b] (feeds the next replayed step) */

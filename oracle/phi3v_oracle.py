@@ -144,9 +144,12 @@ def masked_softmax(w, allowed):
 class OraclePhi3V:
     """Phi3VForCausalLM / Phi3ForCausalLM (phi.py:565-617) on CPU."""
 
-    def __init__(self, cfg, weights, cache_fp32=False):
+    def __init__(self, cfg, weights, cache_fp32=False, adapters=None):
+        """adapters: {"model.layers.<i>.<target>.weight": (lora_a [in,r] f32, lora_b [r,out] f32, scale)} --
+        the LoRA layers `_linear_to_lora_layers` would install (phi_3_vision_mlx.py:234-245)."""
         self.cfg = cfg
         self.w = weights
+        self.adapters = adapters or {}
         self._f32 = {} if cache_fp32 else None
         self.vision = cfg.architectures[0].startswith("Phi3V")
         self._masker = None
@@ -162,6 +165,17 @@ class OraclePhi3V:
         if t is None:
             t = self._f32[name] = self.w[name].to(F32)
         return t
+
+    def proj(self, x, name):
+        """nn.Linear, or LoRALinear.__call__ (phi.py:129-133) when the projection carries an adapter:
+        y = linear(x); z = (x @ lora_a) @ lora_b  (fp32 by promotion); (y + scale * z).astype(x.dtype)."""
+        y = _linear(x, self.W(name))
+        ad = self.adapters.get(name)
+        if ad is None:
+            return y
+        a, b, scale = ad
+        z = (x.to(F32) @ a.to(F32)) @ b.to(F32)
+        return (y.to(F32) + scale * z).to(x.dtype)
 
     # -- vision tower (phi.py:135-221) ------------------------------------
     def clip_embeddings(self, x_nchw):
@@ -248,7 +262,7 @@ class OraclePhi3V:
         nh, nkv = cfg.num_attention_heads, cfg.num_key_value_heads
         hd = cfg.hidden_size // nh
         B, L, _ = x.shape
-        qkv = _linear(x, self.W(p + "qkv_proj.weight"))
+        qkv = self.proj(x, p + "qkv_proj.weight")
         q, k, v = torch.split(qkv, [nh * hd, nkv * hd, nkv * hd], dim=-1)
         q = q.reshape(B, L, nh, -1).transpose(1, 2)
         k = k.reshape(B, L, nkv, -1).transpose(1, 2)
@@ -264,15 +278,15 @@ class OraclePhi3V:
         w = masked_softmax(w, allowed)
         o = w @ v.to(F32)
         o = o.transpose(1, 2).reshape(B, L, -1)
-        return _linear(o, self.W(p + "o_proj.weight")).to(qkv.dtype)
+        return self.proj(o, p + "o_proj.weight").to(qkv.dtype)
 
     def mlp(self, x, i):
         """Phi3MLP.__call__ (phi.py:468-471); nn.silu on bf16, per-op bf16 rounding."""
         p = f"model.layers.{i}.mlp."
-        y = _linear(x, self.W(p + "gate_up_proj.weight"))
+        y = self.proj(x, p + "gate_up_proj.weight")
         gate, up = torch.chunk(y, 2, dim=-1)
         act = gate * torch.sigmoid(gate)
-        return _linear(act * up, self.W(p + "down_proj.weight"))
+        return self.proj(act * up, p + "down_proj.weight")
 
     def decoder_layer(self, x, i, cache, cos, sin, allowed, n_beam):
         """Phi3DecoderLayer.__call__ (phi.py:481-485)."""

@@ -10,8 +10,9 @@ Host code stays Python; everything that touches the device goes through
 
 `quantize_cache=True` selects the int8 KV cache and `quantize_model=True` fp8 (e4m3) decoder weights -- the build's
 analogues of the reference's 4-bit prompt cache / int4 weights (BASELINE config 5).
-Not carried over (out of scope): LoRA adapters
-(`use_adapter=True` raises NotImplementedError), the `<|api_input|>` tool hook,
+`use_adapter=True` attaches the LoRA adapter of `adapters/<model dir name>` (or `adapter_path=...`) at inference
+(reference phi_3_vision_mlx.py:266-271); training adapters is not part of this build.
+Not carried over (out of scope): the `<|api_input|>` tool hook,
 HF-hub download (`_setup`): a model directory must exist locally, or pass
 `synthetic=...` to `load()` for seeded random weights of the real architecture.
 """
@@ -28,7 +29,7 @@ import torch
 from . import ops as model_ops
 from .config import is_vision, load_config, make_config, phi3v_config_dict, tiny_config_dict
 from .processor import Phi3FProcessor, Phi3VProcessor
-from .weights import load_safetensors_dir, synth_weights
+from .weights import load_adapter, load_safetensors_dir, resolve_adapter, synth_weights
 
 PATH_ADAPTERS = "adapters"
 PATH_ORIGINAL_PHI3_VISION = "models/phi3_v"
@@ -208,24 +209,40 @@ def _load(model_path=PATH_ORIGINAL_PHI3_VISION, adapter_path=None, return_mx=Tru
     """reference phi_3_vision_mlx.py:257-274: config -> model class by `architectures[0]`,
     HF safetensors -> device weights."""
     from .model import Phi3VModel
-    if adapter_path:
-        raise NotImplementedError("LoRA adapters are outside the inference hot path of this build")
     cfg = _get_cfg(f"{model_path}/config.json", **kwargs)
     if getattr(cfg, "quantized", False):
         raise NotImplementedError("MLX int4 checkpoints are not supported (SURVEY.md section 8f item 4)")
     processor = _make_processor(cfg, model_path, return_mx)
     device = device or f"cuda:{torch.cuda.current_device()}"
     model = Phi3VModel(cfg, load_safetensors_dir(model_path, cfg, device="cpu"), device=device)
+    if adapter_path:
+        _attach_adapter(model, adapter_path, model_path)
     return model, processor
 
 
-def load_synthetic(blind_model=False, tiny=False, seed=0, device=None, std_scale=1.0, **kwargs):
+def _get_adapter_path(model_path):
+    """reference phi_3_vision_mlx.py:462-464."""
+    print(f"{PATH_ADAPTERS}/{Path(model_path).name}")
+    return f"{PATH_ADAPTERS}/{Path(model_path).name}"
+
+
+def _attach_adapter(model, adapter_path, model_path=None):
+    """reference phi_3_vision_mlx.py:266-271: adapter_config.json -> LoRA layers, adapters.safetensors -> their weights."""
+    lora_cfg, tensors = load_adapter(adapter_path)
+    if model_path is not None and lora_cfg.get("model_path") != model_path:
+        print(f"WARNING: LoRA trained for {lora_cfg.get('model_path')} is being used with {model_path}")
+    model.set_adapters(resolve_adapter(model.cfg, lora_cfg, tensors))
+
+
+def load_synthetic(blind_model=False, tiny=False, seed=0, device=None, std_scale=1.0, adapter_path=None, **kwargs):
     """Seeded random weights of the real (or tiny) architecture -- no checkpoint needed."""
     from .model import Phi3VModel
     d = tiny_config_dict(vision=not blind_model) if tiny else phi3v_config_dict(vision=not blind_model)
     cfg = make_config(d, **kwargs)
     device = device or f"cuda:{torch.cuda.current_device()}"
     model = Phi3VModel(cfg, synth_weights(cfg, seed=seed, device=device, std_scale=std_scale), device=device)
+    if adapter_path:
+        _attach_adapter(model, adapter_path)
     return model, _make_processor(cfg, None)
 
 
@@ -233,17 +250,19 @@ def load(blind_model=False, quantize_model=False, quantize_cache=False, use_adap
     """reference phi_3_vision_mlx.py:1279-1322.  Extra: `synthetic=True|'tiny'` builds seeded
     random weights instead of reading `models/...` (there is no hub access here)."""
     synthetic = kwargs.pop("synthetic", None)
-    if use_adapter:
-        raise NotImplementedError("use_adapter=True: LoRA is outside the inference hot path of this build")
+    adapter_path = kwargs.pop("adapter_path", None)
+    model_path = kwargs.pop("model_path", None) or (PATH_ORIGINAL_PHI3_BLIND if blind_model else PATH_ORIGINAL_PHI3_VISION)
+    if use_adapter and adapter_path is None:
+        adapter_path = _get_adapter_path(model_path)                                   # reference :1316-1317
     if synthetic:
         return load_synthetic(blind_model=blind_model, tiny=(synthetic == "tiny"), use_quantized_cache=quantize_cache,
-                              quantized_fp8=quantize_model, **kwargs)
-    model_path = kwargs.pop("model_path", None) or (PATH_ORIGINAL_PHI3_BLIND if blind_model else PATH_ORIGINAL_PHI3_VISION)
+                              quantized_fp8=quantize_model, adapter_path=adapter_path if use_adapter else None, **kwargs)
     if not os.path.exists(model_path):
         raise FileNotFoundError(
             f"model directory {model_path!r} not found and this build cannot download checkpoints; "
             "place HF-layout safetensors + config.json there, or use load(synthetic=True)")
-    return _load(model_path=model_path, use_quantized_cache=quantize_cache, quantized_fp8=quantize_model, adapter_path=None, **kwargs)
+    return _load(model_path=model_path, use_quantized_cache=quantize_cache, quantized_fp8=quantize_model,
+                 adapter_path=adapter_path if use_adapter else None, **kwargs)
 
 
 # ----------------------------------------------------------------------------- generate

@@ -94,6 +94,8 @@ class Phi3VModel:
             raise ValueError(f"decoder head_dim must be 96 (got {self.hd})")
         self._state = None
         self.w8 = {}
+        self.adapters = {}                           # weight key -> (lora_a, lora_b, scale), see set_adapters
+        self._lora_tmp = {}
         if getattr(cfg, "quantized_fp8", False):
             self._quantize_decoder_fp8()
         if self.vision:
@@ -109,8 +111,47 @@ class Phi3VModel:
         n_max = max(v[0].shape[0] * v[0].shape[1] for v in self.w8.values())
         self._deq = torch.empty(n_max, dtype=BF16, device=self.device)      # one dequantised matrix (prefill GEMM scratch)
 
+    # ------------------------------------------------------------------ LoRA adapters (use_adapter=True)
+    def set_adapters(self, adapters):
+        """Attach LoRA adapters: {"model.layers.<i>.<target>.weight": (lora_a [in,r] f32, lora_b [r,out] f32, scale)}
+        (weights.resolve_adapter).  An adapted projection runs unfused: materialised RMSNorm -> frozen projection with a
+        plain epilogue -> p3v_lora_down / p3v_lora_up, which carries the residual / SiLU*up epilogue (phi.py:129-133)."""
+        for k, (a, b, _) in adapters.items():
+            w = self.w.get(k)
+            shape = w.shape if w is not None else self.w8[k][0].shape
+            if tuple(a.shape[:1]) != (shape[1],) or tuple(b.shape[1:]) != (shape[0],):
+                raise ValueError(f"LoRA shapes {tuple(a.shape)} x {tuple(b.shape)} do not fit {k} {tuple(shape)}")
+        self.adapters = {k: (a.to(self.device, F32).contiguous(), b.to(self.device, F32).contiguous(), float(s))
+                         for k, (a, b, s) in adapters.items()}
+        self._lora_tmp = {}
+        if self._state is not None:
+            self._state.graphs.clear()               # captured decode graphs bake the kernel sequence in
+
     def _proj(self, x, key, epilogue=EPI_NONE, resid=None, norm_w=None, out=None, h=None):
-        """One projection of the decoder: weight-streaming kernel for skinny x, MFMA GEMM otherwise; bf16 or fp8 weights."""
+        """One projection of the decoder (+ its LoRA adapter, if one is attached)."""
+        ad = self.adapters.get(key)
+        if ad is None:
+            return self._proj_frozen(x, key, epilogue, resid, norm_w, out, h)
+        a, b, scale = ad
+        M, N = x.shape[0], b.shape[1]
+        if norm_w is not None:                                  # the adapter needs the normalised input itself
+            tmp = self._lora_tmp.get(("h", M))
+            if tmp is None:
+                tmp = self._lora_tmp[("h", M)] = torch.empty_like(x)
+            x = ops.rmsnorm(x, norm_w, self.cfg.rms_norm_eps, out=tmp)
+        y = self._lora_tmp.get(("y", M, N))
+        if y is None:
+            y = self._lora_tmp[("y", M, N)] = torch.empty((M, N), dtype=BF16, device=self.device)
+            self._lora_tmp[("t", M, a.shape[1])] = torch.empty((M, a.shape[1]), dtype=F32, device=self.device)
+        t = self._lora_tmp.get(("t", M, a.shape[1]))
+        if t is None:
+            t = self._lora_tmp[("t", M, a.shape[1])] = torch.empty((M, a.shape[1]), dtype=F32, device=self.device)
+        self._proj_frozen(x, key, EPI_NONE, None, None, y, None)
+        ops.lora_down(x, a, out=t)
+        return ops.lora_up(y, t, b, scale, epilogue, resid=resid, out=out)
+
+    def _proj_frozen(self, x, key, epilogue=EPI_NONE, resid=None, norm_w=None, out=None, h=None):
+        """Weight-streaming kernel for skinny x, MFMA GEMM otherwise; bf16 or fp8 weights."""
         eps = self.cfg.rms_norm_eps
         M, K = x.shape
         q = self.w8.get(key)

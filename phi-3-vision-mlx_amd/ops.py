@@ -105,6 +105,29 @@ def gemv(x, w, epilogue=EPI_NONE, resid=None, norm_w=None, norm_eps=0.0, out=Non
     return out
 
 
+def lora_down(x, lora_a, out=None):
+    """t = x @ lora_a  (first half of LoRALinear.__call__, phi.py:131): x [M,K] bf16, lora_a [K,r] f32 -> [M,r] f32."""
+    _chk(x, BF16, "x"), _chk(lora_a, F32, "lora_a")
+    M, K = x.shape
+    r = lora_a.shape[1]
+    if out is None:
+        out = torch.empty((M, r), dtype=F32, device=x.device)
+    L.check(L.lib().p3v_lora_down(_p(x), _p(lora_a), _p(out), M, K, r, _stream()), "lora_down")
+    return out
+
+
+def lora_up(y, t, lora_b, scale, epilogue=EPI_NONE, resid=None, out=None):
+    """out = epilogue((y + scale * (t @ lora_b)).astype(bf16))  (phi.py:131-133): y [M,N] bf16 (frozen projection),
+    t [M,r] f32, lora_b [r,N] f32.  epilogue: EPI_NONE / EPI_RESID_BF16 / EPI_SILU_MUL (out [M, N/2])."""
+    _chk(y, BF16, "y"), _chk(t, F32, "t"), _chk(lora_b, F32, "lora_b")
+    M, N = y.shape
+    r = lora_b.shape[0]
+    if out is None:
+        out = torch.empty((M, N // 2 if epilogue == EPI_SILU_MUL else N), dtype=BF16, device=y.device)
+    L.check(L.lib().p3v_lora_up(_p(y), _p(t), _p(lora_b), float(scale), epilogue, _p(resid), _p(out), M, N, r, _stream()), "lora_up")
+    return out
+
+
 def quantize_fp8_rows(w):
     """bf16 [N,K] -> (u8 e4m3fn bit patterns [N,K], fp32 scale [N]); w ~ fp8 * scale.  Load-time weight prep."""
     wf = w.float()

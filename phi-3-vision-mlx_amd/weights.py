@@ -9,6 +9,7 @@ integer/fp32 torch ops only so the same values come out on any device.  It is
 data generation for tests/bench, not part of the compute path.
 """
 import glob
+import os
 import zlib
 
 import torch
@@ -151,3 +152,61 @@ def save_safetensors_dir(weights, cfg_dict, model_path):
     save_file({k: v.detach().cpu().contiguous() for k, v in weights.items()}, f"{model_path}/model.safetensors")
     with open(f"{model_path}/config.json", "w") as f:
         json.dump(cfg_dict, f, indent=1)
+
+
+# ---------------------------------------------------------------- LoRA adapters (phi_3_vision_mlx.py:234-245, 266-271)
+ADAPTER_CONFIG, ADAPTER_WEIGHTS = "adapter_config.json", "adapters.safetensors"
+
+
+def save_adapter(path, lora_cfg, tensors):
+    """Write `adapter_config.json` + `adapters.safetensors` in the reference's format (phi.py:56,61):
+    lora_cfg = {model_path, adapter_path, lora_layers (int = last n | list of indices), lora_targets (module names
+    inside a decoder layer, e.g. "self_attn.qkv_proj"), lora_parameters {rank, alpha, dropout, scale}};
+    tensors = {"model.layers.<i>.<target>.lora_a": [in, r] f32, "...lora_b": [r, out] f32}."""
+    import json
+    from safetensors.torch import save_file
+    os.makedirs(path, exist_ok=True)
+    with open(os.path.join(path, ADAPTER_CONFIG), "w") as f:
+        json.dump(lora_cfg, f, indent=4)
+    save_file({k: v.detach().cpu().contiguous() for k, v in tensors.items()}, os.path.join(path, ADAPTER_WEIGHTS))
+
+
+def load_adapter(path):
+    """-> (lora_cfg dict, {name: tensor}) from an adapter directory; FileNotFoundError like the reference's
+    `_get_cfg` / `load_weights` when either file is missing."""
+    import json
+    from safetensors.torch import load_file
+    cfg_file, wt_file = os.path.join(path, ADAPTER_CONFIG), os.path.join(path, ADAPTER_WEIGHTS)
+    for f in (cfg_file, wt_file):
+        if not os.path.exists(f):
+            raise FileNotFoundError(f)
+    with open(cfg_file) as f:
+        lora_cfg = json.load(f)
+    return lora_cfg, load_file(wt_file)
+
+
+def resolve_adapter(cfg, lora_cfg, tensors, device="cpu"):
+    """`_linear_to_lora_layers` (phi_3_vision_mlx.py:234-245) + `load_weights(strict=False)` (:271):
+    -> {"model.layers.<i>.<target>.weight": (lora_a [in,r] f32, lora_b [r,out] f32, scale)} for every adapted projection.
+    lora_layers int n = the LAST n decoder layers, list = layer indices; scale = cfg.scale * alpha / rank (phi.py:120).
+    A LoRA layer whose tensors are absent from the file keeps its initial lora_b = 0, i.e. is an identity: skipped."""
+    n_layers = cfg.num_hidden_layers
+    layers = lora_cfg["lora_layers"]
+    if isinstance(layers, int):
+        idx = list(range(n_layers))[-layers:] if layers > 0 else []
+    elif isinstance(layers, list):
+        idx = [i % n_layers for i in layers]
+    else:
+        raise ValueError("Invalid type for lora_layers. Expected int (number of layers) or list (layer indices or names).")
+    prm = lora_cfg["lora_parameters"]
+    scale = float(prm["scale"]) * (float(prm["alpha"]) / float(prm["rank"]))
+    out = {}
+    for i in idx:
+        for tgt in lora_cfg["lora_targets"]:
+            a, b = tensors.get(f"model.layers.{i}.{tgt}.lora_a"), tensors.get(f"model.layers.{i}.{tgt}.lora_b")
+            if a is None or b is None:
+                continue
+            if a.shape[1] != b.shape[0] or a.shape[1] > 64:
+                raise ValueError(f"unsupported LoRA shapes for layer {i} {tgt}: {tuple(a.shape)} x {tuple(b.shape)} (rank <= 64)")
+            out[f"model.layers.{i}.{tgt}.weight"] = (a.to(device, torch.float32).contiguous(), b.to(device, torch.float32).contiguous(), scale)
+    return out

@@ -105,12 +105,15 @@ def test_safetensors_roundtrip_and_loader_errors(tmp_path):
         load_safetensors_dir(str(tmp_path / "m2"), cfg2)
 
 
-def test_load_rejects_out_of_scope_variants():
+def test_load_error_behaviour():
+    """Missing model / adapter directories raise FileNotFoundError (the reference fails in _get_cfg / load_weights);
+    use_adapter=True resolves adapters/<model dir name> as phi_3_vision_mlx.py:462-464,1316-1317."""
     from phi_3_vision_mlx_amd import api
-    with pytest.raises(NotImplementedError):
-        api.load(use_adapter=True)
     with pytest.raises(FileNotFoundError):
         api.load(model_path="/definitely/not/here")
+    with pytest.raises(FileNotFoundError):
+        api.load(use_adapter=True, model_path="/definitely/not/here")
+    assert api._get_adapter_path("models/phi3_v") == "adapters/phi3_v"
 
 
 def test_shim_exports_reference_api():
@@ -128,3 +131,51 @@ def test_shim_exports_reference_api():
     assert inspect.signature(m.generate).parameters["max_tokens"].default == 512
     assert inspect.signature(m.constrain).parameters["constraints"].default == [(0, "\nThe"), (100, " The correct answer is"), "ABCDE"]
     assert m.ID_EOS == 32007 and m.ID_ASS == 32001
+
+
+def test_adapter_files_round_trip_and_layer_selection(tmp_path):
+    """adapter_config.json / adapters.safetensors in the reference's format (phi.py:56,61; phi_3_vision_mlx.py:234-245,
+    1005-1012): int lora_layers = the LAST n layers, list = indices, scale = scale * alpha / rank, missing tensors = identity."""
+    import torch
+    from phi_3_vision_mlx_amd.config import make_config, tiny_config_dict
+    from phi_3_vision_mlx_amd.weights import load_adapter, resolve_adapter, save_adapter
+    cfg = make_config(tiny_config_dict(vision=False))
+    H, nl = cfg.hidden_size, cfg.num_hidden_layers
+    t = {f"model.layers.{i}.self_attn.qkv_proj.lora_a": torch.randn(H, 2) for i in range(nl)}
+    t.update({f"model.layers.{i}.self_attn.qkv_proj.lora_b": torch.randn(2, 3 * H) for i in range(nl)})
+    lora_cfg = {"model_path": "m", "adapter_path": "a", "lora_layers": 1, "lora_targets": ["self_attn.qkv_proj", "mlp.down_proj"],
+                "lora_parameters": {"rank": 2, "alpha": 4, "dropout": 0.0, "scale": 10.0}}
+    save_adapter(str(tmp_path / "ad"), lora_cfg, t)
+    got_cfg, got_t = load_adapter(str(tmp_path / "ad"))
+    assert got_cfg == lora_cfg and set(got_t) == set(t)
+    ad = resolve_adapter(cfg, got_cfg, got_t)
+    assert list(ad) == [f"model.layers.{nl - 1}.self_attn.qkv_proj.weight"]      # last layer only; down_proj has no tensors
+    a, b, scale = ad[f"model.layers.{nl - 1}.self_attn.qkv_proj.weight"]
+    assert scale == 20.0 and a.dtype == torch.float32 and torch.equal(a, t[f"model.layers.{nl - 1}.self_attn.qkv_proj.lora_a"])
+    got_cfg["lora_layers"] = [0]
+    assert list(resolve_adapter(cfg, got_cfg, got_t)) == ["model.layers.0.self_attn.qkv_proj.weight"]
+    got_cfg["lora_layers"] = "all"
+    with pytest.raises(ValueError):
+        resolve_adapter(cfg, got_cfg, got_t)
+    with pytest.raises(FileNotFoundError):
+        load_adapter(str(tmp_path / "missing"))
+
+
+def test_oracle_lora_is_the_reference_formula():
+    """OraclePhi3V.proj == LoRALinear.__call__ (phi.py:129-133) and reduces to nn.Linear when lora_b = 0 (its init)."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import torch
+    import phi3v_oracle as orc
+    from phi_3_vision_mlx_amd.config import make_config, tiny_config_dict
+    cfg = make_config(tiny_config_dict(vision=False))
+    g = torch.Generator().manual_seed(0)
+    w = {"w": (torch.randn(24, 16, generator=g) * 0.3).to(torch.bfloat16)}
+    x = torch.randn(3, 16, generator=g).to(torch.bfloat16)
+    a, b = torch.randn(16, 4, generator=g), torch.randn(4, 24, generator=g)
+    o = orc.OraclePhi3V(cfg, w, adapters={"w": (a, b, 0.5)})
+    y = (x.float() @ w["w"].float().t()).to(torch.bfloat16)
+    want = (y.float() + 0.5 * ((x.float() @ a) @ b)).to(torch.bfloat16)
+    assert torch.equal(o.proj(x, "w"), want)
+    o0 = orc.OraclePhi3V(cfg, w, adapters={"w": (a, torch.zeros_like(b), 0.5)})
+    assert torch.equal(o0.proj(x, "w"), y)

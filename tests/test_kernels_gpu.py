@@ -458,3 +458,22 @@ def test_step_begin_end_match_separate_kernels(ops, B):
         want.append(ref.clone())
         assert d_step.item() == s + 1 and d_past.item() == 12 + s and ticket.item() == 0
     assert torch.equal(hist, torch.stack(want[:steps], dim=1))
+
+
+@pytest.mark.parametrize("M,K,N,r", [(1, 3072, 9216, 1), (5, 192, 576, 8), (300, 256, 512, 20)])
+def test_lora_down_up(ops, M, K, N, r):
+    """p3v_lora_down / p3v_lora_up vs LoRALinear.__call__ (phi.py:129-133) in fp32, all three fused epilogues."""
+    from phi_3_vision_mlx_amd.ops import EPI_NONE, EPI_RESID_BF16, EPI_SILU_MUL
+    x, y, res = g((M, K), 100), g((M, N), 101), g((M, N), 102)
+    a = torch.randn((K, r), generator=torch.Generator().manual_seed(103)) * K ** -0.5
+    b = torch.randn((r, N), generator=torch.Generator().manual_seed(104)) * 0.5
+    scale = 1.7
+    t = ops.lora_down(x.cuda(), a.cuda())
+    t_ref = x.float() @ a
+    assert torch.allclose(t.cpu(), t_ref, rtol=1e-4, atol=1e-4)
+    v = (y.float() + scale * (t_ref @ b)).to(BF16)
+    close(ops.lora_up(y.cuda(), t, b.cuda(), scale, EPI_NONE), v, rtol=2 ** -7, atol=1e-2)
+    close(ops.lora_up(y.cuda(), t, b.cuda(), scale, EPI_RESID_BF16, resid=res.cuda()), (res.float() + v.float()).to(BF16), rtol=2 ** -7, atol=2e-2)
+    gate, up = v[:, :N // 2], v[:, N // 2:]
+    act = gate * torch.sigmoid(gate)
+    close(ops.lora_up(y.cuda(), t, b.cuda(), scale, EPI_SILU_MUL), act * up, rtol=2 ** -6, atol=2e-2)
