@@ -1,0 +1,77 @@
+"""The HTTP façade: reference endpoint contract (server.py:8-29) + request queue + batching."""
+import json
+import threading
+import time
+import urllib.error
+import urllib.request
+
+import pytest
+
+
+def _post(port, path, payload, raw=None):
+    data = raw if raw is not None else json.dumps(payload).encode()
+    req = urllib.request.Request(f"http://127.0.0.1:{port}{path}", data=data, headers={"Content-Type": "application/json"})
+    with urllib.request.urlopen(req, timeout=10) as r:
+        return r.status, json.loads(r.read())
+
+
+@pytest.fixture()
+def server():
+    from phi_3_vision_mlx_amd.server import serve
+    calls = []
+
+    def fake_generate(prompts, max_tokens):
+        calls.append((list(prompts), max_tokens))
+        time.sleep(0.05)                                     # long enough for concurrent requests to pile up
+        if any(p == "boom" for p in prompts):
+            raise RuntimeError("engine failure")
+        out = [f"{p}|{max_tokens}" for p in prompts]
+        return out[0] if len(out) == 1 else out              # like generate(): str for B=1, list otherwise
+
+    httpd, engine = serve(fake_generate, port=0, host="127.0.0.1")
+    t = threading.Thread(target=httpd.serve_forever, daemon=True)
+    t.start()
+    yield httpd.server_address[1], calls, engine
+    httpd.shutdown()
+    engine.close()
+
+
+def test_completions_contract(server):
+    port, calls, _ = server
+    assert _post(port, "/v1/completions", {"prompt": "Hello, world!", "max_tokens": 50}) == \
+        (200, {"model": "phi-3-vision", "responses": ["Hello, world!|50"]})
+    assert _post(port, "/v1/completions", {"prompt": ["a", "b"]})[1]["responses"] == ["a|512", "b|512"]   # default budget
+    with pytest.raises(urllib.error.HTTPError) as e:
+        _post(port, "/v1/other", {"prompt": "x"})
+    assert e.value.code == 404
+    for bad in (b"{not json", json.dumps({"prompt": 7}).encode(), json.dumps({"prompt": []}).encode()):
+        with pytest.raises(urllib.error.HTTPError) as e:
+            _post(port, "/v1/completions", None, raw=bad)
+        assert e.value.code == 400
+    with pytest.raises(urllib.error.HTTPError) as e:
+        _post(port, "/v1/completions", {"prompt": "boom"})
+    assert e.value.code == 500
+    assert _post(port, "/v1/completions", {"prompt": "still alive", "max_tokens": 3})[0] == 200
+
+
+def test_concurrent_requests_are_batched_and_routed_back(server):
+    port, calls, engine = server
+    results = {}
+
+    def worker(i, mt):
+        results[i] = _post(port, "/v1/completions", {"prompt": [f"p{i}a", f"p{i}b"], "max_tokens": mt})[1]["responses"]
+
+    _post(port, "/v1/completions", {"prompt": "warm"})        # engine busy -> the next ones queue up behind it
+    ths = [threading.Thread(target=worker, args=(i, 8 if i < 4 else 9)) for i in range(6)]
+    blocker = threading.Thread(target=worker, args=(99, 7))
+    blocker.start()
+    time.sleep(0.01)
+    [t.start() for t in ths]
+    [t.join() for t in ths + [blocker]]
+    for i in range(6):
+        mt = 8 if i < 4 else 9
+        assert results[i] == [f"p{i}a|{mt}", f"p{i}b|{mt}"]      # every request got exactly its own texts
+    assert max(engine.batches) >= 4                             # same-budget requests were merged into one call
+    want_mt = {f"p{i}{s}": (8 if i < 4 else 9) for i in range(6) for s in "ab"} | {"p99a": 7, "p99b": 7, "warm": 512}
+    for prompts, mt in calls:                                   # a batch never mixes budgets
+        assert all(want_mt[p] == mt for p in prompts), (prompts, mt)
