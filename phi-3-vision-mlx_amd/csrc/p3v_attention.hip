@@ -28,6 +28,36 @@ struct AttnP {
   float scale;
 };
 
+// cross-row all-reduce over the four 16-lane rows of a wave (lanes sharing lane & 15), on gfx950's
+// v_permlane{16,32}_swap: swap(x, x) leaves {row r, row r^1} pairs in the two results, so one max / add finishes a
+// butterfly step without the LDS crossbar latency of ds_bpermute.
+// (The two integer results pass through an empty asm before they are reinterpreted as floats: hipcc 7.2 otherwise
+// folds bitcast(result 1) into bitcast(result 0).)
+__device__ __forceinline__ void rows_swap32(float v, float& a, float& b) {
+  const unsigned u = __builtin_bit_cast(unsigned, v);
+  auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  unsigned x = r[0], y = r[1];
+  asm("" : "+v"(x), "+v"(y));
+  a = __builtin_bit_cast(float, x); b = __builtin_bit_cast(float, y);
+}
+__device__ __forceinline__ void rows_swap16(float v, float& a, float& b) {
+  const unsigned u = __builtin_bit_cast(unsigned, v);
+  auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  unsigned x = r[0], y = r[1];
+  asm("" : "+v"(x), "+v"(y));
+  a = __builtin_bit_cast(float, x); b = __builtin_bit_cast(float, y);
+}
+__device__ __forceinline__ float rows_max(float v) {
+  float a, b;
+  rows_swap32(v, a, b); v = fmaxf(a, b);
+  rows_swap16(v, a, b); return fmaxf(a, b);
+}
+__device__ __forceinline__ float rows_sum(float v) {
+  float a, b;
+  rows_swap32(v, a, b); v = a + b;
+  rows_swap16(v, a, b); return a + b;
+}
+
 template <int HD>
 __global__ void __launch_bounds__(256) k_attn(AttnP p) {
   constexpr int KSTR = HD * 2 + 16;        // bytes per K row in LDS (padded: conflict-free b128 fragment reads)
@@ -143,8 +173,7 @@ __global__ void __launch_bounds__(256) k_attn(AttnP p) {
         s[st][r] = v;
         m_t = fmaxf(m_t, v);
       }
-    m_t = fmaxf(m_t, __shfl_xor(m_t, 16, 64));
-    m_t = fmaxf(m_t, __shfl_xor(m_t, 32, 64));
+    m_t = rows_max(m_t);
     const float m_new = fmaxf(m_run, m_t);
     const float m_use = m_new == -INFINITY ? 0.f : m_new;
     const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);       // m_run = -inf -> 0
@@ -157,8 +186,7 @@ __global__ void __launch_bounds__(256) k_attn(AttnP p) {
         s[st][r] = e;
         l_t += e;
       }
-    l_t += __shfl_xor(l_t, 16, 64);
-    l_t += __shfl_xor(l_t, 32, 64);
+    l_t = rows_sum(l_t);
     l_run = l_run * alpha + l_t;
     m_run = m_new;
 #pragma unroll
@@ -347,8 +375,7 @@ __global__ void __launch_bounds__(256, 2) k_attn_prefill(AttnP p) {
               m_t = fmaxf(m_t, v);
             }
         }
-        m_t = fmaxf(m_t, __shfl_xor(m_t, 16, 64));
-        m_t = fmaxf(m_t, __shfl_xor(m_t, 32, 64));
+        m_t = rows_max(m_t);
         // running max / exponentials in the log2 domain: exp(x*scale - m) = exp2(x*c - m2), c = scale*log2(e)
         const float m_new = fmaxf(m_run[u], m_t * sc2);
         const float m_use = m_new == -INFINITY ? 0.f : m_new;
@@ -362,8 +389,7 @@ __global__ void __launch_bounds__(256, 2) k_attn_prefill(AttnP p) {
             s[u][st][r] = e;
             l_t += e;
           }
-        l_t += __shfl_xor(l_t, 16, 64);
-        l_t += __shfl_xor(l_t, 32, 64);
+        l_t = rows_sum(l_t);
         l_run[u] = l_run[u] * alpha + l_t;
         m_run[u] = m_new;
         if (!__all(alpha == 1.f)) {
@@ -410,6 +436,200 @@ __global__ void __launch_bounds__(256, 2) k_attn_prefill(AttnP p) {
   }
 }
 
+// Prefill / CLIP attention over a cache whose capacity is a multiple of 64 (every caller in the model): the K tile
+// (64 rows x 2*HD bytes, contiguous) and the V^T tile (HD rows x 128 bytes) go HBM/L2 -> LDS by LDS-DMA, each wave
+// issuing a quarter of the tile's 1 KiB pieces -- no staging registers, no ds_write pass, no per-tile address
+// arithmetic (k_attn_prefill spends most of its issue slots there).  Bank-conflict swizzles on the source side:
+//   192-byte K rows (HD = 96): chunk c ^ ((row >> 2) & 3);   128-byte rows (K at HD = 64, V^T): chunk c ^ ((row >> 1) & 7).
+// Two LDS buffers, one barrier per tile; compute part and masks identical to k_attn_prefill.
+typedef const __attribute__((address_space(1))) void* pf_gptr_t;
+typedef __attribute__((address_space(3))) void* pf_lptr_t;
+template <int HD>
+__global__ void __launch_bounds__(256, 2) k_attn_prefill_dma(AttnP p) {
+  constexpr int KROW = HD * 2, VROW = 128, NKS = HD / 32, NDT = HD / 16, CPR = HD / 8;
+  constexpr int KTILE = 64 * KROW, VTILE = HD * VROW, BUF = KTILE + VTILE;
+  constexpr int NK = KTILE / 1024, NV = VTILE / 1024;         // 1 KiB DMA pieces per tile (K, V^T); NK % 4 == NV % 4 == 0
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, qi = lane & 15;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // grid (heads, query blocks, B) with the query blocks walked from the LAST one down: under a causal mask block i costs
+  // i+1 tiles, so the dispatcher sees the longest jobs first and the tail of the launch is made of the short ones
+  const int b = blockIdx.z, head = blockIdx.x, kvh = head / (p.nh / p.nkv);
+  const int past = p.d_past ? *p.d_past : p.past;
+  const int total = past + p.L;
+  const int pad = p.pad_len ? p.pad_len[b / p.pad_div] : 0;
+  const int qb0 = (gridDim.y - 1 - blockIdx.y) * 128, q0 = qb0 + wave * 32;
+  const int kv_end = p.causal ? min(total, past + qb0 + 128) : total;
+  const int kv_begin = pad & ~63;
+  const int wave_last = p.causal ? past + q0 + 31 : total;  // last key position this wave can see
+  const float sc2 = p.scale * 1.4426950408889634f;          // scale * log2(e)
+
+  bf16x8_t qf[2][NKS];
+  int qpos[2];
+  bool qvalid[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int qrow = q0 + u * 16 + qi;
+    qvalid[u] = qrow < p.L;
+    qpos[u] = past + qrow;
+    const bf16_t* qp = p.q + (((size_t)b * p.nh + head) * p.L + (qvalid[u] ? qrow : 0)) * HD + 8 * g;
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+      u32x4_t v = *(const u32x4_t*)(qp + 32 * ks);
+      if (!qvalid[u]) v = (u32x4_t){0, 0, 0, 0};
+      qf[u][ks] = __builtin_bit_cast(bf16x8_t, v);
+    }
+  }
+  const unsigned char* kbase = (const unsigned char*)(p.k_past + ((size_t)(b / p.past_div) * p.nkv + kvh) * (size_t)p.past_t * HD);
+  const unsigned char* vbase = (const unsigned char*)(p.v_past + ((size_t)(b / p.past_div) * p.nkv + kvh) * (size_t)HD * p.past_t);
+
+  // ---- per-lane DMA source offsets of this wave's pieces (piece j = wave + 4*jj covers LDS slots 64j .. 64j+63)
+  unsigned koff[NK / 4];
+#pragma unroll
+  for (int jj = 0; jj < NK / 4; ++jj) {
+    const int i = (wave + 4 * jj) * 64 + lane, row = i / CPR, pc = i - row * CPR;
+    const int sw = HD == 96 ? (row >> 2) & 3 : (row >> 1) & 7;
+    koff[jj] = row * KROW + ((pc ^ sw) << 4);
+  }
+  const size_t vrow = (size_t)p.past_t * 2;
+  size_t voff[NV / 4];
+#pragma unroll
+  for (int jj = 0; jj < NV / 4; ++jj) {
+    const int i = (wave + 4 * jj) * 64 + lane, row = i >> 3, pc = i & 7;
+    voff[jj] = (size_t)row * vrow + ((pc ^ ((row >> 1) & 7)) << 4);
+  }
+  auto stage = [&](int kv0, int buf) {
+    unsigned char* Ks = smem + buf * BUF;
+    const unsigned char* ks = kbase + (size_t)kv0 * KROW;
+    const unsigned char* vs = vbase + (size_t)kv0 * 2;
+#pragma unroll
+    for (int jj = 0; jj < NK / 4; ++jj)
+      __builtin_amdgcn_global_load_lds((pf_gptr_t)(ks + koff[jj]), (pf_lptr_t)(Ks + (wave + 4 * jj) * 1024), 16, 0, 0);
+#pragma unroll
+    for (int jj = 0; jj < NV / 4; ++jj)
+      __builtin_amdgcn_global_load_lds((pf_gptr_t)(vs + voff[jj]), (pf_lptr_t)(Ks + KTILE + (wave + 4 * jj) * 1024), 16, 0, 0);
+  };
+
+  // ---- fragment read offsets
+  unsigned k_rd[NKS];
+#pragma unroll
+  for (int ks = 0; ks < NKS; ++ks) {
+    const int c = 4 * ks + g, sw = HD == 96 ? (qi >> 2) & 3 : (qi >> 1) & 7;
+    k_rd[ks] = qi * KROW + ((c ^ sw) << 4);                  // + st*16*KROW
+  }
+  unsigned v_rd[4];                                           // chunk (4 st + 2 h + g/2) ^ ((qi>>1)&7)
+#pragma unroll
+  for (int k = 0; k < 4; ++k) v_rd[k] = KTILE + qi * VROW + (((2 * k + (g >> 1)) ^ ((qi >> 1) & 7)) << 4) + (g & 1) * 8;   // + d*16*VROW
+
+  float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};
+  f32x4_t o[2][NDT];
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+#pragma unroll
+    for (int d = 0; d < NDT; ++d) o[u][d] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  if (kv_begin < kv_end) stage(kv_begin, 0);
+  int buf = 0;
+  for (int kv0 = kv_begin; kv0 < kv_end; kv0 += 64, buf ^= 1) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's pieces of the tile have landed ...
+    __syncthreads();                                          // ... everybody's have, and the other buffer is free
+    if (kv0 + 64 < kv_end) stage(kv0 + 64, buf ^ 1);          // next tile streams in under the MFMAs below
+    if (kv0 <= wave_last) {                                   // wave-uniform: tiles above this wave's diagonal are skipped
+      const unsigned char* Ks = smem + buf * BUF;
+      f32x4_t s[2][4];
+#pragma unroll
+      for (int st = 0; st < 4; ++st) {
+        s[0][st] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        s[1][st] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+          const bf16x8_t kf = *(const bf16x8_t*)(Ks + k_rd[ks] + st * 16 * KROW);
+          s[0][st] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[0][ks], s[0][st], 0, 0, 0);
+          s[1][st] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[1][ks], s[1][st], 0, 0, 0);
+        }
+      }
+      // every key of the tile visible to every query of the wave -> no per-element mask work (wave-uniform)
+      const bool interior = kv0 + 64 <= kv_end && kv0 >= pad && past + q0 >= pad && (!p.causal || kv0 + 63 <= past + q0);
+      bf16x8_t pf[2][2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        float m_t = -INFINITY;
+        if (interior) {
+#pragma unroll
+          for (int st = 0; st < 4; ++st)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) m_t = fmaxf(m_t, s[u][st][r]);
+        } else {
+#pragma unroll
+          for (int st = 0; st < 4; ++st)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int t = kv0 + 16 * st + 4 * g + r;
+              const bool vis = t < kv_end && t >= pad && (!p.causal || t <= qpos[u]) && qpos[u] >= pad;
+              const float v = vis ? s[u][st][r] : -INFINITY;
+              s[u][st][r] = v;
+              m_t = fmaxf(m_t, v);
+            }
+        }
+        m_t = rows_max(m_t);
+        const float m_new = fmaxf(m_run[u], m_t * sc2);
+        const float m_use = m_new == -INFINITY ? 0.f : m_new;
+        const float alpha = __builtin_amdgcn_exp2f(m_run[u] - m_use);
+        float l_t = 0.f;
+#pragma unroll
+        for (int st = 0; st < 4; ++st)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float e = __builtin_amdgcn_exp2f(fmaf(s[u][st][r], sc2, -m_use));
+            s[u][st][r] = e;
+            l_t += e;
+          }
+        l_t = rows_sum(l_t);
+        l_run[u] = l_run[u] * alpha + l_t;
+        m_run[u] = m_new;
+        if (!__all(alpha == 1.f)) {
+#pragma unroll
+          for (int d = 0; d < NDT; ++d) o[u][d] *= alpha;
+        }
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+          u32x4_t pw;
+          pw[0] = pack_bf16x2(s[u][2 * st][0], s[u][2 * st][1]);
+          pw[1] = pack_bf16x2(s[u][2 * st][2], s[u][2 * st][3]);
+          pw[2] = pack_bf16x2(s[u][2 * st + 1][0], s[u][2 * st + 1][1]);
+          pw[3] = pack_bf16x2(s[u][2 * st + 1][2], s[u][2 * st + 1][3]);
+          pf[u][st] = __builtin_bit_cast(bf16x8_t, pw);
+        }
+      }
+#pragma unroll
+      for (int st = 0; st < 2; ++st)
+#pragma unroll
+        for (int d = 0; d < NDT; ++d) {
+          const u32x2_t a0 = *(const u32x2_t*)(Ks + v_rd[2 * st] + d * 16 * VROW);
+          const u32x2_t a1 = *(const u32x2_t*)(Ks + v_rd[2 * st + 1] + d * 16 * VROW);
+          const u32x4_t aw = {a0[0], a0[1], a1[0], a1[1]};
+          const bf16x8_t vf = __builtin_bit_cast(bf16x8_t, aw);
+          o[0][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[0][st], o[0][d], 0, 0, 0);
+          o[1][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[1][st], o[1][d], 0, 0, 0);
+        }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    if (!qvalid[u]) continue;
+    const float inv = l_run[u] > 0.f ? 1.f / l_run[u] : 0.f;
+    bf16_t* op = p.out + ((size_t)b * p.L + (q0 + u * 16 + qi)) * (size_t)(p.nh * HD) + head * HD + 4 * g;
+#pragma unroll
+    for (int d = 0; d < NDT; ++d) {
+      u32x2_t w;
+      w[0] = pack_bf16x2(o[u][d][0] * inv, o[u][d][1] * inv);
+      w[1] = pack_bf16x2(o[u][d][2] * inv, o[u][d][3] * inv);
+      *(u32x2_t*)(op + 16 * d) = w;
+    }
+  }
+}
+
 template <int HD>
 static int launch_attn_prefill(const AttnP& p, hipStream_t s) {
   constexpr int LDS = 2 * (64 * (HD * 2 + 16) + HD * (64 * 2 + 16));
@@ -419,7 +639,19 @@ static int launch_attn_prefill(const AttnP& p, hipStream_t s) {
       return P3V_ERR_HIP;
     attr_set = true;
   }
-  hipLaunchKernelGGL(k_attn_prefill<HD>, dim3(p3v_cdiv(p.L, 128), p.nh, p.B), dim3(256), LDS, s, p);
+  const dim3 grid(p3v_cdiv(p.L, 128), p.nh, p.B);
+  if (p.new_is_cache && p.past_t % 64 == 0 && !getenv("P3V_ATTN_NO_DMA")) {      // every caller in the model
+    constexpr int LDS2 = 2 * (64 * HD * 2 + HD * 128);
+    static bool attr2_set = false;
+    if (!attr2_set) {
+      if (hipFuncSetAttribute((const void*)k_attn_prefill_dma<HD>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS2) != hipSuccess)
+        return P3V_ERR_HIP;
+      attr2_set = true;
+    }
+    hipLaunchKernelGGL(k_attn_prefill_dma<HD>, dim3(p.nh, p3v_cdiv(p.L, 128), p.B), dim3(256), LDS2, s, p);
+  } else {
+    hipLaunchKernelGGL(k_attn_prefill<HD>, grid, dim3(256), LDS, s, p);
+  }
   P3V_CHECK_LAUNCH();
   return P3V_OK;
 }
@@ -528,36 +760,6 @@ __device__ __forceinline__ u32x4_t rope_chunk(const bf16_t* head_row, int c, con
     o[j] = pack_bf16x2(bf16lo(x0[j]) * cs[2 * j] + sg * bf16lo(x1[j]) * sn[2 * j],
                        bf16hi(x0[j]) * cs[2 * j + 1] + sg * bf16hi(x1[j]) * sn[2 * j + 1]);
   return o;
-}
-
-// cross-row all-reduce over the four 16-lane rows of a wave (lanes sharing lane & 15), on gfx950's
-// v_permlane{16,32}_swap: swap(x, x) leaves {row r, row r^1} pairs in the two results, so one max / add finishes a
-// butterfly step without the LDS crossbar latency of ds_bpermute.
-// (The two integer results pass through an empty asm before they are reinterpreted as floats: hipcc 7.2 otherwise
-// folds bitcast(result 1) into bitcast(result 0).)
-__device__ __forceinline__ void rows_swap32(float v, float& a, float& b) {
-  const unsigned u = __builtin_bit_cast(unsigned, v);
-  auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-  unsigned x = r[0], y = r[1];
-  asm("" : "+v"(x), "+v"(y));
-  a = __builtin_bit_cast(float, x); b = __builtin_bit_cast(float, y);
-}
-__device__ __forceinline__ void rows_swap16(float v, float& a, float& b) {
-  const unsigned u = __builtin_bit_cast(unsigned, v);
-  auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
-  unsigned x = r[0], y = r[1];
-  asm("" : "+v"(x), "+v"(y));
-  a = __builtin_bit_cast(float, x); b = __builtin_bit_cast(float, y);
-}
-__device__ __forceinline__ float rows_max(float v) {
-  float a, b;
-  rows_swap32(v, a, b); v = fmaxf(a, b);
-  rows_swap16(v, a, b); return fmaxf(a, b);
-}
-__device__ __forceinline__ float rows_sum(float v) {
-  float a, b;
-  rows_swap32(v, a, b); v = a + b;
-  rows_swap16(v, a, b); return a + b;
 }
 
 typedef const __attribute__((address_space(1))) void* dec_gptr_t;
@@ -1114,6 +1316,7 @@ struct AttnDecQ8P {
   const int32_t* pad_len; const int32_t* d_past; float* ws;
   int B, L, nh, nkv, past, cache_t, rope_bstride, n_split;
   float scale;
+  int grp, grp_magic;          // heads per kv head and ceil(2^16 / grp) (k_attn_decode_q8s)
 };
 
 // 16 offset-binary bytes -> 16 bf16 holding the RAW byte values 0..255 (exact in bf16: 8 significant bits).
@@ -1236,8 +1439,7 @@ __global__ void __launch_bounds__(64) k_attn_decode_q8(AttnDecQ8P p) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) qoff += bf16lo(qw[j]) + bf16hi(qw[j]);
   }
-  qoff += __shfl_xor(qoff, 16, 64);
-  qoff += __shfl_xor(qoff, 32, 64);
+  qoff = rows_sum(qoff);
   qoff *= 128.f;
   float m_run = -INFINITY, l_run = 0.f, p_run = 0.f;          // p_run = sum_t P'[t] (the folded V offset)
   f32x4_t o[NDT];
@@ -1290,8 +1492,7 @@ __global__ void __launch_bounds__(64) k_attn_decode_q8(AttnDecQ8P p) {
         m_t = fmaxf(m_t, v);
       }
     }
-    m_t = fmaxf(m_t, __shfl_xor(m_t, 16, 64));
-    m_t = fmaxf(m_t, __shfl_xor(m_t, 32, 64));
+    m_t = rows_max(m_t);
     const float m_new = fmaxf(m_run, m_t);
     const float m_use = m_new == -INFINITY ? 0.f : m_new;
     const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);
@@ -1306,10 +1507,8 @@ __global__ void __launch_bounds__(64) k_attn_decode_q8(AttnDecQ8P p) {
         s[st][r] = pv;
         p_t += pv;
       }
-    l_t += __shfl_xor(l_t, 16, 64);
-    l_t += __shfl_xor(l_t, 32, 64);
-    p_t += __shfl_xor(p_t, 16, 64);
-    p_t += __shfl_xor(p_t, 32, 64);
+    l_t = rows_sum(l_t);
+    p_t = rows_sum(p_t);
     l_run = l_run * alpha + l_t;
     p_run = p_run * alpha + p_t;
     m_run = m_new;
@@ -1341,16 +1540,243 @@ __global__ void __launch_bounds__(64) k_attn_decode_q8(AttnDecQ8P p) {
   if (g == 0) { w[HD] = m_run; w[HD + 1] = l_run; }
 }
 
+// Single-tile int8-KV decode attention: the int8 twin of k_attn_decode (4 waves x one 64-key tile, wave w owns keys
+// 16w..16w+15 end to end).  Per wave the K slice is 16 rows x 96 bytes and the V^T slice 96 rows x 16 bytes: 4 loads
+// per lane, converted to the RAW byte values as bf16 (exact) and written to the same swizzled LDS images as the bf16
+// kernel, so the MFMA part is identical; scales and the -128 offsets are applied to the 4 accumulator values per lane
+// (see u8x16_to_bf16).  The L new rows are rotated exactly, parked in LDS, quantised one row per wave (the step
+// attends over the values it stores, phi.py:545-546) and patched into the tile + cache.
+__global__ void __launch_bounds__(256) k_attn_decode_q8s(AttnDecQ8P p) {
+  constexpr int TK = 64, WK = 16, HD = 96, KROW = HD * 2, VROW = WK * 2, NKS = 3, NDT = 6, CPR = 12;
+  constexpr int KS_BYTES = WK * KROW, VS_BYTES = HD * VROW, WREG = KS_BYTES + VS_BYTES;
+  static_assert(WREG >= 16 * HD * 4, "a wave's O partial reuses its tile region");
+  __shared__ __attribute__((aligned(16))) unsigned char KV[4 * WREG];   // [wave]{K slice | V^T slice}, bf16 images
+  __shared__ __attribute__((aligned(16))) unsigned char Qs[16 * KROW];
+  __shared__ __attribute__((aligned(16))) unsigned char Kx[16 * KROW], Vx[16 * KROW];   // exact new rows [r][96] bf16
+  __shared__ __attribute__((aligned(16))) float ksl[TK], vsl[TK];
+  __shared__ float Ml[4][16][2];
+  const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, qi = lane & 15;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int b = blockIdx.z, head = blockIdx.y, kvh = (head * p.grp_magic) >> 16;
+  const bool kv_writer = head == kvh * p.grp;
+  unsigned char* wreg = KV + wave * WREG;
+  const size_t bh = (size_t)b * p.nkv + kvh;
+  uint8_t* kc = p.k8 + bh * (size_t)p.cache_t * HD;
+  uint8_t* vc = p.v8 + bh * (size_t)HD * p.cache_t;
+  float* ksc = p.ksc + bh * p.cache_t;
+  float* vsc = p.vsc + bh * p.cache_t;
+
+  int past = p.past, pad = 0;
+  if (p.d_past) asm volatile("s_load_dword %0, %1, 0x0" : "=s"(past) : "s"(p.d_past) : "memory");
+  if (p.pad_len) asm volatile("s_load_dword %0, %1, 0x0" : "=s"(pad) : "s"(p.pad_len + b) : "memory");
+
+  // ---- this wave's slices of the (static) tile: requested before the cache length has arrived
+  const int kv_lo = blockIdx.x * TK, kv_hi = min(p.cache_t, kv_lo + TK);
+  const int k0 = min(kv_lo, p.cache_t - TK) + WK * wave;
+  const int l32 = lane & 31;
+  const u32x4_t k_a = __builtin_nontemporal_load((const u32x4_t*)(kc + (size_t)k0 * HD) + lane);          // chunks 0..63
+  const u32x4_t k_b = __builtin_nontemporal_load((const u32x4_t*)(kc + (size_t)k0 * HD) + 64 + l32);      // chunks 64..95
+  const u32x4_t v_a = __builtin_nontemporal_load((const u32x4_t*)(vc + (size_t)lane * p.cache_t + k0));        // rows 0..63
+  const u32x4_t v_b = __builtin_nontemporal_load((const u32x4_t*)(vc + (size_t)(64 + l32) * p.cache_t + k0)); // rows 64..95
+  const float ks_r = ksc[k0 + qi], vs_r = vsc[k0 + qi];
+
+  // ---- the L new rows: Q for this head (rotated -> Qs) and K / V (exact, parked in Kx / Vx for the quantiser)
+  const int row_w = (p.nh + 2 * p.nkv) * HD;
+  const float* cos_b = p.cos_t + (size_t)b * p.rope_bstride * (HD / 2);
+  const float* sin_b = p.sin_t + (size_t)b * p.rope_bstride * (HD / 2);
+  const int tr = tid / CPR, tc = tid - tr * CPR;
+  const bool rtask = tr < p.L;
+  const int n_vnew = p.L * HD;
+  if (tid < 16 * CPR) {
+    u32x4_t qv = {0, 0, 0, 0};
+    if (rtask) {
+      const bf16_t* row = p.qkv + ((size_t)b * p.L + tr) * row_w;
+      const RopeRaw qraw = rope_fetch(row + head * HD, tc, cos_b + tr * (HD / 2), sin_b + tr * (HD / 2));
+      RopeRaw kraw = qraw;
+      const bf16_t* krow = row + (p.nh + kvh) * HD;
+      kraw.x0 = *(const u32x4_t*)(krow + tc * 8);
+      kraw.x1 = *(const u32x4_t*)(krow + (tc < 6 ? tc * 8 + 48 : tc * 8 - 48));
+      qv = rope_apply(qraw, tc);
+      *(u32x4_t*)(Kx + tr * KROW + tc * 16) = rope_apply(kraw, tc);
+    }
+    *(u32x4_t*)(Qs + tr * KROW + ((tc ^ ((tr >> 2) & 3)) << 4)) = qv;
+  }
+  {
+    const bf16_t* vnew = p.qkv + (size_t)b * p.L * row_w + (p.nh + p.nkv + kvh) * HD;
+#pragma unroll 1
+    for (int idx = tid; idx < n_vnew; idx += 256) {
+      const int r = idx / HD, d = idx - r * HD;
+      *(bf16_t*)(Vx + r * KROW + d * 2) = vnew[(size_t)r * row_w + d];
+    }
+  }
+
+  // ---- dequantise this wave's slices into the bf16 LDS images (raw byte values)
+  {
+    u32x4_t lo, hi;
+    auto put_k = [&](int i, u32x4_t w) {                       // 16-byte chunk i of the slice: row i/6, values 16*(i%6)..+16
+      const int row = i / 6, c2 = (i - row * 6) * 2, sw = (row >> 2) & 3;
+      u8x16_to_bf16(w, lo, hi);
+      *(u32x4_t*)(wreg + row * KROW + ((c2 ^ sw) << 4)) = lo;
+      *(u32x4_t*)(wreg + row * KROW + (((c2 + 1) ^ sw) << 4)) = hi;
+    };
+    auto put_v = [&](int d, u32x4_t w) {                       // row d: 16 keys
+      const int sw = (d >> 3) & 1;
+      u8x16_to_bf16(w, lo, hi);
+      *(u32x4_t*)(wreg + KS_BYTES + d * VROW + (sw << 4)) = lo;
+      *(u32x4_t*)(wreg + KS_BYTES + d * VROW + ((1 ^ sw) << 4)) = hi;
+    };
+    put_k(lane, k_a);
+    put_v(lane, v_a);
+    if (lane < 32) { put_k(64 + lane, k_b); put_v(64 + lane, v_b); }
+    if (lane < 16) { ksl[WK * wave + lane] = ks_r; vsl[WK * wave + lane] = vs_r; }
+  }
+
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(past), "+s"(pad)::"memory");
+  const int total = past + p.L;
+  const int kv_end = min(total, kv_hi);
+  const int qpos = past + qi;
+  const bool qvalid = qi < p.L;
+  const float sc2 = p.scale * 1.4426950408889634f;
+  const unsigned k_rd = qi * KROW + ((g ^ ((qi >> 2) & 3)) << 4);
+  const unsigned v_rd = KS_BYTES + qi * VROW + (((g >> 1) ^ ((qi >> 3) & 1)) << 4) + (g & 1) * 8;
+
+  float m_run = -INFINITY, l_run = 0.f, p_sum = 0.f;
+  f32x4_t o[NDT];
+#pragma unroll
+  for (int d = 0; d < NDT; ++d) o[d] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  const int kv0 = kv_lo;
+  if (kv0 < kv_end) {
+    __syncthreads();                                           // Qs / Kx / Vx complete, every wave's slices are in LDS
+    if (kv0 + TK > past) {
+      // quantise the new rows that fall in this tile, one row per wave at a time: the tile gets the byte values the
+      // cache gets (one code path: bytes + scale)
+#pragma unroll 1
+      for (int r = wave; r < p.L; r += 4) {
+        const int t = past + r, rr = t - kv0;
+        if (rr < 0 || rr >= TK || t >= kv_end) continue;
+        const float ka = lane < 48 ? bf16_to_f32(*(const bf16_t*)(Kx + r * KROW + 4 * lane)) : 0.f;
+        const float kb = lane < 48 ? bf16_to_f32(*(const bf16_t*)(Kx + r * KROW + 4 * lane + 2)) : 0.f;
+        const float kmax = wave_max(fmaxf(fabsf(ka), fabsf(kb)));
+        const float sk = kmax > 0.f ? kmax / 127.f : 1.f, inv = 1.f / sk;
+        const int qa = (int)rintf(ka * inv) + 128, qb = (int)rintf(kb * inv) + 128;
+        const float va = bf16_to_f32(*(const bf16_t*)(Vx + r * KROW + lane * 2));
+        const float vb = lane < 32 ? bf16_to_f32(*(const bf16_t*)(Vx + r * KROW + (lane + 64) * 2)) : 0.f;
+        const float vmx = wave_max(fmaxf(fabsf(va), fabsf(vb)));
+        const float sv = vmx > 0.f ? vmx / 127.f : 1.f, invv = 1.f / sv;
+        const int qva = (int)rintf(va * invv) + 128, qvb = (int)rintf(vb * invv) + 128;
+        unsigned char* dst = KV + (rr >> 4) * WREG;
+        const int row = rr & 15, kk = rr & 15;
+        if (lane < 48)
+          *(uint32_t*)(dst + row * KROW + ((((lane >> 2)) ^ ((row >> 2) & 3)) << 4) + (lane & 3) * 4) = pack_bf16x2((float)qa, (float)qb);
+        *(bf16_t*)(dst + KS_BYTES + lane * VROW + (((kk >> 3) ^ ((lane >> 3) & 1)) << 4) + (kk & 7) * 2) = f32_to_bf16((float)qva);
+        if (lane < 32)
+          *(bf16_t*)(dst + KS_BYTES + (lane + 64) * VROW + (((kk >> 3) ^ (((lane + 64) >> 3) & 1)) << 4) + (kk & 7) * 2) = f32_to_bf16((float)qvb);
+        if (lane == 0) { ksl[rr] = sk; vsl[rr] = sv; }
+        if (kv_writer) {
+          if (lane < 48) *(uint16_t*)(kc + (size_t)t * HD + 2 * lane) = (uint16_t)(qa | (qb << 8));
+          vc[(size_t)lane * p.cache_t + t] = (uint8_t)qva;
+          if (lane < 32) vc[(size_t)(lane + 64) * p.cache_t + t] = (uint8_t)qvb;
+          if (lane == 0) { ksc[t] = sk; vsc[t] = sv; }
+        }
+      }
+      __syncthreads();
+    }
+    bf16x8_t qf[NKS];
+    float qoff = 0.f;                                          // 128 * sum_d q[d] of this lane's query (the folded K offset)
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+      qf[ks] = *(const bf16x8_t*)(Qs + k_rd + ks * 64);
+      const u32x4_t qw = __builtin_bit_cast(u32x4_t, qf[ks]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) qoff += bf16lo(qw[j]) + bf16hi(qw[j]);
+    }
+    qoff = 128.f * rows_sum(qoff);
+
+    f32x4_t s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+      const bf16x8_t kf = *(const bf16x8_t*)(wreg + k_rd + ks * 64);
+      s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], s, 0, 0, 0);
+    }
+    const f32x4_t kk4 = *(const f32x4_t*)(ksl + WK * wave + 4 * g), vv4 = *(const f32x4_t*)(vsl + WK * wave + 4 * g);
+    float m_t = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int t = kv0 + WK * wave + 4 * g + r;
+      const bool vis = t < kv_end && t >= pad && t <= qpos && qpos >= pad;
+      s[r] = vis ? (s[r] - qoff) * kk4[r] * sc2 : -INFINITY;
+      m_t = fmaxf(m_t, s[r]);
+    }
+    m_t = rows_max(m_t);
+    const float m_use = m_t == -INFINITY ? 0.f : m_t;
+    float l_t = 0.f, p_t = 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float e = __builtin_amdgcn_exp2f(s[r] - m_use);
+      l_t += e;
+      s[r] = bf16_round(e > 0.f ? e * vv4[r] : 0.f);           // V scale folded into P (masked keys stay exactly 0)
+      p_t += s[r];
+    }
+    l_run = rows_sum(l_t);
+    p_sum = rows_sum(p_t);
+    m_run = m_t;
+    const u32x2_t pw = {pack_bf16x2(s[0], s[1]), pack_bf16x2(s[2], s[3])};
+    const s16x4_t pf = __builtin_bit_cast(s16x4_t, pw);
+#pragma unroll
+    for (int d = 0; d < NDT; ++d) {
+      const s16x4_t vf = *(const s16x4_t*)(wreg + v_rd + d * 16 * VROW);
+      o[d] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(vf, pf, o[d], 0, 0, 0);
+    }
+  }
+
+  // ---- merge the four wave partials (as k_attn_decode); the folded V offset leaves here
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __syncthreads();                                             // every wave is done reading the tile regions
+  if (qvalid) {
+    float* Ow = (float*)wreg + qi * HD;
+    const float voff = 128.f * p_sum;
+#pragma unroll
+    for (int d = 0; d < NDT; ++d) *(f32x4_t*)(Ow + 16 * d + 4 * g) = o[d] - voff;
+    if (g == 0) { Ml[wave][qi][0] = m_run; Ml[wave][qi][1] = l_run; }
+  }
+  __syncthreads();
+#pragma unroll 1
+  for (int idx = tid; idx < n_vnew; idx += 256) {
+    const int q = idx / HD, d = idx - q * HD;
+    float mk[4], M = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { mk[k] = Ml[k][q][0]; M = fmaxf(M, mk[k]); }
+    const float Mu = M == -INFINITY ? 0.f : M;
+    float acc = 0.f, lsum = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float c = __builtin_amdgcn_exp2f(mk[k] - Mu);
+      acc += c * ((const float*)(KV + k * WREG))[q * HD + d];
+      lsum += c * Ml[k][q][1];
+    }
+    float* w = p.ws + ((((size_t)b * p.nh + head) * p.n_split + blockIdx.x) * 16 + q) * (HD + 2);
+    w[d] = acc;
+    if (d == 0) { w[HD] = M; w[HD + 1] = lsum; }
+  }
+}
+
 extern "C" int p3v_attention_decode_q8(const p3v_attn_decode_q8_args_t* a, void* stream) {
   if (!a || !a->qkv || !a->cos_t || !a->sin_t || !a->k8 || !a->v8t || !a->k_scale || !a->v_scale || !a->out || !a->ws)
     return P3V_ERR_ARG;
   if (a->hd != 96) return P3V_ERR_UNSUPPORTED;
   if (a->B <= 0 || a->L <= 0 || a->L > P3V_DECODE_MAX_L || a->n_heads % a->n_kv) return P3V_ERR_ARG;
   if (a->n_split < 1 || a->n_split > 128 || a->cache_t % 64) return P3V_ERR_ARG;
+  const int grp = a->n_heads / a->n_kv;
   AttnDecQ8P p = {a->qkv, a->cos_t, a->sin_t, a->k8, a->v8t, a->k_scale, a->v_scale, a->pad_len, a->d_past, a->ws,
-                  a->B, a->L, a->n_heads, a->n_kv, a->past, a->cache_t, a->rope_bstride, a->n_split, a->scale};
+                  a->B, a->L, a->n_heads, a->n_kv, a->past, a->cache_t, a->rope_bstride, a->n_split, a->scale,
+                  grp, (65536 + grp - 1) / grp};
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(k_attn_decode_q8, dim3(a->n_split, a->n_heads, a->B), dim3(64), 0, s, p);
+  const dim3 grid(a->n_split, a->n_heads, a->B);
+  static const bool old_only = getenv("P3V_Q8_OLD") != nullptr;   // A/B knob
+  if (!old_only && a->n_split * 64 >= a->cache_t && a->n_split <= 16)   // short contexts only: measured equal or slower beyond
+    hipLaunchKernelGGL(k_attn_decode_q8s, grid, dim3(256), 0, s, p);
+  else hipLaunchKernelGGL(k_attn_decode_q8, grid, dim3(64), 0, s, p);
   P3V_CHECK_LAUNCH();
   hipLaunchKernelGGL(k_attn_combine2, dim3(a->B * a->n_heads * a->L), dim3(combine_threads(a->n_split)), 0, s, a->ws, a->out, a->L, a->n_heads,
                      a->hd, a->n_split);

@@ -306,12 +306,14 @@ def _dequant(u8, sc, axis):
     return (u8.float() - 128.0) * sc.unsqueeze(axis)
 
 
-def test_kv_quantize_and_q8_decode(ops, orc):
+@pytest.mark.parametrize("past,L,n_split", [(200, 1, 3), (200, 1, 4), (190, 3, 4), (62, 5, 4)])
+def test_kv_quantize_and_q8_decode(ops, orc, past, L, n_split):
     """int8 KV: (a) quantiser = round(x/s)+128 with s = amax/127 per token, (b) the q8 decode attention equals the
-    bf16 oracle attention over the DEQUANTISED cache, (c) the appended row is stored quantised."""
+    bf16 oracle attention over the DEQUANTISED cache, (c) the appended rows are stored quantised.
+    n_split 3 -> multi-tile single-wave kernel, 4 (= tiles) -> single-tile 4-wave kernel; (62, 5) crosses a tile boundary."""
     from phi_3_vision_mlx_amd.config import make_config, rope_scaling_factor
     cfg = make_config()
-    B, nh, hd, past, L, T = 2, 2, 96, 200, 1, 256
+    B, nh, hd, T = 2, 2, 96, 256
     k, v = g((B, nh, T, hd), 90), g((B, nh, T, hd), 91)
     k8 = torch.full((B, nh, T, hd), 128, dtype=torch.uint8).cuda()
     v8 = torch.full((B, nh, hd, T), 128, dtype=torch.uint8).cuda()
@@ -329,7 +331,6 @@ def test_kv_quantize_and_q8_decode(ops, orc):
     cos, sin = ops.rope_table(torch.arange(T, dtype=F32).repeat(B).cuda(), inv.cuda(), rope_scaling_factor(cfg))
     cos, sin = cos.view(B, T, -1), sin.view(B, T, -1)
     out = torch.empty((B, L, nh * hd), dtype=BF16).cuda()
-    n_split = 3
     ws = torch.empty(ops.attention_ws_bytes(B, L, nh, hd, n_split) // 4, dtype=F32).cuda()
     ops.attention_decode_q8(qkv.cuda(), cos[:, past:], sin[:, past:], T, k8, v8, ksc, vsc, out, B, L, nh, nh, hd, hd ** -0.5, past,
                             T, ws, n_split)
@@ -343,7 +344,7 @@ def test_kv_quantize_and_q8_decode(ops, orc):
         return torch.round(t.float() / sc) * sc
     kf = torch.cat([kd[:, :, :past], qdq(k_new)], dim=2)
     vf = torch.cat([vd[:, :, :past], qdq(x[:, 2 * nh:])], dim=2)
-    allowed = torch.ones((B, 1, L, past + L), dtype=torch.bool)
+    allowed = (torch.arange(past + L)[None, :] <= (past + torch.arange(L))[:, None])[None, None].expand(B, 1, L, past + L)
     ref = _attn_ref(orc, q, kf, vf, hd ** -0.5, allowed).transpose(1, 2).reshape(B, L, nh * hd)
     close(out, ref, rtol=2 ** -6, atol=2e-2)
     s_new = k_new.float().abs().amax(-1) / 127
