@@ -26,6 +26,7 @@ struct AttnP {
   bf16_t* out; const int32_t* pad_len; const int32_t* d_past; float* ws;
   int B, L, nh, nkv, past, past_t, past_div, new_t, pad_div, causal, split_mode, n_split, new_is_cache;
   float scale;
+  int head_group;              // k_attn_prefill_dma: heads whose query blocks are interleaved in launch order
 };
 
 // cross-row all-reduce over the four 16-lane rows of a wave (lanes sharing lane & 15), on gfx950's
@@ -452,13 +453,18 @@ __global__ void __launch_bounds__(256, 2) k_attn_prefill_dma(AttnP p) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, qi = lane & 15;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  // grid (heads, query blocks, B) with the query blocks walked from the LAST one down: under a causal mask block i costs
-  // i+1 tiles, so the dispatcher sees the longest jobs first and the tail of the launch is made of the short ones
-  const int b = blockIdx.z, head = blockIdx.x, kvh = head / (p.nh / p.nkv);
+  // Launch order (1-D over heads x query blocks): query blocks are walked from the LAST one down -- under a causal mask
+  // block i costs i+1 tiles, so the dispatcher sees the longest jobs first and the tail of the launch is made of short
+  // ones -- interleaving `head_group` heads at a time, so that the K/V of the heads in flight stay cache-resident
+  // (all heads for short prompts; 8 or 4 when one head's K/V is megabytes).
+  const int nqb = (p.L + 127) >> 7, per_group = p.head_group * nqb;
+  const int grp = blockIdx.x / per_group, within = blockIdx.x - grp * per_group;
+  const int qblk = nqb - 1 - within / p.head_group;
+  const int b = blockIdx.z, head = grp * p.head_group + within % p.head_group, kvh = head / (p.nh / p.nkv);
   const int past = p.d_past ? *p.d_past : p.past;
   const int total = past + p.L;
   const int pad = p.pad_len ? p.pad_len[b / p.pad_div] : 0;
-  const int qb0 = (gridDim.y - 1 - blockIdx.y) * 128, q0 = qb0 + wave * 32;
+  const int qb0 = qblk * 128, q0 = qb0 + wave * 32;
   const int kv_end = p.causal ? min(total, past + qb0 + 128) : total;
   const int kv_begin = pad & ~63;
   const int wave_last = p.causal ? past + q0 + 31 : total;  // last key position this wave can see
@@ -648,7 +654,10 @@ static int launch_attn_prefill(const AttnP& p, hipStream_t s) {
         return P3V_ERR_HIP;
       attr2_set = true;
     }
-    hipLaunchKernelGGL(k_attn_prefill_dma<HD>, dim3(p.nh, p3v_cdiv(p.L, 128), p.B), dim3(256), LDS2, s, p);
+    AttnP q = p;
+    const size_t kv_bytes = (size_t)(p.past + p.L) * HD * 4;     // one head's K + V^T
+    q.head_group = kv_bytes * p.nh <= (64u << 20) ? p.nh : (p.nh % 8 == 0 && kv_bytes * 8 <= (128u << 20) ? 8 : (p.nh % 4 == 0 ? 4 : p.nh));
+    hipLaunchKernelGGL(k_attn_prefill_dma<HD>, dim3(p.nh * p3v_cdiv(p.L, 128), 1, p.B), dim3(256), LDS2, s, q);
   } else {
     hipLaunchKernelGGL(k_attn_prefill<HD>, grid, dim3(256), LDS, s, p);
   }
