@@ -29,36 +29,6 @@ struct AttnP {
   int head_group;              // k_attn_prefill_dma: heads whose query blocks are interleaved in launch order
 };
 
-// cross-row all-reduce over the four 16-lane rows of a wave (lanes sharing lane & 15), on gfx950's
-// v_permlane{16,32}_swap: swap(x, x) leaves {row r, row r^1} pairs in the two results, so one max / add finishes a
-// butterfly step without the LDS crossbar latency of ds_bpermute.
-// (The two integer results pass through an empty asm before they are reinterpreted as floats: hipcc 7.2 otherwise
-// folds bitcast(result 1) into bitcast(result 0).)
-__device__ __forceinline__ void rows_swap32(float v, float& a, float& b) {
-  const unsigned u = __builtin_bit_cast(unsigned, v);
-  auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-  unsigned x = r[0], y = r[1];
-  asm("" : "+v"(x), "+v"(y));
-  a = __builtin_bit_cast(float, x); b = __builtin_bit_cast(float, y);
-}
-__device__ __forceinline__ void rows_swap16(float v, float& a, float& b) {
-  const unsigned u = __builtin_bit_cast(unsigned, v);
-  auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
-  unsigned x = r[0], y = r[1];
-  asm("" : "+v"(x), "+v"(y));
-  a = __builtin_bit_cast(float, x); b = __builtin_bit_cast(float, y);
-}
-__device__ __forceinline__ float rows_max(float v) {
-  float a, b;
-  rows_swap32(v, a, b); v = fmaxf(a, b);
-  rows_swap16(v, a, b); return fmaxf(a, b);
-}
-__device__ __forceinline__ float rows_sum(float v) {
-  float a, b;
-  rows_swap32(v, a, b); v = a + b;
-  rows_swap16(v, a, b); return a + b;
-}
-
 template <int HD>
 __global__ void __launch_bounds__(256) k_attn(AttnP p) {
   constexpr int KSTR = HD * 2 + 16;        // bytes per K row in LDS (padded: conflict-free b128 fragment reads)

@@ -39,15 +39,53 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
 __device__ __forceinline__ float bf16lo(uint32_t w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float bf16hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
 
+// cross-row all-reduce over the four 16-lane rows of a wave (lanes sharing lane & 15), on gfx950's
+// v_permlane{16,32}_swap: swap(x, x) leaves {row r, row r^1} pairs in the two results, so one max / add finishes a
+// butterfly step without the LDS crossbar latency of ds_bpermute.
+// (The two integer results pass through an empty asm before they are reinterpreted as floats: hipcc 7.2 otherwise
+// folds bitcast(result 1) into bitcast(result 0).)
+__device__ __forceinline__ void rows_swap32(float v, float& a, float& b) {
+  const unsigned u = __builtin_bit_cast(unsigned, v);
+  auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  unsigned x = r[0], y = r[1];
+  asm("" : "+v"(x), "+v"(y));
+  a = __builtin_bit_cast(float, x); b = __builtin_bit_cast(float, y);
+}
+__device__ __forceinline__ void rows_swap16(float v, float& a, float& b) {
+  const unsigned u = __builtin_bit_cast(unsigned, v);
+  auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  unsigned x = r[0], y = r[1];
+  asm("" : "+v"(x), "+v"(y));
+  a = __builtin_bit_cast(float, x); b = __builtin_bit_cast(float, y);
+}
+__device__ __forceinline__ float rows_max(float v) {
+  float a, b;
+  rows_swap32(v, a, b); v = fmaxf(a, b);
+  rows_swap16(v, a, b); return fmaxf(a, b);
+}
+__device__ __forceinline__ float rows_sum(float v) {
+  float a, b;
+  rows_swap32(v, a, b); v = a + b;
+  rows_swap16(v, a, b); return a + b;
+}
+
+// full-wave all-reduce without the LDS crossbar: xor-1 / xor-2 inside a quad and the two rotations inside a row of 16
+// lanes are DPP modifiers of the add / max itself, the last two steps are the row swaps above.  (ds_bpermute, which
+// __shfl_xor compiles to, is a ~100-cycle LDS round trip per step, six dependent ones per reduction.)
+#define P3V_DPP_F32(v, ctrl) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xf, 0xf, true))
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  v += P3V_DPP_F32(v, 0xB1);      // quad_perm [1,0,3,2]
+  v += P3V_DPP_F32(v, 0x4E);      // quad_perm [2,3,0,1]
+  v += P3V_DPP_F32(v, 0x124);     // row_ror:4
+  v += P3V_DPP_F32(v, 0x128);     // row_ror:8
+  return rows_sum(v);
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
+  v = fmaxf(v, P3V_DPP_F32(v, 0xB1));
+  v = fmaxf(v, P3V_DPP_F32(v, 0x4E));
+  v = fmaxf(v, P3V_DPP_F32(v, 0x124));
+  v = fmaxf(v, P3V_DPP_F32(v, 0x128));
+  return rows_max(v);
 }
 
 // block-wide sum for blockDim.x = 64*nw (nw <= 16); `red` is >= 16 floats of LDS
