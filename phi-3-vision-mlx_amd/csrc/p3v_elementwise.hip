@@ -356,12 +356,27 @@ __device__ __forceinline__ ValIdx better(ValIdx a, ValIdx b) {   // larger value
   return (b.v > a.v || (b.v == a.v && b.i < a.i)) ? b : a;
 }
 __device__ __forceinline__ ValIdx block_argmax(ValIdx m, ValIdx* red) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    ValIdx t;
-    t.v = __shfl_xor(m.v, o, 64);
-    t.i = __shfl_xor(m.i, o, 64);
-    m = better(m, t);
+  // wave all-reduce of (value, index) on DPP + row swaps (see wave_sum in p3v_common.h)
+#define P3V_ARGMAX_DPP(ctrl)                                                                             \
+  {                                                                                                      \
+    ValIdx t;                                                                                            \
+    t.v = P3V_DPP_F32(m.v, ctrl);                                                                        \
+    t.i = __builtin_amdgcn_update_dpp(0, m.i, ctrl, 0xf, 0xf, true);                                     \
+    m = better(m, t);                                                                                    \
+  }
+  P3V_ARGMAX_DPP(0xB1) P3V_ARGMAX_DPP(0x4E) P3V_ARGMAX_DPP(0x124) P3V_ARGMAX_DPP(0x128)
+#undef P3V_ARGMAX_DPP
+  {
+    ValIdx a, b;
+    float ia, ib;
+    rows_swap32(m.v, a.v, b.v);
+    rows_swap32(__builtin_bit_cast(float, m.i), ia, ib);
+    a.i = __builtin_bit_cast(int, ia); b.i = __builtin_bit_cast(int, ib);
+    m = better(a, b);
+    rows_swap16(m.v, a.v, b.v);
+    rows_swap16(__builtin_bit_cast(float, m.i), ia, ib);
+    a.i = __builtin_bit_cast(int, ia); b.i = __builtin_bit_cast(int, ib);
+    m = better(a, b);
   }
   const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
   __syncthreads();

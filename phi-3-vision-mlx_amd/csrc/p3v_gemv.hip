@@ -389,8 +389,7 @@ __global__ void __launch_bounds__(256) k_gemv_mfma(GemvP p) {
   else compute(IC0{});
 
   // ---- merge the four K quarters.  C layout: lane holds outputs n = n_base + 4*g + r of x row m = li
-  ss += __shfl_xor(ss, 16, 64);
-  ss += __shfl_xor(ss, 32, 64);
+  ss = rows_sum(ss);
   if (g == 0) sspart[wave][li] = ss;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {

@@ -226,8 +226,7 @@ __global__ void __launch_bounds__(256) k_gemv_mfma_f8(GemvF8P p) {
   if (st + 1 < n_st) { issue(st + 1, IC1{}); compute(IC0{}); compute(IC1{}); }
   else compute(IC0{});
 
-  ss += __shfl_xor(ss, 16, 64);
-  ss += __shfl_xor(ss, 32, 64);
+  ss = rows_sum(ss);
   if (g == 0) sspart[wave][li] = ss;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
