@@ -177,6 +177,9 @@ typedef struct {
   const int32_t* pad_len; const int32_t* d_past; float* ws;
   int B, L, n_heads, n_kv, hd, past, cache_t, rope_bstride, n_split;
   float scale;
+  int32_t* counters; /* optional [B * n_heads * n_split] int32, zero-initialised ONCE by the caller (every launch leaves it
+                        zero): the split-KV partials are then merged by the last split of each (b, head) inside the
+                        attention launch; NULL = a separate merge launch */
 } p3v_attn_decode_args_t;
 int p3v_attention_decode(const p3v_attn_decode_args_t* args /* host */, void* stream);
 /* cos/sin rows of positions [past, past+L) of each batch row ([B, tab_t, half] tables) -> [B, L, half] */
@@ -197,6 +200,9 @@ typedef struct {
   const int32_t* pad_len; const int32_t* d_past; float* ws;
   int B, L, n_heads, n_kv, hd, past, cache_t, rope_bstride, n_split;
   float scale;
+  int32_t* counters; /* optional [B * n_heads * n_split] int32, zero-initialised ONCE by the caller (every launch leaves it
+                        zero): the split-KV partials are then merged by the last split of each (b, head) inside the
+                        attention launch; NULL = a separate merge launch */
 } p3v_attn_decode_q8_args_t;
 int p3v_attention_decode_q8(const p3v_attn_decode_q8_args_t* args /* host */, void* stream);
 

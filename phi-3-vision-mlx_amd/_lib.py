@@ -50,7 +50,7 @@ class AttnDecArgs(C.Structure):
     _fields_ = [("qkv", vp), ("cos_t", vp), ("sin_t", vp), ("k_cache", vp), ("v_cache", vp), ("out", vp),
                 ("pad_len", vp), ("d_past", vp), ("ws", vp),
                 ("B", i32), ("L", i32), ("n_heads", i32), ("n_kv", i32), ("hd", i32), ("past", i32),
-                ("cache_t", i32), ("rope_bstride", i32), ("n_split", i32), ("scale", f32)]
+                ("cache_t", i32), ("rope_bstride", i32), ("n_split", i32), ("scale", f32), ("counters", vp)]
 
 
 class AttnDecQ8Args(C.Structure):

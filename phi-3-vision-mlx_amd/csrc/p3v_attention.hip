@@ -692,7 +692,93 @@ struct AttnDecP {
   int B, L, nh, nkv, past, cache_t, rope_bstride, n_split;   // cos/sin row of (b, new position r) = b*rope_bstride + r
   float scale;
   int chunk, grp, grp_magic;   // host-side: keys per split (multiple of 64), heads per kv head and ceil(2^16 / grp)
+  int32_t* counters;           // [B * nh * n_split] zeroed ready-flags: the last split of a (b, head) merges the partials itself
+  bf16_t* out;                 // [B, L, nh * 96] (fused merge only)
 };
+
+// ---- fused split-KV merge ("last workgroup merges").  Protocol without cache write-back / invalidate fences (an
+// agent-scope release costs ~20 us on this chip, tools/scratch/persist_gemv.hip): partials are stored and loaded with
+// agent-scope relaxed atomics (write-through / cache-bypassing accesses), a workgroup waits for its stores
+// (s_waitcnt vmcnt(0) + barrier) before it raises its ready flag, and the last split waits for all flags and merges.
+__device__ __forceinline__ void st_wt(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float ld_wt(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// Publishes this workgroup's partial (flag[split] = 1) and returns true in the ONE workgroup per (b, head) that merges:
+// the one with the highest split index.  Workgroups are dispatched in linear order, so by the time it runs every
+// other split of its (b, head) is resident or finished and the wait below cannot deadlock; the spin is bounded anyway.
+// No atomics: 41 read-modify-writes on one address from eight XCDs serialise into microseconds.
+__device__ __forceinline__ bool split_publish_and_wait(int32_t* flags, int split, int n_split) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this thread's partial stores have been performed
+  __syncthreads();
+  if (split != n_split - 1) {
+    if (threadIdx.x == 0) __hip_atomic_store(flags + split, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return false;
+  }
+  if (threadIdx.x < 64) {
+    for (unsigned spins = 0; spins < (1u << 22); ++spins) {
+      bool ok = true;
+      for (int s = threadIdx.x; s < n_split - 1; s += 64)
+        ok &= __hip_atomic_load(flags + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+      if (__all(ok)) break;
+    }
+  }
+  __syncthreads();
+  return true;
+}
+
+// merge of the n_split partials of one (b, head) by the calling workgroup (NT threads = G groups of 64 lanes)
+template <int NT>
+__device__ __forceinline__ void split_merge(const float* base0, bf16_t* out0, size_t out_qstride, int L, int n_split,
+                                            int32_t* flags) {
+  constexpr int HD = 96, G = NT / 64;
+  __shared__ float pm[G], pl[G];
+  __shared__ float part[G][128];
+  const int t = threadIdx.x, grp = t >> 6, d0 = t & 63;
+  const size_t sstr = (size_t)16 * (HD + 2);
+  const bool two = d0 + 64 < HD;
+  for (int q = 0; q < L; ++q) {
+    const float* base = base0 + (size_t)q * (HD + 2);
+    float m = -INFINITY, l = 0.f, a0 = 0.f, a1 = 0.f;
+#pragma unroll 4
+    for (int s = grp; s < n_split; s += G) {
+      const float ms = ld_wt(base + s * sstr + HD), ls = ld_wt(base + s * sstr + HD + 1);
+      const float o0 = ld_wt(base + s * sstr + d0), o1 = two ? ld_wt(base + s * sstr + d0 + 64) : 0.f;
+      const float mn = fmaxf(m, ms);
+      const float mu = mn == -INFINITY ? 0.f : mn;
+      const float ca = __builtin_amdgcn_exp2f(m - mu), cb = __builtin_amdgcn_exp2f(ms - mu);
+      l = l * ca + ls * cb;
+      a0 = a0 * ca + o0 * cb;
+      a1 = a1 * ca + o1 * cb;
+      m = mn;
+    }
+    if (G > 1) {
+      __syncthreads();
+      if (d0 == 0) { pm[grp] = m; pl[grp] = l; }
+      part[grp][d0] = a0;
+      if (two) part[grp][d0 + 64] = a1;
+      __syncthreads();
+      if (t < HD) {
+        float M = pm[0];
+#pragma unroll
+        for (int k = 1; k < G; ++k) M = fmaxf(M, pm[k]);
+        const float Mu = M == -INFINITY ? 0.f : M;
+        float acc = 0.f, lsum = 0.f;
+#pragma unroll
+        for (int k = 0; k < G; ++k) {
+          const float c = __builtin_amdgcn_exp2f(pm[k] - Mu);
+          acc += c * part[k][t];
+          lsum += c * pl[k];
+        }
+        out0[(size_t)q * out_qstride + t] = f32_to_bf16(lsum > 0.f ? acc / lsum : 0.f);
+      }
+    } else {
+      const float inv = l > 0.f ? 1.f / l : 0.f;
+      out0[(size_t)q * out_qstride + d0] = f32_to_bf16(a0 * inv);
+      if (two) out0[(size_t)q * out_qstride + d0 + 64] = f32_to_bf16(a1 * inv);
+    }
+  }
+  for (int i = t; i < n_split - 1; i += NT) __hip_atomic_store(flags + i, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+}
 
 // operands of one rotated 8-wide chunk, split into a load half and a math half so that the loads can be issued
 // ahead of other memory traffic and consumed later
@@ -956,10 +1042,14 @@ __global__ void __launch_bounds__(256) k_attn_decode(AttnDecP p) {
       lsum += c * Ml[k][q][1];
     }
     float* w = p.ws + ((((size_t)b * p.nh + head) * p.n_split + blockIdx.x) * 16 + q) * (HD + 2);
-    w[d] = acc;
-    if (d == 0) { w[HD] = M; w[HD + 1] = lsum; }
+    st_wt(w + d, acc);
+    if (d == 0) { st_wt(w + HD, M); st_wt(w + HD + 1, lsum); }
   }
   DBG_T(7);
+  int32_t* flags = p.counters + ((size_t)b * p.nh + head) * p.n_split;
+  if (p.counters && split_publish_and_wait(flags, blockIdx.x, p.n_split))
+    split_merge<256>(p.ws + ((size_t)b * p.nh + head) * p.n_split * 16 * (HD + 2), p.out + (size_t)b * p.L * (p.nh * HD) + head * HD,
+                     (size_t)p.nh * HD, p.L, p.n_split, flags);
 }
 
 // Multi-tile variant (contexts beyond ~8k tokens or large batches, where one tile per workgroup would need more than
@@ -1129,11 +1219,18 @@ __global__ void __launch_bounds__(64) k_attn_decode_stream(AttnDecP p) {
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // LDS reads of this tile precede the next tile's writes
   }
-  if (!qvalid) return;
-  float* w = p.ws + ((((size_t)b * p.nh + head) * p.n_split + blockIdx.x) * 16 + qi) * (HD + 2);
+  if (qvalid) {
+    float* w = p.ws + ((((size_t)b * p.nh + head) * p.n_split + blockIdx.x) * 16 + qi) * (HD + 2);
 #pragma unroll
-  for (int d = 0; d < NDT; ++d) *(f32x4_t*)(w + 16 * d + 4 * g) = o[d];
-  if (g == 0) { w[HD] = m_run; w[HD + 1] = l_run; }
+    for (int d = 0; d < NDT; ++d)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) st_wt(w + 16 * d + 4 * g + r, o[d][r]);
+    if (g == 0) { st_wt(w + HD, m_run); st_wt(w + HD + 1, l_run); }
+  }
+  int32_t* flags = p.counters + ((size_t)b * p.nh + head) * p.n_split;
+  if (p.counters && split_publish_and_wait(flags, blockIdx.x, p.n_split))
+    split_merge<64>(p.ws + ((size_t)b * p.nh + head) * p.n_split * 16 * (HD + 2), p.out + (size_t)b * p.L * (p.nh * HD) + head * HD,
+                    (size_t)p.nh * HD, p.L, p.n_split, flags);
 }
 
 // merge split-KV partials: one block of G = 4 or 8 64-lane groups per (b, head, query): thread (grp, d) loads
@@ -1218,12 +1315,13 @@ extern "C" int p3v_attention_decode(const p3v_attn_decode_args_t* a, void* strea
   const int chunk = ((a->cache_t + a->n_split - 1) / a->n_split + 63) & ~63;
   AttnDecP p = {a->qkv, a->cos_t, a->sin_t, a->k_cache, a->v_cache, a->pad_len, a->d_past, a->ws,
                 a->B, a->L, a->n_heads, a->n_kv, a->past, a->cache_t, a->rope_bstride, a->n_split, a->scale,
-                chunk, grp, (65536 + grp - 1) / grp};
+                chunk, grp, (65536 + grp - 1) / grp, a->counters, (bf16_t*)a->out};
   hipStream_t s = (hipStream_t)stream;
   const dim3 grid(a->n_split, a->n_heads, a->B);
   if (a->n_split * 64 >= a->cache_t) hipLaunchKernelGGL(k_attn_decode, grid, dim3(256), 0, s, p);
   else hipLaunchKernelGGL(k_attn_decode_stream<64>, grid, dim3(64), 0, s, p);
   P3V_CHECK_LAUNCH();
+  if (a->counters) return P3V_OK;                              // the last workgroup of every (b, head) merged in-kernel
   hipLaunchKernelGGL(k_attn_combine2, dim3(a->B * a->n_heads * a->L), dim3(combine_threads(a->n_split)), 0, s, a->ws, a->out, a->L, a->n_heads,
                      a->hd, a->n_split);
   P3V_CHECK_LAUNCH();

@@ -300,6 +300,11 @@ class Phi3VModel:
                 n_split = int(os.environ["P3V_ATTN_NSPLIT"])
             bufs["n_split"] = n_split
             bufs["ws"] = torch.empty(ops.attention_ws_bytes(B, L, nh, hd, n_split) // 4, dtype=F32, device=self.device)
+            # ready flags of the fused split-KV merge: used with the one-tile-per-workgroup plan only (measured: -17..-22 us
+            # per step at B = 1; with the multi-tile streaming kernel the write-through partial stores cost more than the
+            # merge launch saves, and beyond ~48 splits the one merging workgroup is slower than 32 parallel ones)
+            fused = n_split == tiles and n_split <= 48 and os.environ.get("P3V_ATTN_FUSED_MERGE", "1") != "0"
+            bufs["attn_cnt"] = torch.zeros(B * nh * n_split, dtype=I32, device=self.device) if fused else None
 
     def _layers(self, x, st, B, L, past, n_beam, bufs=None, d_past=None):
         """Phi3DecoderLayer stack (phi.py:473-485).  `d_past` (device int32) makes every
@@ -348,7 +353,7 @@ class Phi3VModel:
                 else:                                           # eager: views into the prompt tables at `past`
                     rc, rs, rb = st.cos[:, past:], st.sin[:, past:], st.T
                 ops.attention_decode(qkv, rc, rs, rb, st.k[i], st.v[i], o, B, L, nh, nkv, hd, scale, past, st.Tp, ws, n_split,
-                                     pad_len=st.pad_len, d_past=d_past)
+                                     pad_len=st.pad_len, d_past=d_past, counters=bufs.get("attn_cnt"))
             else:
                 ops.rope_kv_append(qkv, st.cos, st.sin, q, st.k[i], st.v[i], B, L, nh, nkv, hd, past, st.Tp, True, st.T, 1)
                 ops.attention(q, o, B, L, nh, nkv, hd, scale, True, past=past, k_past=st.k[i], v_past=st.v[i],

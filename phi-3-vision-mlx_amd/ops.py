@@ -192,11 +192,12 @@ def attention(q, out, B, Lq, nh, nkv, hd, scale, causal, k_new=None, v_new=None,
 
 
 def attention_decode(qkv, cos_new, sin_new, rope_bstride, k_cache, v_cache, out, B, Lq, nh, nkv, hd, scale, past, cache_t, ws,
-                     n_split, pad_len=None, d_past=None):
+                     n_split, pad_len=None, d_past=None, counters=None):
     """Fused decode-step attention: head split + RoPE + KV append + split-KV attention + merge.
-    cos_new/sin_new: rows of the new positions, row (b, r) at b*rope_bstride + r."""
+    cos_new/sin_new: rows of the new positions, row (b, r) at b*rope_bstride + r.
+    counters: optional zeroed int32 [B*nh*n_split] -> the split partials are merged inside the attention launch."""
     args = L.AttnDecArgs(_p(qkv), _p(cos_new), _p(sin_new), _p(k_cache), _p(v_cache), _p(out), _p(pad_len), _p(d_past), _p(ws),
-                         B, Lq, nh, nkv, hd, int(past), cache_t, rope_bstride, n_split, float(scale))
+                         B, Lq, nh, nkv, hd, int(past), cache_t, rope_bstride, n_split, float(scale), _p(counters))
     L.check(L.lib().p3v_attention_decode(C.byref(args), _stream()), "attention_decode")
     return out
 

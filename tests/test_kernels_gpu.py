@@ -260,8 +260,8 @@ def test_attention(ops, orc, B, L, past, hd, nh, causal, pads):
 @pytest.mark.parametrize("B,L,past,nh,n_split,pads", [(1, 1, 300, 4, 5, None), (2, 1, 63, 2, 1, [0, 7]), (1, 6, 130, 2, 3, None),
                                                       (3, 1, 2000, 2, 32, [0, 100, 1999]), (1, 16, 0, 2, 2, None),
                                                       (2, 4, 61, 2, 2, [0, 7]), (2, 5, 20, 2, 1, [3, 0]), (1, 3, 700, 2, 3, None)])
-@pytest.mark.parametrize("dev_past", [True, False])
-def test_attention_decode_fused(ops, orc, B, L, past, nh, n_split, pads, dev_past):
+@pytest.mark.parametrize("dev_past,fused_merge", [(True, True), (False, False), (True, False)])
+def test_attention_decode_fused(ops, orc, B, L, past, nh, n_split, pads, dev_past, fused_merge):
     """Fused split + RoPE + KV append + split-KV attention vs the oracle's rotate_half / cache / softmax."""
     from phi_3_vision_mlx_amd.config import make_config, rope_scaling_factor
     cfg = make_config()
@@ -277,12 +277,14 @@ def test_attention_decode_fused(ops, orc, B, L, past, nh, n_split, pads, dev_pas
     out = torch.empty((B, L, nh * hd), dtype=BF16).cuda()
     ws = torch.empty(ops.attention_ws_bytes(B, L, nh, hd, n_split) // 4, dtype=F32).cuda()
     d_past = torch.tensor([past], dtype=torch.int32).cuda()
+    cnt = torch.zeros(B * nh * n_split, dtype=torch.int32).cuda() if fused_merge else None
     cos_s = torch.empty((B, L, hd // 2), dtype=F32).cuda()
     sin_s = torch.empty_like(cos_s)
     ops.stage_rope(cos.view(B, T, -1), sin.view(B, T, -1), cos_s, sin_s, B, L, T, d_past=d_past)
     assert torch.equal(cos_s.cpu(), cos.view(B, T, -1)[:, past:past + L].cpu())
     ops.attention_decode(qkv.cuda(), cos_s, sin_s, L, kcc, vcc, out, B, L, nh, nh, hd, hd ** -0.5, 0 if dev_past else past, T, ws,
-                         n_split, pad_len=pad.cuda() if pads else None, d_past=d_past if dev_past else None)
+                         n_split, pad_len=pad.cuda() if pads else None, d_past=d_past if dev_past else None, counters=cnt)
+    assert cnt is None or (cnt == 0).all()                     # every launch leaves the ready flags at zero
     x = qkv.view(B, L, 3 * nh, hd).transpose(1, 2)
     cs, sn = cos_ref[:, :, past:past + L], sin_ref[:, :, past:past + L]
     q = orc.rotate_half(x[:, :nh], cs, sn).to(BF16)
