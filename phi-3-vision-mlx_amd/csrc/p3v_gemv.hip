@@ -22,12 +22,19 @@ struct GemvP {
   int M, N, K, epi, units;
 };
 
+// 8 bf16 x 8 bf16 -> fp32 accumulate on v_dot2c_f32_bf16 (two products per instruction straight from the packed
+// operands): 4 VALU instructions per 16-byte weight chunk instead of 8 unpacks + 8 FMAs -- the GEMV's VALU pipe was
+// ~60 % busy with unpacking before.
+// (The pairs are taken with shufflevector from an 8 x bf16 view: hipcc 7.2 folds `bit_cast<2 x bf16>(w[j])` of the four
+// dwords of a u32x4 into element 0 -- same family of bug as the permlane-swap fold noted in p3v_common.h.)
+typedef __bf16 bf16pair_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16oct_t __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ float dot8(u32x4_t w, u32x4_t x, float acc) {
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    acc = fmaf(bf16lo(w[j]), bf16lo(x[j]), acc);
-    acc = fmaf(bf16hi(w[j]), bf16hi(x[j]), acc);
-  }
+  const bf16oct_t wv = __builtin_bit_cast(bf16oct_t, w), xv = __builtin_bit_cast(bf16oct_t, x);
+  acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(wv, wv, 0, 1), __builtin_shufflevector(xv, xv, 0, 1), acc, false);
+  acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(wv, wv, 2, 3), __builtin_shufflevector(xv, xv, 2, 3), acc, false);
+  acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(wv, wv, 4, 5), __builtin_shufflevector(xv, xv, 4, 5), acc, false);
+  acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(wv, wv, 6, 7), __builtin_shufflevector(xv, xv, 6, 7), acc, false);
   return acc;
 }
 
