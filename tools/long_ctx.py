@@ -7,7 +7,9 @@ from phi_3_vision_mlx_amd.api import load_synthetic
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 32768
 model, _ = load_synthetic(blind_model=True, device="cuda:0", use_quantized_cache=bool(os.environ.get("P3V_QCACHE")), quantized_fp8=bool(os.environ.get("P3V_FP8")))
 ids = np.random.default_rng(0).integers(3, 32000, (1, S))
-for rep in range(2):
+lg = cache = None
+for rep in range(3):
+    lg = cache = None                                          # release the previous cache first: the timed call must reuse its blocks
     torch.cuda.synchronize(); t0 = time.perf_counter()
     lg, cache = model(input_ids=ids, max_tokens=136)
     tok = ops.argmax(lg[:, -1].contiguous())[:, None]; tok.tolist()
