@@ -182,6 +182,12 @@ typedef struct {
                         attention launch; NULL = a separate merge launch */
 } p3v_attn_decode_args_t;
 int p3v_attention_decode(const p3v_attn_decode_args_t* args /* host */, void* stream);
+/* Fused launch of a decode step's qkv projection AND the attention that consumes it (B = 1, L = 1, one tile per
+ * split): `qkv_proj` as for p3v_gemv (M = 1, K = 3072, norm_w given, plain epilogue, out == attn->qkv), `attn` as for
+ * p3v_attention_decode with `counters` set.  `flags`: p3v_qkv_attention_decode_flags(N) int32, ALL ZERO on entry (the
+ * GEMV workgroups raise them, nobody clears them: p3v_step_begin zeroes the per-layer arrays once per step). */
+int p3v_qkv_attention_decode_flags(int n_qkv_rows);
+int p3v_qkv_attention_decode(const p3v_gemv_args_t* qkv_proj, const p3v_attn_decode_args_t* attn, int32_t* flags, void* stream);
 /* cos/sin rows of positions [past, past+L) of each batch row ([B, tab_t, half] tables) -> [B, L, half] */
 int p3v_stage_rope(const float* cos_t, const float* sin_t, int past, const int32_t* d_past,
                    float* cos_out, float* sin_out, int B, int L, int tab_t, int half_dim, void* stream);
@@ -200,9 +206,6 @@ typedef struct {
   const int32_t* pad_len; const int32_t* d_past; float* ws;
   int B, L, n_heads, n_kv, hd, past, cache_t, rope_bstride, n_split;
   float scale;
-  int32_t* counters; /* optional [B * n_heads * n_split] int32, zero-initialised ONCE by the caller (every launch leaves it
-                        zero): the split-KV partials are then merged by the last split of each (b, head) inside the
-                        attention launch; NULL = a separate merge launch */
 } p3v_attn_decode_q8_args_t;
 int p3v_attention_decode_q8(const p3v_attn_decode_q8_args_t* args /* host */, void* stream);
 
@@ -244,7 +247,8 @@ int p3v_store_token(const int32_t* tok, int32_t* history, const int32_t* d_step,
  * rows of position *d_past -> cos_out/sin_out [B, 1, half] (p3v_stage_rope with L = 1) */
 int p3v_step_begin(const int32_t* tok, const uint16_t* table, uint16_t* x_out, const float* cos_t, const float* sin_t,
                    const int32_t* d_past, float* cos_out, float* sin_out, int B, int hidden, int vocab, int tab_t,
-                   int half_dim, void* stream);
+                   int half_dim, int32_t* zero_buf /* optional: n_zero int32 cleared (in-launch flags of the step) */,
+                   int n_zero, void* stream);
 /* fused tail: next_tok[b] = tok[b] = argmax(logits[b]) (phi_3_vision_mlx.py:392), history[b, *d_step] = it,
  * then *d_step += 1 and *d_past += 1 (done once, by the last workgroup; `ticket` is a zero-initialised int32) */
 int p3v_step_end(const uint16_t* logits, int32_t* next_tok, int32_t* tok, int32_t* history, int32_t* d_step,

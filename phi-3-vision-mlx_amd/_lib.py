@@ -91,7 +91,9 @@ SIGNATURES = {
     "p3v_store_token": (i32, [vp, vp, vp, vp, i32, i32, vp]),
     "p3v_lora_down": (i32, [vp, vp, vp, i32, i32, i32, vp]),
     "p3v_lora_up": (i32, [vp, vp, vp, f32, i32, vp, vp, i32, i32, i32, vp]),
-    "p3v_step_begin": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
+    "p3v_step_begin": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, i32, vp]),
+    "p3v_qkv_attention_decode_flags": (i32, [i32]),
+    "p3v_qkv_attention_decode": (i32, [vp, vp, vp, vp]),
     "p3v_step_end": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]),
     "p3v_graph_begin": (i32, [vp]),
     "p3v_graph_end": (i32, [vp, C.POINTER(vp)]),

@@ -328,6 +328,17 @@ class Phi3VModel:
             v_new = torch.zeros((B, nkv, hd, Lp), dtype=BF16, device=self.device)
         for i in range(cfg.num_hidden_layers):
             p = f"model.layers.{i}."
+            fused_qkv = (d_past is not None and M == 1 and not st.quantized and bufs.get("qkv_flags") is not None
+                         and bufs.get("attn_cnt") is not None and (p + "self_attn.qkv_proj.weight") in w
+                         and (p + "self_attn.qkv_proj.weight") not in self.adapters and cfg.hidden_size == 3072)
+            if fused_qkv:                                       # ONE launch: RMSNorm + qkv projection + decode attention
+                ops.qkv_attention_decode(x, w[p + "self_attn.qkv_proj.weight"], w[p + "input_layernorm.weight"], eps, qkv,
+                                         bufs["rope_cos"], bufs["rope_sin"], L, st.k[i], st.v[i], o, nh, nkv, hd, scale, past, st.Tp,
+                                         ws, n_split, bufs["attn_cnt"], bufs["qkv_flags"][i], d_past=d_past, pad_len=st.pad_len)
+                self._proj(o, p + "self_attn.o_proj.weight", EPI_RESID_BF16, resid=x, out=x)
+                self._proj(x, p + "mlp.gate_up_proj.weight", EPI_SILU_MUL, norm_w=w[p + "post_attention_layernorm.weight"], out=a, h=h)
+                self._proj(a, p + "mlp.down_proj.weight", EPI_RESID_BF16, resid=x, out=x)
+                continue
             self._proj(x, p + "self_attn.qkv_proj.weight", norm_w=w[p + "input_layernorm.weight"], out=qkv, h=h)
             if st.quantized:
                 if L <= ops.L.DECODE_MAX_L:
@@ -378,13 +389,20 @@ class Phi3VModel:
                  next_tok=torch.zeros((B,), dtype=I32, device=dev), ticket=torch.zeros((1,), dtype=I32, device=dev))
         bufs = self._alloc_bufs(B, 1)
         self._split_plan(bufs, B, 1, st.T)
+        # Fused qkv-projection + attention launch (p3v_qkv_attention_decode): bit-identical, but OFF by default -- measured
+        # 31.7 us against 11.2 + 14.7 us for the two launches: a kernel's registers are sized for its hungriest role (the
+        # GEMV's 144 VGPRs), which leaves 3 workgroups per CU, so only 384 of the 1312 attention workgroups are resident
+        # while the GEMV streams and the K/V prefetch cannot overlap it.
+        if B == 1 and not st.quantized and not self.w8 and os.environ.get("P3V_FUSED_QKV_ATTN", "0") == "1":
+            nf = ops.qkv_attention_decode_flags((cfg.num_attention_heads + 2 * cfg.num_key_value_heads) * self.hd)
+            bufs["qkv_flags"] = torch.zeros((cfg.num_hidden_layers, nf), dtype=I32, device=dev)   # cleared by step_begin every step
         bufs["rope_cos"] = torch.empty((B, 1, self.hd // 2), dtype=F32, device=dev)
         bufs["rope_sin"] = torch.empty_like(bufs["rope_cos"])
         g["bufs"] = bufs
 
         def step():
             ops.step_begin(g["tok"], w["model.embed_tokens.weight"], g["x"], st.cos, st.sin, g["d_past"],
-                           bufs["rope_cos"], bufs["rope_sin"])
+                           bufs["rope_cos"], bufs["rope_sin"], zero_buf=bufs.get("qkv_flags"))
             self._layers(g["x"], st, B, 1, 0, 1, bufs=bufs, d_past=g["d_past"])
             self._proj(g["x"], "lm_head.weight", norm_w=w["model.norm.weight"], out=g["logits"])
             ops.step_end(g["logits"], g["next_tok"], g["tok"], g["history"], g["d_step"], g["d_past"], g["ticket"])

@@ -282,11 +282,28 @@ def add_i32(x, delta):
     L.check(L.lib().p3v_add_i32(_p(x), x.numel(), int(delta), _stream()), "add_i32")
 
 
-def step_begin(tok, table, x_out, cos_t, sin_t, d_past, cos_out, sin_out):
-    """Head of a replayed greedy step: embedding rows of `tok` + rotation rows of position *d_past (one launch)."""
+def step_begin(tok, table, x_out, cos_t, sin_t, d_past, cos_out, sin_out, zero_buf=None):
+    """Head of a replayed greedy step: embedding rows of `tok` + rotation rows of position *d_past (one launch);
+    `zero_buf` (int32) is cleared as well (the in-launch producer flags of the step's fused launches)."""
     B, tab_t, half = tok.numel(), cos_t.shape[-2], cos_t.shape[-1]
     L.check(L.lib().p3v_step_begin(_p(tok), _p(table), _p(x_out), _p(cos_t), _p(sin_t), _p(d_past), _p(cos_out), _p(sin_out),
-                                   B, table.shape[1], table.shape[0], tab_t, half, _stream()), "step_begin")
+                                   B, table.shape[1], table.shape[0], tab_t, half, _p(zero_buf),
+                                   0 if zero_buf is None else zero_buf.numel(), _stream()), "step_begin")
+
+
+def qkv_attention_decode_flags(n_qkv_rows):
+    return L.lib().p3v_qkv_attention_decode_flags(int(n_qkv_rows))
+
+
+def qkv_attention_decode(x, w_qkv, norm_w, norm_eps, qkv, cos_new, sin_new, rope_bstride, k_cache, v_cache, out, nh, nkv, hd, scale,
+                         past, cache_t, ws, n_split, counters, flags, d_past=None, pad_len=None):
+    """ONE launch for RMSNorm + qkv projection + decode attention (B = 1, L = 1): `flags` must be all zero on entry."""
+    _chk(x, BF16, "x"), _chk(w_qkv, BF16, "w_qkv")
+    g = L.GemvArgs(_p(x), _p(w_qkv), _p(qkv), None, _p(norm_w), float(norm_eps), 1, w_qkv.shape[0], w_qkv.shape[1], EPI_NONE, None)
+    a = L.AttnDecArgs(_p(qkv), _p(cos_new), _p(sin_new), _p(k_cache), _p(v_cache), _p(out), _p(pad_len), _p(d_past), _p(ws),
+                      1, 1, nh, nkv, hd, int(past), cache_t, rope_bstride, n_split, float(scale), _p(counters))
+    L.check(L.lib().p3v_qkv_attention_decode(C.byref(g), C.byref(a), _p(flags), _stream()), "qkv_attention_decode")
+    return out
 
 
 def step_end(logits, next_tok, tok, history, d_step, d_past, ticket):

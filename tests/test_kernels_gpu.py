@@ -480,3 +480,37 @@ def test_lora_down_up(ops, M, K, N, r):
     gate, up = v[:, :N // 2], v[:, N // 2:]
     act = gate * torch.sigmoid(gate)
     close(ops.lora_up(y.cuda(), t, b.cuda(), scale, EPI_SILU_MUL), act * up, rtol=2 ** -6, atol=2e-2)
+
+
+@pytest.mark.parametrize("past", [10, 300, 1023])
+def test_fused_qkv_attention_decode_equals_separate_launches(ops, past):
+    """p3v_qkv_attention_decode (ONE launch, producer flags inside the launch) must equal RMSNorm+qkv GEMV followed by
+    p3v_attention_decode bit for bit: same arithmetic, only the synchronisation differs.  Repeated to shake out races."""
+    from phi_3_vision_mlx_amd.ops import EPI_NONE
+    nh, hd, H = 32, 96, 3072
+    T = (past + 1 + 63) // 64 * 64
+    n_split = T // 64
+    x, nw = g((1, H), 200), g((H,), 201) * 0.1 + 1
+    wq = g((3 * nh * hd, H), 202, 0.02).cuda()
+    kc, vc = g((1, nh, T, hd), 203), g((1, nh, hd, T), 204)
+    cos_s, sin_s = torch.rand((1, 1, hd // 2), dtype=F32).cuda(), torch.rand((1, 1, hd // 2), dtype=F32).cuda()
+    d_past = torch.tensor([past], dtype=torch.int32).cuda()
+    ws = torch.empty(ops.attention_ws_bytes(1, 1, nh, hd, n_split) // 4, dtype=F32).cuda()
+    cnt = torch.zeros(nh * n_split, dtype=torch.int32).cuda()
+    # reference: two launches
+    k1, v1 = kc.cuda(), vc.cuda()
+    qkv1 = ops.gemv(x.cuda(), wq, EPI_NONE, norm_w=nw.cuda(), norm_eps=1e-5)
+    out1 = torch.empty((1, 1, nh * hd), dtype=BF16).cuda()
+    ops.attention_decode(qkv1, cos_s, sin_s, 1, k1, v1, out1, 1, 1, nh, nh, hd, hd ** -0.5, 0, T, ws, n_split, d_past=d_past, counters=cnt)
+    nf = ops.qkv_attention_decode_flags(3 * nh * hd)
+    for rep in range(6):
+        k2, v2 = kc.cuda(), vc.cuda()
+        qkv2 = torch.zeros_like(qkv1)
+        out2 = torch.zeros_like(out1)
+        flags = torch.zeros(nf, dtype=torch.int32).cuda()
+        ops.qkv_attention_decode(x.cuda(), wq, nw.cuda(), 1e-5, qkv2, cos_s, sin_s, 1, k2, v2, out2, nh, nh, hd, hd ** -0.5, 0, T, ws,
+                                 n_split, cnt, flags, d_past=d_past)
+        torch.cuda.synchronize()
+        assert (flags == 1).all() and (cnt == 0).all()
+        assert torch.equal(qkv2, qkv1) and torch.equal(out2, out1), rep
+        assert torch.equal(k2, k1) and torch.equal(v2, v1)
