@@ -139,7 +139,7 @@ def main():
     rng = np.random.default_rng(rank)
     img = Image.fromarray(rng.integers(0, 256, (336, 336, 3), dtype=np.uint8))
     t0 = time.perf_counter()
-    image_inputs = processor.img_processor([img])
+    image_inputs = processor.img_processor([img], dtype=np.float32)   # what processor(...) does with return_mx (the default)
     pixel_values = processor._to_device(image_inputs["pixel_values"])      # f64 -> f32 device tensor, as the processor's
     torch.cuda.synchronize()                                               # `mx.array(images)` (phi.py:279): before the timer
     host_pre_ms = (time.perf_counter() - t0) * 1e3
