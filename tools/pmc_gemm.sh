@@ -5,7 +5,8 @@ export TMPDIR=/tmp
 OUT=$PWD/gpurun_out/pmcg_$TAG
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp
-for grp in "SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "SQ_WAVE_CYCLES SQ_WAIT_INST_LDS" "SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_ACTIVE_INST_LDS"; do
+PMCG=("SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "SQ_WAVE_CYCLES SQ_WAIT_INST_LDS" "SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_ACTIVE_INST_LDS" "SQ_WAIT_ANY SQ_WAIT_INST_ANY" "SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU")
+for grp in "${PMCG[@]}"; do
   name=$(echo $grp | tr ' ' '+')
   timeout 120 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $OUT/$name -o c -- python3 $GRAFT_REPO_ROOT/tools/pmc_gemm.py > $OUT/$name.log 2>&1
 done
