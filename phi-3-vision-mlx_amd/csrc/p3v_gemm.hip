@@ -125,25 +125,31 @@ __global__ void __launch_bounds__(256, 2) k_gemm(GemmP p) {
     if (kt + 1 < nk) stage(kt + 1, (kt + 1) & 1);
     const unsigned char* ta = smem + (kt & 1) * (2 * TILE_BYTES);
     const unsigned char* tb = ta + TILE_BYTES;
+    // All 16 fragment reads of the K-tile are requested up front (64 VGPRs) and the MFMAs of the first k-step start as
+    // soon as ITS eight have landed (LDS returns in order -> counted lgkmcnt): one exposed LDS latency per K-tile instead
+    // of four (hipcc otherwise recycles two A registers and waits lgkmcnt(0) before every run of eight MFMAs).
+    bf16x8_t af[2][4], bfr[2][4];
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
-      bf16x8_t af[4], bfr[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int r = wr * 64 + i * 16 + frow;
-        af[i] = *(const bf16x8_t*)(ta + r * 128 + (((kk * 4 + fchunk) ^ (r & 7)) << 4));
+        af[kk][i] = *(const bf16x8_t*)(ta + r * 128 + (((kk * 4 + fchunk) ^ (r & 7)) << 4));
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int r = wc * 64 + j * 16 + frow;
-        bfr[j] = *(const bf16x8_t*)(tb + r * 128 + (((kk * 4 + fchunk) ^ (r & 7)) << 4));
+        bfr[kk][j] = *(const bf16x8_t*)(tb + r * 128 + (((kk * 4 + fchunk) ^ (r & 7)) << 4));
       }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
-    }
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[kk][i], bfr[kk][j], acc[i][j], 0, 0, 0);
   }
 
   // ---- epilogue: MFMA C layout (col = lane&15, row = (lane>>4)*4 + r) -> wave-private LDS tile -> rows of 8 columns
