@@ -98,6 +98,11 @@ typedef struct {
   float* ws;              /* reserved (optional scratch, p3v_gemv_ws_bytes(M, N, K) bytes; currently 0) */
 } p3v_gemv_args_t;
 int p3v_gemv(const p3v_gemv_args_t* args /* host */, void* stream);
+/* Up to 4 DEPENDENT M = 1 projections (stage i reads what stage i-1 wrote: decode's o_proj -> gate_up -> down -> next
+ * qkv) in ONE launch.  Every stage: K = 3072 or 8192, N even, epilogue NONE / RESID_BF16 / SILU_MUL.  `counters`:
+ * n_stages * 1024 int32 (16 arrival counters per stage, one per 256-byte line), ALL ZERO on entry (arrival counters of the stages; nobody clears them -- p3v_step_begin zeroes
+ * the per-layer arrays once per step).  Results equal n_stages p3v_gemv calls bit for bit. */
+int p3v_gemv_chain(const p3v_gemv_args_t* stages /* host array */, int n_stages, int32_t* counters, void* stream);
 int64_t p3v_gemv_ws_bytes(int M, int N, int K);
 
 /* ---- fp8 (OCP e4m3fn) weight-only projections (quantize_model=True; replaces the int4 `nn.quantize` of

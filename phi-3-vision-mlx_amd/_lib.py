@@ -92,6 +92,7 @@ SIGNATURES = {
     "p3v_lora_down": (i32, [vp, vp, vp, i32, i32, i32, vp]),
     "p3v_lora_up": (i32, [vp, vp, vp, f32, i32, vp, vp, i32, i32, i32, vp]),
     "p3v_step_begin": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, i32, vp]),
+    "p3v_gemv_chain": (i32, [vp, i32, vp, vp]),
     "p3v_qkv_attention_decode_flags": (i32, [i32]),
     "p3v_qkv_attention_decode": (i32, [vp, vp, vp, vp]),
     "p3v_step_end": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]),

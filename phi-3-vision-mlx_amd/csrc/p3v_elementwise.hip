@@ -513,10 +513,11 @@ __global__ void __launch_bounds__(128) k_step_begin(const int32_t* __restrict__ 
                                                     const float* __restrict__ cos_t, const float* __restrict__ sin_t,
                                                     const int32_t* __restrict__ d_past, float* __restrict__ cos_o,
                                                     float* __restrict__ sin_o, int tab_t, int half,
-                                                    int32_t* __restrict__ zero_buf, int n_zero) {
+                                                    int32_t* __restrict__ zero_buf, int n_zero, int n_rows) {
   const int b = blockIdx.x;
-  const int past = *d_past;
   for (int i = b * blockDim.x + threadIdx.x; i < n_zero; i += gridDim.x * blockDim.x) zero_buf[i] = 0;
+  if (b >= n_rows) return;                   // extra workgroups only help clearing zero_buf
+  const int past = *d_past;
   int id = ids[b];
   id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
   const u32x4_t* src = table + (size_t)id * chunks;
@@ -533,8 +534,9 @@ extern "C" int p3v_step_begin(const int32_t* tok, const uint16_t* table, uint16_
                               int vocab, int tab_t, int half_dim, int32_t* zero_buf, int n_zero, void* stream) {
   if (!tok || !table || !x_out || !cos_t || !sin_t || !d_past || !cos_out || !sin_out) return P3V_ERR_ARG;
   if (B <= 0 || hidden % 8 || vocab <= 0 || tab_t <= 0 || half_dim <= 0) return P3V_ERR_ARG;
-  hipLaunchKernelGGL(k_step_begin, dim3(B), dim3(128), 0, (hipStream_t)stream, tok, (const u32x4_t*)table, (u32x4_t*)x_out,
-                     hidden / 8, vocab, cos_t, sin_t, d_past, cos_out, sin_out, tab_t, half_dim, zero_buf, zero_buf ? n_zero : 0);
+  const int n_wg = zero_buf && n_zero > 4096 ? (B > 128 ? B : 128) : B;
+  hipLaunchKernelGGL(k_step_begin, dim3(n_wg), dim3(128), 0, (hipStream_t)stream, tok, (const u32x4_t*)table, (u32x4_t*)x_out,
+                     hidden / 8, vocab, cos_t, sin_t, d_past, cos_out, sin_out, tab_t, half_dim, zero_buf, zero_buf ? n_zero : 0, B);
   P3V_CHECK_LAUNCH();
   return P3V_OK;
 }

@@ -128,6 +128,17 @@ def lora_up(y, t, lora_b, scale, epilogue=EPI_NONE, resid=None, out=None):
     return out
 
 
+def gemv_chain(stages, counters):
+    """Dependent M = 1 projections in ONE launch: stages = [(x, w, epilogue, resid, norm_w, norm_eps, out), ...] (at most 4,
+    K in {3072, 8192}); `counters` int32 [>= 1024 * len(stages)], all zero on entry."""
+    arr = (L.GemvArgs * len(stages))()
+    for i, (x, w, epi, resid, norm_w, eps, out) in enumerate(stages):
+        _chk(x, BF16, "x"), _chk(w, BF16, "w")
+        N = w.shape[0] // 2 if epi == EPI_SILU_MUL else w.shape[0]
+        arr[i] = L.GemvArgs(_p(x), _p(w), _p(out), _p(resid), _p(norm_w), float(eps), 1, N, w.shape[1], epi, None)
+    L.check(L.lib().p3v_gemv_chain(arr, len(stages), _p(counters), _stream()), "gemv_chain")
+
+
 def quantize_fp8_rows(w):
     """bf16 [N,K] -> (u8 e4m3fn bit patterns [N,K], fp32 scale [N]); w ~ fp8 * scale.  Load-time weight prep."""
     wf = w.float()

@@ -514,3 +514,28 @@ def test_fused_qkv_attention_decode_equals_separate_launches(ops, past):
         assert (flags == 1).all() and (cnt == 0).all()
         assert torch.equal(qkv2, qkv1) and torch.equal(out2, out1), rep
         assert torch.equal(k2, k1) and torch.equal(v2, v1)
+
+
+def test_gemv_chain_equals_separate_launches(ops):
+    """p3v_gemv_chain (o_proj -> gate_up -> down -> next qkv in ONE launch, arrival counters between the stages) must equal
+    four p3v_gemv launches bit for bit; repeated to shake out ordering races."""
+    from phi_3_vision_mlx_amd.ops import EPI_NONE, EPI_RESID_BF16, EPI_SILU_MUL
+    H, I = 3072, 8192
+    wo, wgu, wd, wq = g((H, H), 300, 0.02).cuda(), g((2 * I, H), 301, 0.02).cuda(), g((H, I), 302, 0.02).cuda(), g((3 * H, H), 303, 0.02).cuda()
+    n1, n2 = (g((H,), 304) * 0.1 + 1).cuda(), (g((H,), 305) * 0.1 + 1).cuda()
+    o, x0 = g((1, H), 306).cuda(), g((1, H), 307).cuda()
+    # reference: four launches
+    x = ops.gemv(o, wo, EPI_RESID_BF16, resid=x0.clone())
+    a = ops.gemv(x, wgu, EPI_SILU_MUL, norm_w=n1, norm_eps=1e-5)
+    x2 = ops.gemv(a, wd, EPI_RESID_BF16, resid=x)
+    q = ops.gemv(x2, wq, EPI_NONE, norm_w=n2, norm_eps=1e-5)
+    for rep in range(8):
+        xc = x0.clone()
+        ac, qc = torch.zeros_like(a), torch.zeros_like(q)
+        cnt = torch.zeros(4096, dtype=torch.int32).cuda()
+        ops.gemv_chain([(o, wo, EPI_RESID_BF16, xc, None, 0.0, xc), (xc, wgu, EPI_SILU_MUL, None, n1, 1e-5, ac),
+                        (ac, wd, EPI_RESID_BF16, xc, None, 0.0, xc), (xc, wq, EPI_NONE, None, n2, 1e-5, qc)], cnt)
+        torch.cuda.synchronize()
+        assert torch.equal(ac, a), rep
+        assert torch.equal(xc, x2) and torch.equal(qc, q), rep
+        assert cnt.view(4, 1024).sum(1).tolist() == [384, 512, 384, 384]
