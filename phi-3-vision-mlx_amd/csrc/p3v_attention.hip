@@ -708,29 +708,35 @@ __device__ __forceinline__ float ld_wt(const float* p) { return __hip_atomic_loa
 // the one with the highest split index.  Workgroups are dispatched in linear order, so by the time it runs every
 // other split of its (b, head) is resident or finished and the wait below cannot deadlock; the spin is bounded anyway.
 // No atomics: 41 read-modify-writes on one address from eight XCDs serialise into microseconds.
-__device__ __forceinline__ bool split_publish_and_wait(int32_t* flags, int split, int n_split) {
+// Returns 0 (not the merging workgroup), 1 (merge) or 2 (merge, but the bounded wait ran out: the caller then writes
+// NaN so that the failure is loud instead of a silently wrong token).
+__device__ __forceinline__ int split_publish_and_wait(int32_t* flags, int split, int n_split) {
+  __shared__ int s_timeout;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this thread's partial stores have been performed
+  if (threadIdx.x == 0) s_timeout = 0;
   __syncthreads();
   if (split != n_split - 1) {
     if (threadIdx.x == 0) __hip_atomic_store(flags + split, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return false;
+    return 0;
   }
   if (threadIdx.x < 64) {
-    for (unsigned spins = 0; spins < (1u << 22); ++spins) {
+    bool done = false;
+    for (unsigned spins = 0; spins < (1u << 22) && !done; ++spins) {
       bool ok = true;
       for (int s = threadIdx.x; s < n_split - 1; s += 64)
         ok &= __hip_atomic_load(flags + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
-      if (__all(ok)) break;
+      done = __all(ok);
     }
+    if (!done && threadIdx.x == 0) s_timeout = 1;
   }
   __syncthreads();
-  return true;
+  return 1 + s_timeout;
 }
 
 // merge of the n_split partials of one (b, head) by the calling workgroup (NT threads = G groups of 64 lanes)
 template <int NT>
 __device__ __forceinline__ void split_merge(const float* base0, bf16_t* out0, size_t out_qstride, int L, int n_split,
-                                            int32_t* flags) {
+                                            int32_t* flags, bool poison) {
   constexpr int HD = 96, G = NT / 64;
   __shared__ float pm[G], pl[G];
   __shared__ float part[G][128];
@@ -770,10 +776,10 @@ __device__ __forceinline__ void split_merge(const float* base0, bf16_t* out0, si
           acc += c * part[k][t];
           lsum += c * pl[k];
         }
-        out0[(size_t)q * out_qstride + t] = f32_to_bf16(lsum > 0.f ? acc / lsum : 0.f);
+        out0[(size_t)q * out_qstride + t] = poison ? (bf16_t)0x7fc0 : f32_to_bf16(lsum > 0.f ? acc / lsum : 0.f);
       }
     } else {
-      const float inv = l > 0.f ? 1.f / l : 0.f;
+      const float inv = poison ? __builtin_nanf("") : (l > 0.f ? 1.f / l : 0.f);
       out0[(size_t)q * out_qstride + d0] = f32_to_bf16(a0 * inv);
       if (two) out0[(size_t)q * out_qstride + d0 + 64] = f32_to_bf16(a1 * inv);
     }
@@ -1091,9 +1097,10 @@ __device__ __forceinline__ void attn_decode_body(const AttnDecP& p, const int bx
   }
   DBG_T(7);
   int32_t* flags = p.counters + ((size_t)b * p.nh + head) * p.n_split;
-  if (p.counters && split_publish_and_wait(flags, bx, p.n_split))
+  const int role = p.counters ? split_publish_and_wait(flags, bx, p.n_split) : 0;
+  if (role)
     split_merge<256>(p.ws + ((size_t)b * p.nh + head) * p.n_split * 16 * (HD + 2), p.out + (size_t)b * p.L * (p.nh * HD) + head * HD,
-                     (size_t)p.nh * HD, p.L, p.n_split, flags);
+                     (size_t)p.nh * HD, p.L, p.n_split, flags, role == 2);
 }
 
 __global__ void __launch_bounds__(256) k_attn_decode(AttnDecP p) {
@@ -1335,9 +1342,10 @@ __global__ void __launch_bounds__(64) k_attn_decode_stream(AttnDecP p) {
     if (g == 0) { st_wt(w + HD, m_run); st_wt(w + HD + 1, l_run); }
   }
   int32_t* flags = p.counters + ((size_t)b * p.nh + head) * p.n_split;
-  if (p.counters && split_publish_and_wait(flags, blockIdx.x, p.n_split))
+  const int role = p.counters ? split_publish_and_wait(flags, blockIdx.x, p.n_split) : 0;
+  if (role)
     split_merge<64>(p.ws + ((size_t)b * p.nh + head) * p.n_split * 16 * (HD + 2), p.out + (size_t)b * p.L * (p.nh * HD) + head * HD,
-                    (size_t)p.nh * HD, p.L, p.n_split, flags);
+                    (size_t)p.nh * HD, p.L, p.n_split, flags, role == 2);
 }
 
 // merge split-KV partials: one block of G = 4 or 8 64-lane groups per (b, head, query): thread (grp, d) loads
