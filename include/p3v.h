@@ -232,6 +232,21 @@ int p3v_log_softmax(const uint16_t* x, uint16_t* y, int rows, int n, void* strea
 /* ---- top-k (k<=8) by (-value, index), replaces mx.argpartition phi_3_vision_mlx.py:507 */
 int p3v_topk(const uint16_t* x, int32_t* idx_out, int rows, int n, int k, int64_t row_stride, void* stream);
 
+/* ---- on-device image preprocessing (Phi3VImageProcessor, phi.py:283-372), bit-compatible with the host path.
+ * p3v_resample_u8: one pass of Pillow's 8-bit ImagingResample (what `img.resize(..., Image.BILINEAR)` phi.py:301 runs):
+ *   in [outer, in_len, inner] u8 -> out [outer, out_len, inner]; coeffs [out_len, ksize] 22-bit fixed point and
+ *   bounds [out_len, 2] = (first input index, tap count) are computed on the host (processor.pil_bilinear_coeffs).
+ *   Horizontal pass: outer = rows, inner = 3; vertical pass: outer = 1, inner = 3 * width.
+ * p3v_hd_preprocess: resized image [rh, rw, 3] u8 -> pixel_values [n_slots, 3, 336, 336] f32: white padding of `top` rows
+ *   above / (hp - rh - top) below (phi.py:302-306), transpose back if `portrait` (:307-308), normalisation through
+ *   lut [3][256] f64 = (v / 255 - mean) / std (:309), crop grid into slots 1.. (:313-314), degenerate-bicubic global view
+ *   into slot 0 with taps hw/ww [336][2] f32, hi/wi [336][2] i32 (:331-372), remaining slots zero (:315-316). */
+int p3v_resample_u8(const uint8_t* in, uint8_t* out, int outer, int in_len, int out_len, int inner,
+                    const int32_t* coeffs, const int32_t* bounds, int ksize, void* stream);
+int p3v_hd_preprocess(const uint8_t* resized, int rh, int rw, int top, int hp, int portrait, const double* lut,
+                      const float* hw, const int32_t* hi, const float* ww, const int32_t* wi, float* pixel_values,
+                      int n_slots, void* stream);
+
 /* ---- LoRA adapter inference, LoRALinear.__call__ (phi.py:129-133):
  *   y = linear(x); z = (x @ lora_a) @ lora_b; out = (y + scale*z).astype(bf16),  scale = cfg.scale * alpha / rank (phi.py:120)
  * lora_a [K, r] and lora_b [r, N] are the fp32 tensors of adapters.safetensors, r <= 64.

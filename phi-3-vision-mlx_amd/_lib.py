@@ -89,6 +89,8 @@ SIGNATURES = {
     "p3v_topk": (i32, [vp, vp, i32, i32, i32, i64, vp]),
     "p3v_add_i32": (i32, [vp, i32, i32, vp]),
     "p3v_store_token": (i32, [vp, vp, vp, vp, i32, i32, vp]),
+    "p3v_resample_u8": (i32, [vp, vp, i32, i32, i32, i32, vp, vp, i32, vp]),
+    "p3v_hd_preprocess": (i32, [vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, i32, vp]),
     "p3v_lora_down": (i32, [vp, vp, vp, i32, i32, i32, vp]),
     "p3v_lora_up": (i32, [vp, vp, vp, f32, i32, vp, vp, i32, i32, i32, vp]),
     "p3v_step_begin": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, i32, vp]),

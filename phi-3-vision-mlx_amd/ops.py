@@ -105,6 +105,30 @@ def gemv(x, w, epilogue=EPI_NONE, resid=None, norm_w=None, norm_eps=0.0, out=Non
     return out
 
 
+def resample_u8(src, out_len, axis, coeffs, bounds):
+    """One pass of Pillow's 8-bit bilinear resample (phi.py:301) along `axis` (0 = rows, 1 = columns) of a uint8 image
+    [H, W, C]; coeffs [out_len, ksize] int32, bounds [out_len, 2] int32 (processor.pil_bilinear_coeffs)."""
+    _chk(src, torch.uint8, "src"), _chk(coeffs, I32, "coeffs"), _chk(bounds, I32, "bounds")
+    H, W, Cn = src.shape
+    if axis == 1:
+        out = torch.empty((H, out_len, Cn), dtype=torch.uint8, device=src.device)
+        outer, in_len, inner = H, W, Cn
+    else:
+        out = torch.empty((out_len, W, Cn), dtype=torch.uint8, device=src.device)
+        outer, in_len, inner = 1, H, W * Cn
+    L.check(L.lib().p3v_resample_u8(_p(src), _p(out), outer, in_len, out_len, inner, _p(coeffs), _p(bounds), coeffs.shape[1],
+                                    _stream()), "resample_u8")
+    return out
+
+
+def hd_preprocess(resized, top, hp, portrait, lut, hw, hi, ww, wi, out):
+    """Padded / transposed-back / normalised HD image -> crop slots + global view of `out` [n_slots, 3, 336, 336] f32."""
+    _chk(resized, torch.uint8, "resized"), _chk(lut, torch.float64, "lut"), _chk(out, F32, "out")
+    L.check(L.lib().p3v_hd_preprocess(_p(resized), resized.shape[0], resized.shape[1], int(top), int(hp), int(bool(portrait)), _p(lut),
+                                      _p(hw), _p(hi), _p(ww), _p(wi), _p(out), out.shape[0], _stream()), "hd_preprocess")
+    return out
+
+
 def lora_down(x, lora_a, out=None):
     """t = x @ lora_a  (first half of LoRALinear.__call__, phi.py:131): x [M,K] bf16, lora_a [K,r] f32 -> [M,r] f32."""
     _chk(x, BF16, "x"), _chk(lora_a, F32, "lora_a")

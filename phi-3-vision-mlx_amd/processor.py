@@ -135,6 +135,10 @@ class Phi3VProcessor(Phi3FProcessor):
     def __call__(self, texts, images=None):
         if images is None:
             return self._tokenize(texts)
+        if self.return_mx and os.environ.get("P3V_HOST_PREPROCESS") != "1":
+            import torch
+            if torch.cuda.is_available():                        # resize / pad / normalise / crop on the GPU, same bits
+                return self._merge(self.img_processor.device_call(images, f"cuda:{torch.cuda.current_device()}"), texts)
         return self._merge(self.img_processor(images, dtype=np.float32 if self.return_mx else np.float64), texts)
 
     def _to_device(self, pixel_values):
@@ -144,6 +148,8 @@ class Phi3VProcessor(Phi3FProcessor):
         if not self.return_mx:
             return pixel_values
         import torch
+        if torch.is_tensor(pixel_values):                        # already produced on the device (device_call)
+            return pixel_values
         t = torch.as_tensor(np.asarray(pixel_values), dtype=torch.float32)
         return t.cuda(non_blocking=True) if torch.cuda.is_available() else t
 
@@ -204,6 +210,30 @@ def _taps(scale, out_size, in_size):
     return w, idx
 
 
+def pil_bilinear_coeffs(in_size, out_size):
+    """Coefficients of Pillow's ImagingResample (libImaging/Resample.c: precompute_coeffs + normalize_coeffs_8bpc) for the
+    triangle filter `Image.BILINEAR` selects, restated: per output coordinate the first input index, the tap count and the
+    taps as 22-bit fixed point.  Same double-precision operations in the same order (the tap sum is accumulated tap by
+    tap), so the integers -- and with them the resized image -- equal Pillow's (tests/test_processor_golden.py)."""
+    scale = in_size / out_size
+    fs = max(scale, 1.0)
+    support = 1.0 * fs
+    ksize = int(np.ceil(support)) * 2 + 1
+    center = (np.arange(out_size) + 0.5) * scale
+    xmin = np.maximum(np.trunc(center - support + 0.5).astype(np.int64), 0)
+    xmax = np.minimum(np.trunc(center + support + 0.5).astype(np.int64), in_size) - xmin
+    ss = 1.0 / fs
+    w = np.zeros((out_size, ksize))
+    ww = np.zeros(out_size)
+    for x in range(ksize):
+        a = np.abs((x + xmin - center + 0.5) * ss)
+        w[:, x] = np.where((x < xmax) & (a < 1.0), 1.0 - a, 0.0)
+        ww = ww + w[:, x]
+    w = np.where(ww[:, None] != 0.0, w / np.where(ww == 0.0, 1.0, ww)[:, None], w)
+    kk = np.trunc(0.5 + w * (1 << 22)).astype(np.int32)
+    return kk, np.stack([xmin, xmax], axis=1).astype(np.int32)
+
+
 class Phi3VImageProcessor:
     """reference phi.py:283-372."""
 
@@ -260,6 +290,42 @@ class Phi3VImageProcessor:
             return wab * x[:, :, hi[:, a], :][:, :, :, wi[:, b]]      # fp32 x fp64 -> fp64
         out = 0.0 + ((term(0, 0) + term(0, 1)) + (term(1, 0) + term(1, 1)))
         return out.astype(x.dtype, copy=False)
+
+    def device_call(self, images, device):
+        """`__call__` with everything after the RGB conversion on the GPU (p3v_resample_u8 x 2, p3v_hd_preprocess):
+        pixel_values comes back as a float32 torch tensor on `device`, bit-identical to `__call__(..., dtype=float32)`."""
+        import torch
+        from . import ops
+        from PIL import Image
+        out = torch.empty((len(images), 17, 3, 336, 336), dtype=torch.float32, device=device)
+        lut = torch.as_tensor(np.ascontiguousarray(((np.arange(256)[:, None] / 255.0 - self.image_mean) / self.image_std).T)).to(device)
+        shapes = []
+
+        def dev(a):
+            return torch.as_tensor(np.ascontiguousarray(a)).to(device)
+        for n, img in enumerate(images):
+            a = np.asarray(img.convert("RGB"))
+            h, w = a.shape[:2]
+            portrait = w < h
+            if portrait:                                         # Image.TRANSPOSE (phi.py:295-297)
+                a = a.transpose(1, 0, 2)
+                h, w = a.shape[:2]
+            scale = int(np.sqrt(self.num_crops * w / h))
+            rw, rh = int(scale * 336), int(scale * 336 * h / w)
+            hp = int(np.ceil(rh / 336) * 336)
+            top = int((hp - rh) / 2)
+            t = dev(a)
+            if rw != w:
+                t = ops.resample_u8(t, rw, 1, *map(dev, pil_bilinear_coeffs(w, rw)))
+            if rh != h:
+                t = ops.resample_u8(t, rh, 0, *map(dev, pil_bilinear_coeffs(h, rh)))
+            H, W = (rw, hp) if portrait else (hp, rw)
+            hw, hi = _taps(336 / H, 336, H)
+            ww, wi = _taps(336 / W, 336, W)
+            ops.hd_preprocess(t, top, hp, portrait, lut, dev(hw[:, :2]), dev(hi[:, :2]), dev(ww[:, :2]), dev(wi[:, :2]), out[n])
+            shapes.append([H, W])
+        num_img_tokens = [int((h // 336 * w // 336 + 1) * 144 + 1 + (h // 336 + 1) * 12) for h, w in shapes]
+        return {"pixel_values": out, "image_sizes": shapes, "num_img_tokens": num_img_tokens}
 
     def __call__(self, images, dtype=np.float64):
         """-> pixel_values [n, 17, 3, 336, 336] `dtype` (float64 like the reference; float32 = the SAME values after the

@@ -539,3 +539,23 @@ def test_gemv_chain_equals_separate_launches(ops):
         assert torch.equal(ac, a), rep
         assert torch.equal(xc, x2) and torch.equal(qc, q), rep
         assert cnt.view(4, 1024).sum(1).tolist() == [384, 512, 384, 384]
+
+
+@pytest.mark.parametrize("w,h,kind,seed", [(336, 336, "noise", 0), (640, 480, "gradient", 1), (500, 1000, "noise", 2), (1600, 1200, "noise", 3),
+                                          (90, 61, "noise", 4)])
+def test_device_preprocessing_is_bit_identical_to_host(w, h, kind, seed):
+    """p3v_resample_u8 x 2 + p3v_hd_preprocess == the host image processor (itself sha256-pinned to the reference):
+    square, landscape, portrait (transposed path), down-scaled and tiny inputs."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import numpy as np
+    from golden_inputs import make_image
+    from phi_3_vision_mlx_amd.processor import Phi3VImageProcessor
+    p = Phi3VImageProcessor()
+    img = make_image(w, h, kind, seed)
+    host = p([img], dtype=np.float32)
+    dev = p.device_call([img], "cuda:0")
+    assert dev["image_sizes"] == host["image_sizes"] and dev["num_img_tokens"] == host["num_img_tokens"]
+    got = dev["pixel_values"].cpu().numpy()
+    assert got.dtype == np.float32 and got.shape == host["pixel_values"].shape
+    assert np.array_equal(got.view(np.uint32), host["pixel_values"].view(np.uint32))        # bit patterns, signed zeros included
