@@ -232,6 +232,21 @@ int p3v_log_softmax(const uint16_t* x, uint16_t* y, int rows, int n, void* strea
 /* ---- top-k (k<=8) by (-value, index), replaces mx.argpartition phi_3_vision_mlx.py:507 */
 int p3v_topk(const uint16_t* x, int32_t* idx_out, int rows, int n, int k, int64_t row_stride, void* stream);
 
+/* ---- 4-bit group-64 affine weights = the reference's `quantize_model=True` (nn.quantize(model, 64, 4),
+ * phi_3_vision_mlx.py:264,297-305; w = scale * q + bias per 64 input columns, mx.quantized_matmul).
+ * W [N or 2N, K/8] u32 in the DEVICE nibble order (weights 8d..8d+7 at bits 0,16,4,20,8,24,12,28 of dword d;
+ * weights.q4_repack converts MLX's sequential order), sb [N or 2N, K/64] u32 = scale bf16 | bias bf16 << 16.
+ * p3v_gemv_q4: decode projection, M = 1, K = 3072 or 8192, same norm / epilogue options as p3v_gemv.
+ * p3v_dequant_q4: -> bf16 [rows, K] (prefill / batched decode run the bf16 kernels on a dequantised scratch). */
+typedef struct {
+  const uint16_t* x; const uint32_t* W; const uint32_t* sb; void* out;
+  const uint16_t* resid; const uint16_t* norm_w; float norm_eps;
+  int M, N, K;
+  int epilogue;
+} p3v_gemv_q4_args_t;
+int p3v_gemv_q4(const p3v_gemv_q4_args_t* args /* host */, void* stream);
+int p3v_dequant_q4(const uint32_t* w4, const uint32_t* sb, uint16_t* out_bf16, int rows, int K, void* stream);
+
 /* ---- on-device image preprocessing (Phi3VImageProcessor, phi.py:283-372), bit-compatible with the host path.
  * p3v_resample_u8: one pass of Pillow's 8-bit ImagingResample (what `img.resize(..., Image.BILINEAR)` phi.py:301 runs):
  *   in [outer, in_len, inner] u8 -> out [outer, out_len, inner]; coeffs [out_len, ksize] 22-bit fixed point and

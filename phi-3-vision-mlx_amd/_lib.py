@@ -46,6 +46,11 @@ class AttnArgs(C.Structure):
                 ("causal", i32), ("scale", f32), ("n_split", i32), ("new_is_cache", i32)]
 
 
+class GemvQ4Args(C.Structure):
+    _fields_ = [("x", vp), ("W", vp), ("sb", vp), ("out", vp), ("resid", vp), ("norm_w", vp), ("norm_eps", f32),
+                ("M", i32), ("N", i32), ("K", i32), ("epilogue", i32)]
+
+
 class AttnDecArgs(C.Structure):
     _fields_ = [("qkv", vp), ("cos_t", vp), ("sin_t", vp), ("k_cache", vp), ("v_cache", vp), ("out", vp),
                 ("pad_len", vp), ("d_past", vp), ("ws", vp),
@@ -89,6 +94,8 @@ SIGNATURES = {
     "p3v_topk": (i32, [vp, vp, i32, i32, i32, i64, vp]),
     "p3v_add_i32": (i32, [vp, i32, i32, vp]),
     "p3v_store_token": (i32, [vp, vp, vp, vp, i32, i32, vp]),
+    "p3v_gemv_q4": (i32, [vp, vp]),
+    "p3v_dequant_q4": (i32, [vp, vp, vp, i32, i32, vp]),
     "p3v_resample_u8": (i32, [vp, vp, i32, i32, i32, i32, vp, vp, i32, vp]),
     "p3v_hd_preprocess": (i32, [vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, i32, vp]),
     "p3v_lora_down": (i32, [vp, vp, vp, i32, i32, i32, vp]),

@@ -8,7 +8,8 @@ reference's `load / generate / choose / constrain / benchmark`
 Host code stays Python; everything that touches the device goes through
 `model(...)` (model.py) and `model_ops` (ops.py), i.e. hand-written HIP kernels.
 
-`quantize_cache=True` selects the int8 KV cache and `quantize_model=True` fp8 (e4m3) decoder weights -- the build's
+`quantize_cache=True` selects the int8 KV cache and `quantize_model=True` fp8 (e4m3) decoder weights (or the reference's
+own 4-bit group-64 format: an MLX `*_Q` checkpoint directory if present, or `quantize_format="int4"`) -- the build's
 analogues of the reference's 4-bit prompt cache / int4 weights (BASELINE config 5).
 `use_adapter=True` attaches the LoRA adapter of `adapters/<model dir name>` (or `adapter_path=...`) at inference
 (reference phi_3_vision_mlx.py:266-271); training adapters is not part of this build.
@@ -210,8 +211,6 @@ def _load(model_path=PATH_ORIGINAL_PHI3_VISION, adapter_path=None, return_mx=Tru
     HF safetensors -> device weights."""
     from .model import Phi3VModel
     cfg = _get_cfg(f"{model_path}/config.json", **kwargs)
-    if getattr(cfg, "quantized", False):
-        raise NotImplementedError("MLX int4 checkpoints are not supported (SURVEY.md section 8f item 4)")
     processor = _make_processor(cfg, model_path, return_mx)
     device = device or f"cuda:{torch.cuda.current_device()}"
     model = Phi3VModel(cfg, load_safetensors_dir(model_path, cfg, device="cpu"), device=device)
@@ -251,17 +250,27 @@ def load(blind_model=False, quantize_model=False, quantize_cache=False, use_adap
     random weights instead of reading `models/...` (there is no hub access here)."""
     synthetic = kwargs.pop("synthetic", None)
     adapter_path = kwargs.pop("adapter_path", None)
-    model_path = kwargs.pop("model_path", None) or (PATH_ORIGINAL_PHI3_BLIND if blind_model else PATH_ORIGINAL_PHI3_VISION)
+    fmt = kwargs.pop("quantize_format", "fp8")               # on-the-fly weight format of quantize_model=True: "fp8" | "int4"
+    if fmt not in ("fp8", "int4"):
+        raise ValueError(f"quantize_format must be 'fp8' or 'int4', got {fmt!r}")
+    model_path = kwargs.pop("model_path", None)
+    if model_path is None:
+        model_path = PATH_ORIGINAL_PHI3_BLIND if blind_model else PATH_ORIGINAL_PHI3_VISION
+        q_path = PATH_QUANTIZED_PHI3_BLIND if blind_model else PATH_QUANTIZED_PHI3_VISION
+        if quantize_model and not synthetic and os.path.exists(q_path):
+            model_path, quantize_model = q_path, False          # reference :1305-1311: an MLX 4-bit checkpoint, loaded as is
     if use_adapter and adapter_path is None:
         adapter_path = _get_adapter_path(model_path)                                   # reference :1316-1317
     if synthetic:
         return load_synthetic(blind_model=blind_model, tiny=(synthetic == "tiny"), use_quantized_cache=quantize_cache,
-                              quantized_fp8=quantize_model, adapter_path=adapter_path if use_adapter else None, **kwargs)
+                              quantized_fp8=quantize_model and fmt == "fp8", quantized_int4=quantize_model and fmt == "int4",
+                              adapter_path=adapter_path if use_adapter else None, **kwargs)
     if not os.path.exists(model_path):
         raise FileNotFoundError(
             f"model directory {model_path!r} not found and this build cannot download checkpoints; "
             "place HF-layout safetensors + config.json there, or use load(synthetic=True)")
-    return _load(model_path=model_path, use_quantized_cache=quantize_cache, quantized_fp8=quantize_model,
+    return _load(model_path=model_path, use_quantized_cache=quantize_cache, quantized_fp8=quantize_model and fmt == "fp8",
+                 quantized_int4=quantize_model and fmt == "int4",
                  adapter_path=adapter_path if use_adapter else None, **kwargs)
 
 

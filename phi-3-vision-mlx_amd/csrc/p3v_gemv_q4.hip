@@ -1,0 +1,236 @@
+// 4-bit group-64 affine weights (the reference's `quantize_model=True`: nn.quantize(model, group_size=64, bits=4),
+// phi_3_vision_mlx.py:264,297-305 -> mx.quantized_matmul):  w[n, k] = scale[n, k/64] * q[n, k] + bias[n, k/64], q in 0..15.
+// Decode-time projection y = x W^T streaming 0.5 byte per weight (+ 1/16 for scales and biases).
+//
+// Device layout (repacked once at load time from MLX's, see weights.q4_repack):
+//   W4 [N, K/8] u32: the 8 nibbles of weights 8d .. 8d+7 sit at bits 0,16,4,20,8,24,12,28, so that
+//        P_j = ((R >> 4j) & 0x000F000F) | 0x43004300      (one v_and_or_b32 after the shift)
+//      is the bf16 PAIR (128 + q[2j], 128 + q[2j+1]) -- 0x4300 | q is exactly 128 + q in bf16 -- ready for v_dot2c_f32_bf16
+//      against the activation pair (x[2j], x[2j+1]);
+//   SB [N, K/64] u32: scale (bf16) | bias (bf16) << 16.
+// Per 16-weight piece p of a row, with D = sum_k x_k (128 + q_k) and X = sum_k x_k (16 activations, shared by all rows,
+// precomputed in LDS):   contribution = scale * (D - 128 X) + bias * X.
+// Same streaming skeleton as k_gemv3: x (+RMSNorm) staged in LDS, (row pair, stage) pipeline with two register buffers,
+// unconditional loads, branch-free body.  HBM-bound: N*K/2 + N*K/16 bytes per launch.
+#include <stdlib.h>
+
+#include <type_traits>
+
+#include "p3v_common.h"
+
+struct GemvQ4P {
+  const bf16_t* x; const uint32_t* W; const uint32_t* sb; void* out; const bf16_t* resid; const bf16_t* norm_w;
+  float eps;
+  int M, N, K, epi, units;
+};
+typedef std::integral_constant<int, 0> QC0;
+typedef std::integral_constant<int, 1> QC1;
+typedef __bf16 q4_pair_t __attribute__((ext_vector_type(2)));
+typedef __bf16 q4_oct_t __attribute__((ext_vector_type(8)));
+
+// 8 weights (one repacked dword) . 8 activations -> += sum_k x_k (128 + q_k)
+__device__ __forceinline__ float dot8_q4(uint32_t r, u32x4_t x, float acc) {
+  const q4_oct_t xv = __builtin_bit_cast(q4_oct_t, x);
+  const uint32_t p0 = (r & 0x000F000Fu) | 0x43004300u, p1 = ((r >> 4) & 0x000F000Fu) | 0x43004300u;
+  const uint32_t p2 = ((r >> 8) & 0x000F000Fu) | 0x43004300u, p3 = ((r >> 12) & 0x000F000Fu) | 0x43004300u;
+  // (each dword goes through an asm no-op before it is viewed as a bf16 pair: hipcc 7.2 folds such bit_casts, see dot8)
+  uint32_t q0 = p0, q1 = p1, q2 = p2, q3 = p3;
+  asm("" : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3));
+  acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(q4_pair_t, q0), __builtin_shufflevector(xv, xv, 0, 1), acc, false);
+  acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(q4_pair_t, q1), __builtin_shufflevector(xv, xv, 2, 3), acc, false);
+  acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(q4_pair_t, q2), __builtin_shufflevector(xv, xv, 4, 5), acc, false);
+  acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(q4_pair_t, q3), __builtin_shufflevector(xv, xv, 6, 7), acc, false);
+  return acc;
+}
+
+// NST stages x NP 16-weight pieces per lane per row: K = NST * NP * 64 * 16
+template <int NST, int NP>
+__global__ void __launch_bounds__(256) k_gemv3_q4(GemvQ4P p, int units_per_wave) {
+  constexpr int PIECES = NST * NP * 64;                 // 16-weight pieces per row
+  constexpr int K = PIECES * 16, XCH = K / 8;           // 16-byte x chunks
+  constexpr int XC = (XCH + 255) / 256;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ float red[4];
+  u32x4_t* xs = (u32x4_t*)smem;                         // [K] bf16 x (normalised)
+  float* xsum = (float*)(smem + K * 2);                 // [PIECES] sum of the 16 activations of a piece
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const bool silu = p.epi == P3V_EPI_SILU_MUL, has_res = p.epi == P3V_EPI_RESID_BF16;
+  const int u_begin = min(p.units, (blockIdx.x * 4 + wave) * units_per_wave);
+  const int u_end = min(p.units, u_begin + units_per_wave);
+  const int n_st = (u_end - u_begin) * NST;
+
+  u32x4_t xv[XC], gv[XC];
+#pragma unroll
+  for (int k = 0; k < XC; ++k) {
+    const int c = min(tid + k * 256, XCH - 1);
+    xv[k] = ((const u32x4_t*)p.x)[c];
+    gv[k] = p.norm_w ? ((const u32x4_t*)p.norm_w)[c] : (u32x4_t){0, 0, 0, 0};
+  }
+  u32x2_t wbuf[2][2][NP];
+  uint32_t sbuf[2][2][NP];
+  uint32_t rbuf[2];
+  auto issue = [&](int gs, auto bufc) {
+    constexpr int buf = decltype(bufc)::value;
+    const int u = min(u_begin + gs / NST, p.units - 1), s = gs % NST;
+    const int r0 = silu ? u : 2 * u, r1 = silu ? u + p.N : min(2 * u + 1, p.N - 1);
+    const u32x2_t* w0 = (const u32x2_t*)(p.W + (size_t)r0 * (K / 8)) + s * NP * 64 + lane;
+    const u32x2_t* w1 = (const u32x2_t*)(p.W + (size_t)r1 * (K / 8)) + s * NP * 64 + lane;
+    const uint32_t* s0 = p.sb + (size_t)r0 * (K / 64) + ((s * NP * 64 + lane) >> 2);
+    const uint32_t* s1 = p.sb + (size_t)r1 * (K / 64) + ((s * NP * 64 + lane) >> 2);
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+      wbuf[buf][0][j] = __builtin_nontemporal_load(w0 + j * 64);
+      wbuf[buf][1][j] = __builtin_nontemporal_load(w1 + j * 64);
+      sbuf[buf][0][j] = s0[j * 16];
+      sbuf[buf][1][j] = s1[j * 16];
+    }
+    rbuf[buf] = has_res ? *(const uint32_t*)(p.resid + 2 * u) : 0u;
+  };
+  if (n_st > 0) issue(0, QC0{});
+
+  float r = 1.f;
+  if (p.norm_w) {
+    float ss = 0.f;
+#pragma unroll
+    for (int k = 0; k < XC; ++k)
+      if (tid + k * 256 < XCH) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const float a = bf16lo(xv[k][j]), b = bf16hi(xv[k][j]); ss += a * a + b * b; }
+      }
+    ss = wave_sum(ss);
+    if (lane == 0) red[wave] = ss;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    r = rsqrtf(((red[0] + red[1]) + (red[2] + red[3])) / (float)K + p.eps);
+  }
+#pragma unroll
+  for (int k = 0; k < XC; ++k) {
+    const int c = tid + k * 256;
+    if (c < XCH) {
+      u32x4_t o = xv[k];
+      if (p.norm_w) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          o[j] = pack_bf16x2(bf16lo(xv[k][j]) * r * bf16lo(gv[k][j]), bf16hi(xv[k][j]) * r * bf16hi(gv[k][j]));
+      }
+      xs[c] = o;
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  for (int pc = tid; pc < PIECES; pc += 256) {           // X of every piece, from the (rounded) activations the dots see
+    const u32x4_t a = xs[2 * pc], b = xs[2 * pc + 1];
+    float t = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) t += (bf16lo(a[j]) + bf16hi(a[j])) + (bf16lo(b[j]) + bf16hi(b[j]));
+    xsum[pc] = t;
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+  float a0 = 0.f, a1 = 0.f;
+  auto compute = [&](int gs, auto bufc) {
+    constexpr int buf = decltype(bufc)::value;
+    const int s = gs % NST;
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+      const int pc = (s * NP + j) * 64 + lane;
+      const u32x4_t xa = xs[2 * pc], xb = xs[2 * pc + 1];
+      const float X = xsum[pc], X128 = 128.f * X;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const u32x2_t w = wbuf[buf][h][j];
+        const float D = dot8_q4(w[1], xb, dot8_q4(w[0], xa, 0.f));
+        const uint32_t sb = sbuf[buf][h][j];
+        const float c = bf16lo(sb) * (D - X128) + bf16hi(sb) * X;
+        if (h == 0) a0 += c; else a1 += c;
+      }
+    }
+    if (s == NST - 1) {
+      const int u = u_begin + gs / NST;
+      a0 = wave_sum(a0);
+      a1 = wave_sum(a1);
+      if (lane == 0) {
+        if (silu) {
+          const float g = bf16_round(a0), up = bf16_round(a1);
+          ((bf16_t*)p.out)[u] = f32_to_bf16(bf16_round(g * bf16_round(1.f / (1.f + __expf(-g)))) * up);
+        } else if (p.epi == P3V_EPI_F32) {
+          ((float*)p.out)[2 * u] = a0;
+          ((float*)p.out)[2 * u + 1] = a1;
+        } else {
+          float v0 = a0, v1 = a1;
+          if (has_res) { v0 = bf16lo(rbuf[buf]) + bf16_round(v0); v1 = bf16hi(rbuf[buf]) + bf16_round(v1); }
+          *(uint32_t*)((bf16_t*)p.out + 2 * u) = pack_bf16x2(v0, v1);
+        }
+      }
+      a0 = a1 = 0.f;
+    }
+  };
+  int gs = 0;
+  while (gs + 2 < n_st) {
+    issue(gs + 1, QC1{}); compute(gs, QC0{});
+    issue(gs + 2, QC0{}); compute(gs + 1, QC1{});
+    gs += 2;
+  }
+  if (gs + 1 < n_st) {
+    issue(gs + 1, QC1{}); compute(gs, QC0{}); compute(gs + 1, QC1{});
+  } else if (gs < n_st) {
+    compute(gs, QC0{});
+  }
+}
+
+// W4 / SB -> bf16 [rows, K] (prefill and batched decode run the bf16 kernels on a dequantised scratch copy)
+__global__ void __launch_bounds__(256) k_dequant_q4(const uint32_t* __restrict__ w, const uint32_t* __restrict__ sb,
+                                                    u32x4_t* __restrict__ out, int kd, long total) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;   // dword index: row * kd + d
+  if (i >= total) return;
+  const long row = i / kd;
+  const int d = (int)(i - row * kd);
+  const uint32_t r = w[i], s = sb[row * (kd / 8) + (d >> 3)];
+  const float sc = bf16lo(s), bi = bf16hi(s);
+  u32x4_t o;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float q0 = (float)((r >> (4 * j)) & 15u), q1 = (float)((r >> (4 * j + 16)) & 15u);
+    o[j] = pack_bf16x2(sc * q0 + bi, sc * q1 + bi);
+  }
+  out[i] = o;
+}
+
+extern "C" int p3v_dequant_q4(const uint32_t* w4, const uint32_t* sb, uint16_t* out_bf16, int rows, int K, void* stream) {
+  if (!w4 || !sb || !out_bf16 || rows <= 0 || K <= 0 || K % 64) return P3V_ERR_ARG;
+  const long total = (long)rows * (K / 8);
+  hipLaunchKernelGGL(k_dequant_q4, dim3(p3v_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, w4, sb, (u32x4_t*)out_bf16, K / 8, total);
+  P3V_CHECK_LAUNCH();
+  return P3V_OK;
+}
+
+template <int NST, int NP>
+static int launch_gemv3_q4(const GemvQ4P& p, hipStream_t s) {
+  static int n_cu = 0;
+  if (!n_cu) {
+    int dev = 0;
+    hipDeviceProp_t pr;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess) return P3V_ERR_HIP;
+    n_cu = pr.multiProcessorCount;
+  }
+  int upw = p3v_cdiv(p.units, n_cu * 8);
+  if (upw < 1) upw = 1;
+  const int waves = p3v_cdiv(p.units, upw);
+  hipLaunchKernelGGL((k_gemv3_q4<NST, NP>), dim3(p3v_cdiv(waves, 4)), dim3(256), (size_t)p.K * 2 + (size_t)p.K / 4, s, p, upw);
+  P3V_CHECK_LAUNCH();
+  return P3V_OK;
+}
+
+extern "C" int p3v_gemv_q4(const p3v_gemv_q4_args_t* a, void* stream) {
+  if (!a || !a->x || !a->W || !a->sb || !a->out) return P3V_ERR_ARG;
+  if (a->M != 1 || a->N <= 0 || a->N % 2 || (a->K != 3072 && a->K != 8192)) return P3V_ERR_UNSUPPORTED;
+  if (a->epilogue != P3V_EPI_NONE && a->epilogue != P3V_EPI_RESID_BF16 && a->epilogue != P3V_EPI_SILU_MUL &&
+      a->epilogue != P3V_EPI_F32)
+    return P3V_ERR_UNSUPPORTED;
+  if (a->epilogue == P3V_EPI_RESID_BF16 && !a->resid) return P3V_ERR_ARG;
+  GemvQ4P p = {a->x, a->W, a->sb, a->out, a->resid, a->norm_w, a->norm_eps, a->M, a->N, a->K, a->epilogue,
+               a->epilogue == P3V_EPI_SILU_MUL ? a->N : a->N / 2};
+  hipStream_t s = (hipStream_t)stream;
+  return a->K == 3072 ? launch_gemv3_q4<1, 3>(p, s) : launch_gemv3_q4<2, 4>(p, s);
+}

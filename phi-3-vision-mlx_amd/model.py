@@ -29,6 +29,7 @@ import torch
 
 from . import ops
 from .config import head_dim, is_vision, rope_scaling_factor
+from .weights import Q4Weight, mlx_quantize, q4_repack
 from .ops import (BF16, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_QGELU, EPI_BIAS_RESID_F32, EPI_NONE, EPI_PATCH,
                   EPI_RESID_BF16, EPI_SILU_MUL, F32, I32)
 
@@ -88,7 +89,9 @@ class Phi3VModel:
         ops.L.lib()                                  # fail loudly if libp3v.so is missing
         self.cfg, self.device = cfg, torch.device(device)
         self.vision = is_vision(cfg)
-        self.w = {k: v.to(self.device, BF16).contiguous() for k, v in weights.items()}
+        self.w = {k: v.to(self.device, BF16).contiguous() for k, v in weights.items() if not isinstance(v, Q4Weight)}
+        # 4-bit group-64 projections (MLX nn.quantize checkpoints / quantized_int4): device layout of p3v_gemv_q4
+        self.w4 = {k: tuple(t.to(self.device) for t in q4_repack(*v)) for k, v in weights.items() if isinstance(v, Q4Weight)}
         self.hd = head_dim(cfg)
         if self.hd != 96:
             raise ValueError(f"decoder head_dim must be 96 (got {self.hd})")
@@ -98,6 +101,11 @@ class Phi3VModel:
         self._lora_tmp = {}
         if getattr(cfg, "quantized_fp8", False):
             self._quantize_decoder_fp8()
+        if getattr(cfg, "quantized_int4", False):
+            self._quantize_decoder_q4()
+        if self.w4 and not hasattr(self, "_deq"):
+            n_max = max(v[0].shape[0] * v[0].shape[1] * 8 for v in self.w4.values())
+            self._deq = torch.empty(n_max, dtype=BF16, device=self.device)  # one dequantised matrix (prefill GEMM scratch)
         if self.vision:
             self._prep_vision()
 
@@ -118,7 +126,7 @@ class Phi3VModel:
         plain epilogue -> p3v_lora_down / p3v_lora_up, which carries the residual / SiLU*up epilogue (phi.py:129-133)."""
         for k, (a, b, _) in adapters.items():
             w = self.w.get(k)
-            shape = w.shape if w is not None else self.w8[k][0].shape
+            shape = w.shape if w is not None else (self.w8[k][0].shape if k in self.w8 else (self.w4[k][0].shape[0], self.w4[k][0].shape[1] * 8))
             if tuple(a.shape[:1]) != (shape[1],) or tuple(b.shape[1:]) != (shape[0],):
                 raise ValueError(f"LoRA shapes {tuple(a.shape)} x {tuple(b.shape)} do not fit {k} {tuple(shape)}")
         self.adapters = {k: (a.to(self.device, F32).contiguous(), b.to(self.device, F32).contiguous(), float(s))
@@ -126,6 +134,13 @@ class Phi3VModel:
         self._lora_tmp = {}
         if self._state is not None:
             self._state.graphs.clear()               # captured decode graphs bake the kernel sequence in
+
+    def _quantize_decoder_q4(self):
+        """Decoder projections + lm_head -> 4-bit group-64 (the reference's nn.quantize(model, 64, 4)): 7.4 GB -> 2.1 GB
+        streamed per token.  Quantised on the device with the MLX algorithm (weights.mlx_quantize)."""
+        names = [k for k in self.w if k == "lm_head.weight" or (k.startswith("model.layers.") and k.endswith("_proj.weight"))]
+        for k in names:
+            self.w4[k] = tuple(t.to(self.device) for t in q4_repack(*mlx_quantize(self.w.pop(k))))
 
     def _proj(self, x, key, epilogue=EPI_NONE, resid=None, norm_w=None, out=None, h=None):
         """One projection of the decoder (+ its LoRA adapter, if one is attached)."""
@@ -154,11 +169,15 @@ class Phi3VModel:
         """Weight-streaming kernel for skinny x, MFMA GEMM otherwise; bf16 or fp8 weights."""
         eps = self.cfg.rms_norm_eps
         M, K = x.shape
-        q = self.w8.get(key)
+        q, q4 = self.w8.get(key), self.w4.get(key)
         skinny = M <= 8 or (M <= ops.GEMV_MAX_M and K % 512 == 0)
+        if q4 is not None and M == 1 and K in (3072, 8192):
+            return ops.gemv_q4(x, q4[0], q4[1], epilogue, resid=resid, norm_w=norm_w, norm_eps=eps, out=out)
         if q is not None and skinny and K in (3072, 8192):
             return ops.gemv_fp8(x, q[0], q[1], epilogue, resid=resid, norm_w=norm_w, norm_eps=eps, out=out)
-        if q is not None:
+        if q4 is not None:
+            w = ops.dequant_q4(q4[0], q4[1], out=self._deq[:q4[0].numel() * 8].view(q4[0].shape[0], q4[0].shape[1] * 8))
+        elif q is not None:
             w = ops.dequant_fp8(q[0], q[1], out=self._deq[:q[0].numel()].view(q[0].shape))
         else:
             w = self.w[key]
@@ -414,7 +433,7 @@ class Phi3VModel:
         #    its hungriest role (the GEMV's 144 VGPRs) and only 384 of the 1312 attention workgroups are then resident
         #    while the GEMV streams.
         nl = cfg.num_hidden_layers
-        plain = B == 1 and not st.quantized and not self.w8 and not self.adapters and cfg.hidden_size == 3072 \
+        plain = B == 1 and not st.quantized and not self.w8 and not self.w4 and not self.adapters and cfg.hidden_size == 3072 \
             and cfg.intermediate_size == 8192
         n_chain = nl * 4096 if plain and os.environ.get("P3V_GEMV_CHAIN", "0") == "1" else 0
         nf = ops.qkv_attention_decode_flags((cfg.num_attention_heads + 2 * cfg.num_key_value_heads) * self.hd) \

@@ -152,6 +152,28 @@ def lora_up(y, t, lora_b, scale, epilogue=EPI_NONE, resid=None, out=None):
     return out
 
 
+def gemv_q4(x, w4, sb, epilogue=EPI_NONE, resid=None, norm_w=None, norm_eps=0.0, out=None):
+    """`gemv` on 4-bit group-64 weights (device layout of weights.q4_repack): x [1,K] bf16, w4 [N,K/8] i32, sb [N,K/64] i32."""
+    _chk(x, BF16, "x"), _chk(w4, I32, "w4"), _chk(sb, I32, "sb")
+    M, K = x.shape
+    N = w4.shape[0] // 2 if epilogue == EPI_SILU_MUL else w4.shape[0]
+    if out is None:
+        out = torch.empty((M, N), dtype=F32 if epilogue == EPI_F32 else BF16, device=x.device)
+    args = L.GemvQ4Args(_p(x), _p(w4), _p(sb), _p(out), _p(resid), _p(norm_w), float(norm_eps), M, N, K, epilogue)
+    L.check(L.lib().p3v_gemv_q4(C.byref(args), _stream()), "gemv_q4")
+    return out
+
+
+def dequant_q4(w4, sb, out=None):
+    """4-bit group-64 weights -> bf16 [N, K] (scale * q + bias, rounded once)."""
+    _chk(w4, I32, "w4"), _chk(sb, I32, "sb")
+    N, K = w4.shape[0], w4.shape[1] * 8
+    if out is None:
+        out = torch.empty((N, K), dtype=BF16, device=w4.device)
+    L.check(L.lib().p3v_dequant_q4(_p(w4), _p(sb), _p(out), N, K, _stream()), "dequant_q4")
+    return out
+
+
 def gemv_chain(stages, counters):
     """Dependent M = 1 projections in ONE launch: stages = [(x, w, epilogue, resid, norm_w, norm_eps, out), ...] (at most 4,
     K in {3072, 8192}); `counters` int32 [>= 1024 * len(stages)], all zero on entry."""

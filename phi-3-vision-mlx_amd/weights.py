@@ -126,17 +126,32 @@ def load_safetensors_dir(model_path, cfg, device="cpu"):
     order (the patch-embed kernel unfolds patches in the matching (c,ky,kx)
     order); a 'sanitized' MLX re-save (``[O,kh,kw,C]``) is permuted back."""
     from safetensors import safe_open
-    out = {}
+    out, raw = {}, {}
     files = sorted(glob.glob(f"{model_path}/*.safetensors"))
     if not files:
         raise FileNotFoundError(f"no *.safetensors under {model_path}")
     for wf in files:
         with safe_open(wf, framework="pt", device="cpu") as f:
             for k in f.keys():
-                t = f.get_tensor(k)
-                if "patch_embedding.weight" in k and getattr(cfg, "sanitized", False):
-                    t = t.permute(0, 3, 1, 2).contiguous()
-                out[k] = t.to(torch.bfloat16).to(device)
+                raw[k] = f.get_tensor(k)
+    quantized = getattr(cfg, "quantized", None) or None
+    for k, t in raw.items():
+        if quantized and (k.endswith(".scales") or k.endswith(".biases")):
+            continue
+        base = k[:-len(".weight")] if k.endswith(".weight") else None
+        if quantized and base is not None and base + ".scales" in raw:
+            # MLX nn.quantize checkpoint (quantized_model.safetensors, phi_3_vision_mlx.py:297-305): uint32 codes + per-group
+            # scales / biases.  Decoder projections and lm_head keep their 4-bit form (Q4Weight -> p3v_gemv_q4); embeddings,
+            # the ViT and the projector are dequantised here (prefill-only / tiny), exactly scale * q + bias.
+            if int(quantized.get("bits", 4)) != Q4_BITS or int(quantized.get("group_size", 64)) != Q4_GROUP:
+                raise NotImplementedError(f"only {Q4_BITS}-bit group-{Q4_GROUP} MLX checkpoints are supported, got {quantized}")
+            q = Q4Weight(t.view(torch.int32) if t.dtype != torch.int32 else t, raw[base + ".scales"], raw[base + ".biases"])
+            fast = k == "lm_head.weight" or (k.startswith("model.layers.") and k.endswith("_proj.weight"))
+            out[k] = q if fast else mlx_dequantize(*q).to(torch.bfloat16).to(device)
+            continue
+        if "patch_embedding.weight" in k and getattr(cfg, "sanitized", False):
+            t = t.permute(0, 3, 1, 2).contiguous()
+        out[k] = t.to(torch.bfloat16).to(device)
     missing = [n for n, _, _ in weight_specs(cfg) if n not in out]
     if missing:
         raise KeyError(f"weights missing from {model_path}: {missing[:4]}{'...' if len(missing) > 4 else ''}")
@@ -210,3 +225,68 @@ def resolve_adapter(cfg, lora_cfg, tensors, device="cpu"):
                 raise ValueError(f"unsupported LoRA shapes for layer {i} {tgt}: {tuple(a.shape)} x {tuple(b.shape)} (rank <= 64)")
             out[f"model.layers.{i}.{tgt}.weight"] = (a.to(device, torch.float32).contiguous(), b.to(device, torch.float32).contiguous(), scale)
     return out
+
+
+# ---------------------------------------------------------------- 4-bit group-64 weights (MLX nn.quantize format)
+Q4_GROUP, Q4_BITS = 64, 4
+
+
+class Q4Weight(tuple):
+    """(packed int32 [N, K/8] in MLX's nibble order, scales [N, K/64], biases [N, K/64]) of one quantised projection."""
+    def __new__(cls, packed, scales, biases):
+        return super().__new__(cls, (packed, scales, biases))
+
+
+def mlx_quantize(w, group_size=Q4_GROUP, bits=Q4_BITS):
+    """Affine group quantisation as mx.quantize documents it (the reference calls nn.quantize(model, 64, 4),
+    phi_3_vision_mlx.py:264,297-305): per group of `group_size` input columns  w ~ scale * q + bias,  q in 0..2^bits-1.
+    -> (packed uint32-as-int32 [N, K*bits/32] in MLX's order: weight k of a word at bits [4k, 4k+4), scales, biases
+    [N, K/group] in w.dtype).  The scale/edge selection follows MLX's kernel (the end of the range with the larger
+    magnitude is represented exactly); a checkpoint written by MLX only needs `mlx_dequantize` below."""
+    N, K = w.shape
+    g = w.float().reshape(N, K // group_size, group_size)
+    n_bins = (1 << bits) - 1
+    w_max, w_min = g.amax(-1), g.amin(-1)
+    mask = w_min.abs() > w_max.abs()
+    scales = ((w_max - w_min) / n_bins).clamp_min(1e-7)
+    scales = torch.where(mask, scales, -scales)
+    edge = torch.where(mask, w_min, w_max)
+    q0 = torch.round(edge / scales)
+    scales = torch.where(q0 != 0, edge / q0, scales)
+    biases = torch.where(q0 == 0, torch.zeros_like(edge), edge)
+    scales, biases = scales.to(w.dtype), biases.to(w.dtype)                 # stored in the model dtype
+    q = torch.round((g - biases.float()[..., None]) / scales.float()[..., None]).clamp(0, n_bins).to(torch.int64).reshape(N, K)
+    per = 32 // bits
+    shifts = (torch.arange(per, dtype=torch.int64, device=w.device) * bits)
+    packed = (q.reshape(N, K // per, per) << shifts).sum(-1)
+    packed = torch.where(packed >= 2 ** 31, packed - 2 ** 32, packed).to(torch.int32)     # uint32 bit pattern in int32
+    return packed, scales, biases
+
+
+def mlx_unpack(packed, bits=Q4_BITS):
+    """uint32 words (as int32 / uint32 tensor) -> integer codes [N, K]."""
+    per = 32 // bits
+    u = packed.to(torch.int64) & 0xFFFFFFFF
+    shifts = (torch.arange(per, dtype=torch.int64, device=packed.device) * bits)
+    return ((u[..., None] >> shifts) & ((1 << bits) - 1)).reshape(packed.shape[0], -1)
+
+
+def mlx_dequantize(packed, scales, biases, group_size=Q4_GROUP, bits=Q4_BITS):
+    """mx.dequantize: scale * q + bias per group, in float32."""
+    q = mlx_unpack(packed, bits).float()
+    N, K = q.shape
+    return (q.reshape(N, K // group_size, group_size) * scales.float()[..., None] + biases.float()[..., None]).reshape(N, K)
+
+
+def q4_repack(packed, scales, biases):
+    """MLX layout -> the device layout of p3v_gemv_q4 (include/p3v.h): nibbles of weights 8d..8d+7 at bits
+    0,16,4,20,8,24,12,28 of dword d; scale | bias << 16 as one dword per group."""
+    q = mlx_unpack(packed).reshape(packed.shape[0], -1, 8)
+    pos = torch.tensor([0, 16, 4, 20, 8, 24, 12, 28], dtype=torch.int64, device=packed.device)
+    w4 = (q << pos).sum(-1)
+    w4 = torch.where(w4 >= 2 ** 31, w4 - 2 ** 32, w4).to(torch.int32)
+    s16 = scales.to(torch.bfloat16).view(torch.int16).to(torch.int64) & 0xFFFF
+    b16 = biases.to(torch.bfloat16).view(torch.int16).to(torch.int64) & 0xFFFF
+    sb = s16 | (b16 << 16)
+    sb = torch.where(sb >= 2 ** 31, sb - 2 ** 32, sb).to(torch.int32)
+    return w4.contiguous(), sb.contiguous()

@@ -179,3 +179,49 @@ def test_oracle_lora_is_the_reference_formula():
     assert torch.equal(o.proj(x, "w"), want)
     o0 = orc.OraclePhi3V(cfg, w, adapters={"w": (a, torch.zeros_like(b), 0.5)})
     assert torch.equal(o0.proj(x, "w"), y)
+
+
+def test_mlx_int4_format_round_trip_and_checkpoint_loading(tmp_path):
+    """MLX nn.quantize format (phi_3_vision_mlx.py:297-305): 8 codes per uint32 (code k at bits 4k), group-64 scales/biases;
+    w ~ scale*q+bias within half a step; a quantised checkpoint directory loads with decoder projections kept 4-bit
+    (Q4Weight) and everything else dequantised; the device repacking is a pure permutation of the codes."""
+    import torch
+    from safetensors.torch import save_file
+    from phi_3_vision_mlx_amd.config import load_config, make_config, tiny_config_dict
+    from phi_3_vision_mlx_amd.weights import (Q4Weight, load_safetensors_dir, mlx_dequantize, mlx_quantize, mlx_unpack, q4_repack,
+                                              synth_weights)
+    g = torch.Generator().manual_seed(0)
+    w = (torch.randn(8, 192, generator=g) * 0.05).to(torch.bfloat16)
+    packed, sc, bi = mlx_quantize(w)
+    assert packed.shape == (8, 24) and sc.shape == (8, 3) and packed.dtype == torch.int32
+    q = mlx_unpack(packed)
+    assert q.min() >= 0 and q.max() <= 15
+    assert int(q[0, 0]) == int(packed[0, 0].item() & 15) and int(q[0, 1]) == int((packed[0, 0].item() >> 4) & 15)
+    d = mlx_dequantize(packed, sc, bi)
+    step = (w.float().reshape(8, 3, 64).amax(-1) - w.float().reshape(8, 3, 64).amin(-1)) / 15
+    assert ((d - w.float()).abs().reshape(8, 3, 64) <= 1.0 * step[..., None] + 2e-3).all()       # the exact-edge rescaling can clip the far end by almost a step
+    w4, sb = q4_repack(packed, sc, bi)
+    pos = [0, 16, 4, 20, 8, 24, 12, 28]
+    back = torch.stack([(w4.to(torch.int64) >> p) & 15 for p in pos], dim=-1).reshape(8, 192)
+    assert torch.equal(back, q)
+    assert torch.equal((sb.to(torch.int64) & 0xFFFF).to(torch.int16).view(torch.bfloat16), sc)
+    # a quantised checkpoint directory
+    dcfg = tiny_config_dict(vision=False)
+    cfg = make_config(dcfg)
+    ws = synth_weights(cfg, seed=2)
+    tensors = {}
+    for k, v in ws.items():
+        if v.dim() == 2 and v.shape[1] % 64 == 0 and ("proj" in k or k in ("lm_head.weight", "model.embed_tokens.weight")):
+            p_, s_, b_ = mlx_quantize(v)
+            tensors[k], tensors[k[:-7] + ".scales"], tensors[k[:-7] + ".biases"] = p_, s_, b_
+        else:
+            tensors[k] = v
+    (tmp_path / "q").mkdir()
+    save_file(tensors, str(tmp_path / "q" / "quantized_model.safetensors"))
+    (tmp_path / "q" / "config.json").write_text(json.dumps(dict(dcfg, quantized={"group_size": 64, "bits": 4})))
+    cfg_q = load_config(str(tmp_path / "q" / "config.json"))
+    got = load_safetensors_dir(str(tmp_path / "q"), cfg_q)
+    assert isinstance(got["model.layers.0.self_attn.qkv_proj.weight"], Q4Weight) and isinstance(got["lm_head.weight"], Q4Weight)
+    emb = got["model.embed_tokens.weight"]
+    assert emb.dtype == torch.bfloat16 and torch.equal(emb, mlx_dequantize(*mlx_quantize(ws["model.embed_tokens.weight"])).to(torch.bfloat16))
+    assert torch.equal(got["model.norm.weight"], ws["model.norm.weight"])

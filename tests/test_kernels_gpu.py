@@ -559,3 +559,35 @@ def test_device_preprocessing_is_bit_identical_to_host(w, h, kind, seed):
     got = dev["pixel_values"].cpu().numpy()
     assert got.dtype == np.float32 and got.shape == host["pixel_values"].shape
     assert np.array_equal(got.view(np.uint32), host["pixel_values"].view(np.uint32))        # bit patterns, signed zeros included
+
+
+@pytest.mark.parametrize("N,K,epi", [(3072, 3072, "resid"), (9216, 3072, "none"), (8192, 3072, "silu"), (3072, 8192, "resid"), (512, 8192, "f32")])
+@pytest.mark.parametrize("norm", [False, True])
+def test_gemv_q4_and_dequant(ops, N, K, epi, norm):
+    """4-bit group-64 affine weights (the reference's nn.quantize(model, 64, 4)): p3v_dequant_q4 == scale*q+bias exactly
+    (one bf16 rounding), p3v_gemv_q4 == the fp32 product with the DEQUANTISED weights (mx.quantized_matmul semantics)."""
+    from phi_3_vision_mlx_amd.ops import EPI_F32, EPI_NONE, EPI_RESID_BF16, EPI_SILU_MUL
+    from phi_3_vision_mlx_amd.weights import mlx_dequantize, mlx_quantize, q4_repack
+    rows = 2 * N if epi == "silu" else N
+    w = g((rows, K), 400, 0.03)
+    packed, sc, bi = mlx_quantize(w)
+    wd = mlx_dequantize(packed, sc, bi)                                   # fp32, exact scale*q+bias
+    w4, sb = (t.cuda() for t in q4_repack(packed, sc, bi))
+    assert torch.equal(ops.dequant_q4(w4, sb).cpu(), wd.to(BF16))
+    x = g((1, K), 401)
+    nw = (g((K,), 402) * 0.1 + 1) if norm else None
+    xin = x.float()
+    if norm:
+        xin = (xin * torch.rsqrt(xin.pow(2).mean(-1, keepdim=True) + 1e-5) * nw.float()).to(BF16).float()
+    y = xin @ wd.t()
+    res = g((1, N), 403)
+    e = {"none": EPI_NONE, "resid": EPI_RESID_BF16, "silu": EPI_SILU_MUL, "f32": EPI_F32}[epi]
+    got = ops.gemv_q4(x.cuda(), w4, sb, e, resid=res.cuda() if epi == "resid" else None, norm_w=nw.cuda() if norm else None, norm_eps=1e-5)
+    if epi == "resid":
+        ref = (res.float() + y.to(BF16).float()).to(BF16)
+    elif epi == "silu":
+        gt, up = y[:, :N].to(BF16), y[:, N:].to(BF16)
+        ref = (gt * torch.sigmoid(gt)) * up
+    else:
+        ref = y if epi == "f32" else y.to(BF16)
+    close(got, ref, rtol=2 ** -6, atol=3e-2)

@@ -472,3 +472,31 @@ def test_lora_adapter_matches_oracle(tmp_path, targets, layers, rank):
                 logits, cache = model(input_ids=tok, cache=cache)            # eager cached call
             else:
                 logits, _ = model.greedy_step(tok, cache)                   # graph replay
+
+
+def test_int4_weights_full_size_decode_matches_dequantised_model():
+    """quantize_model (4-bit group-64, the reference's nn.quantize format): a full-size model running p3v_gemv_q4 in
+    decode and dequantise-to-scratch in prefill vs THE SAME model with its 4-bit weights expanded to bf16 up front
+    (scale*q+bias rounded once): logits within the 32-layer tolerance, greedy tokens equal where the margin is clear."""
+    from phi_3_vision_mlx_amd import ops
+    from phi_3_vision_mlx_amd.api import load_synthetic
+    from phi_3_vision_mlx_amd.model import Phi3VModel
+    mq, _ = load_synthetic(blind_model=True, tiny=False, seed=0, device="cuda:0", quantized_int4=True)
+    assert mq.w4 and "lm_head.weight" in mq.w4 and "lm_head.weight" not in mq.w
+    wd = dict(mq.w)
+    for k, (w4, sb) in mq.w4.items():
+        wd[k] = ops.dequant_q4(w4, sb)
+    cfg = type(mq.cfg)(**{k: v for k, v in vars(mq.cfg).items() if k != "quantized_int4"})
+    md = Phi3VModel(cfg, wd, device="cuda:0")
+    ids = np.random.default_rng(5).integers(3, 32000, (1, 200)).astype(np.int64)
+    lq, cq = mq(input_ids=ids, max_tokens=6)
+    ld, cd = md(input_ids=ids, max_tokens=6)
+    assert_logits(lq[:, -1], ld[:, -1], "int4 prefill")          # same bf16 GEMMs on the same dequantised values; only the
+                                                                # last-row lm_head differs (4-bit GEMV vs bf16 GEMV)
+    for step in range(5):
+        tok = ops.argmax(ld[:, -1].contiguous())[:, None]
+        lq, _ = mq.greedy_step(tok, cq)
+        ld, _ = md.greedy_step(tok, cd)
+        assert_logits(lq[:, -1], ld[:, -1], f"int4 decode step {step}", rel_atol=6e-2)
+    del mq, md
+    torch.cuda.empty_cache()
