@@ -302,7 +302,7 @@ class Phi3VImageProcessor:
         shapes = []
 
         def dev(a):
-            return torch.as_tensor(np.ascontiguousarray(a)).to(device)
+            return torch.from_numpy(np.array(a, copy=True, order="C")).to(device)   # (np.asarray(PIL image) is read-only)
         for n, img in enumerate(images):
             a = np.asarray(img.convert("RGB"))
             h, w = a.shape[:2]
