@@ -164,7 +164,14 @@ static int launch_gemv3(const GemvP& p, hipStream_t s) {
   int upw = p3v_cdiv(p.units, n_cu * wpc);               // row pairs per wave
   if (upw < 1) upw = 1;
   const int waves = p3v_cdiv(p.units, upw);
-  hipLaunchKernelGGL((k_gemv3<MT, NST, CH>), dim3(p3v_cdiv(waves, 4)), dim3(256), (size_t)MT * p.K * 2, s, p, upw);
+  const size_t lds = (size_t)MT * p.K * 2;
+  static bool attr_set = false;
+  if (!attr_set && lds > 48 * 1024) {
+    if (hipFuncSetAttribute((const void*)k_gemv3<MT, NST, CH>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256) != hipSuccess)
+      return P3V_ERR_HIP;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((k_gemv3<MT, NST, CH>), dim3(p3v_cdiv(waves, 4)), dim3(256), lds, s, p, upw);
   P3V_CHECK_LAUNCH();
   return P3V_OK;
 }
@@ -355,6 +362,15 @@ extern "C" int p3v_gemv(const p3v_gemv_args_t* a, void* stream) {
   if (variant == 3 && mt == 1 && a->N % 2 == 0 && (a->K == 3072 || a->K == 8192)) {
     if (a->K == 3072) return launch_gemv3<1, 1, 6>(p, s);
     return launch_gemv3<1, 4, 4>(p, s);                  // 8192 = 4 stages x 4 chunks: keeps 2 waves/SIMD resident
+  }
+  // 2 <= M <= 4: the same streaming kernel with MT activation rows in LDS (full-line weight loads, 4 v_dot2c per row and
+  // 16-byte chunk): measured 2.19 vs 2.94 ms/step at B = 2 and 2.64 vs 3.26 at B = 4 against the MFMA kernel below, which
+  // wins from M = 5 on (at MT = 8 the VALU / LDS work per weight byte catches up: 4.72 vs 4.08 ms/step at B = 8).
+  static const int rows_variant = gemv_env("P3V_GEMV_ROWS", 1);
+  if (rows_variant && variant == 3 && a->M >= 2 && a->M <= 4 && a->N % 2 == 0 && a->epilogue != P3V_EPI_F32 &&
+      (a->K == 3072 || a->K == 8192)) {
+    if (a->K == 3072) return mt == 2 ? launch_gemv3<2, 1, 6>(p, s) : launch_gemv3<4, 1, 6>(p, s);
+    return mt == 2 ? launch_gemv3<2, 4, 4>(p, s) : launch_gemv3<4, 4, 4>(p, s);
   }
   if (a->M >= 2 && a->K % (4 * 32 * GM_G) == 0 && !getenv("P3V_GEMV_NO_MFMA")) return launch_gemv_mfma(p, s);
   if (a->M > 8 || (size_t)mt * a->K * 2 > 160 * 1024 - 256) return P3V_ERR_UNSUPPORTED;
