@@ -51,7 +51,7 @@ __device__ __forceinline__ void store8_bf16(bf16_t* p, const float* v) {
   *(u32x4_t*)p = w;
 }
 
-template <int EPI>
+template <int EPI, int ORD = 0>
 __global__ void __launch_bounds__(256, 2) k_gemm(GemmP p) {
   constexpr bool SILU = EPI == P3V_EPI_SILU_MUL;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -122,7 +122,7 @@ __global__ void __launch_bounds__(256, 2) k_gemm(GemmP p) {
   for (int kt = 0; kt < nk; ++kt) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (kt + 1 < nk) stage(kt + 1, (kt + 1) & 1);
+    if (ORD == 0 && kt + 1 < nk) stage(kt + 1, (kt + 1) & 1);
     const unsigned char* ta = smem + (kt & 1) * (2 * TILE_BYTES);
     const unsigned char* tb = ta + TILE_BYTES;
     // All 16 fragment reads of the K-tile are requested up front (64 VGPRs) and the MFMAs of the first k-step start as
@@ -142,14 +142,21 @@ __global__ void __launch_bounds__(256, 2) k_gemm(GemmP p) {
         bfr[kk][j] = *(const bf16x8_t*)(tb + r * 128 + (((kk * 4 + fchunk) ^ (r & 7)) << 4));
       }
     }
+    if (ORD == 1 && kt + 1 < nk) stage(kt + 1, (kt + 1) & 1);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk)
+    for (int kk = 0; kk < 2; ++kk) {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[kk][i], bfr[kk][j], acc[i][j], 0, 0, 0);
+      if (ORD == 2 && kk == 0) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (kt + 1 < nk) stage(kt + 1, (kt + 1) & 1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
   }
 
   // ---- epilogue: MFMA C layout (col = lane&15, row = (lane>>4)*4 + r) -> wave-private LDS tile -> rows of 8 columns
@@ -242,22 +249,55 @@ __global__ void __launch_bounds__(256, 2) k_gemm(GemmP p) {
   }
 }
 
-template <int EPI>
-static int launch_gemm(const GemmP& p, hipStream_t s) {
+template <int EPI, int ORD>
+static int launch_gemm_v(const GemmP& p, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)k_gemm<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)k_gemm<EPI, ORD>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS) != hipSuccess)
       return P3V_ERR_HIP;
     attr_set = true;
   }
   const int n_tile = EPI == P3V_EPI_SILU_MUL ? BN / 2 : BN;
   dim3 grid(p3v_cdiv(p.N, n_tile), p3v_cdiv(p.M, BM));
-  hipLaunchKernelGGL(k_gemm<EPI>, grid, dim3(256), GEMM_LDS, s, p);
+  hipLaunchKernelGGL((k_gemm<EPI, ORD>), grid, dim3(256), GEMM_LDS, s, p);
   P3V_CHECK_LAUNCH();
   return P3V_OK;
 }
 
-int p3v_gemm256_try(const p3v_gemm_args_t* a, hipStream_t s);   // p3v_gemm256.hip: 256x256 tiles for prefill-sized problems
+template <int EPI>
+static int launch_gemm(const GemmP& p, hipStream_t s) { return launch_gemm_v<EPI, 0>(p, s); }
+
+int p3v_gemm256_try(const p3v_gemm_args_t* a, hipStream_t s);   // p3v_gemm256.hip: 256x256 tiles, P3V_ERR_UNSUPPORTED if the shape does not fit
+static int gemm128(const p3v_gemm_args_t* a, hipStream_t s);
+
+// How many leading rows go to the 256x256 kernel (a multiple of 256, or M for all of them); the rest runs on the
+// 128x128 kernel in a second launch on the same stream.  The machine holds 256 big workgroups or 512 small ones
+// per round; a round of big tiles costs 1, a round of small ones 0.675 (half the output area at 0.97 vs 1.31
+// PFLOP/s), a last round that leaves every CU at most one small workgroup 0.42 -- pick the cheapest whole-round
+// packing, e.g. 2531 x 16384 (gate_up): 8 x 64 = 512 big tiles = 2 rounds + 4 x 128 small = 1 round.
+static int gemm_big_rows(const p3v_gemm_args_t* a) {
+  const int n_big = a->epilogue == P3V_EPI_SILU_MUL ? 128 : 256, n_small = n_big / 2;
+  if (a->M < 1024 || a->N % n_big || a->epilogue == P3V_EPI_PATCH) return 0;
+  static const char* force = getenv("P3V_GEMM_BIG_ROWS");
+  if (force) return min(atoi(force), a->M);
+  const int mt = p3v_cdiv(a->M, 256), nt_big = a->N / n_big, nt_small = p3v_cdiv(a->N, n_small);
+  // a short K loop leaves the big tile's 128-KiB prologue and four-pass epilogue exposed (one workgroup per CU)
+  const float big_round = a->K >= 2048 ? 1.0f : 1.0f + 0.25f * (2048 - a->K) / 1024.f;
+  float best = 1e30f;
+  int best_rows = 0;
+  for (int ms = 0; ms <= mt; ++ms) {
+    const int rows_big = min(ms * 256, a->M), rows_small = a->M - rows_big;
+    const long big = (long)ms * nt_big, small = (long)p3v_cdiv(rows_small, 128) * nt_small;
+    float c = (float)((big + 255) / 256) * big_round;
+    if (small) {
+      const long full = small / 512, rest = small % 512;
+      c += 0.675f * full + (rest == 0 ? 0.f : rest <= 256 ? 0.42f : 0.675f);
+    }
+    if (big && small) c += 0.04f;                       // the second launch
+    if (c < best - 1e-4f) { best = c; best_rows = rows_big; }
+  }
+  return best_rows;
+}
 
 extern "C" int p3v_gemm(const p3v_gemm_args_t* a, void* stream) {
   if (!a || !a->A || !a->W || !a->out) return P3V_ERR_ARG;
@@ -267,15 +307,33 @@ extern "C" int p3v_gemm(const p3v_gemm_args_t* a, void* stream) {
     return P3V_ERR_ARG;
   if ((a->epilogue == P3V_EPI_BIAS_RESID_F32 || a->epilogue == P3V_EPI_RESID_BF16) && !a->resid) return P3V_ERR_ARG;
   if (a->epilogue == P3V_EPI_PATCH && (!a->pos || a->patches_per_img <= 0)) return P3V_ERR_ARG;
+  if (a->epilogue < 0 || a->epilogue > P3V_EPI_F32) return P3V_ERR_ARG;
   if (a->M == 0) return P3V_OK;
-  const GemmP p = {a->A, a->W, a->out, a->bias, a->resid, a->pos, a->M, a->N, a->K, a->lda, a->ldw, a->ldo,
-                   a->patches_per_img};
   hipStream_t s = (hipStream_t)stream;
   static const bool big_tiles = !getenv("P3V_GEMM_128");
-  if (big_tiles) {
-    const int rc = p3v_gemm256_try(a, s);
+  const int rows_big = big_tiles ? gemm_big_rows(a) : 0;
+  if (rows_big > 0) {
+    p3v_gemm_args_t top = *a;
+    top.M = rows_big;
+    const int rc = p3v_gemm256_try(&top, s);
+    if (rc == P3V_OK && rows_big < a->M) {
+      const bool f32_out = a->epilogue == P3V_EPI_BIAS_RESID_F32 || a->epilogue == P3V_EPI_F32;
+      const size_t out_row = (size_t)a->ldo * (f32_out ? 4 : 2);
+      p3v_gemm_args_t rest = *a;
+      rest.M = a->M - rows_big;
+      rest.A = a->A + (size_t)rows_big * a->lda;
+      rest.out = (char*)a->out + rows_big * out_row;
+      if (a->resid) rest.resid = (const char*)a->resid + rows_big * out_row;
+      return gemm128(&rest, s);
+    }
     if (rc != P3V_ERR_UNSUPPORTED) return rc;
   }
+  return gemm128(a, s);
+}
+
+static int gemm128(const p3v_gemm_args_t* a, hipStream_t s) {
+  const GemmP p = {a->A, a->W, a->out, a->bias, a->resid, a->pos,
+                   a->M, a->N, a->K, a->lda, a->ldw, a->ldo, a->patches_per_img};
   switch (a->epilogue) {
     case P3V_EPI_NONE: return launch_gemm<P3V_EPI_NONE>(p, s);
     case P3V_EPI_BIAS: return launch_gemm<P3V_EPI_BIAS>(p, s);

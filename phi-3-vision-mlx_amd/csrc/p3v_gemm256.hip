@@ -1,11 +1,15 @@
-// Large-tile variant of the dense projection for prefill-sized problems (M >= 1024, N % 256 == 0, K % 64 == 0):
+// Large-tile variant of the dense projection for prefill-sized problems (N % 256 == 0, K % 64 == 0; p3v_gemm decides
+// how many rows of a problem it gets):
 //   256(M) x 256(N) x 64(K) tile, 512 threads = 8 waves as 2(M) x 4(N), each wave 128 x 64 =
 //   8 x 4 v_mfma_f32_16x16x32_bf16 accumulators (128 registers), 2.67 MFMAs per LDS fragment read
 //   (the 128x128 kernel: 2.0) and 25 % less global->LDS traffic per flop.
-//   K-tile t lives in LDS buffer t&1 (2 x 64 KiB); the four 16-KiB half-tiles of tile t+1 are requested by
-//   LDS-DMA one per PHASE of tile t (a phase = one 64x32 accumulator quadrant = 16 MFMAs), so the loads are
-//   spread under the whole tile's matrix work; one vmcnt(0) + barrier per K-tile.  No barrier inside a tile:
-//   the waves de-phase, one wave's fragment reads overlap another's MFMAs.
+//   K-tile t lives in LDS buffer t&1 (2 x 64 KiB); a tile is four PHASES (one 64x32 accumulator quadrant = 16
+//   MFMAs each).  The four 16-KiB half-tiles of tile t+1 are requested by LDS-DMA in the first two phases of
+//   tile t, each batch AFTER that phase's fragment reads are issued (SCHED 0x50, ORDER 1): measured against one
+//   half-tile per phase (the last one then has only 16 MFMAs to land before the vmcnt(0)) +12 % at 4096^3
+//   (1170 -> 1310 TF/s), against all four up front +7 % (eight DMA issues ahead of the first fragment reads
+//   delay the first MFMA).  One vmcnt(0) + barrier per K-tile.  No barrier inside a tile: the waves de-phase,
+//   one wave's fragment reads overlap another's MFMAs.
 //   Same XOR-swizzled LDS image and the same epilogues as p3v_gemm.hip (through a wave-private LDS tile).
 #include <stdlib.h>
 
@@ -29,7 +33,7 @@ struct Gemm256P {
 
 __device__ __forceinline__ float gelu_erf2(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
 
-template <int EPI>
+template <int EPI, int SCHED = 0x50, int ORDER = 0>
 __global__ void __launch_bounds__(512, 1) k_gemm256(Gemm256P p) {
   constexpr bool SILU = EPI == P3V_EPI_SILU_MUL;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -129,21 +133,32 @@ __global__ void __launch_bounds__(512, 1) k_gemm256(Gemm256P p) {
                 __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][kk], bf[j][kk], acc[asub * 4 + i][bsub * 2 + j], 0, 0, 0);
       __builtin_amdgcn_s_setprio(0);
     };
+    // half-tile h of K-tile kt+1 is requested in phase (SCHED >> 2h) & 3; ORDER 1 = after the phase's fragment reads
+    auto dma_phase = [&](int ph) {
+      if (more) {
+#pragma unroll
+        for (int h = 0; h < 4; ++h)
+          if (((SCHED >> (2 * h)) & 3) == ph) dma_half(h, kt + 1, nb);
+      }
+    };
     // phase 0
-    if (more) dma_half(0, kt + 1, nb);
+    if (ORDER == 0) dma_phase(0);
     read_b(0, bf0);
     read_a(0);
+    if (ORDER == 1) dma_phase(0);
     quad(0, 0, bf0);
     // phase 1
-    if (more) dma_half(1, kt + 1, nb);
+    if (ORDER == 0) dma_phase(1);
     read_b(1, bf1);
+    if (ORDER == 1) dma_phase(1);
     quad(0, 1, bf1);
     // phase 2
-    if (more) dma_half(2, kt + 1, nb);
+    if (ORDER == 0) dma_phase(2);
     read_a(1);
+    if (ORDER == 1) dma_phase(2);
     quad(1, 1, bf1);
     // phase 3
-    if (more) dma_half(3, kt + 1, nb);
+    dma_phase(3);
     quad(1, 0, bf0);
   }
 
@@ -234,29 +249,28 @@ __global__ void __launch_bounds__(512, 1) k_gemm256(Gemm256P p) {
   }
 }
 
-template <int EPI>
-static int launch_gemm256(const Gemm256P& p, hipStream_t s) {
+template <int EPI, int SCHED, int ORDER>
+static int launch_gemm256_v(const Gemm256P& p, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)k_gemm256<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM256_LDS) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)k_gemm256<EPI, SCHED, ORDER>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM256_LDS) != hipSuccess)
       return P3V_ERR_HIP;
     attr_set = true;
   }
   const int n_tile = EPI == P3V_EPI_SILU_MUL ? TN / 2 : TN;
   dim3 grid(p3v_cdiv(p.N, n_tile), p3v_cdiv(p.M, TM));
-  hipLaunchKernelGGL(k_gemm256<EPI>, grid, dim3(512), GEMM256_LDS, s, p);
+  hipLaunchKernelGGL((k_gemm256<EPI, SCHED, ORDER>), grid, dim3(512), GEMM256_LDS, s, p);
   P3V_CHECK_LAUNCH();
   return P3V_OK;
 }
 
-// called by p3v_gemm for the large-problem epilogues it supports; returns P3V_ERR_UNSUPPORTED to fall back
+template <int EPI>
+static int launch_gemm256(const Gemm256P& p, hipStream_t s) { return launch_gemm256_v<EPI, 0x50, 1>(p, s); }
+
+// called by p3v_gemm (which decides how many rows get the big tile); returns P3V_ERR_UNSUPPORTED to fall back
 int p3v_gemm256_try(const p3v_gemm_args_t* a, hipStream_t s) {
   const int n_tile = a->epilogue == P3V_EPI_SILU_MUL ? TN / 2 : TN;
-  if (a->M < 1024 || a->N % n_tile || a->K % TK || a->epilogue == P3V_EPI_PATCH) return P3V_ERR_UNSUPPORTED;
-  // 1 workgroup per CU: the big tile only pays when the grid is several rounds of 256 workgroups deep (measured:
-  // +13 % at 4096^3/8192^3, but -25 % on 2531x3072x3072 = 120 workgroups) -- otherwise the 128x128 kernel runs
-  const long blocks = (long)p3v_cdiv(a->M, TM) * (a->N / n_tile);
-  if (!getenv("P3V_GEMM_256_ALWAYS") && !(blocks >= 1024 || (blocks >= 448 && a->K >= 2048))) return P3V_ERR_UNSUPPORTED;
+  if (a->N % n_tile || a->K % TK || a->epilogue == P3V_EPI_PATCH) return P3V_ERR_UNSUPPORTED;
   const Gemm256P p = {a->A, a->W, a->out, a->bias, a->resid, a->M, a->N, a->K, a->lda, a->ldw, a->ldo};
   switch (a->epilogue) {
     case P3V_EPI_NONE: return launch_gemm256<P3V_EPI_NONE>(p, s);
