@@ -278,8 +278,7 @@ static int gemm128(const p3v_gemm_args_t* a, hipStream_t s);
 static int gemm_big_rows(const p3v_gemm_args_t* a) {
   const int n_big = a->epilogue == P3V_EPI_SILU_MUL ? 128 : 256, n_small = n_big / 2;
   if (a->M < 1024 || a->N % n_big || a->epilogue == P3V_EPI_PATCH) return 0;
-  static const char* force = getenv("P3V_GEMM_BIG_ROWS");
-  if (force) return min(atoi(force), a->M);
+  if (const char* force = getenv("P3V_GEMM_BIG_ROWS")) return min(atoi(force) / 256 * 256, a->M);   // tests: pin the split
   const int mt = p3v_cdiv(a->M, 256), nt_big = a->N / n_big, nt_small = p3v_cdiv(a->N, n_small);
   // a short K loop leaves the big tile's 128-KiB prologue and four-pass epilogue exposed (one workgroup per CU)
   const float big_round = a->K >= 2048 ? 1.0f : 1.0f + 0.25f * (2048 - a->K) / 1024.f;

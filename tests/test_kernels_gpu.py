@@ -87,8 +87,8 @@ EPI_CASES = [
 
 @pytest.mark.parametrize("epi,M,N,K", EPI_CASES)
 def test_gemm(ops, epi, M, N, K):
-    # (P3V_GEMM_256_ALWAYS is read at first use inside the library; conftest sets it so the big-tile kernel
-    #  is exercised on these small shapes too)
+    # (conftest pins P3V_GEMM_BIG_ROWS=512, so every M >= 1024 case runs rows [0,512) on the big-tile kernel and the
+    #  rest on the small one: both kernels and the row offsets of A / out / resid are exercised on small shapes)
     a = g((M, K), 10)
     nw = 2 * N if epi == "silu" else N
     w = g((nw, K), 11, 1.0 / math.sqrt(K))
@@ -125,6 +125,36 @@ def test_gemm(ops, epi, M, N, K):
         close(out, acc, rtol=1e-3, atol=2e-3)
         return
     close(out, ref, rtol=2 ** -6, atol=2e-2)
+
+
+@pytest.mark.parametrize("epi,M,N,K", [("none", 2531, 9216, 3072), ("silu", 2531, 8192, 3072), ("resid_bf16", 2531, 3072, 3072),
+                                       ("resid_f32", 9809, 1024, 1024), ("bias", 9809, 3072, 1024), ("none", 4096, 4096, 512)])
+def test_gemm_round_packing(ops, monkeypatch, epi, M, N, K):
+    """The bench request's prefill shapes with the row split p3v_gemm's round-packing model picks (no pin), then all-big
+    and all-small tiles: the three must agree bit for bit (same K order, same epilogue arithmetic per element)."""
+    a = g((M, K), 30).cuda()
+    w = g(((2 * N if epi == "silu" else N), K), 31, 1.0 / math.sqrt(K)).cuda()
+    bias = g((N,), 32, 0.5).cuda()
+    r = g((M, N), 33, 1.0, F32 if epi == "resid_f32" else BF16).cuda()
+
+    def run():
+        if epi == "none": return ops.gemm(a, w)
+        if epi == "silu": return ops.gemm(a, w, ops.EPI_SILU_MUL)
+        if epi == "bias": return ops.gemm(a, w, ops.EPI_BIAS, bias=bias)
+        rc = r.clone()
+        if epi == "resid_bf16": return ops.gemm(a, w, ops.EPI_RESID_BF16, resid=rc, out=rc)
+        return ops.gemm(a, w, ops.EPI_BIAS_RESID_F32, bias=bias, resid=rc, out=rc)
+
+    monkeypatch.delenv("P3V_GEMM_BIG_ROWS", raising=False)
+    picked = run()
+    monkeypatch.setenv("P3V_GEMM_BIG_ROWS", "0")
+    small = run()
+    monkeypatch.setenv("P3V_GEMM_BIG_ROWS", "1000000")
+    big = run()
+    torch.cuda.synchronize()
+    assert torch.equal(picked, small) and torch.equal(picked, big)
+    acc = a[:64].float() @ w.float().t()          # spot check of the first rows against fp32 torch
+    if epi == "none": close(picked[:64], acc.to(BF16), rtol=2 ** -6, atol=2e-2)
 
 
 def test_gemm_asymmetric_identity(ops):
