@@ -337,6 +337,190 @@ __global__ void __launch_bounds__(256) k_gemv_mfma(GemvP p) {
   }
 }
 
+// ---------------------------------------------------------------------------
+// 5 <= M <= 8 rows (batched decode, B = 8 per GPU).  Three things the k_gemv_mfma stream above gets wrong at M = 8
+// (qkv, 56.6 MB: 21.7 us = 2.6 TB/s) and this kernel fixes:
+//   * WHOLE cache lines per load instruction.  An MFMA A fragment loaded straight from memory (lane -> row lane&15,
+//     16 bytes at k-group lane>>4) touches 16 rows x 64 B = sixteen HALF lines per instruction; a pure stream with that
+//     pattern tops out at 3.98 TB/s, one with eight full 128-byte lines per instruction at 5.5-5.6
+//     (tools/scratch/frag_stream.hip: patterns A / C, F).  So the 16 MFMA rows here are 8 weight rows x 2 k-halves:
+//     MFMA row i = 2*r + h, lane (i, g) loads row r, 16-byte chunk 2g + h of a 64-element line -- lane pairs are 32
+//     contiguous bytes, the instruction covers 8 full lines (pattern F: 5.54 TB/s).  The B operand is laid out the same
+//     way (column j = 2*m + h: x row m, chunk 2g + h), so C[2r + h][2m + h'] is the (row r, x row m) dot product over the
+//     k-half h when h == h' and junk otherwise; the two halves are added with one DPP lane swap at the end.  Half the
+//     matrix-core work is thrown away -- it is idle anyway.
+//   * the activations are staged ONCE per workgroup in LDS as bf16(x * r * g) -- exactly the M = 1 kernel's RMSNorm
+//     arithmetic -- instead of two more L2 loads (x, norm weights) per lane next to every weight load.
+//   * a wave's whole weight slice (NST stages of 8 loads; 3 for K = 3072) is requested up front: the x loads go first
+//     (loads retire in order and these come back from L2), then two weight stages, the third as soon as the raw x is
+//     parked in LDS.  Every workgroup of a launch is resident at once, so with a two-deep pipeline the chip moved in
+//     lockstep through [stage 0 in flight] [prologue] [stage 1 in flight] ...
+// A workgroup = 16 weight rows (two 8-row sets; SiLU*up: 8 gate rows + the matching 8 up rows); wave w owns K slice w and
+// stages that slice of x itself; the only workgroup barrier before the stream is the RMSNorm sum-of-squares exchange.
+// LDS row stride 2K + 64 bytes: the 16 (x row, chunk) slots of every ds_read_b128 lane group fall on 16 different
+// 16-byte bank groups.  K = 3072: 4 waves, 49.7 KB -> 3 workgroups / CU.  K = 8192: 8 waves, 131 KB -> 1 workgroup / CU.
+template <bool SILU, int NW, int NST>
+__global__ void __launch_bounds__(NW * 64) k_gemv_mfma8(GemvP p) {
+  constexpr int NBUF = NST < 3 ? NST : 3;
+  constexpr int KQ = NST * 256, K = KQ * NW, XS = K * 2 + 64, NCH = KQ / 8;     // slice elements, LDS row stride (bytes), slice chunks
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ float red[NW][8];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4;
+  const int r8 = (lane & 15) >> 1, chunk = 2 * g + (lane & 1);                   // weight row in the set / x row; 16-byte chunk of a line
+  const int n_base = blockIdx.x * (SILU ? 8 : 16), k_lo = wave * KQ;
+  const int row0 = min(n_base + r8, p.N - 1);
+  const int row1 = SILU ? p.N + row0 : min(n_base + 8 + r8, p.N - 1);
+  const bf16_t* w0 = p.W + (size_t)row0 * K + k_lo + 8 * chunk;
+  const bf16_t* w1 = p.W + (size_t)row1 * K + k_lo + 8 * chunk;
+
+  u32x4_t wa[NBUF][8];                                                           // stage = 4 lines x 2 row sets
+  auto issue = [&](int st, auto bufc) {
+    constexpr int buf = decltype(bufc)::value;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      wa[buf][2 * q] = __builtin_nontemporal_load((const u32x4_t*)(w0 + (st * 4 + q) * 64));
+      wa[buf][2 * q + 1] = __builtin_nontemporal_load((const u32x4_t*)(w1 + (st * 4 + q) * 64));
+    }
+  };
+  typedef std::integral_constant<int, 2> IC2;
+
+  // ---- x slice (8 rows x NCH chunks, lanes over chunks) first, then the weight stages that fit next to it
+  unsigned char* xslice = smem + k_lo * 2;
+  u32x4_t gv[2];
+  float ss[8];
+  {
+    u32x4_t xv[8][2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int c = min(lane + 64 * k, NCH - 1);
+#pragma unroll
+      for (int m = 0; m < 8; ++m) xv[m][k] = *(const u32x4_t*)(p.x + (size_t)min(m, p.M - 1) * K + k_lo + 8 * c);
+      gv[k] = p.norm_w ? *(const u32x4_t*)(p.norm_w + k_lo + 8 * c) : (u32x4_t){0, 0, 0, 0};
+    }
+    issue(0, IC0{});
+    if constexpr (NBUF > 1) issue(1, IC1{});
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+      ss[m] = 0.f;
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int c = lane + 64 * k;
+        if (c < NCH) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { const float a = bf16lo(xv[m][k][j]), b = bf16hi(xv[m][k][j]); ss[m] += a * a + b * b; }
+          *(u32x4_t*)(xslice + m * XS + c * 16) = m < p.M ? xv[m][k] : (u32x4_t){0, 0, 0, 0};
+        }
+      }
+    }
+  }
+  if constexpr (NBUF > 2) issue(2, IC2{});
+  if (p.norm_w) {
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+      const float t = wave_sum(ss[m]);
+      if (lane == 0) red[wave][m] = t;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) t += red[w][m];
+      const float r = rsqrtf(t / (float)K + p.eps);
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int c = lane + 64 * k;
+        if (c < NCH) {
+          u32x4_t* px = (u32x4_t*)(xslice + m * XS + c * 16);
+          const u32x4_t v = *px;
+          u32x4_t o;
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            o[j] = pack_bf16x2(bf16lo(v[j]) * r * bf16lo(gv[k][j]), bf16hi(v[j]) * r * bf16hi(gv[k][j]));
+          *px = o;
+        }
+      }
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                           // the slice is wave-private: no barrier
+
+  f32x4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+  const unsigned char* xrow = xslice + r8 * XS + chunk * 16;
+  auto compute = [&](int st, auto bufc) {
+    constexpr int buf = decltype(bufc)::value;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const bf16x8_t xb = *(const bf16x8_t*)(xrow + (st * 4 + q) * 128);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wa[buf][2 * q]), xb, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wa[buf][2 * q + 1]), xb, acc1, 0, 0, 0);
+    }
+  };
+  // stage st lives in buffer st % NBUF; stage st + NBUF is requested right after stage st has been consumed
+  auto step = [&](auto stc) {
+    constexpr int st = decltype(stc)::value;
+    if constexpr (st < NST) {
+      compute(st, std::integral_constant<int, st % NBUF>{});
+      if constexpr (st + NBUF < NST) issue(st + NBUF, std::integral_constant<int, st % NBUF>{});
+    }
+  };
+  step(IC0{}); step(IC1{}); step(IC2{}); step(std::integral_constant<int, 3>{});
+  static_assert(NST <= 4, "unrolled for at most four stages");
+
+  // ---- C[4*(lane>>4) + e][lane&15]: with column j = 2m + h only elements e = h (weight row 2*(lane>>4)) and e = h + 2
+  // (row 2*(lane>>4) + 1) are dot products; add the two k-halves (lanes j = 2m, 2m + 1), then the NW K slices through LDS
+  const bool odd = lane & 1;
+  float e[2][2] = {{odd ? acc0[1] : acc0[0], odd ? acc0[3] : acc0[2]}, {odd ? acc1[1] : acc1[0], odd ? acc1[3] : acc1[2]}};
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int u = 0; u < 2; ++u) e[t][u] += P3V_DPP_F32(e[t][u], 0xB1);          // quad_perm [1,0,3,2]
+  __syncthreads();                                                    // the x image is dead once every wave is past its stream
+  float* cpart = (float*)smem;                                        // [NW][2 sets][8 rows][8 x rows]
+  if (!odd) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) cpart[((wave * 2 + t) * 8 + 2 * g + u) * 8 + r8] = e[t][u];
+  }
+  __syncthreads();
+  if (tid >= (SILU ? 64 : 128)) return;
+  const int R = tid & 7, m = (tid >> 3) & 7, set = tid >> 6;
+  const int n = n_base + set * 8 + R;
+  if (m >= p.M || n >= p.N) return;
+  float v0 = 0.f, v1 = 0.f;
+#pragma unroll
+  for (int w = 0; w < NW; ++w) {
+    v0 += cpart[((w * 2 + set) * 8 + R) * 8 + m];
+    if (SILU) v1 += cpart[((w * 2 + 1) * 8 + R) * 8 + m];
+  }
+  const size_t o = (size_t)m * p.N + n;
+  if (SILU) {
+    const float gt = bf16_round(v0), up = bf16_round(v1);
+    ((bf16_t*)p.out)[o] = f32_to_bf16(bf16_round(gt * bf16_round(1.f / (1.f + __expf(-gt)))) * up);
+  } else if (p.epi == P3V_EPI_F32) {
+    ((float*)p.out)[o] = v0;
+  } else if (p.epi == P3V_EPI_RESID_BF16) {
+    ((bf16_t*)p.out)[o] = f32_to_bf16(bf16_to_f32(p.resid[o]) + bf16_round(v0));
+  } else {
+    ((bf16_t*)p.out)[o] = f32_to_bf16(v0);
+  }
+}
+
+template <bool SILU, int NW, int NST>
+static int launch_gemv_mfma8(const GemvP& p, hipStream_t s) {
+  const size_t lds = (size_t)8 * (p.K * 2 + 64);
+  static bool attr_set = false;
+  if (!attr_set && lds > 48 * 1024) {
+    if (hipFuncSetAttribute((const void*)k_gemv_mfma8<SILU, NW, NST>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512) != hipSuccess)
+      return P3V_ERR_HIP;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((k_gemv_mfma8<SILU, NW, NST>), dim3(p3v_cdiv(p.N, SILU ? 8 : 16)), dim3(NW * 64), lds, s, p);
+  P3V_CHECK_LAUNCH();
+  return P3V_OK;
+}
+
 extern "C" int64_t p3v_gemv_ws_bytes(int M, int N, int K) { return 0; }   // kept in the ABI; the MFMA path needs no scratch
 
 static int launch_gemv_mfma(const GemvP& p, hipStream_t s) {
@@ -364,13 +548,26 @@ extern "C" int p3v_gemv(const p3v_gemv_args_t* a, void* stream) {
     return launch_gemv3<1, 4, 4>(p, s);                  // 8192 = 4 stages x 4 chunks: keeps 2 waves/SIMD resident
   }
   // 2 <= M <= 4: the same streaming kernel with MT activation rows in LDS (full-line weight loads, 4 v_dot2c per row and
-  // 16-byte chunk): measured 2.19 vs 2.94 ms/step at B = 2 and 2.64 vs 3.26 at B = 4 against the MFMA kernel below, which
-  // wins from M = 5 on (at MT = 8 the VALU / LDS work per weight byte catches up: 4.72 vs 4.08 ms/step at B = 8).
+  // 16-byte chunk): measured 2.19 vs 2.94 ms/step at B = 2 and 2.64 vs 3.26 at B = 4 against k_gemv_mfma; from M = 5 on the
+  // matrix cores take over (at MT = 8 the VALU / LDS work per weight byte catches up: 4.72 ms/step at B = 8 against 4.08
+  // with k_gemv_mfma and 3.27 with k_gemv_mfma8).
   static const int rows_variant = gemv_env("P3V_GEMV_ROWS", 1);
   if (rows_variant && variant == 3 && a->M >= 2 && a->M <= 4 && a->N % 2 == 0 && a->epilogue != P3V_EPI_F32 &&
       (a->K == 3072 || a->K == 8192)) {
     if (a->K == 3072) return mt == 2 ? launch_gemv3<2, 1, 6>(p, s) : launch_gemv3<4, 1, 6>(p, s);
     return mt == 2 ? launch_gemv3<2, 4, 4>(p, s) : launch_gemv3<4, 4, 4>(p, s);
+  }
+  static const int rows8 = gemv_env("P3V_GEMV_MFMA8", 1);
+  if (rows8 && a->M >= 5 && a->M <= 8) {
+    const bool silu = a->epilogue == P3V_EPI_SILU_MUL;
+    switch (a->K) {                                      // K = NW waves x NST stages x 256
+      case 1024: return silu ? launch_gemv_mfma8<true, 4, 1>(p, s) : launch_gemv_mfma8<false, 4, 1>(p, s);
+      case 2048: return silu ? launch_gemv_mfma8<true, 4, 2>(p, s) : launch_gemv_mfma8<false, 4, 2>(p, s);
+      case 3072: return silu ? launch_gemv_mfma8<true, 4, 3>(p, s) : launch_gemv_mfma8<false, 4, 3>(p, s);
+      case 4096: return silu ? launch_gemv_mfma8<true, 8, 2>(p, s) : launch_gemv_mfma8<false, 8, 2>(p, s);
+      case 8192: return silu ? launch_gemv_mfma8<true, 8, 4>(p, s) : launch_gemv_mfma8<false, 8, 4>(p, s);
+      default: break;
+    }
   }
   if (a->M >= 2 && a->K % (4 * 32 * GM_G) == 0 && !getenv("P3V_GEMV_NO_MFMA")) return launch_gemv_mfma(p, s);
   if (a->M > 8 || (size_t)mt * a->K * 2 > 160 * 1024 - 256) return P3V_ERR_UNSUPPORTED;

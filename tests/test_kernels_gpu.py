@@ -170,7 +170,10 @@ def test_gemm_asymmetric_identity(ops):
                                        (3, 576, 192, "none"), (8, 3072, 8192, "resid"), (5, 256, 192, "silu"),
                                        (1, 32064, 3072, "norm"), (8, 9216, 3072, "norm"), (2, 101, 192, "none"),
                                        (16, 3072, 3072, "resid"), (16, 8192, 3072, "silu"), (12, 9216, 3072, "norm"),
-                                       (2, 3072, 8192, "resid"), (9, 32064, 3072, "norm"), (16, 1000, 1024, "none")])
+                                       (2, 3072, 8192, "resid"), (9, 32064, 3072, "norm"), (16, 1000, 1024, "none"),
+                                       # 5 <= M <= 8: activations staged in LDS (k_gemv_mfma8), 4 waves (K <= 3072) / 8 waves
+                                       (8, 8192, 3072, "silu"), (6, 3072, 3072, "resid"), (7, 32064, 3072, "norm"),
+                                       (5, 1000, 1024, "none"), (8, 3072, 4096, "none"), (5, 8192, 2048, "silu")])
 def test_gemv(ops, orc, M, N, K, epi):
     x = g((M, K), 20)
     nw = 2 * N if epi == "silu" else N
