@@ -260,6 +260,155 @@ __global__ void __launch_bounds__(256) k_gemv_mfma_f8(GemvF8P p) {
   }
 }
 
+// ---------------------------------------------------------------- 5 <= M <= 8 rows: e4m3 twin of k_gemv_mfma8 (p3v_gemv.hip)
+// Same three ideas: whole 128-byte lines per load instruction (MFMA row i = 2r + h: weight row r of an 8-row set, lane (i, g)
+// loads the 16 bytes = 16 weights of chunk 2g + h; one load feeds the two MFMAs of its k-halves), activations staged once per
+// workgroup in LDS as bf16(x * r * g), and the wave's whole weight slice (12 loads at K = 3072) requested up front.  The
+// k_gemv_mfma_f8 stream above issues FIVE 16-byte loads per lane (weights, 2 x, 2 norm weights) for each one from HBM.
+template <bool SILU, int NW, int NL>                     // NL = 128-element lines per wave slice
+__global__ void __launch_bounds__(NW * 64) k_gemv_mfma8_f8(GemvF8P p) {
+  constexpr int KQ = NL * 128, K = KQ * NW, XS = K * 2 + 64, NCH = KQ / 8;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ float red[NW][8];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4;
+  const int r8 = (lane & 15) >> 1, chunk = 2 * g + (lane & 1);
+  const int n_base = blockIdx.x * (SILU ? 8 : 16), k_lo = wave * KQ;
+  const int row0 = min(n_base + r8, p.N - 1);
+  const int row1 = SILU ? p.N + row0 : min(n_base + 8 + r8, p.N - 1);
+  const uint8_t* w0 = p.W + (size_t)row0 * K + k_lo + 16 * chunk;
+  const uint8_t* w1 = p.W + (size_t)row1 * K + k_lo + 16 * chunk;
+
+  unsigned char* xslice = smem + k_lo * 2;
+  constexpr int XP = (NCH + 63) / 64;                    // x chunks per lane and row (2 at K = 3072, 8192)
+  u32x4_t gv[XP], wa[NL], wb[NL];
+  float ss[8];
+  {
+    u32x4_t xv[8][XP];
+#pragma unroll
+    for (int k = 0; k < XP; ++k) {
+      const int c = min(lane + 64 * k, NCH - 1);
+#pragma unroll
+      for (int m = 0; m < 8; ++m) xv[m][k] = *(const u32x4_t*)(p.x + (size_t)min(m, p.M - 1) * K + k_lo + 8 * c);
+      gv[k] = p.norm_w ? *(const u32x4_t*)(p.norm_w + k_lo + 8 * c) : (u32x4_t){0, 0, 0, 0};
+    }
+#pragma unroll
+    for (int l = 0; l < NL; ++l) {
+      wa[l] = __builtin_nontemporal_load((const u32x4_t*)(w0 + l * 128));
+      wb[l] = __builtin_nontemporal_load((const u32x4_t*)(w1 + l * 128));
+    }
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+      ss[m] = 0.f;
+#pragma unroll
+      for (int k = 0; k < XP; ++k) {
+        const int c = lane + 64 * k;
+        if (c < NCH) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { const float a = bf16lo(xv[m][k][j]), b = bf16hi(xv[m][k][j]); ss[m] += a * a + b * b; }
+          *(u32x4_t*)(xslice + m * XS + c * 16) = m < p.M ? xv[m][k] : (u32x4_t){0, 0, 0, 0};
+        }
+      }
+    }
+  }
+  if (p.norm_w) {
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+      const float t = wave_sum(ss[m]);
+      if (lane == 0) red[wave][m] = t;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) t += red[w][m];
+      const float r = rsqrtf(t / (float)K + p.eps);
+#pragma unroll
+      for (int k = 0; k < XP; ++k) {
+        const int c = lane + 64 * k;
+        if (c < NCH) {
+          u32x4_t* px = (u32x4_t*)(xslice + m * XS + c * 16);
+          const u32x4_t v = *px;
+          u32x4_t o;
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            o[j] = pack_bf16x2(bf16lo(v[j]) * r * bf16lo(gv[k][j]), bf16hi(v[j]) * r * bf16hi(gv[k][j]));
+          *px = o;
+        }
+      }
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                           // the slice is wave-private: no barrier
+
+  f32x4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+  const unsigned char* xrow = xslice + r8 * XS + chunk * 32;                     // 16 weights <-> 32 bytes of bf16 x
+#pragma unroll
+  for (int l = 0; l < NL; ++l) {
+    u32x4_t a_lo, a_hi, b_lo, b_hi;
+    f8x16_to_bf16(wa[l], a_lo, a_hi);
+    f8x16_to_bf16(wb[l], b_lo, b_hi);
+    const bf16x8_t x0 = *(const bf16x8_t*)(xrow + l * 256), x1 = *(const bf16x8_t*)(xrow + l * 256 + 16);
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a_lo), x0, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, b_lo), x0, acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a_hi), x1, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, b_hi), x1, acc1, 0, 0, 0);
+  }
+
+  const bool odd = lane & 1;
+  float e[2][2] = {{odd ? acc0[1] : acc0[0], odd ? acc0[3] : acc0[2]}, {odd ? acc1[1] : acc1[0], odd ? acc1[3] : acc1[2]}};
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int u = 0; u < 2; ++u) e[t][u] += P3V_DPP_F32(e[t][u], 0xB1);          // quad_perm [1,0,3,2]: the other k-half
+  __syncthreads();
+  float* cpart = (float*)smem;                                        // [NW][2 sets][8 rows][8 x rows]
+  if (!odd) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) cpart[((wave * 2 + t) * 8 + 2 * g + u) * 8 + r8] = e[t][u];
+  }
+  __syncthreads();
+  if (tid >= (SILU ? 64 : 128)) return;
+  const int R = tid & 7, m = (tid >> 3) & 7, set = tid >> 6;
+  const int n = n_base + set * 8 + R;
+  if (m >= p.M || n >= p.N) return;
+  float v0 = 0.f, v1 = 0.f;
+#pragma unroll
+  for (int w = 0; w < NW; ++w) {
+    v0 += cpart[((w * 2 + set) * 8 + R) * 8 + m];
+    if (SILU) v1 += cpart[((w * 2 + 1) * 8 + R) * 8 + m];
+  }
+  v0 *= p.wscale[n];
+  const size_t o = (size_t)m * p.N + n;
+  if (SILU) {
+    v1 *= p.wscale[n + p.N];
+    const float gt = bf16_round(v0), up = bf16_round(v1);
+    ((bf16_t*)p.out)[o] = f32_to_bf16(bf16_round(gt * bf16_round(1.f / (1.f + __expf(-gt)))) * up);
+  } else if (p.epi == P3V_EPI_F32) {
+    ((float*)p.out)[o] = v0;
+  } else if (p.epi == P3V_EPI_RESID_BF16) {
+    ((bf16_t*)p.out)[o] = f32_to_bf16(bf16_to_f32(p.resid[o]) + bf16_round(v0));
+  } else {
+    ((bf16_t*)p.out)[o] = f32_to_bf16(v0);
+  }
+}
+
+template <bool SILU, int NW, int NL>
+static int launch_gemv_mfma8_f8(const GemvF8P& p, hipStream_t s) {
+  const size_t lds = (size_t)8 * (p.K * 2 + 64);
+  static bool attr_set = false;
+  if (!attr_set && lds > 48 * 1024) {
+    if (hipFuncSetAttribute((const void*)k_gemv_mfma8_f8<SILU, NW, NL>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512) != hipSuccess)
+      return P3V_ERR_HIP;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((k_gemv_mfma8_f8<SILU, NW, NL>), dim3(p3v_cdiv(p.N, SILU ? 8 : 16)), dim3(NW * 64), lds, s, p);
+  P3V_CHECK_LAUNCH();
+  return P3V_OK;
+}
+
 // ---------------------------------------------------------------- fp8 -> bf16 (prefill scratch)
 __global__ void __launch_bounds__(256) k_dequant_fp8(const u32x4_t* __restrict__ w8, const float* __restrict__ scale,
                                                      u32x4_t* __restrict__ out, int chunks_per_row, long total) {
@@ -317,6 +466,11 @@ extern "C" int p3v_gemv_fp8(const p3v_gemv_fp8_args_t* a, void* stream) {
                a->epilogue == P3V_EPI_SILU_MUL ? a->N : a->N / 2};
   hipStream_t s = (hipStream_t)stream;
   if (a->M == 1) return a->K == 3072 ? launch_gemv3_f8<1, 3>(p, s) : launch_gemv3_f8<2, 4>(p, s);
+  if (a->M >= 5 && a->M <= 8 && !getenv("P3V_GEMV_NO_MFMA8")) {
+    const bool silu = a->epilogue == P3V_EPI_SILU_MUL;
+    if (a->K == 3072) return silu ? launch_gemv_mfma8_f8<true, 4, 6>(p, s) : launch_gemv_mfma8_f8<false, 4, 6>(p, s);
+    return silu ? launch_gemv_mfma8_f8<true, 8, 8>(p, s) : launch_gemv_mfma8_f8<false, 8, 8>(p, s);
+  }
   dim3 grid(p3v_cdiv(a->N, 16));
   if (a->epilogue == P3V_EPI_SILU_MUL) hipLaunchKernelGGL(k_gemv_mfma_f8<true>, grid, dim3(256), 0, s, p);
   else hipLaunchKernelGGL(k_gemv_mfma_f8<false>, grid, dim3(256), 0, s, p);

@@ -198,7 +198,9 @@ def test_gemv(ops, orc, M, N, K, epi):
 
 @pytest.mark.parametrize("M,N,K,epi", [(1, 9216, 3072, "norm"), (1, 3072, 8192, "resid"), (1, 8192, 3072, "silu"),
                                        (8, 3072, 3072, "resid"), (16, 8192, 3072, "silu"), (5, 9216, 3072, "norm"),
-                                       (2, 3072, 8192, "none"), (1, 32064, 3072, "norm")])
+                                       (2, 3072, 8192, "none"), (1, 32064, 3072, "norm"),
+                                       # 5 <= M <= 8: k_gemv_mfma8_f8 (whole-line fragment loads, x staged in LDS)
+                                       (8, 8192, 3072, "silu"), (7, 3072, 8192, "resid"), (6, 32064, 3072, "norm"), (8, 1000, 3072, "none")])
 def test_gemv_fp8(ops, orc, M, N, K, epi):
     """fp8 weight-only projection == the bf16 math on the DEQUANTISED weights (the only new error is weight rounding,
     which the reference comparison below does not see: both sides use fp8*scale)."""
