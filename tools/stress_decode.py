@@ -7,8 +7,9 @@ from phi_3_vision_mlx_amd import ops
 from phi_3_vision_mlx_amd.api import load_synthetic
 ctx = int(sys.argv[1]) if len(sys.argv) > 1 else 2531
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 1500
+B = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 model, _ = load_synthetic(blind_model=True, device="cuda:0")
-ids = np.random.default_rng(0).integers(3, 32000, (1, ctx))
+ids = np.random.default_rng(0).integers(3, 32000, (B, ctx))
 runs = []
 for rep in range(2):
     lg, cache = model(input_ids=ids, max_tokens=steps + 8)
@@ -23,5 +24,5 @@ for rep in range(2):
     runs.append((torch.cat(toks, 1).cpu(), lg.float().cpu().clone()))
     del cache
 same_tok = torch.equal(runs[0][0], runs[1][0]); same_lg = torch.equal(runs[0][1], runs[1][1])
-print(f"ctx {ctx}, {steps} steps x 2 runs: tokens identical {same_tok}, final logits identical {same_lg}, distinct tokens {runs[0][0].unique().numel()}")
+print(f"ctx {ctx}, B {B}, {steps} steps x 2 runs: tokens identical {same_tok}, final logits identical {same_lg}, distinct tokens {runs[0][0].unique().numel()}")
 assert same_tok and same_lg
