@@ -303,7 +303,7 @@ class Phi3VModel:
             h=torch.empty((M, H), dtype=BF16, device=dev), n_split=0, ws=None)
         return bufs
 
-    def _split_plan(self, bufs, B, L, T):
+    def _split_plan(self, bufs, B, L, T, quantized=False):
         """Split-KV plan for the decode-shaped attention (L <= 16): enough blocks to fill 256 CUs."""
         nh, hd = self.cfg.num_attention_heads, self.hd
         if L <= ops.L.DECODE_MAX_L:
@@ -314,7 +314,9 @@ class Phi3VModel:
             if tiles <= 128 and B * nh * tiles <= 4096:
                 n_split = tiles
             else:
-                n_split = max(1, min(128, tiles, -(-768 // max(1, B * nh))))
+                # (int8 KV: a tile is half the bytes and the single-wave kernel's 27.5 KB of LDS lets 5 workgroups share a CU,
+                #  so ~1280 workgroups keep as many bytes in flight: 3.68 -> 3.40 ms/step at 32k)
+                n_split = max(1, min(128, tiles, -(-(1280 if quantized else 768) // max(1, B * nh))))
             if os.environ.get("P3V_ATTN_NSPLIT"):
                 n_split = int(os.environ["P3V_ATTN_NSPLIT"])
             bufs["n_split"] = n_split
@@ -336,7 +338,7 @@ class Phi3VModel:
         scale = hd ** -0.5
         if bufs is None:
             bufs = self._alloc_bufs(B, L)
-            self._split_plan(bufs, B, L, past + L)
+            self._split_plan(bufs, B, L, past + L, st.quantized)
         q, o, qkv, a, h, n_split, ws = (bufs[k] for k in ("q", "o", "qkv", "a", "h", "n_split", "ws"))
         if st.quantized and n_beam > 1:
             raise NotImplementedError("Beam Search is not yet compatible with Quantized Cache")       # as phi.py:525
@@ -423,7 +425,7 @@ class Phi3VModel:
                  logits=torch.empty((B, cfg.vocab_size), dtype=BF16, device=dev),
                  next_tok=torch.zeros((B,), dtype=I32, device=dev), ticket=torch.zeros((1,), dtype=I32, device=dev))
         bufs = self._alloc_bufs(B, 1)
-        self._split_plan(bufs, B, 1, st.T)
+        self._split_plan(bufs, B, 1, st.T, st.quantized)
         # In-launch synchronisation state of the step's fused launches, cleared by step_begin every step:
         #  * chain_cnt: arrival counters of the GEMV chain o_proj -> gate_up -> down -> next qkv (ONE launch per layer,
         #    p3v_gemv_chain) -- bit-identical but OFF by default (P3V_GEMV_CHAIN=1): 2.42 ms/step against 1.87 with
