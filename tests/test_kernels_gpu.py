@@ -173,7 +173,8 @@ def test_gemm_asymmetric_identity(ops):
                                        (2, 3072, 8192, "resid"), (9, 32064, 3072, "norm"), (16, 1000, 1024, "none"),
                                        # 5 <= M <= 8: activations staged in LDS (k_gemv_mfma8), 4 waves (K <= 3072) / 8 waves
                                        (8, 8192, 3072, "silu"), (6, 3072, 3072, "resid"), (7, 32064, 3072, "norm"),
-                                       (5, 1000, 1024, "none"), (8, 3072, 4096, "none"), (5, 8192, 2048, "silu")])
+                                       (5, 1000, 1024, "none"), (8, 3072, 4096, "none"), (5, 8192, 2048, "silu"),
+                                       (6, 100, 1024, "silu"), (7, 37, 2048, "none"), (8, 24, 3072, "resid")])   # ragged N
 def test_gemv(ops, orc, M, N, K, epi):
     x = g((M, K), 20)
     nw = 2 * N if epi == "silu" else N
