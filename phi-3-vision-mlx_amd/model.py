@@ -325,7 +325,7 @@ class Phi3VModel:
             # per step at B = 1; with the multi-tile streaming kernel the write-through partial stores cost more than the
             # merge launch saves, and beyond ~48 splits the one merging workgroup is slower than 32 parallel ones)
             mode = os.environ.get("P3V_ATTN_FUSED_MERGE", "1")
-            fused = (n_split == tiles or mode == "2") and 1 < n_split <= 48 and mode != "0"
+            fused = (n_split == tiles or mode == "2") and n_split <= 48 and mode != "0"
             bufs["attn_cnt"] = torch.zeros(B * nh * n_split, dtype=I32, device=self.device) if fused else None
 
     def _layers(self, x, st, B, L, past, n_beam, bufs=None, d_past=None):
