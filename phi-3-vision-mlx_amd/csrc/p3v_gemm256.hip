@@ -5,11 +5,13 @@
 //   (the 128x128 kernel: 2.0) and 25 % less global->LDS traffic per flop.
 //   K-tile t lives in LDS buffer t&1 (2 x 64 KiB); a tile is four PHASES (one 64x32 accumulator quadrant = 16
 //   MFMAs each).  The four 16-KiB half-tiles of tile t+1 are requested by LDS-DMA in the first two phases of
-//   tile t, each batch AFTER that phase's fragment reads are issued (SCHED 0x50, ORDER 1): measured against one
+//   tile t, each batch AFTER that phase's fragment reads are issued (SCHED 0x50): measured against one
 //   half-tile per phase (the last one then has only 16 MFMAs to land before the vmcnt(0)) +12 % at 4096^3
 //   (1170 -> 1310 TF/s), against all four up front +7 % (eight DMA issues ahead of the first fragment reads
-//   delay the first MFMA).  One vmcnt(0) + barrier per K-tile.  No barrier inside a tile: the waves de-phase,
-//   one wave's fragment reads overlap another's MFMAs.
+//   delay the first MFMA).  The fragment reads are software-pipelined (ORDER 2): the fragments of phase p+1 are requested
+//   before the MFMAs of phase p (second A-fragment buffer, 256 registers, no spill), +1.5-2 % at 4096^3 / 8192^3
+//   (1.28 -> 1.30, 1.32 -> 1.34 PFLOP/s).  One vmcnt(0) + barrier per K-tile.  No barrier inside a tile: the waves
+//   de-phase, one wave's fragment reads overlap another's MFMAs.
 //   Same XOR-swizzled LDS image and the same epilogues as p3v_gemm.hip (through a wave-private LDS tile).
 #include <stdlib.h>
 
@@ -102,16 +104,17 @@ __global__ void __launch_bounds__(512, 1) k_gemm256(Gemm256P p) {
     const int nb = (kt + 1) & 1;
     const unsigned char* ta = smem + (kt & 1) * BUF_BYTES + wr * HALF_BYTES;                      // this wave's A half
     const unsigned char* tb = smem + (kt & 1) * BUF_BYTES + (2 + (wc >> 1)) * HALF_BYTES + (wc & 1) * 64 * 128;  // its 64 B rows
-    bf16x8_t af[4][2], bf0[2][2], bf1[2][2];
-    auto read_a = [&](int sub) {
+    bf16x8_t af[4][2], af1[4][2], bf0[2][2], bf1[2][2];
+    auto read_a_to = [&](int sub, bf16x8_t (&dst)[4][2]) {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
           const int r = sub * 64 + i * 16 + frow;
-          af[i][kk] = *(const bf16x8_t*)(ta + r * 128 + (((kk * 4 + fchunk) ^ (r & 7)) << 4));
+          dst[i][kk] = *(const bf16x8_t*)(ta + r * 128 + (((kk * 4 + fchunk) ^ (r & 7)) << 4));
         }
     };
+    auto read_a = [&](int sub) { read_a_to(sub, af); };
     auto read_b = [&](int sub, bf16x8_t (&bf)[2][2]) {
 #pragma unroll
       for (int j = 0; j < 2; ++j)
@@ -121,7 +124,7 @@ __global__ void __launch_bounds__(512, 1) k_gemm256(Gemm256P p) {
           bf[j][kk] = *(const bf16x8_t*)(tb + r * 128 + (((kk * 4 + fchunk) ^ (r & 7)) << 4));
         }
     };
-    auto quad = [&](int asub, int bsub, bf16x8_t (&bf)[2][2]) {
+    auto quad_from = [&](int asub, int bsub, bf16x8_t (&a)[4][2], bf16x8_t (&bf)[2][2]) {
       __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk)
@@ -130,9 +133,10 @@ __global__ void __launch_bounds__(512, 1) k_gemm256(Gemm256P p) {
 #pragma unroll
           for (int j = 0; j < 2; ++j)
             acc[asub * 4 + i][bsub * 2 + j] =
-                __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][kk], bf[j][kk], acc[asub * 4 + i][bsub * 2 + j], 0, 0, 0);
+                __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][kk], bf[j][kk], acc[asub * 4 + i][bsub * 2 + j], 0, 0, 0);
       __builtin_amdgcn_s_setprio(0);
     };
+    auto quad = [&](int asub, int bsub, bf16x8_t (&bf)[2][2]) { quad_from(asub, bsub, af, bf); };
     // half-tile h of K-tile kt+1 is requested in phase (SCHED >> 2h) & 3; ORDER 1 = after the phase's fragment reads
     auto dma_phase = [&](int ph) {
       if (more) {
@@ -141,6 +145,25 @@ __global__ void __launch_bounds__(512, 1) k_gemm256(Gemm256P p) {
           if (((SCHED >> (2 * h)) & 3) == ph) dma_half(h, kt + 1, nb);
       }
     };
+    if (ORDER == 2) {
+      // software-pipelined fragment reads: the fragments of phase p+1 are requested BEFORE the MFMAs of phase p (second A
+      // fragment buffer, 224 of 256 registers), so only the first reads after the barrier expose their LDS latency
+      read_b(0, bf0);
+      read_a_to(0, af);
+      dma_phase(0);
+      read_b(1, bf1);
+      __builtin_amdgcn_sched_barrier(0);
+      quad_from(0, 0, af, bf0);
+      __builtin_amdgcn_sched_barrier(0);
+      read_a_to(1, af1);
+      dma_phase(1);
+      __builtin_amdgcn_sched_barrier(0);
+      quad_from(0, 1, af, bf1);
+      __builtin_amdgcn_sched_barrier(0);
+      quad_from(1, 1, af1, bf1);
+      quad_from(1, 0, af1, bf0);
+      continue;
+    }
     // phase 0
     if (ORDER == 0) dma_phase(0);
     read_b(0, bf0);
@@ -265,7 +288,7 @@ static int launch_gemm256_v(const Gemm256P& p, hipStream_t s) {
 }
 
 template <int EPI>
-static int launch_gemm256(const Gemm256P& p, hipStream_t s) { return launch_gemm256_v<EPI, 0x50, 1>(p, s); }
+static int launch_gemm256(const Gemm256P& p, hipStream_t s) { return launch_gemm256_v<EPI, 0x50, 2>(p, s); }
 
 // called by p3v_gemm (which decides how many rows get the big tile); returns P3V_ERR_UNSUPPORTED to fall back
 int p3v_gemm256_try(const p3v_gemm_args_t* a, hipStream_t s) {
