@@ -55,7 +55,7 @@ template <int EPI, int ORD = 0>
 __global__ void __launch_bounds__(256, 2) k_gemm(GemmP p) {
   constexpr bool SILU = EPI == P3V_EPI_SILU_MUL;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // uniform: LDS-DMA bases stay in SGPRs
   const int wr = wave >> 1, wc = wave & 1;
   const int n_out_tile = SILU ? BN / 2 : BN;
   // XCD-aware tile order: the dispatcher places workgroup i on XCD i % 8 (speed only, never correctness), so

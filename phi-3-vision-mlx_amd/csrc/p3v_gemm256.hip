@@ -39,7 +39,7 @@ template <int EPI, int SCHED = 0x50, int ORDER = 0>
 __global__ void __launch_bounds__(512, 1) k_gemm256(Gemm256P p) {
   constexpr bool SILU = EPI == P3V_EPI_SILU_MUL;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // uniform: LDS-DMA bases stay in SGPRs
   const int wr = wave >> 2, wc = wave & 3;
   constexpr int n_out_tile = SILU ? TN / 2 : TN;
   int m_t, n_t;
@@ -55,18 +55,21 @@ __global__ void __launch_bounds__(512, 1) k_gemm256(Gemm256P p) {
   }
   const int m0 = m_t * TM, n0 = n_t * n_out_tile;
 
-  // ---- DMA source pointers: half-tile h (128 rows), instruction q (64 rows), this thread: row tid/8, chunk tid%8
+  // ---- DMA sources: half-tile h (128 rows), instruction q (64 rows), this thread: row tid/8, chunk tid%8.
+  // Buffer addressing (SGPR descriptor + 32-bit per-lane byte offset + SGPR K offset): a request is `s_mov m0` +
+  // `buffer_load_dwordx4 ... offen lds` with no vector ALU work at all -- with 64-bit flat addresses every one of the
+  // 8 requests per wave and K-tile carried a v_lshl_add_u64 and, before the wave id was made uniform, a
+  // v_readfirstlane + hazard nop (4096^3: 1.30 -> 1.34 PFLOP/s for the uniform wave id alone).
   const int srow = tid >> 3, schunk = tid & 7;
-  const bf16_t* a_src[2][2];
-  const bf16_t* b_src[2][2];
+  int a_off[2][2], b_off[2][2];                                 // bytes from the tile's first A row / from W
 #pragma unroll
   for (int h = 0; h < 2; ++h)
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       const int r = h * 128 + q * 64 + srow;
       const int sw = (schunk ^ (r & 7)) * 8;
-      const int ar = min(m0 + r, p.M - 1);
-      a_src[h][q] = p.A + (size_t)ar * p.lda + sw;
+      const int ar = min(m0 + r, p.M - 1) - m0;
+      a_off[h][q] = (ar * p.lda + sw) * 2;
       int br;
       if (SILU) {                                   // wave column group wcol (64 tile rows) = 32 gate + 32 up rows
         const int wcol = r >> 6, ni = (r & 63) >> 4, c = r & 15;
@@ -74,16 +77,17 @@ __global__ void __launch_bounds__(512, 1) k_gemm256(Gemm256P p) {
       } else {
         br = min(n0 + r, p.N - 1);
       }
-      b_src[h][q] = p.W + (size_t)br * p.ldw + sw;
+      b_off[h][q] = (int)(((unsigned)br * (unsigned)p.ldw + (unsigned)sw) * 2u);   // < 2^32: checked by the launcher
     }
+  const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A + (size_t)m0 * p.lda), 0, 0xffffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, 0xffffffff, 0x00020000);
   auto dma_half = [&](int which, int kt, int buf) {   // which: 0 A0, 1 A1, 2 B0, 3 B1
     unsigned char* base = smem + buf * BUF_BYTES + which * HALF_BYTES + wave * 1024;
     const int h = which & 1;
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const bf16_t* src = (which < 2 ? a_src[h][q] : b_src[h][q]) + (size_t)kt * TK;
-      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(base + q * 8192), 16, 0, 0);
-    }
+    for (int q = 0; q < 2; ++q)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(which < 2 ? rs_a : rs_w, (lptr_t)(base + q * 8192), 16,
+                                               which < 2 ? a_off[h][q] : b_off[h][q], kt * (TK * 2), 0, 0);
   };
 
   f32x4_t acc[8][4];
@@ -294,6 +298,8 @@ static int launch_gemm256(const Gemm256P& p, hipStream_t s) { return launch_gemm
 int p3v_gemm256_try(const p3v_gemm_args_t* a, hipStream_t s) {
   const int n_tile = a->epilogue == P3V_EPI_SILU_MUL ? TN / 2 : TN;
   if (a->N % n_tile || a->K % TK || a->epilogue == P3V_EPI_PATCH) return P3V_ERR_UNSUPPORTED;
+  const size_t w_rows = (size_t)a->N * (a->epilogue == P3V_EPI_SILU_MUL ? 2 : 1);
+  if (w_rows * a->ldw * 2 >= ((size_t)1 << 32) || (size_t)256 * a->lda * 2 >= ((size_t)1 << 31)) return P3V_ERR_UNSUPPORTED;  // 32-bit buffer offsets
   const Gemm256P p = {a->A, a->W, a->out, a->bias, a->resid, a->M, a->N, a->K, a->lda, a->ldw, a->ldo};
   switch (a->epilogue) {
     case P3V_EPI_NONE: return launch_gemm256<P3V_EPI_NONE>(p, s);
