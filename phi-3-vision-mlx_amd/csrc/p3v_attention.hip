@@ -853,8 +853,12 @@ typedef __attribute__((address_space(3))) void* dec_lptr_t;
 #ifdef P3V_ATTN_DEBUG
 __device__ unsigned long long p3v_dbg[16];
 #define DBG_T(i) do { if (blockIdx.x == 7 && blockIdx.y == 3 && threadIdx.x == 0) p3v_dbg[i] = __builtin_readcyclecounter(); } while (0)
+// launch-level timeline on the 100 MHz wall clock: first workgroup's entry, and entry / partials stored / merge done of the
+// LAST workgroup of the launch (highest split of the last head = the last merger)
+#define DBG_W(i, first) do { if (threadIdx.x == 0 && ((first) ? (blockIdx.x == 0 && blockIdx.y == 0) : (blockIdx.x == gridDim.x - 1 && blockIdx.y == gridDim.y - 1))) p3v_dbg[i] = wall_clock64(); } while (0)
 #else
 #define DBG_T(i)
+#define DBG_W(i, first)
 #endif
 typedef short s16x4_t __attribute__((ext_vector_type(4)));
 // 16 bytes through four agent-scope relaxed loads (cache-bypassing): for data another workgroup of the SAME launch wrote
@@ -872,6 +876,8 @@ __device__ __forceinline__ u32x4_t ld16_wt(const void* ptr) {
 __device__ __forceinline__ void attn_decode_body(const AttnDecP& p, const int bx, const int by, const int bz, unsigned char* KV,
                                                  const int32_t* qkv_flags, const int qkv_upw) {
   DBG_T(0);
+  DBG_W(10, true);
+  DBG_W(12, false);
   constexpr int TK = 64, WK = 16, HD = 96, KROW = HD * 2, VROW = WK * 2, NKS = 3, NDT = 6, CPR = 12;
   constexpr int KS_BYTES = WK * KROW, VS_BYTES = HD * VROW, WREG = KS_BYTES + VS_BYTES;
   static_assert(WREG >= 16 * HD * 4, "a wave's O partial reuses its tile region");
@@ -1096,11 +1102,13 @@ __device__ __forceinline__ void attn_decode_body(const AttnDecP& p, const int bx
     if (d == 0) { st_wt(w + HD, M); st_wt(w + HD + 1, lsum); }
   }
   DBG_T(7);
+  DBG_W(13, false);
   int32_t* flags = p.counters + ((size_t)b * p.nh + head) * p.n_split;
   const int role = p.counters ? split_publish_and_wait(flags, bx, p.n_split) : 0;
   if (role)
     split_merge<256>(p.ws + ((size_t)b * p.nh + head) * p.n_split * 16 * (HD + 2), p.out + (size_t)b * p.L * (p.nh * HD) + head * HD,
                      (size_t)p.nh * HD, p.L, p.n_split, flags, role == 2);
+  DBG_W(11, false);
 }
 
 __global__ void __launch_bounds__(256) k_attn_decode(AttnDecP p) {

@@ -16,3 +16,4 @@ L = _lib.lib(); L.p3v_debug_read.argtypes = [ctypes.c_void_p]; L.p3v_debug_read(
 v = list(buf)
 order = [(0, "entry"), (9, "tile DMA issued"), (2, "q rotated"), (1, "past arrived"), (3, "tile landed"), (4, "S^T MFMAs done"), (5, "softmax done"), (6, "PV done"), (7, "partials stored")]
 for (i, n), (j, _) in zip(order[1:], order[:-1]): print(f"{n:20s} +{v[i]-v[j]:6d} cycles  (cum {v[i]-v[0]})")
+print(f"launch timeline (100 MHz clock): last workgroup enters +{(v[12]-v[10])/100:.2f} us after the first, its partials stored +{(v[13]-v[10])/100:.2f} us, merge done +{(v[11]-v[10])/100:.2f} us")
