@@ -48,6 +48,11 @@ class CacheState:
         self.B, self.S, self.max_tokens = B, S, max_tokens
         self.T = S + max(max_tokens, 0)
         self.Tp = (self.T + 63) // 64 * 64                     # row/column stride of the caches (64-key tiles)
+        if self.Tp % 512 == 0:
+            # V^T rows are Tp * 2 bytes apart: at multiples of 1 KiB the 96 rows of a tile crowd the same memory channels
+            # (measured decode step at B = 1: +3.5 % at Tp = 2560, +2 % at 3584, +1.4 % at 4096 against the neighbouring
+            # lengths) -- one spare tile of capacity moves the stride off the grid
+            self.Tp += 64
         nl, nkv, hd = cfg.num_hidden_layers, cfg.num_key_value_heads, head_dim(cfg)
         self.quantized = bool(getattr(cfg, "use_quantized_cache", False))
         if self.quantized:
@@ -425,7 +430,7 @@ class Phi3VModel:
                  logits=torch.empty((B, cfg.vocab_size), dtype=BF16, device=dev),
                  next_tok=torch.zeros((B,), dtype=I32, device=dev), ticket=torch.zeros((1,), dtype=I32, device=dev))
         bufs = self._alloc_bufs(B, 1)
-        self._split_plan(bufs, B, 1, st.T, st.quantized)
+        self._split_plan(bufs, B, 1, st.Tp, st.quantized)          # the single-tile kernel needs one split per tile of CAPACITY
         # In-launch synchronisation state of the step's fused launches, cleared by step_begin every step:
         #  * chain_cnt: arrival counters of the GEMV chain o_proj -> gate_up -> down -> next qkv (ONE launch per layer,
         #    p3v_gemv_chain) -- bit-identical but OFF by default (P3V_GEMV_CHAIN=1): 2.42 ms/step against 1.87 with

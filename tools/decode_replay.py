@@ -9,7 +9,7 @@ B = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 24
 model, _ = load_synthetic(blind_model=True, device="cuda:0")
 ids = np.random.default_rng(0).integers(3, 32000, (B, ctx))
-lg, cache = model(input_ids=ids, max_tokens=steps + 4)
+lg, cache = model(input_ids=ids, max_tokens=max(steps + 4, 144))   # >= bench.py's cache capacity (8 + 128 + 8): same tile count
 t = ops.argmax(lg[:, -1].contiguous())[:, None]
 for _ in range(steps): lg, t = model.greedy_step(t, cache)
 torch.cuda.synchronize()
