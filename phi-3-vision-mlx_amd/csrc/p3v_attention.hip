@@ -838,7 +838,8 @@ typedef const __attribute__((address_space(1))) void* dec_gptr_t;
 typedef __attribute__((address_space(3))) void* dec_lptr_t;
 
 // Workgroup = 4 waves x one 64-key tile; wave w owns keys [16w, 16w+16) of the tile end to end: it DMAs its own K
-// slice (16 rows x 192 B, contiguous in the cache) and V^T slice (96 rows x 32 B) HBM -> LDS with
+// slice (16 rows x 192 B, contiguous in the cache) and a quarter of the V^T tile BY ROWS (24 rows x 128 B, whole cache
+// lines; the tile is shared after the workgroup barrier) HBM -> LDS with
 // global_load_lds_dwordx4 (no staging registers, no ds_write pass), runs S^T = K.Q^T (3 MFMA 16x16x32), a
 // 4-value-per-lane softmax and O^T += V^T.P^T (6 MFMA 16x16x16, P straight from the S^T accumulator layout), and
 // the four wave partials are merged through LDS before one (m, l, O) partial per workgroup goes to `ws`.
@@ -909,18 +910,27 @@ __device__ __forceinline__ void attn_decode_body(const AttnDecP& p, const int bx
     koff[j] = r0 * KROW + ((pc ^ ((r0 >> 2) & 3)) << 4);
   }
   const size_t vrow = (size_t)p.cache_t * 2;                   // bytes per V^T row
-  const unsigned char* vsrc = (const unsigned char*)vc + (size_t)(lane >> 1) * vrow + (((lane & 1) ^ ((lane >> 4) & 1)) << 4);
+  // LDS image: [K slice of wave 0..3 (16 keys x 192 B each)] [V^T tile: 96 rows x 128 B].  K is sliced by KEYS (wave w
+  // fetches and consumes keys 16w..16w+15: 3 KiB contiguous in the cache).  V^T is fetched by ROWS -- wave w brings rows
+  // 24w..24w+23 across all 64 keys, eight whole 128-byte lines per DMA instruction -- and consumed by keys after the
+  // workgroup barrier that follows the DMA anyway: a per-wave 16-key slice of V^T would be 96 rows x 32 bytes, quarter lines
+  // per request (half / quarter-line streams run at 4.0-4.3 TB/s on this chip, whole lines at 5.5:
+  // tools/scratch/frag_stream.hip).  16-byte chunk c of row d sits in slot c ^ ((d >> 1) & 7): the 16 rows x 2 key groups of
+  // a ds_read_b64 lane group then hit 32 different banks.
+  unsigned char* kslice = KV + wave * KS_BYTES;
+  unsigned char* vtile = KV + 4 * KS_BYTES;
   auto load_tile = [&](int kv0) {
-    const int k0 = kv0 + WK * wave;
-    unsigned char* dst = wreg;
-    const unsigned char* ksrc = kc + (size_t)k0 * KROW;
+    const unsigned char* ksrc = kc + (size_t)(kv0 + WK * wave) * KROW;
 #pragma unroll
     for (int j = 0; j < 3; ++j)
-      __builtin_amdgcn_global_load_lds((dec_gptr_t)(ksrc + koff[j]), (dec_lptr_t)(dst + j * 1024), 16, 0, 0);
-    const unsigned char* vs = vsrc + (size_t)k0 * 2;
+      __builtin_amdgcn_global_load_lds((dec_gptr_t)(ksrc + koff[j]), (dec_lptr_t)(kslice + j * 1024), 16, 0, 0);
+    const unsigned char* vs = (const unsigned char*)vc + (size_t)kv0 * 2;
 #pragma unroll
-    for (int j = 0; j < 3; ++j)
-      __builtin_amdgcn_global_load_lds((dec_gptr_t)(vs + (size_t)j * 32 * vrow), (dec_lptr_t)(dst + KS_BYTES + j * 1024), 16, 0, 0);
+    for (int j = 0; j < 3; ++j) {
+      const int d = 24 * wave + 8 * j + (lane >> 3);
+      const unsigned voff = (unsigned)d * (unsigned)vrow + ((((unsigned)lane & 7) ^ (((unsigned)d >> 1) & 7)) << 4);
+      __builtin_amdgcn_global_load_lds((dec_gptr_t)(vs + voff), (dec_lptr_t)(vtile + wave * VS_BYTES + j * 1024), 16, 0, 0);
+    }
   };
   load_tile(min(kv_lo, p.cache_t - TK));                    // unconditional (an empty split fetches a tile it never uses)
   DBG_T(9);
@@ -994,7 +1004,7 @@ __device__ __forceinline__ void attn_decode_body(const AttnDecP& p, const int bx
 
   // ---- fragment read offsets (swizzled as above)
   const unsigned k_rd = qi * KROW + ((g ^ ((qi >> 2) & 3)) << 4);                         // + ks*64
-  const unsigned v_rd = KS_BYTES + qi * VROW + (((g >> 1) ^ ((qi >> 3) & 1)) << 4) + (g & 1) * 8;   // + dt*16*VROW
+  const unsigned v_rd = qi * 128 + (((2 * wave + (g >> 1)) ^ ((qi >> 1) & 7)) << 4) + (g & 1) * 8;   // + dt*16*128 (row 16*dt + qi)
 
   float m_run = -INFINITY, l_run = 0.f;
   f32x4_t o[NDT];
@@ -1004,7 +1014,7 @@ __device__ __forceinline__ void attn_decode_body(const AttnDecP& p, const int bx
 
   const int kv0 = kv_lo;
   if (kv0 < kv_end) {
-    const unsigned char* Wb = wreg;
+    const unsigned char* Wb = kslice;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the DMA of this wave's slices has landed
     __syncthreads();                                           // Qs is complete, every wave's slices are in LDS
     DBG_T(3);
@@ -1019,7 +1029,7 @@ __device__ __forceinline__ void attn_decode_body(const AttnDecP& p, const int bx
         if (rr >= 0 && rr < TK && t < kv_end) {
           const u32x4_t kn = rope_apply(kraw, tc);
           const int row = rr & 15;
-          *(u32x4_t*)(KV + (rr >> 4) * WREG + row * KROW + ((tc ^ ((row >> 2) & 3)) << 4)) = kn;
+          *(u32x4_t*)(KV + (rr >> 4) * KS_BYTES + row * KROW + ((tc ^ ((row >> 2) & 3)) << 4)) = kn;
           if (kv_writer) *(u32x4_t*)(p.k_cache + (((size_t)b * p.nkv + kvh) * p.cache_t + t) * HD + tc * 8) = kn;   // phi.py:545
         }
       }
@@ -1028,8 +1038,7 @@ __device__ __forceinline__ void attn_decode_body(const AttnDecP& p, const int bx
         const int r = idx / HD, d = idx - r * HD, t = past + r, rr = t - kv0;
         if (rr >= 0 && rr < TK && t < kv_end) {
           const bf16_t val = idx == tid ? v_early : vnew[(size_t)r * row_w + d];
-          const int kk = rr & 15;
-          *(bf16_t*)(KV + (rr >> 4) * WREG + KS_BYTES + d * VROW + (((kk >> 3) ^ ((d >> 3) & 1)) << 4) + (kk & 7) * 2) = val;
+          *(bf16_t*)(vtile + d * 128 + (((rr >> 3) ^ ((d >> 1) & 7)) << 4) + (rr & 7) * 2) = val;
           if (kv_writer) vc[(size_t)d * p.cache_t + t] = val;                                               // phi.py:546
         }
       }
@@ -1067,7 +1076,7 @@ __device__ __forceinline__ void attn_decode_body(const AttnDecP& p, const int bx
     const s16x4_t pf = __builtin_bit_cast(s16x4_t, pw);
 #pragma unroll
     for (int d = 0; d < NDT; ++d) {
-      const s16x4_t vf = *(const s16x4_t*)(Wb + v_rd + d * 16 * VROW);
+      const s16x4_t vf = *(const s16x4_t*)(vtile + v_rd + d * 16 * 128);
       o[d] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(vf, pf, o[d], 0, 0, 0);
     }
     DBG_T(6);
@@ -1076,6 +1085,7 @@ __device__ __forceinline__ void attn_decode_body(const AttnDecP& p, const int bx
   // ---- merge the four wave partials: each wave parks (O, m, l) of its valid queries in its own (now dead) tile
   //      region, then thread idx < L*96 folds element (q, d) over the waves and writes the workgroup partial
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); // no DMA may still target this region / LDS at exit
+  __syncthreads();                                            // the V^T tile is shared: every wave is done with it before it is reused
   if (qvalid) {
     float* Ow = (float*)wreg + qi * HD;
 #pragma unroll
