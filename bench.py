@@ -1,18 +1,21 @@
 #!/usr/bin/env python3
 """Headline benchmark: Phi-3-Vision bf16 single-image VQA on MI355X
-(BASELINE.json `configs[1]`): prefill ms + decode tokens/s, with the roofline
-of the dominant decode kernel and the CPU oracle timed beside it.
+(BASELINE.json `configs[1]`): prefill ms + decode tokens/s, with the rooflines
+of the dominant decode kernel and of the prefill, and the CPU oracle timed beside it.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W            (N > 1 without a launcher: this process starts the N ranks itself)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py --config4 [--gpus N]                     (BASELINE configs[3]: 8 mixed image + text requests per GPU, B = 8)
 
-One process per GPU, each with its own replica and its own request (batch
+One process per GPU, each with its own replica and its own request(s) (batch
 sharding, no data-path collective -> "weak" scaling); RCCL is used for the
 barriers, the max-over-ranks of the timed span and the token gather.
 A "step" = one greedy decode step (one new token per sequence) through the
 same graph-replayed path `generate()` uses; timing definitions follow the
 reference (phi_3_vision_mlx.py:384-403): prefill = first `model(**inputs)` +
-argmax + sync, timer started AFTER host preprocessing.
+argmax + sync, timer started AFTER preprocessing.  `value` is the device rate
+(K graph replays between two syncs); `generate_loop` is the same K steps through
+`_generate`'s own loop (per-token D2H copy + Streamer + TokenStopper, :390-400).
 Synthetic data: seeded random weights of the real architecture, one seeded
 random 336x336 image (-> 1344x1344 HD, 17 crops, 2509 image tokens) + 20
 random text tokens.  Prints ONE JSON line on rank 0.
@@ -27,6 +30,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy)
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak
 
 
 def parse():
@@ -36,8 +40,23 @@ def parse():
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--prefill-reps", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--config4", action="store_true", help="BASELINE configs[3]: 8 mixed image+text requests per GPU, batched (B = 8)")
     ap.add_argument("--tiny", action="store_true", help="tiny config (debug only; the result is NOT the headline metric)")
     return ap.parse_args()
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks (one per GPU) as a CHILD torchrun before this
+    process has touched the GPU, relay its output, exit with its code."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.run(cmd).returncode)
 
 
 def usable_cores(cap=64):
@@ -52,59 +71,60 @@ def usable_cores(cap=64):
     return max(1, min(n, cap))
 
 
-def cpu_baseline(model, ctx_len, n_layers_sample=4, n_tokens=2):
-    """Oracle (CPU restatement of phi.py) timed on the host cores, bounded sample:
-    `n_tokens` greedy decode steps at the same context length through
-    `n_layers_sample` of the decoder layers (fp32 weights resident) + final norm + lm_head,
-    extrapolated linearly to all layers.  Baseline only."""
+def cpu_baseline(model, n_decode=4, runs=3):
+    """the CPU oracle (torch-CPU restatement of phi.py, kind "port") on BASELINE config 1 --
+    text-only, 128-token prompt, greedy, ALL layers -- on this box's host cores: 1 warm-up + `runs` timed runs, median;
+    prefill ms and decode tokens/s with the reference's definitions (phi_3_vision_mlx.py:384-403).  Bounded: `n_decode`
+    decode steps per run.  Baseline only -- never on the product path."""
+    import numpy as np
     import torch
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import phi3v_oracle as orc
     cfg = model.cfg
     cores = usable_cores()
     torch.set_num_threads(cores)
-    names = ["model.embed_tokens.weight", "model.norm.weight", "lm_head.weight"]
-    for i in range(n_layers_sample):
-        names += [k for k in model.w if k.startswith(f"model.layers.{i}.")]
-    w = {k: model.w[k].cpu() for k in names}
+    w = {k: v.cpu() for k, v in model.w.items() if k.startswith("model.layers.") or k in
+         ("model.embed_tokens.weight", "model.norm.weight", "lm_head.weight")}
     o = orc.OraclePhi3V(cfg, w, cache_fp32=True)
-    nkv, hd = cfg.num_key_value_heads, cfg.hidden_size // cfg.num_attention_heads
-    caches = []
-    for i in range(n_layers_sample):
-        c = orc.OracleKVCache(cfg, 1, ctx_len, n_tokens + 1)
-        c.kv = torch.randn(c.shape, dtype=torch.float32) * 0.5
-        c.offset = ctx_len
-        caches.append(c)
-    cos, sin = orc.su_rope_tables(cfg, ctx_len + n_tokens + 1, None)
-    tok = torch.tensor([[17]])
+    o.vision = False
+    ids = np.random.default_rng(0).integers(3, 32000, (1, 128)).astype(np.int64)
+    pre, dec = [], []
+    for run in range(runs + 1):
+        t0 = time.perf_counter()
+        logits, cache = o(input_ids=ids, max_tokens=n_decode + 1)
+        tok = torch.argmax(logits[:, -1].float(), dim=-1)[:, None]
+        t1 = time.perf_counter()
+        for _ in range(n_decode):
+            logits, cache = o(input_ids=tok, cache=cache)
+            tok = torch.argmax(logits[:, -1].float(), dim=-1)[:, None]
+        t2 = time.perf_counter()
+        if run > 0:                                               # run 0 = warm-up (builds the fp32 weight copies)
+            pre.append((t1 - t0) * 1e3), dec.append(n_decode / (t2 - t1))
+    return {"value": round(float(np.median(dec)), 3), "unit": "tokens/s", "cores": cores, "kind": "port",
+            "prefill_ms": round(float(np.median(pre)), 1),
+            "sample": f"BASELINE config 1 (text-only, 128-token prompt, all {cfg.num_hidden_layers} layers, fp32 attention/KV as "
+                      f"phi.py) on torch-CPU: 1 warm-up + {runs} runs, median; {n_decode} decode steps per run"}
 
-    def step(t):
-        x = o.embed(tok)
-        past = caches[0].offset
-        allowed = torch.ones((1, 1, 1, past + 1), dtype=torch.bool)
-        for i in range(n_layers_sample):
-            x = o.decoder_layer(x, i, caches[i], cos[:, :, past:past + 1], sin[:, :, past:past + 1], allowed, 1)
-        t0 = time.perf_counter()
-        lg = orc._linear(orc.rms_norm(x, o.W("model.norm.weight"), cfg.rms_norm_eps), o.W("lm_head.weight"))
-        return lg, time.perf_counter() - t0
-    step(0)                                                     # warm-up (fp32 weight copies, page-in)
-    for c in caches:
-        c.offset = ctx_len
-    t_layers = t_head = 0.0
-    for t in range(n_tokens):
-        t0 = time.perf_counter()
-        _, th = step(t)
-        dt = time.perf_counter() - t0
-        t_head += th
-        t_layers += dt - th
-    per_tok = (t_layers / n_tokens) * (cfg.num_hidden_layers / n_layers_sample) + t_head / n_tokens
-    return {"value": round(1.0 / per_tok, 3), "unit": "tokens/s", "cores": cores, "kind": "port",
-            "sample": f"{n_tokens} decode steps at context {ctx_len}, {n_layers_sample}/{cfg.num_hidden_layers} decoder layers "
-                      f"+ lm_head on torch-CPU fp32, extrapolated to all layers; prefill not timed on CPU"}
+
+def prefill_flops(cfg, S, n_img_tokens, n_crops):
+    """Algorithmic FLOPs of the prefill: decoder linears (lm_head on the last row only), causal attention
+    (lower triangle), ViT on the live crops, projector."""
+    H, I, V, NL = cfg.hidden_size, cfg.intermediate_size, cfg.vocab_size, cfg.num_hidden_layers
+    hd = H // cfg.num_attention_heads
+    per_tok = NL * ((cfg.num_attention_heads + 2 * cfg.num_key_value_heads) * hd * H + H * H + 2 * I * H + I * H)
+    f = 2.0 * S * per_tok + 2.0 * V * H + 2.0 * NL * S * S * H
+    if n_crops:
+        c = cfg.clip
+        D, DI, T, P = c["hidden_size"], c["intermediate_size"], (c["image_size"] // c["patch_size"]) ** 2 + 1, c["patch_size"]
+        vit = (c["num_hidden_layers"] - 1) * (2.0 * T * (4 * D * D + 2 * D * DI) + 4.0 * T * T * D) + 2.0 * (T - 1) * 3 * P * P * D
+        f += n_crops * vit + 2.0 * n_img_tokens * (4 * cfg.img_processor["image_dim_out"] * H + H * H)
+    return f
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args)                                         # does not return
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -112,10 +132,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus or world == 1, f"WORLD_SIZE={world} but --gpus {args.gpus}"
+    assert world == args.gpus, f"WORLD_SIZE={world} but --gpus {args.gpus}"
     share = bool(os.environ.get("P3V_BENCH_SHARE_GPU"))           # debug only: all ranks on GPU 0 over gloo (1-GPU boxes)
     if share:
         local = 0
+    elif torch.cuda.device_count() <= local:
+        raise SystemExit(f"rank {rank}: needs GPU {local}, {torch.cuda.device_count()} visible (one rank per GPU)")
     torch.cuda.set_device(local)
     dev = f"cuda:{local}"
     if world > 1:
@@ -125,40 +147,42 @@ def main():
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(dev))
 
-    from phi_3_vision_mlx_amd import ops
+    from phi_3_vision_mlx_amd import api, ops
     from phi_3_vision_mlx_amd.api import load_synthetic
-    from PIL import Image
+    from phi_3_vision_mlx_amd.processor import collate_requests
+    from phi_3_vision_mlx_amd.workloads import c4_share, vqa_request
 
     t0 = time.perf_counter()
     model, processor = load_synthetic(blind_model=False, tiny=args.tiny, seed=0, device=dev)
     torch.cuda.synchronize()
     t_weights = time.perf_counter() - t0
     cfg = model.cfg
+    ip = processor.img_processor
 
-    # ---- request: one 336x336 image (seed = rank) + 20 random text tokens
-    rng = np.random.default_rng(rank)
-    img = Image.fromarray(rng.integers(0, 256, (336, 336, 3), dtype=np.uint8))
-    t0 = time.perf_counter()
-    # image stage exactly as `processor(text, images)` runs it: resize / pad / normalise / crop on the GPU (same bits as the
-    # host path, P3V_HOST_PREPROCESS=1 selects that one), outside the prefill timer like the reference's processor
-    if os.environ.get("P3V_HOST_PREPROCESS") == "1":
-        image_inputs = processor.img_processor([img], dtype=np.float32)
-        pixel_values = processor._to_device(image_inputs["pixel_values"])
-    else:
-        processor.img_processor.device_call([img], dev)            # warm-up (first launch of the kernels)
+    # ---- request(s): the image stage exactly as `processor(text, images)` runs it -- resize / pad / normalise / crop on
+    #      the GPU (same bits as the host path; P3V_HOST_PREPROCESS=1 selects that one), outside the prefill timer like
+    #      the reference's processor.  Default: one 336x336 image (seed = rank) + 20 random text tokens;
+    #      --config4: this rank's 4 image + 4 text requests as ONE left-padded batch
+    host_pre = os.environ.get("P3V_HOST_PREPROCESS") == "1"
+    pdev = None if host_pre else dev
+
+    def build():
+        if args.config4:
+            return collate_requests(c4_share(ip, rank, device=pdev))
+        return vqa_request(ip, rank, device=pdev)
+    if not host_pre:
+        build()                                                   # warm-up (first launch of the preprocessing kernels)
         torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        image_inputs = processor.img_processor.device_call([img], dev)
-        pixel_values = image_inputs["pixel_values"]
+    t0 = time.perf_counter()
+    inputs = build()
+    if host_pre:
+        inputs["pixel_values"] = processor._to_device(inputs["pixel_values"])
     torch.cuda.synchronize()
     host_pre_ms = (time.perf_counter() - t0) * 1e3
-    n_img = image_inputs["num_img_tokens"][0]
-    text_ids = rng.integers(3, 32000, 20)
-    ids = np.concatenate([[1], text_ids[:8], -np.ones(n_img, dtype=np.int64), [1], text_ids[8:]])[None].astype(np.int64)
-    inputs = {"input_ids": ids, "pixel_values": pixel_values,
-              "image_sizes": np.asarray(image_inputs["image_sizes"]), "positions": np.argwhere(ids < 0)}
-    S = ids.shape[1]
-    max_tokens = args.warmup + args.steps + 8
+    B, S = inputs["input_ids"].shape
+    n_img = int((np.asarray(inputs["input_ids"]) < 0).sum())
+    n_crops = int(sum(h * w + 1 for h, w in (np.asarray(inputs["image_sizes"]) // 336).tolist()))
+    max_tokens = 2 * (args.warmup + args.steps) + 8
 
     def barrier():
         if world > 1:
@@ -179,7 +203,7 @@ def main():
     prefill = float(np.median(prefill_ms))
     print("prefill reps ms:", [round(v, 1) for v in prefill_ms], file=sys.stderr)
 
-    # ---- decode: W untimed + K timed graph-replayed greedy steps
+    # ---- decode: W untimed + K timed graph-replayed greedy steps (device rate: no host work between replays)
     for _ in range(args.warmup):
         logits, token = model.greedy_step(token, cache)
     barrier()
@@ -188,21 +212,38 @@ def main():
         logits, token = model.greedy_step(token, cache)
     barrier()
     elapsed = time.perf_counter() - t0
+
+    # ---- the same K steps through `_generate`'s own loop (reference phi_3_vision_mlx.py:390-400): one D2H copy of the
+    #      token per step (the reference's mx.eval), Streamer, TokenStopper, detokenisation in Streamer.end() inside the span
+    streamer = api.Streamer(processor, False, True)
+    stopper = api.TokenStopper(processor, B)
+    for _ in range(args.warmup):
+        logits, token = model.greedy_step(token, cache)
+    barrier()
+    t0 = time.perf_counter()
+    streamer(api._rows(token))
+    for _ in range(args.steps):
+        logits, token = model.greedy_step(token, cache)
+        rows = api._rows(token)
+        streamer(rows)
+        if stopper(rows):                                         # EOS (32007) from random weights: not expected
+            break
+    _, gen_len = streamer.end()
+    gen_elapsed = time.perf_counter() - t0
+    gen_tps = (gen_len - 1) / gen_elapsed
     if world > 1:
-        t = torch.tensor([elapsed], device=dev)
+        t = torch.tensor([elapsed, prefill, gen_elapsed], device="cpu" if share else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = t.item()
-        pf = torch.tensor([prefill], device=dev)
-        dist.all_reduce(pf, op=dist.ReduceOp.MAX)
-        prefill = pf.item()
+        elapsed, prefill, gen_elapsed = t.tolist()
+        gen_tps = (gen_len - 1) / gen_elapsed
         hist = cache[0].state.graphs["greedy"]["history"]
+        hist = hist.cpu() if share else hist
         gathered = [torch.empty_like(hist) for _ in range(world)] if rank == 0 else None
         dist.gather(hist, gathered, dst=0)                        # token gather over RCCL (request boundary only)
-    B = 1
     tokens_per_s = world * B * args.steps / elapsed
 
     # ---- roofline of the dominant decode kernel (gate_up GEMV + fused RMSNorm + SiLU*up): the 32 layers' launches
-    #      replayed as one hipGraph on the launch stream (exactly the launches of a decode step, weights of every
+    #      replayed as one hipGraph on the launch stream (exactly the launches of a B = 1 decode step, weights of every
     #      layer in turn so nothing is cache-resident), HIP events around the replay
     I, H, L = cfg.intermediate_size, cfg.hidden_size, cfg.num_hidden_layers
     alg_bytes = 2 * I * H * 2                                     # bf16 [2I, H] weights streamed once per launch
@@ -242,28 +283,44 @@ def main():
             traffic = json.load(f)["hbm_bytes_per_launch_corrected"]
     except Exception:
         pass
-    kv_bytes = 2 * L * cfg.num_key_value_heads * (cfg.hidden_size // cfg.num_attention_heads) * 2 * (S + args.warmup + args.steps // 2)
+    hd = cfg.hidden_size // cfg.num_attention_heads
+    valid = int(np.asarray(inputs["mask"]).sum()) if "mask" in inputs else B * S
+    kv_bytes = 2 * L * cfg.num_key_value_heads * hd * 2 * (valid + B * (args.warmup + args.steps // 2))
     w_bytes = sum(v.numel() * 2 for k, v in model.w.items() if k.startswith("model.layers.") or k == "lm_head.weight")
     step_s = elapsed / args.steps
+    pf = prefill_flops(cfg, S, n_img, n_crops) if B == 1 else None
+    if args.config4:
+        workload = (f"BASELINE configs[3], one GPU's share per rank: {B} requests = {n_crops // 17} single-image VQA (2531 tokens) + "
+                    f"{B - n_crops // 17} text prompts (16..256 tokens) as one left-padded batch; greedy, EOS suppressed")
+        metric = "decode tokens/sec (+ prefill ms), Phi-3-Vision bf16, batched mixed image+text generate (config 4 share)"
+    else:
+        workload = ("Phi-3-Vision single 336x336 image VQA (BASELINE configs[1]); 17 crops, "
+                    f"{n_img} image tokens + 22 text tokens, prompt {S}, B=1 per GPU, greedy, EOS suppressed")
+        metric = "decode tokens/sec (+ prefill ms), Phi-3-Vision bf16 1-image VQA"
     out = {
-        "metric": "decode tokens/sec (+ prefill ms), Phi-3-Vision bf16 1-image VQA",
+        "metric": metric,
         "value": round(tokens_per_s, 2), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(step_s * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "bf16", "data": "synthetic",
-        "config": {"workload": "Phi-3-Vision single 336x336 image VQA (BASELINE configs[1]); 17 crops, "
-                               f"{n_img} image tokens + 22 text tokens, prompt {S}, B=1 per GPU, greedy, EOS suppressed",
-                   "parallelism": f"batch-sharded replicas x{world}", "tiny": bool(args.tiny)},
-        "prefill_ms": round(prefill, 3), "prefill_tokens": int(S), "preprocess_ms": round(host_pre_ms, 1), "preprocess": "host" if os.environ.get("P3V_HOST_PREPROCESS") == "1" else "device",
+        "config": {"workload": workload, "parallelism": f"batch-sharded replicas x{world}", "batch_per_gpu": int(B), "tiny": bool(args.tiny)},
+        "prefill_ms": round(prefill, 3), "prefill_tokens": int(B * S), "preprocess_ms": round(host_pre_ms, 1),
+        "preprocess": "host" if host_pre else "device",
+        "generate_loop": {"tokens_per_s": round(world * gen_tps, 2), "definition": "(gen_len - 1) / gen_time over the same steps through "
+                          "_generate's loop: per-token D2H copy + Streamer + TokenStopper + detokenisation (phi_3_vision_mlx.py:390-403)"},
         "decode_step_hbm": {"algorithmic_GB_per_token": round((w_bytes + kv_bytes) / 1e9, 3),
                             "achieved_GBps": round((w_bytes + kv_bytes) / step_s / 1e9, 1),
                             "frac_of_peak": round((w_bytes + kv_bytes) / step_s / 1e9 / HBM_PEAK_GBS, 4)},
-        "roofline": {"bound": "hbm", "kernel": "k_gemv3<1,1,6> (RMSNorm + gate_up_proj + SiLU*up), 32 launches/step", "achieved": round(achieved, 1),
+        "roofline": {"bound": "hbm", "kernel": "k_gemv3<1,1,6> (RMSNorm + gate_up_proj + SiLU*up), 32 launches per B=1 step", "achieved": round(achieved, 1),
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                      "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(k_ms, 5)},
+        "roofline_prefill": None if pf is None else {
+            "bound": "mfma", "algorithmic_TFLOP": round(pf / 1e12, 2), "achieved": round(pf / (prefill * 1e-3) / 1e12, 1),
+            "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(pf / (prefill * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
+            "span": "whole prefill wall time (ViT + projector + 32 layers + lm_head + argmax + sync), not a single kernel"},
         "first_token": first, "weights_init_s": round(t_weights, 1),
     }
     if rank == 0 and not args.no_cpu_baseline and world == 1 and not args.tiny:
-        out["cpu_baseline"] = cpu_baseline(model, S)
+        out["cpu_baseline"] = cpu_baseline(model)
     elif rank == 0:
         out["cpu_baseline"] = None
     if rank == 0:

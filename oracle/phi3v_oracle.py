@@ -397,11 +397,30 @@ def _div(x, n):
     return (x.to(F32) / n).to(x.dtype)
 
 
-def constrain_one(model, dict_input, constraint, id_constraint, use_beam=False, log_norm=False):
+def constrain_one(model, dict_input, constraint, id_constraint, use_beam=False, log_norm=False, trace=None):
     """One (max_new, text) constraint of `_constrain` (phi_3_vision_mlx.py:537-601).
     Scores stay in the logits dtype (bf16) as in the reference; reductions
     accumulate in fp32 and round once (sum) then once more (divide).
-    Returns (synth_sofar [B, *] token ids padded with ID_EOS, score_sofar [B])."""
+    Returns (synth_sofar [B, *] token ids padded with ID_EOS, score_sofar [B]).
+
+    trace (test infrastructure, not in the reference): a list that receives one (kind, margin, outcome) record per
+    data-dependent DECISION of the loop -- argmax / top-3 picks (margin = gap to the runner-up) and score comparisons
+    (margin = |a - b|), margins divided by max|logit| of the forward that produced them, outcome = the picked ids /
+    booleans as a list -- so a parity test can walk two runs decision by decision and tell a near-tie flip from a bug."""
+    scale_box = [1.0]
+
+    def _note(kind, margin, outcome):
+        if trace is not None:
+            trace.append((kind, float(torch.as_tensor(margin).to(F32).min()) / scale_box[0], torch.as_tensor(outcome).reshape(-1).tolist()))
+
+    def _gap(row_logits, k=1):
+        """gap between the k-th and (k+1)-th largest entry of every row (min over rows)."""
+        v = row_logits.to(F32).topk(k + 1, dim=-1).values
+        return (v[..., k - 1] - v[..., k]).min()
+
+    def _lsm(logits):
+        scale_box[0] = max(float(logits.to(F32).abs().max()), 1e-6)
+        return log_softmax(logits)
 
     def _log_mean(x):
         if log_norm:
@@ -416,21 +435,24 @@ def constrain_one(model, dict_input, constraint, id_constraint, use_beam=False, 
     def _get_beam(logits, cache, beam_idx=0, n_beam=3):
         token = torch.argmax(logits[:, beam_idx, :].to(F32), dim=-1)
         arg_beam = top3_candidates(logits[:, beam_idx, :], n_beam)
+        _note("argmax", _gap(logits[:, beam_idx, :]), token)
+        _note("top3_set", _gap(logits[:, beam_idx, :], n_beam), arg_beam.sort(dim=-1).values)
         beam = arg_beam.reshape(-1)[:, None]
         beam = torch.cat([beam, idc[None].expand(beam.shape[0], -1)], dim=-1)
         bl, _ = model(input_ids=beam, cache=cache, n_beam=n_beam, advance_offset=0)
-        bl = log_softmax(bl)
+        bl = _lsm(bl)
         s0 = logits[ar(arg_beam.shape[0])[:, None], beam_idx, arg_beam].reshape(-1)[:, None]
         s1 = bl[ar(bl.shape[0])[:, None], ar(beam.shape[1] - 1)[None, :], beam[:, 1:]]
         beam_score_all = torch.cat([s0, s1], dim=1)
         mean = _div(_sum_last(beam_score_all), beam_score_all.shape[1])
         amax = torch.argmax(mean.reshape(-1, n_beam).to(F32), dim=-1)
+        _note("beam_pick", _gap(mean.reshape(-1, n_beam)), arg_beam[ar(amax.shape[0]), amax])
         beam_token = arg_beam[ar(amax.shape[0]), amax]
         beam_score = beam_score_all.reshape(logits.shape[0], n_beam, -1)[ar(amax.shape[0]), amax]
         return token, beam_token, beam_score
 
     logits, cache = model(**dict_input, max_tokens=constraint[0] + idc.shape[0] + 10)
-    logits = log_softmax(logits)
+    logits = _lsm(logits)
     score_0 = logits[:, -1, idc[0]]
     tiled = idc[None].expand(Bn, -1)
     lr, _ = model(input_ids=tiled, cache=cache, advance_offset=0)
@@ -444,10 +466,12 @@ def constrain_one(model, dict_input, constraint, id_constraint, use_beam=False, 
         post_score = _log_mean(beam_score)
         post_synth = torch.cat([beam_token[:, None], tiled], dim=1)
         win = pre_score > post_score
+        _note("pre_vs_post", (pre_score.to(F32) - post_score.to(F32)).abs(), win)
         score_sofar = torch.where(win, pre_score, post_score)
         synth_sofar = torch.where(win[:, None], pre_synth, post_synth)
     else:
         token = torch.argmax(logits[:, -1, :].to(F32), dim=-1)
+        _note("argmax", _gap(logits[:, -1, :]), token)
         score_sofar, synth_sofar = pre_score, pre_synth
     token = token[:, None]
     tokens = []
@@ -456,7 +480,7 @@ def constrain_one(model, dict_input, constraint, id_constraint, use_beam=False, 
         tokens.append(token)
         token_plus = torch.cat([token, tiled], dim=1)
         logits, cache = model(input_ids=token_plus, cache=cache, advance_offset=1)
-        logits = log_softmax(logits)
+        logits = _lsm(logits)
         g = logits[ar(Bn)[:, None], ar(logits.shape[1] - 1)[None, :], token_plus[:, 1:]]
         pre_score = _log_mean(torch.cat([running_score, g], dim=1))
         pre_synth = torch.cat(tokens + [tiled, synth_pad], dim=1)
@@ -465,14 +489,17 @@ def constrain_one(model, dict_input, constraint, id_constraint, use_beam=False, 
             post_score = _log_mean(torch.cat([running_score, beam_score], dim=1))
             post_synth = torch.cat(tokens + [beam_token[:, None], tiled], dim=1)
             win = pre_score > post_score
+            _note("pre_vs_post", (pre_score.to(F32) - post_score.to(F32)).abs(), win)
             score = torch.where(win, pre_score, post_score)
             synth = torch.where(win[:, None], pre_synth, post_synth)
         else:
             token = torch.argmax(logits[:, 0, :].to(F32), dim=-1)
+            _note("argmax", _gap(logits[:, 0, :]), token)
             score, synth = pre_score, pre_synth
         synth_sofar = torch.cat([synth_sofar, synth_pad], dim=1)
         finished = finished * _already(torch.cat(tokens, dim=1), idc)
         upd = (score > score_sofar).to(F32) * finished
+        _note("update", (score.to(F32) - score_sofar.to(F32)).abs(), upd)
         synth_sofar = torch.where(upd[:, None] > 0, synth, synth_sofar)
         score_sofar = torch.where(upd > 0, score, score_sofar)
         running_score = torch.cat([running_score, logits[ar(Bn), 0, token][:, None]], dim=1)

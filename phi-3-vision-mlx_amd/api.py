@@ -233,13 +233,16 @@ def _attach_adapter(model, adapter_path, model_path=None):
     model.set_adapters(resolve_adapter(model.cfg, lora_cfg, tensors))
 
 
-def load_synthetic(blind_model=False, tiny=False, seed=0, device=None, std_scale=1.0, adapter_path=None, **kwargs):
-    """Seeded random weights of the real (or tiny) architecture -- no checkpoint needed."""
+def load_synthetic(blind_model=False, tiny=False, seed=0, device=None, std_scale=1.0, adapter_path=None, lm_head_spread=0.0,
+                   lm_head_seed=0, **kwargs):
+    """Seeded random weights of the real (or tiny) architecture -- no checkpoint needed.
+    lm_head_spread / lm_head_seed: decisive-argmax head of the parity fixtures (weights.peaked_lm_head)."""
     from .model import Phi3VModel
     d = tiny_config_dict(vision=not blind_model) if tiny else phi3v_config_dict(vision=not blind_model)
     cfg = make_config(d, **kwargs)
     device = device or f"cuda:{torch.cuda.current_device()}"
-    model = Phi3VModel(cfg, synth_weights(cfg, seed=seed, device=device, std_scale=std_scale), device=device)
+    model = Phi3VModel(cfg, synth_weights(cfg, seed=seed, device=device, std_scale=std_scale, lm_head_spread=lm_head_spread,
+                                          lm_head_seed=lm_head_seed), device=device)
     if adapter_path:
         _attach_adapter(model, adapter_path)
     return model, _make_processor(cfg, None)
@@ -292,7 +295,7 @@ def _generate(model, processor, prompt, images=None, max_tokens=512, verbose=Tru
     tic = Tic()
     logits, cache = model(**dict_input, max_tokens=max_tokens)
     token = model_ops.argmax(_last_logits(logits))[:, None]
-    streamer(token)                                             # D2H copy = the per-token sync the reference has (mx.eval)
+    streamer(_rows(token))                                      # D2H copy = the per-token sync the reference has (mx.eval)
     prompt_time = tic()
     graph_step = getattr(model, "greedy_step", None)        # one hipGraph launch per token (HIP model)
     for i in range(max_tokens - 1):
@@ -301,10 +304,11 @@ def _generate(model, processor, prompt, images=None, max_tokens=512, verbose=Tru
         else:
             logits, cache = model(input_ids=token, cache=cache, mask=mask, pids=pids)
             token = model_ops.argmax(_last_logits(logits))[:, None]
-        streamer(token)
+        rows = _rows(token)                                     # ONE D2H copy per step, shared by the streamer and the stopper
+        streamer(rows)
         if logit_stopper(logits):
             break
-        if token_stopper(token):
+        if token_stopper(rows):
             break
     result, gen_len = streamer.end()
     gen_time = tic()
@@ -392,14 +396,20 @@ def _already(a2, a1):
     return (~torch.all(a2[:, -len(a1):] == a1, dim=1)).float()
 
 
-def constrain_tokens(model, dict_input, constraint, id_constraint, use_beam=False, log_norm=False):
+def constrain_tokens(model, dict_input, constraint, id_constraint, use_beam=False, log_norm=False, trace=None):
     """One (max_new, text) constraint of the reference's `_constrain`
     (phi_3_vision_mlx.py:537-601).  Vocabulary-wide work (log-softmax, argmax,
     top-3) runs in HIP kernels; the [B, C]-sized score bookkeeping is host-side
     on CPU tensors in the logits dtype, like the reference keeps it in bf16.
-    Returns (synth_sofar [B, *] int64 padded with ID_EOS, score_sofar [B])."""
+    Returns (synth_sofar [B, *] int64 padded with ID_EOS, score_sofar [B]).
+    trace: optional list receiving (kind, outcome ids / booleans) per data-dependent decision (parity tests walk it
+    against the oracle's trace)."""
     dev = model.device
     ar = torch.arange
+
+    def _note(kind, outcome):
+        if trace is not None:
+            trace.append((kind, torch.as_tensor(outcome).reshape(-1).tolist()))
 
     def _log_mean(x):
         return _div(_sum_last(x), math.log(x.shape[-1]) if log_norm else x.shape[-1])
@@ -423,6 +433,7 @@ def constrain_tokens(model, dict_input, constraint, id_constraint, use_beam=Fals
     def _get_beam(lp, cache, beam_idx=0, n_beam=3):
         token = amax(lp, beam_idx)
         arg_beam = model_ops.topk(lp[:, beam_idx, :].contiguous(), n_beam).long().cpu()      # (-value, index) order, Q9
+        _note("argmax", token), _note("top3_set", arg_beam.sort(dim=-1).values)
         beam = torch.cat([arg_beam.reshape(-1)[:, None], idc[None].expand(Bn * n_beam, -1)], dim=-1)
         bl, _ = model(input_ids=beam, cache=cache, n_beam=n_beam, advance_offset=0)
         bl = lsm(bl)
@@ -431,6 +442,7 @@ def constrain_tokens(model, dict_input, constraint, id_constraint, use_beam=Fals
         score_all = torch.cat([s0, s1], dim=1)
         mean = _div(_sum_last(score_all), score_all.shape[1])
         am = torch.argmax(mean.reshape(-1, n_beam).float(), dim=-1)
+        _note("beam_pick", arg_beam[ar(Bn), am])
         return token, arg_beam[ar(Bn), am], score_all.reshape(Bn, n_beam, -1)[ar(Bn), am]
 
     logits, cache = model(**dict_input, max_tokens=constraint[0] + C_ + 10)
@@ -447,10 +459,12 @@ def constrain_tokens(model, dict_input, constraint, id_constraint, use_beam=Fals
         post_score = _log_mean(beam_score)
         post_synth = torch.cat([beam_token[:, None], tiled], dim=1)
         win = pre_score > post_score
+        _note("pre_vs_post", win)
         score_sofar = torch.where(win, pre_score, post_score)
         synth_sofar = torch.where(win[:, None], pre_synth, post_synth)
     else:
         token = amax(lp, -1)
+        _note("argmax", token)
         score_sofar, synth_sofar = pre_score, pre_synth
     token = token[:, None]
     tokens = []
@@ -468,14 +482,17 @@ def constrain_tokens(model, dict_input, constraint, id_constraint, use_beam=Fals
             post_score = _log_mean(torch.cat([running_score, beam_score], dim=1))
             post_synth = torch.cat(tokens + [beam_token[:, None], tiled], dim=1)
             win = pre_score > post_score
+            _note("pre_vs_post", win)
             score = torch.where(win, pre_score, post_score)
             synth = torch.where(win[:, None], pre_synth, post_synth)
         else:
             token = amax(lp, 0)
+            _note("argmax", token)
             score, synth = pre_score, pre_synth
         synth_sofar = torch.cat([synth_sofar, synth_pad], dim=1)
         finished = finished * _already(torch.cat(tokens, dim=1), idc)
         upd = (score > score_sofar).float() * finished
+        _note("update", upd)
         synth_sofar = torch.where(upd[:, None] > 0, synth, synth_sofar)
         score_sofar = torch.where(upd > 0, score, score_sofar)
         running_score = torch.cat([running_score, pick(lp, torch.tensor([0]), token[:, None])], dim=1)

@@ -91,49 +91,65 @@ def run_sharded(n_requests, worker, group=None):
     return gather_results(idx, local, n_requests, group)
 
 
-def generate_sharded(prompts, images=None, preload=None, max_tokens=512, group=None, **kwargs):
-    """Batched `generate()` over all ranks.
-
-    `prompts`: list of str.  `images`: None, or a list (one entry or None per prompt).
-    Text-only requests of a rank run as ONE left-padded batch padded to the global
-    maximum length; image requests run one by one (the reference only supports B=1
-    with images, phi_3_vision_mlx.py:377-378).  Returns the full list on every rank."""
-    from . import api
+def _all_max(value, group=None):
+    """max of a Python int over all ranks (request-boundary collective, a few bytes)."""
     rank, world = _world(group)
-    prompts = broadcast_requests(list(prompts), group=group)
+    if world == 1:
+        return value
+    box = [None] * world
+    dist.all_gather_object(box, int(value), group=group)
+    return max(box)
+
+
+def generate_sharded(prompts, images=None, preload=None, max_tokens=512, group=None, max_batch=8, apply_chat_template=True,
+                     return_tokens=False):
+    """Batched `generate()` over all ranks -- BASELINE config 4 (mixed image + text requests).
+
+    `prompts`: list of str.  `images`: None, or a list with one entry (an image / path / URL as `generate` takes it, or
+    None) per prompt.  Rank 0's request table is broadcast (the images travel with it, pickled: ~340 KB per 336x336 image);
+    rank r serves requests r, r+W, ... in chunks of `max_batch` rows.  A chunk -- image and text requests alike -- runs as
+    ONE left-padded batch (`processor.collate_requests`: batched ViT, one prefill, graph-replayed batched decode), padded
+    to the longest prompt of the WHOLE request list so that the pad geometry and the one-shot short / long RoPE choice
+    (phi.py:492, Q2) do not depend on the number of ranks: sharded output == single-process output, request-ordered.
+    The reference runs image prompts at B = 1 only (phi_3_vision_mlx.py:377-378); per row the batch computes what the
+    B = 1 run computes (tests/test_model_gpu.py::test_c4_share_batched_vs_per_request_oracle).
+    Returns the full list of texts (or token lists) on every rank."""
+    from . import api
+    from .processor import collate_requests
+    rank, world = _world(group)
+    prompts, images = broadcast_requests((list(prompts), list(images) if images is not None else None), group=group)
     n = len(prompts)
-    images = list(images) if images is not None else [None] * n
+    images = images if images is not None else [None] * n
     model, processor = preload
-
-    def worker(idx):
-        out = {}
-        text_idx = [i for i in idx if images[i] is None]
-        if text_idx:
-            templ, _ = api._apply_chat_template([prompts[i] for i in range(n)], None, False)
-            templ = [templ] if isinstance(templ, str) else templ
-            full = processor(templ)
-            rows = {k: np.ascontiguousarray(np.asarray(v)[text_idx]) for k, v in full.items()}
-            texts = _generate_rows(model, processor, rows, max_tokens)
-            out.update(dict(zip(text_idx, texts)))
-        for i in idx:
-            if images[i] is not None:
-                r = api.generate(prompts[i], images[i], preload=preload, max_tokens=max_tokens, verbose=False, stream=False, **kwargs)
-                out[i] = r[0] if isinstance(r, list) else r
-        return [out[i] for i in idx]
-    return run_sharded(n, worker, group)
+    idx = shard_indices(n, rank, world)
+    reqs = []
+    for i in idx:
+        if apply_chat_template:
+            text, imgs = api._apply_chat_template(prompts[i], images[i], False)
+        else:
+            text, imgs = prompts[i], (None if images[i] is None else [api._load_image(images[i])])
+        reqs.append(processor(text, imgs) if imgs is not None else processor(text))
+    width = _all_max(max([np.asarray(r["input_ids"]).shape[-1] for r in reqs], default=0), group)
+    local = []
+    for c in range(0, len(reqs), max_batch):
+        local += generate_rows(model, processor, collate_requests(reqs[c:c + max_batch], width=width), max_tokens, return_tokens)
+    return gather_results(idx, local, n, group)
 
 
-def _generate_rows(model, processor, rows, max_tokens):
-    """Greedy loop of `_generate` (phi_3_vision_mlx.py:384-400) on pre-tokenised rows; EOS-trimmed texts."""
-    from . import api, ops
-    logits, cache = model(**rows, max_tokens=max_tokens)
-    token = ops.argmax(logits[:, -1, :].contiguous())[:, None]
+def generate_rows(model, processor, rows, max_tokens, return_tokens=False):
+    """Greedy loop of `_generate` (phi_3_vision_mlx.py:384-400) on a collated batch; EOS-trimmed texts (or token lists)."""
+    from . import api
+    token, cache = model.greedy_prefill(max_tokens, **rows)
     streamer = api.Streamer(processor, False, True)
-    stopper = api.TokenStopper(processor, rows["input_ids"].shape[0])
-    streamer(token)
+    stopper = api.TokenStopper(processor, np.asarray(rows["input_ids"]).shape[0])
+    streamer(api._rows(token))
     for _ in range(max_tokens - 1):
-        logits, token = model.greedy_step(token, cache)
-        streamer(token)
-        if stopper(token):
+        _, token = model.greedy_step(token, cache)
+        rows = api._rows(token)
+        streamer(rows)
+        if stopper(rows):
             break
-    return streamer.end()[0]
+    if return_tokens:
+        per_row = [list(r) for r in zip(*streamer.list_tokens)]
+        return [(r[:r.index(api.ID_EOS) + 1] if api.ID_EOS in r else r) for r in per_row]
+    return list(streamer.end()[0])

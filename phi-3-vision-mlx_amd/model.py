@@ -477,6 +477,12 @@ class Phi3VModel:
         g["graph"] = graph
         return g
 
+    def greedy_prefill(self, max_tokens, **inputs):
+        """Prefill + first greedy token: `logits, cache = model(**inputs, max_tokens); argmax(logits[:, -1])`
+        (reference phi_3_vision_mlx.py:385-386).  Returns (token [B,1] int32 on the device, cache)."""
+        logits, cache = self(**inputs, max_tokens=max_tokens)
+        return ops.argmax(logits[:, -1, :].contiguous())[:, None], cache
+
     def greedy_step(self, token, cache):
         """One greedy decode step through the captured graph.  Equivalent to
         `logits, cache = model(input_ids=token, cache=cache); next = argmax(logits[:, -1])`

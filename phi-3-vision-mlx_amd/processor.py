@@ -174,6 +174,39 @@ class Phi3VProcessor(Phi3FProcessor):
                 "positions": np.argwhere(input_ids < 0)}
 
 
+def collate_requests(requests, width=None):
+    """B = 1 model inputs (`processor(text)` / `processor(text, images)` results) -> ONE left-padded batch.
+
+    The reference batches text prompts only (`_tokenize`, phi.py:233-245) and runs image prompts at B = 1
+    (phi_3_vision_mlx.py:377-378, `_merge` phi.py:276); BASELINE config 4 batches mixed image + text requests, so the
+    batch is built with `_tokenize`'s own conventions -- left pad with id 0, position id 1 and mask 0 on the pad,
+    positions 0..n-1 on the tokens -- and every image's slot positions move to (batch row, column + pad).  A row of the
+    batch then sees exactly what its B = 1 run sees (pad keys get zero weight, Q7), which is what the parity tests check."""
+    ids = [np.asarray(r["input_ids"]).reshape(-1) for r in requests]
+    width = max(max(len(s) for s in ids), width or 0)            # `width`: the GLOBAL longest prompt when the batch is sharded
+    out = {"input_ids": np.asarray([[0] * (width - len(s)) + s.tolist() for s in ids], dtype=np.int64),
+           "pids": np.asarray([[1] * (width - len(s)) + list(range(len(s))) for s in ids], dtype=np.int64),
+           "mask": np.asarray([[0] * (width - len(s)) + [1] * len(s) for s in ids], dtype=np.int64)}
+    pix, sizes, pos = [], [], []
+    for row, (r, s) in enumerate(zip(requests, ids)):
+        if r.get("pixel_values") is None:
+            continue
+        pix.append(r["pixel_values"]), sizes.append(np.asarray(r["image_sizes"]))
+        p = np.asarray(r["positions"]).copy()
+        p[:, 0], p[:, 1] = row, p[:, 1] + (width - len(s))
+        pos.append(p)
+    if pix:
+        import torch
+        if any(torch.is_tensor(p) for p in pix):
+            dev = next(p.device for p in pix if torch.is_tensor(p))
+            out["pixel_values"] = torch.cat([p if torch.is_tensor(p) else torch.as_tensor(np.asarray(p), dtype=torch.float32).to(dev)
+                                             for p in pix], dim=0)
+        else:
+            out["pixel_values"] = np.concatenate([np.asarray(p) for p in pix], axis=0)
+        out["image_sizes"], out["positions"] = np.concatenate(sizes, axis=0), np.concatenate(pos, axis=0)
+    return out
+
+
 # ---------------------------------------------------------------------------
 # Image processor
 # ---------------------------------------------------------------------------

@@ -51,3 +51,10 @@ class FakeTokenizer:
         if isinstance(texts, str):
             return _Enc(self._one(texts))
         return _Enc([self._one(t) for t in texts])
+
+
+# synthetic requests of the BASELINE configs live in the package (bench.py uses them too)
+import os as _os
+import sys as _sys
+_sys.path.insert(0, _os.path.dirname(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__)))))
+from phi_3_vision_mlx_amd.workloads import c4_share, text_request, vqa_request  # noqa: E402,F401

@@ -51,6 +51,71 @@ def _worker(rank, world, port, out_dir):
     open(os.path.join(out_dir, f"ok{rank}"), "w").write("ok")
 
 
+class StubModel:
+    """CPU stand-in with the engine's interface (`greedy_prefill` / `greedy_step`): each row's tokens are a function of
+    that row's valid prompt ids, its image (if any) and the step only -- like the real model, pad-invariant."""
+    device = "cpu"
+
+    def greedy_prefill(self, max_tokens, input_ids, pids=None, mask=None, pixel_values=None, image_sizes=None, positions=None):
+        ids, m = np.asarray(input_ids), np.asarray(mask)
+        assert np.array_equal(np.asarray(pids), np.where(m == 1, np.cumsum(m, axis=1) - 1, 1))     # _tokenize's conventions
+        key = (np.where(ids > 0, ids, 0) * m).sum(axis=1)
+        if pixel_values is not None:
+            pos = np.asarray(positions)
+            rows = pos[np.concatenate([[True], pos[1:, 0] != pos[:-1, 0]]), 0]
+            assert (ids[pos[:, 0], pos[:, 1]] < 0).all()                                  # slots moved with the left pad
+            for k, r in enumerate(rows):
+                key[r] += int(np.abs(np.asarray(pixel_values[k], dtype=np.float64)).sum()) % 9973
+        self.key, self.step = key, 0
+        return self._tok(), [self]
+
+    def _tok(self):
+        t = (self.key * 31 + self.step * 7919) % 31000 + 3
+        t = np.where((self.key + self.step) % 11 == 10, 32007, t)                          # some rows stop early (EOS)
+        return torch.as_tensor(t[:, None].astype(np.int32))
+
+    def greedy_step(self, token, cache):
+        self.step += 1
+        return None, self._tok()
+
+
+def _worker_generate(rank, world, port, out_dir):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path[:0] = [root, os.path.join(root, "tests", "golden")]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from golden_inputs import make_image
+    from phi_3_vision_mlx_amd import api, dist as pd
+    from phi_3_vision_mlx_amd.processor import Phi3VProcessor, collate_requests
+    proc = Phi3VProcessor(None, return_mx=False)
+    prompts = [f"question {i} " + "y" * (5 * i) for i in range(7)]
+    images = [make_image(336, 336, "noise", 3), None, None, make_image(640, 480, "smooth", 1), None, None, None]
+    mine = (prompts, images) if rank == 0 else (["junk"], None)          # only rank 0 holds the request table
+    got = pd.generate_sharded(*mine, preload=(StubModel(), proc), max_tokens=6, max_batch=2, return_tokens=True)
+    # single-process result: every request collated into one batch
+    reqs = []
+    for p_, im in zip(prompts, images):
+        text, imgs = api._apply_chat_template(p_, im, False)
+        reqs.append(proc(text, imgs) if imgs is not None else proc(text))
+    want = pd.generate_rows(StubModel(), proc, collate_requests(reqs), 6, return_tokens=True)
+    assert got == want and len(got) == 7, (got, want)
+    assert any(r[-1] == 32007 and len(r) < 6 for r in got) and any(len(r) == 6 for r in got)
+    texts = pd.generate_sharded(*mine, preload=(StubModel(), proc), max_tokens=4)
+    assert isinstance(texts, list) and len(texts) == 7 and all(isinstance(t, str) for t in texts)
+    dist.barrier()
+    dist.destroy_process_group()
+    open(os.path.join(out_dir, f"gen{rank}"), "w").write("ok")
+
+
+def test_generate_sharded_world2_equals_single_process(tmp_path):
+    """`generate_sharded` (mixed image + text requests, rank 0 holds the table, chunks of 2 rows per rank) on 2 gloo ranks
+    == the single-process result, request-ordered, EOS-trimmed."""
+    world, port = 2, _free_port()
+    mp.spawn(_worker_generate, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    assert all(os.path.exists(tmp_path / f"gen{r}") for r in range(world))
+
+
 def test_sharding_world2_gloo(tmp_path):
     world, port = 2, _free_port()
     mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)

@@ -219,41 +219,74 @@ def test_fp8_weights_equal_bf16_model_on_dequantised_weights():
         tok = tb.clone()
 
 
+def walk_decisions(got, ref, clear):
+    """Two decision traces of the same loop (api.constrain_tokens / oracle.constrain_one): every decision must have the
+    same outcome until the first one whose ORACLE margin is below `clear` (a near-tie may legitimately flip and the runs
+    part ways there).  Returns (number of agreeing decisions, diverged?)."""
+    n = 0
+    for (gk, gout), (rk, margin, rout) in zip(got, ref):
+        assert gk == rk, (n, gk, rk)
+        if gout != rout:
+            assert margin <= clear, f"decision {n} ({rk}) differs at a clear margin {margin:.3f}: {gout} vs {rout}"
+            return n, True
+        n += 1
+    assert len(got) == len(ref)
+    return n, False
+
+
 def test_generate_choose_constrain_match_oracle_loops(text):
-    """The public API on the HIP model vs the oracle's restatement of the same loops."""
+    """The public API's loops on the HIP model vs the oracle's restatement of the same loops (phi_3_vision_mlx.py:376-409,
+    466-487, 500-619), under a decisive lm_head: tokens / picks are compared exactly, decision by decision; a difference
+    is accepted only at a decision whose oracle margin is below 4 x the logit tolerance, and must not happen early."""
     import phi3v_oracle as orc
     from phi_3_vision_mlx_amd import api
+    from phi_3_vision_mlx_amd.weights import peaked_lm_head
     model, proc, oracle = text
-    prompts = ["<|user|>\nWhat is 2+2? A: 3 B: 4<|end|>\n<|assistant|>\n", "<|user|>\nName a colour.<|end|>\n<|assistant|>\n"]
-    # choose
-    got = api._choose_from(model, proc, prompts, "ABCDE", mute=True)
-    options = proc([f" {c}" for c in "ABCDE"])["input_ids"][:, -1]
-    ref_idx = orc.choose_from(oracle, proc(prompts), options)
-    assert got == ["ABCDE"[i] for i in ref_idx]
-    # greedy generate (B=2), EOS not expected with random weights: compare full token matrix
-    n = 6
-    inputs = proc(prompts)
-    ref_tok, ref_lg = orc.greedy_generate(oracle, dict(inputs), n)
-    logits, cache = model(**inputs, max_tokens=n)
-    toks = [model_tok(logits)]
-    for _ in range(n - 1):
-        logits, cache = model(input_ids=toks[-1], cache=cache, mask=inputs["mask"], pids=inputs["pids"])
-        toks.append(model_tok(logits))
-    got_tok = torch.cat(toks, dim=1).cpu().long()
-    top2 = ref_lg.float().topk(2, dim=-1).values
-    if ((top2[..., 0] - top2[..., 1]) > 0.25).all():        # only assert exact when no near-tie occurred
-        assert torch.equal(got_tok, ref_tok)
-    # constrain (with and without beam): compare synthesised token rows and scores
-    for use_beam in (False, True):
+    g = np.load(GOLDEN + "/tiny_oracle.npz")
+    clear = 4 * float(g["rel_tol"][0])
+    base_dev, base_cpu = model.w["lm_head.weight"], oracle.w["lm_head.weight"]
+
+    def with_head(hs):
+        model.w["lm_head.weight"] = peaked_lm_head(base_dev, float(g["spread"][0]), int(hs))
+        oracle.w["lm_head.weight"] = peaked_lm_head(base_cpu, float(g["spread"][0]), int(hs))
+        oracle._f32.pop("lm_head.weight", None)
+    prompts = ["<|user|>\nPick A or B.<|end|>\n<|assistant|>\n", "<|user|>\nName a colour of the sky.<|end|>\n<|assistant|>\n"]
+    try:
+        # choose: the fixture's seed makes the option margins clear -> exact
+        with_head(g["choose_head_seed"][0])
+        got = api._choose_from(model, proc, prompts, "ABCDE", mute=True)
+        assert got == ["ABCDE"[i] for i in g["choose_idx"]]
+        # greedy generate through the public loop (B = 2, graph-replayed steps): exact token matrix
+        with_head(g["batch_head_seed"][0])
+        n = g["batch_tokens"].shape[1]
+        inputs = proc(prompts)
+        logits, cache = model(**inputs, max_tokens=n)
+        toks = [model_tok(logits)]
+        for _ in range(n - 1):
+            logits, cache = model(input_ids=toks[-1], cache=cache, mask=inputs["mask"], pids=inputs["pids"])
+            toks.append(model_tok(logits))
+        assert torch.equal(torch.cat(toks, dim=1).cpu().long(), torch.as_tensor(g["batch_tokens"]).long())
+        # constrain (with and without beam): same decisions as a live oracle run
         idc = proc.tokenizer.encode(" The answer is", add_special_tokens=False)[1:]
-        gs, gscore = api.constrain_tokens(model, dict(inputs), (4, " The answer is"), idc, use_beam=use_beam)
-        rs, rscore = orc.constrain_one(oracle, dict(inputs), (4, " The answer is"), idc, use_beam=use_beam)
-        assert gs.shape == rs.shape
-        assert (gscore.float() - rscore.float()).abs().max().item() < 0.15, (gscore, rscore)
-        if torch.equal(gs, rs) is False:
-            # a near-tie may legitimately flip a greedy pick; the constraint tail must still be present
-            tail = torch.tensor(idc)
-            assert (gs[:, -len(idc):] == tail).all() or (gs[:, -len(idc) - 1:-1] == tail).all() or (gs == 32007).any()
+        checked = 0
+        for use_beam in (False, True):
+            for hs in (0, 1, 2):
+                with_head(hs)
+                cin = dict(inputs) if not use_beam else proc(prompts[:1] * 2)
+                gt, rt = [], []
+                gs, gscore = api.constrain_tokens(model, dict(cin), (3, " The answer is"), idc, use_beam=use_beam, trace=gt)
+                rs, rscore = orc.constrain_one(oracle, dict(cin), (3, " The answer is"), idc, use_beam=use_beam, trace=rt)
+                n_same, diverged = walk_decisions(gt, rt, clear)
+                checked += n_same
+                if not diverged:
+                    assert torch.equal(gs, rs), (gs, rs)
+                    scale = max(abs(float(rscore.float().min())), 1.0)
+                    assert (gscore.float() - rscore.float()).abs().max().item() <= 0.03 * scale, (gscore, rscore)
+        assert checked >= 40, checked                           # 6 runs x (7 | 19) decisions: most of them are compared
+    finally:
+        model.w["lm_head.weight"] = base_dev
+        oracle.w["lm_head.weight"] = base_cpu
+        oracle._f32.pop("lm_head.weight", None)
 
 
 def model_tok(logits):
@@ -280,58 +313,121 @@ def test_public_generate_runs_and_reports(text, capsys):
 GOLDEN = __import__("os").path.join(__import__("os").path.dirname(__import__("os").path.abspath(__file__)), "golden")
 
 
-def _check_topk(logits, topv, topi, what, rel=2.5e-2):
-    """HIP logits vs the fixture's top-16 (ids, values) of the oracle: values within `rel`*max|logit| at the
-    oracle's top ids, and the argmax agrees whenever the oracle's top-2 margin exceeds twice that.
-    rel: 2.5 % for the 2-layer tiny model, 6 % for the 32-layer model -- tools/precision_study.py shows that ONE
-    bf16 rounding anywhere in the attention block (the reference keeps q, k, P, o in fp32) already moves the
-    final bf16 logits by 2-3 % of their maximum after 24 layers: the bf16 residual stream amplifies it."""
-    lg = logits.float().cpu()
-    ref_v, ref_i = torch.as_tensor(topv), torch.as_tensor(topi).long()
-    got_v = torch.gather(lg, -1, ref_i)
-    scale = ref_v.abs().max().item()
-    err = (got_v - ref_v).abs().max().item()
-    assert err <= rel * scale + 1e-2, f"{what}: top-k logit error {err:.4f} (scale {scale:.2f})"
-    margin = ref_v[..., 0] - ref_v[..., 1]
-    clear = margin > 2 * rel * scale
-    assert torch.equal(lg.argmax(-1)[clear], ref_i[..., 0][clear]), what
-    return clear
+def _from_bits(a):
+    return torch.from_numpy(np.ascontiguousarray(a).view(np.int16).copy()).view(torch.bfloat16).float()
 
 
-def test_tiny_fixture_text_and_batch(text):
-    model, proc, _ = text
+def check_step(logits, g, step, what, prefix="", rows=None):
+    """HIP last-position logits vs the fixture's FULL oracle logits of `step`: EVERY vocabulary entry within
+    rel_tol x max|logit| of its row (+ one bf16 ulp of the entry), and the greedy token exact -- the fixture's lm_head seed
+    was searched so that the oracle's top-2 margin of every step exceeds 4 x rel_tol (asserted here too).
+    Returns the worst error as a fraction of max|logit|."""
+    rel_tol = float(g["rel_tol"][0])
+    ref = _from_bits(g[prefix + "logits_bf16"][:, step])
+    margin = torch.as_tensor(g[prefix + "margins"][:, step])
+    tok = torch.as_tensor(g[prefix + "tokens"][:, step]).long()
+    if rows is not None:
+        ref, margin, tok = ref[rows], margin[rows], tok[rows]
+    got = logits.float().cpu().reshape(ref.shape)
+    scale = ref.abs().amax(-1, keepdim=True)
+    err = (got - ref).abs()
+    worst = (err / scale).max().item()
+    assert (err <= rel_tol * scale + 2.0 ** -7 * ref.abs()).all(), f"{what}: max logit error {worst:.4f} of max|logit| > {rel_tol}"
+    assert (margin > 4 * rel_tol).all(), f"{what}: fixture step is not clear ({margin.tolist()})"
+    assert torch.equal(got.argmax(-1), tok), f"{what}: greedy token {got.argmax(-1).tolist()} != oracle {tok.tolist()}"
+    return worst
+
+
+def run_fixture(model, inputs, g, prefix, what, mask=None, pids=None):
+    """Teacher-forced pass over a fixture (every step checked against the oracle's full logits, tokens exact), then the
+    same request FREE-RUNNING through the graph-replayed greedy loop: the token matrix must equal the oracle's."""
+    ref_tok = torch.as_tensor(g[prefix + "tokens"]).long()
+    n = ref_tok.shape[1]
+    logits, cache = model(**inputs, max_tokens=n)
+    worst = 0.0
+    for step in range(n):
+        worst = max(worst, check_step(logits[:, -1], g, step, f"{what} step {step}", prefix))
+        if step + 1 < n:
+            logits, _ = model.greedy_step(ref_tok[:, step:step + 1].to(model.device, torch.int32), cache)
+    logits, cache = model(**inputs, max_tokens=n)
+    tok = model_tok(logits)
+    free = [tok]
+    for _ in range(n - 1):
+        _, tok = model.greedy_step(tok, cache)
+        free.append(tok.clone())
+    assert torch.equal(torch.cat(free, dim=1).cpu().long(), ref_tok), f"{what}: free-running greedy tokens differ"
+    print(f"{what}: {n} steps token-exact, worst logit error {worst:.4f} of max|logit|, min margin {g[prefix + 'margins'].min():.3f}")
+    return worst
+
+
+def _tiny_with_head(blind, g, key):
+    from phi_3_vision_mlx_amd.api import load_synthetic
+    return load_synthetic(blind_model=blind, tiny=True, seed=0, std_scale=4.0, device="cuda:0",
+                          lm_head_spread=float(g["spread"][0]), lm_head_seed=int(g[key + "head_seed"][0]))
+
+
+def test_tiny_fixture_text_and_batch():
     g = np.load(GOLDEN + "/tiny_oracle.npz")
-    from phi_3_vision_mlx_amd import ops
-    for key, inputs in (("text", {"input_ids": g["text_ids"]}),
-                        ("batch", proc(["<|user|>\nPick A or B.<|end|>\n<|assistant|>\n",
-                                        "<|user|>\nName a colour of the sky.<|end|>\n<|assistant|>\n"]))):
-        ref_tok = torch.as_tensor(g[f"{key}_tokens"]).long()
-        n = ref_tok.shape[1]
-        logits, cache = model(**inputs, max_tokens=n)
-        for step in range(n):                                   # teacher-forced with the fixture's tokens
-            _check_topk(logits[:, -1], g[f"{key}_topv"][:, step], g[f"{key}_topi"][:, step], f"{key} step {step}")
-            if step + 1 < n:
-                logits, cache = model(input_ids=ref_tok[:, step:step + 1], cache=cache, mask=inputs.get("mask"), pids=inputs.get("pids"))
+    model, proc = _tiny_with_head(True, g, "text_")
+    run_fixture(model, {"input_ids": g["text_ids"]}, g, "text_", "tiny text")
+    model, proc = _tiny_with_head(True, g, "batch_")
+    inputs = proc(["<|user|>\nPick A or B.<|end|>\n<|assistant|>\n", "<|user|>\nName a colour of the sky.<|end|>\n<|assistant|>\n"])
+    run_fixture(model, inputs, g, "batch_", "tiny batch")
 
 
-def test_tiny_fixture_vision(vis):
-    model, proc, _ = vis
+def test_tiny_fixture_vision():
     from golden_inputs import make_image
     g = np.load(GOLDEN + "/tiny_oracle.npz")
+    model, proc = _tiny_with_head(False, g, "vis_")
     inputs = proc("<|user|>\n<|image_1|>\nWhat is shown?<|end|>\n<|assistant|>\n", [make_image(336, 336, "noise", 0)])
     assert np.asarray(inputs["input_ids"]).shape[1] == int(g["vis_n_ids"][0])
-    ref_tok = torch.as_tensor(g["vis_tokens"]).long()
-    logits, cache = model(**inputs, max_tokens=4)
-    for step in range(4):
-        _check_topk(logits[:, -1], g["vis_topv"][:, step], g["vis_topi"][:, step], f"vision step {step}")
-        if step + 1 < 4:
-            logits, cache = model(input_ids=ref_tok[:, step:step + 1], cache=cache)
+    run_fixture(model, inputs, g, "vis_", "tiny vision")
+
+
+def test_parity_check_can_fail():
+    """The fixture check must FAIL on a model that is subtly wrong: (a) one layer's o_proj scaled by 1.25, (b) the RoPE
+    magnitude factor of a 64k instead of a 128k context window (1.16 instead of 1.19), (c) SiLU gate and up halves of one
+    MLP swapped.  Each fault is injected into the tiny HIP model and the tiny text fixture must reject it."""
+    g = np.load(GOLDEN + "/tiny_oracle.npz")
+    model, _ = _tiny_with_head(True, g, "text_")
+    inputs = {"input_ids": g["text_ids"]}
+    run_fixture(model, inputs, g, "text_", "sound model")
+
+    def rejected(what):
+        try:
+            run_fixture(model, inputs, g, "text_", what)
+        except AssertionError:
+            return True
+        return False
+    k = "model.layers.1.self_attn.o_proj.weight"
+    good = model.w[k].clone()
+    model.w[k].mul_(1.25)
+    assert rejected("o_proj x1.25")
+    model.w[k].copy_(good)
+    model.cfg.max_position_embeddings //= 2
+    assert rejected("rope magnitude")
+    model.cfg.max_position_embeddings *= 2
+    k = "model.layers.0.mlp.gate_up_proj.weight"
+    good = model.w[k].clone()
+    half = good.shape[0] // 2
+    model.w[k].copy_(torch.cat([good[half:], good[:half]]))
+    assert rejected("gate/up swapped")
+    model.w[k].copy_(good)
+    run_fixture(model, inputs, g, "text_", "restored model")
 
 
 def test_synthetic_weights_identical_on_gpu_and_cpu():
-    from phi_3_vision_mlx_amd.weights import synth_values
+    from phi_3_vision_mlx_amd.weights import peaked_lm_head, synth_values
     a, b = synth_values(300001, 12345, 0.02, device="cpu"), synth_values(300001, 12345, 0.02, device="cuda:0")
     assert torch.equal(a, b.cpu())
+    w = synth_values(4096 * 64, 7, 0.02).reshape(4096, 64)
+    assert torch.equal(peaked_lm_head(w, 4.0, 3), peaked_lm_head(w.cuda(), 4.0, 3).cpu())
+
+
+def _full_model(g, blind=False, **kw):
+    from phi_3_vision_mlx_amd.api import load_synthetic
+    return load_synthetic(blind_model=blind, tiny=False, seed=0, device="cuda:0", lm_head_spread=float(g["spread"][0]),
+                          lm_head_seed=int(g["head_seed"][0]), **kw)
 
 
 @pytest.fixture(scope="module")
@@ -343,46 +439,89 @@ def full_text():
     torch.cuda.empty_cache()
 
 
-def test_c1_fixture_full_size(full_text):
-    """BASELINE config 1 (Phi-3-mini-128K, 128-token prompt, greedy) at FULL size vs the oracle fixture
-    generated on CPU (tests/golden/gen_golden_oracle.py c1): same hash-seeded weights on both sides."""
-    model, _ = full_text
+def test_c1_fixture_full_size():
+    """BASELINE config 1 (Phi-3-mini-128K, 128-token prompt, greedy) at FULL size vs the oracle fixture generated on CPU
+    (tests/golden/gen_golden_oracle.py): same hash-seeded weights on both sides; 8 steps, every vocabulary entry within
+    tolerance, every greedy token exact, teacher-forced and free-running."""
     g = np.load(GOLDEN + "/c1_oracle.npz")
-    ref_tok = torch.as_tensor(g["tokens"]).long()
-    n = ref_tok.shape[1]
-    logits, cache = model(input_ids=g["ids"], max_tokens=n)
-    n_clear = 0
-    for step in range(n):
-        n_clear += int(_check_topk(logits[:, -1], g["topv"][:, step], g["topi"][:, step], f"C1 step {step}", rel=6e-2).sum())
-        if step + 1 < n:
-            logits, tok = model.greedy_step(ref_tok[:, step:step + 1].to("cuda:0", torch.int32), cache)
-    # rank agreement where it is meaningful: the oracle's top-1 must be inside the HIP top-16 at every step
-    last = logits[:, -1].float().cpu().topk(16).indices[0].tolist()
-    assert int(g["topi"][0, n - 1, 0]) in last
+    model, _ = _full_model(g, blind=True)
+    run_fixture(model, {"input_ids": g["ids"]}, g, "", "C1")
+    del model
+    torch.cuda.empty_cache()
 
 
 def test_c2_fixture_full_size_vision():
     """BASELINE config 2 = bench.py's rank-0 request (one seeded 336x336 image -> 17 CLIP crops -> 2509 image tokens,
-    2531-token prompt) at FULL size vs the oracle fixture (tests/golden/gen_golden_oracle.py c2): CLIP tower,
-    projector, HD merge, 32 decoder layers and 3 graph-replayed decode steps, same hash-seeded weights on both sides."""
-    import sys
-    sys.path.insert(0, GOLDEN)
-    from gen_golden_oracle import c2_request
-    from phi_3_vision_mlx_amd.api import load_synthetic
-    model, proc = load_synthetic(blind_model=False, tiny=False, seed=0, device="cuda:0")
+    2531-token prompt) at FULL size vs the oracle fixture: CLIP tower, projector, HD merge, 32 decoder layers, prefill +
+    3 graph-replayed decode steps; token-exact on every step."""
+    from golden_inputs import vqa_request
     g = np.load(GOLDEN + "/c2_oracle.npz")
-    inp = c2_request(proc.img_processor)
+    model, proc = _full_model(g)
+    inp = vqa_request(proc.img_processor, 0)
     assert inp["input_ids"].shape[1] == int(g["n_ids"][0]) == 2531
+    inp["pixel_values"] = torch.from_numpy(inp["pixel_values"]).to("cuda:0")
+    run_fixture(model, inp, g, "", "C2")
+    del model
+    torch.cuda.empty_cache()
+
+
+def test_c4_share_batched_vs_per_request_oracle():
+    """BASELINE config 4, one GPU's share: 4 single-image VQA requests + 4 text prompts of 65..233 tokens run as ONE
+    left-padded B = 8 batch (batched ViT over 68 crops, B = 8 prefill, B = 8 graph-replayed decode through the MFMA
+    skinny projections and the streaming decode attention) against the PER-REQUEST B = 1 oracle runs of the fixture --
+    B = 1 is the reference's only image path (phi_3_vision_mlx.py:377-378, phi.py:276), so it is the oracle of every row.
+    All logits within tolerance on every row and step; tokens exact on every (row, step) whose oracle margin is clear (the
+    head seed makes all 8 prefill steps clear; the fixture's count of clear decode steps is asserted, not assumed)."""
+    from golden_inputs import c4_share
+    from phi_3_vision_mlx_amd.processor import collate_requests
+    g = np.load(GOLDEN + "/c4_oracle.npz")
+    model, proc = _full_model(g)
+    share = c4_share(proc.img_processor)
+    assert [r["input_ids"].shape[1] for r in share] == g["n_ids"].tolist()
+    batch = collate_requests(share)
+    batch["pixel_values"] = torch.from_numpy(batch["pixel_values"]).to("cuda:0")
+    rel_tol = float(g["rel_tol"][0])
+    ref_tok = torch.as_tensor(g["tokens"]).long()
+    margins = torch.as_tensor(g["margins"])
+    n = ref_tok.shape[1]
+    logits, cache = model(**batch, max_tokens=n)
+    n_exact, worst = 0, 0.0
+    for step in range(n):
+        ref = _from_bits(g["logits_bf16"][:, step])
+        got = logits[:, -1].float().cpu()
+        scale = ref.abs().amax(-1, keepdim=True)
+        err = (got - ref).abs()
+        worst = max(worst, (err / scale).max().item())
+        assert (err <= rel_tol * scale + 2.0 ** -7 * ref.abs()).all(), f"C4 step {step}: error {(err / scale).amax(-1).tolist()}"
+        clear = margins[:, step] > 4 * rel_tol
+        assert torch.equal(got.argmax(-1)[clear], ref_tok[:, step][clear]), f"C4 step {step}"
+        n_exact += int(clear.sum())
+        if step + 1 < n:
+            logits, _ = model.greedy_step(ref_tok[:, step:step + 1].to("cuda:0", torch.int32), cache)
+    assert bool((margins[:, 0] > 4 * rel_tol).all()) and n_exact == int((margins > 4 * rel_tol).sum()) and n_exact >= 16
+    print(f"C4 share: {n_exact} of {margins.numel()} (row, step) tokens exact (all clear ones), worst logit error {worst:.4f}")
+    del model, cache
+    torch.cuda.empty_cache()
+
+
+def test_c5_fp8_weights_int8_kv_vs_quantised_oracle():
+    """BASELINE config 5 on config 2's request: fp8 (e4m3, per-row scale) decoder weights AND the int8 KV cache together,
+    against an oracle that applies the same two quantisers (tests/golden/gen_golden_oracle.py c5): e4m3 x scale weights
+    as exact fp32 products, keys / values quantised per (head, token) after the call that produced them."""
+    from golden_inputs import vqa_request
+    g = np.load(GOLDEN + "/c5_oracle.npz")
+    model, proc = _full_model(g, quantized_fp8=True, use_quantized_cache=True)
+    assert model.w8 and "lm_head.weight" in model.w8
+    inp = vqa_request(proc.img_processor, 0)
     inp["pixel_values"] = torch.from_numpy(inp["pixel_values"]).to("cuda:0")
     ref_tok = torch.as_tensor(g["tokens"]).long()
     n = ref_tok.shape[1]
     logits, cache = model(**inp, max_tokens=n)
+    assert cache[0].state.quantized
     for step in range(n):
-        _check_topk(logits[:, -1], g["topv"][:, step], g["topi"][:, step], f"C2 step {step}", rel=6e-2)
-        top16 = logits[:, -1].float().cpu().topk(16).indices[0].tolist()
-        assert int(g["topi"][0, step, 0]) in top16, f"C2 step {step}: oracle top-1 not in the HIP top-16"
+        check_step(logits[:, -1], g, step, f"C5 step {step}")
         if step + 1 < n:
-            logits, tok = model.greedy_step(ref_tok[:, step:step + 1].to("cuda:0", torch.int32), cache)
+            logits, _ = model.greedy_step(ref_tok[:, step:step + 1].to("cuda:0", torch.int32), cache)
     del model, cache
     torch.cuda.empty_cache()
 
