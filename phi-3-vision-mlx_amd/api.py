@@ -105,8 +105,8 @@ class LogitStopper:
 
     def __init__(self, max_tokens, early_stop):
         self.step = 0
-        self.early_stop = early_stop if isinstance(early_stop, int) and not isinstance(early_stop, bool) \
-            and (early_stop < max_tokens) else False
+        # isinstance(True, int) holds in Python: the reference takes early_stop=True as the integer 1 (:82) -- kept
+        self.early_stop = early_stop if isinstance(early_stop, int) and (early_stop < max_tokens) else False
         self.log_prob_sum = 0.0
         self.best_eos_sofar = -math.inf
         self.log_prob_sum_at_best_eos = 0.0

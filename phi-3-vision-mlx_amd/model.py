@@ -33,6 +33,21 @@ from .weights import Q4Weight, mlx_quantize, q4_repack
 from .ops import (BF16, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_QGELU, EPI_BIAS_RESID_F32, EPI_NONE, EPI_PATCH,
                   EPI_RESID_BF16, EPI_SILU_MUL, F32, I32)
 
+import functools
+import weakref
+
+
+def _on_device(fn):
+    """Run a model entry point with the model's GPU as the current device: ops.py launches on
+    `torch.cuda.current_stream()` of the CURRENT device, and a thread other than the one that loaded the model (the
+    server's engine thread) starts on device 0."""
+    @functools.wraps(fn)
+    def wrapped(self, *a, **kw):
+        with torch.cuda.device(self.device):
+            return fn(self, *a, **kw)
+    return wrapped
+
+
 V_PREFIX = "model.vision_embed_tokens.img_processor.vision_model."
 E_PREFIX = "model.vision_embed_tokens."
 
@@ -70,6 +85,7 @@ class CacheState:
         self.offset = 0
         self.cos = self.sin = self.pad_len = None
         self.graphs = {}
+        self.epoch = None                                       # model.epoch the graphs were captured under
 
 
 class LayerCache:
@@ -103,7 +119,10 @@ class Phi3VModel:
         self._state = None
         self.w8 = {}
         self.adapters = {}                           # weight key -> (lora_a, lora_b, scale), see set_adapters
-        self._lora_tmp = {}
+        self._lora_tmp = {}                          # decode-sized (M <= 16) adapter scratch: captured graphs point at it
+        self._lora_flat = None                       # ONE grow-only scratch for prefill-sized calls (not graph-captured)
+        self.epoch = 0                               # bumped whenever captured decode graphs become stale
+        self._states = weakref.WeakSet()             # every live CacheState (their graphs bake pointers into this model)
         if getattr(cfg, "quantized_fp8", False):
             self._quantize_decoder_fp8()
         if getattr(cfg, "quantized_int4", False):
@@ -125,6 +144,7 @@ class Phi3VModel:
         self._deq = torch.empty(n_max, dtype=BF16, device=self.device)      # one dequantised matrix (prefill GEMM scratch)
 
     # ------------------------------------------------------------------ LoRA adapters (use_adapter=True)
+    @_on_device
     def set_adapters(self, adapters):
         """Attach LoRA adapters: {"model.layers.<i>.<target>.weight": (lora_a [in,r] f32, lora_b [r,out] f32, scale)}
         (weights.resolve_adapter).  An adapted projection runs unfused: materialised RMSNorm -> frozen projection with a
@@ -136,9 +156,10 @@ class Phi3VModel:
                 raise ValueError(f"LoRA shapes {tuple(a.shape)} x {tuple(b.shape)} do not fit {k} {tuple(shape)}")
         self.adapters = {k: (a.to(self.device, F32).contiguous(), b.to(self.device, F32).contiguous(), float(s))
                          for k, (a, b, s) in adapters.items()}
-        self._lora_tmp = {}
-        if self._state is not None:
-            self._state.graphs.clear()               # captured decode graphs bake the kernel sequence in
+        self.epoch += 1                              # captured decode graphs bake the kernel sequence and the scratch
+        for st in list(self._states):                # pointers in: drop them on EVERY live cache before the scratch goes
+            st.graphs.clear()
+        self._lora_tmp, self._lora_flat = {}, None
 
     def _quantize_decoder_q4(self):
         """Decoder projections + lm_head -> 4-bit group-64 (the reference's nn.quantize(model, 64, 4)): 7.4 GB -> 2.1 GB
@@ -153,19 +174,25 @@ class Phi3VModel:
         if ad is None:
             return self._proj_frozen(x, key, epilogue, resid, norm_w, out, h)
         a, b, scale = ad
-        M, N = x.shape[0], b.shape[1]
+        M, K, N, r = x.shape[0], x.shape[1], b.shape[1], a.shape[1]
+        if M <= ops.GEMV_MAX_M:                                 # decode-sized: persistent buffers (graph replays read them)
+            def buf(tag, shape, dtype):
+                t_ = self._lora_tmp.get((tag,) + shape)
+                if t_ is None:
+                    t_ = self._lora_tmp[(tag,) + shape] = torch.empty(shape, dtype=dtype, device=self.device)
+                return t_
+            hbuf, y, t = buf("h", (M, K), BF16), buf("y", (M, N), BF16), buf("t", (M, r), F32)
+        else:                                                   # prefill-sized: carved out of one grow-only allocation,
+            nb = (M * K + M * N) * 2 + M * r * 4 + 512          # not one set per prompt length (a server would leak VRAM)
+            if self._lora_flat is None or self._lora_flat.numel() < nb:
+                self._lora_flat = torch.empty(nb, dtype=torch.uint8, device=self.device)
+            f, o1 = self._lora_flat, (M * K * 2 + 255) // 256 * 256
+            o2 = o1 + (M * N * 2 + 255) // 256 * 256
+            hbuf = f[:M * K * 2].view(BF16).view(M, K)
+            y = f[o1:o1 + M * N * 2].view(BF16).view(M, N)
+            t = f[o2:o2 + M * r * 4].view(F32).view(M, r)
         if norm_w is not None:                                  # the adapter needs the normalised input itself
-            tmp = self._lora_tmp.get(("h", M))
-            if tmp is None:
-                tmp = self._lora_tmp[("h", M)] = torch.empty_like(x)
-            x = ops.rmsnorm(x, norm_w, self.cfg.rms_norm_eps, out=tmp)
-        y = self._lora_tmp.get(("y", M, N))
-        if y is None:
-            y = self._lora_tmp[("y", M, N)] = torch.empty((M, N), dtype=BF16, device=self.device)
-            self._lora_tmp[("t", M, a.shape[1])] = torch.empty((M, a.shape[1]), dtype=F32, device=self.device)
-        t = self._lora_tmp.get(("t", M, a.shape[1]))
-        if t is None:
-            t = self._lora_tmp[("t", M, a.shape[1])] = torch.empty((M, a.shape[1]), dtype=F32, device=self.device)
+            x = ops.rmsnorm(x, norm_w, self.cfg.rms_norm_eps, out=hbuf)
         self._proj_frozen(x, key, EPI_NONE, None, None, y, None)
         ops.lora_down(x, a, out=t)
         return ops.lora_up(y, t, b, scale, epilogue, resid=resid, out=out)
@@ -210,6 +237,7 @@ class Phi3VModel:
             bq = torch.cat([self.w[q + f"{n}_proj.bias"] for n in "qkv"], dim=0).contiguous()
             self.clip_qkv.append((wq, bq))
 
+    @_on_device
     def clip_forward(self, pix):
         """ClipModel.__call__ (phi.py:216-221) on live crops; pix f32 [n,3,336,336] -> f32 [n,577,D]
         (row 0 = CLS, which the caller skips)."""
@@ -277,6 +305,7 @@ class Phi3VModel:
     def _new_state(self, B, S, max_tokens, pids, mask):
         cfg = self.cfg
         st = CacheState(cfg, B, S, max_tokens, self.device)
+        self._states.add(st)
         L_all = S + max_tokens                                  # reference sizes tables with max_tokens as given
         half = self.hd // 2
         su = cfg.rope_scaling["long_factor"] if L_all > cfg.original_max_position_embeddings else cfg.rope_scaling["short_factor"]
@@ -477,12 +506,14 @@ class Phi3VModel:
         g["graph"] = graph
         return g
 
+    @_on_device
     def greedy_prefill(self, max_tokens, **inputs):
         """Prefill + first greedy token: `logits, cache = model(**inputs, max_tokens); argmax(logits[:, -1])`
         (reference phi_3_vision_mlx.py:385-386).  Returns (token [B,1] int32 on the device, cache)."""
         logits, cache = self(**inputs, max_tokens=max_tokens)
         return ops.argmax(logits[:, -1, :].contiguous())[:, None], cache
 
+    @_on_device
     def greedy_step(self, token, cache):
         """One greedy decode step through the captured graph.  Equivalent to
         `logits, cache = model(input_ids=token, cache=cache); next = argmax(logits[:, -1])`
@@ -491,6 +522,9 @@ class Phi3VModel:
         st = cache[0].state
         if st.offset + 1 > st.T:
             raise ValueError(f"KV cache overflow: {st.offset}+1 > {st.T} (prompt + max_tokens)")
+        if st.epoch != self.epoch:                              # adapters changed since the capture: stale pointers
+            st.graphs.clear()
+            st.epoch = self.epoch
         g = st.graphs.get("greedy")
         if g is None:
             g = st.graphs["greedy"] = self._build_decode_graph(st)
@@ -504,6 +538,7 @@ class Phi3VModel:
         g["host_tok"] = g["next_tok"].view(-1, 1)
         return g["logits"].view(st.B, 1, -1), g["host_tok"]
 
+    @_on_device
     def __call__(self, input_ids, pixel_values=None, image_sizes=None, positions=None, cache=None, pids=None, mask=None,
                  max_tokens=0, advance_offset=None, n_beam=1, full_logits=None):
         """Phi3ForCausalLM.__call__ (phi.py:606-608) + Phi3F.__call__ (phi.py:576-592).

@@ -328,8 +328,12 @@ class Phi3VImageProcessor:
         """`__call__` with everything after the RGB conversion on the GPU (p3v_resample_u8 x 2, p3v_hd_preprocess):
         pixel_values comes back as a float32 torch tensor on `device`, bit-identical to `__call__(..., dtype=float32)`."""
         import torch
+        with torch.cuda.device(torch.device(device)):            # ops launch on the CURRENT device's stream
+            return self._device_call(images, device)
+
+    def _device_call(self, images, device):
+        import torch
         from . import ops
-        from PIL import Image
         out = torch.empty((len(images), 17, 3, 336, 336), dtype=torch.float32, device=device)
         lut = torch.as_tensor(np.ascontiguousarray(((np.arange(256)[:, None] / 255.0 - self.image_mean) / self.image_std).T)).to(device)
         shapes = []

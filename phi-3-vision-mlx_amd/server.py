@@ -4,9 +4,15 @@
       -> 200 {"model": "phi-3-vision", "responses": [str, ...]}            anything else -> 404
 
 with one difference in the plumbing: requests do not call the model from the HTTP thread.  They go into a queue that a
-single engine thread drains (the model object holds one in-flight sequence group), and requests that are
-waiting at the same time and ask for the same `max_tokens` are merged into ONE batched `generate` call (the batch
-dimension is what shards across GPUs, `dist.generate_sharded`).  Malformed bodies get 400 instead of a dropped connection.
+single engine thread drains (the model object holds one in-flight sequence group).  By default every
+request is its own `generate` call, as in the reference's server -- a client's output never depends on who else is in
+flight.  `merge=True` (opt-in, `--merge`) folds requests that wait at the same time and ask for the same `max_tokens`
+into ONE batched call: throughput for left-pad geometry that now depends on the longest co-batched prompt (results of
+valid rows are pad-invariant EXCEPT the one-shot short/long RoPE choice, phi.py:492 -- so requests are only merged
+while prompt + max_tokens of the merged batch stays on the same side of the 4096-token window as each request alone;
+`regime_fn` supplies the prompt lengths).  `max_tokens` is clamped to `max_tokens_cap` (an unbounded value would size
+the KV cache).  Malformed bodies get 400 instead of a dropped connection; a request that waits longer than `timeout_s`
+gets 500.
 
     python -m phi_3_vision_mlx_amd.server --port 8000 [--synthetic] [--blind]
 """
@@ -29,8 +35,11 @@ class _Job:
 class EngineQueue:
     """Single consumer in front of a non-re-entrant `generate_fn(prompts: list[str], max_tokens) -> str | list[str]`."""
 
-    def __init__(self, generate_fn, max_batch=64, window_s=0.005):
+    def __init__(self, generate_fn, max_batch=64, window_s=0.005, merge=False, max_tokens_cap=4096, timeout_s=600.0,
+                 length_fn=None, window_tokens=4096, device=None):
         self.generate_fn, self.max_batch, self.window_s = generate_fn, max_batch, window_s
+        self.merge, self.max_tokens_cap, self.timeout_s = merge, max_tokens_cap, timeout_s
+        self.length_fn, self.window_tokens, self.device = length_fn, window_tokens, device
         self.jobs = queue.Queue()
         self.batches = []                       # sizes of the generate calls issued (observability / tests)
         self._stop = False
@@ -38,9 +47,10 @@ class EngineQueue:
         self.thread.start()
 
     def submit(self, prompts, max_tokens):
-        job = _Job(prompts, max_tokens)
+        job = _Job(prompts, max(1, min(int(max_tokens), self.max_tokens_cap)))
         self.jobs.put(job)
-        job.done.wait()
+        if not job.done.wait(self.timeout_s):
+            raise TimeoutError(f"no result within {self.timeout_s} s")
         if job.error is not None:
             raise job.error
         return job.result
@@ -50,9 +60,19 @@ class EngineQueue:
         self.jobs.put(None)
         self.thread.join(timeout=5)
 
+    def _regime(self, prompts, max_tokens):
+        """Side of the RoPE window the batch falls on (phi.py:492: long factors iff longest prompt + max_tokens > 4096)."""
+        if self.length_fn is None:
+            return None
+        return max(self.length_fn(p) for p in prompts) + max_tokens > self.window_tokens
+
     def _collect(self, first):
-        """`first` plus every queued job with the same max_tokens that fits, waiting at most `window_s` for stragglers."""
+        """merge=False: `first` alone.  merge=True: plus every queued job with the same max_tokens that fits and keeps the
+        RoPE regime of each member unchanged, waiting at most `window_s` for stragglers."""
         group, n, held = [first], len(first.prompts), []
+        if not self.merge:
+            return group
+        regime = self._regime(first.prompts, first.max_tokens)
         while n < self.max_batch:
             try:
                 job = self.jobs.get(timeout=self.window_s)
@@ -61,7 +81,8 @@ class EngineQueue:
             if job is None:
                 self.jobs.put(None)
                 break
-            if job.max_tokens == first.max_tokens and n + len(job.prompts) <= self.max_batch:
+            if job.max_tokens == first.max_tokens and n + len(job.prompts) <= self.max_batch \
+                    and self._regime(job.prompts, job.max_tokens) == regime:
                 group.append(job)
                 n += len(job.prompts)
             else:
@@ -71,6 +92,9 @@ class EngineQueue:
         return group
 
     def _run(self):
+        if self.device is not None:                             # a new thread starts on GPU 0 whatever the loader used
+            import torch
+            torch.cuda.set_device(self.device)
         while not self._stop:
             first = self.jobs.get()
             if first is None:
@@ -131,21 +155,25 @@ def make_handler(engine):
     return CompletionHandler
 
 
-def serve(generate_fn, port=8000, host="", max_batch=64):
+def serve(generate_fn, port=8000, host="", max_batch=64, **engine_kwargs):
     """-> (httpd, engine); call httpd.serve_forever() (or run it in a thread) and engine.close() at the end."""
-    engine = EngineQueue(generate_fn, max_batch=max_batch)
+    engine = EngineQueue(generate_fn, max_batch=max_batch, **engine_kwargs)
     httpd = ThreadingHTTPServer((host, port), make_handler(engine))
     return httpd, engine
 
 
-def run(port=8000, synthetic=False, blind_model=False):
-    from .api import generate, load
+def run(port=8000, synthetic=False, blind_model=False, merge=False):
+    from .api import _apply_chat_template, generate, load
     preload = load(blind_model=blind_model, synthetic=synthetic or None)
+    processor = preload[1]
 
     def generate_fn(prompts, max_tokens):
         return generate(prompts if len(prompts) > 1 else prompts[0], preload=preload, max_tokens=max_tokens, verbose=False)
 
-    httpd, engine = serve(generate_fn, port=port)
+    def length_fn(prompt):
+        return len(processor.tokenizer(_apply_chat_template(prompt, None, False)[0]).input_ids)
+
+    httpd, engine = serve(generate_fn, port=port, merge=merge, length_fn=length_fn, device=preload[0].device)
     print(f"Starting server on port {port}")
     try:
         httpd.serve_forever()
@@ -159,5 +187,6 @@ if __name__ == "__main__":
     ap.add_argument("--port", type=int, default=8000)
     ap.add_argument("--synthetic", action="store_true", help="seeded random weights instead of models/phi3_v")
     ap.add_argument("--blind", action="store_true", help="text-only Phi-3-mini-128K")
+    ap.add_argument("--merge", action="store_true", help="fold concurrent same-budget requests into one batched generate (opt-in)")
     a = ap.parse_args()
-    run(a.port, a.synthetic, a.blind)
+    run(a.port, a.synthetic, a.blind, a.merge)

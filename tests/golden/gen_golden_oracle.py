@@ -33,8 +33,14 @@ from phi_3_vision_mlx_amd.config import make_config, phi3v_config_dict, tiny_con
 from phi_3_vision_mlx_amd.processor import Phi3FProcessor, Phi3VProcessor  # noqa: E402
 from phi_3_vision_mlx_amd.weights import peaked_lm_head, synth_weights  # noqa: E402
 
-REL_TOL = 0.03                 # |HIP - oracle| <= REL_TOL * max|logit| is what the GPU tests assert on every entry
-CLEAR = 4 * REL_TOL            # a step is "clear" when the oracle's top-2 margin exceeds this fraction of max|logit|
+# |HIP - oracle| <= REL_TOL * max|logit| on EVERY vocabulary entry is what the GPU tests assert; a step is "clear" when the
+# oracle's top-2 margin exceeds 4 x REL_TOL of max|logit|.  2 layers: 3 %; 32 layers: 4.5 % (measured worst entry 3.6 %:
+# the bf16 residual stream alone moves the hidden state by ~3 % between two correct implementations -- the oracle against
+# itself with float64 accumulation differs by 2.4 % of max|logit| after 24 layers, tools/precision_study.py)
+REL_TOL = 0.03
+REL_TOL_FULL = 0.045
+CLEAR = 4 * REL_TOL
+CKPT = os.environ.get("P3V_ORACLE_CKPT", "/tmp/p3v_oracle_ckpt")     # prefilled requests are kept here between runs (GBs)
 SPREAD = 4.0                   # log2-sd of the lm_head row scales
 BF16, F32 = torch.bfloat16, torch.float32
 
@@ -53,15 +59,32 @@ class Prefilled:
     """A request after the oracle's prefill: last-position hidden state + KV cache; decode steps can be replayed for any
     lm_head by rewinding `offset` (KVCache semantics, phi.py:589-591)."""
 
-    def __init__(self, o, inputs, n_steps):
+    def __init__(self, o, inputs, n_steps, tag=None):
         self.o, self.inputs = o, inputs
         t0 = time.time()
+        f = os.path.join(CKPT, f"{tag}_n{n_steps}.pt") if tag else None
+        if f and os.path.exists(f):
+            d = torch.load(f)
+            self.h0, self.S, self.masker, self.roper = d["h0"], d["S"], orc.OracleMask4D(1, None), d["roper"]
+            self.masker.allowed = d["allowed"]
+            self.cache = []
+            for kv in d["kv"]:
+                c = orc.OracleKVCache(o.cfg, kv.shape[1], self.S, n_steps)
+                c.kv, c.offset = kv, self.S
+                self.cache.append(c)
+            print(f"  prefill S={self.S} loaded from {f}", flush=True)
+            return
         x, self.cache = o.backbone(inputs["input_ids"], inputs.get("pixel_values"), inputs.get("image_sizes"),
                                    inputs.get("positions"), None, inputs.get("pids"), inputs.get("mask"), n_steps, None, 1)
         self.h0 = x[:, -1:, :].clone()
         self.S = self.cache[0].offset
         self.masker, self.roper = o._masker, o._roper
         print(f"  prefill S={self.S} B={x.shape[0]}: {time.time() - t0:.0f}s", flush=True)
+        if f:
+            os.makedirs(CKPT, exist_ok=True)
+            torch.save({"h0": self.h0, "S": self.S, "allowed": self.masker.allowed, "roper": self.roper, "kv": [c.kv for c in self.cache]}, f)
+
+    clear = CLEAR
 
     def greedy(self, head_f32, n_steps, need_clear_steps=None, teacher=None):
         """Greedy steps under lm_head `head_f32`; stops early (returns None) when one of the first `need_clear_steps`
@@ -74,7 +97,7 @@ class Prefilled:
         for t in range(n_steps):
             lg = orc._linear(h, head_f32)[:, -1]
             m = margins_of(lg)
-            if need_clear_steps is not None and t < need_clear_steps and m.min().item() <= CLEAR:
+            if need_clear_steps is not None and t < need_clear_steps and m.min().item() <= self.clear:
                 return None
             tok = torch.argmax(lg.to(F32), dim=-1)[:, None]
             toks.append(tok), lgs.append(lg), mgs.append(m)
@@ -84,14 +107,15 @@ class Prefilled:
         return torch.cat(toks, 1), torch.stack(lgs, 1), torch.stack(mgs, 1)
 
 
-def search_head(reqs, base_head, n_steps, max_seeds=4000, first_seed=0, need="all", min_distinct=1):
+def search_head(reqs, base_head, n_steps, max_seeds=20000, first_seed=0, need="all", min_distinct=1):
     """Smallest lm_head seed for which the requests' greedy runs are clear.  need = "all": every step of every request;
     need = "prefill": the first step of every request (then the decode steps are taken as they come).
     min_distinct: a greedy run that repeats one token is a weak witness -- ask for some variety."""
     base = base_head.to(F32)
+    clear = reqs[0].clear
     for hs in range(first_seed, first_seed + max_seeds):
         head = peaked_lm_head(base, SPREAD, hs)
-        if min(margins_of(orc._linear(r.h0, head)[:, -1]).min().item() for r in reqs) <= CLEAR:
+        if min(margins_of(orc._linear(r.h0, head)[:, -1]).min().item() for r in reqs) <= clear:
             continue                                        # cheap filter: the prefill step of every request
         out = []
         for r in reqs:
@@ -114,6 +138,7 @@ def pack(prefix, hs, res, out):
 
 
 COMMON = dict(rel_tol=np.asarray([REL_TOL], dtype=np.float32), spread=np.asarray([SPREAD], dtype=np.float32))
+COMMON_FULL = dict(COMMON, rel_tol=np.asarray([REL_TOL_FULL], dtype=np.float32))
 TINY_PROMPTS = ["<|user|>\nPick A or B.<|end|>\n<|assistant|>\n", "<|user|>\nName a colour of the sky.<|end|>\n<|assistant|>\n"]
 TINY_VIS_PROMPT = "<|user|>\n<|image_1|>\nWhat is shown?<|end|>\n<|assistant|>\n"
 CONSTRAINT = (3, " The answer is")
@@ -186,26 +211,28 @@ def full():
     cfg, o, base = _full_oracle()
     ip = Phi3VProcessor(None).img_processor
     ids = np.random.default_rng(0).integers(3, 32000, (1, 128)).astype(np.int64)
+    Prefilled.clear = 4 * REL_TOL_FULL
     print("c1", flush=True)
-    r1 = Prefilled(o, {"input_ids": ids}, 8)
+    r1 = Prefilled(o, {"input_ids": ids}, 8, tag="c1")
     hs, (res,) = search_head([r1], base, 8, min_distinct=3)
-    out = dict(COMMON, ids=ids)
+    out = dict(COMMON_FULL, ids=ids)
     pack("", hs, res, out)
     np.savez_compressed(os.path.join(HERE, "c1_oracle.npz"), **out)
     del r1
     print("c4 share (request 0 = c2)", flush=True)
     share = c4_share(ip)
-    reqs = [Prefilled(o, {k: (torch.from_numpy(v) if k == "pixel_values" else v) for k, v in r.items()}, 4) for r in share]
+    reqs = [Prefilled(o, {k: (torch.from_numpy(v) if k == "pixel_values" else v) for k, v in r.items()}, 4, tag=f"c4r{i}")
+            for i, r in enumerate(share)]
     hs, (res,) = search_head(reqs[:1], base, 4, min_distinct=2)
-    out = dict(COMMON, n_ids=np.asarray([reqs[0].S], dtype=np.int32))
+    out = dict(COMMON_FULL, n_ids=np.asarray([reqs[0].S], dtype=np.int32))
     pack("", hs, res, out)
     np.savez_compressed(os.path.join(HERE, "c2_oracle.npz"), **out)
     hs, results = search_head(reqs, base, 4, need="prefill")
-    out = dict(COMMON, n_ids=np.asarray([r.S for r in reqs], dtype=np.int32), head_seed=np.asarray([hs], dtype=np.int32))
+    out = dict(COMMON_FULL, n_ids=np.asarray([r.S for r in reqs], dtype=np.int32), head_seed=np.asarray([hs], dtype=np.int32))
     out["tokens"] = np.concatenate([r[0].numpy() for r in results]).astype(np.int32)              # [8, 4]
     out["logits_bf16"] = np.concatenate([bits(r[1]) for r in results])                            # [8, 4, V]
     out["margins"] = np.concatenate([r[2].numpy() for r in results]).astype(np.float32)
-    print(f"  c4: head_seed {hs}, clear {(out['margins'] > CLEAR).sum()} of {out['margins'].size}", flush=True)
+    print(f"  c4: head_seed {hs}, clear {(out['margins'] > Prefilled.clear).sum()} of {out['margins'].size}", flush=True)
     np.savez_compressed(os.path.join(HERE, "c4_oracle.npz"), **out)
     print("wrote c1 / c2 / c4")
 
@@ -251,7 +278,8 @@ def c5():
     try:
         ip = Phi3VProcessor(None).img_processor
         inp = vqa_request(ip, 0)
-        r = Prefilled(o, {k: (torch.from_numpy(v) if k == "pixel_values" else v) for k, v in inp.items()}, 4)
+        Prefilled.clear = 4 * REL_TOL_FULL
+        r = Prefilled(o, {k: (torch.from_numpy(v) if k == "pixel_values" else v) for k, v in inp.items()}, 4, tag="c5")
 
         def q_head(b, spread, hs):                                    # the peaked head goes through the weight quantiser too
             w8, sc = quantize_fp8_rows(peaked_lm_head(b.to(BF16), spread, hs))
@@ -265,7 +293,7 @@ def c5():
             peaked_lm_head = plain
     finally:
         orc.OracleKVCache = orig
-    out = dict(COMMON, n_ids=np.asarray([r.S], dtype=np.int32))
+    out = dict(COMMON_FULL, n_ids=np.asarray([r.S], dtype=np.int32))
     pack("", hs, res, out)
     np.savez_compressed(os.path.join(HERE, "c5_oracle.npz"), **out)
     print("wrote c5_oracle.npz")

@@ -62,7 +62,7 @@ def test_token_stopper_waits_for_all_rows():
 def test_logit_stopper_only_active_for_int_below_max_tokens():
     from phi_3_vision_mlx_amd.api import LogitStopper
     assert LogitStopper(100, False).early_stop is False
-    assert LogitStopper(100, True).early_stop is False          # bool is not an int budget
+    assert LogitStopper(100, True).early_stop is True           # isinstance(True, int): the reference enables it (as the int 1)
     assert LogitStopper(100, 200).early_stop is False
     assert LogitStopper(100, 20).early_stop == 20
 

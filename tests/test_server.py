@@ -15,8 +15,8 @@ def _post(port, path, payload, raw=None):
         return r.status, json.loads(r.read())
 
 
-@pytest.fixture()
-def server():
+@pytest.fixture(params=[True, False], ids=["merge", "solo"])
+def server(request):
     from phi_3_vision_mlx_amd.server import serve
     calls = []
 
@@ -28,7 +28,10 @@ def server():
         out = [f"{p}|{max_tokens}" for p in prompts]
         return out[0] if len(out) == 1 else out              # like generate(): str for B=1, list otherwise
 
-    httpd, engine = serve(fake_generate, port=0, host="127.0.0.1")
+    # length_fn: prompts starting with "L" count as 4000 tokens (the far side of the RoPE window with any budget >= 97)
+    httpd, engine = serve(fake_generate, port=0, host="127.0.0.1", merge=request.param, max_tokens_cap=1000,
+                          length_fn=lambda p: 4000 if p.startswith("L") else len(p))
+    engine.merge_param = request.param
     t = threading.Thread(target=httpd.serve_forever, daemon=True)
     t.start()
     yield httpd.server_address[1], calls, engine
@@ -71,7 +74,26 @@ def test_concurrent_requests_are_batched_and_routed_back(server):
     for i in range(6):
         mt = 8 if i < 4 else 9
         assert results[i] == [f"p{i}a|{mt}", f"p{i}b|{mt}"]      # every request got exactly its own texts
-    assert max(engine.batches) >= 4                             # same-budget requests were merged into one call
+    if engine.merge_param:
+        assert max(engine.batches) >= 4                         # opt-in: same-budget requests were merged into one call
+    else:
+        assert max(engine.batches) == 2                         # default: every request is its own generate call
     want_mt = {f"p{i}{s}": (8 if i < 4 else 9) for i in range(6) for s in "ab"} | {"p99a": 7, "p99b": 7, "warm": 512}
     for prompts, mt in calls:                                   # a batch never mixes budgets
         assert all(want_mt[p] == mt for p in prompts), (prompts, mt)
+
+
+def test_max_tokens_is_clamped_and_regimes_do_not_mix(server):
+    port, calls, engine = server
+    assert _post(port, "/v1/completions", {"prompt": "x", "max_tokens": 10 ** 9})[1]["responses"] == ["x|1000"]
+    results = {}
+
+    def worker(p):
+        results[p] = _post(port, "/v1/completions", {"prompt": p, "max_tokens": 200})[1]["responses"]
+    _post(port, "/v1/completions", {"prompt": "warm"})
+    ths = [threading.Thread(target=worker, args=(p,)) for p in ("Long one", "short a", "short b", "Long two")]
+    [t.start() for t in ths]
+    [t.join() for t in ths]
+    assert all(results[p] == [f"{p}|200"] for p in results) and len(results) == 4
+    for prompts, mt in calls:                                   # a long-RoPE request never shares a batch with a short one
+        assert len({p.startswith("L") for p in prompts}) == 1, prompts
