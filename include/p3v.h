@@ -118,6 +118,23 @@ typedef struct {
 int p3v_gemv_fp8(const p3v_gemv_fp8_args_t* args /* host */, void* stream);
 int p3v_dequant_fp8(const uint8_t* w8, const float* w_scale, uint16_t* out_bf16, int rows, int K, void* stream);
 
+/* ---- W8A8 projection on the fp8 matrix cores (BASELINE config 5, prompt-sized inputs; the same call sites:
+ * QuantizedLinear, phi_3_vision_mlx.py:264,291-305, under `quantize_model=True`).
+ *   out[M, N] = epilogue((a_scale[m] * w_scale[n]) * sum_k A8[m,k] * W8[n,k])     A8 [M, lda], W8 [N or 2N, ldw]: e4m3 bytes
+ * on v_mfma_scale_f32_16x16x128_f8f6f4 (block scales 1.0).  epilogue: P3V_EPI_NONE, P3V_EPI_RESID_BF16 (resid bf16 [M, ldo]),
+ * P3V_EPI_SILU_MUL (W8 / w_scale hold the N gate rows then the N up rows; out [M, N]).  K % 128 == 0, N % 256 == 0
+ * (128 for SILU_MUL), 16-byte aligned pointers and row strides.
+ * p3v_quant_fp8_rows makes A8 / a_scale from bf16 rows: one scale per row = max|h| / 448, h = x or, with norm_w,
+ * h = bf16(x * rsqrt(mean x^2 + eps) * norm_w) (nn.RMSNorm, phi.py:478-479), so the norm costs no extra pass. */
+typedef struct {
+  const uint8_t* A; const float* a_scale; const uint8_t* W; const float* w_scale;
+  uint16_t* out; const uint16_t* resid;
+  int M, N, K, lda, ldw, ldo, epilogue;
+} p3v_gemm_fp8_args_t;
+int p3v_gemm_fp8(const p3v_gemm_fp8_args_t* args /* host */, void* stream);
+int p3v_quant_fp8_rows(const uint16_t* x, const uint16_t* norm_w /* optional */, float eps, uint8_t* q, float* scale,
+                       int rows, int K, void* stream);
+
 /* ---- SuRoPE tables, phi.py:487-504: cos/sin[n_pos, half] = {cos,sin}(pos*inv_freq)*scale (fp32) */
 int p3v_rope_table(const float* pos, const float* inv_freq, float scale, float* cos_out, float* sin_out,
                    int n_pos, int half_dim, void* stream);

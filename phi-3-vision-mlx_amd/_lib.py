@@ -38,6 +38,11 @@ class GemvF8Args(C.Structure):
                 ("M", i32), ("N", i32), ("K", i32), ("epilogue", i32)]
 
 
+class GemmF8Args(C.Structure):
+    _fields_ = [("A", vp), ("a_scale", vp), ("W", vp), ("w_scale", vp), ("out", vp), ("resid", vp),
+                ("M", i32), ("N", i32), ("K", i32), ("lda", i32), ("ldw", i32), ("ldo", i32), ("epilogue", i32)]
+
+
 class AttnArgs(C.Structure):
     _fields_ = [("q", vp), ("k_past", vp), ("v_past", vp), ("k_new", vp), ("v_new", vp), ("out", vp),
                 ("pad_len", vp), ("d_past", vp), ("ws", vp),
@@ -78,6 +83,8 @@ SIGNATURES = {
     "p3v_gemv_ws_bytes": (i64, [i32, i32, i32]),
     "p3v_gemv_fp8": (i32, [C.POINTER(GemvF8Args), vp]),
     "p3v_dequant_fp8": (i32, [vp, vp, vp, i32, i32, vp]),
+    "p3v_gemm_fp8": (i32, [C.POINTER(GemmF8Args), vp]),
+    "p3v_quant_fp8_rows": (i32, [vp, vp, f32, vp, vp, i32, i32, vp]),
     "p3v_rope_table": (i32, [vp, vp, f32, vp, vp, i32, i32, vp]),
     "p3v_rope_kv_append": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, i32, i32, i32, i32, vp]),
     "p3v_attention": (i32, [C.POINTER(AttnArgs), vp]),

@@ -123,6 +123,9 @@ class Phi3VModel:
         self._lora_flat = None                       # ONE grow-only scratch for prefill-sized calls (not graph-captured)
         self.epoch = 0                               # bumped whenever captured decode graphs become stale
         self._states = weakref.WeakSet()             # every live CacheState (their graphs bake pointers into this model)
+        # quantize_model=True (fp8): prompt-sized projections run W8A8 on the fp8 MFMA unless fp8_activations=False
+        # (then: dequantise to a bf16 scratch + bf16 MFMA, weight-only accuracy at bf16 prefill speed)
+        self.fp8_act = bool(getattr(cfg, "fp8_activations", True)) and os.environ.get("P3V_FP8_PREFILL", "mfma") != "dequant"
         if getattr(cfg, "quantized_fp8", False):
             self._quantize_decoder_fp8()
         if getattr(cfg, "quantized_int4", False):
@@ -207,6 +210,10 @@ class Phi3VModel:
             return ops.gemv_q4(x, q4[0], q4[1], epilogue, resid=resid, norm_w=norm_w, norm_eps=eps, out=out)
         if q is not None and skinny and K in (3072, 8192):
             return ops.gemv_fp8(x, q[0], q[1], epilogue, resid=resid, norm_w=norm_w, norm_eps=eps, out=out)
+        if q is not None and not skinny and self.fp8_act and ops.gemm_fp8_ok(M, q[0].shape[0], K, epilogue):
+            # prompt-sized input: W8A8 on the fp8 matrix cores, activations quantised per token row (fused with the norm)
+            a8, sa = ops.quant_fp8_rows(x, norm_w, eps)
+            return ops.gemm_fp8(a8, sa, q[0], q[1], epilogue, resid=resid, out=out)
         if q4 is not None:
             w = ops.dequant_q4(q4[0], q4[1], out=self._deq[:q4[0].numel() * 8].view(q4[0].shape[0], q4[0].shape[1] * 8))
         elif q is not None:

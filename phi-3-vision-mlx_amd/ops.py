@@ -213,6 +213,36 @@ def dequant_fp8(w8, w_scale, out=None):
     return out
 
 
+def quant_fp8_rows(x, norm_w=None, norm_eps=0.0, out=None, scale=None):
+    """bf16 rows -> (e4m3 bytes [M, K], fp32 scale [M]), one scale per row = max|h| / 448; with `norm_w` h is the
+    RMSNorm of x (the fused activation quantiser of the W8A8 prefill projections)."""
+    _chk(x, BF16, "x")
+    M, K = x.shape
+    out = torch.empty((M, K), dtype=torch.uint8, device=x.device) if out is None else out
+    scale = torch.empty((M,), dtype=F32, device=x.device) if scale is None else scale
+    L.check(L.lib().p3v_quant_fp8_rows(_p(x), _p(norm_w), float(norm_eps), _p(out), _p(scale), M, K, _stream()), "quant_fp8_rows")
+    return out, scale
+
+
+def gemm_fp8(a8, a_scale, w8, w_scale, epilogue=EPI_NONE, resid=None, out=None):
+    """W8A8 nn.Linear on the fp8 matrix cores: out[M,N] = epilogue(a_scale[m] w_scale[n] sum_k a8[m,k] w8[n,k]), bf16 out."""
+    _chk(a8, torch.uint8, "a8"), _chk(w8, torch.uint8, "w8"), _chk(a_scale, F32, "a_scale"), _chk(w_scale, F32, "w_scale")
+    M, K = a8.shape
+    N = w8.shape[0] // 2 if epilogue == EPI_SILU_MUL else w8.shape[0]
+    if w8.shape[1] != K:
+        raise ValueError(f"gemm_fp8: K mismatch {a8.shape} x {w8.shape}")
+    out = torch.empty((M, N), dtype=BF16, device=a8.device) if out is None else out
+    args = L.GemmF8Args(_p(a8), _p(a_scale), _p(w8), _p(w_scale), _p(out), _p(resid), M, N, K, a8.stride(0), w8.stride(0), N, epilogue)
+    L.check(L.lib().p3v_gemm_fp8(C.byref(args), _stream()), "gemm_fp8")
+    return out
+
+
+def gemm_fp8_ok(M, N_rows, K, epilogue):
+    """Shapes p3v_gemm_fp8 takes (N_rows = rows of the weight matrix)."""
+    n = N_rows // 2 if epilogue == EPI_SILU_MUL else N_rows
+    return K % 128 == 0 and n % (128 if epilogue == EPI_SILU_MUL else 256) == 0 and epilogue in (EPI_NONE, EPI_RESID_BF16, EPI_SILU_MUL)
+
+
 def linear(x, w, epilogue=EPI_NONE, resid=None, out=None):
     """Dispatch a projection to the weight-streaming GEMV (M<=8) or the MFMA GEMM."""
     if x.shape[0] <= GEMV_MAX_M and x.shape[1] % 512 == 0 or x.shape[0] <= 8 and epilogue in (EPI_NONE, EPI_RESID_BF16, EPI_SILU_MUL, EPI_F32):

@@ -627,3 +627,69 @@ def test_gemv_q4_and_dequant(ops, N, K, epi, norm):
     else:
         ref = y if epi == "f32" else y.to(BF16)
     close(got, ref, rtol=2 ** -6, atol=3e-2)
+
+
+# ----------------------------------------------------------------------------- W8A8 on the fp8 matrix cores (config 5 prefill)
+def _e4m3(x):
+    return x.to(torch.float8_e4m3fn)
+
+
+@pytest.mark.parametrize("rows,K,norm", [(1, 3072, False), (300, 3072, True), (37, 8192, False), (2531, 3072, True)])
+def test_quant_fp8_rows(ops, rows, K, norm):
+    """Activation quantiser: one scale per token row = max|h| / 448, codes = e4m3(h / scale) (RNE), h = x or RMSNorm(x)."""
+    x = g((rows, K), 30, 2.0)
+    x[0, :] = 0 if rows > 1 else x[0, :]                        # an all-zero row keeps scale 1
+    w = (g((K,), 31, 0.1) + 1) if norm else None
+    q, s = ops.quant_fp8_rows(x.cuda(), None if w is None else w.cuda(), 1e-5)
+    h = x.float()
+    if norm:
+        h = (h * torch.rsqrt(h.pow(2).mean(-1, keepdim=True) + 1e-5) * w.float()).to(BF16).float()
+    amax = h.abs().amax(-1)
+    s_ref = torch.where(amax > 0, amax / 448.0, torch.ones_like(amax))
+    q_ref = _e4m3(h / s_ref[:, None]).view(torch.uint8)
+    if not norm:
+        assert torch.equal(s.cpu(), s_ref) and torch.equal(q.cpu(), q_ref)
+    else:                                                       # rsqrt differs by an ulp between the two sides: a few bf16 flips
+        assert torch.allclose(s.cpu(), s_ref, rtol=2 ** -7)
+        same = (q.cpu() == q_ref).float().mean().item()
+        assert same > 0.995, same
+        dq = q.cpu().view(torch.float8_e4m3fn).float() * s.cpu()[:, None]
+        assert (dq - h).abs().max().item() <= 2 ** -3 * h.abs().amax().item()
+
+
+@pytest.mark.parametrize("epi,M,N,K", [("none", 300, 512, 384), ("none", 2531, 9216, 3072), ("resid", 2531, 3072, 8192),
+                                       ("silu", 700, 1024, 3072), ("resid", 17, 256, 128)])
+def test_gemm_fp8(ops, epi, M, N, K):
+    """out = epilogue(sa[m] sw[n] sum_k a8[m,k] w8[n,k]) on v_mfma_scale_f32_16x16x128_f8f6f4 vs the same products in fp32
+    on the CPU (e4m3 x e4m3 products are exact in fp32; only the summation order differs)."""
+    EPI = {"none": ops.EPI_NONE, "resid": ops.EPI_RESID_BF16, "silu": ops.EPI_SILU_MUL}[epi]
+    n_rows = 2 * N if epi == "silu" else N
+    a8 = _e4m3(g((M, K), 40, 1.0, F32) * 3).view(torch.uint8)          # asymmetric random codes incl. denormals / zeros
+    w8 = _e4m3(g((n_rows, K), 41, 1.0, F32) * 3).view(torch.uint8)
+    sa = torch.rand((M,), generator=torch.Generator().manual_seed(42)) * 0.02 + 0.002
+    sw = torch.rand((n_rows,), generator=torch.Generator().manual_seed(43)) * 0.01 + 0.001
+    resid = g((M, N), 44, 1.0) if epi == "resid" else None
+    out = ops.gemm_fp8(a8.cuda(), sa.cuda(), w8.cuda(), sw.cuda(), EPI, resid=None if resid is None else resid.cuda())
+    af = a8.view(torch.float8_e4m3fn).float() * sa[:, None]
+    wf = w8.view(torch.float8_e4m3fn).float() * sw[:, None]
+    y = (af.double() @ wf.double().t()).float()
+    if epi == "resid":
+        ref = (resid.float() + y.to(BF16).float()).to(BF16)
+    elif epi == "silu":
+        gte, up = y[:, :N].to(BF16), y[:, N:].to(BF16)
+        ref = ((gte * torch.sigmoid(gte)) * up).to(BF16)
+    else:
+        ref = y.to(BF16)
+    assert out.shape == ref.shape
+    close(out, ref, rtol=2 ** -6, atol=2e-2 * ref.float().abs().max().item() / 16)
+
+
+def test_gemm_fp8_asymmetric_identity(ops):
+    """A = I (scaled), asymmetric W: catches a transposed / permuted C write and a wrong lane -> k mapping."""
+    K = N = 256
+    eye = torch.eye(K)
+    a8 = _e4m3(eye).view(torch.uint8)
+    wv = ((torch.arange(N)[:, None] * 3 + torch.arange(K)[None, :] * 5) % 17 - 8).float()      # exactly representable small ints
+    w8 = _e4m3(wv).view(torch.uint8)
+    out = ops.gemm_fp8(a8.cuda(), torch.ones(K).cuda(), w8.cuda(), torch.ones(N).cuda())
+    assert torch.equal(out.float().cpu(), wv.t().contiguous())
