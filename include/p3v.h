@@ -124,7 +124,8 @@ int p3v_dequant_fp8(const uint8_t* w8, const float* w_scale, uint16_t* out_bf16,
  * on v_mfma_scale_f32_16x16x128_f8f6f4 (block scales 1.0).  epilogue: P3V_EPI_NONE, P3V_EPI_RESID_BF16 (resid bf16 [M, ldo]),
  * P3V_EPI_SILU_MUL (W8 / w_scale hold the N gate rows then the N up rows; out [M, N]).  K % 128 == 0, N % 256 == 0
  * (128 for SILU_MUL), 16-byte aligned pointers and row strides.
- * p3v_quant_fp8_rows makes A8 / a_scale from bf16 rows: one scale per row = max|h| / 448, h = x or, with norm_w,
+ * p3v_quant_fp8_rows makes A8 / a_scale from bf16 rows: one scale s per row = max|h| / 448, codes e4m3(h * (1 / s)),
+ * h = x or, with norm_w,
  * h = bf16(x * rsqrt(mean x^2 + eps) * norm_w) (nn.RMSNorm, phi.py:478-479), so the norm costs no extra pass. */
 typedef struct {
   const uint8_t* A; const float* a_scale; const uint8_t* W; const float* w_scale;
@@ -222,6 +223,11 @@ int p3v_kv_quantize(const uint16_t* k, const uint16_t* vt, uint8_t* k8, uint8_t*
                     int BH, int hd, int src_t, int dst_t, int t0, int n_tok, void* stream);
 /* p3v_attention_decode on the int8 cache: same contract; the step's own new rows are quantised,
  * appended, and attended in their quantised form (one representation per key, whenever it is read). */
+/* the inverse, tokens [0, n_tok) of every (batch row, kv head): bf16 K [BH, dst_t, hd] / V^T [BH, hd, dst_t] = (code - 128) * scale.
+ * For cached calls with more than 16 new tokens on the int8 cache (they attend through p3v_attention on this copy). */
+int p3v_kv_dequantize(const uint8_t* k8, const uint8_t* v8t, const float* k_scale, const float* v_scale, uint16_t* k,
+                      uint16_t* vt, int BH, int hd, int src_t, int dst_t, int n_tok, void* stream);
+
 typedef struct {
   const uint16_t* qkv; const float* cos_t; const float* sin_t;
   uint8_t* k8; uint8_t* v8t; float* k_scale; float* v_scale; uint16_t* out;

@@ -90,6 +90,7 @@ SIGNATURES = {
     "p3v_attention": (i32, [C.POINTER(AttnArgs), vp]),
     "p3v_attention_decode": (i32, [C.POINTER(AttnDecArgs), vp]),
     "p3v_kv_quantize": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
+    "p3v_kv_dequantize": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "p3v_attention_decode_q8": (i32, [C.POINTER(AttnDecQ8Args), vp]),
     "p3v_stage_rope": (i32, [vp, vp, i32, vp, vp, vp, i32, i32, i32, i32, vp]),
     "p3v_attention_ws_bytes": (i64, [i32, i32, i32, i32, i32]),

@@ -1521,6 +1521,34 @@ extern "C" int p3v_kv_quantize(const uint16_t* k, const uint16_t* vt, uint8_t* k
   return P3V_OK;
 }
 
+// int8 caches -> bf16 K [BH, dst_t, hd] / V^T [BH, hd, dst_t], tokens [0, n_tok): (code - 128) * scale, rounded once.
+// Used by cached calls with more than 16 new tokens on the quantised cache (constrain() with a long constraint text):
+// they attend through the prefill kernel on a dequantised copy of the layer (the reference re-dequantises the whole
+// prompt every step, phi.py:534-540).
+__global__ void __launch_bounds__(256) k_kv_dequantize(const uint8_t* __restrict__ k8, const uint8_t* __restrict__ v8,
+                                                       const float* __restrict__ ksc, const float* __restrict__ vsc,
+                                                       bf16_t* __restrict__ k, bf16_t* __restrict__ vt, int hd, int src_t,
+                                                       int dst_t, int n_tok) {
+  const int bh = blockIdx.y;
+  const int n = n_tok * hd;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    const int t = i / hd, d = i - t * hd;                       // K: token-major
+    k[((size_t)bh * dst_t + t) * hd + d] = f32_to_bf16(((float)k8[((size_t)bh * src_t + t) * hd + d] - 128.f) * ksc[(size_t)bh * src_t + t]);
+    const int d2 = i / n_tok, t2 = i - d2 * n_tok;              // V^T: dim-major
+    vt[((size_t)bh * hd + d2) * dst_t + t2] = f32_to_bf16(((float)v8[((size_t)bh * hd + d2) * src_t + t2] - 128.f) * vsc[(size_t)bh * src_t + t2]);
+  }
+}
+
+extern "C" int p3v_kv_dequantize(const uint8_t* k8, const uint8_t* v8t, const float* k_scale, const float* v_scale, uint16_t* k,
+                                 uint16_t* vt, int BH, int hd, int src_t, int dst_t, int n_tok, void* stream) {
+  if (!k8 || !v8t || !k_scale || !v_scale || !k || !vt || BH <= 0 || hd <= 0 || n_tok < 0 || n_tok > src_t || n_tok > dst_t) return P3V_ERR_ARG;
+  if (n_tok == 0) return P3V_OK;
+  hipLaunchKernelGGL(k_kv_dequantize, dim3(min(p3v_cdiv((long)n_tok * hd, 256), 64), BH), dim3(256), 0, (hipStream_t)stream, k8, v8t,
+                     k_scale, v_scale, k, vt, hd, src_t, dst_t, n_tok);
+  P3V_CHECK_LAUNCH();
+  return P3V_OK;
+}
+
 struct AttnDecQ8P {
   const bf16_t* qkv; const float* cos_t; const float* sin_t; uint8_t* k8; uint8_t* v8; float* ksc; float* vsc;
   const int32_t* pad_len; const int32_t* d_past; float* ws;

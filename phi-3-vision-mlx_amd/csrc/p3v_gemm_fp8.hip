@@ -17,6 +17,8 @@
 //             on the source address, two 64-KiB buffers, half-tiles of K-step t+1 requested in the first two phases of t.
 //             Same bytes per K step as the bf16 kernel, twice the k: the step costs the same, the flops double.
 //   epilogue  scales, then none / residual add / SiLU(gate) * up, bf16 out (wave-private LDS tile -> 16-byte stores).
+#include <stdlib.h>
+
 #include "p3v_common.h"
 
 #define TM 256
@@ -35,13 +37,17 @@ struct GemmF8P {
   int M, N, K, lda, ldw, ldo;
 };
 
-template <int EPI>
+// NJ = 16-column blocks per wave: 4 -> 256 x 256 tile; 2 -> 256 x 128 tile (one B half-tile, 96 KiB of LDS in use): the
+// N = 3072 projections (o_proj, down_proj) have only 120 tiles of 256 x 256 for 256 CUs -- 240 narrower tiles fill the chip.
+template <int EPI, int NJ = 4>
 __global__ void __launch_bounds__(512, 1) k_gemm256_f8(GemmF8P p) {
   constexpr bool SILU = EPI == P3V_EPI_SILU_MUL;
+  static_assert(NJ == 4 || (NJ == 2 && !SILU), "narrow tiles: plain epilogues only");
+  constexpr int TNW = NJ * 64;                       // tile width in W rows
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 2, wc = wave & 3;
-  constexpr int n_out_tile = SILU ? TN / 2 : TN;
+  constexpr int n_out_tile = SILU ? TNW / 2 : TNW;
   int m_t, n_t;
   {   // XCD-aware tile order (as p3v_gemm256.hip): each XCD gets a contiguous run of tiles, bands of 4 M tiles
     const int gx = gridDim.x, gy = gridDim.y, nwg = gx * gy, wid = blockIdx.y * gx + blockIdx.x;
@@ -85,16 +91,16 @@ __global__ void __launch_bounds__(512, 1) k_gemm256_f8(GemmF8P p) {
                                                which < 2 ? a_off[h][q] : b_off[h][q], kt * TKB, 0, 0);
   };
 
-  f32x4_t acc[8][4];
+  f32x4_t acc[8][NJ];
 #pragma unroll
   for (int i = 0; i < 8; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
   const int frow = lane & 15, fchunk = lane >> 4;
   const int nk = p.K / TKB;
 #pragma unroll
-  for (int w4 = 0; w4 < 4; ++w4) dma_half(w4, 0, 0);
+  for (int w4 = 0; w4 < (NJ == 4 ? 4 : 3); ++w4) dma_half(w4, 0, 0);
 
   for (int kt = 0; kt < nk; ++kt) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -103,6 +109,7 @@ __global__ void __launch_bounds__(512, 1) k_gemm256_f8(GemmF8P p) {
     const int nb = (kt + 1) & 1;
     const unsigned char* ta = smem + (kt & 1) * BUF_BYTES + wr * HALF_BYTES;
     const unsigned char* tb = smem + (kt & 1) * BUF_BYTES + (2 + (wc >> 1)) * HALF_BYTES + (wc & 1) * 64 * 128;
+    if (NJ == 2) tb = smem + (kt & 1) * BUF_BYTES + 2 * HALF_BYTES + wc * 32 * 128;                   // 32 B rows per wave
     u32x4_t af[4][2], af1[4][2], bf0[2][2], bf1[2][2];
     // lane (row frow, k-block fchunk) owns bytes [32 * fchunk, 32 * fchunk + 32) of its row = logical chunks 2*fchunk, +1
     auto read_a_to = [&](int sub, u32x4_t (&dst)[4][2]) {
@@ -141,23 +148,34 @@ __global__ void __launch_bounds__(512, 1) k_gemm256_f8(GemmF8P p) {
     auto dma_phase = [&](int ph) {                    // half-tiles A0 A1 in phase 0, B0 B1 in phase 1 (SCHED 0x50 of the bf16 kernel)
       if (more) {
         if (ph == 0) { dma_half(0, kt + 1, nb); dma_half(1, kt + 1, nb); }
-        else { dma_half(2, kt + 1, nb); dma_half(3, kt + 1, nb); }
+        else { dma_half(2, kt + 1, nb); if (NJ == 4) dma_half(3, kt + 1, nb); }
       }
     };
-    read_b(0, bf0);
-    read_a_to(0, af);
-    dma_phase(0);
-    read_b(1, bf1);
-    __builtin_amdgcn_sched_barrier(0);
-    quad_from(0, 0, af, bf0);
-    __builtin_amdgcn_sched_barrier(0);
-    read_a_to(1, af1);
-    dma_phase(1);
-    __builtin_amdgcn_sched_barrier(0);
-    quad_from(0, 1, af, bf1);
-    __builtin_amdgcn_sched_barrier(0);
-    quad_from(1, 1, af1, bf1);
-    quad_from(1, 0, af1, bf0);
+    if (NJ == 4) {
+      read_b(0, bf0);
+      read_a_to(0, af);
+      dma_phase(0);
+      read_b(1, bf1);
+      __builtin_amdgcn_sched_barrier(0);
+      quad_from(0, 0, af, bf0);
+      __builtin_amdgcn_sched_barrier(0);
+      read_a_to(1, af1);
+      dma_phase(1);
+      __builtin_amdgcn_sched_barrier(0);
+      quad_from(0, 1, af, bf1);
+      __builtin_amdgcn_sched_barrier(0);
+      quad_from(1, 1, af1, bf1);
+      quad_from(1, 0, af1, bf0);
+    } else {
+      read_b(0, bf0);
+      read_a_to(0, af);
+      dma_phase(0);
+      read_a_to(1, af1);
+      dma_phase(1);
+      __builtin_amdgcn_sched_barrier(0);
+      quad_from(0, 0, af, bf0);
+      quad_from(1, 0, af1, bf0);
+    }
   }
 
   // ---- epilogue: 128 x 64 per wave, four passes of 32 rows through a wave-private [32][68] fp32 LDS tile
@@ -169,7 +187,7 @@ __global__ void __launch_bounds__(512, 1) k_gemm256_f8(GemmF8P p) {
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+      for (int j = 0; j < NJ; ++j)
 #pragma unroll
         for (int r = 0; r < 4; ++r) ct[(i * 16 + crow + r) * CT_LD + j * 16 + ccol] = acc[pass * 2 + i][j][r];
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -206,7 +224,9 @@ __global__ void __launch_bounds__(512, 1) k_gemm256_f8(GemmF8P p) {
         }
       }
     } else {
-      const int c8 = (lane & 7) * 8, n = n0 + wc * 64 + c8;
+      // a row of the wave tile is NJ * 16 columns = NJ * 2 lanes of 8 columns: 8 (4) rows per pass of the 64 lanes
+      constexpr int LPR = NJ * 2, RPI = 64 / LPR;
+      const int c8 = (lane % LPR) * 8, n = n0 + wc * (NJ * 16) + c8;
       const bool ncol_ok = n < p.N;
       float sc[8];
       if (ncol_ok) {
@@ -214,8 +234,8 @@ __global__ void __launch_bounds__(512, 1) k_gemm256_f8(GemmF8P p) {
         for (int e = 0; e < 8; ++e) sc[e] = p.sw[n + e];
       }
 #pragma unroll
-      for (int it = 0; it < 4; ++it) {
-        const int row = it * 8 + (lane >> 3);
+      for (int it = 0; it < 32 / RPI; ++it) {
+        const int row = it * RPI + lane / LPR;
         const int m = m0 + wr * 128 + pass * 32 + row;
         if (m < p.M && ncol_ok) {
           const float s = p.sa[m];
@@ -240,24 +260,38 @@ __global__ void __launch_bounds__(512, 1) k_gemm256_f8(GemmF8P p) {
   }
 }
 
-template <int EPI>
-static int launch_gemm_f8(const GemmF8P& p, hipStream_t s) {
+template <int EPI, int NJ>
+static int launch_gemm_f8_v(const GemmF8P& p, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)k_gemm256_f8<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMMF8_LDS) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)k_gemm256_f8<EPI, NJ>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMMF8_LDS) != hipSuccess)
       return P3V_ERR_HIP;
     attr_set = true;
   }
-  const int n_tile = EPI == P3V_EPI_SILU_MUL ? TN / 2 : TN;
+  const int n_tile = EPI == P3V_EPI_SILU_MUL ? TN / 2 : NJ * 64;
   dim3 grid(p3v_cdiv(p.N, n_tile), p3v_cdiv(p.M, TM));
-  hipLaunchKernelGGL((k_gemm256_f8<EPI>), grid, dim3(512), GEMMF8_LDS, s, p);
+  hipLaunchKernelGGL((k_gemm256_f8<EPI, NJ>), grid, dim3(512), GEMMF8_LDS, s, p);
   P3V_CHECK_LAUNCH();
   return P3V_OK;
 }
 
+// tile width: the wide tile unless it leaves most of the chip idle (fewer wide tiles than ~0.6 x 256 CUs, or a last round
+// that narrow tiles fill better); P3V_GEMM_F8_NARROW=0/1 pins the choice (kernel tests run both)
+template <int EPI>
+static int launch_gemm_f8(const GemmF8P& p, hipStream_t s) {
+  if constexpr (EPI == P3V_EPI_SILU_MUL) {
+    return launch_gemm_f8_v<EPI, 4>(p, s);
+  } else {
+    const long mt = p3v_cdiv(p.M, TM), wide = mt * p3v_cdiv(p.N, 256), narrow = mt * p3v_cdiv(p.N, 128);
+    bool use_narrow = p.N % 256 != 0 || wide <= 160 || (wide % 256 != 0 && wide % 256 <= 64 && narrow % 256 > 128);
+    if (const char* f = getenv("P3V_GEMM_F8_NARROW")) use_narrow = p.N % 256 != 0 || atoi(f) != 0;
+    return use_narrow ? launch_gemm_f8_v<EPI, 2>(p, s) : launch_gemm_f8_v<EPI, 4>(p, s);
+  }
+}
+
 extern "C" int p3v_gemm_fp8(const p3v_gemm_fp8_args_t* a, void* stream) {
   if (!a || !a->A || !a->a_scale || !a->W || !a->w_scale || !a->out) return P3V_ERR_ARG;
-  const int n_tile = a->epilogue == P3V_EPI_SILU_MUL ? TN / 2 : TN;
+  const int n_tile = 128;                              // SILU: 128 outputs per wide tile; plain: the narrow tile
   if (a->M < 0 || a->N <= 0 || a->K <= 0 || a->K % TKB || a->N % n_tile || a->ldo % 8) return P3V_ERR_ARG;
   if (a->lda < a->K || a->ldw < a->K || a->lda % 16 || a->ldw % 16) return P3V_ERR_ARG;
   if (((uintptr_t)a->A | (uintptr_t)a->W | (uintptr_t)a->out | (uintptr_t)a->resid) & 15) return P3V_ERR_ARG;
@@ -276,9 +310,12 @@ extern "C" int p3v_gemm_fp8(const p3v_gemm_fp8_args_t* a, void* stream) {
 }
 
 // ---------------------------------------------------------------- activation quantiser (one wave per token row)
-// q[m, k] = e4m3(h[m, k] / s[m]),  s[m] = max_k |h[m, k]| / 448 (1 for an all-zero row),  h = x, or -- with a norm weight --
+// q[m, k] = e4m3(h[m, k] * (1 / s[m])),  s[m] = max_k |h[m, k]| / 448 (1 for an all-zero row; 1 / s rounded to fp32 once per
+// row -- 8 million IEEE divisions per call kept the first version VALU-bound),  h = x, or -- with a norm weight --
 // h = bf16(x * rsqrt(mean x^2 + eps) * g): exactly the row p3v_rmsnorm would have written (phi.py:478-479, 482, 484).
-template <bool NORM>
+// The row is read ONCE and stays in registers (CH 16-byte chunks per lane: 6 for K = 3072, 16 for K = 8192) through the
+// sum of squares, the maximum and the conversion: 3 bytes of traffic per element.
+template <bool NORM, int CH>
 __global__ void __launch_bounds__(256) k_quant_fp8_rows(const u32x4_t* __restrict__ x, const u32x4_t* __restrict__ g,
                                                         u32x2_t* __restrict__ q, float* __restrict__ scale, int rows,
                                                         int chunks, float inv_h, float eps) {
@@ -286,71 +323,78 @@ __global__ void __launch_bounds__(256) k_quant_fp8_rows(const u32x4_t* __restric
   const int lane = threadIdx.x & 63;
   if (row >= rows) return;
   const u32x4_t* xr = x + (size_t)row * chunks;
+  u32x4_t v[CH];
+#pragma unroll
+  for (int i = 0; i < CH; ++i) {
+    const int c = i * 64 + lane;
+    v[i] = c < chunks ? xr[c] : (u32x4_t){0u, 0u, 0u, 0u};
+  }
   float r = 1.f;
   if (NORM) {
     float ss = 0.f;
-    for (int c = lane; c < chunks; c += 64) {
-      const u32x4_t v = xr[c];
+#pragma unroll
+    for (int i = 0; i < CH; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const float a = bf16lo(v[j]), b = bf16hi(v[j]);
+        const float a = bf16lo(v[i][j]), b = bf16hi(v[i][j]);
         ss += a * a + b * b;
       }
-    }
     r = rsqrtf(wave_sum(ss) * inv_h + eps);
   }
-  auto row8 = [&](int c, float* h) {
-    const u32x4_t v = xr[c];
-    if (NORM) {
+  float amax = 0.f;
+#pragma unroll
+  for (int i = 0; i < CH; ++i) {
+    const int c = i * 64 + lane;
+    if (NORM && c < chunks) {
       const u32x4_t w = g[c];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        h[2 * j] = bf16_round(bf16lo(v[j]) * r * bf16lo(w[j]));
-        h[2 * j + 1] = bf16_round(bf16hi(v[j]) * r * bf16hi(w[j]));
-      }
-    } else {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) { h[2 * j] = bf16lo(v[j]); h[2 * j + 1] = bf16hi(v[j]); }
+      for (int j = 0; j < 4; ++j) v[i][j] = pack_bf16x2(bf16lo(v[i][j]) * r * bf16lo(w[j]), bf16hi(v[i][j]) * r * bf16hi(w[j]));
     }
-  };
-  float amax = 0.f;
-  for (int c = lane; c < chunks; c += 64) {
-    float h[8];
-    row8(c, h);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) amax = fmaxf(amax, fabsf(h[e]));
+    for (int j = 0; j < 4; ++j) amax = fmaxf(amax, fmaxf(fabsf(bf16lo(v[i][j])), fabsf(bf16hi(v[i][j]))));
   }
   amax = wave_max(amax);
   const float s = amax > 0.f ? amax / 448.f : 1.f;
+  const float inv = 1.f / s;
   if (lane == 0) scale[row] = s;
   u32x2_t* qr = q + (size_t)row * chunks;
-  for (int c = lane; c < chunks; c += 64) {
-    float h[8];
-    row8(c, h);
-    u32x2_t o;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      int w = 0;
-      w = __builtin_amdgcn_cvt_pk_fp8_f32(h[4 * j] / s, h[4 * j + 1] / s, w, false);
-      w = __builtin_amdgcn_cvt_pk_fp8_f32(h[4 * j + 2] / s, h[4 * j + 3] / s, w, true);
-      o[j] = (uint32_t)w;
+  for (int i = 0; i < CH; ++i) {
+    const int c = i * 64 + lane;
+    if (c < chunks) {
+      u32x2_t o;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        int w = 0;
+        w = __builtin_amdgcn_cvt_pk_fp8_f32(bf16lo(v[i][2 * j]) * inv, bf16hi(v[i][2 * j]) * inv, w, false);
+        w = __builtin_amdgcn_cvt_pk_fp8_f32(bf16lo(v[i][2 * j + 1]) * inv, bf16hi(v[i][2 * j + 1]) * inv, w, true);
+        o[j] = (uint32_t)w;
+      }
+      qr[c] = o;
     }
-    qr[c] = o;
   }
+}
+
+template <bool NORM, int CH>
+static void launch_quant(const uint16_t* x, const uint16_t* norm_w, float eps, uint8_t* q, float* scale, int rows, int K, hipStream_t s) {
+  hipLaunchKernelGGL((k_quant_fp8_rows<NORM, CH>), dim3(p3v_cdiv(rows, 4)), dim3(256), 0, s, (const u32x4_t*)x, (const u32x4_t*)norm_w,
+                     (u32x2_t*)q, scale, rows, K / 8, 1.0f / K, eps);
 }
 
 extern "C" int p3v_quant_fp8_rows(const uint16_t* x, const uint16_t* norm_w, float eps, uint8_t* q, float* scale, int rows,
                                   int K, void* stream) {
-  if (!x || !q || !scale || rows < 0 || K <= 0 || K % 8) return P3V_ERR_ARG;
+  if (!x || !q || !scale || rows < 0 || K <= 0 || K % 8 || K > 16 * 64 * 8) return P3V_ERR_ARG;
   if (((uintptr_t)x | (uintptr_t)norm_w) & 15 || (uintptr_t)q & 7) return P3V_ERR_ARG;
   if (rows == 0) return P3V_OK;
   hipStream_t s = (hipStream_t)stream;
-  if (norm_w)
-    hipLaunchKernelGGL(k_quant_fp8_rows<true>, dim3(p3v_cdiv(rows, 4)), dim3(256), 0, s, (const u32x4_t*)x, (const u32x4_t*)norm_w,
-                       (u32x2_t*)q, scale, rows, K / 8, 1.0f / K, eps);
-  else
-    hipLaunchKernelGGL(k_quant_fp8_rows<false>, dim3(p3v_cdiv(rows, 4)), dim3(256), 0, s, (const u32x4_t*)x, (const u32x4_t*)nullptr,
-                       (u32x2_t*)q, scale, rows, K / 8, 1.0f / K, eps);
+  const int ch = p3v_cdiv(K / 8, 64);
+  if (norm_w) {
+    if (ch <= 6) launch_quant<true, 6>(x, norm_w, eps, q, scale, rows, K, s);
+    else launch_quant<true, 16>(x, norm_w, eps, q, scale, rows, K, s);
+  } else {
+    if (ch <= 6) launch_quant<false, 6>(x, norm_w, eps, q, scale, rows, K, s);
+    else launch_quant<false, 16>(x, norm_w, eps, q, scale, rows, K, s);
+  }
   P3V_CHECK_LAUNCH();
   return P3V_OK;
 }

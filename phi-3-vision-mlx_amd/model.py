@@ -383,8 +383,6 @@ class Phi3VModel:
         q, o, qkv, a, h, n_split, ws = (bufs[k] for k in ("q", "o", "qkv", "a", "h", "n_split", "ws"))
         if st.quantized and n_beam > 1:
             raise NotImplementedError("Beam Search is not yet compatible with Quantized Cache")       # as phi.py:525
-        if st.quantized and L > ops.L.DECODE_MAX_L and past > 0:
-            raise NotImplementedError("a cached call with more than 16 new tokens is not supported with the quantised cache")
         if n_beam > 1:                                          # beams: K/V of this call go to a scratch, cache is read-only
             Lp = (L + 7) // 8 * 8
             k_new = torch.empty((B, nkv, Lp, hd), dtype=BF16, device=self.device)
@@ -427,10 +425,12 @@ class Phi3VModel:
                     ops.attention_decode_q8(qkv, rc, rs, rb, st.k8[i], st.v8[i], st.ks[i], st.vs[i], o, B, L, nh, nkv, hd, scale,
                                             past, st.Tp, ws, n_split, pad_len=st.pad_len, d_past=d_past)
                 else:                                           # prefill: exact attention, quantised copy stored
-                    ops.rope_kv_append(qkv, st.cos, st.sin, q, st.k_tmp, st.v_tmp, B, L, nh, nkv, hd, 0, st.Tp, True, st.T, 1)
-                    ops.attention(q, o, B, L, nh, nkv, hd, scale, True, past=0, k_past=st.k_tmp, v_past=st.v_tmp,
+                    if past > 0:                                # long cached call (constrain with > 16 tokens): attend on a
+                        ops.kv_dequantize(st.k8[i], st.v8[i], st.ks[i], st.vs[i], st.k_tmp, st.v_tmp, past)   # dequantised copy
+                    ops.rope_kv_append(qkv, st.cos, st.sin, q, st.k_tmp, st.v_tmp, B, L, nh, nkv, hd, past, st.Tp, True, st.T, 1)
+                    ops.attention(q, o, B, L, nh, nkv, hd, scale, True, past=past, k_past=st.k_tmp, v_past=st.v_tmp,
                                   past_t=st.Tp, pad_len=st.pad_len, new_is_cache=True)
-                    ops.kv_quantize(st.k_tmp, st.v_tmp, st.k8[i], st.v8[i], st.ks[i], st.vs[i], 0, L)
+                    ops.kv_quantize(st.k_tmp, st.v_tmp, st.k8[i], st.v8[i], st.ks[i], st.vs[i], past, L)
             elif n_beam > 1:
                 ops.rope_kv_append(qkv, st.cos, st.sin, q, k_new, v_new, B, L, nh, nkv, hd, past, Lp, False, st.T, n_beam)
                 ops.attention(q, o, B, L, nh, nkv, hd, scale, True, k_new=k_new, v_new=v_new, new_t=Lp, past=past,

@@ -296,6 +296,13 @@ def kv_quantize(k, vt, k8, v8t, k_scale, v_scale, t0, n_tok):
                                     k8.shape[2], int(t0), int(n_tok), _stream()), "kv_quantize")
 
 
+def kv_dequantize(k8, v8t, k_scale, v_scale, k, vt, n_tok):
+    """offset-binary u8 caches -> bf16 K [B,nkv,Td,hd] / V^T [B,nkv,hd,Td], tokens [0, n_tok)."""
+    B, nkv, src_t, hd = k8.shape
+    L.check(L.lib().p3v_kv_dequantize(_p(k8), _p(v8t), _p(k_scale), _p(v_scale), _p(k), _p(vt), B * nkv, hd, src_t, k.shape[2],
+                                      int(n_tok), _stream()), "kv_dequantize")
+
+
 def attention_decode_q8(qkv, cos_new, sin_new, rope_bstride, k8, v8t, k_scale, v_scale, out, B, Lq, nh, nkv, hd, scale, past,
                         cache_t, ws, n_split, pad_len=None, d_past=None):
     """`attention_decode` on the int8 KV cache."""

@@ -12,7 +12,8 @@ N(0, 0.02) head never allows (its top-2 gap is a few bf16 ulps of the logits; to
   c4_oracle.npz     FULL-SIZE, one GPU's share of BASELINE config 4 (4 image + 4 text requests), each run on its own at
                     B = 1 (the reference's only image path, phi_3_vision_mlx.py:377-378): prefill + 3 steps per request
   c5_oracle.npz     config 2's request on the oracle with config 5's quantisers applied (e4m3 weights with per-row scales,
-                    int8 KV with per-token scales; see `c5`)
+                    e4m3 activations with per-token scales in the prompt-sized projections, int8 KV with per-token scales;
+                    see `c5`)
 
     python tests/golden/gen_golden_oracle.py [tiny|full|c5|all]        (full = c1 + c2 + c4 in one process, ~40 GB RAM)
 """
@@ -249,6 +250,26 @@ def c5_quantisers(cfg, w):
     return out
 
 
+def quantize_act_rows(x):
+    """Config 5's activation quantiser (csrc k_quant_fp8_rows) on what the build feeds it -- the bf16 value of the
+    projection's input: one scale s per token row = max|x| / 448, codes e4m3(x * (1 / s)); returns the dequantised rows."""
+    xb = x.to(BF16).to(F32)
+    amax = xb.abs().amax(dim=-1, keepdim=True)
+    s = torch.where(amax > 0, amax / 448.0, torch.ones_like(amax))
+    return (xb * (1.0 / s)).to(torch.float8_e4m3fn).to(F32) * s
+
+
+def c5_proj(o):
+    """nn.Linear of the config-5 model: e4m3 x scale weights (already folded into o.W); prompt-sized inputs (more than 16
+    rows: the build's MFMA path) get their activations quantised too (W8A8), decode-sized ones stay bf16 (W8A16 GEMV)."""
+    def proj(x, name):
+        W = o.W(name)
+        xe = quantize_act_rows(x) if x.shape[0] * x.shape[1] > 16 else x.to(F32)
+        y = xe @ W.to(F32).t()
+        return y.to(BF16) if x.dtype == BF16 else y
+    return proj
+
+
 def quantize_kv_rows(x):
     """Config 5's KV quantiser (csrc k_kv_quantize): per (row, head, token) scale = max|x| / 127, code = rne(x / scale)
     clamped to [-127, 127]; returns the dequantised values."""
@@ -272,6 +293,7 @@ class QuantKVCache(orc.OracleKVCache):
 
 def c5():
     cfg, o, base = _full_oracle(c5_quantisers)
+    o.proj = c5_proj(o)
     from phi_3_vision_mlx_amd.ops import quantize_fp8_rows
     orig = orc.OracleKVCache
     orc.OracleKVCache = QuantKVCache

@@ -636,7 +636,7 @@ def _e4m3(x):
 
 @pytest.mark.parametrize("rows,K,norm", [(1, 3072, False), (300, 3072, True), (37, 8192, False), (2531, 3072, True)])
 def test_quant_fp8_rows(ops, rows, K, norm):
-    """Activation quantiser: one scale per token row = max|h| / 448, codes = e4m3(h / scale) (RNE), h = x or RMSNorm(x)."""
+    """Activation quantiser: one scale s per token row = max|h| / 448, codes = e4m3(h * (1 / s)) (RNE), h = x or RMSNorm(x)."""
     x = g((rows, K), 30, 2.0)
     x[0, :] = 0 if rows > 1 else x[0, :]                        # an all-zero row keeps scale 1
     w = (g((K,), 31, 0.1) + 1) if norm else None
@@ -646,7 +646,7 @@ def test_quant_fp8_rows(ops, rows, K, norm):
         h = (h * torch.rsqrt(h.pow(2).mean(-1, keepdim=True) + 1e-5) * w.float()).to(BF16).float()
     amax = h.abs().amax(-1)
     s_ref = torch.where(amax > 0, amax / 448.0, torch.ones_like(amax))
-    q_ref = _e4m3(h / s_ref[:, None]).view(torch.uint8)
+    q_ref = _e4m3(h * (1.0 / s_ref)[:, None]).view(torch.uint8)
     if not norm:
         assert torch.equal(s.cpu(), s_ref) and torch.equal(q.cpu(), q_ref)
     else:                                                       # rsqrt differs by an ulp between the two sides: a few bf16 flips
@@ -657,11 +657,17 @@ def test_quant_fp8_rows(ops, rows, K, norm):
         assert (dq - h).abs().max().item() <= 2 ** -3 * h.abs().amax().item()
 
 
+@pytest.mark.parametrize("narrow", [None, "0", "1"])
 @pytest.mark.parametrize("epi,M,N,K", [("none", 300, 512, 384), ("none", 2531, 9216, 3072), ("resid", 2531, 3072, 8192),
-                                       ("silu", 700, 1024, 3072), ("resid", 17, 256, 128)])
-def test_gemm_fp8(ops, epi, M, N, K):
+                                       ("silu", 700, 1024, 3072), ("resid", 17, 256, 128), ("none", 513, 384, 256)])
+def test_gemm_fp8(ops, monkeypatch, epi, M, N, K, narrow):
     """out = epilogue(sa[m] sw[n] sum_k a8[m,k] w8[n,k]) on v_mfma_scale_f32_16x16x128_f8f6f4 vs the same products in fp32
-    on the CPU (e4m3 x e4m3 products are exact in fp32; only the summation order differs)."""
+    on the CPU (e4m3 x e4m3 products are exact in fp32; only the summation order differs).  narrow: the launcher's own
+    choice of tile width / 256-wide tiles / 128-wide tiles."""
+    if narrow is not None:
+        if epi == "silu" and narrow == "1":
+            pytest.skip("SiLU*up runs on wide tiles only")
+        monkeypatch.setenv("P3V_GEMM_F8_NARROW", narrow)
     EPI = {"none": ops.EPI_NONE, "resid": ops.EPI_RESID_BF16, "silu": ops.EPI_SILU_MUL}[epi]
     n_rows = 2 * N if epi == "silu" else N
     a8 = _e4m3(g((M, K), 40, 1.0, F32) * 3).view(torch.uint8)          # asymmetric random codes incl. denormals / zeros

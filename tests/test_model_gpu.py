@@ -190,6 +190,14 @@ def test_quantized_cache_close_to_bf16_cache():
         tok = tb.clone()
     with pytest.raises(NotImplementedError):
         mq(input_ids=np.zeros((6, 3), dtype=np.int64), cache=cq, n_beam=3, advance_offset=0)
+    # a cached call with MORE than 16 new tokens (constrain() with a long constraint text, phi_3_vision_mlx.py:545): the
+    # int8 layer is dequantised and attended through the prefill kernel, the new rows are quantised behind it
+    long_ids = np.random.default_rng(3).integers(3, 32000, (2, 21)).astype(np.int64)
+    off = cq[0].offset
+    lq, _ = mq(input_ids=long_ids, cache=cq, advance_offset=0)
+    lb, _ = mb(input_ids=long_ids, cache=cb, advance_offset=0)
+    assert cq[0].offset == off and lq.shape == lb.shape == (2, 21, mq.cfg.vocab_size)
+    assert (lq.float() - lb.float()).abs().max().item() <= 3e-2 * lb.float().abs().max().item() + 1e-2
 
 
 def test_fp8_weights_equal_bf16_model_on_dequantised_weights():
