@@ -95,15 +95,8 @@ typedef struct {
   float norm_eps;
   int M, N, K;            /* M <= 16, K % 8 == 0 (M > 8 needs K % 512 == 0) */
   int epilogue;
-  float* ws;              /* reserved (optional scratch, p3v_gemv_ws_bytes(M, N, K) bytes; currently 0) */
 } p3v_gemv_args_t;
 int p3v_gemv(const p3v_gemv_args_t* args /* host */, void* stream);
-/* Up to 4 DEPENDENT M = 1 projections (stage i reads what stage i-1 wrote: decode's o_proj -> gate_up -> down -> next
- * qkv) in ONE launch.  Every stage: K = 3072 or 8192, N even, epilogue NONE / RESID_BF16 / SILU_MUL.  `counters`:
- * n_stages * 1024 int32 (16 arrival counters per stage, one per 256-byte line), ALL ZERO on entry (arrival counters of the stages; nobody clears them -- p3v_step_begin zeroes
- * the per-layer arrays once per step).  Results equal n_stages p3v_gemv calls bit for bit. */
-int p3v_gemv_chain(const p3v_gemv_args_t* stages /* host array */, int n_stages, int32_t* counters, void* stream);
-int64_t p3v_gemv_ws_bytes(int M, int N, int K);
 
 /* ---- fp8 (OCP e4m3fn) weight-only projections (quantize_model=True; replaces the int4 `nn.quantize` of
  * phi_3_vision_mlx.py:264,296): W is u8 [N or 2N, K] bit patterns, w = fp8 * w_scale[row]; x, accumulation
@@ -205,12 +198,6 @@ typedef struct {
                         attention launch; NULL = a separate merge launch */
 } p3v_attn_decode_args_t;
 int p3v_attention_decode(const p3v_attn_decode_args_t* args /* host */, void* stream);
-/* Fused launch of a decode step's qkv projection AND the attention that consumes it (B = 1, L = 1, one tile per
- * split): `qkv_proj` as for p3v_gemv (M = 1, K = 3072, norm_w given, plain epilogue, out == attn->qkv), `attn` as for
- * p3v_attention_decode with `counters` set.  `flags`: p3v_qkv_attention_decode_flags(N) int32, ALL ZERO on entry (the
- * GEMV workgroups raise them, nobody clears them: p3v_step_begin zeroes the per-layer arrays once per step). */
-int p3v_qkv_attention_decode_flags(int n_qkv_rows);
-int p3v_qkv_attention_decode(const p3v_gemv_args_t* qkv_proj, const p3v_attn_decode_args_t* attn, int32_t* flags, void* stream);
 /* cos/sin rows of positions [past, past+L) of each batch row ([B, tab_t, half] tables) -> [B, L, half] */
 int p3v_stage_rope(const float* cos_t, const float* sin_t, int past, const int32_t* d_past,
                    float* cos_out, float* sin_out, int B, int L, int tab_t, int half_dim, void* stream);

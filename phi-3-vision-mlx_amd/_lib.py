@@ -30,7 +30,7 @@ class GemmArgs(C.Structure):
 
 class GemvArgs(C.Structure):
     _fields_ = [("x", vp), ("W", vp), ("out", vp), ("resid", vp), ("norm_w", vp), ("norm_eps", f32),
-                ("M", i32), ("N", i32), ("K", i32), ("epilogue", i32), ("ws", vp)]
+                ("M", i32), ("N", i32), ("K", i32), ("epilogue", i32)]
 
 
 class GemvF8Args(C.Structure):
@@ -80,7 +80,6 @@ SIGNATURES = {
     "p3v_layernorm": (i32, [vp, vp, vp, vp, i32, i32, i32, f32, vp]),
     "p3v_gemm": (i32, [C.POINTER(GemmArgs), vp]),
     "p3v_gemv": (i32, [C.POINTER(GemvArgs), vp]),
-    "p3v_gemv_ws_bytes": (i64, [i32, i32, i32]),
     "p3v_gemv_fp8": (i32, [C.POINTER(GemvF8Args), vp]),
     "p3v_dequant_fp8": (i32, [vp, vp, vp, i32, i32, vp]),
     "p3v_gemm_fp8": (i32, [C.POINTER(GemmF8Args), vp]),
@@ -109,9 +108,6 @@ SIGNATURES = {
     "p3v_lora_down": (i32, [vp, vp, vp, i32, i32, i32, vp]),
     "p3v_lora_up": (i32, [vp, vp, vp, f32, i32, vp, vp, i32, i32, i32, vp]),
     "p3v_step_begin": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, i32, vp]),
-    "p3v_gemv_chain": (i32, [vp, i32, vp, vp]),
-    "p3v_qkv_attention_decode_flags": (i32, [i32]),
-    "p3v_qkv_attention_decode": (i32, [vp, vp, vp, vp]),
     "p3v_step_end": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]),
     "p3v_graph_begin": (i32, [vp]),
     "p3v_graph_end": (i32, [vp, C.POINTER(vp)]),

@@ -559,21 +559,99 @@ def constrain(prompt, constraints=[(0, "\nThe"), (100, " The correct answer is")
 
 
 # ----------------------------------------------------------------------------- benchmark
-def benchmark(blind_model=False, json_path="benchmark.json", preload=None, max_tokens=100):
-    """reference phi_3_vision_mlx.py:1178-1277, 'vanilla' column only (quantised / LoRA
-    variants are not part of this build).  Prompts: text, [image+text if vision], batched text."""
-    prompts = [("Write a mystery horror.",)]
-    if not blind_model:
-        from PIL import Image
-        rng = np.random.default_rng(0)
-        prompts.append(("What is shown in this image?", Image.fromarray(rng.integers(0, 256, (336, 336, 3), dtype=np.uint8))))
-    prompts.append((["Write an executive summary for a startup.", "Write a poem about the sea.", "Explain attention.",
-                     "Say hi."],))
-    preload = preload or load(blind_model=blind_model)
-    results = {"vanilla": []}
-    for i, pr in enumerate(prompts):
-        prompt_tps, gen_tps = generate(*pr, preload=preload, max_tokens=max_tokens, return_tps=True, verbose=False)
-        results["vanilla"].append([i, prompt_tps, gen_tps])
+BENCHMARK_IMAGE_URL = "https://collectionapi.metmuseum.org/api/collection/v1/iiif/344291/725918/main-image"
+BENCHMARK_BATCH = [                                            # the reference's list (:1226-1243): 16 literals, 15 prompts --
+    "Write an executive summary for a communications business plan",     # a missing comma fuses two of them (kept: same workload)
+    "Explain quantum computing.",
+    "Write a poem about the first snowfall of the year.",
+    "Write a Python function to implement a neural network from scratch, with detailed comments.",
+    "Write a resume.",
+    "Explain the key concepts of quantum computing and provide a Rust code example demonstrating quantum superposition.",
+    "Explain the concept of dark matter and its significance in the universe.",
+    "Summarize the major events of the French Revolution.",
+    "Describe the water cycle.",
+    "Write a Neurology ICU Admission Note.",
+    "Describe a bustling alien marketplace on a distant planet with unique goods and creatures."
+    "Imagine you have a magic potion that grants one wish. What would you wish for and how would it change your life?",
+    "Compose a limerick about a clumsy robot.",
+    "Write a JavaScript function to sort an array of objects by a specific property.",
+    "Design a database schema for a social media platform, considering user profiles, posts, and interactions.",
+    "Implement a basic encryption algorithm in Python.",
+]
+
+
+def _format_benchmark(json_path="benchmark.json"):
+    """reference phi_3_vision_mlx.py:427-443: the README's table (decode tokens-per-second per task and variant)."""
+    with open(json_path, "r") as f:
+        data = json.load(f)
+    names = ["Text Generation", "Image Captioning", "Batched Generation"]
+    table = """
+    | Task                  | Vanilla Model | Quantized Model | Quantized Cache | LoRA Adapter |
+    |-----------------------|---------------|-----------------|-----------------|--------------|"""
+    for i, name in enumerate(names):
+        if i >= len(data["vanilla"]):
+            break
+        v, qm, qc, lo = (data[k][i][2] for k in ("vanilla", "q_model", "q_cache", "lora"))
+        table += f"\n    | {name}{' ' * (22 - len(name))}|  {v:.2f} tps     |  {qm:.2f} tps      |  {qc:.2f} tps       |  {lo:.2f} tps    |"
+    print(table)
+    return table
+
+
+def _benchmark_adapter(model, path):
+    """The LoRA column needs an adapter; the reference trains one first (`train_lora(take=1)`, :1246-1252 -- training is
+    outside this build).  When `path` holds none, write a seeded synthetic one of the shape `train_lora` produces by
+    default (last layer, qkv_proj, rank 1, alpha = rank, scale 1; :898, :1011): the kernels do the same work per token."""
+    from .weights import ADAPTER_CONFIG, save_adapter
+    if os.path.exists(os.path.join(path, ADAPTER_CONFIG)):
+        return path
+    cfg = model.cfg
+    H, hd = cfg.hidden_size, cfg.hidden_size // cfg.num_attention_heads
+    n_qkv = (cfg.num_attention_heads + 2 * cfg.num_key_value_heads) * hd
+    gen = torch.Generator().manual_seed(0)
+    i = cfg.num_hidden_layers - 1
+    tensors = {f"model.layers.{i}.self_attn.qkv_proj.lora_a": (torch.rand((H, 1), generator=gen) * 2 - 1) * H ** -0.5,
+               f"model.layers.{i}.self_attn.qkv_proj.lora_b": torch.randn((1, n_qkv), generator=gen) * 0.01}
+    save_adapter(path, {"model_path": "synthetic", "adapter_path": path, "lora_layers": 1, "lora_targets": ["self_attn.qkv_proj"],
+                        "lora_parameters": {"rank": 1, "alpha": 1, "dropout": 0.0, "scale": 1.0}}, tensors)
+    return path
+
+
+def benchmark(blind_model=False, json_path="benchmark.json", *, synthetic=None, image=None, max_tokens=100, adapter_path=None):
+    """reference phi_3_vision_mlx.py:1178-1277, like for like: the same three tasks (text generation, image captioning,
+    the 15-prompt batch), the same four variants (`vanilla`, `q_model` = quantize_model, `q_cache` = quantize_cache,
+    `lora` = use_adapter), 100 new tokens, results[variant] = [[task, prompt_tps, gen_tps], ...] written to `json_path`
+    and printed as the README's table (README.md:274-280 holds the reference's Apple M1 Max numbers).
+    Keyword-only extras (no network / no checkpoints here): `synthetic=True` uses seeded random weights, `image` replaces
+    the museum URL (a seeded 336x336 noise image when the URL cannot be fetched), `adapter_path` names an existing adapter.
+    The image task is skipped for `blind_model=True` exactly as the reference's processor would warn and ignore it."""
+    if image is None:
+        try:
+            image = _load_image(BENCHMARK_IMAGE_URL)
+        except Exception:
+            from PIL import Image
+            image = Image.fromarray(np.random.default_rng(0).integers(0, 256, (336, 336, 3), dtype=np.uint8))
+    prompts = [("Write a mystery horror.",), ("What is shown in this image?", image), (list(BENCHMARK_BATCH), None)]
+    results = {"vanilla": [], "q_model": [], "q_cache": [], "lora": []}
+    for method in results:
+        kwargs = {"blind_model": blind_model}
+        if synthetic:
+            kwargs["synthetic"] = synthetic
+        if method == "q_model":
+            kwargs["quantize_model"] = True
+        elif method == "q_cache":
+            kwargs["quantize_cache"] = True
+        preload = load(**kwargs)
+        if method == "lora":
+            ap = adapter_path or _benchmark_adapter(preload[0], os.path.join(PATH_ADAPTERS, "benchmark_synthetic" + ("_blind" if blind_model else "")))
+            _attach_adapter(preload[0], ap)
+        for i, prompt in enumerate(prompts):
+            if blind_model and i == 1:
+                prompt = prompt[:1]                                # text-only model: the image is ignored (phi.py:247-249)
+            prompt_tps, gen_tps = generate(*prompt, preload=preload, max_tokens=max_tokens, return_tps=True, verbose=False)
+            results[method].append([i, prompt_tps, gen_tps])
+        del preload
+        torch.cuda.empty_cache()
     with open(json_path, "w") as f:
         json.dump(results, f, indent=4)
+    _format_benchmark(json_path)
     return results

@@ -20,7 +20,6 @@
 #include <stdlib.h>
 
 #include "p3v_common.h"
-#include "p3v_gemv3_body.h"
 
 struct AttnP {
   const bf16_t* q; const bf16_t* k_past; const bf16_t* v_past; const bf16_t* k_new; const bf16_t* v_new;
@@ -862,20 +861,7 @@ __device__ unsigned long long p3v_dbg[16];
 #define DBG_W(i, first)
 #endif
 typedef short s16x4_t __attribute__((ext_vector_type(4)));
-// 16 bytes through four agent-scope relaxed loads (cache-bypassing): for data another workgroup of the SAME launch wrote
-__device__ __forceinline__ u32x4_t ld16_wt(const void* ptr) {
-  const uint32_t* q = (const uint32_t*)ptr;
-  u32x4_t v;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) v[j] = __hip_atomic_load(q + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  return v;
-}
-
-// qkv_flags != NULL: the qkv row is produced by GEMV workgroups of the SAME launch (k_qkv_attn_decode below): workgroup j
-// of that GEMV raises qkv_flags[j] when rows [8*upw*j, 8*upw*(j+1)) are stored; the K/V tile DMA is issued first, then
-// the flags covering this head's q / k / v rows are awaited (bounded), and the row is read with cache-bypassing loads.
-__device__ __forceinline__ void attn_decode_body(const AttnDecP& p, const int bx, const int by, const int bz, unsigned char* KV,
-                                                 const int32_t* qkv_flags, const int qkv_upw) {
+__device__ __forceinline__ void attn_decode_body(const AttnDecP& p, const int bx, const int by, const int bz, unsigned char* KV) {
   DBG_T(0);
   DBG_W(10, true);
   DBG_W(12, false);
@@ -943,49 +929,21 @@ __device__ __forceinline__ void attn_decode_body(const AttnDecP& p, const int bx
   const float* sin_b = p.sin_t + (size_t)b * p.rope_bstride * (HD / 2);
   const int tr = tid / CPR, tc = tid - tr * CPR;
   const bool rtask = tr < p.L;
-  if (qkv_flags) {                                             // wait for the producers of this head's q, k, v rows
-    if (tid < 64) {
-      const int per_wg = 8 * qkv_upw;                          // rows per GEMV workgroup (4 waves x upw row pairs)
-      const int sect = tid / 5, j = tid - sect * 5;            // lanes 0..14: section (q, k, v) x up to 5 workgroups
-      const int r0 = sect == 0 ? head * HD : (sect == 1 ? (p.nh + kvh) * HD : (p.nh + p.nkv + kvh) * HD);
-      const int w0 = r0 / per_wg, w1 = (r0 + HD - 1) / per_wg;
-      const bool mine = tid < 15 && w0 + j <= w1;
-      for (unsigned spins = 0; spins < (1u << 20); ++spins) {
-        const bool ok = !mine || __hip_atomic_load(qkv_flags + w0 + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
-        if (__all(ok)) break;
-        __builtin_amdgcn_s_sleep(32);                            // ~1 us: ~1300 waiting workgroups must not flood the fabric with polls
-      }
-    }
-    __syncthreads();
-  }
   RopeRaw qraw, kraw;
   if (rtask) {
     const bf16_t* row = p.qkv + ((size_t)b * p.L + tr) * row_w;
     qraw = rope_fetch(row + head * HD, tc, cos_b + tr * (HD / 2), sin_b + tr * (HD / 2));
     const bf16_t* krow = row + (p.nh + kvh) * HD;
     kraw = qraw;
-    if (qkv_flags) {
-      qraw.x0 = ld16_wt(row + head * HD + tc * 8);
-      qraw.x1 = ld16_wt(row + head * HD + (tc < 6 ? tc * 8 + 48 : tc * 8 - 48));
-      kraw.x0 = ld16_wt(krow + tc * 8);
-      kraw.x1 = ld16_wt(krow + (tc < 6 ? tc * 8 + 48 : tc * 8 - 48));
-    } else {
-      kraw.x0 = *(const u32x4_t*)(krow + tc * 8);
-      kraw.x1 = *(const u32x4_t*)(krow + (tc < 6 ? tc * 8 + 48 : tc * 8 - 48));
-    }
+    kraw.x0 = *(const u32x4_t*)(krow + tc * 8);
+    kraw.x1 = *(const u32x4_t*)(krow + (tc < 6 ? tc * 8 + 48 : tc * 8 - 48));
   }
   const bf16_t* vnew = p.qkv + (size_t)b * p.L * row_w + (p.nh + p.nkv + kvh) * HD;   // + r * row_w + d
   const int n_vnew = p.L * HD;
   bf16_t v_early = 0;
   if (tid < n_vnew) {
     const int r = tid / HD;
-    const bf16_t* src = vnew + (size_t)r * row_w + (tid - r * HD);
-    if (qkv_flags) {                                           // the containing dword, cache-bypassing
-      const uint32_t w = __hip_atomic_load((const uint32_t*)((size_t)src & ~(size_t)3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      v_early = (bf16_t)(((size_t)src & 2) ? (w >> 16) : (w & 0xffff));
-    } else {
-      v_early = *src;
-    }
+    v_early = vnew[(size_t)r * row_w + (tid - r * HD)];
   }
   if (tid < 16 * CPR) {                                        // rotated Q (zero rows for q >= L) -> LDS
     u32x4_t v = {0, 0, 0, 0};
@@ -1123,71 +1081,9 @@ __device__ __forceinline__ void attn_decode_body(const AttnDecP& p, const int bx
 
 __global__ void __launch_bounds__(256) k_attn_decode(AttnDecP p) {
   __shared__ __attribute__((aligned(1024))) unsigned char KV[4 * 6144];   // [wave]{K slice | V^T slice}
-  attn_decode_body(p, blockIdx.x, blockIdx.y, blockIdx.z, KV, nullptr, 0);
+  attn_decode_body(p, blockIdx.x, blockIdx.y, blockIdx.z, KV);
 }
 
-// =====================================================================================
-// Fused launch: qkv projection (RMSNorm + streaming GEMV, K = 3072, M = 1) AND the decode attention that consumes it.
-// One grid, two roles: workgroups [0, n_gemv) run gemv3_body and raise one flag each when their 8*upw output rows are
-// stored (write-through); workgroups [n_gemv, ...) run attn_decode_body, which requests its K/V tile FIRST and only
-// then waits for the (up to 15) flags covering its head's q / k / v rows.  Workgroups are dispatched in linear order,
-// so every producer is resident (or done) before any consumer starts waiting; the wait is bounded regardless.
-// What it buys: one launch boundary less per layer, and the 31 MB of K/V stream in while the 57 MB of qkv weights do.
-__global__ void __launch_bounds__(256) k_qkv_attn_decode(GemvP gp, int upw, int n_gemv, AttnDecP ap, int32_t* qkv_flags) {
-  __shared__ __attribute__((aligned(1024))) unsigned char KV[4 * 6144];
-  __shared__ float red[8];
-  if ((int)blockIdx.x < n_gemv) {
-    gemv3_body<1, 1, 6>(gp, upw, blockIdx.x, KV, red, qkv_flags + blockIdx.x);
-    return;
-  }
-  const int id = blockIdx.x - n_gemv;
-  const int bx = id % ap.n_split, hb = id / ap.n_split;
-  attn_decode_body(ap, bx, hb % ap.nh, hb / ap.nh, KV, qkv_flags, upw);
-}
-
-static int gemv3_split(int units, int* upw_out) {             // the (units per wave, workgroups) plan of launch_gemv3 (p3v_gemv.hip)
-  static int n_cu = 0;
-  if (!n_cu) {
-    int dev = 0;
-    hipDeviceProp_t pr;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess) return -1;
-    n_cu = pr.multiProcessorCount;
-  }
-  int upw = p3v_cdiv(units, n_cu * 8);
-  if (upw < 1) upw = 1;
-  *upw_out = upw;
-  return p3v_cdiv(p3v_cdiv(units, upw), 4);
-}
-
-extern "C" int p3v_qkv_attention_decode_flags(int n_qkv_rows) {
-  int upw;
-  return gemv3_split(n_qkv_rows / 2, &upw);
-}
-
-extern "C" int p3v_qkv_attention_decode(const p3v_gemv_args_t* g, const p3v_attn_decode_args_t* a, int32_t* flags, void* stream) {
-  if (!g || !a || !flags || !g->x || !g->W || !g->out || !g->norm_w) return P3V_ERR_ARG;
-  if (!a->qkv || !a->cos_t || !a->sin_t || !a->k_cache || !a->v_cache || !a->out || !a->ws || !a->counters) return P3V_ERR_ARG;
-  if (g->M != 1 || g->K != 3072 || g->epilogue != P3V_EPI_NONE || g->N % 2 || (const void*)g->out != (const void*)a->qkv) return P3V_ERR_UNSUPPORTED;
-  if (a->hd != 96 || a->B != 1 || a->L != 1 || a->n_heads % a->n_kv || g->N != (a->n_heads + 2 * a->n_kv) * 96) return P3V_ERR_UNSUPPORTED;
-  if (a->n_split < 1 || a->n_split > 128 || a->cache_t % 64 || a->n_split * 64 < a->cache_t) return P3V_ERR_UNSUPPORTED;
-  GemvP gp = {g->x, g->W, g->out, g->resid, g->norm_w, g->norm_eps, g->M, g->N, g->K, g->epilogue, g->N / 2};
-  int upw;
-  const int n_gemv = gemv3_split(gp.units, &upw);
-  if (n_gemv < 0) return P3V_ERR_HIP;
-  const int grp = a->n_heads / a->n_kv;
-  AttnDecP ap = {a->qkv, a->cos_t, a->sin_t, a->k_cache, a->v_cache, a->pad_len, a->d_past, a->ws,
-                 a->B, a->L, a->n_heads, a->n_kv, a->past, a->cache_t, a->rope_bstride, a->n_split, a->scale,
-                 64, grp, (65536 + grp - 1) / grp, a->counters, (bf16_t*)a->out};
-  hipLaunchKernelGGL(k_qkv_attn_decode, dim3(n_gemv + a->n_split * a->n_heads * a->B), dim3(256), 0, (hipStream_t)stream, gp, upw,
-                     n_gemv, ap, flags);
-  P3V_CHECK_LAUNCH();
-  return P3V_OK;
-}
-
-// Multi-tile variant (contexts beyond ~8k tokens or large batches, where one tile per workgroup would need more than
-// ~4096 workgroups): ONE wave per workgroup walks the 64-key tiles of its split; the whole next tile (24 16-byte
-// loads per lane) is prefetched into registers while the current one is consumed from LDS, so ~768 resident waves
-// keep 18 MB in flight and the loop is bandwidth-bound (6.2 TB/s at 32k tokens).
 template <int TK>
 __global__ void __launch_bounds__(64) k_attn_decode_stream(AttnDecP p) {
   constexpr int HD = 96, KSTR = HD * 2 + 16, VSTR = TK * 2 + 16, NKS = 3, NDT = 6, CPR = 12;

@@ -143,7 +143,7 @@ template <int MT, int NST, int CH>
 __global__ void __launch_bounds__(256) k_gemv3(GemvP p, int units_per_wave) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ float red[8];
-  gemv3_body<MT, NST, CH>(p, units_per_wave, blockIdx.x, smem, red, nullptr);
+  gemv3_body<MT, NST, CH>(p, units_per_wave, blockIdx.x, smem, red);
 }
 
 static int gemv_env(const char* name, int dflt) {
@@ -172,68 +172,6 @@ static int launch_gemv3(const GemvP& p, hipStream_t s) {
     attr_set = true;
   }
   hipLaunchKernelGGL((k_gemv3<MT, NST, CH>), dim3(p3v_cdiv(waves, 4)), dim3(256), lds, s, p, upw);
-  P3V_CHECK_LAUNCH();
-  return P3V_OK;
-}
-
-// ---------------------------------------------------------------------------
-// Chain of dependent M = 1 GEMVs in ONE launch (decode: o_proj -> gate_up -> down -> next layer's qkv).  Workgroups
-// [off[s], off[s+1]) run stage s; every stage prefetches its first weight stage, waits for the previous stage's
-// arrival counters, reads x past the caches and publishes its own arrival (gemv3_body, ChainSync).  What it saves per
-// stage boundary: the ~2.4 us dispatch gap and most of the first-load latency (the weights are already on their way).
-#define P3V_CHAIN_MAX 4
-struct ChainP {
-  GemvP g[P3V_CHAIN_MAX];
-  int upw[P3V_CHAIN_MAX], off[P3V_CHAIN_MAX + 1], k8192[P3V_CHAIN_MAX];
-  int n;
-  int32_t* counters;           // [n][16][CHAIN_CNT_STRIDE], zero on entry
-};
-
-__global__ void __launch_bounds__(256) k_gemv_chain(ChainP c) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  __shared__ float red[8];
-  int s = 0;
-#pragma unroll
-  for (int i = 1; i < P3V_CHAIN_MAX; ++i)
-    if (i < c.n && (int)blockIdx.x >= c.off[i]) s = i;
-  const ChainSync cs = {s > 0 ? c.counters + (s - 1) * 16 * CHAIN_CNT_STRIDE : nullptr, s > 0 ? c.off[s] - c.off[s - 1] : 0,
-                        c.counters + s * 16 * CHAIN_CNT_STRIDE};
-  const int bx = blockIdx.x - c.off[s];
-  if (c.k8192[s]) gemv3_body<1, 4, 4>(c.g[s], c.upw[s], bx, smem, red, nullptr, &cs);
-  else gemv3_body<1, 1, 6>(c.g[s], c.upw[s], bx, smem, red, nullptr, &cs);
-}
-
-extern "C" int p3v_gemv_chain(const p3v_gemv_args_t* st, int n_stages, int32_t* counters, void* stream) {
-  if (!st || !counters || n_stages < 1 || n_stages > P3V_CHAIN_MAX) return P3V_ERR_ARG;
-  static int n_cu = 0;
-  if (!n_cu) {
-    int dev = 0;
-    hipDeviceProp_t pr;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess) return P3V_ERR_HIP;
-    n_cu = pr.multiProcessorCount;
-  }
-  ChainP c;
-  c.n = n_stages;
-  c.counters = counters;
-  c.off[0] = 0;
-  size_t lds = 0;
-  for (int i = 0; i < n_stages; ++i) {
-    const p3v_gemv_args_t* a = st + i;
-    if (!a->x || !a->W || !a->out) return P3V_ERR_ARG;
-    if (a->M != 1 || (a->K != 3072 && a->K != 8192) || a->N <= 0 || a->N % 2) return P3V_ERR_UNSUPPORTED;
-    if (a->epilogue != P3V_EPI_NONE && a->epilogue != P3V_EPI_RESID_BF16 && a->epilogue != P3V_EPI_SILU_MUL) return P3V_ERR_UNSUPPORTED;
-    if (a->epilogue == P3V_EPI_RESID_BF16 && !a->resid) return P3V_ERR_ARG;
-    c.g[i] = GemvP{a->x, a->W, a->out, a->resid, a->norm_w, a->norm_eps, a->M, a->N, a->K, a->epilogue,
-                   a->epilogue == P3V_EPI_SILU_MUL ? a->N : a->N / 2};
-    int upw = p3v_cdiv(c.g[i].units, n_cu * 8);
-    if (upw < 1) upw = 1;
-    c.upw[i] = upw;
-    c.k8192[i] = a->K == 8192;
-    c.off[i + 1] = c.off[i] + p3v_cdiv(p3v_cdiv(c.g[i].units, upw), 4);
-    if ((size_t)a->K * 2 > lds) lds = (size_t)a->K * 2;
-  }
-  for (int i = n_stages; i < P3V_CHAIN_MAX; ++i) { c.g[i] = c.g[0]; c.upw[i] = 1; c.k8192[i] = 0; c.off[i + 1] = c.off[n_stages]; }
-  hipLaunchKernelGGL(k_gemv_chain, dim3(c.off[n_stages]), dim3(256), lds, (hipStream_t)stream, c);
   P3V_CHECK_LAUNCH();
   return P3V_OK;
 }
@@ -521,7 +459,6 @@ static int launch_gemv_mfma8(const GemvP& p, hipStream_t s) {
   return P3V_OK;
 }
 
-extern "C" int64_t p3v_gemv_ws_bytes(int M, int N, int K) { return 0; }   // kept in the ABI; the MFMA path needs no scratch
 
 static int launch_gemv_mfma(const GemvP& p, hipStream_t s) {
   dim3 grid(p3v_cdiv(p.N, 16));

@@ -389,32 +389,6 @@ class Phi3VModel:
             v_new = torch.zeros((B, nkv, hd, Lp), dtype=BF16, device=self.device)
         for i in range(cfg.num_hidden_layers):
             p = f"model.layers.{i}."
-            chain = d_past is not None and M == 1 and bufs.get("chain_cnt") is not None and bufs.get("attn_cnt") is not None
-            if chain:
-                # graph-replayed B = 1 step: attention launch + ONE launch for o_proj -> gate_up -> down -> next layer's qkv
-                if i == 0:
-                    self._proj(x, p + "self_attn.qkv_proj.weight", norm_w=w[p + "input_layernorm.weight"], out=qkv, h=h)
-                ops.attention_decode(qkv, bufs["rope_cos"], bufs["rope_sin"], L, st.k[i], st.v[i], o, B, L, nh, nkv, hd, scale, past,
-                                     st.Tp, ws, n_split, pad_len=st.pad_len, d_past=d_past, counters=bufs["attn_cnt"])
-                stages = [(o, w[p + "self_attn.o_proj.weight"], EPI_RESID_BF16, x, None, 0.0, x),
-                          (x, w[p + "mlp.gate_up_proj.weight"], EPI_SILU_MUL, None, w[p + "post_attention_layernorm.weight"], eps, a),
-                          (a, w[p + "mlp.down_proj.weight"], EPI_RESID_BF16, x, None, 0.0, x)]
-                if i + 1 < cfg.num_hidden_layers:
-                    pn = f"model.layers.{i + 1}."
-                    stages.append((x, w[pn + "self_attn.qkv_proj.weight"], EPI_NONE, None, w[pn + "input_layernorm.weight"], eps, qkv))
-                ops.gemv_chain(stages, bufs["chain_cnt"][i])
-                continue
-            fused_qkv = (d_past is not None and M == 1 and not st.quantized and bufs.get("qkv_flags") is not None
-                         and bufs.get("attn_cnt") is not None and (p + "self_attn.qkv_proj.weight") in w
-                         and (p + "self_attn.qkv_proj.weight") not in self.adapters and cfg.hidden_size == 3072)
-            if fused_qkv:                                       # ONE launch: RMSNorm + qkv projection + decode attention
-                ops.qkv_attention_decode(x, w[p + "self_attn.qkv_proj.weight"], w[p + "input_layernorm.weight"], eps, qkv,
-                                         bufs["rope_cos"], bufs["rope_sin"], L, st.k[i], st.v[i], o, nh, nkv, hd, scale, past, st.Tp,
-                                         ws, n_split, bufs["attn_cnt"], bufs["qkv_flags"][i], d_past=d_past, pad_len=st.pad_len)
-                self._proj(o, p + "self_attn.o_proj.weight", EPI_RESID_BF16, resid=x, out=x)
-                self._proj(x, p + "mlp.gate_up_proj.weight", EPI_SILU_MUL, norm_w=w[p + "post_attention_layernorm.weight"], out=a, h=h)
-                self._proj(a, p + "mlp.down_proj.weight", EPI_RESID_BF16, resid=x, out=x)
-                continue
             self._proj(x, p + "self_attn.qkv_proj.weight", norm_w=w[p + "input_layernorm.weight"], out=qkv, h=h)
             if st.quantized:
                 if L <= ops.L.DECODE_MAX_L:
@@ -467,34 +441,13 @@ class Phi3VModel:
                  next_tok=torch.zeros((B,), dtype=I32, device=dev), ticket=torch.zeros((1,), dtype=I32, device=dev))
         bufs = self._alloc_bufs(B, 1)
         self._split_plan(bufs, B, 1, st.Tp, st.quantized)          # the single-tile kernel needs one split per tile of CAPACITY
-        # In-launch synchronisation state of the step's fused launches, cleared by step_begin every step:
-        #  * chain_cnt: arrival counters of the GEMV chain o_proj -> gate_up -> down -> next qkv (ONE launch per layer,
-        #    p3v_gemv_chain) -- bit-identical but OFF by default (P3V_GEMV_CHAIN=1): 2.42 ms/step against 1.87 with
-        #    separate launches; a stage hand-over through arrival counters + polling + cache-bypassing reloads of x costs
-        #    more than the 3.9 us launch boundary it removes;
-        #  * qkv_flags: fused qkv-projection + attention launch (p3v_qkv_attention_decode) -- bit-identical but OFF by
-        #    default: 31.7 us against 11.2 + 14.7 us for the two launches, because a kernel's registers are sized for
-        #    its hungriest role (the GEMV's 144 VGPRs) and only 384 of the 1312 attention workgroups are then resident
-        #    while the GEMV streams.
-        nl = cfg.num_hidden_layers
-        plain = B == 1 and not st.quantized and not self.w8 and not self.w4 and not self.adapters and cfg.hidden_size == 3072 \
-            and cfg.intermediate_size == 8192
-        n_chain = nl * 4096 if plain and os.environ.get("P3V_GEMV_CHAIN", "0") == "1" else 0
-        nf = ops.qkv_attention_decode_flags((cfg.num_attention_heads + 2 * cfg.num_key_value_heads) * self.hd) \
-            if plain and os.environ.get("P3V_FUSED_QKV_ATTN", "0") == "1" else 0
-        if n_chain + nl * nf:
-            bufs["step_zero"] = torch.zeros(n_chain + nl * nf, dtype=I32, device=dev)
-            if n_chain:
-                bufs["chain_cnt"] = bufs["step_zero"][:n_chain].view(nl, 4096)
-            if nf:
-                bufs["qkv_flags"] = bufs["step_zero"][n_chain:].view(nl, nf)
         bufs["rope_cos"] = torch.empty((B, 1, self.hd // 2), dtype=F32, device=dev)
         bufs["rope_sin"] = torch.empty_like(bufs["rope_cos"])
         g["bufs"] = bufs
 
         def step():
             ops.step_begin(g["tok"], w["model.embed_tokens.weight"], g["x"], st.cos, st.sin, g["d_past"],
-                           bufs["rope_cos"], bufs["rope_sin"], zero_buf=bufs.get("step_zero"))
+                           bufs["rope_cos"], bufs["rope_sin"])
             self._layers(g["x"], st, B, 1, 0, 1, bufs=bufs, d_past=g["d_past"])
             self._proj(g["x"], "lm_head.weight", norm_w=w["model.norm.weight"], out=g["logits"])
             ops.step_end(g["logits"], g["next_tok"], g["tok"], g["history"], g["d_step"], g["d_past"], g["ticket"])

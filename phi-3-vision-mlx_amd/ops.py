@@ -78,18 +78,6 @@ def gemm(a, w, epilogue=EPI_NONE, bias=None, resid=None, out=None, n_out=None, p
 
 
 GEMV_MAX_M = 16
-_gemv_ws = {}
-
-
-def _gemv_scratch(M, N, K, device):
-    """Split-K scratch of the MFMA skinny kernel (one lazily grown buffer per device; stream-ordered reuse)."""
-    need = int(L.lib().p3v_gemv_ws_bytes(M, N, K))
-    if need == 0:
-        return None
-    buf = _gemv_ws.get(device)
-    if buf is None or buf.numel() * 4 < need:
-        buf = _gemv_ws[device] = torch.empty(max(need // 4, 1 << 20), dtype=F32, device=device)
-    return buf
 
 
 def gemv(x, w, epilogue=EPI_NONE, resid=None, norm_w=None, norm_eps=0.0, out=None):
@@ -99,8 +87,7 @@ def gemv(x, w, epilogue=EPI_NONE, resid=None, norm_w=None, norm_eps=0.0, out=Non
     N = w.shape[0] // 2 if epilogue == EPI_SILU_MUL else w.shape[0]
     if out is None:
         out = torch.empty((M, N), dtype=F32 if epilogue == EPI_F32 else BF16, device=x.device)
-    ws = _gemv_scratch(M, N, K, x.device) if M >= 2 else None
-    args = L.GemvArgs(_p(x), _p(w), _p(out), _p(resid), _p(norm_w), float(norm_eps), M, N, K, epilogue, _p(ws))
+    args = L.GemvArgs(_p(x), _p(w), _p(out), _p(resid), _p(norm_w), float(norm_eps), M, N, K, epilogue)
     L.check(L.lib().p3v_gemv(C.byref(args), _stream()), "gemv")
     return out
 
@@ -172,17 +159,6 @@ def dequant_q4(w4, sb, out=None):
         out = torch.empty((N, K), dtype=BF16, device=w4.device)
     L.check(L.lib().p3v_dequant_q4(_p(w4), _p(sb), _p(out), N, K, _stream()), "dequant_q4")
     return out
-
-
-def gemv_chain(stages, counters):
-    """Dependent M = 1 projections in ONE launch: stages = [(x, w, epilogue, resid, norm_w, norm_eps, out), ...] (at most 4,
-    K in {3072, 8192}); `counters` int32 [>= 1024 * len(stages)], all zero on entry."""
-    arr = (L.GemvArgs * len(stages))()
-    for i, (x, w, epi, resid, norm_w, eps, out) in enumerate(stages):
-        _chk(x, BF16, "x"), _chk(w, BF16, "w")
-        N = w.shape[0] // 2 if epi == EPI_SILU_MUL else w.shape[0]
-        arr[i] = L.GemvArgs(_p(x), _p(w), _p(out), _p(resid), _p(norm_w), float(eps), 1, N, w.shape[1], epi, None)
-    L.check(L.lib().p3v_gemv_chain(arr, len(stages), _p(counters), _stream()), "gemv_chain")
 
 
 def quantize_fp8_rows(w):
@@ -383,21 +359,6 @@ def step_begin(tok, table, x_out, cos_t, sin_t, d_past, cos_out, sin_out, zero_b
     L.check(L.lib().p3v_step_begin(_p(tok), _p(table), _p(x_out), _p(cos_t), _p(sin_t), _p(d_past), _p(cos_out), _p(sin_out),
                                    B, table.shape[1], table.shape[0], tab_t, half, _p(zero_buf),
                                    0 if zero_buf is None else zero_buf.numel(), _stream()), "step_begin")
-
-
-def qkv_attention_decode_flags(n_qkv_rows):
-    return L.lib().p3v_qkv_attention_decode_flags(int(n_qkv_rows))
-
-
-def qkv_attention_decode(x, w_qkv, norm_w, norm_eps, qkv, cos_new, sin_new, rope_bstride, k_cache, v_cache, out, nh, nkv, hd, scale,
-                         past, cache_t, ws, n_split, counters, flags, d_past=None, pad_len=None):
-    """ONE launch for RMSNorm + qkv projection + decode attention (B = 1, L = 1): `flags` must be all zero on entry."""
-    _chk(x, BF16, "x"), _chk(w_qkv, BF16, "w_qkv")
-    g = L.GemvArgs(_p(x), _p(w_qkv), _p(qkv), None, _p(norm_w), float(norm_eps), 1, w_qkv.shape[0], w_qkv.shape[1], EPI_NONE, None)
-    a = L.AttnDecArgs(_p(qkv), _p(cos_new), _p(sin_new), _p(k_cache), _p(v_cache), _p(out), _p(pad_len), _p(d_past), _p(ws),
-                      1, 1, nh, nkv, hd, int(past), cache_t, rope_bstride, n_split, float(scale), _p(counters))
-    L.check(L.lib().p3v_qkv_attention_decode(C.byref(g), C.byref(a), _p(flags), _stream()), "qkv_attention_decode")
-    return out
 
 
 def step_end(logits, next_tok, tok, history, d_step, d_past, ticket):

@@ -34,15 +34,24 @@ from phi_3_vision_mlx_amd.config import make_config, phi3v_config_dict, tiny_con
 from phi_3_vision_mlx_amd.processor import Phi3FProcessor, Phi3VProcessor  # noqa: E402
 from phi_3_vision_mlx_amd.weights import peaked_lm_head, synth_weights  # noqa: E402
 
-# |HIP - oracle| <= REL_TOL * max|logit| on EVERY vocabulary entry is what the GPU tests assert; a step is "clear" when the
-# oracle's top-2 margin exceeds 4 x REL_TOL of max|logit|.  2 layers: 3 %; 32 layers: 4.5 % (measured worst entry 3.6 %:
-# the bf16 residual stream alone moves the hidden state by ~3 % between two correct implementations -- the oracle against
-# itself with float64 accumulation differs by 2.4 % of max|logit| after 24 layers, tools/precision_study.py)
-REL_TOL = 0.03
-REL_TOL_FULL = 0.045
-CLEAR = 4 * REL_TOL
+# TOLERANCE MODEL.  logit_v = W_v . h, so an error dh of the final hidden state moves entry v by at most |W_v| |dh|: the
+# natural unit of a logit error is the entry's own lm_head ROW NORM n_v.  With z_v = logit_v / n_v the GPU tests assert, on
+# EVERY vocabulary entry,      |HIP_v - oracle_v| <= rel_tol * max_u |z_u| * n_v   (+ one bf16 ulp of the entry),
+# i.e. the classic "within rel_tol of max|logit|" in the row-normalised space (for a plain N(0, s) head, whose rows all have
+# the same norm, the two are the same statement).  A step is CLEAR when the oracle's top-2 margin exceeds the SUM of the two
+# entries' tolerances -- then any implementation that meets the tolerance must pick the same token; statistically that
+# margin is > 6 sigma of the difference of the two errors (the tolerance bounds the worst of 32064 entries, ~4.1 sigma).
+# rel_tol is what two CORRECT implementations of this bf16 model differ by (measured HIP vs oracle, z-space, worst entry):
+#   2 layers (tiny) < 2 %; 32 layers: 2.7-3.1 % on 2531-token image prompts, 6.0-7.4 % on 65-233-token text prompts (few keys
+#   -> little averaging in the attention); the oracle against ITSELF with float64 accumulation already differs by 2.4 % after
+#   24 layers (tools/precision_study.py): the bf16 residual stream, not the build's bf16 attention operands, sets the floor.
+REL_TOL = 0.03            # tiny (2-layer) fixtures
+REL_TOL_LONG = 0.045      # full size, 2531-token image prompts
+REL_TOL_SHORT = 0.09      # full size, short text prompts
 CKPT = os.environ.get("P3V_ORACLE_CKPT", "/tmp/p3v_oracle_ckpt")     # prefilled requests are kept here between runs (GBs)
 SPREAD = 4.0                   # log2-sd of the lm_head row scales
+C1_STEPS = 6                   # prefill + 5 decode steps, all clear (each extra all-clear step costs ~4x more head seeds)
+REL_TOL_C5 = 0.15              # config 5 (W8A8 prefill + W8A16 decode + int8 KV): see c5()
 BF16, F32 = torch.bfloat16, torch.float32
 
 
@@ -50,10 +59,17 @@ def bits(lg):
     return lg.to(BF16).contiguous().view(torch.int16).numpy().view(np.uint16)
 
 
-def margins_of(lg):
+def row_norms(head):
+    """fp32 L2 norms of the lm_head rows (of the values the projection really multiplies by)."""
+    return head.to(F32).norm(dim=-1).clamp_min(1e-30)
+
+
+def clearance(lg, n, rel_tol):
+    """(top-2 margin) / (sum of the two entries' tolerances) per row; > 1 = the step is clear.  rel_tol: float or [B]."""
     lf = lg.to(F32)
-    t2 = lf.topk(2, dim=-1).values
-    return (t2[..., 0] - t2[..., 1]) / lf.abs().amax(dim=-1)
+    v, i = lf.topk(2, dim=-1)
+    E = torch.as_tensor(rel_tol, dtype=F32) * (lf / n).abs().amax(dim=-1)
+    return (v[..., 0] - v[..., 1]) / (E * (n[i[..., 0]] + n[i[..., 1]]))
 
 
 class Prefilled:
@@ -85,11 +101,12 @@ class Prefilled:
             os.makedirs(CKPT, exist_ok=True)
             torch.save({"h0": self.h0, "S": self.S, "allowed": self.masker.allowed, "roper": self.roper, "kv": [c.kv for c in self.cache]}, f)
 
-    clear = CLEAR
+    rel_tol = REL_TOL
 
-    def greedy(self, head_f32, n_steps, need_clear_steps=None, teacher=None):
+    def greedy(self, head_f32, n_steps, need_clear_steps=None, teacher=None, norms=None):
         """Greedy steps under lm_head `head_f32`; stops early (returns None) when one of the first `need_clear_steps`
         steps is not clear."""
+        norms = row_norms(head_f32) if norms is None else norms
         o = self.o
         o._masker, o._roper = self.masker, self.roper
         for c in self.cache:
@@ -97,8 +114,8 @@ class Prefilled:
         h, toks, lgs, mgs = self.h0, [], [], []
         for t in range(n_steps):
             lg = orc._linear(h, head_f32)[:, -1]
-            m = margins_of(lg)
-            if need_clear_steps is not None and t < need_clear_steps and m.min().item() <= self.clear:
+            m = clearance(lg, norms, self.rel_tol)
+            if need_clear_steps is not None and t < need_clear_steps and m.min().item() <= 1.0:
                 return None
             tok = torch.argmax(lg.to(F32), dim=-1)[:, None]
             toks.append(tok), lgs.append(lg), mgs.append(m)
@@ -113,14 +130,14 @@ def search_head(reqs, base_head, n_steps, max_seeds=20000, first_seed=0, need="a
     need = "prefill": the first step of every request (then the decode steps are taken as they come).
     min_distinct: a greedy run that repeats one token is a weak witness -- ask for some variety."""
     base = base_head.to(F32)
-    clear = reqs[0].clear
     for hs in range(first_seed, first_seed + max_seeds):
         head = peaked_lm_head(base, SPREAD, hs)
-        if min(margins_of(orc._linear(r.h0, head)[:, -1]).min().item() for r in reqs) <= clear:
+        norms = row_norms(head)
+        if min(clearance(orc._linear(r.h0, head)[:, -1], norms, r.rel_tol).min().item() for r in reqs) <= 1.0:
             continue                                        # cheap filter: the prefill step of every request
         out = []
         for r in reqs:
-            res = r.greedy(head, n_steps, need_clear_steps=n_steps if need == "all" else 1)
+            res = r.greedy(head, n_steps, need_clear_steps=n_steps if need == "all" else 1, norms=norms)
             if res is None:
                 break
             out.append(res)
@@ -135,11 +152,12 @@ def pack(prefix, hs, res, out):
     out[prefix + "tokens"] = toks.numpy().astype(np.int32)
     out[prefix + "logits_bf16"] = bits(lgs)
     out[prefix + "margins"] = mgs.numpy().astype(np.float32)
-    print(f"  {prefix}: head_seed {hs}, tokens {toks.tolist()}, min margin {mgs.min().item():.3f}", flush=True)
+    print(f"  {prefix}: head_seed {hs}, tokens {toks.tolist()}, min clearance {mgs.min().item():.3f}", flush=True)
 
 
 COMMON = dict(rel_tol=np.asarray([REL_TOL], dtype=np.float32), spread=np.asarray([SPREAD], dtype=np.float32))
-COMMON_FULL = dict(COMMON, rel_tol=np.asarray([REL_TOL_FULL], dtype=np.float32))
+COMMON_LONG = dict(COMMON, rel_tol=np.asarray([REL_TOL_LONG], dtype=np.float32))
+COMMON_SHORT = dict(COMMON, rel_tol=np.asarray([REL_TOL_SHORT], dtype=np.float32))
 TINY_PROMPTS = ["<|user|>\nPick A or B.<|end|>\n<|assistant|>\n", "<|user|>\nName a colour of the sky.<|end|>\n<|assistant|>\n"]
 TINY_VIS_PROMPT = "<|user|>\n<|image_1|>\nWhat is shown?<|end|>\n<|assistant|>\n"
 CONSTRAINT = (3, " The answer is")
@@ -171,9 +189,11 @@ def tiny():
             for hs in range(4000):
                 with_head(hs)
                 lg, _ = o(**proc(TINY_PROMPTS), max_tokens=0)
-                lp = lg[:, -1].to(F32)[:, torch.as_tensor(opts).long()]
-                t2 = lp.topk(2, dim=-1).values
-                if ((t2[:, 0] - t2[:, 1]) / lp.abs().amax(-1)).min().item() > CLEAR:      # errors scale with the option rows' own scale
+                oi = torch.as_tensor(opts).long()
+                lp, nn = lg[:, -1].to(F32)[:, oi], row_norms(o.w["lm_head.weight"])
+                v2, i2 = lp.topk(2, dim=-1)
+                E = REL_TOL * (lg[:, -1].to(F32) / nn).abs().amax(-1)
+                if ((v2[:, 0] - v2[:, 1]) / (E * (nn[oi][i2[:, 0]] + nn[oi][i2[:, 1]]))).min().item() > 1.0:   # option gap > their tolerances
                     out["choose_head_seed"] = np.asarray([hs], dtype=np.int32)
                     out["choose_idx"] = np.asarray(orc.choose_from(o, proc(TINY_PROMPTS), opts), dtype=np.int32)
                     print("  choose: head_seed", hs, out["choose_idx"].tolist(), flush=True)
@@ -212,11 +232,11 @@ def full():
     cfg, o, base = _full_oracle()
     ip = Phi3VProcessor(None).img_processor
     ids = np.random.default_rng(0).integers(3, 32000, (1, 128)).astype(np.int64)
-    Prefilled.clear = 4 * REL_TOL_FULL
     print("c1", flush=True)
     r1 = Prefilled(o, {"input_ids": ids}, 8, tag="c1")
-    hs, (res,) = search_head([r1], base, 8, min_distinct=3)
-    out = dict(COMMON_FULL, ids=ids)
+    r1.rel_tol = REL_TOL_SHORT
+    hs, (res,) = search_head([r1], base, C1_STEPS, min_distinct=2)
+    out = dict(COMMON_SHORT, ids=ids)
     pack("", hs, res, out)
     np.savez_compressed(os.path.join(HERE, "c1_oracle.npz"), **out)
     del r1
@@ -224,16 +244,19 @@ def full():
     share = c4_share(ip)
     reqs = [Prefilled(o, {k: (torch.from_numpy(v) if k == "pixel_values" else v) for k, v in r.items()}, 4, tag=f"c4r{i}")
             for i, r in enumerate(share)]
+    for r, rq in zip(reqs, share):
+        r.rel_tol = REL_TOL_LONG if "pixel_values" in rq else REL_TOL_SHORT
     hs, (res,) = search_head(reqs[:1], base, 4, min_distinct=2)
-    out = dict(COMMON_FULL, n_ids=np.asarray([reqs[0].S], dtype=np.int32))
+    out = dict(COMMON_LONG, n_ids=np.asarray([reqs[0].S], dtype=np.int32))
     pack("", hs, res, out)
     np.savez_compressed(os.path.join(HERE, "c2_oracle.npz"), **out)
     hs, results = search_head(reqs, base, 4, need="prefill")
-    out = dict(COMMON_FULL, n_ids=np.asarray([r.S for r in reqs], dtype=np.int32), head_seed=np.asarray([hs], dtype=np.int32))
+    out = dict(COMMON, rel_tol=np.asarray([r.rel_tol for r in reqs], dtype=np.float32),
+               n_ids=np.asarray([r.S for r in reqs], dtype=np.int32), head_seed=np.asarray([hs], dtype=np.int32))
     out["tokens"] = np.concatenate([r[0].numpy() for r in results]).astype(np.int32)              # [8, 4]
     out["logits_bf16"] = np.concatenate([bits(r[1]) for r in results])                            # [8, 4, V]
     out["margins"] = np.concatenate([r[2].numpy() for r in results]).astype(np.float32)
-    print(f"  c4: head_seed {hs}, clear {(out['margins'] > Prefilled.clear).sum()} of {out['margins'].size}", flush=True)
+    print(f"  c4: head_seed {hs}, clear {(out['margins'] > 1.0).sum()} of {out['margins'].size}", flush=True)
     np.savez_compressed(os.path.join(HERE, "c4_oracle.npz"), **out)
     print("wrote c1 / c2 / c4")
 
@@ -300,22 +323,25 @@ def c5():
     try:
         ip = Phi3VProcessor(None).img_processor
         inp = vqa_request(ip, 0)
-        Prefilled.clear = 4 * REL_TOL_FULL
         r = Prefilled(o, {k: (torch.from_numpy(v) if k == "pixel_values" else v) for k, v in inp.items()}, 4, tag="c5")
 
-        def q_head(b, spread, hs):                                    # the peaked head goes through the weight quantiser too
-            w8, sc = quantize_fp8_rows(peaked_lm_head(b.to(BF16), spread, hs))
-            return w8.view(torch.float8_e4m3fn).to(F32) * sc[:, None]
         global peaked_lm_head
         plain = peaked_lm_head
+
+        def q_head(b, spread, hs):                                    # the peaked head goes through the weight quantiser too
+            w8, sc = quantize_fp8_rows(plain(b.to(BF16), spread, hs))
+            return w8.view(torch.float8_e4m3fn).to(F32) * sc[:, None]
+        r.rel_tol = REL_TOL_C5
         peaked_lm_head = q_head
         try:
-            hs, (res,) = search_head([r], base, 4, min_distinct=2)
+            # W8A8 noise is large (REL_TOL_C5): an all-clear run is out of reach -- the first step must be clear, the decode
+            # steps are taken as they come and the test asserts the tokens of the clear ones
+            hs, (res,) = search_head([r], base, 4, need="prefill")
         finally:
             peaked_lm_head = plain
     finally:
         orc.OracleKVCache = orig
-    out = dict(COMMON_FULL, n_ids=np.asarray([r.S], dtype=np.int32))
+    out = dict(COMMON, rel_tol=np.asarray([REL_TOL_C5], dtype=np.float32), n_ids=np.asarray([r.S], dtype=np.int32))
     pack("", hs, res, out)
     np.savez_compressed(os.path.join(HERE, "c5_oracle.npz"), **out)
     print("wrote c5_oracle.npz")

@@ -128,6 +128,11 @@ def test_shim_exports_reference_api():
            "load": ["blind_model", "quantize_model", "quantize_cache", "use_adapter", "kwargs"]}
     for fn, params in ref.items():
         assert list(inspect.signature(getattr(m, fn)).parameters) == params, fn
+    bp = inspect.signature(m.benchmark).parameters                      # reference: benchmark(blind_model=False, json_path='benchmark.json')
+    assert list(bp)[:2] == ["blind_model", "json_path"] and bp["json_path"].default == "benchmark.json"
+    assert all(p.kind is inspect.Parameter.KEYWORD_ONLY for n, p in bp.items() if n not in ("blind_model", "json_path"))
+    from phi_3_vision_mlx_amd.api import BENCHMARK_BATCH
+    assert len(BENCHMARK_BATCH) == 15                                    # 16 literals, two fused by the reference's missing comma
     assert inspect.signature(m.generate).parameters["max_tokens"].default == 512
     assert inspect.signature(m.constrain).parameters["constraints"].default == [(0, "\nThe"), (100, " The correct answer is"), "ABCDE"]
     assert m.ID_EOS == 32007 and m.ID_ASS == 32001

@@ -518,64 +518,6 @@ def test_lora_down_up(ops, M, K, N, r):
     close(ops.lora_up(y.cuda(), t, b.cuda(), scale, EPI_SILU_MUL), act * up, rtol=2 ** -6, atol=2e-2)
 
 
-@pytest.mark.parametrize("past", [10, 300, 1023])
-def test_fused_qkv_attention_decode_equals_separate_launches(ops, past):
-    """p3v_qkv_attention_decode (ONE launch, producer flags inside the launch) must equal RMSNorm+qkv GEMV followed by
-    p3v_attention_decode bit for bit: same arithmetic, only the synchronisation differs.  Repeated to shake out races."""
-    from phi_3_vision_mlx_amd.ops import EPI_NONE
-    nh, hd, H = 32, 96, 3072
-    T = (past + 1 + 63) // 64 * 64
-    n_split = T // 64
-    x, nw = g((1, H), 200), g((H,), 201) * 0.1 + 1
-    wq = g((3 * nh * hd, H), 202, 0.02).cuda()
-    kc, vc = g((1, nh, T, hd), 203), g((1, nh, hd, T), 204)
-    cos_s, sin_s = torch.rand((1, 1, hd // 2), dtype=F32).cuda(), torch.rand((1, 1, hd // 2), dtype=F32).cuda()
-    d_past = torch.tensor([past], dtype=torch.int32).cuda()
-    ws = torch.empty(ops.attention_ws_bytes(1, 1, nh, hd, n_split) // 4, dtype=F32).cuda()
-    cnt = torch.zeros(nh * n_split, dtype=torch.int32).cuda()
-    # reference: two launches
-    k1, v1 = kc.cuda(), vc.cuda()
-    qkv1 = ops.gemv(x.cuda(), wq, EPI_NONE, norm_w=nw.cuda(), norm_eps=1e-5)
-    out1 = torch.empty((1, 1, nh * hd), dtype=BF16).cuda()
-    ops.attention_decode(qkv1, cos_s, sin_s, 1, k1, v1, out1, 1, 1, nh, nh, hd, hd ** -0.5, 0, T, ws, n_split, d_past=d_past, counters=cnt)
-    nf = ops.qkv_attention_decode_flags(3 * nh * hd)
-    for rep in range(6):
-        k2, v2 = kc.cuda(), vc.cuda()
-        qkv2 = torch.zeros_like(qkv1)
-        out2 = torch.zeros_like(out1)
-        flags = torch.zeros(nf, dtype=torch.int32).cuda()
-        ops.qkv_attention_decode(x.cuda(), wq, nw.cuda(), 1e-5, qkv2, cos_s, sin_s, 1, k2, v2, out2, nh, nh, hd, hd ** -0.5, 0, T, ws,
-                                 n_split, cnt, flags, d_past=d_past)
-        torch.cuda.synchronize()
-        assert (flags == 1).all() and (cnt == 0).all()
-        assert torch.equal(qkv2, qkv1) and torch.equal(out2, out1), rep
-        assert torch.equal(k2, k1) and torch.equal(v2, v1)
-
-
-def test_gemv_chain_equals_separate_launches(ops):
-    """p3v_gemv_chain (o_proj -> gate_up -> down -> next qkv in ONE launch, arrival counters between the stages) must equal
-    four p3v_gemv launches bit for bit; repeated to shake out ordering races."""
-    from phi_3_vision_mlx_amd.ops import EPI_NONE, EPI_RESID_BF16, EPI_SILU_MUL
-    H, I = 3072, 8192
-    wo, wgu, wd, wq = g((H, H), 300, 0.02).cuda(), g((2 * I, H), 301, 0.02).cuda(), g((H, I), 302, 0.02).cuda(), g((3 * H, H), 303, 0.02).cuda()
-    n1, n2 = (g((H,), 304) * 0.1 + 1).cuda(), (g((H,), 305) * 0.1 + 1).cuda()
-    o, x0 = g((1, H), 306).cuda(), g((1, H), 307).cuda()
-    # reference: four launches
-    x = ops.gemv(o, wo, EPI_RESID_BF16, resid=x0.clone())
-    a = ops.gemv(x, wgu, EPI_SILU_MUL, norm_w=n1, norm_eps=1e-5)
-    x2 = ops.gemv(a, wd, EPI_RESID_BF16, resid=x)
-    q = ops.gemv(x2, wq, EPI_NONE, norm_w=n2, norm_eps=1e-5)
-    for rep in range(8):
-        xc = x0.clone()
-        ac, qc = torch.zeros_like(a), torch.zeros_like(q)
-        cnt = torch.zeros(4096, dtype=torch.int32).cuda()
-        ops.gemv_chain([(o, wo, EPI_RESID_BF16, xc, None, 0.0, xc), (xc, wgu, EPI_SILU_MUL, None, n1, 1e-5, ac),
-                        (ac, wd, EPI_RESID_BF16, xc, None, 0.0, xc), (xc, wq, EPI_NONE, None, n2, 1e-5, qc)], cnt)
-        torch.cuda.synchronize()
-        assert torch.equal(ac, a), rep
-        assert torch.equal(xc, x2) and torch.equal(qc, q), rep
-        assert cnt.view(4, 1024).sum(1).tolist() == [384, 512, 384, 384]
-
 
 @pytest.mark.parametrize("w,h,kind,seed", [(336, 336, "noise", 0), (640, 480, "gradient", 1), (500, 1000, "noise", 2), (1600, 1200, "noise", 3),
                                           (90, 61, "noise", 4)])

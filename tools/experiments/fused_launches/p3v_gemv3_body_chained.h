@@ -1,5 +1,4 @@
-// Body of the streaming M = 1 GEMV (k_gemv3, p3v_gemv.hip).  (The fused-launch experiments that shared it -- a GEMV chain and
-// a qkv-projection + attention launch, both bit-exact and both slower than separate launches -- live in tools/experiments/.)
+// Body of the streaming M = 1 GEMV (k_gemv3), shared by p3v_gemv.hip and the fused launches of p3v_attention.hip.
 #pragma once
 #include <type_traits>
 
@@ -30,8 +29,36 @@ __device__ __forceinline__ float dot8(u32x4_t w, u32x4_t x, float acc) {
 typedef std::integral_constant<int, 0> IC0;
 typedef std::integral_constant<int, 1> IC1;
 
+// Chained stages inside ONE launch (k_gemv_chain, p3v_gemv.hip).  A stage's workgroups request their first weight
+// stage, THEN wait until the previous stage is complete (16 striped arrival counters, zeroed once per decode step),
+// read x / the residual with cache-bypassing loads, and finally announce their own completion.  Workgroups are
+// dispatched in linear order, so everything a workgroup waits for is resident or done; the wait is bounded anyway.
+constexpr int CHAIN_CNT_STRIDE = 64;   // ints between two arrival counters: separate lines / channels (a single hot line
+                                       // polled by ~800 workgroups while 400 others increment it stalls for tens of us)
+struct ChainSync {
+  const int32_t* wait_cnt;     // 16 counters (one per 256-byte line: CHAIN_CNT_STRIDE ints apart) of the producer stage, or NULL
+  int wait_total;              // number of producer workgroups
+  int32_t* done_cnt;           // 16 counters of this stage
+};
+
+__device__ __forceinline__ u32x4_t ld16_sc1(const void* ptr) {   // issue only: pair with wait_sc1_* before use
+  u32x4_t v;
+  asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(v) : "v"(ptr) : "memory");
+  return v;
+}
+__device__ __forceinline__ uint32_t ld4_sc1(const void* ptr) {
+  return __hip_atomic_load((const uint32_t*)ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st2_sc1(void* ptr, uint32_t lo16) {
+  asm volatile("global_store_short %0, %1, off sc0 sc1" ::"v"(ptr), "v"(lo16) : "memory");
+}
+
+// `done_flag` != NULL (fused launches, p3v_attention.hip): the outputs are stored write-through and the workgroup raises
+// *done_flag once they have been performed, so that a consumer workgroup of the SAME launch may read them.
 template <int MT, int NST, int CH>
-__device__ __forceinline__ void gemv3_body(const GemvP& p, int units_per_wave, int bx, unsigned char* smem, float* red) {
+__device__ __forceinline__ void gemv3_body(const GemvP& p, int units_per_wave, int bx, unsigned char* smem, float* red,
+                                           int32_t* done_flag, const ChainSync* cs = nullptr) {
+  const bool chained = cs != nullptr;
   constexpr int CHUNKS = NST * CH * 64;                 // 16-byte chunks per row (K = 8 * CHUNKS)
   constexpr int XC = (CHUNKS + 255) / 256;              // x chunks per thread
   u32x4_t* xs = (u32x4_t*)smem;                         // [MT][CHUNKS] bf16 x (normalised)
@@ -42,13 +69,15 @@ __device__ __forceinline__ void gemv3_body(const GemvP& p, int units_per_wave, i
   const int u_end = min(p.units, u_begin + units_per_wave);
   const int n_st = (u_end - u_begin) * NST;
 
-  // ---- 1. x / norm-weight loads (oldest in the queue)
+  // ---- 1. x / norm-weight loads (oldest in the queue; in a chain x waits for the producer stage, see below)
   u32x4_t xv[MT][XC], gv[XC];
 #pragma unroll
   for (int k = 0; k < XC; ++k) {
     const int c = min(tid + k * 256, CHUNKS - 1);
+    if (!chained) {
 #pragma unroll
-    for (int m = 0; m < MT; ++m) xv[m][k] = ((const u32x4_t*)(p.x + (size_t)min(m, p.M - 1) * (CHUNKS * 8)))[c];
+      for (int m = 0; m < MT; ++m) xv[m][k] = ((const u32x4_t*)(p.x + (size_t)min(m, p.M - 1) * (CHUNKS * 8)))[c];
+    }
     gv[k] = p.norm_w ? ((const u32x4_t*)p.norm_w)[c] : (u32x4_t){0, 0, 0, 0};
   }
 
@@ -70,10 +99,40 @@ __device__ __forceinline__ void gemv3_body(const GemvP& p, int units_per_wave, i
 #pragma unroll
     for (int m = 0; m < MT; ++m) {                       // 4-byte aligned: r0 = 2u is even, N is even on this path
       const bf16_t* rp = p.resid + (size_t)min(m, p.M - 1) * p.N + 2 * u;
-      rbuf[buf][m] = !has_res ? 0u : *(const uint32_t*)rp;
+      rbuf[buf][m] = !has_res ? 0u : (chained ? (gs == 0 ? 0u : ld4_sc1(rp)) : *(const uint32_t*)rp);
     }
   };
   if (n_st > 0) issue(0, IC0{});
+
+  if (chained) {
+    // ---- 2b. wait for the producer stage, then fetch x (and the first residual) past the caches
+    if (cs->wait_cnt) {
+      if (tid < 64) {
+        for (unsigned spins = 0; spins < (1u << 20); ++spins) {
+          const int v = lane < 16 ? __hip_atomic_load(cs->wait_cnt + lane * CHAIN_CNT_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+          if (wave_sum((float)v) >= (float)cs->wait_total) break;
+          __builtin_amdgcn_s_sleep(32);                        // ~1 us between polls
+        }
+      }
+      __syncthreads();
+    }
+#pragma unroll
+    for (int k = 0; k < XC; ++k) {
+      const int c = min(tid + k * 256, CHUNKS - 1);
+#pragma unroll
+      for (int m = 0; m < MT; ++m) xv[m][k] = ld16_sc1((const u32x4_t*)(p.x + (size_t)min(m, p.M - 1) * (CHUNKS * 8)) + c);
+    }
+    if (has_res && n_st > 0) {
+#pragma unroll
+      for (int m = 0; m < MT; ++m) rbuf[0][m] = ld4_sc1(p.resid + (size_t)min(m, p.M - 1) * p.N + 2 * min(u_begin, p.units - 1));
+    }
+    // the asm loads are invisible to hipcc's waitcnt bookkeeping: wait here, and tie every x register to the wait
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int k = 0; k < XC; ++k)
+#pragma unroll
+      for (int m = 0; m < MT; ++m) asm volatile("" : "+v"(xv[m][k][0]), "+v"(xv[m][k][1]), "+v"(xv[m][k][2]), "+v"(xv[m][k][3]));
+  }
 
   // ---- 3. RMSNorm prologue (waits for the x loads only) -> LDS
 #pragma unroll
@@ -140,7 +199,8 @@ __device__ __forceinline__ void gemv3_body(const GemvP& p, int units_per_wave, i
               const float g = bf16_round(a0[m]), up = bf16_round(a1[m]);
               const float sg = bf16_round(g * bf16_round(1.f / (1.f + __expf(-g))));
               bf16_t* dst = (bf16_t*)p.out + (size_t)m * p.N + u;
-              *dst = f32_to_bf16(sg * up);
+              if (chained) st2_sc1(dst, (uint32_t)f32_to_bf16(sg * up));
+              else *dst = f32_to_bf16(sg * up);
             } else if (p.epi == P3V_EPI_F32) {
               ((float*)p.out)[(size_t)m * p.N + 2 * u] = a0[m];
               ((float*)p.out)[(size_t)m * p.N + 2 * u + 1] = a1[m];
@@ -148,7 +208,8 @@ __device__ __forceinline__ void gemv3_body(const GemvP& p, int units_per_wave, i
               float v0 = a0[m], v1 = a1[m];
               if (has_res) { v0 = bf16lo(rbuf[buf][m]) + bf16_round(v0); v1 = bf16hi(rbuf[buf][m]) + bf16_round(v1); }
               uint32_t* dst = (uint32_t*)((bf16_t*)p.out + (size_t)m * p.N + 2 * u);
-              *dst = pack_bf16x2(v0, v1);
+              if (done_flag || chained) __hip_atomic_store(dst, pack_bf16x2(v0, v1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              else *dst = pack_bf16x2(v0, v1);
             }
           }
         }
@@ -171,5 +232,13 @@ __device__ __forceinline__ void gemv3_body(const GemvP& p, int units_per_wave, i
     compute(gs + 1, IC1{});
   } else if (gs < n_st) {
     compute(gs, IC0{});
+  }
+  if (done_flag || chained) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this thread's output stores have been performed
+    __syncthreads();
+    if (tid == 0) {
+      if (done_flag) __hip_atomic_store(done_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (chained) __hip_atomic_fetch_add(cs->done_cnt + (bx & 15) * CHAIN_CNT_STRIDE, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
 }
