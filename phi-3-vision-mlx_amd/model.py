@@ -333,6 +333,60 @@ class Phi3VModel:
             st.pad_len = torch.as_tensor((m == 0).sum(axis=1).astype(np.int32)).to(self.device)
         return st
 
+    # ------------------------------------------------------------------ slot state of the continuous-batching engine
+    @_on_device
+    def new_slot_state(self, slots, window):
+        """A cache of `slots` batch rows and `window` columns that is not tied to one prompt batch (engine.py): every row
+        has its OWN left padding and position table, so a request can be prefilled into a free row while the other rows
+        are mid-generation.  All rows start empty (pad_len = window: every key masked).  window <= the original context
+        (4096): the short RoPE factors, which is what each request alone would pick (phi.py:492)."""
+        if window > self.cfg.original_max_position_embeddings:
+            raise ValueError("the slot window must stay inside the short-RoPE regime")
+        st = self._new_state(slots, 0, window, None, None)
+        st.pad_len = torch.full((slots,), window, dtype=I32, device=self.device)
+        st.slots = True
+        return st
+
+    @_on_device
+    def prefill_slot(self, st, row, inputs):
+        """Prefill one request (a B = 1 `processor(...)` result) into batch row `row` of a slot state so that its LAST prompt
+        token sits in column st.offset - 1: left padding pad = st.offset - S, position ids 0..S-1 from column pad on.
+        Keys left of `pad` (stale rows of an earlier occupant) are masked by pad_len.  Returns the first greedy token
+        (int32 [1, 1] on the device).  The row computes what a B = 1 run of the request computes (pad invariance)."""
+        cfg = self.cfg
+        S = int(np.asarray(inputs["input_ids"]).shape[-1])
+        pad = st.offset - S
+        if pad < 0:
+            raise ValueError(f"prompt of {S} tokens does not fit left of column {st.offset}")
+        half = self.hd // 2
+        inv_freq = 1.0 / (torch.tensor(cfg.rope_scaling["short_factor"], dtype=F32)
+                          * (torch.tensor(float(cfg.rope_theta), dtype=F32) ** (torch.arange(0, self.hd, 2, dtype=F32) / self.hd)))
+        pos = (torch.arange(st.T, dtype=F32) - pad).clamp_min(0).to(self.device)
+        cos, sin = ops.rope_table(pos, inv_freq.to(self.device), rope_scaling_factor(cfg))
+        st.cos[row].copy_(cos.view(st.T, half)), st.sin[row].copy_(sin.view(st.T, half))
+        st.pad_len[row:row + 1].fill_(pad)
+        view = CacheState.__new__(CacheState)                   # this row as a one-row cache at offset `pad`
+        view.__dict__.update(B=1, S=S, max_tokens=st.max_tokens, T=st.T, Tp=st.Tp, quantized=False, offset=pad, graphs={}, epoch=self.epoch,
+                             k=st.k[:, row:row + 1], v=st.v[:, row:row + 1], cos=st.cos[row:row + 1], sin=st.sin[row:row + 1],
+                             pad_len=st.pad_len[row:row + 1])
+        kw = {k: v for k, v in inputs.items() if k in ("pixel_values", "image_sizes", "positions")}
+        logits, _ = self(input_ids=inputs["input_ids"], cache=[LayerCache(view, i) for i in range(cfg.num_hidden_layers)],
+                         full_logits=False, **kw)
+        assert view.offset == st.offset
+        return ops.argmax(logits[:, -1, :].contiguous())[:, None]
+
+    @_on_device
+    def decode_graph(self, st):
+        """The captured greedy step of a state (built on first use): its `tok` / `next_tok` / `d_past` device buffers."""
+        if st.epoch != self.epoch:
+            st.graphs.clear()
+            st.epoch = self.epoch
+        g = st.graphs.get("greedy")
+        if g is None:
+            g = st.graphs["greedy"] = self._build_decode_graph(st)
+            g["host_tok"] = None
+        return g
+
     # ------------------------------------------------------------------ decoder stack
     def _alloc_bufs(self, B, L):
         cfg = self.cfg
