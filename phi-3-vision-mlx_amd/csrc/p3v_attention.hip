@@ -786,6 +786,14 @@ __device__ __forceinline__ void split_merge(const float* base0, bf16_t* out0, si
   for (int i = t; i < n_split - 1; i += NT) __hip_atomic_store(flags + i, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
 }
 
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pack_f16x2(float lo, float hi) {
+  const f16x2_t r = {(_Float16)lo, (_Float16)hi};
+  return __builtin_bit_cast(uint32_t, r);
+}
+
 // operands of one rotated 8-wide chunk, split into a load half and a math half so that the loads can be issued
 // ahead of other memory traffic and consumed later
 struct RopeRaw { u32x4_t x0, x1; float4 c0, c1, s0, s1; };
@@ -799,6 +807,7 @@ __device__ __forceinline__ RopeRaw rope_fetch(const bf16_t* head_row, int c, con
   r.s0 = *(const float4*)(st + tb); r.s1 = *(const float4*)(st + tb + 4);
   return r;
 }
+template <bool F16 = false>
 __device__ __forceinline__ u32x4_t rope_apply(const RopeRaw& r, int c, unsigned sh16 = 16, unsigned himask = 0xffff0000u) {
   auto bf16lo = [&](unsigned x) { return __builtin_bit_cast(float, x << sh16); };
   auto bf16hi = [&](unsigned x) { return __builtin_bit_cast(float, x & himask); };
@@ -807,12 +816,15 @@ __device__ __forceinline__ u32x4_t rope_apply(const RopeRaw& r, int c, unsigned 
   const float sg = c < 6 ? -1.f : 1.f;
   u32x4_t o;
 #pragma unroll
-  for (int j = 0; j < 4; ++j)
-    o[j] = pack_bf16x2(bf16lo(r.x0[j]) * cs[2 * j] + sg * bf16lo(r.x1[j]) * sn[2 * j],
-                       bf16hi(r.x0[j]) * cs[2 * j + 1] + sg * bf16hi(r.x1[j]) * sn[2 * j + 1]);
+  for (int j = 0; j < 4; ++j) {
+    const float v0 = bf16lo(r.x0[j]) * cs[2 * j] + sg * bf16lo(r.x1[j]) * sn[2 * j];
+    const float v1 = bf16hi(r.x0[j]) * cs[2 * j + 1] + sg * bf16hi(r.x1[j]) * sn[2 * j + 1];
+    o[j] = F16 ? pack_f16x2(v0, v1) : pack_bf16x2(v0, v1);
+  }
   return o;
 }
 
+template <bool F16 = false>
 __device__ __forceinline__ u32x4_t rope_chunk(const bf16_t* head_row, int c, const float* ct, const float* st) {
   // rotated 8-wide chunk c (0..11) of a 96-wide head: low half pairs with +48, high half with -48
   constexpr int HALF = 48;
@@ -827,9 +839,11 @@ __device__ __forceinline__ u32x4_t rope_chunk(const bf16_t* head_row, int c, con
   const float sg = lo ? -1.f : 1.f;
   u32x4_t o;
 #pragma unroll
-  for (int j = 0; j < 4; ++j)
-    o[j] = pack_bf16x2(bf16lo(x0[j]) * cs[2 * j] + sg * bf16lo(x1[j]) * sn[2 * j],
-                       bf16hi(x0[j]) * cs[2 * j + 1] + sg * bf16hi(x1[j]) * sn[2 * j + 1]);
+  for (int j = 0; j < 4; ++j) {
+    const float v0 = bf16lo(x0[j]) * cs[2 * j] + sg * bf16lo(x1[j]) * sn[2 * j];
+    const float v1 = bf16hi(x0[j]) * cs[2 * j + 1] + sg * bf16hi(x1[j]) * sn[2 * j + 1];
+    o[j] = F16 ? pack_f16x2(v0, v1) : pack_bf16x2(v0, v1);
+  }
   return o;
 }
 
@@ -1453,21 +1467,27 @@ struct AttnDecQ8P {
   int grp, grp_magic;          // heads per kv head and ceil(2^16 / grp) (k_attn_decode_q8s)
 };
 
-// 16 offset-binary bytes -> 16 bf16 holding the RAW byte values 0..255 (exact in bf16: 8 significant bits).
-// The -128 offset is not applied per element: it is folded out of the dot products,
-//   sum_d q[d]*(u-128) = sum_d q[d]*u - 128*sum_d q[d]     and     sum_t P[t]*(u-128) = sum_t P[t]*u - 128*sum_t P[t],
-// so dequantisation costs one v_cvt_f32_ubyteN per value plus the pair-wise bf16 pack.
-__device__ __forceinline__ void u8x16_to_bf16(u32x4_t w, u32x4_t& lo, u32x4_t& hi) {
-  float f[16];
+// 16 offset-binary bytes -> 16 FP16 values 1024 + byte: a byte dropped into the mantissa of 0x6400 (= 1024.0) is exactly
+// 1024 + u, so ONE v_perm_b32 converts TWO codes (the first version went through v_cvt_f32_ubyteN + a bf16 pack: three VALU
+// instructions per two codes, and that conversion -- not the bytes -- bounded the int8 decode).  Q and P are rounded to
+// fp16 (11 significant bits; bf16 has 8) and the products run on the fp16 MFMA at the bf16 rate.  Neither offset is applied
+// per element; both fold out of the dot products:
+//   sum_d q[d]*(u-128) = sum_d q[d]*(1024+u) - 1152*sum_d q[d]     and     sum_t P[t]*(u-128) = sum_t P[t]*(1024+u) - 1152*sum_t P[t].
+#define Q8_OFF 1152.f
+__device__ __forceinline__ float f16_round(float x) { return (float)(_Float16)x; }
+__device__ __forceinline__ float f16lo(uint32_t w) { return (float)__builtin_bit_cast(f16x2_t, w)[0]; }
+__device__ __forceinline__ float f16hi(uint32_t w) { return (float)__builtin_bit_cast(f16x2_t, w)[1]; }
+__device__ __forceinline__ uint32_t code_pair_f16(int a, int b) { return (0x6400u | (uint32_t)a) | ((0x6400u | (uint32_t)b) << 16); }
+__device__ __forceinline__ uint16_t code_f16(int a) { return (uint16_t)(0x6400u | (uint32_t)a); }
+__device__ __forceinline__ void u8x16_to_f16(u32x4_t w, u32x4_t& lo, u32x4_t& hi) {
+  uint32_t a[4], b[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    asm("v_cvt_f32_ubyte0 %0, %1" : "=v"(f[4 * j + 0]) : "v"(w[j]));
-    asm("v_cvt_f32_ubyte1 %0, %1" : "=v"(f[4 * j + 1]) : "v"(w[j]));
-    asm("v_cvt_f32_ubyte2 %0, %1" : "=v"(f[4 * j + 2]) : "v"(w[j]));
-    asm("v_cvt_f32_ubyte3 %0, %1" : "=v"(f[4 * j + 3]) : "v"(w[j]));
+    a[j] = __builtin_amdgcn_perm(0x64646464u, w[j], 0x04010400u);     // bytes {b0, 0x64, b1, 0x64}: codes 4j, 4j+1
+    b[j] = __builtin_amdgcn_perm(0x64646464u, w[j], 0x04030402u);     // bytes {b2, 0x64, b3, 0x64}: codes 4j+2, 4j+3
   }
-#pragma unroll
-  for (int j = 0; j < 4; ++j) { lo[j] = pack_bf16x2(f[2 * j], f[2 * j + 1]); hi[j] = pack_bf16x2(f[8 + 2 * j], f[9 + 2 * j]); }
+  lo = (u32x4_t){a[0], b[0], a[1], b[1]};
+  hi = (u32x4_t){a[2], b[2], a[3], b[3]};
 }
 
 __global__ void __launch_bounds__(64) k_attn_decode_q8(AttnDecQ8P p) {
@@ -1536,9 +1556,9 @@ __global__ void __launch_bounds__(64) k_attn_decode_q8(AttnDecQ8P p) {
       const float vmx = wave_max(fmaxf(fabsf(va), fabsf(vb)));
       const float sv = vmx > 0.f ? vmx / 127.f : 1.f, invv = 1.f / sv;
       const int qva = (int)rintf(va * invv) + 128, qvb = (int)rintf(vb * invv) + 128;
-      if (lane < 48) *(uint32_t*)(Ks + (t - kv0) * KSTR + 4 * lane) = pack_bf16x2((float)qa, (float)qb);
-      *(bf16_t*)(Vt + lane * VSTR + (t - kv0) * 2) = f32_to_bf16((float)qva);
-      if (lane < 32) *(bf16_t*)(Vt + (lane + 64) * VSTR + (t - kv0) * 2) = f32_to_bf16((float)qvb);
+      if (lane < 48) *(uint32_t*)(Ks + (t - kv0) * KSTR + 4 * lane) = code_pair_f16(qa, qb);
+      *(uint16_t*)(Vt + lane * VSTR + (t - kv0) * 2) = code_f16(qva);
+      if (lane < 32) *(uint16_t*)(Vt + (lane + 64) * VSTR + (t - kv0) * 2) = code_f16(qvb);
       if (lane == 0) { ksl[t - kv0] = s; vsl[t - kv0] = sv; }
       if (kv_writer) {
         if (lane < 48) *(uint16_t*)(kc + (size_t)t * HD + 2 * lane) = (uint16_t)(qa | (qb << 8));
@@ -1553,28 +1573,28 @@ __global__ void __launch_bounds__(64) k_attn_decode_q8(AttnDecQ8P p) {
 
   const bool qvalid = qi < p.L;
   const int qpos = past + qi;
-  bf16x8_t qf[NKS];
+  f16x8_t qf[NKS];
   {
     const bf16_t* qrow = p.qkv + ((size_t)b * p.L + (qvalid ? qi : 0)) * row_w + head * HD;
     const float* ct = cos_b + (qvalid ? qi : 0) * (HD / 2);
     const float* st = sin_b + (qvalid ? qi : 0) * (HD / 2);
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) {
-      u32x4_t v = rope_chunk(qrow, 4 * ks + g, ct, st);
+      u32x4_t v = rope_chunk<true>(qrow, 4 * ks + g, ct, st);
       if (!qvalid) v = (u32x4_t){0, 0, 0, 0};
-      qf[ks] = __builtin_bit_cast(bf16x8_t, v);
+      qf[ks] = __builtin_bit_cast(f16x8_t, v);
     }
   }
-  // 128 * sum_d q[d] of this lane's query (the folded K offset): the lane holds 3 x 8 of the 96 values
+  // 1152 * sum_d q[d] of this lane's query (the folded K offsets): the lane holds 3 x 8 of the 96 values
   float qoff = 0.f;
 #pragma unroll
   for (int ks = 0; ks < NKS; ++ks) {
     const u32x4_t qw = __builtin_bit_cast(u32x4_t, qf[ks]);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) qoff += bf16lo(qw[j]) + bf16hi(qw[j]);
+    for (int j = 0; j < 4; ++j) qoff += f16lo(qw[j]) + f16hi(qw[j]);
   }
   qoff = rows_sum(qoff);
-  qoff *= 128.f;
+  qoff *= Q8_OFF;
   float m_run = -INFINITY, l_run = 0.f, p_run = 0.f;          // p_run = sum_t P'[t] (the folded V offset)
   f32x4_t o[NDT];
 #pragma unroll
@@ -1582,13 +1602,13 @@ __global__ void __launch_bounds__(64) k_attn_decode_q8(AttnDecQ8P p) {
 
   for (int kv0 = kv_begin; kv0 < kv_end; kv0 += TK) {
 #pragma unroll
-    for (int it = 0; it < NLD; ++it) {                        // dequantise to the bf16 LDS images of the bf16 kernel
+    for (int it = 0; it < NLD; ++it) {                        // bytes -> fp16 (1024 + code) LDS images, laid out as the bf16 kernel's
       const int i = it * 64 + lane;
       u32x4_t lo, hi;
-      u8x16_to_bf16(kreg[it], lo, hi);
+      u8x16_to_f16(kreg[it], lo, hi);
       *(u32x4_t*)(Ks + (i / 6) * KSTR + (i % 6) * 32) = lo;
       *(u32x4_t*)(Ks + (i / 6) * KSTR + (i % 6) * 32 + 16) = hi;
-      u8x16_to_bf16(vreg[it], lo, hi);
+      u8x16_to_f16(vreg[it], lo, hi);
       *(u32x4_t*)(Vt + (i >> 2) * VSTR + (i & 3) * 32) = lo;
       *(u32x4_t*)(Vt + (i >> 2) * VSTR + (i & 3) * 32 + 16) = hi;
     }
@@ -1607,8 +1627,8 @@ __global__ void __launch_bounds__(64) k_attn_decode_q8(AttnDecQ8P p) {
       s[st] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int ks = 0; ks < NKS; ++ks) {
-        const bf16x8_t kf = *(const bf16x8_t*)(Ks + (16 * st + qi) * KSTR + (32 * ks + 8 * g) * 2);
-        s[st] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], s[st], 0, 0, 0);
+        const f16x8_t kf = *(const f16x8_t*)(Ks + (16 * st + qi) * KSTR + (32 * ks + 8 * g) * 2);
+        s[st] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[ks], s[st], 0, 0, 0);
       }
     }
     float m_t = -INFINITY;
@@ -1637,7 +1657,7 @@ __global__ void __launch_bounds__(64) k_attn_decode_q8(AttnDecQ8P p) {
       for (int r = 0; r < 4; ++r) {
         const float e = __builtin_amdgcn_exp2f(s[st][r] - m_use);
         l_t += e;
-        const float pv = bf16_round(e > 0.f ? e * vsv[st][r] : 0.f);   // V scale folded into P (masked keys stay exactly 0)
+        const float pv = f16_round(e > 0.f ? e * vsv[st][r] : 0.f);    // V scale folded into P (masked keys stay exactly 0)
         s[st][r] = pv;
         p_t += pv;
       }
@@ -1651,24 +1671,24 @@ __global__ void __launch_bounds__(64) k_attn_decode_q8(AttnDecQ8P p) {
 #pragma unroll
     for (int st = 0; st < 2; ++st) {
       u32x4_t pw;
-      pw[0] = pack_bf16x2(s[2 * st][0], s[2 * st][1]);
-      pw[1] = pack_bf16x2(s[2 * st][2], s[2 * st][3]);
-      pw[2] = pack_bf16x2(s[2 * st + 1][0], s[2 * st + 1][1]);
-      pw[3] = pack_bf16x2(s[2 * st + 1][2], s[2 * st + 1][3]);
-      const bf16x8_t pf = __builtin_bit_cast(bf16x8_t, pw);
+      pw[0] = pack_f16x2(s[2 * st][0], s[2 * st][1]);
+      pw[1] = pack_f16x2(s[2 * st][2], s[2 * st][3]);
+      pw[2] = pack_f16x2(s[2 * st + 1][0], s[2 * st + 1][1]);
+      pw[3] = pack_f16x2(s[2 * st + 1][2], s[2 * st + 1][3]);
+      const f16x8_t pf = __builtin_bit_cast(f16x8_t, pw);
 #pragma unroll
       for (int d = 0; d < NDT; ++d) {
         const unsigned char* vr = Vt + (16 * d + qi) * VSTR + (32 * st + 4 * g) * 2;
         const u32x2_t a0 = *(const u32x2_t*)vr, a1 = *(const u32x2_t*)(vr + 32);
         const u32x4_t aw = {a0[0], a0[1], a1[0], a1[1]};
-        o[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, aw), pf, o[d], 0, 0, 0);
+        o[d] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, aw), pf, o[d], 0, 0, 0);
       }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   }
   if (!qvalid) return;
   float* w = p.ws + ((((size_t)b * p.nh + head) * p.n_split + blockIdx.x) * 16 + qi) * (HD + 2);
-  const float voff = 128.f * p_run;
+  const float voff = Q8_OFF * p_run;
 #pragma unroll
   for (int d = 0; d < NDT; ++d) *(f32x4_t*)(w + 16 * d + 4 * g) = o[d] - voff;
   if (g == 0) { w[HD] = m_run; w[HD + 1] = l_run; }
@@ -1678,7 +1698,7 @@ __global__ void __launch_bounds__(64) k_attn_decode_q8(AttnDecQ8P p) {
 // 16w..16w+15 end to end).  Per wave the K slice is 16 rows x 96 bytes and the V^T slice 96 rows x 16 bytes: 4 loads
 // per lane, converted to the RAW byte values as bf16 (exact) and written to the same swizzled LDS images as the bf16
 // kernel, so the MFMA part is identical; scales and the -128 offsets are applied to the 4 accumulator values per lane
-// (see u8x16_to_bf16).  The L new rows are rotated exactly, parked in LDS, quantised one row per wave (the step
+// (see u8x16_to_f16).  The L new rows are rotated exactly, parked in LDS, quantised one row per wave (the step
 // attends over the values it stores, phi.py:545-546) and patched into the tile + cache.
 __global__ void __launch_bounds__(256) k_attn_decode_q8s(AttnDecQ8P p) {
   constexpr int TK = 64, WK = 16, HD = 96, KROW = HD * 2, VROW = WK * 2, NKS = 3, NDT = 6, CPR = 12;
@@ -1730,7 +1750,7 @@ __global__ void __launch_bounds__(256) k_attn_decode_q8s(AttnDecQ8P p) {
       const bf16_t* krow = row + (p.nh + kvh) * HD;
       kraw.x0 = *(const u32x4_t*)(krow + tc * 8);
       kraw.x1 = *(const u32x4_t*)(krow + (tc < 6 ? tc * 8 + 48 : tc * 8 - 48));
-      qv = rope_apply(qraw, tc);
+      qv = rope_apply<true>(qraw, tc);                         // Q: fp16 (MFMA operand); K: the exact bf16 row for the quantiser
       *(u32x4_t*)(Kx + tr * KROW + tc * 16) = rope_apply(kraw, tc);
     }
     *(u32x4_t*)(Qs + tr * KROW + ((tc ^ ((tr >> 2) & 3)) << 4)) = qv;
@@ -1749,13 +1769,13 @@ __global__ void __launch_bounds__(256) k_attn_decode_q8s(AttnDecQ8P p) {
     u32x4_t lo, hi;
     auto put_k = [&](int i, u32x4_t w) {                       // 16-byte chunk i of the slice: row i/6, values 16*(i%6)..+16
       const int row = i / 6, c2 = (i - row * 6) * 2, sw = (row >> 2) & 3;
-      u8x16_to_bf16(w, lo, hi);
+      u8x16_to_f16(w, lo, hi);
       *(u32x4_t*)(wreg + row * KROW + ((c2 ^ sw) << 4)) = lo;
       *(u32x4_t*)(wreg + row * KROW + (((c2 + 1) ^ sw) << 4)) = hi;
     };
     auto put_v = [&](int d, u32x4_t w) {                       // row d: 16 keys
       const int sw = (d >> 3) & 1;
-      u8x16_to_bf16(w, lo, hi);
+      u8x16_to_f16(w, lo, hi);
       *(u32x4_t*)(wreg + KS_BYTES + d * VROW + (sw << 4)) = lo;
       *(u32x4_t*)(wreg + KS_BYTES + d * VROW + ((1 ^ sw) << 4)) = hi;
     };
@@ -1802,10 +1822,10 @@ __global__ void __launch_bounds__(256) k_attn_decode_q8s(AttnDecQ8P p) {
         unsigned char* dst = KV + (rr >> 4) * WREG;
         const int row = rr & 15, kk = rr & 15;
         if (lane < 48)
-          *(uint32_t*)(dst + row * KROW + ((((lane >> 2)) ^ ((row >> 2) & 3)) << 4) + (lane & 3) * 4) = pack_bf16x2((float)qa, (float)qb);
-        *(bf16_t*)(dst + KS_BYTES + lane * VROW + (((kk >> 3) ^ ((lane >> 3) & 1)) << 4) + (kk & 7) * 2) = f32_to_bf16((float)qva);
+          *(uint32_t*)(dst + row * KROW + ((((lane >> 2)) ^ ((row >> 2) & 3)) << 4) + (lane & 3) * 4) = code_pair_f16(qa, qb);
+        *(uint16_t*)(dst + KS_BYTES + lane * VROW + (((kk >> 3) ^ ((lane >> 3) & 1)) << 4) + (kk & 7) * 2) = code_f16(qva);
         if (lane < 32)
-          *(bf16_t*)(dst + KS_BYTES + (lane + 64) * VROW + (((kk >> 3) ^ (((lane + 64) >> 3) & 1)) << 4) + (kk & 7) * 2) = f32_to_bf16((float)qvb);
+          *(uint16_t*)(dst + KS_BYTES + (lane + 64) * VROW + (((kk >> 3) ^ (((lane + 64) >> 3) & 1)) << 4) + (kk & 7) * 2) = code_f16(qvb);
         if (lane == 0) { ksl[rr] = sk; vsl[rr] = sv; }
         if (kv_writer) {
           if (lane < 48) *(uint16_t*)(kc + (size_t)t * HD + 2 * lane) = (uint16_t)(qa | (qb << 8));
@@ -1816,22 +1836,22 @@ __global__ void __launch_bounds__(256) k_attn_decode_q8s(AttnDecQ8P p) {
       }
       __syncthreads();
     }
-    bf16x8_t qf[NKS];
-    float qoff = 0.f;                                          // 128 * sum_d q[d] of this lane's query (the folded K offset)
+    f16x8_t qf[NKS];
+    float qoff = 0.f;                                          // 1152 * sum_d q[d] of this lane's query (the folded K offsets)
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) {
-      qf[ks] = *(const bf16x8_t*)(Qs + k_rd + ks * 64);
+      qf[ks] = *(const f16x8_t*)(Qs + k_rd + ks * 64);
       const u32x4_t qw = __builtin_bit_cast(u32x4_t, qf[ks]);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) qoff += bf16lo(qw[j]) + bf16hi(qw[j]);
+      for (int j = 0; j < 4; ++j) qoff += f16lo(qw[j]) + f16hi(qw[j]);
     }
-    qoff = 128.f * rows_sum(qoff);
+    qoff = Q8_OFF * rows_sum(qoff);
 
     f32x4_t s = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) {
-      const bf16x8_t kf = *(const bf16x8_t*)(wreg + k_rd + ks * 64);
-      s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], s, 0, 0, 0);
+      const f16x8_t kf = *(const f16x8_t*)(wreg + k_rd + ks * 64);
+      s = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[ks], s, 0, 0, 0);
     }
     const f32x4_t kk4 = *(const f32x4_t*)(ksl + WK * wave + 4 * g), vv4 = *(const f32x4_t*)(vsl + WK * wave + 4 * g);
     float m_t = -INFINITY;
@@ -1849,18 +1869,18 @@ __global__ void __launch_bounds__(256) k_attn_decode_q8s(AttnDecQ8P p) {
     for (int r = 0; r < 4; ++r) {
       const float e = __builtin_amdgcn_exp2f(s[r] - m_use);
       l_t += e;
-      s[r] = bf16_round(e > 0.f ? e * vv4[r] : 0.f);           // V scale folded into P (masked keys stay exactly 0)
+      s[r] = f16_round(e > 0.f ? e * vv4[r] : 0.f);            // V scale folded into P (masked keys stay exactly 0)
       p_t += s[r];
     }
     l_run = rows_sum(l_t);
     p_sum = rows_sum(p_t);
     m_run = m_t;
-    const u32x2_t pw = {pack_bf16x2(s[0], s[1]), pack_bf16x2(s[2], s[3])};
-    const s16x4_t pf = __builtin_bit_cast(s16x4_t, pw);
+    const u32x2_t pw = {pack_f16x2(s[0], s[1]), pack_f16x2(s[2], s[3])};
+    const f16x4_t pf = __builtin_bit_cast(f16x4_t, pw);
 #pragma unroll
     for (int d = 0; d < NDT; ++d) {
-      const s16x4_t vf = *(const s16x4_t*)(wreg + v_rd + d * 16 * VROW);
-      o[d] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(vf, pf, o[d], 0, 0, 0);
+      const f16x4_t vf = *(const f16x4_t*)(wreg + v_rd + d * 16 * VROW);
+      o[d] = __builtin_amdgcn_mfma_f32_16x16x16f16(vf, pf, o[d], 0, 0, 0);
     }
   }
 
@@ -1869,7 +1889,7 @@ __global__ void __launch_bounds__(256) k_attn_decode_q8s(AttnDecQ8P p) {
   __syncthreads();                                             // every wave is done reading the tile regions
   if (qvalid) {
     float* Ow = (float*)wreg + qi * HD;
-    const float voff = 128.f * p_sum;
+    const float voff = Q8_OFF * p_sum;
 #pragma unroll
     for (int d = 0; d < NDT; ++d) *(f32x4_t*)(Ow + 16 * d + 4 * g) = o[d] - voff;
     if (g == 0) { Ml[wave][qi][0] = m_run; Ml[wave][qi][1] = l_run; }

@@ -2,6 +2,7 @@
 
     POST /v1/completions   {"prompt": str | [str, ...], "max_tokens": int (default 512)}
       -> 200 {"model": "phi-3-vision", "responses": [str, ...]}            anything else -> 404
+    (extension: "images": [null | path | URL | "data:image/...;base64,..." per prompt] -- the reference's endpoint is text-only)
 
 with one difference in the plumbing: requests do not call the model from the HTTP thread.  They go into a queue that a
 single engine thread drains (the model object holds one in-flight sequence group).  By default every
@@ -14,7 +15,10 @@ while prompt + max_tokens of the merged batch stays on the same side of the 4096
 the KV cache).  Malformed bodies get 400 instead of a dropped connection; a request that waits longer than `timeout_s`
 gets 500.
 
-    python -m phi_3_vision_mlx_amd.server --port 8000 [--synthetic] [--blind]
+`--continuous` replaces the queue by `engine.ContinuousEngine`: requests are prefilled into free batch rows between the
+decode steps of the rows already generating and leave at their own EOS / budget (no request waits for a batch to drain).
+
+    python -m phi_3_vision_mlx_amd.server --port 8000 [--synthetic] [--blind] [--merge | --continuous]
 """
 import json
 import queue
@@ -25,11 +29,21 @@ MODEL_NAME = "phi-3-vision"
 
 
 class _Job:
-    __slots__ = ("prompts", "max_tokens", "done", "result", "error")
+    __slots__ = ("prompts", "max_tokens", "images", "done", "result", "error")
 
-    def __init__(self, prompts, max_tokens):
-        self.prompts, self.max_tokens = prompts, max_tokens
+    def __init__(self, prompts, max_tokens, images=None):
+        self.prompts, self.max_tokens, self.images = prompts, max_tokens, images
         self.done, self.result, self.error = threading.Event(), None, None
+
+
+def decode_image(spec):
+    """null | path | URL | data URI -> what `generate(images=...)` takes (a PIL image for data URIs)."""
+    if spec is None or not isinstance(spec, str) or not spec.startswith("data:"):
+        return spec
+    import base64
+    from io import BytesIO
+    from PIL import Image
+    return Image.open(BytesIO(base64.b64decode(spec.split(",", 1)[1])))
 
 
 class EngineQueue:
@@ -46,8 +60,8 @@ class EngineQueue:
         self.thread = threading.Thread(target=self._run, daemon=True)
         self.thread.start()
 
-    def submit(self, prompts, max_tokens):
-        job = _Job(prompts, max(1, min(int(max_tokens), self.max_tokens_cap)))
+    def submit(self, prompts, max_tokens, images=None):
+        job = _Job(prompts, max(1, min(int(max_tokens), self.max_tokens_cap)), images)
         self.jobs.put(job)
         if not job.done.wait(self.timeout_s):
             raise TimeoutError(f"no result within {self.timeout_s} s")
@@ -70,7 +84,7 @@ class EngineQueue:
         """merge=False: `first` alone.  merge=True: plus every queued job with the same max_tokens that fits and keeps the
         RoPE regime of each member unchanged, waiting at most `window_s` for stragglers."""
         group, n, held = [first], len(first.prompts), []
-        if not self.merge:
+        if not self.merge or first.images is not None:          # image requests are never merged
             return group
         regime = self._regime(first.prompts, first.max_tokens)
         while n < self.max_batch:
@@ -81,7 +95,7 @@ class EngineQueue:
             if job is None:
                 self.jobs.put(None)
                 break
-            if job.max_tokens == first.max_tokens and n + len(job.prompts) <= self.max_batch \
+            if job.images is None and job.max_tokens == first.max_tokens and n + len(job.prompts) <= self.max_batch \
                     and self._regime(job.prompts, job.max_tokens) == regime:
                 group.append(job)
                 n += len(job.prompts)
@@ -102,7 +116,8 @@ class EngineQueue:
             group = self._collect(first)
             flat = [p for j in group for p in j.prompts]
             try:
-                out = self.generate_fn(flat, first.max_tokens)
+                out = self.generate_fn(flat, first.max_tokens) if first.images is None else \
+                    self.generate_fn(flat, first.max_tokens, first.images)
                 out = [out] if isinstance(out, str) else list(out)
                 if len(out) != len(flat):
                     raise RuntimeError(f"generate returned {len(out)} texts for {len(flat)} prompts")
@@ -139,11 +154,18 @@ def make_handler(engine):
                 prompts = [prompts] if isinstance(prompts, str) else list(prompts)
                 if not prompts or not all(isinstance(p, str) for p in prompts):
                     raise ValueError("prompt must be a string or a list of strings")
-            except (ValueError, TypeError, AttributeError) as e:
+                images = request.get("images")
+                if images is not None:
+                    images = [images] if isinstance(images, str) else list(images)
+                    if len(images) != len(prompts):
+                        raise ValueError("images must list one entry (or null) per prompt")
+                    images = [decode_image(i) for i in images]
+                    images = None if all(i is None for i in images) else images
+            except (ValueError, TypeError, AttributeError, OSError) as e:
                 self._send(400, {"error": str(e)})
                 return
             try:
-                responses = engine.submit(prompts, max_tokens)
+                responses = engine.submit(prompts, max_tokens, images) if images is not None else engine.submit(prompts, max_tokens)
             except Exception as e:              # noqa: BLE001
                 self._send(500, {"error": f"{type(e).__name__}: {e}"})
                 return
@@ -162,12 +184,46 @@ def serve(generate_fn, port=8000, host="", max_batch=64, **engine_kwargs):
     return httpd, engine
 
 
-def run(port=8000, synthetic=False, blind_model=False, merge=False):
+class ContinuousBackend:
+    """The handler's `submit` on top of engine.ContinuousEngine (its own stepping thread)."""
+
+    def __init__(self, engine, max_tokens_cap=4096, timeout_s=600.0):
+        self.engine, self.max_tokens_cap, self.timeout_s = engine, max_tokens_cap, timeout_s
+        self.stop = threading.Event()
+        self.thread = threading.Thread(target=engine.serve_forever, args=(self.stop,), daemon=True)
+        self.thread.start()
+
+    def submit(self, prompts, max_tokens, images=None):
+        return self.engine.generate(prompts, images, max(1, min(int(max_tokens), self.max_tokens_cap)), self.timeout_s)
+
+    def close(self):
+        self.stop.set()
+        self.thread.join(timeout=5)
+
+
+def serve_continuous(engine, port=8000, host="", **kw):
+    backend = ContinuousBackend(engine, **kw)
+    return ThreadingHTTPServer((host, port), make_handler(backend)), backend
+
+
+def run(port=8000, synthetic=False, blind_model=False, merge=False, continuous=False):
     from .api import _apply_chat_template, generate, load
     preload = load(blind_model=blind_model, synthetic=synthetic or None)
     processor = preload[1]
+    if continuous:
+        from .engine import ContinuousEngine
+        httpd, engine = serve_continuous(ContinuousEngine(*preload), port=port)
+        print(f"Starting server on port {port} (continuous batching)")
+        try:
+            httpd.serve_forever()
+        finally:
+            engine.close()
+        return
 
-    def generate_fn(prompts, max_tokens):
+    def generate_fn(prompts, max_tokens, images=None):
+        if images is not None:                               # mixed image + text requests: one left-padded batch (dist.py)
+            from .dist import generate_sharded
+            return generate_sharded(prompts, images, preload=preload, max_tokens=max_tokens)
         return generate(prompts if len(prompts) > 1 else prompts[0], preload=preload, max_tokens=max_tokens, verbose=False)
 
     def length_fn(prompt):
@@ -188,5 +244,6 @@ if __name__ == "__main__":
     ap.add_argument("--synthetic", action="store_true", help="seeded random weights instead of models/phi3_v")
     ap.add_argument("--blind", action="store_true", help="text-only Phi-3-mini-128K")
     ap.add_argument("--merge", action="store_true", help="fold concurrent same-budget requests into one batched generate (opt-in)")
+    ap.add_argument("--continuous", action="store_true", help="continuous batching engine (requests join / leave between decode steps)")
     a = ap.parse_args()
-    run(a.port, a.synthetic, a.blind, a.merge)
+    run(a.port, a.synthetic, a.blind, a.merge, a.continuous)

@@ -230,3 +230,23 @@ def test_mlx_int4_format_round_trip_and_checkpoint_loading(tmp_path):
     emb = got["model.embed_tokens.weight"]
     assert emb.dtype == torch.bfloat16 and torch.equal(emb, mlx_dequantize(*mlx_quantize(ws["model.embed_tokens.weight"])).to(torch.bfloat16))
     assert torch.equal(got["model.norm.weight"], ws["model.norm.weight"])
+
+
+def test_mlx_quantize_documented_example():
+    """tests/golden/mlx_quantize_doc_example.json: a hand-worked instance of the affine group quantisation mx.quantize
+    documents (formula, 8 four-bit codes per uint32 with element k in bits [4k, 4k+4), the larger-magnitude end of the range
+    represented exactly).  It pins what the loader ASSUMES about `quantized_model.safetensors` (phi_3_vision_mlx.py:297-305);
+    no MLX-written file exists in this environment to pin it harder."""
+    import json
+    import os
+    import torch
+    from phi_3_vision_mlx_amd.weights import mlx_dequantize, mlx_quantize, mlx_unpack
+    ex = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "mlx_quantize_doc_example.json")))
+    w = torch.tensor(ex["weights"], dtype=torch.float32)
+    packed = torch.tensor([[int(h, 16) for h in row] for row in ex["packed_hex"]], dtype=torch.int64)
+    packed = torch.where(packed >= 2 ** 31, packed - 2 ** 32, packed).to(torch.int32)
+    scales, biases = torch.tensor(ex["scales"]), torch.tensor(ex["biases"])
+    assert mlx_unpack(packed).tolist() == ex["codes"]
+    assert torch.equal(mlx_dequantize(packed, scales, biases), w)          # s * q + beta reproduces the ramp exactly
+    p2, s2, b2 = mlx_quantize(w)
+    assert torch.equal(p2, packed) and torch.equal(s2.float(), scales) and torch.equal(b2.float(), biases)

@@ -737,3 +737,46 @@ def test_continuous_batching_engine_matches_solo_generate():
     assert same >= 0.6 * total and identical >= 5, (same, total, identical)       # measured: 35 of 46 tokens, 6 of 7 requests
     big = eng.submit(reqs[0][0], 5000)                             # beyond the window: refused, not queued
     assert big.done.is_set() and isinstance(big.error, ValueError)
+
+
+def test_http_server_on_the_engine_matches_direct_generate():
+    """POST /v1/completions through the HTTP handler on top of the continuous-batching engine (text + one image request,
+    concurrent clients) == direct `generate()` of each request (tiny decisive model; texts compared where the runs agree
+    token for token, which near-ties aside they do)."""
+    import base64, json, threading, urllib.request
+    from io import BytesIO
+    from golden_inputs import make_image
+    from phi_3_vision_mlx_amd import api
+    from phi_3_vision_mlx_amd.engine import ContinuousEngine
+    from phi_3_vision_mlx_amd.server import serve_continuous
+    g = np.load(GOLDEN + "/tiny_oracle.npz")
+    model, proc = _tiny_with_head(False, g, "vis_")
+    img = make_image(336, 336, "noise", 0)
+    buf = BytesIO()
+    img.save(buf, format="PNG")
+    uri = "data:image/png;base64," + base64.b64encode(buf.getvalue()).decode()
+    jobs = [({"prompt": "Say hi.", "max_tokens": 5}, None), ({"prompt": ["Name a colour.", "Count to three."], "max_tokens": 4}, None),
+            ({"prompt": "What is shown?", "images": [uri], "max_tokens": 4}, img)]
+    want = []
+    for body, im in jobs:
+        ps = [body["prompt"]] if isinstance(body["prompt"], str) else body["prompt"]
+        want.append([api.generate(p, im, preload=(model, proc), max_tokens=body["max_tokens"], verbose=False, stream=False) for p in ps])
+    httpd, backend = serve_continuous(ContinuousEngine(model, proc, slots=2, window=4096), port=0, host="127.0.0.1")
+    t = threading.Thread(target=httpd.serve_forever, daemon=True)
+    t.start()
+    port, got = httpd.server_address[1], {}
+
+    def post(i, body):
+        req = urllib.request.Request(f"http://127.0.0.1:{port}/v1/completions", data=json.dumps(body).encode(), headers={"Content-Type": "application/json"})
+        with urllib.request.urlopen(req, timeout=60) as r:
+            got[i] = json.loads(r.read())
+    ths = [threading.Thread(target=post, args=(i, b)) for i, (b, _) in enumerate(jobs)]
+    [x.start() for x in ths]
+    [x.join() for x in ths]
+    httpd.shutdown()
+    backend.close()
+    n_same = 0
+    for i, w in enumerate(want):
+        assert got[i]["model"] == "phi-3-vision" and len(got[i]["responses"]) == len(w)
+        n_same += sum(a == b for a, b in zip(got[i]["responses"], [x if isinstance(x, str) else x[0] for x in w]))
+    assert n_same >= 3, (got, want)                              # 4 texts; a near-tie may flip one with the pad geometry
