@@ -41,6 +41,8 @@ def parse():
     ap.add_argument("--prefill-reps", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--config4", action="store_true", help="BASELINE configs[3]: 8 mixed image+text requests per GPU, batched (B = 8)")
+    ap.add_argument("--config5", action="store_true", help="BASELINE configs[4]: fp8 (e4m3) weights, W8A8 prefill on the fp8 MFMA, int8 KV cache")
+    ap.add_argument("--fp8-weight-only", action="store_true", help="with --config5: fp8_activations=False (dequantise + bf16 MFMA prefill)")
     ap.add_argument("--tiny", action="store_true", help="tiny config (debug only; the result is NOT the headline metric)")
     return ap.parse_args()
 
@@ -153,7 +155,8 @@ def main():
     from phi_3_vision_mlx_amd.workloads import c4_share, vqa_request
 
     t0 = time.perf_counter()
-    model, processor = load_synthetic(blind_model=False, tiny=args.tiny, seed=0, device=dev)
+    q5 = dict(quantized_fp8=True, use_quantized_cache=True, fp8_activations=not args.fp8_weight_only) if args.config5 else {}
+    model, processor = load_synthetic(blind_model=False, tiny=args.tiny, seed=0, device=dev, **q5)
     torch.cuda.synchronize()
     t_weights = time.perf_counter() - t0
     cfg = model.cfg
@@ -246,14 +249,18 @@ def main():
     #      replayed as one hipGraph on the launch stream (exactly the launches of a B = 1 decode step, weights of every
     #      layer in turn so nothing is cache-resident), HIP events around the replay
     I, H, L = cfg.intermediate_size, cfg.hidden_size, cfg.num_hidden_layers
-    alg_bytes = 2 * I * H * 2                                     # bf16 [2I, H] weights streamed once per launch
+    wbytes = 1 if model.w8 else 2
+    alg_bytes = 2 * I * H * wbytes                                # [2I, H] weights (bf16, or e4m3 under --config5) streamed once per launch
     xb = torch.randn((1, H), device=dev).to(torch.bfloat16)
     ab = torch.empty((1, I), dtype=torch.bfloat16, device=dev)
 
     def gate_up_all_layers():
         for i in range(L):
-            ops.gemv(xb, model.w[f"model.layers.{i}.mlp.gate_up_proj.weight"], ops.EPI_SILU_MUL,
-                     norm_w=model.w[f"model.layers.{i}.post_attention_layernorm.weight"], norm_eps=cfg.rms_norm_eps, out=ab)
+            k, nw = f"model.layers.{i}.mlp.gate_up_proj.weight", model.w[f"model.layers.{i}.post_attention_layernorm.weight"]
+            if model.w8:
+                ops.gemv_fp8(xb, *model.w8[k], ops.EPI_SILU_MUL, norm_w=nw, norm_eps=cfg.rms_norm_eps, out=ab)
+            else:
+                ops.gemv(xb, model.w[k], ops.EPI_SILU_MUL, norm_w=nw, norm_eps=cfg.rms_norm_eps, out=ab)
     side = torch.cuda.Stream(device=dev)
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):
@@ -279,14 +286,17 @@ def main():
     # runs, FETCH_SIZE x2 on gfx950); a committed measurement, not re-collected inside the timed benchmark
     traffic = None
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_gate_up_gemv.json")) as f:
-            traffic = json.load(f)["hbm_bytes_per_launch_corrected"]
+        if not model.w8:
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_gate_up_gemv.json")) as f:
+                traffic = json.load(f)["hbm_bytes_per_launch_corrected"]
     except Exception:
         pass
     hd = cfg.hidden_size // cfg.num_attention_heads
     valid = int(np.asarray(inputs["mask"]).sum()) if "mask" in inputs else B * S
-    kv_bytes = 2 * L * cfg.num_key_value_heads * hd * 2 * (valid + B * (args.warmup + args.steps // 2))
-    w_bytes = sum(v.numel() * 2 for k, v in model.w.items() if k.startswith("model.layers.") or k == "lm_head.weight")
+    kv_elt = 1 if args.config5 else 2
+    kv_bytes = 2 * L * cfg.num_key_value_heads * hd * kv_elt * (valid + B * (args.warmup + args.steps // 2))
+    w_bytes = sum(v.numel() * 2 for k, v in model.w.items() if k.startswith("model.layers.") or k == "lm_head.weight") \
+        + sum(v[0].numel() for v in model.w8.values())
     step_s = elapsed / args.steps
     pf = prefill_flops(cfg, S, n_img, n_crops) if B == 1 else None
     if args.config4:
@@ -297,11 +307,16 @@ def main():
         workload = ("Phi-3-Vision single 336x336 image VQA (BASELINE configs[1]); 17 crops, "
                     f"{n_img} image tokens + 22 text tokens, prompt {S}, B=1 per GPU, greedy, EOS suppressed")
         metric = "decode tokens/sec (+ prefill ms), Phi-3-Vision bf16 1-image VQA"
+    if args.config5:
+        workload += ("; BASELINE configs[4]: e4m3 decoder weights (per-row scales), " +
+                     ("bf16 activations (weight-only)" if args.fp8_weight_only else "e4m3 activations in the prompt-sized projections (fp8 MFMA)") +
+                     ", int8 KV cache")
+        metric = metric.replace("bf16", "fp8 weights + int8 KV")
     out = {
         "metric": metric,
         "value": round(tokens_per_s, 2), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(step_s * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "bf16", "data": "synthetic",
+        "dtype": "fp8(e4m3)+int8kv" if args.config5 else "bf16", "data": "synthetic",
         "config": {"workload": workload, "parallelism": f"batch-sharded replicas x{world}", "batch_per_gpu": int(B), "tiny": bool(args.tiny)},
         "prefill_ms": round(prefill, 3), "prefill_tokens": int(B * S), "preprocess_ms": round(host_pre_ms, 1),
         "preprocess": "host" if host_pre else "device",
@@ -310,12 +325,13 @@ def main():
         "decode_step_hbm": {"algorithmic_GB_per_token": round((w_bytes + kv_bytes) / 1e9, 3),
                             "achieved_GBps": round((w_bytes + kv_bytes) / step_s / 1e9, 1),
                             "frac_of_peak": round((w_bytes + kv_bytes) / step_s / 1e9 / HBM_PEAK_GBS, 4)},
-        "roofline": {"bound": "hbm", "kernel": "k_gemv3<1,1,6> (RMSNorm + gate_up_proj + SiLU*up), 32 launches per B=1 step", "achieved": round(achieved, 1),
+        "roofline": {"bound": "hbm", "kernel": ("k_gemv3_f8" if model.w8 else "k_gemv3<1,1,6>") + " (RMSNorm + gate_up_proj + SiLU*up), 32 launches per B=1 step", "achieved": round(achieved, 1),
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                      "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(k_ms, 5)},
         "roofline_prefill": None if pf is None else {
             "bound": "mfma", "algorithmic_TFLOP": round(pf / 1e12, 2), "achieved": round(pf / (prefill * 1e-3) / 1e12, 1),
             "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(pf / (prefill * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
+            "peak_note": "bf16 dense MFMA peak (under --config5 the decoder projections run on the fp8 MFMA, 2x that peak; the ViT stays bf16)",
             "span": "whole prefill wall time (ViT + projector + 32 layers + lm_head + argmax + sync), not a single kernel"},
         "first_token": first, "weights_init_s": round(t_weights, 1),
     }

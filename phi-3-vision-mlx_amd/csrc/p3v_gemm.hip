@@ -19,6 +19,7 @@
 //
 // Roofline: MFMA-bound for M >= ~512 (2*M*N*K flops vs (M+N)*K*2 bytes).
 #include <stdlib.h>
+#include <string.h>
 
 #include "p3v_common.h"
 
@@ -278,7 +279,8 @@ static int gemm128(const p3v_gemm_args_t* a, hipStream_t s);
 static int gemm_big_rows(const p3v_gemm_args_t* a) {
   const int n_big = a->epilogue == P3V_EPI_SILU_MUL ? 128 : 256, n_small = n_big / 2;
   if (a->M < 1024 || a->N % n_big || a->epilogue == P3V_EPI_PATCH) return 0;
-  if (const char* force = getenv("P3V_GEMM_BIG_ROWS")) return min(atoi(force) / 256 * 256, a->M);   // tests: pin the split
+  if (const char* force = getenv("P3V_GEMM_BIG_ROWS"))                                              // tests: pin the split
+    if (strcmp(force, "auto")) return min(atoi(force) / 256 * 256, a->M);                             // ("auto" = the model below)
   const int mt = p3v_cdiv(a->M, 256), nt_big = a->N / n_big, nt_small = p3v_cdiv(a->N, n_small);
   // a short K loop leaves the big tile's 128-KiB prologue and four-pass epilogue exposed (one workgroup per CU)
   const float big_round = a->K >= 2048 ? 1.0f : 1.0f + 0.25f * (2048 - a->K) / 1024.f;

@@ -51,7 +51,8 @@ REL_TOL_SHORT = 0.09      # full size, short text prompts
 CKPT = os.environ.get("P3V_ORACLE_CKPT", "/tmp/p3v_oracle_ckpt")     # prefilled requests are kept here between runs (GBs)
 SPREAD = 4.0                   # log2-sd of the lm_head row scales
 C1_STEPS = 6                   # prefill + 5 decode steps, all clear (each extra all-clear step costs ~4x more head seeds)
-REL_TOL_C5 = 0.15              # config 5 (W8A8 prefill + W8A16 decode + int8 KV): see c5()
+REL_TOL_C5 = 0.25              # config 5, W8A8 prefill + W8A16 decode + int8 KV: see c5()
+REL_TOL_C5W = 0.07             # config 5 with fp8_activations=False (weight-only fp8 + int8 KV)
 BF16, F32 = torch.bfloat16, torch.float32
 
 
@@ -282,12 +283,12 @@ def quantize_act_rows(x):
     return (xb * (1.0 / s)).to(torch.float8_e4m3fn).to(F32) * s
 
 
-def c5_proj(o):
+def c5_proj(o, act8=True):
     """nn.Linear of the config-5 model: e4m3 x scale weights (already folded into o.W); prompt-sized inputs (more than 16
     rows: the build's MFMA path) get their activations quantised too (W8A8), decode-sized ones stay bf16 (W8A16 GEMV)."""
     def proj(x, name):
         W = o.W(name)
-        xe = quantize_act_rows(x) if x.shape[0] * x.shape[1] > 16 else x.to(F32)
+        xe = quantize_act_rows(x) if act8 and x.shape[0] * x.shape[1] > 16 else x.to(F32)
         y = xe @ W.to(F32).t()
         return y.to(BF16) if x.dtype == BF16 else y
     return proj
@@ -302,28 +303,38 @@ def quantize_kv_rows(x):
 
 
 class QuantKVCache(orc.OracleKVCache):
-    """KVCache with config 5's int8 storage: what a call appends is quantised AFTER the call attended to its exact values
-    (prompt keys stay exact during the prefill, phi.py:531-533; the build does the same for every later token)."""
+    """KVCache with config 5's int8 storage, as the build keeps it: a PROMPT-sized call (more than 16 new tokens) attends to
+    its exact keys / values and stores their quantised copy (the prompt stays exact during the prefill, phi.py:531-533);
+    a decode-sized call quantises its new rows FIRST and attends over what it stores (csrc k_attn_decode_q8*: one code
+    path in the tile, phi.py:545-546)."""
 
     def __call__(self, keys, values, n_beam):
         start = self.offset
+        if keys.shape[2] <= 16:
+            return super().__call__(quantize_kv_rows(keys.to(BF16).to(F32)), quantize_kv_rows(values.to(BF16).to(F32)), n_beam)
         k, v = super().__call__(keys, values, n_beam)
         k, v = k.clone(), v.clone()                                    # this call attends to the exact new rows ...
-        self.kv[0, :, :, start:self.offset] = quantize_kv_rows(self.kv[0, :, :, start:self.offset])
-        self.kv[1, :, :, start:self.offset] = quantize_kv_rows(self.kv[1, :, :, start:self.offset])
+        self.kv[0, :, :, start:self.offset] = quantize_kv_rows(self.kv[0, :, :, start:self.offset].to(BF16).to(F32))
+        self.kv[1, :, :, start:self.offset] = quantize_kv_rows(self.kv[1, :, :, start:self.offset].to(BF16).to(F32))
         return k, v                                                    # ... later calls read the quantised ones
 
 
-def c5():
+def c5(act8=True):
+    """act8=True: the default config-5 path (W8A8 prompt projections on the fp8 MFMA) -> c5_oracle.npz; False: weight-only
+    fp8 (`fp8_activations=False`: dequantise + bf16 MFMA) -> c5w_oracle.npz.  Both with the int8 KV cache.
+    Why the W8A8 tolerance is so wide: an e4m3 code is a 6-12 % step, so wherever two correct implementations feed a
+    quantiser values that differ by eps (the build's bf16 attention output vs the oracle's fp32 one: 0.4 %), eps / 9 % of
+    the codes flip by a whole step -- rounding noise sqrt(eps x 9 %) instead of eps, at every quantiser of every layer.
+    Measured: 2 layers 4-9 % (tests: test_c5_quantisers_small_model_tight), 32 layers 18 % of max|z|."""
     cfg, o, base = _full_oracle(c5_quantisers)
-    o.proj = c5_proj(o)
+    o.proj = c5_proj(o, act8)
     from phi_3_vision_mlx_amd.ops import quantize_fp8_rows
     orig = orc.OracleKVCache
     orc.OracleKVCache = QuantKVCache
     try:
         ip = Phi3VProcessor(None).img_processor
         inp = vqa_request(ip, 0)
-        r = Prefilled(o, {k: (torch.from_numpy(v) if k == "pixel_values" else v) for k, v in inp.items()}, 4, tag="c5")
+        r = Prefilled(o, {k: (torch.from_numpy(v) if k == "pixel_values" else v) for k, v in inp.items()}, 4, tag="c5" if act8 else "c5w")
 
         global peaked_lm_head
         plain = peaked_lm_head
@@ -331,7 +342,7 @@ def c5():
         def q_head(b, spread, hs):                                    # the peaked head goes through the weight quantiser too
             w8, sc = quantize_fp8_rows(plain(b.to(BF16), spread, hs))
             return w8.view(torch.float8_e4m3fn).to(F32) * sc[:, None]
-        r.rel_tol = REL_TOL_C5
+        r.rel_tol = REL_TOL_C5 if act8 else REL_TOL_C5W
         peaked_lm_head = q_head
         try:
             # W8A8 noise is large (REL_TOL_C5): an all-clear run is out of reach -- the first step must be clear, the decode
@@ -341,10 +352,11 @@ def c5():
             peaked_lm_head = plain
     finally:
         orc.OracleKVCache = orig
-    out = dict(COMMON, rel_tol=np.asarray([REL_TOL_C5], dtype=np.float32), n_ids=np.asarray([r.S], dtype=np.int32))
+    out = dict(COMMON, rel_tol=np.asarray([r.rel_tol], dtype=np.float32), n_ids=np.asarray([r.S], dtype=np.int32))
     pack("", hs, res, out)
-    np.savez_compressed(os.path.join(HERE, "c5_oracle.npz"), **out)
-    print("wrote c5_oracle.npz")
+    name = "c5_oracle.npz" if act8 else "c5w_oracle.npz"
+    np.savez_compressed(os.path.join(HERE, name), **out)
+    print("wrote", name)
 
 
 if __name__ == "__main__":
@@ -354,4 +366,6 @@ if __name__ == "__main__":
     if which in ("full", "all"):
         full()
     if which in ("c5", "all"):
-        c5()
+        c5(True)
+    if which in ("c5w", "all"):
+        c5(False)

@@ -540,16 +540,19 @@ def test_c4_share_batched_vs_per_request_oracle():
     torch.cuda.empty_cache()
 
 
-def test_c5_fp8_weights_int8_kv_vs_quantised_oracle():
+@pytest.mark.parametrize("act8", [True, False], ids=["w8a8", "w8a16"])
+def test_c5_fp8_weights_int8_kv_vs_quantised_oracle(act8):
     """BASELINE config 5 on config 2's request: fp8 (e4m3, per-row scale) decoder weights AND the int8 KV cache together,
     against an oracle that applies the same quantisers (tests/golden/gen_golden_oracle.py c5): e4m3 x scale weights as exact
-    fp32 products, e4m3 activations with one scale per token row in the prompt-sized projections (the fp8-MFMA prefill),
-    keys / values quantised per (head, token) after the call that produced them.  Tolerance: 15 % (z-space) -- two correct
-    W8A8 implementations differ by 7-12 % after 24 layers (a flipped e4m3 code is a 6-12 % step; CPU study in DESIGN.md)."""
+    fp32 products, keys / values quantised per (head, token) as the build stores them, and -- w8a8, the default path --
+    e4m3 activations with one scale per token row in the prompt-sized projections (the fp8-MFMA prefill).
+    Tolerances (z-space, see the generator): w8a16 7 %; w8a8 25 % -- an e4m3 code is a 6-12 % step, and wherever two correct
+    implementations feed a quantiser values 0.4 % apart (bf16 vs fp32 attention output) ~5 % of the codes flip by a whole
+    step; measured 18 % after 32 layers, 4-9 % after 2 (test_c5_quantisers_small_model_tight is the tight check)."""
     from golden_inputs import vqa_request
-    g = np.load(GOLDEN + "/c5_oracle.npz")
-    model, proc = _full_model(g, quantized_fp8=True, use_quantized_cache=True)
-    assert model.w8 and "lm_head.weight" in model.w8
+    g = np.load(GOLDEN + ("/c5_oracle.npz" if act8 else "/c5w_oracle.npz"))
+    model, proc = _full_model(g, quantized_fp8=True, use_quantized_cache=True, fp8_activations=act8)
+    assert model.w8 and "lm_head.weight" in model.w8 and model.fp8_act == act8
     inp = vqa_request(proc.img_processor, 0)
     inp["pixel_values"] = torch.from_numpy(inp["pixel_values"]).to("cuda:0")
     ref_tok = torch.as_tensor(g["tokens"]).long()
@@ -557,15 +560,16 @@ def test_c5_fp8_weights_int8_kv_vs_quantised_oracle():
     norms = head_row_norms(model)
     logits, cache = model(**inp, max_tokens=n)
     assert cache[0].state.quantized
-    n_exact = 0
+    n_exact, worst = 0, 0.0
     for step in range(n):
-        got, clear, worst = logits_vs_fixture(logits[:, -1], g, step, norms, f"C5 step {step}")
+        got, clear, w = logits_vs_fixture(logits[:, -1], g, step, norms, f"C5 step {step}")
+        worst = max(worst, w)
         assert torch.equal(got.argmax(-1)[clear], ref_tok[:, step][clear]), f"C5 step {step}"
         n_exact += int(clear.sum())
         if step + 1 < n:
             logits, _ = model.greedy_step(ref_tok[:, step:step + 1].to("cuda:0", torch.int32), cache)
     assert bool(torch.as_tensor(g["margins"])[:, 0].gt(1).all()) and n_exact >= 1
-    print(f"C5: {n_exact} of {n} tokens exact (the clear steps)")
+    print(f"C5 {'W8A8' if act8 else 'W8A16'}: {n_exact} of {n} tokens exact (the clear steps), worst logit error {worst:.2f} x tolerance")
     del model, cache
     torch.cuda.empty_cache()
 
@@ -780,3 +784,47 @@ def test_http_server_on_the_engine_matches_direct_generate():
         assert got[i]["model"] == "phi-3-vision" and len(got[i]["responses"]) == len(w)
         n_same += sum(a == b for a, b in zip(got[i]["responses"], [x if isinstance(x, str) else x[0] for x in w]))
     assert n_same >= 3, (got, want)                              # 4 texts; a near-tie may flip one with the pad geometry
+
+
+def test_c5_quantisers_small_model_tight():
+    """Config 5's three quantisers (e4m3 weights, e4m3 activations in the prompt-sized projections on the fp8 MFMA, int8 KV)
+    on a 2-layer model whose shapes the fp8 GEMM takes (H = 384, I = 512): HIP vs a LIVE oracle that applies the same
+    quantisers (tests/golden/gen_golden_oracle.py: c5_quantisers / c5_proj / QuantKVCache).  Two layers leave little room for
+    the rounding noise to grow, so this is the tightest end-to-end check that both sides implement the SAME quantised
+    arithmetic (the kernels themselves are held to bf16 rounding against fp32 math in tests/test_kernels_gpu.py)."""
+    import phi3v_oracle as orc
+    import gen_golden_oracle as gg
+    from phi_3_vision_mlx_amd.config import make_config, tiny_config_dict
+    from phi_3_vision_mlx_amd.model import Phi3VModel
+    from phi_3_vision_mlx_amd.weights import synth_weights
+    d = tiny_config_dict(vision=False)
+    d.update(hidden_size=384, num_attention_heads=4, num_key_value_heads=4, intermediate_size=512, quantized_fp8=True,
+             use_quantized_cache=True)
+    cfg = make_config(d)
+    w = synth_weights(cfg, seed=0, std_scale=2.0)
+    model = Phi3VModel(cfg, w, device="cuda:0")
+    assert model.fp8_act and len(model.w8) == 2 * 4 + 1
+    ow = gg.c5_quantisers(cfg, w)
+    w8, sc = model.w8["lm_head.weight"]
+    ow["lm_head.weight"] = w8.view(torch.float8_e4m3fn).float().cpu() * sc.cpu()[:, None]
+    oracle = orc.OraclePhi3V(cfg, ow, cache_fp32=True)
+    oracle.proj = gg.c5_proj(oracle)
+    keep = orc.OracleKVCache
+    orc.OracleKVCache = gg.QuantKVCache
+    try:
+        ids = np.random.default_rng(8).integers(3, 32000, (2, 300)).astype(np.int64)
+        n = 5
+        ref, oc = oracle(input_ids=ids, max_tokens=n)
+        got, cache = model(input_ids=ids, max_tokens=n)
+        worst = []
+        for step in range(n):
+            r, gl = ref[:, -1].float(), got[:, -1].float().cpu()
+            worst.append(((gl - r).abs().amax() / r.abs().amax()).item())
+            if step + 1 < n:
+                tok = torch.argmax(r, dim=-1)[:, None]
+                ref, oc = oracle(input_ids=tok, cache=oc)
+                got, _ = model.greedy_step(tok.to("cuda:0", torch.int32), cache)
+    finally:
+        orc.OracleKVCache = keep
+    print("C5 small model: worst logit error per step (fraction of max|logit|):", [round(x, 4) for x in worst])
+    assert max(worst) <= 0.13, worst                            # measured 0.04-0.09: e4m3 code flips (see the C5 fixture test)
