@@ -221,6 +221,8 @@ typedef struct {
   const int32_t* pad_len; const int32_t* d_past; float* ws;
   int B, L, n_heads, n_kv, hd, past, cache_t, rope_bstride, n_split;
   float scale;
+  int32_t* counters;      /* optional, as p3v_attn_decode_args_t.counters: zeroed int32 [B * n_heads * n_split] -> the splits are
+                             merged inside the attention launch (used when there is one tile per split and n_split <= 16) */
 } p3v_attn_decode_q8_args_t;
 int p3v_attention_decode_q8(const p3v_attn_decode_q8_args_t* args /* host */, void* stream);
 

@@ -1465,6 +1465,8 @@ struct AttnDecQ8P {
   int B, L, nh, nkv, past, cache_t, rope_bstride, n_split;
   float scale;
   int grp, grp_magic;          // heads per kv head and ceil(2^16 / grp) (k_attn_decode_q8s)
+  int32_t* counters;           // [B * nh * n_split] zeroed ready flags: fused split merge (k_attn_decode_q8s only), as AttnDecP
+  bf16_t* out;                 // [B, L, nh * 96] (fused merge only)
 };
 
 // 16 offset-binary bytes -> 16 FP16 values 1024 + byte: a byte dropped into the mantissa of 0x6400 (= 1024.0) is exactly
@@ -1910,8 +1912,16 @@ __global__ void __launch_bounds__(256) k_attn_decode_q8s(AttnDecQ8P p) {
       lsum += c * Ml[k][q][1];
     }
     float* w = p.ws + ((((size_t)b * p.nh + head) * p.n_split + blockIdx.x) * 16 + q) * (HD + 2);
-    w[d] = acc;
-    if (d == 0) { w[HD] = M; w[HD + 1] = lsum; }
+    st_wt(w + d, acc);
+    if (d == 0) { st_wt(w + HD, M); st_wt(w + HD + 1, lsum); }
+  }
+  // fused split merge (as k_attn_decode): the highest split of a (b, head) waits for the others' flags and merges
+  if (p.counters) {
+    int32_t* flags = p.counters + ((size_t)b * p.nh + head) * p.n_split;
+    const int role = split_publish_and_wait(flags, blockIdx.x, p.n_split);
+    if (role)
+      split_merge<256>(p.ws + ((size_t)b * p.nh + head) * p.n_split * 16 * (HD + 2), p.out + (size_t)b * p.L * (p.nh * HD) + head * HD,
+                       (size_t)p.nh * HD, p.L, p.n_split, flags, role == 2);
   }
 }
 
@@ -1924,12 +1934,22 @@ extern "C" int p3v_attention_decode_q8(const p3v_attn_decode_q8_args_t* a, void*
   const int grp = a->n_heads / a->n_kv;
   AttnDecQ8P p = {a->qkv, a->cos_t, a->sin_t, a->k8, a->v8t, a->k_scale, a->v_scale, a->pad_len, a->d_past, a->ws,
                   a->B, a->L, a->n_heads, a->n_kv, a->past, a->cache_t, a->rope_bstride, a->n_split, a->scale,
-                  grp, (65536 + grp - 1) / grp};
+                  grp, (65536 + grp - 1) / grp, nullptr, (bf16_t*)a->out};
   hipStream_t s = (hipStream_t)stream;
   const dim3 grid(a->n_split, a->n_heads, a->B);
   static const bool old_only = getenv("P3V_Q8_OLD") != nullptr;   // A/B knob
-  if (!old_only && a->n_split * 64 >= a->cache_t && a->n_split <= 16)   // short contexts only: measured equal or slower beyond
+  // one tile per workgroup and at most 16 of them (contexts up to 1k): the 4-wave kernel, which with `counters` also
+  // merges the splits inside the launch.  Beyond that the single-wave kernel + merge launch is as fast or faster
+  // (measured at 42 tiles, config 5 decode: 1.543 ms/step against 1.560 with the 4-wave kernel + fused merge: its
+  // bytes go through registers and a ds_write pass into the fp16 images, where the bf16 kernel uses LDS-DMA).
+  const bool single_tile = !old_only && a->n_split * 64 >= a->cache_t && a->n_split <= 16;
+  if (single_tile && a->counters) {
+    p.counters = a->counters;
     hipLaunchKernelGGL(k_attn_decode_q8s, grid, dim3(256), 0, s, p);
+    P3V_CHECK_LAUNCH();
+    return P3V_OK;
+  }
+  if (single_tile) hipLaunchKernelGGL(k_attn_decode_q8s, grid, dim3(256), 0, s, p);
   else hipLaunchKernelGGL(k_attn_decode_q8, grid, dim3(64), 0, s, p);
   P3V_CHECK_LAUNCH();
   hipLaunchKernelGGL(k_attn_combine2, dim3(a->B * a->n_heads * a->L), dim3(combine_threads(a->n_split)), 0, s, a->ws, a->out, a->L, a->n_heads,

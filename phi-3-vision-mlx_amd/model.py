@@ -451,7 +451,7 @@ class Phi3VModel:
                     else:
                         rc, rs, rb = st.cos[:, past:], st.sin[:, past:], st.T
                     ops.attention_decode_q8(qkv, rc, rs, rb, st.k8[i], st.v8[i], st.ks[i], st.vs[i], o, B, L, nh, nkv, hd, scale,
-                                            past, st.Tp, ws, n_split, pad_len=st.pad_len, d_past=d_past)
+                                            past, st.Tp, ws, n_split, pad_len=st.pad_len, d_past=d_past, counters=bufs.get("attn_cnt"))
                 else:                                           # prefill: exact attention, quantised copy stored
                     if past > 0:                                # long cached call (constrain with > 16 tokens): attend on a
                         ops.kv_dequantize(st.k8[i], st.v8[i], st.ks[i], st.vs[i], st.k_tmp, st.v_tmp, past)   # dequantised copy

@@ -280,10 +280,10 @@ def kv_dequantize(k8, v8t, k_scale, v_scale, k, vt, n_tok):
 
 
 def attention_decode_q8(qkv, cos_new, sin_new, rope_bstride, k8, v8t, k_scale, v_scale, out, B, Lq, nh, nkv, hd, scale, past,
-                        cache_t, ws, n_split, pad_len=None, d_past=None):
-    """`attention_decode` on the int8 KV cache."""
+                        cache_t, ws, n_split, pad_len=None, d_past=None, counters=None):
+    """`attention_decode` on the int8 KV cache (counters: as there -- the split partials are merged inside the launch)."""
     args = L.AttnDecQ8Args(_p(qkv), _p(cos_new), _p(sin_new), _p(k8), _p(v8t), _p(k_scale), _p(v_scale), _p(out), _p(pad_len),
-                           _p(d_past), _p(ws), B, Lq, nh, nkv, hd, int(past), cache_t, rope_bstride, n_split, float(scale))
+                           _p(d_past), _p(ws), B, Lq, nh, nkv, hd, int(past), cache_t, rope_bstride, n_split, float(scale), _p(counters))
     L.check(L.lib().p3v_attention_decode_q8(C.byref(args), _stream()), "attention_decode_q8")
     return out
 

@@ -344,11 +344,13 @@ def _dequant(u8, sc, axis):
     return (u8.float() - 128.0) * sc.unsqueeze(axis)
 
 
-@pytest.mark.parametrize("past,L,n_split", [(200, 1, 3), (200, 1, 4), (190, 3, 4), (62, 5, 4)])
-def test_kv_quantize_and_q8_decode(ops, orc, past, L, n_split):
+@pytest.mark.parametrize("past,L,n_split,fused", [(200, 1, 3, False), (200, 1, 4, False), (190, 3, 4, False), (62, 5, 4, False),
+                                                   (200, 1, 4, True), (62, 5, 4, True)])
+def test_kv_quantize_and_q8_decode(ops, orc, past, L, n_split, fused):
     """int8 KV: (a) quantiser = round(x/s)+128 with s = amax/127 per token, (b) the q8 decode attention equals the
     bf16 oracle attention over the DEQUANTISED cache, (c) the appended rows are stored quantised.
-    n_split 3 -> multi-tile single-wave kernel, 4 (= tiles) -> single-tile 4-wave kernel; (62, 5) crosses a tile boundary."""
+    n_split 3 -> multi-tile single-wave kernel, 4 (= tiles) -> single-tile 4-wave kernel; (62, 5) crosses a tile boundary;
+    fused: the split partials are merged inside the attention launch (ready flags), twice in a row (the flags re-arm)."""
     from phi_3_vision_mlx_amd.config import make_config, rope_scaling_factor
     cfg = make_config()
     B, nh, hd, T = 2, 2, 96, 256
@@ -370,8 +372,12 @@ def test_kv_quantize_and_q8_decode(ops, orc, past, L, n_split):
     cos, sin = cos.view(B, T, -1), sin.view(B, T, -1)
     out = torch.empty((B, L, nh * hd), dtype=BF16).cuda()
     ws = torch.empty(ops.attention_ws_bytes(B, L, nh, hd, n_split) // 4, dtype=F32).cuda()
-    ops.attention_decode_q8(qkv.cuda(), cos[:, past:], sin[:, past:], T, k8, v8, ksc, vsc, out, B, L, nh, nh, hd, hd ** -0.5, past,
-                            T, ws, n_split)
+    cnt = torch.zeros(B * nh * n_split, dtype=torch.int32).cuda() if fused else None
+    for _ in range(2 if fused else 1):
+        out.fill_(float("nan"))
+        ops.attention_decode_q8(qkv.cuda(), cos[:, past:], sin[:, past:], T, k8, v8, ksc, vsc, out, B, L, nh, nh, hd, hd ** -0.5, past,
+                                T, ws, n_split, counters=cnt)
+    assert cnt is None or int(cnt.abs().sum()) == 0             # every flag cleared for the next launch
     cos_ref, sin_ref = orc.su_rope_tables(cfg, T, None)
     x = qkv.view(B, L, 3 * nh, hd).transpose(1, 2)
     cs, sn = cos_ref[:, :, past:past + L], sin_ref[:, :, past:past + L]
