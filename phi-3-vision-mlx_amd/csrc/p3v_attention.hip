@@ -733,12 +733,14 @@ __device__ __forceinline__ int split_publish_and_wait(int32_t* flags, int split,
 }
 
 // merge of the n_split partials of one (b, head) by the calling workgroup (NT threads = G groups of 64 lanes)
+#define SPLIT_MERGE_SCRATCH(NT) ((NT) / 64 * 130)              // floats: pm[G], pl[G], part[G][128]
 template <int NT>
 __device__ __forceinline__ void split_merge(const float* base0, bf16_t* out0, size_t out_qstride, int L, int n_split,
-                                            int32_t* flags, bool poison) {
+                                            int32_t* flags, bool poison, float* scratch) {
   constexpr int HD = 96, G = NT / 64;
-  __shared__ float pm[G], pl[G];
-  __shared__ float part[G][128];
+  float* pm = scratch;
+  float* pl = scratch + G;
+  float (*part)[128] = (float (*)[128])(scratch + 2 * G);
   const int t = threadIdx.x, grp = t >> 6, d0 = t & 63;
   const size_t sstr = (size_t)16 * (HD + 2);
   const bool two = d0 + 64 < HD;
@@ -1087,10 +1089,219 @@ __device__ __forceinline__ void attn_decode_body(const AttnDecP& p, const int bx
   DBG_W(13, false);
   int32_t* flags = p.counters + ((size_t)b * p.nh + head) * p.n_split;
   const int role = p.counters ? split_publish_and_wait(flags, bx, p.n_split) : 0;
+  if (role) {
+    __shared__ float merge_scratch[SPLIT_MERGE_SCRATCH(256)];
+    split_merge<256>(p.ws + ((size_t)b * p.nh + head) * p.n_split * 16 * (HD + 2), p.out + (size_t)b * p.L * (p.nh * HD) + head * HD,
+                     (size_t)p.nh * HD, p.L, p.n_split, flags, role == 2, merge_scratch);
+  }
+  DBG_W(11, false);
+}
+
+// ---- 128-key tiles (round 2).  Same structure as attn_decode_body, twice the keys per workgroup: wave w owns keys
+// [32w, 32w + 32) -- two 16-key S^T blocks (6 MFMA 16x16x32), an 8-value-per-lane softmax, and O^T += V^T.P^T as 6 MFMA
+// 16x16x32 whose k index runs over both blocks (k = (j / 4) * 16 + 4g + j % 4, the same permutation on the V^T fragment:
+// two 8-byte reads) with P straight from the two accumulators.  Why: at the bench context the 64-key plan needs 1344-1408
+// workgroups of which 1280 are resident (5 per CU) -- a second residency round of 64-128 workgroups starts 6 us into the
+// launch, and the last head's merge reads 42-44 partials.  With 128-key tiles all 672-704 workgroups are resident at once
+// (48 KiB of tile + 3.6 KiB: 3 per CU), every DMA of the launch is in flight from the start, and the merge reads half as
+// many partials.  LDS image: [K slice of wave 0..3: 32 keys x 192 B, chunk c of row r at c ^ ((r >> 2) & 3)]
+// [V^T tile: 96 rows x 256 B, chunk c (of 16) of row d at c ^ (d & 15): the 16 rows x 2 key groups of a ds_read_b64 lane
+// group hit 32 different 8-byte slots].  The merge scratch aliases the (dead) tile region.
+__device__ __forceinline__ void attn_decode_body128(const AttnDecP& p, const int bx, const int by, const int bz, unsigned char* KV) {
+  constexpr int TK = 128, WK = 32, HD = 96, KROW = HD * 2, VROWB = TK * 2, NKS = 3, NDT = 6, CPR = 12;
+  constexpr int KS_BYTES = WK * KROW;                          // 6 KiB per wave = 16 x 96 fp32: the wave's O partial parks here
+  static_assert(KS_BYTES >= 16 * HD * 4, "a wave's O partial reuses its K slice");
+  __shared__ __attribute__((aligned(16))) unsigned char Qs[16 * KROW];
+  __shared__ float Ml[4][16][2];
+  const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, qi = lane & 15;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int b = bz, head = by, kvh = (head * p.grp_magic) >> 16;
+  const bool kv_writer = head == kvh * p.grp;
+  unsigned char* kslice = KV + wave * KS_BYTES;
+  unsigned char* vtile = KV + 4 * KS_BYTES;
+
+  int past = p.past, pad = 0;
+  if (p.d_past) asm volatile("s_load_dword %0, %1, 0x0" : "=s"(past) : "s"(p.d_past) : "memory");
+  if (p.pad_len) asm volatile("s_load_dword %0, %1, 0x0" : "=s"(pad) : "s"(p.pad_len + b) : "memory");
+
+  // ---- tile DMA (static key range: requested before the cache length has arrived)
+  const unsigned char* kc = (const unsigned char*)(p.k_cache + ((size_t)b * p.nkv + kvh) * (size_t)p.cache_t * HD);
+  bf16_t* vc = p.v_cache + ((size_t)b * p.nkv + kvh) * (size_t)HD * p.cache_t;          // V^T: [hd][cache_t]
+  const int kv_lo = bx * TK, kv_hi = min(p.cache_t, kv_lo + TK);
+  const size_t vrow = (size_t)p.cache_t * 2;
+  {
+    const int kv0 = min(kv_lo, p.cache_t - TK);
+    const unsigned char* ksrc = kc + (size_t)(kv0 + WK * wave) * KROW;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {                              // K: LDS slot i = j*64 + lane holds (row i/12, physical chunk i%12)
+      const int i = j * 64 + lane, r0 = i / CPR, pc = i - r0 * CPR;
+      const unsigned koff = r0 * KROW + ((pc ^ ((r0 >> 2) & 3)) << 4);
+      __builtin_amdgcn_global_load_lds((dec_gptr_t)(ksrc + koff), (dec_lptr_t)(kslice + j * 1024), 16, 0, 0);
+    }
+    const unsigned char* vs = (const unsigned char*)vc + (size_t)kv0 * 2;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {                              // V^T: wave w brings rows 24w..24w+23, four whole 256-B rows per instruction
+      const int d = 24 * wave + 4 * j + (lane >> 4);
+      const unsigned voff = (unsigned)d * (unsigned)vrow + ((((unsigned)lane & 15) ^ ((unsigned)d & 15)) << 4);
+      __builtin_amdgcn_global_load_lds((dec_gptr_t)(vs + voff), (dec_lptr_t)(vtile + wave * 6144 + j * 1024), 16, 0, 0);
+    }
+  }
+
+  // ---- the L new rows (as attn_decode_body): rotated Q -> LDS, rotated K / V kept until the tile that holds them has landed
+  const int row_w = (p.nh + 2 * p.nkv) * HD;
+  const float* cos_b = p.cos_t + (size_t)b * p.rope_bstride * (HD / 2);
+  const float* sin_b = p.sin_t + (size_t)b * p.rope_bstride * (HD / 2);
+  const int tr = tid / CPR, tc = tid - tr * CPR;
+  const bool rtask = tr < p.L;
+  RopeRaw qraw, kraw;
+  if (rtask) {
+    const bf16_t* row = p.qkv + ((size_t)b * p.L + tr) * row_w;
+    qraw = rope_fetch(row + head * HD, tc, cos_b + tr * (HD / 2), sin_b + tr * (HD / 2));
+    const bf16_t* krow = row + (p.nh + kvh) * HD;
+    kraw = qraw;
+    kraw.x0 = *(const u32x4_t*)(krow + tc * 8);
+    kraw.x1 = *(const u32x4_t*)(krow + (tc < 6 ? tc * 8 + 48 : tc * 8 - 48));
+  }
+  const bf16_t* vnew = p.qkv + (size_t)b * p.L * row_w + (p.nh + p.nkv + kvh) * HD;   // + r * row_w + d
+  const int n_vnew = p.L * HD;
+  bf16_t v_early = 0;
+  if (tid < n_vnew) {
+    const int r = tid / HD;
+    v_early = vnew[(size_t)r * row_w + (tid - r * HD)];
+  }
+  if (tid < 16 * CPR) {
+    u32x4_t v = {0, 0, 0, 0};
+    if (rtask) v = rope_apply(qraw, tc);
+    *(u32x4_t*)(Qs + tr * KROW + ((tc ^ ((tr >> 2) & 3)) << 4)) = v;
+  }
+
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(past), "+s"(pad)::"memory");
+  const int total = past + p.L;
+  const int kv_end = min(total, kv_hi);
+  const int qpos = past + qi;
+  const bool qvalid = qi < p.L;
+  const float sc2 = p.scale * 1.4426950408889634f;
+
+  const unsigned k_rd = qi * KROW + ((g ^ ((qi >> 2) & 3)) << 4);                                   // + kb*16*KROW + ks*64
+  // V^T fragment of key block kb: row 16*dt + qi, keys 32w + 16kb + 4g .. +3 = logical chunk 4w + 2kb + (g >> 1), half g & 1
+  unsigned v_rd[2];
+#pragma unroll
+  for (int kb = 0; kb < 2; ++kb) v_rd[kb] = qi * VROWB + (((4 * wave + 2 * kb + (g >> 1)) ^ qi) << 4) + (g & 1) * 8;   // + dt*16*VROWB
+
+  float m_run = -INFINITY, l_run = 0.f;
+  f32x4_t o[NDT];
+#pragma unroll
+  for (int d = 0; d < NDT; ++d) o[d] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  const int kv0 = kv_lo;
+  if (kv0 < kv_end) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    bf16x8_t qf[NKS];
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) qf[ks] = *(const bf16x8_t*)(Qs + k_rd + ks * 64);
+    if (kv0 + TK > past) {                                     // workgroup-uniform: the tile holds new positions
+      if (rtask) {
+        const int t = past + tr, rr = t - kv0;
+        if (rr >= 0 && rr < TK && t < kv_end) {
+          const u32x4_t kn = rope_apply(kraw, tc);
+          const int row = rr & 31;
+          *(u32x4_t*)(KV + (rr >> 5) * KS_BYTES + row * KROW + ((tc ^ ((row >> 2) & 3)) << 4)) = kn;
+          if (kv_writer) *(u32x4_t*)(p.k_cache + (((size_t)b * p.nkv + kvh) * p.cache_t + t) * HD + tc * 8) = kn;   // phi.py:545
+        }
+      }
+#pragma unroll 1
+      for (int idx = tid; idx < n_vnew; idx += 256) {
+        const int r = idx / HD, d = idx - r * HD, t = past + r, rr = t - kv0;
+        if (rr >= 0 && rr < TK && t < kv_end) {
+          const bf16_t val = idx == tid ? v_early : vnew[(size_t)r * row_w + d];
+          *(bf16_t*)(vtile + d * VROWB + (((rr >> 3) ^ (d & 15)) << 4) + (rr & 7) * 2) = val;
+          if (kv_writer) vc[(size_t)d * p.cache_t + t] = val;                                               // phi.py:546
+        }
+      }
+      __syncthreads();
+    }
+
+    f32x4_t s[2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      s[kb] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks) {
+        const bf16x8_t kf = *(const bf16x8_t*)(kslice + kb * 16 * KROW + k_rd + ks * 64);
+        s[kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], s[kb], 0, 0, 0);
+      }
+    }
+    float m_t = -INFINITY;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int t = kv0 + WK * wave + 16 * kb + 4 * g + r;
+        const bool vis = t < kv_end && t >= pad && t <= qpos && qpos >= pad;
+        s[kb][r] = vis ? s[kb][r] * sc2 : -INFINITY;
+        m_t = fmaxf(m_t, s[kb][r]);
+      }
+    m_t = rows_max(m_t);
+    const float m_use = m_t == -INFINITY ? 0.f : m_t;
+    float l_t = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        s[kb][r] = __builtin_amdgcn_exp2f(s[kb][r] - m_use);
+        l_t += s[kb][r];
+      }
+    l_run = rows_sum(l_t);
+    m_run = m_t;
+    const u32x4_t pw = {pack_bf16x2(s[0][0], s[0][1]), pack_bf16x2(s[0][2], s[0][3]), pack_bf16x2(s[1][0], s[1][1]), pack_bf16x2(s[1][2], s[1][3])};
+    const bf16x8_t pf = __builtin_bit_cast(bf16x8_t, pw);
+#pragma unroll
+    for (int d = 0; d < NDT; ++d) {
+      const u32x2_t a0 = *(const u32x2_t*)(vtile + v_rd[0] + d * 16 * VROWB), a1 = *(const u32x2_t*)(vtile + v_rd[1] + d * 16 * VROWB);
+      const u32x4_t aw = {a0[0], a0[1], a1[0], a1[1]};
+      o[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, aw), pf, o[d], 0, 0, 0);
+    }
+  }
+
+  // ---- merge the four wave partials through the (dead) K slices, one (m, l, O) partial per workgroup to `ws`
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (qvalid) {
+    float* Ow = (float*)kslice + qi * HD;
+#pragma unroll
+    for (int d = 0; d < NDT; ++d) *(f32x4_t*)(Ow + 16 * d + 4 * g) = o[d];
+    if (g == 0) { Ml[wave][qi][0] = m_run; Ml[wave][qi][1] = l_run; }
+  }
+  __syncthreads();
+#pragma unroll 1
+  for (int idx = tid; idx < n_vnew; idx += 256) {
+    const int q = idx / HD, d = idx - q * HD;
+    float mk[4], M = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { mk[k] = Ml[k][q][0]; M = fmaxf(M, mk[k]); }
+    const float Mu = M == -INFINITY ? 0.f : M;
+    float acc = 0.f, lsum = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float c = __builtin_amdgcn_exp2f(mk[k] - Mu);
+      acc += c * ((const float*)(KV + k * KS_BYTES))[q * HD + d];
+      lsum += c * Ml[k][q][1];
+    }
+    float* w = p.ws + ((((size_t)b * p.nh + head) * p.n_split + bx) * 16 + q) * (HD + 2);
+    st_wt(w + d, acc);
+    if (d == 0) { st_wt(w + HD, M); st_wt(w + HD + 1, lsum); }
+  }
+  int32_t* flags = p.counters + ((size_t)b * p.nh + head) * p.n_split;
+  const int role = p.counters ? split_publish_and_wait(flags, bx, p.n_split) : 0;
   if (role)
     split_merge<256>(p.ws + ((size_t)b * p.nh + head) * p.n_split * 16 * (HD + 2), p.out + (size_t)b * p.L * (p.nh * HD) + head * HD,
-                     (size_t)p.nh * HD, p.L, p.n_split, flags, role == 2);
-  DBG_W(11, false);
+                     (size_t)p.nh * HD, p.L, p.n_split, flags, role == 2, (float*)vtile);
+}
+
+__global__ void __launch_bounds__(256) k_attn_decode128(AttnDecP p) {
+  __shared__ __attribute__((aligned(1024))) unsigned char KV[4 * 6144 + 96 * 256];   // [K slice x 4 | V^T tile] = 48 KiB
+  attn_decode_body128(p, blockIdx.x, blockIdx.y, blockIdx.z, KV);
 }
 
 __global__ void __launch_bounds__(256) k_attn_decode(AttnDecP p) {
@@ -1271,9 +1482,11 @@ __global__ void __launch_bounds__(64) k_attn_decode_stream(AttnDecP p) {
   }
   int32_t* flags = p.counters + ((size_t)b * p.nh + head) * p.n_split;
   const int role = p.counters ? split_publish_and_wait(flags, blockIdx.x, p.n_split) : 0;
-  if (role)
+  if (role) {
+    __shared__ float merge_scratch[SPLIT_MERGE_SCRATCH(64)];
     split_merge<64>(p.ws + ((size_t)b * p.nh + head) * p.n_split * 16 * (HD + 2), p.out + (size_t)b * p.L * (p.nh * HD) + head * HD,
-                    (size_t)p.nh * HD, p.L, p.n_split, flags, role == 2);
+                    (size_t)p.nh * HD, p.L, p.n_split, flags, role == 2, merge_scratch);
+  }
 }
 
 // merge split-KV partials: one block of G = 4 or 8 64-lane groups per (b, head, query): thread (grp, d) loads
@@ -1362,6 +1575,7 @@ extern "C" int p3v_attention_decode(const p3v_attn_decode_args_t* a, void* strea
   hipStream_t s = (hipStream_t)stream;
   const dim3 grid(a->n_split, a->n_heads, a->B);
   if (a->n_split * 64 >= a->cache_t) hipLaunchKernelGGL(k_attn_decode, grid, dim3(256), 0, s, p);
+  else if (a->n_split * 128 >= a->cache_t && a->cache_t % 128 == 0) hipLaunchKernelGGL(k_attn_decode128, grid, dim3(256), 0, s, p);   // 128-key tiles
   else hipLaunchKernelGGL(k_attn_decode_stream<64>, grid, dim3(64), 0, s, p);
   P3V_CHECK_LAUNCH();
   if (a->counters) return P3V_OK;                              // the last workgroup of every (b, head) merged in-kernel
@@ -1919,9 +2133,11 @@ __global__ void __launch_bounds__(256) k_attn_decode_q8s(AttnDecQ8P p) {
   if (p.counters) {
     int32_t* flags = p.counters + ((size_t)b * p.nh + head) * p.n_split;
     const int role = split_publish_and_wait(flags, blockIdx.x, p.n_split);
-    if (role)
+    if (role) {
+      __shared__ float merge_scratch[SPLIT_MERGE_SCRATCH(256)];
       split_merge<256>(p.ws + ((size_t)b * p.nh + head) * p.n_split * 16 * (HD + 2), p.out + (size_t)b * p.L * (p.nh * HD) + head * HD,
-                       (size_t)p.nh * HD, p.L, p.n_split, flags, role == 2);
+                       (size_t)p.nh * HD, p.L, p.n_split, flags, role == 2, merge_scratch);
+    }
   }
 }
 

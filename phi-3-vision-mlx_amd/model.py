@@ -62,14 +62,17 @@ class CacheState:
     def __init__(self, cfg, B, S, max_tokens, device):
         self.B, self.S, self.max_tokens = B, S, max_tokens
         self.T = S + max(max_tokens, 0)
-        self.Tp = (self.T + 63) // 64 * 64                     # row/column stride of the caches (64-key tiles)
+        self.quantized = bool(getattr(cfg, "use_quantized_cache", False))
+        # row/column stride of the caches: whole 128-key tiles (the decode attention takes one 128-key tile per workgroup
+        # when the capacity allows it); the int8 kernels work on 64-key tiles
+        gran = 64 if self.quantized else 128
+        self.Tp = (self.T + gran - 1) // gran * gran
         if self.Tp % 512 == 0:
             # V^T rows are Tp * 2 bytes apart: at multiples of 1 KiB the 96 rows of a tile crowd the same memory channels
             # (measured decode step at B = 1: +3.5 % at Tp = 2560, +2 % at 3584, +1.4 % at 4096 against the neighbouring
             # lengths) -- one spare tile of capacity moves the stride off the grid
-            self.Tp += 64
+            self.Tp += gran
         nl, nkv, hd = cfg.num_hidden_layers, cfg.num_key_value_heads, head_dim(cfg)
-        self.quantized = bool(getattr(cfg, "use_quantized_cache", False))
         if self.quantized:
             # int8 KV (quantize_cache=True): offset-binary bytes + one fp32 scale per (layer, row, head, token);
             # one bf16 K / V^T scratch layer holds the exact prompt keys while a layer's prefill attends (phi.py:531-533)
@@ -406,7 +409,13 @@ class Phi3VModel:
             # tile's dependency chain); beyond that ~768 single-wave workgroups (one resident round, each with its
             # next 24 KB tile in flight) walking several tiles
             tiles = -(-T // 64)
-            if tiles <= 128 and B * nh * tiles <= 4096:
+            tiles128 = T // 128 if T % 128 == 0 else 0           # T is the cache CAPACITY when the plan is for a captured graph
+            if not quantized and tiles128 and tiles > 16 and tiles128 <= 48 and B * nh * tiles128 <= 2048 \
+                    and os.environ.get("P3V_ATTN_TILE128", "1") != "0":
+                # one 128-key tile per workgroup: every workgroup of the launch resident at once (3 per CU), half the
+                # partials to merge (k_attn_decode128).  Short caches keep 64-key tiles (more workgroups than CUs matters more)
+                n_split = tiles128
+            elif tiles <= 128 and B * nh * tiles <= 4096:
                 n_split = tiles
             else:
                 # (int8 KV: a tile is half the bytes and the single-wave kernel's 27.5 KB of LDS lets 5 workgroups share a CU,
@@ -420,7 +429,7 @@ class Phi3VModel:
             # per step at B = 1; with the multi-tile streaming kernel the write-through partial stores cost more than the
             # merge launch saves, and beyond ~48 splits the one merging workgroup is slower than 32 parallel ones)
             mode = os.environ.get("P3V_ATTN_FUSED_MERGE", "1")
-            fused = (n_split == tiles or mode == "2") and n_split <= 48 and mode != "0"
+            fused = (n_split in (tiles, tiles128) or mode == "2") and n_split <= 48 and mode != "0"
             bufs["attn_cnt"] = torch.zeros(B * nh * n_split, dtype=I32, device=self.device) if fused else None
 
     def _layers(self, x, st, B, L, past, n_beam, bufs=None, d_past=None):
@@ -433,7 +442,8 @@ class Phi3VModel:
         scale = hd ** -0.5
         if bufs is None:
             bufs = self._alloc_bufs(B, L)
-            self._split_plan(bufs, B, L, past + L, st.quantized)
+            self._split_plan(bufs, B, L, st.Tp, st.quantized)     # the CAPACITY, as the captured graph plans: same kernel, same
+                                                                # split boundaries -> eager and replayed steps agree bit for bit
         q, o, qkv, a, h, n_split, ws = (bufs[k] for k in ("q", "o", "qkv", "a", "h", "n_split", "ws"))
         if st.quantized and n_beam > 1:
             raise NotImplementedError("Beam Search is not yet compatible with Quantized Cache")       # as phi.py:525

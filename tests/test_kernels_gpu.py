@@ -295,13 +295,20 @@ def test_attention(ops, orc, B, L, past, hd, nh, causal, pads):
 
 @pytest.mark.parametrize("B,L,past,nh,n_split,pads", [(1, 1, 300, 4, 5, None), (2, 1, 63, 2, 1, [0, 7]), (1, 6, 130, 2, 3, None),
                                                       (3, 1, 2000, 2, 32, [0, 100, 1999]), (1, 16, 0, 2, 2, None),
-                                                      (2, 4, 61, 2, 2, [0, 7]), (2, 5, 20, 2, 1, [3, 0]), (1, 3, 700, 2, 3, None)])
+                                                      (2, 4, 61, 2, 2, [0, 7]), (2, 5, 20, 2, 1, [3, 0]), (1, 3, 700, 2, 3, None),
+                                                      (2, 4, 126, 2, 3, [0, 9]), (1, 2, 31, 2, 1, None)])
 @pytest.mark.parametrize("dev_past,fused_merge", [(True, True), (False, False), (True, False)])
-def test_attention_decode_fused(ops, orc, B, L, past, nh, n_split, pads, dev_past, fused_merge):
-    """Fused split + RoPE + KV append + split-KV attention vs the oracle's rotate_half / cache / softmax."""
+@pytest.mark.parametrize("tile", [64, 128])
+def test_attention_decode_fused(ops, orc, B, L, past, nh, n_split, pads, dev_past, fused_merge, tile):
+    """Fused split + RoPE + KV append + split-KV attention vs the oracle's rotate_half / cache / softmax.
+    tile = 128: the cache capacity is a multiple of 128 and there is one split per 128 keys -> k_attn_decode128
+    ((2, 4, 61) and (1, 6, 130) put new rows on both sides of a tile / wave-slice boundary)."""
     from phi_3_vision_mlx_amd.config import make_config, rope_scaling_factor
     cfg = make_config()
     hd, T = 96, (past + L + 5 + 63) // 64 * 64
+    if tile == 128:
+        T = (past + L + 5 + 127) // 128 * 128
+        n_split = T // 128
     qkv = g((B * L, 3 * nh * hd), 45)
     kc, vc = g((B, nh, T, hd), 46), g((B, nh, T, hd), 47)
     cos_ref, sin_ref = orc.su_rope_tables(cfg, T, None)
