@@ -849,6 +849,12 @@ __device__ __forceinline__ u32x4_t rope_chunk(const bf16_t* head_row, int c, con
   return o;
 }
 
+// cache policy of the decode kernels' K / V^T tile DMA: 2 = nt.  A decode step reads every cache tile exactly once, so the
+// lines need not displace the weights' in L2 / MALL: measured on the bench step 1.856 -> 1.815 ms (-1.3 us per layer);
+// (the prefill GEMMs keep the default policy: every CU re-reads the same weight slices there)
+#ifndef P3V_ATTN_AUX
+#define P3V_ATTN_AUX 2
+#endif
 typedef const __attribute__((address_space(1))) void* dec_gptr_t;
 typedef __attribute__((address_space(3))) void* dec_lptr_t;
 
@@ -925,13 +931,13 @@ __device__ __forceinline__ void attn_decode_body(const AttnDecP& p, const int bx
     const unsigned char* ksrc = kc + (size_t)(kv0 + WK * wave) * KROW;
 #pragma unroll
     for (int j = 0; j < 3; ++j)
-      __builtin_amdgcn_global_load_lds((dec_gptr_t)(ksrc + koff[j]), (dec_lptr_t)(kslice + j * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((dec_gptr_t)(ksrc + koff[j]), (dec_lptr_t)(kslice + j * 1024), 16, 0, P3V_ATTN_AUX);
     const unsigned char* vs = (const unsigned char*)vc + (size_t)kv0 * 2;
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
       const int d = 24 * wave + 8 * j + (lane >> 3);
       const unsigned voff = (unsigned)d * (unsigned)vrow + ((((unsigned)lane & 7) ^ (((unsigned)d >> 1) & 7)) << 4);
-      __builtin_amdgcn_global_load_lds((dec_gptr_t)(vs + voff), (dec_lptr_t)(vtile + wave * VS_BYTES + j * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((dec_gptr_t)(vs + voff), (dec_lptr_t)(vtile + wave * VS_BYTES + j * 1024), 16, 0, P3V_ATTN_AUX);
     }
   };
   load_tile(min(kv_lo, p.cache_t - TK));                    // unconditional (an empty split fetches a tile it never uses)
@@ -1136,14 +1142,14 @@ __device__ __forceinline__ void attn_decode_body128(const AttnDecP& p, const int
     for (int j = 0; j < 6; ++j) {                              // K: LDS slot i = j*64 + lane holds (row i/12, physical chunk i%12)
       const int i = j * 64 + lane, r0 = i / CPR, pc = i - r0 * CPR;
       const unsigned koff = r0 * KROW + ((pc ^ ((r0 >> 2) & 3)) << 4);
-      __builtin_amdgcn_global_load_lds((dec_gptr_t)(ksrc + koff), (dec_lptr_t)(kslice + j * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((dec_gptr_t)(ksrc + koff), (dec_lptr_t)(kslice + j * 1024), 16, 0, P3V_ATTN_AUX);
     }
     const unsigned char* vs = (const unsigned char*)vc + (size_t)kv0 * 2;
 #pragma unroll
     for (int j = 0; j < 6; ++j) {                              // V^T: wave w brings rows 24w..24w+23, four whole 256-B rows per instruction
       const int d = 24 * wave + 4 * j + (lane >> 4);
       const unsigned voff = (unsigned)d * (unsigned)vrow + ((((unsigned)lane & 15) ^ ((unsigned)d & 15)) << 4);
-      __builtin_amdgcn_global_load_lds((dec_gptr_t)(vs + voff), (dec_lptr_t)(vtile + wave * 6144 + j * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((dec_gptr_t)(vs + voff), (dec_lptr_t)(vtile + wave * 6144 + j * 1024), 16, 0, P3V_ATTN_AUX);
     }
   }
 

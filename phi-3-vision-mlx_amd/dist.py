@@ -132,8 +132,72 @@ def generate_sharded(prompts, images=None, preload=None, max_tokens=512, group=N
     width = _all_max(max([np.asarray(r["input_ids"]).shape[-1] for r in reqs], default=0), group)
     local = []
     for c in range(0, len(reqs), max_batch):
-        local += generate_rows(model, processor, collate_requests(reqs[c:c + max_batch], width=width), max_tokens, return_tokens)
+        local += generate_requests(model, processor, reqs[c:c + max_batch], max_tokens, return_tokens, width=width)
     return gather_results(idx, local, n, group)
+
+
+class _SlotCache:
+    def __init__(self, state):
+        self.state = state
+
+
+def prefill_requests(model, reqs, max_tokens, width=None):
+    """Prefill B = 1 requests of DIFFERENT lengths into one decode batch without computing on padding.
+
+    A left-padded batch (`collate_requests`) runs every projection over B x longest-prompt rows: for one GPU's share of
+    config 4 (4 x 2531-token image prompts + 4 text prompts of 65..233 tokens) almost half of them are padding.  Here the
+    requests are sorted by length, each group of EQUAL length is prefilled as its own batch straight into adjacent rows of a
+    slot state (`model.prefill_slot`: right-aligned to the longest prompt, per-row left padding and position tables -- the
+    geometry `_tokenize` gives a padded row, phi.py:238-240), and decode then runs all rows as ONE graph-replayed batch.
+    Returns (first tokens int32 [B, 1] in SLOT order, cache, order) with order[slot] = request index; None when the
+    model has no slot states or prompt + max_tokens leaves the short-RoPE window (callers then take the padded batch)."""
+    lens = [int(np.asarray(r["input_ids"]).shape[-1]) for r in reqs]
+    W = max(max(lens), width or 0)
+    if not hasattr(model, "new_slot_state") or W + max_tokens > model.cfg.original_max_position_embeddings:
+        return None
+    from .processor import collate_requests
+    order = sorted(range(len(reqs)), key=lambda i: (-lens[i], i))
+    st = model.new_slot_state(len(reqs), W + max_tokens)
+    st.offset = W
+    g = model.decode_graph(st)
+    row = 0
+    while row < len(order):
+        n = 1
+        while row + n < len(order) and lens[order[row + n]] == lens[order[row]]:
+            n += 1
+        group = [reqs[i] for i in order[row:row + n]]
+        tok = model.prefill_slot(st, row, collate_requests(group) if n > 1 else group[0])
+        g["tok"][row:row + n].copy_(tok.reshape(-1))
+        row += n
+    return g["tok"].view(-1, 1), [_SlotCache(st)], order
+
+
+def generate_requests(model, processor, reqs, max_tokens, return_tokens=False, width=None):
+    """Greedy generation for a list of B = 1 model inputs as one decode batch; results in request order."""
+    from . import api
+    from .processor import collate_requests
+    pre = prefill_requests(model, reqs, max_tokens, width)
+    if pre is None:
+        return generate_rows(model, processor, collate_requests(reqs, width=width), max_tokens, return_tokens)
+    token, cache, order = pre
+    streamer = api.Streamer(processor, False, True)
+    stopper = api.TokenStopper(processor, len(reqs))
+    streamer(api._rows(token))
+    for _ in range(max_tokens - 1):
+        _, token = model.greedy_step(token, cache)
+        rows = api._rows(token)
+        streamer(rows)
+        if stopper(rows):
+            break
+    if return_tokens:
+        per_slot = [list(r) for r in zip(*streamer.list_tokens)]
+        per_slot = [(r[:r.index(api.ID_EOS) + 1] if api.ID_EOS in r else r) for r in per_slot]
+    else:
+        per_slot = list(streamer.end()[0])
+    out = [None] * len(reqs)
+    for slot, i in enumerate(order):
+        out[i] = per_slot[slot]
+    return out
 
 
 def generate_rows(model, processor, rows, max_tokens, return_tokens=False):

@@ -351,13 +351,19 @@ class Phi3VModel:
         return st
 
     @_on_device
-    def prefill_slot(self, st, row, inputs):
-        """Prefill one request (a B = 1 `processor(...)` result) into batch row `row` of a slot state so that its LAST prompt
-        token sits in column st.offset - 1: left padding pad = st.offset - S, position ids 0..S-1 from column pad on.
-        Keys left of `pad` (stale rows of an earlier occupant) are masked by pad_len.  Returns the first greedy token
-        (int32 [1, 1] on the device).  The row computes what a B = 1 run of the request computes (pad invariance)."""
+    def prefill_slot(self, st, row, inputs, return_logits=False):
+        """Prefill one request (a B = 1 `processor(...)` result) -- or n requests of EQUAL length as one batch (`inputs` with
+        n rows and no padding, e.g. `collate_requests` of equally long prompts) -- into the batch rows row .. row+n-1 of a slot
+        state so that the LAST prompt token sits in column st.offset - 1: left padding pad = st.offset - S, position ids
+        0..S-1 from column pad on.  Keys left of `pad` (stale rows of an earlier occupant) are masked by pad_len.
+        Returns the first greedy tokens (int32 [n, 1] on the device; with return_logits also the last-position logits).
+        Each row computes what a B = 1 run of its request computes (pad invariance)."""
         cfg = self.cfg
-        S = int(np.asarray(inputs["input_ids"]).shape[-1])
+        ids = np.asarray(inputs["input_ids"])
+        ids = ids[None] if ids.ndim == 1 else ids
+        n, S = ids.shape
+        if "mask" in inputs and int(np.asarray(inputs["mask"]).sum()) != n * S:
+            raise ValueError("prefill_slot takes requests of equal length (no padding inside the group)")
         pad = st.offset - S
         if pad < 0:
             raise ValueError(f"prompt of {S} tokens does not fit left of column {st.offset}")
@@ -366,17 +372,17 @@ class Phi3VModel:
                           * (torch.tensor(float(cfg.rope_theta), dtype=F32) ** (torch.arange(0, self.hd, 2, dtype=F32) / self.hd)))
         pos = (torch.arange(st.T, dtype=F32) - pad).clamp_min(0).to(self.device)
         cos, sin = ops.rope_table(pos, inv_freq.to(self.device), rope_scaling_factor(cfg))
-        st.cos[row].copy_(cos.view(st.T, half)), st.sin[row].copy_(sin.view(st.T, half))
-        st.pad_len[row:row + 1].fill_(pad)
-        view = CacheState.__new__(CacheState)                   # this row as a one-row cache at offset `pad`
-        view.__dict__.update(B=1, S=S, max_tokens=st.max_tokens, T=st.T, Tp=st.Tp, quantized=False, offset=pad, graphs={}, epoch=self.epoch,
-                             k=st.k[:, row:row + 1], v=st.v[:, row:row + 1], cos=st.cos[row:row + 1], sin=st.sin[row:row + 1],
-                             pad_len=st.pad_len[row:row + 1])
+        rows = slice(row, row + n)
+        st.cos[rows].copy_(cos.view(1, st.T, half).expand(n, -1, -1)), st.sin[rows].copy_(sin.view(1, st.T, half).expand(n, -1, -1))
+        st.pad_len[rows].fill_(pad)
+        view = CacheState.__new__(CacheState)                   # these rows as an n-row cache at offset `pad`
+        view.__dict__.update(B=n, S=S, max_tokens=st.max_tokens, T=st.T, Tp=st.Tp, quantized=False, offset=pad, graphs={}, epoch=self.epoch,
+                             k=st.k[:, rows], v=st.v[:, rows], cos=st.cos[rows], sin=st.sin[rows], pad_len=st.pad_len[rows])
         kw = {k: v for k, v in inputs.items() if k in ("pixel_values", "image_sizes", "positions")}
-        logits, _ = self(input_ids=inputs["input_ids"], cache=[LayerCache(view, i) for i in range(cfg.num_hidden_layers)],
-                         full_logits=False, **kw)
+        logits, _ = self(input_ids=ids, cache=[LayerCache(view, i) for i in range(cfg.num_hidden_layers)], full_logits=False, **kw)
         assert view.offset == st.offset
-        return ops.argmax(logits[:, -1, :].contiguous())[:, None]
+        tok = ops.argmax(logits[:, -1, :].contiguous())[:, None]
+        return (tok, logits) if return_logits else tok
 
     @_on_device
     def decode_graph(self, st):
@@ -432,9 +438,12 @@ class Phi3VModel:
             fused = (n_split in (tiles, tiles128) or mode == "2") and n_split <= 48 and mode != "0"
             bufs["attn_cnt"] = torch.zeros(B * nh * n_split, dtype=I32, device=self.device) if fused else None
 
-    def _layers(self, x, st, B, L, past, n_beam, bufs=None, d_past=None):
+    def _layers(self, x, st, B, L, past, n_beam, bufs=None, d_past=None, last_only=False):
         """Phi3DecoderLayer stack (phi.py:473-485).  `d_past` (device int32) makes every
-        position-dependent kernel read the cache length from HBM -> graph-replayable."""
+        position-dependent kernel read the cache length from HBM -> graph-replayable.
+        last_only: the caller reads the LAST position only (prefill of generate / choose, Q8): the final layer still builds
+        K / V for every position, but its o_proj and MLP run on the B last rows alone (0.4 ms of a 30 ms prefill);
+        returns [B, H] then."""
         cfg, w = self.cfg, self.w
         nh, nkv, hd, eps = cfg.num_attention_heads, cfg.num_key_value_heads, self.hd, cfg.rms_norm_eps
         M = B * L
@@ -485,6 +494,10 @@ class Phi3VModel:
                 ops.rope_kv_append(qkv, st.cos, st.sin, q, st.k[i], st.v[i], B, L, nh, nkv, hd, past, st.Tp, True, st.T, 1)
                 ops.attention(q, o, B, L, nh, nkv, hd, scale, True, past=past, k_past=st.k[i], v_past=st.v[i],
                               past_t=st.Tp, pad_len=st.pad_len, new_is_cache=True)
+            if last_only and i == cfg.num_hidden_layers - 1 and L > 1:
+                o = o.view(B, L, -1)[:, -1].contiguous()
+                x = x.view(B, L, -1)[:, -1].contiguous()
+                a, h = a[:B], h[:B]
             self._proj(o, p + "self_attn.o_proj.weight", EPI_RESID_BF16, resid=x, out=x)
             self._proj(x, p + "mlp.gate_up_proj.weight", EPI_SILU_MUL, norm_w=w[p + "post_attention_layernorm.weight"], out=a, h=h)
             self._proj(a, p + "mlp.down_proj.weight", EPI_RESID_BF16, resid=x, out=x)
@@ -594,14 +607,14 @@ class Phi3VModel:
         past = st.offset
         if n_beam == 1 and past + L > st.T:
             raise ValueError(f"KV cache overflow: {past}+{L} > {st.T} (prompt + max_tokens)")
-        x = self._layers(x, st, B, L, past, n_beam)
+        if full_logits is None:
+            full_logits = not prefill
+        x = self._layers(x, st, B, L, past, n_beam, last_only=not full_logits)
         if n_beam == 1:
             st.offset = past + L                                 # KVCache.__call__ auto-advance (phi.py:544-547)
         if advance_offset is not None:
             st.offset = past + advance_offset                    # phi.py:589-591
-        if full_logits is None:
-            full_logits = not prefill
-        if not full_logits:
+        if not full_logits and x.shape[0] != B:
             x = x.view(B, L, H)[:, -1, :].contiguous()
         logits = self._proj(x, "lm_head.weight", norm_w=w["model.norm.weight"])
         return logits.view(B, -1, cfg.vocab_size), cache

@@ -536,6 +536,21 @@ def test_c4_share_batched_vs_per_request_oracle():
             logits, _ = model.greedy_step(ref_tok[:, step:step + 1].to("cuda:0", torch.int32), cache)
     assert bool((clearance[:, 0] > 1).all()) and n_exact == int((clearance > 1).sum()) and n_exact >= 12
     print(f"C4 share: {n_exact} of {clearance.numel()} (row, step) tokens exact (all clear ones), worst logit error {worst:.2f} x tolerance")
+    # the same share through the length-bucketed path (dist.prefill_requests: no projection ever runs on a pad row; equal-length
+    # requests are prefilled together straight into rows of a slot state, decode is one B = 8 batch): free-running greedy
+    # tokens of every request equal the oracle's as long as the steps are clear
+    from phi_3_vision_mlx_amd.dist import generate_requests
+    dev_share = [dict(r, pixel_values=torch.from_numpy(r["pixel_values"]).to("cuda:0")) if "pixel_values" in r else r for r in share]
+    toks = generate_requests(model, proc, dev_share, n, return_tokens=True)
+    n_free = 0
+    for r in range(len(share)):
+        for step in range(n):
+            if clearance[r, step] <= 1:
+                break
+            assert toks[r][step] == int(ref_tok[r, step]), (r, step, toks[r], ref_tok[r].tolist())
+            n_free += 1
+    assert n_free >= 12
+    print(f"C4 share, length-bucketed prefill: {n_free} free-running tokens exact")
     del model, cache
     torch.cuda.empty_cache()
 
