@@ -2147,6 +2147,233 @@ __global__ void __launch_bounds__(256) k_attn_decode_q8s(AttnDecQ8P p) {
   }
 }
 
+// ---- int8 twin of k_attn_decode128 (round 2): 4 waves x one 128-key tile, wave w owns keys [32w, 32w + 32).
+// The RAW BYTES go HBM -> LDS by LDS-DMA (K slice: 32 rows x 96 B, contiguous in the cache; V^T tile by rows: 96 x 128 B,
+// 16-byte chunk c of row d stored at c ^ (d & 7)) -- half the bytes of the bf16 kernel and no pass through registers --
+// and become fp16 operands (1024 + code, see u8x16_to_f16) only when a fragment is read: ds_read_b64 / 2 x ds_read_b32 +
+// v_perm_b32.  Scales ride in registers (two float4 per lane and operand).  New rows: rotated exactly, quantised one row
+// per wave (the step attends over what it stores, phi.py:545-546), patched into the byte tile + scale registers' LDS
+// copy + the cache.  In-launch split merge as the bf16 kernel.
+__global__ void __launch_bounds__(256) k_attn_decode128_q8(AttnDecQ8P p) {
+  constexpr int TK = 128, WK = 32, HD = 96, KROWB = HD, VROWB = TK, NKS = 3, NDT = 6, CPR = 12, KROW = HD * 2;
+  constexpr int KS_BYTES = WK * KROWB;                         // 3 KiB of key bytes per wave
+  __shared__ __attribute__((aligned(1024))) unsigned char KV[4 * 6144];   // [K bytes x 4 waves (12 KiB) | V^T bytes (12 KiB)]; later 4 x O partial
+  __shared__ __attribute__((aligned(16))) unsigned char Qs[16 * KROW];    // rotated Q, fp16
+  __shared__ __attribute__((aligned(16))) unsigned char Kx[16 * KROW], Vx[16 * KROW];   // exact new rows [r][96] bf16
+  __shared__ __attribute__((aligned(16))) float ksl[TK], vsl[TK];
+  __shared__ float Ml[4][16][2];
+  const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, qi = lane & 15;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int b = blockIdx.z, head = blockIdx.y, kvh = (head * p.grp_magic) >> 16;
+  const bool kv_writer = head == kvh * p.grp;
+  unsigned char* kslice = KV + wave * KS_BYTES;
+  unsigned char* vtile = KV + 4 * KS_BYTES;
+  const size_t bh = (size_t)b * p.nkv + kvh;
+  uint8_t* kc = p.k8 + bh * (size_t)p.cache_t * HD;
+  uint8_t* vc = p.v8 + bh * (size_t)HD * p.cache_t;
+  float* ksc = p.ksc + bh * p.cache_t;
+  float* vsc = p.vsc + bh * p.cache_t;
+
+  int past = p.past, pad = 0;
+  if (p.d_past) asm volatile("s_load_dword %0, %1, 0x0" : "=s"(past) : "s"(p.d_past) : "memory");
+  if (p.pad_len) asm volatile("s_load_dword %0, %1, 0x0" : "=s"(pad) : "s"(p.pad_len + b) : "memory");
+
+  const int kv_lo = blockIdx.x * TK, kv_hi = min(p.cache_t, kv_lo + TK);
+  const int kvd = min(kv_lo, p.cache_t - TK);                  // tile actually fetched (an empty split fetches one it never uses)
+  {
+    const unsigned char* ksrc = kc + (size_t)(kvd + WK * wave) * KROWB;
+#pragma unroll
+    for (int j = 0; j < 3; ++j)                                // K bytes: 3 KiB per wave, linear
+      __builtin_amdgcn_global_load_lds((dec_gptr_t)(ksrc + j * 1024 + lane * 16), (dec_lptr_t)(kslice + j * 1024), 16, 0, P3V_ATTN_AUX);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {                              // V^T bytes: wave w brings rows 24w..24w+23, 8 rows of 128 B per instruction
+      const int d = 24 * wave + 8 * j + (lane >> 3);
+      const unsigned char* src = vc + (size_t)d * p.cache_t + kvd + ((((unsigned)lane & 7) ^ ((unsigned)d & 7)) << 4);
+      __builtin_amdgcn_global_load_lds((dec_gptr_t)src, (dec_lptr_t)(vtile + wave * 3072 + j * 1024), 16, 0, P3V_ATTN_AUX);
+    }
+  }
+  // scales of the tile -> LDS (patched for new rows below), one float per thread
+  if (tid < TK) ksl[tid] = ksc[kvd + tid];
+  else vsl[tid - TK] = vsc[kvd + tid - TK];
+
+  // ---- the L new rows: Q (rotated, fp16 -> Qs), K / V exact (bf16, parked for the quantiser)
+  const int row_w = (p.nh + 2 * p.nkv) * HD;
+  const float* cos_b = p.cos_t + (size_t)b * p.rope_bstride * (HD / 2);
+  const float* sin_b = p.sin_t + (size_t)b * p.rope_bstride * (HD / 2);
+  const int tr = tid / CPR, tc = tid - tr * CPR;
+  const bool rtask = tr < p.L;
+  const int n_vnew = p.L * HD;
+  if (tid < 16 * CPR) {
+    u32x4_t qv = {0, 0, 0, 0};
+    if (rtask) {
+      const bf16_t* row = p.qkv + ((size_t)b * p.L + tr) * row_w;
+      const RopeRaw qraw = rope_fetch(row + head * HD, tc, cos_b + tr * (HD / 2), sin_b + tr * (HD / 2));
+      RopeRaw kraw = qraw;
+      const bf16_t* krow = row + (p.nh + kvh) * HD;
+      kraw.x0 = *(const u32x4_t*)(krow + tc * 8);
+      kraw.x1 = *(const u32x4_t*)(krow + (tc < 6 ? tc * 8 + 48 : tc * 8 - 48));
+      qv = rope_apply<true>(qraw, tc);
+      *(u32x4_t*)(Kx + tr * KROW + tc * 16) = rope_apply(kraw, tc);
+    }
+    *(u32x4_t*)(Qs + tr * KROW + ((tc ^ ((tr >> 2) & 3)) << 4)) = qv;
+  }
+  {
+    const bf16_t* vnew = p.qkv + (size_t)b * p.L * row_w + (p.nh + p.nkv + kvh) * HD;
+#pragma unroll 1
+    for (int idx = tid; idx < n_vnew; idx += 256) {
+      const int r = idx / HD, d = idx - r * HD;
+      *(bf16_t*)(Vx + r * KROW + d * 2) = vnew[(size_t)r * row_w + d];
+    }
+  }
+
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(past), "+s"(pad)::"memory");
+  const int total = past + p.L;
+  const int kv_end = min(total, kv_hi);
+  const int qpos = past + qi;
+  const bool qvalid = qi < p.L;
+  const float sc2 = p.scale * 1.4426950408889634f;
+  const unsigned q_rd = qi * KROW + ((g ^ ((qi >> 2) & 3)) << 4);          // + ks*64 (fp16 Q, swizzled as the bf16 kernels')
+
+  float m_run = -INFINITY, l_run = 0.f, p_sum = 0.f;
+  f32x4_t o[NDT];
+#pragma unroll
+  for (int d = 0; d < NDT; ++d) o[d] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  const int kv0 = kv_lo;
+  if (kv0 < kv_end) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wave's DMA pieces and scale loads have landed
+    __syncthreads();                                           // Qs / Kx / Vx / scales complete, every wave's slices are in LDS
+    if (kv0 + TK > past) {
+#pragma unroll 1
+      for (int r = wave; r < p.L; r += 4) {                    // one new row per wave at a time
+        const int t = past + r, rr = t - kv0;
+        if (rr < 0 || rr >= TK || t >= kv_end) continue;
+        const float ka = lane < 48 ? bf16_to_f32(*(const bf16_t*)(Kx + r * KROW + 4 * lane)) : 0.f;
+        const float kb = lane < 48 ? bf16_to_f32(*(const bf16_t*)(Kx + r * KROW + 4 * lane + 2)) : 0.f;
+        const float kmax = wave_max(fmaxf(fabsf(ka), fabsf(kb)));
+        const float sk = kmax > 0.f ? kmax / 127.f : 1.f, inv = 1.f / sk;
+        const int qa = (int)rintf(ka * inv) + 128, qb = (int)rintf(kb * inv) + 128;
+        const float va = bf16_to_f32(*(const bf16_t*)(Vx + r * KROW + lane * 2));
+        const float vb = lane < 32 ? bf16_to_f32(*(const bf16_t*)(Vx + r * KROW + (lane + 64) * 2)) : 0.f;
+        const float vmx = wave_max(fmaxf(fabsf(va), fabsf(vb)));
+        const float sv = vmx > 0.f ? vmx / 127.f : 1.f, invv = 1.f / sv;
+        const int qva = (int)rintf(va * invv) + 128, qvb = (int)rintf(vb * invv) + 128;
+        if (lane < 48) *(uint16_t*)(KV + (rr >> 5) * KS_BYTES + (rr & 31) * KROWB + 2 * lane) = (uint16_t)(qa | (qb << 8));
+        vtile[lane * VROWB + ((((rr >> 4)) ^ (lane & 7)) << 4) + (rr & 15)] = (unsigned char)qva;
+        if (lane < 32) vtile[(lane + 64) * VROWB + ((((rr >> 4)) ^ ((lane + 64) & 7)) << 4) + (rr & 15)] = (unsigned char)qvb;
+        if (lane == 0) { ksl[rr] = sk; vsl[rr] = sv; }
+        if (kv_writer) {
+          if (lane < 48) *(uint16_t*)(kc + (size_t)t * HD + 2 * lane) = (uint16_t)(qa | (qb << 8));
+          vc[(size_t)lane * p.cache_t + t] = (uint8_t)qva;
+          if (lane < 32) vc[(size_t)(lane + 64) * p.cache_t + t] = (uint8_t)qvb;
+          if (lane == 0) { ksc[t] = sk; vsc[t] = sv; }
+        }
+      }
+      __syncthreads();
+    }
+    f16x8_t qf[NKS];
+    float qoff = 0.f;                                          // 1152 * sum_d q[d] of this lane's query (the folded K offsets)
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+      qf[ks] = *(const f16x8_t*)(Qs + q_rd + ks * 64);
+      const u32x4_t qw = __builtin_bit_cast(u32x4_t, qf[ks]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) qoff += f16lo(qw[j]) + f16hi(qw[j]);
+    }
+    qoff = Q8_OFF * rows_sum(qoff);
+
+    f32x4_t s[2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      s[kb] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks) {                       // key row 16kb + qi, k = 32ks + 8g .. +7: eight code bytes
+        const u32x2_t kb8 = *(const u32x2_t*)(kslice + (16 * kb + qi) * KROWB + 32 * ks + 8 * g);
+        const u32x4_t kw = {__builtin_amdgcn_perm(0x64646464u, kb8[0], 0x04010400u), __builtin_amdgcn_perm(0x64646464u, kb8[0], 0x04030402u),
+                            __builtin_amdgcn_perm(0x64646464u, kb8[1], 0x04010400u), __builtin_amdgcn_perm(0x64646464u, kb8[1], 0x04030402u)};
+        s[kb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, kw), qf[ks], s[kb], 0, 0, 0);
+      }
+    }
+    float m_t = -INFINITY;
+    f32x4_t vsv[2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      const f32x4_t kk = *(const f32x4_t*)(ksl + WK * wave + 16 * kb + 4 * g);
+      vsv[kb] = *(const f32x4_t*)(vsl + WK * wave + 16 * kb + 4 * g);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int t = kv0 + WK * wave + 16 * kb + 4 * g + r;
+        const bool vis = t < kv_end && t >= pad && t <= qpos && qpos >= pad;
+        s[kb][r] = vis ? (s[kb][r] - qoff) * kk[r] * sc2 : -INFINITY;
+        m_t = fmaxf(m_t, s[kb][r]);
+      }
+    }
+    m_t = rows_max(m_t);
+    const float m_use = m_t == -INFINITY ? 0.f : m_t;
+    float l_t = 0.f, p_t = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float e = __builtin_amdgcn_exp2f(s[kb][r] - m_use);
+        l_t += e;
+        s[kb][r] = f16_round(e > 0.f ? e * vsv[kb][r] : 0.f);  // V scale folded into P (masked keys stay exactly 0)
+        p_t += s[kb][r];
+      }
+    l_run = rows_sum(l_t);
+    p_sum = rows_sum(p_t);
+    m_run = m_t;
+    const u32x4_t pw = {pack_f16x2(s[0][0], s[0][1]), pack_f16x2(s[0][2], s[0][3]), pack_f16x2(s[1][0], s[1][1]), pack_f16x2(s[1][2], s[1][3])};
+    const f16x8_t pf = __builtin_bit_cast(f16x8_t, pw);
+#pragma unroll
+    for (int d = 0; d < NDT; ++d) {                            // V^T row 16d + qi, keys 32w + 16kb + 4g .. +3: four code bytes per block
+      const int row = 16 * d + qi;
+      const unsigned char* vr = vtile + row * VROWB + 4 * g;
+      const uint32_t v0 = *(const uint32_t*)(vr + (((2 * wave) ^ (row & 7)) << 4)), v1 = *(const uint32_t*)(vr + (((2 * wave + 1) ^ (row & 7)) << 4));
+      const u32x4_t aw = {__builtin_amdgcn_perm(0x64646464u, v0, 0x04010400u), __builtin_amdgcn_perm(0x64646464u, v0, 0x04030402u),
+                          __builtin_amdgcn_perm(0x64646464u, v1, 0x04010400u), __builtin_amdgcn_perm(0x64646464u, v1, 0x04030402u)};
+      o[d] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, aw), pf, o[d], 0, 0, 0);
+    }
+  }
+
+  // ---- merge the four wave partials through the (dead) byte tiles; the folded V offset leaves here
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (qvalid) {
+    float* Ow = (float*)(KV + wave * 6144) + qi * HD;
+    const float voff = Q8_OFF * p_sum;
+#pragma unroll
+    for (int d = 0; d < NDT; ++d) *(f32x4_t*)(Ow + 16 * d + 4 * g) = o[d] - voff;
+    if (g == 0) { Ml[wave][qi][0] = m_run; Ml[wave][qi][1] = l_run; }
+  }
+  __syncthreads();
+#pragma unroll 1
+  for (int idx = tid; idx < n_vnew; idx += 256) {
+    const int q = idx / HD, d = idx - q * HD;
+    float mk[4], M = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { mk[k] = Ml[k][q][0]; M = fmaxf(M, mk[k]); }
+    const float Mu = M == -INFINITY ? 0.f : M;
+    float acc = 0.f, lsum = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float c = __builtin_amdgcn_exp2f(mk[k] - Mu);
+      acc += c * ((const float*)(KV + k * 6144))[q * HD + d];
+      lsum += c * Ml[k][q][1];
+    }
+    float* w = p.ws + ((((size_t)b * p.nh + head) * p.n_split + blockIdx.x) * 16 + q) * (HD + 2);
+    st_wt(w + d, acc);
+    if (d == 0) { st_wt(w + HD, M); st_wt(w + HD + 1, lsum); }
+  }
+  if (p.counters) {
+    int32_t* flags = p.counters + ((size_t)b * p.nh + head) * p.n_split;
+    const int role = split_publish_and_wait(flags, blockIdx.x, p.n_split);
+    if (role)
+      split_merge<256>(p.ws + ((size_t)b * p.nh + head) * p.n_split * 16 * (HD + 2), p.out + (size_t)b * p.L * (p.nh * HD) + head * HD,
+                       (size_t)p.nh * HD, p.L, p.n_split, flags, role == 2, (float*)Kx);
+  }
+}
+
 extern "C" int p3v_attention_decode_q8(const p3v_attn_decode_q8_args_t* a, void* stream) {
   if (!a || !a->qkv || !a->cos_t || !a->sin_t || !a->k8 || !a->v8t || !a->k_scale || !a->v_scale || !a->out || !a->ws)
     return P3V_ERR_ARG;
@@ -2164,6 +2391,16 @@ extern "C" int p3v_attention_decode_q8(const p3v_attn_decode_q8_args_t* a, void*
   // merges the splits inside the launch.  Beyond that the single-wave kernel + merge launch is as fast or faster
   // (measured at 42 tiles, config 5 decode: 1.543 ms/step against 1.560 with the 4-wave kernel + fused merge: its
   // bytes go through registers and a ds_write pass into the fp16 images, where the bf16 kernel uses LDS-DMA).
+  if (!old_only && a->cache_t % 128 == 0 && a->n_split * 128 >= a->cache_t && a->n_split * 64 < a->cache_t) {   // 128-key tiles
+    p.counters = a->counters;
+    hipLaunchKernelGGL(k_attn_decode128_q8, grid, dim3(256), 0, s, p);
+    P3V_CHECK_LAUNCH();
+    if (a->counters) return P3V_OK;
+    hipLaunchKernelGGL(k_attn_combine2, dim3(a->B * a->n_heads * a->L), dim3(combine_threads(a->n_split)), 0, s, a->ws, a->out, a->L, a->n_heads,
+                       a->hd, a->n_split);
+    P3V_CHECK_LAUNCH();
+    return P3V_OK;
+  }
   const bool single_tile = !old_only && a->n_split * 64 >= a->cache_t && a->n_split <= 16;
   if (single_tile && a->counters) {
     p.counters = a->counters;

@@ -64,8 +64,8 @@ class CacheState:
         self.T = S + max(max_tokens, 0)
         self.quantized = bool(getattr(cfg, "use_quantized_cache", False))
         # row/column stride of the caches: whole 128-key tiles (the decode attention takes one 128-key tile per workgroup
-        # when the capacity allows it); the int8 kernels work on 64-key tiles
-        gran = 64 if self.quantized else 128
+        # when the capacity allows it)
+        gran = 128
         self.Tp = (self.T + gran - 1) // gran * gran
         if self.Tp % 512 == 0:
             # V^T rows are Tp * 2 bytes apart: at multiples of 1 KiB the 96 rows of a tile crowd the same memory channels
@@ -416,7 +416,7 @@ class Phi3VModel:
             # next 24 KB tile in flight) walking several tiles
             tiles = -(-T // 64)
             tiles128 = T // 128 if T % 128 == 0 else 0           # T is the cache CAPACITY when the plan is for a captured graph
-            if not quantized and tiles128 and tiles > 16 and tiles128 <= 48 and B * nh * tiles128 <= 2048 \
+            if tiles128 and tiles > 16 and tiles128 <= 48 and B * nh * tiles128 <= 2048 \
                     and os.environ.get("P3V_ATTN_TILE128", "1") != "0":
                 # one 128-key tile per workgroup: every workgroup of the launch resident at once (3 per CU), half the
                 # partials to merge (k_attn_decode128).  Short caches keep 64-key tiles (more workgroups than CUs matters more)

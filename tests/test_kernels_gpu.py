@@ -352,11 +352,13 @@ def _dequant(u8, sc, axis):
 
 
 @pytest.mark.parametrize("past,L,n_split,fused", [(200, 1, 3, False), (200, 1, 4, False), (190, 3, 4, False), (62, 5, 4, False),
-                                                   (200, 1, 4, True), (62, 5, 4, True)])
+                                                   (200, 1, 4, True), (62, 5, 4, True),
+                                                   (200, 1, 2, False), (200, 1, 2, True), (126, 5, 2, True), (30, 16, 2, False)])
 def test_kv_quantize_and_q8_decode(ops, orc, past, L, n_split, fused):
     """int8 KV: (a) quantiser = round(x/s)+128 with s = amax/127 per token, (b) the q8 decode attention equals the
     bf16 oracle attention over the DEQUANTISED cache, (c) the appended rows are stored quantised.
-    n_split 3 -> multi-tile single-wave kernel, 4 (= tiles) -> single-tile 4-wave kernel; (62, 5) crosses a tile boundary;
+    n_split 3 -> multi-tile single-wave kernel, 4 (= tiles) -> single-tile 4-wave kernel, 2 (= one split per 128 keys) ->
+    k_attn_decode128_q8 (raw bytes by LDS-DMA, fp16 conversion at fragment read); (62, 5) / (126, 5) cross a tile boundary;
     fused: the split partials are merged inside the attention launch (ready flags), twice in a row (the flags re-arm)."""
     from phi_3_vision_mlx_amd.config import make_config, rope_scaling_factor
     cfg = make_config()
