@@ -1641,12 +1641,104 @@ __global__ void __launch_bounds__(256) k_kv_quantize(const bf16_t* __restrict__ 
   }
 }
 
+// Vector-access version (t0 % 8 == 0, src_t % 8 == 0, dst_t % 8 == 0, hd == 96: every prefill): the first version went
+// through 2-byte loads and one dependent row per wave and pass (34 us per layer at 2531 tokens, 1.1 ms of a config-5
+// prefill).  K: thread = one 16-byte chunk (8 dims) of a row, 12 chunks per row, 16 lanes per row -> row maximum by DPP
+// inside the 16-lane row; V^T: thread = 8 tokens of one dim, per-token maximum over the 96 dims through LDS atomics on
+// the (non-negative) float bits.  Same arithmetic as k_kv_quantize: s = amax / 127, code = rint(x * (1 / s)) + 128 for K,
+// rint(x / s) + 128 for V.
+__global__ void __launch_bounds__(256) k_kv_quantize_v(const bf16_t* __restrict__ k, const bf16_t* __restrict__ vt,
+                                                       uint8_t* __restrict__ k8, uint8_t* __restrict__ v8,
+                                                       float* __restrict__ ksc, float* __restrict__ vsc, int src_t, int dst_t,
+                                                       int t0, int n_tok) {
+  constexpr int HD = 96;
+  __shared__ unsigned vmax_bits[64];
+  const int bh = blockIdx.y, tt = blockIdx.x * 64, tid = threadIdx.x, lane = tid & 63;
+  if (tid < 64) vmax_bits[tid] = 0u;
+  // ---- V^T loads first (3 chunks of 8 tokens per thread): thread -> (dim d, token chunk c)
+  u32x4_t vv[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const int i = j * 256 + tid, d = i >> 3, c = i & 7;
+    vv[j] = *(const u32x4_t*)(vt + ((size_t)bh * HD + d) * src_t + t0 + tt + 8 * c);
+  }
+  // ---- K: 4 passes of 16 rows; lane group of 16 = one row, lanes 0..11 hold its 12 chunks
+#pragma unroll
+  for (int pass = 0; pass < 4; ++pass) {
+    const int r = pass * 16 + (tid >> 4), c = tid & 15, t = t0 + tt + r;
+    const bool live = c < 12 && tt + r < n_tok;
+    u32x4_t w = {0u, 0u, 0u, 0u};
+    if (live) w = *(const u32x4_t*)(k + ((size_t)bh * src_t + t) * HD + c * 8);
+    float amax = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) amax = fmaxf(amax, fmaxf(fabsf(bf16lo(w[j])), fabsf(bf16hi(w[j]))));
+    amax = fmaxf(amax, P3V_DPP_F32(amax, 0xB1));
+    amax = fmaxf(amax, P3V_DPP_F32(amax, 0x4E));
+    amax = fmaxf(amax, P3V_DPP_F32(amax, 0x124));
+    amax = fmaxf(amax, P3V_DPP_F32(amax, 0x128));                // maximum over the 16-lane row
+    const float sc = amax > 0.f ? amax / 127.f : 1.f, inv = 1.f / sc;
+    if (live) {
+      u32x2_t o;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int q0 = (int)rintf(bf16lo(w[2 * h]) * inv) + 128, q1 = (int)rintf(bf16hi(w[2 * h]) * inv) + 128;
+        const int q2 = (int)rintf(bf16lo(w[2 * h + 1]) * inv) + 128, q3 = (int)rintf(bf16hi(w[2 * h + 1]) * inv) + 128;
+        o[h] = (uint32_t)q0 | ((uint32_t)q1 << 8) | ((uint32_t)q2 << 16) | ((uint32_t)q3 << 24);
+      }
+      *(u32x2_t*)(k8 + ((size_t)bh * dst_t + t) * HD + c * 8) = o;
+      if (c == 0) ksc[(size_t)bh * dst_t + t] = sc;
+    }
+  }
+  // ---- V^T: per-token maximum over d
+  __syncthreads();                                               // vmax_bits cleared
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const int c = (j * 256 + tid) & 7;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      atomicMax(&vmax_bits[8 * c + 2 * e], __float_as_uint(fabsf(bf16lo(vv[j][e]))));
+      atomicMax(&vmax_bits[8 * c + 2 * e + 1], __float_as_uint(fabsf(bf16hi(vv[j][e]))));
+    }
+  }
+  __syncthreads();
+  if (tid < 64 && tt + tid < n_tok) {
+    const float m = __uint_as_float(vmax_bits[tid]);
+    vsc[(size_t)bh * dst_t + t0 + tt + tid] = m > 0.f ? m / 127.f : 1.f;
+  }
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const int i = j * 256 + tid, d = i >> 3, c = i & 7;
+    uint32_t o[2] = {0u, 0u};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float m = __uint_as_float(vmax_bits[8 * c + e]);
+      const float sc = m > 0.f ? m / 127.f : 1.f;
+      const float x = (e & 1) ? bf16hi(vv[j][e >> 1]) : bf16lo(vv[j][e >> 1]);
+      o[e >> 2] |= (uint32_t)(((int)rintf(x / sc) + 128) & 0xff) << (8 * (e & 3));
+    }
+    uint8_t* dst = v8 + ((size_t)bh * HD + d) * dst_t + t0 + tt + 8 * c;
+    if (tt + 8 * c + 8 <= n_tok) {
+      *(u32x2_t*)dst = (u32x2_t){o[0], o[1]};
+    } else {
+      for (int e = 0; e < 8; ++e)
+        if (tt + 8 * c + e < n_tok) dst[e] = (uint8_t)(o[e >> 2] >> (8 * (e & 3)));
+    }
+  }
+}
+
 extern "C" int p3v_kv_quantize(const uint16_t* k, const uint16_t* vt, uint8_t* k8, uint8_t* v8t, float* k_scale,
                                float* v_scale, int BH, int hd, int src_t, int dst_t, int t0, int n_tok, void* stream) {
   if (!k || !vt || !k8 || !v8t || !k_scale || !v_scale || BH <= 0 || hd > 96 || hd % 2 || n_tok < 0) return P3V_ERR_ARG;
   if (n_tok == 0) return P3V_OK;
-  hipLaunchKernelGGL(k_kv_quantize, dim3(p3v_cdiv(n_tok, 64), BH), dim3(256), 0, (hipStream_t)stream, k, vt, k8, v8t,
-                     k_scale, v_scale, hd, src_t, dst_t, t0, n_tok);
+  static const bool old_only = getenv("P3V_KVQ_OLD") != nullptr;     // A/B knob
+  const bool whole_tiles = (long)p3v_cdiv(n_tok, 64) * 64 + t0 <= src_t;   // the vector kernel reads whole 64-token tiles
+  if (!old_only && hd == 96 && t0 % 8 == 0 && src_t % 8 == 0 && dst_t % 8 == 0 && whole_tiles && !(((uintptr_t)k | (uintptr_t)vt) & 15) &&
+      !(((uintptr_t)k8 | (uintptr_t)v8t) & 7))
+    hipLaunchKernelGGL(k_kv_quantize_v, dim3(p3v_cdiv(n_tok, 64), BH), dim3(256), 0, (hipStream_t)stream, k, vt, k8, v8t,
+                       k_scale, v_scale, src_t, dst_t, t0, n_tok);
+  else
+    hipLaunchKernelGGL(k_kv_quantize, dim3(p3v_cdiv(n_tok, 64), BH), dim3(256), 0, (hipStream_t)stream, k, vt, k8, v8t,
+                       k_scale, v_scale, hd, src_t, dst_t, t0, n_tok);
   P3V_CHECK_LAUNCH();
   return P3V_OK;
 }
