@@ -153,7 +153,8 @@ def prefill_requests(model, reqs, max_tokens, width=None):
     model has no slot states or prompt + max_tokens leaves the short-RoPE window (callers then take the padded batch)."""
     lens = [int(np.asarray(r["input_ids"]).shape[-1]) for r in reqs]
     W = max(max(lens), width or 0)
-    if not hasattr(model, "new_slot_state") or W + max_tokens > model.cfg.original_max_position_embeddings:
+    if not hasattr(model, "new_slot_state") or W + max_tokens > model.cfg.original_max_position_embeddings \
+            or getattr(model.cfg, "use_quantized_cache", False):
         return None
     from .processor import collate_requests
     order = sorted(range(len(reqs)), key=lambda i: (-lens[i], i))

@@ -345,6 +345,8 @@ class Phi3VModel:
         (4096): the short RoPE factors, which is what each request alone would pick (phi.py:492)."""
         if window > self.cfg.original_max_position_embeddings:
             raise ValueError("the slot window must stay inside the short-RoPE regime")
+        if getattr(self.cfg, "use_quantized_cache", False):
+            raise NotImplementedError("slot states keep a bf16 KV cache (quantize_cache=True is not supported by the engine)")
         st = self._new_state(slots, 0, window, None, None)
         st.pad_len = torch.full((slots,), window, dtype=I32, device=self.device)
         st.slots = True
