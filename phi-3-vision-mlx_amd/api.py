@@ -54,10 +54,12 @@ class Tic:
 
 
 def _rows(token):
-    """token: int tensor [B,1] / [B] or nested list -> list[int] per row (one D2H copy)."""
-    if torch.is_tensor(token):
-        return token.reshape(-1).tolist()
-    return np.asarray(token).reshape(-1).tolist()
+    """token: int tensor [B,1] / [B] or nested list -> list[int] per row (one D2H copy).  A negative id is the device's
+    report of a failed step (NaN logits, see p3v_argmax / p3v_step_end): raise instead of decoding garbage."""
+    rows = token.reshape(-1).tolist() if torch.is_tensor(token) else np.asarray(token).reshape(-1).tolist()
+    if rows and min(rows) < 0:
+        raise RuntimeError(f"device step failed: NaN logits (token ids {rows})")
+    return rows
 
 
 class Streamer:

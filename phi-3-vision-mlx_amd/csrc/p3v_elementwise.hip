@@ -391,7 +391,13 @@ __device__ __forceinline__ ValIdx block_argmax(ValIdx m, ValIdx* red) {
 // trip for a 32064-wide row on 1024 threads); first maximum wins
 __device__ __forceinline__ ValIdx row_argmax_partial(const bf16_t* __restrict__ r, int n) {
   ValIdx m = {-INFINITY, 0x7fffffff};
-  auto take = [&](float v, int i) { if (v > m.v || (v == m.v && i < m.i) || m.i == 0x7fffffff) { m.v = v; m.i = i; } };
+  // A NaN logit means a kernel upstream failed (the split-KV merge poisons its output when its bounded wait runs out).
+  // It enters the reduction as (+inf, index -1), which beats every real entry: the row's arg-max is then -1 instead of
+  // an arbitrary index, and the host loops raise on a negative token (api._rows) -- loud, not a silently wrong token.
+  auto take = [&](float v, int i) {
+    if (v != v) { v = INFINITY; i = -1; }
+    if (v > m.v || (v == m.v && i < m.i) || m.i == 0x7fffffff) { m.v = v; m.i = i; }
+  };
   if ((((size_t)r) & 15) == 0) {
     const int nv = n >> 3;
     const u32x4_t* rv = (const u32x4_t*)r;

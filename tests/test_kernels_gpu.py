@@ -467,6 +467,17 @@ def test_argmax_logsoftmax_topk(ops, orc):
     assert tk.tolist() == orc.top3_candidates(x, 3).tolist()
 
 
+def test_argmax_reports_nan_rows(ops):
+    """A NaN anywhere in a row makes its arg-max -1 (the host loops raise on it), other rows are unaffected."""
+    from phi_3_vision_mlx_amd.api import _rows
+    x = g((3, 32064), 77)
+    x[1, 20000] = float("nan")
+    got = ops.argmax(x.cuda())
+    assert got.tolist() == [int(x[0].float().argmax()), -1, int(x[2].float().argmax())]
+    with pytest.raises(RuntimeError):
+        _rows(got)
+
+
 def test_graph_replay(ops):
     """hipGraph capture of a launch sequence replays with updated inputs."""
     x, w = g((4, 192), 80).cuda(), (g((192,), 81, 0.1) + 1).cuda()
