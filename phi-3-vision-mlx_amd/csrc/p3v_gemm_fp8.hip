@@ -9,8 +9,8 @@
 //
 //   MFMA      v_mfma_scale_f32_16x16x128_f8f6f4 with both block scales = 1.0 (E8M0 0x7f): the only fp8 form that runs at
 //             twice the bf16 rate on this chip (the unscaled 16x16x32 fp8 MFMA runs at the bf16 rate).  A lane holds 32
-//             consecutive k of its row (lane & 15) in k-block lane >> 4 -- A and B alike, so any k permutation inside the
-//             instruction cancels.
+//             k bytes of its row (lane & 15) for k-block lane >> 4 -- the SAME bytes for A and B, so which k they are
+//             does not matter (the kernel takes 16-byte chunks fchunk and fchunk + 4: bank-conflict-free reads).
 //   tile      256(M) x 256(N) x 128(K) per K step, 512 threads = 8 waves as 2(M) x 4(N), wave tile 128 x 64 = 8 x 4
 //             accumulators; ONE MFMA per accumulator and K step.  The LDS image is the bf16 kernel's (p3v_gemm256.hip):
 //             rows of 128 BYTES, 16-byte chunk c of row r stored at chunk c ^ (r & 7), staged by LDS-DMA with the swizzle
@@ -111,14 +111,17 @@ __global__ void __launch_bounds__(512, 1) k_gemm256_f8(GemmF8P p) {
     const unsigned char* tb = smem + (kt & 1) * BUF_BYTES + (2 + (wc >> 1)) * HALF_BYTES + (wc & 1) * 64 * 128;
     if (NJ == 2) tb = smem + (kt & 1) * BUF_BYTES + 2 * HALF_BYTES + wc * 32 * 128;                   // 32 B rows per wave
     u32x4_t af[4][2], af1[4][2], bf0[2][2], bf1[2][2];
-    // lane (row frow, k-block fchunk) owns bytes [32 * fchunk, 32 * fchunk + 32) of its row = logical chunks 2*fchunk, +1
+    // lane (row frow, k-block fchunk) owns the 16-byte chunks fchunk and fchunk + 4 of its 128-byte row (A and B alike, so the
+    // k permutation cancels).  Contiguous chunks 2*fchunk, 2*fchunk + 1 -- the obvious choice -- put the 16 lanes of a
+    // ds_read_b128 group on 8 bank slots, two-way conflicts on every fragment read (PMC: SQ_LDS_BANK_CONFLICT 48 % of the
+    // LDS-active cycles); with chunks (kk * 4 + fchunk) the group covers all 16 slots, as in the bf16 kernel
     auto read_a_to = [&](int sub, u32x4_t (&dst)[4][2]) {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
           const int r = sub * 64 + i * 16 + frow;
-          dst[i][kk] = *(const u32x4_t*)(ta + r * 128 + (((2 * fchunk + kk) ^ (r & 7)) << 4));
+          dst[i][kk] = *(const u32x4_t*)(ta + r * 128 + (((fchunk + 4 * kk) ^ (r & 7)) << 4));
         }
     };
     auto read_b = [&](int sub, u32x4_t (&bf)[2][2]) {
@@ -127,7 +130,7 @@ __global__ void __launch_bounds__(512, 1) k_gemm256_f8(GemmF8P p) {
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
           const int r = sub * 32 + j * 16 + frow;
-          bf[j][kk] = *(const u32x4_t*)(tb + r * 128 + (((2 * fchunk + kk) ^ (r & 7)) << 4));
+          bf[j][kk] = *(const u32x4_t*)(tb + r * 128 + (((fchunk + 4 * kk) ^ (r & 7)) << 4));
         }
     };
     auto quad_from = [&](int asub, int bsub, u32x4_t (&a)[4][2], u32x4_t (&bf)[2][2]) {
