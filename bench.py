@@ -296,9 +296,9 @@ def main():
     # runs, FETCH_SIZE x2 on gfx950); a committed measurement, not re-collected inside the timed benchmark
     traffic = None
     try:
-        if not model.w8:
-            with open(os.path.join(ROOT, "profiles", "r01_pmc_gate_up_gemv.json")) as f:
-                traffic = json.load(f)["hbm_bytes_per_launch_corrected"]
+        if not model.w8:                                          # round-2 passes (tools/pmc_round2.sh); the kernel is round 1's
+            with open(os.path.join(ROOT, "profiles", "r02_pmc_hbm_traffic.json")) as f:
+                traffic = json.load(f)["gemv"]["hbm_bytes_per_launch_corrected"]
     except Exception:
         pass
     hd = cfg.hidden_size // cfg.num_attention_heads

@@ -11,6 +11,7 @@ N(0, 0.02) head never allows (its top-2 gap is a few bf16 ulps of the logits; to
   c2_oracle.npz     FULL-SIZE Phi-3-Vision, BASELINE config 2 = bench.py's rank-0 request (2531-token prompt): prefill + 3 steps
   c4_oracle.npz     FULL-SIZE, one GPU's share of BASELINE config 4 (4 image + 4 text requests), each run on its own at
                     B = 1 (the reference's only image path, phi_3_vision_mlx.py:377-378): prefill + 3 steps per request
+  c3_oracle.npz     FULL-SIZE text model, 5000-token prompt (LONG RoPE factors, BASELINE config 3's path): prefill + 3 steps
   c5_oracle.npz     config 2's request on the oracle with config 5's quantisers applied (e4m3 weights with per-row scales,
                     e4m3 activations with per-token scales in the prompt-sized projections, int8 KV with per-token scales;
                     see `c5`)
@@ -51,6 +52,7 @@ REL_TOL_SHORT = 0.09      # full size, short text prompts
 CKPT = os.environ.get("P3V_ORACLE_CKPT", "/tmp/p3v_oracle_ckpt")     # prefilled requests are kept here between runs (GBs)
 SPREAD = 4.0                   # log2-sd of the lm_head row scales
 C1_STEPS = 6                   # prefill + 5 decode steps, all clear (each extra all-clear step costs ~4x more head seeds)
+REL_TOL_C3 = 0.07              # full size, 5000-token text prompt (long RoPE factors)
 REL_TOL_C5 = 0.25              # config 5, W8A8 prefill + W8A16 decode + int8 KV: see c5()
 REL_TOL_C5W = 0.07             # config 5 with fp8_activations=False (weight-only fp8 + int8 KV)
 BF16, F32 = torch.bfloat16, torch.float32
@@ -262,6 +264,22 @@ def full():
     print("wrote c1 / c2 / c4")
 
 
+def c3():
+    """BASELINE config 3's distinguishing path at a size the O(S^2) oracle can hold: a 5000-token text prompt, so that
+    S + max_tokens > 4096 selects the LONG RoPE factors (phi.py:492) -- full-size model, prefill + 3 decode steps, all clear.
+    (32768 tokens would need 137 GB of fp32 scores per layer in the reference's formulation; the GPU tests cover that
+    size through properties.)"""
+    cfg, o, base = _full_oracle()
+    ids = np.random.default_rng(4).integers(3, 32000, (1, 5000)).astype(np.int64)
+    r = Prefilled(o, {"input_ids": ids}, 4, tag="c3")
+    r.rel_tol = REL_TOL_C3                                     # random TEXT ids: measured 5.3 % (image prompts of half the length: 3 %)
+    hs, (res,) = search_head([r], base, 4, min_distinct=2)
+    out = dict(COMMON, rel_tol=np.asarray([REL_TOL_C3], dtype=np.float32), n_ids=np.asarray([r.S], dtype=np.int32))
+    pack("", hs, res, out)
+    np.savez_compressed(os.path.join(HERE, "c3_oracle.npz"), **out)
+    print("wrote c3_oracle.npz")
+
+
 def c5_quantisers(cfg, w):
     """Config 5's weight quantiser applied to the oracle's weights: decoder projections + lm_head -> e4m3 with one fp32
     scale per output row (ops.quantize_fp8_rows), kept as the exact fp32 products."""
@@ -365,6 +383,8 @@ if __name__ == "__main__":
         tiny()
     if which in ("full", "all"):
         full()
+    if which in ("c3", "all"):
+        c3()
     if which in ("c5", "all"):
         c5(True)
     if which in ("c5w", "all"):

@@ -505,6 +505,21 @@ def test_c2_fixture_full_size_vision():
     torch.cuda.empty_cache()
 
 
+def test_c3_long_rope_fixture_full_size():
+    """BASELINE config 3's path against the oracle at a size its O(S^2) formulation can hold: a 5000-token text prompt on the
+    full-size model -> S + max_tokens > 4096 -> LONG RoPE factors chosen once (phi.py:492), prefill through the big-tile
+    GEMMs and the long flash prefill, 3 graph-replayed decode steps; every logit in tolerance, every token exact
+    (teacher-forced and free-running).  32768 tokens stay with the property test below (the reference's own formulation
+    would need 137 GB of scores per layer there)."""
+    g = np.load(GOLDEN + "/c3_oracle.npz")
+    model, _ = _full_model(g, blind=True)
+    ids = np.random.default_rng(4).integers(3, 32000, (1, 5000)).astype(np.int64)
+    assert ids.shape[1] == int(g["n_ids"][0])
+    run_fixture(model, {"input_ids": ids}, g, "", "C3 (5000 tokens, long factors)")
+    del model
+    torch.cuda.empty_cache()
+
+
 def test_c4_share_batched_vs_per_request_oracle():
     """BASELINE config 4, one GPU's share: 4 single-image VQA requests + 4 text prompts of 65..233 tokens run as ONE
     left-padded B = 8 batch (batched ViT over 68 crops, B = 8 prefill, B = 8 graph-replayed decode through the MFMA
