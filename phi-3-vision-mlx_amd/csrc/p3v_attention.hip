@@ -692,65 +692,51 @@ struct AttnDecP {
   int B, L, nh, nkv, past, cache_t, rope_bstride, n_split;   // cos/sin row of (b, new position r) = b*rope_bstride + r
   float scale;
   int chunk, grp, grp_magic;   // host-side: keys per split (multiple of 64), heads per kv head and ceil(2^16 / grp)
-  int32_t* counters;           // [B * nh * n_split] zeroed ready-flags: the last split of a (b, head) merges the partials itself
+  int32_t* counters;           // non-null: the last split of a (b, head) merges the partials itself (split_merge)
   bf16_t* out;                 // [B, L, nh * 96] (fused merge only)
 };
 
-// ---- fused split-KV merge ("last workgroup merges").  Protocol without cache write-back / invalidate fences (an
-// agent-scope release costs ~20 us on this chip, tools/scratch/persist_gemv.hip): partials are stored and loaded with
-// agent-scope relaxed atomics (write-through / cache-bypassing accesses), a workgroup waits for its stores
-// (s_waitcnt vmcnt(0) + barrier) before it raises its ready flag, and the last split waits for all flags and merges.
+// ---- fused split-KV merge ("last workgroup merges") without flags.  `ws` holds the SENTINEL bit pattern (all ones: a
+// NaN no arithmetic produces) in every word between launches.  A split stores its partial with write-through stores and is
+// done -- no store wait, no flag.  The workgroup of the highest split of a (b, head) polls the partial WORDS themselves
+// (4-byte stores are atomic, so a word is either the sentinel or final; 24 loads in flight per lane), merges when none is
+// the sentinel, and puts the sentinel back.  Its own partial never leaves LDS (`own`).  Compared with data + ready flags
+// this takes the store acknowledgement, the flag store and a flag poll off the critical path of every launch (tail of the
+// launch at 21 splits: 3.3 -> 2.4 us).  No cache write-back / invalidate fences anywhere (an agent-scope release costs
+// ~20 us on this chip, tools/scratch/persist_gemv.hip): partials are stored and loaded with agent-scope relaxed atomics
+// (write-through / cache-bypassing accesses).  Workgroups are dispatched in linear order, so by the time the merging
+// workgroup runs every other split of its (b, head) is resident or finished and the wait cannot deadlock; it is bounded
+// anyway, and when the bound runs out the output is NaN so that the failure is loud (api._rows raises) instead of a
+// silently wrong token.
+#define WS_SENTINEL 0xffffffffu
 __device__ __forceinline__ void st_wt(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ float ld_wt(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ bool is_sentinel(float v) { return __builtin_bit_cast(uint32_t, v) == WS_SENTINEL; }
 
-// Publishes this workgroup's partial (flag[split] = 1) and returns true in the ONE workgroup per (b, head) that merges:
-// the one with the highest split index.  Workgroups are dispatched in linear order, so by the time it runs every
-// other split of its (b, head) is resident or finished and the wait below cannot deadlock; the spin is bounded anyway.
-// No atomics: 41 read-modify-writes on one address from eight XCDs serialise into microseconds.
-// Returns 0 (not the merging workgroup), 1 (merge) or 2 (merge, but the bounded wait ran out: the caller then writes
-// NaN so that the failure is loud instead of a silently wrong token).
-__device__ __forceinline__ int split_publish_and_wait(int32_t* flags, int split, int n_split) {
-  __shared__ int s_timeout;
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this thread's partial stores have been performed
-  if (threadIdx.x == 0) s_timeout = 0;
-  __syncthreads();
-  if (split != n_split - 1) {
-    if (threadIdx.x == 0) __hip_atomic_store(flags + split, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return 0;
-  }
-  if (threadIdx.x < 64) {
-    bool done = false;
-    for (unsigned spins = 0; spins < (1u << 22) && !done; ++spins) {
-      bool ok = true;
-      for (int s = threadIdx.x; s < n_split - 1; s += 64)
-        ok &= __hip_atomic_load(flags + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
-      done = __all(ok);
-    }
-    if (!done && threadIdx.x == 0) s_timeout = 1;
-  }
-  __syncthreads();
-  return 1 + s_timeout;
-}
-
-// merge of the n_split partials of one (b, head) by the calling workgroup (NT threads = G groups of 64 lanes)
-#define SPLIT_MERGE_SCRATCH(NT) ((NT) / 64 * 130)              // floats: pm[G], pl[G], part[G][128]
+// merge of the n_split partials of one (b, head) by the calling workgroup (NT threads = G groups of 64 lanes).
+// own: the calling workgroup's partial (split n_split - 1) in LDS, [16][HD + 2] like a `ws` record, or nullptr when it
+// went to `ws` like the others.
+#define SPLIT_MERGE_SCRATCH(NT) ((NT) / 64 * 130 + 2)          // floats: pm[G], pl[G], part[G][128], timeout flag
 template <int NT>
-__device__ __forceinline__ void split_merge(const float* base0, bf16_t* out0, size_t out_qstride, int L, int n_split,
-                                            int32_t* flags, bool poison, float* scratch) {
+__device__ __forceinline__ void split_merge(float* base0, bf16_t* out0, size_t out_qstride, int L, int n_split,
+                                            const float* own, float* scratch) {
   constexpr int HD = 96, G = NT / 64;
   float* pm = scratch;
   float* pl = scratch + G;
   float (*part)[128] = (float (*)[128])(scratch + 2 * G);
+  int* s_timeout = (int*)(scratch + 2 * G + G * 128);
   const int t = threadIdx.x, grp = t >> 6, d0 = t & 63;
   const size_t sstr = (size_t)16 * (HD + 2);
   const bool two = d0 + 64 < HD;
+  const float sentinel = __builtin_bit_cast(float, WS_SENTINEL);
+  if (t == 0) *s_timeout = 0;
+  __syncthreads();                                             // also: `own` is complete
   for (int q = 0; q < L; ++q) {
-    const float* base = base0 + (size_t)q * (HD + 2);
-    float m = -INFINITY, l = 0.f, a0 = 0.f, a1 = 0.f;
-#pragma unroll 4
-    for (int s = grp; s < n_split; s += G) {
-      const float ms = ld_wt(base + s * sstr + HD), ls = ld_wt(base + s * sstr + HD + 1);
-      const float o0 = ld_wt(base + s * sstr + d0), o1 = two ? ld_wt(base + s * sstr + d0 + 64) : 0.f;
+    float* base = base0 + (size_t)q * (HD + 2);
+    const float* own_q = own ? own + q * (HD + 2) : nullptr;
+    const int n_glob = own_q ? n_split - 1 : n_split;          // partials that come through `ws`
+    float m, l, a0, a1;
+    auto fold = [&](float ms, float ls, float o0, float o1) {
       const float mn = fmaxf(m, ms);
       const float mu = mn == -INFINITY ? 0.f : mn;
       const float ca = __builtin_amdgcn_exp2f(m - mu), cb = __builtin_amdgcn_exp2f(ms - mu);
@@ -758,7 +744,32 @@ __device__ __forceinline__ void split_merge(const float* base0, bf16_t* out0, si
       a0 = a0 * ca + o0 * cb;
       a1 = a1 * ca + o1 * cb;
       m = mn;
+    };
+    constexpr int UB = 6;                                      // partials per load round: 4 * UB loads in flight per lane
+    for (unsigned tries = 0;; ++tries) {
+      m = -INFINITY, l = 0.f, a0 = 0.f, a1 = 0.f;
+      bool bad = false;
+      for (int s = grp; s < n_glob; s += UB * G) {
+        float ms[UB], ls[UB], o0[UB], o1[UB];
+#pragma unroll
+        for (int j = 0; j < UB; ++j) {
+          const float* r = base + (size_t)min(s + j * G, n_glob - 1) * sstr;
+          ms[j] = ld_wt(r + HD); ls[j] = ld_wt(r + HD + 1);
+          o0[j] = ld_wt(r + d0); o1[j] = two ? ld_wt(r + d0 + 64) : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < UB; ++j) {
+          if (s + j * G < n_glob) {
+            bad |= is_sentinel(ms[j]) | is_sentinel(ls[j]) | is_sentinel(o0[j]) | is_sentinel(o1[j]);
+            fold(ms[j], ls[j], o0[j], o1[j]);
+          }
+        }
+      }
+      if (!__any(bad)) break;
+      if (tries >= (1u << 18)) { *s_timeout = 1; break; }
     }
+    if (own_q && grp == (n_split - 1) % G)                     // split n_split - 1 is the last one of its group: same order as through `ws`
+      fold(own_q[HD], own_q[HD + 1], own_q[d0], two ? own_q[d0 + 64] : 0.f);
     if (G > 1) {
       __syncthreads();
       if (d0 == 0) { pm[grp] = m; pl[grp] = l; }
@@ -766,6 +777,7 @@ __device__ __forceinline__ void split_merge(const float* base0, bf16_t* out0, si
       if (two) part[grp][d0 + 64] = a1;
       __syncthreads();
       if (t < HD) {
+        const bool poison = *s_timeout != 0;
         float M = pm[0];
 #pragma unroll
         for (int k = 1; k < G; ++k) M = fmaxf(M, pm[k]);
@@ -780,12 +792,16 @@ __device__ __forceinline__ void split_merge(const float* base0, bf16_t* out0, si
         out0[(size_t)q * out_qstride + t] = poison ? (bf16_t)0x7fc0 : f32_to_bf16(lsum > 0.f ? acc / lsum : 0.f);
       }
     } else {
-      const float inv = poison ? __builtin_nanf("") : (l > 0.f ? 1.f / l : 0.f);
+      const float inv = *s_timeout ? __builtin_nanf("") : (l > 0.f ? 1.f / l : 0.f);
       out0[(size_t)q * out_qstride + d0] = f32_to_bf16(a0 * inv);
       if (two) out0[(size_t)q * out_qstride + d0 + 64] = f32_to_bf16(a1 * inv);
     }
+    for (int s = grp; s < n_glob; s += G) {                    // sentinel back (after the output: off its path): ready for the next launch
+      st_wt(base + s * sstr + d0, sentinel);
+      if (two) st_wt(base + s * sstr + d0 + 64, sentinel);
+      if (d0 == 0) { st_wt(base + s * sstr + HD, sentinel); st_wt(base + s * sstr + HD + 1, sentinel); }
+    }
   }
-  for (int i = t; i < n_split - 1; i += NT) __hip_atomic_store(flags + i, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
 }
 
 typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
@@ -1093,12 +1109,10 @@ __device__ __forceinline__ void attn_decode_body(const AttnDecP& p, const int bx
   }
   DBG_T(7);
   DBG_W(13, false);
-  int32_t* flags = p.counters + ((size_t)b * p.nh + head) * p.n_split;
-  const int role = p.counters ? split_publish_and_wait(flags, bx, p.n_split) : 0;
-  if (role) {
+  if (p.counters && bx == p.n_split - 1) {                     // in-launch merge by the highest split of the (b, head)
     __shared__ float merge_scratch[SPLIT_MERGE_SCRATCH(256)];
     split_merge<256>(p.ws + ((size_t)b * p.nh + head) * p.n_split * 16 * (HD + 2), p.out + (size_t)b * p.L * (p.nh * HD) + head * HD,
-                     (size_t)p.nh * HD, p.L, p.n_split, flags, role == 2, merge_scratch);
+                     (size_t)p.nh * HD, p.L, p.n_split, nullptr, merge_scratch);
   }
   DBG_W(11, false);
 }
@@ -1271,6 +1285,9 @@ __device__ __forceinline__ void attn_decode_body128(const AttnDecP& p, const int
   }
 
   // ---- merge the four wave partials through the (dead) K slices, one (m, l, O) partial per workgroup to `ws`
+  const bool merger = p.counters && bx == p.n_split - 1;       // the highest split of a (b, head) merges in-launch
+  float* own = (float*)(vtile + 4096);                         // its partial: [16][HD + 2] in the dead V^T tile (merge scratch: first 4 KiB)
+  static_assert(SPLIT_MERGE_SCRATCH(256) * 4 <= 4096 && 4096 + 16 * (HD + 2) * 4 <= 96 * 256, "merge scratch + own partial fit the V^T tile");
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __syncthreads();
   if (qvalid) {
@@ -1294,15 +1311,18 @@ __device__ __forceinline__ void attn_decode_body128(const AttnDecP& p, const int
       acc += c * ((const float*)(KV + k * KS_BYTES))[q * HD + d];
       lsum += c * Ml[k][q][1];
     }
-    float* w = p.ws + ((((size_t)b * p.nh + head) * p.n_split + bx) * 16 + q) * (HD + 2);
-    st_wt(w + d, acc);
-    if (d == 0) { st_wt(w + HD, M); st_wt(w + HD + 1, lsum); }
+    if (merger) {                                              // stays in LDS: split_merge takes it from there
+      own[q * (HD + 2) + d] = acc;
+      if (d == 0) { own[q * (HD + 2) + HD] = M; own[q * (HD + 2) + HD + 1] = lsum; }
+    } else {
+      float* w = p.ws + ((((size_t)b * p.nh + head) * p.n_split + bx) * 16 + q) * (HD + 2);
+      st_wt(w + d, acc);
+      if (d == 0) { st_wt(w + HD, M); st_wt(w + HD + 1, lsum); }
+    }
   }
-  int32_t* flags = p.counters + ((size_t)b * p.nh + head) * p.n_split;
-  const int role = p.counters ? split_publish_and_wait(flags, bx, p.n_split) : 0;
-  if (role)
+  if (merger)
     split_merge<256>(p.ws + ((size_t)b * p.nh + head) * p.n_split * 16 * (HD + 2), p.out + (size_t)b * p.L * (p.nh * HD) + head * HD,
-                     (size_t)p.nh * HD, p.L, p.n_split, flags, role == 2, (float*)vtile);
+                     (size_t)p.nh * HD, p.L, p.n_split, own, (float*)vtile);
 }
 
 __global__ void __launch_bounds__(256) k_attn_decode128(AttnDecP p) {
@@ -1486,12 +1506,10 @@ __global__ void __launch_bounds__(64) k_attn_decode_stream(AttnDecP p) {
       for (int r = 0; r < 4; ++r) st_wt(w + 16 * d + 4 * g + r, o[d][r]);
     if (g == 0) { st_wt(w + HD, m_run); st_wt(w + HD + 1, l_run); }
   }
-  int32_t* flags = p.counters + ((size_t)b * p.nh + head) * p.n_split;
-  const int role = p.counters ? split_publish_and_wait(flags, blockIdx.x, p.n_split) : 0;
-  if (role) {
+  if (p.counters && blockIdx.x == p.n_split - 1) {
     __shared__ float merge_scratch[SPLIT_MERGE_SCRATCH(64)];
     split_merge<64>(p.ws + ((size_t)b * p.nh + head) * p.n_split * 16 * (HD + 2), p.out + (size_t)b * p.L * (p.nh * HD) + head * HD,
-                    (size_t)p.nh * HD, p.L, p.n_split, flags, role == 2, merge_scratch);
+                    (size_t)p.nh * HD, p.L, p.n_split, nullptr, merge_scratch);
   }
 }
 
@@ -1521,6 +1539,15 @@ __global__ void __launch_bounds__(64 * CMB_G) k_attn_combine2(const float* __res
     a0 = a0 * ca + o0 * cb;
     a1 = a1 * ca + o1 * cb;
     m = mn;
+  }
+  {                                                            // `ws` is all-sentinel between launches (see split_merge)
+    float* wbase = const_cast<float*>(base);
+    const float sentinel = __builtin_bit_cast(float, WS_SENTINEL);
+    for (int s = s0; s < s1; ++s) {
+      wbase[s * sstr + d0] = sentinel;
+      if (two) wbase[s * sstr + d0 + 64] = sentinel;
+      if (d0 == 0) { wbase[s * sstr + hd] = sentinel; wbase[s * sstr + hd + 1] = sentinel; }
+    }
   }
   if (d0 == 0) { pm[grp] = m; pl[grp] = l; }
   part[grp][d0] = a0;
@@ -2228,14 +2255,10 @@ __global__ void __launch_bounds__(256) k_attn_decode_q8s(AttnDecQ8P p) {
     if (d == 0) { st_wt(w + HD, M); st_wt(w + HD + 1, lsum); }
   }
   // fused split merge (as k_attn_decode): the highest split of a (b, head) waits for the others' flags and merges
-  if (p.counters) {
-    int32_t* flags = p.counters + ((size_t)b * p.nh + head) * p.n_split;
-    const int role = split_publish_and_wait(flags, blockIdx.x, p.n_split);
-    if (role) {
-      __shared__ float merge_scratch[SPLIT_MERGE_SCRATCH(256)];
-      split_merge<256>(p.ws + ((size_t)b * p.nh + head) * p.n_split * 16 * (HD + 2), p.out + (size_t)b * p.L * (p.nh * HD) + head * HD,
-                       (size_t)p.nh * HD, p.L, p.n_split, flags, role == 2, merge_scratch);
-    }
+  if (p.counters && blockIdx.x == p.n_split - 1) {
+    __shared__ float merge_scratch[SPLIT_MERGE_SCRATCH(256)];
+    split_merge<256>(p.ws + ((size_t)b * p.nh + head) * p.n_split * 16 * (HD + 2), p.out + (size_t)b * p.L * (p.nh * HD) + head * HD,
+                     (size_t)p.nh * HD, p.L, p.n_split, nullptr, merge_scratch);
   }
 }
 
@@ -2457,13 +2480,9 @@ __global__ void __launch_bounds__(256) k_attn_decode128_q8(AttnDecQ8P p) {
     st_wt(w + d, acc);
     if (d == 0) { st_wt(w + HD, M); st_wt(w + HD + 1, lsum); }
   }
-  if (p.counters) {
-    int32_t* flags = p.counters + ((size_t)b * p.nh + head) * p.n_split;
-    const int role = split_publish_and_wait(flags, blockIdx.x, p.n_split);
-    if (role)
-      split_merge<256>(p.ws + ((size_t)b * p.nh + head) * p.n_split * 16 * (HD + 2), p.out + (size_t)b * p.L * (p.nh * HD) + head * HD,
-                       (size_t)p.nh * HD, p.L, p.n_split, flags, role == 2, (float*)Kx);
-  }
+  if (p.counters && blockIdx.x == p.n_split - 1)
+    split_merge<256>(p.ws + ((size_t)b * p.nh + head) * p.n_split * 16 * (HD + 2), p.out + (size_t)b * p.L * (p.nh * HD) + head * HD,
+                     (size_t)p.nh * HD, p.L, p.n_split, nullptr, (float*)Kx);
 }
 
 extern "C" int p3v_attention_decode_q8(const p3v_attn_decode_q8_args_t* a, void* stream) {

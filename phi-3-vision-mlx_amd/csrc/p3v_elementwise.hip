@@ -51,9 +51,53 @@ __global__ void __launch_bounds__(256) k_rmsnorm(const u32x4_t* __restrict__ x, 
   }
 }
 
+// the same with the row held in registers (CH 16-byte chunks per lane): x is read once instead of twice
+template <int CH>
+__global__ void __launch_bounds__(256) k_rmsnorm_r(const u32x4_t* __restrict__ x, const u32x4_t* __restrict__ w,
+                                                   u32x4_t* __restrict__ y, int rows, int chunks, float inv_h, float eps) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const u32x4_t* xr = x + (size_t)row * chunks;
+  u32x4_t v[CH], g[CH];
+#pragma unroll
+  for (int i = 0; i < CH; ++i) {
+    const int c = i * 64 + lane;
+    v[i] = c < chunks ? xr[c] : (u32x4_t){0u, 0u, 0u, 0u};
+    g[i] = c < chunks ? w[c] : (u32x4_t){0u, 0u, 0u, 0u};
+  }
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < CH; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float a = bf16lo(v[i][j]), b = bf16hi(v[i][j]);
+      ss += a * a + b * b;
+    }
+  const float r = rsqrtf(wave_sum(ss) * inv_h + eps);
+  u32x4_t* yr = y + (size_t)row * chunks;
+#pragma unroll
+  for (int i = 0; i < CH; ++i) {
+    const int c = i * 64 + lane;
+    if (c < chunks) {
+      u32x4_t o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] = pack_bf16x2(bf16lo(v[i][j]) * r * bf16lo(g[i][j]), bf16hi(v[i][j]) * r * bf16hi(g[i][j]));
+      yr[c] = o;
+    }
+  }
+}
+
 extern "C" int p3v_rmsnorm(const uint16_t* x, const uint16_t* w, uint16_t* y, int rows, int hidden, float eps, void* stream) {
   if (!x || !w || !y || rows < 0 || hidden <= 0 || hidden % 8) return P3V_ERR_ARG;
   if (rows == 0) return P3V_OK;
+  const int chunks = hidden / 8;
+  if (chunks <= 6 * 64) {   // hidden <= 3072: same per-lane summation order as k_rmsnorm, so the results are bit-identical
+    hipLaunchKernelGGL(k_rmsnorm_r<6>, dim3(p3v_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, (const u32x4_t*)x,
+                       (const u32x4_t*)w, (u32x4_t*)y, rows, chunks, 1.0f / hidden, eps);
+    P3V_CHECK_LAUNCH();
+    return P3V_OK;
+  }
   hipLaunchKernelGGL(k_rmsnorm, dim3(p3v_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, (const u32x4_t*)x,
                      (const u32x4_t*)w, (u32x4_t*)y, rows, hidden / 8, 1.0f / hidden, eps);
   P3V_CHECK_LAUNCH();
@@ -101,10 +145,70 @@ __global__ void __launch_bounds__(256) k_layernorm(const float4* __restrict__ x,
   }
 }
 
+// the same with the row held in registers (CH float4 per lane): x is read once instead of three times
+template <bool OUT_F32, int CH>
+__global__ void __launch_bounds__(256) k_layernorm_r(const float4* __restrict__ x, const u32x2_t* __restrict__ w,
+                                                     const u32x2_t* __restrict__ b, void* __restrict__ yv, int rows,
+                                                     int chunks, float inv_h, float eps) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const float4* xr = x + (size_t)row * chunks;
+  float4 v[CH];
+#pragma unroll
+  for (int i = 0; i < CH; ++i) {
+    const int c = i * 64 + lane;
+    v[i] = c < chunks ? xr[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < CH; ++i) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+  const float mu = wave_sum(s) * inv_h;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < CH; ++i) {
+    if (i * 64 + lane < chunks) {
+      const float d0 = v[i].x - mu, d1 = v[i].y - mu, d2 = v[i].z - mu, d3 = v[i].w - mu;
+      q += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+    }
+  }
+  const float r = rsqrtf(wave_sum(q) * inv_h + eps);
+#pragma unroll
+  for (int i = 0; i < CH; ++i) {
+    const int c = i * 64 + lane;
+    if (c < chunks) {
+      const u32x2_t g = w[c], be = b[c];
+      float4 t;
+      t.x = (v[i].x - mu) * r * bf16lo(g[0]) + bf16lo(be[0]);
+      t.y = (v[i].y - mu) * r * bf16hi(g[0]) + bf16hi(be[0]);
+      t.z = (v[i].z - mu) * r * bf16lo(g[1]) + bf16lo(be[1]);
+      t.w = (v[i].w - mu) * r * bf16hi(g[1]) + bf16hi(be[1]);
+      if (OUT_F32) {
+        ((float4*)yv)[(size_t)row * chunks + c] = t;
+      } else {
+        u32x2_t o;
+        o[0] = pack_bf16x2(t.x, t.y);
+        o[1] = pack_bf16x2(t.z, t.w);
+        ((u32x2_t*)yv)[(size_t)row * chunks + c] = o;
+      }
+    }
+  }
+}
+
 extern "C" int p3v_layernorm(const float* x, const uint16_t* w, const uint16_t* b, void* y, int out_f32, int rows,
                              int hidden, float eps, void* stream) {
   if (!x || !w || !b || !y || rows < 0 || hidden <= 0 || hidden % 4) return P3V_ERR_ARG;
   if (rows == 0) return P3V_OK;
+  if (hidden / 4 <= 4 * 64) {
+    if (out_f32)
+      hipLaunchKernelGGL((k_layernorm_r<true, 4>), dim3(p3v_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, (const float4*)x,
+                         (const u32x2_t*)w, (const u32x2_t*)b, y, rows, hidden / 4, 1.0f / hidden, eps);
+    else
+      hipLaunchKernelGGL((k_layernorm_r<false, 4>), dim3(p3v_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, (const float4*)x,
+                         (const u32x2_t*)w, (const u32x2_t*)b, y, rows, hidden / 4, 1.0f / hidden, eps);
+    P3V_CHECK_LAUNCH();
+    return P3V_OK;
+  }
   if (out_f32)
     hipLaunchKernelGGL(k_layernorm<true>, dim3(p3v_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, (const float4*)x,
                        (const u32x2_t*)w, (const u32x2_t*)b, y, rows, hidden / 4, 1.0f / hidden, eps);

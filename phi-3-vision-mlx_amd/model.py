@@ -432,7 +432,7 @@ class Phi3VModel:
             if os.environ.get("P3V_ATTN_NSPLIT"):
                 n_split = int(os.environ["P3V_ATTN_NSPLIT"])
             bufs["n_split"] = n_split
-            bufs["ws"] = torch.empty(ops.attention_ws_bytes(B, L, nh, hd, n_split) // 4, dtype=F32, device=self.device)
+            bufs["ws"] = ops.attention_ws(B, L, nh, hd, n_split, self.device)
             # ready flags of the fused split-KV merge: used with the one-tile-per-workgroup plan only (measured: -17..-22 us
             # per step at B = 1; with the multi-tile streaming kernel the write-through partial stores cost more than the
             # merge launch saves, and beyond ~48 splits the one merging workgroup is slower than 32 parallel ones)

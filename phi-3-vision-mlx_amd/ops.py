@@ -298,6 +298,12 @@ def attention_ws_bytes(B, Lq, nh, hd, n_split):
     return int(L.lib().p3v_attention_ws_bytes(B, Lq, nh, hd, n_split))
 
 
+def attention_ws(B, Lq, nh, hd, n_split, device):
+    """The split-partial workspace in the state every decode-attention launch expects and leaves it in: all bytes 0xFF
+    (the 'not written yet' sentinel of the in-launch merge, include/p3v.h)."""
+    return torch.full((attention_ws_bytes(B, Lq, nh, hd, n_split) // 4,), -1, dtype=torch.int32, device=device).view(F32)
+
+
 def im2col_patches(pix, patch, kpad):
     _chk(pix, F32, "pix")
     n, _, S, _ = pix.shape

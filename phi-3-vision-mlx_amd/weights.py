@@ -310,7 +310,17 @@ def mlx_dequantize(packed, scales, biases, group_size=Q4_GROUP, bits=Q4_BITS):
 
 def q4_repack(packed, scales, biases):
     """MLX layout -> the device layout of p3v_gemv_q4 (include/p3v.h): nibbles of weights 8d..8d+7 at bits
-    0,16,4,20,8,24,12,28 of dword d; scale | bias << 16 as one dword per group."""
+    0,16,4,20,8,24,12,28 of dword d; scale | bias << 16 as one dword per group.
+    The device format holds scale and bias as bf16 -- the dtype the reference's `*_Q` checkpoints have (they are quantised
+    from the bf16 HF checkpoint, phi_3_vision_mlx.py:291-305).  A checkpoint converted to fp16 / fp32 loses mantissa
+    bits here and no longer dequantises to exactly scale * q + bias: that is reported, not hidden."""
+    if scales.dtype != torch.bfloat16:
+        lossy = bool((scales.to(torch.bfloat16).to(scales.dtype) != scales).any() or
+                     (biases.to(torch.bfloat16).to(biases.dtype) != biases).any())
+        if lossy:
+            import warnings
+            warnings.warn(f"q4_repack: {scales.dtype} scales / biases rounded to bf16 (device format); dequantised weights "
+                          "differ from the checkpoint's by up to 2^-9 relative", stacklevel=2)
     q = mlx_unpack(packed).reshape(packed.shape[0], -1, 8)
     pos = torch.tensor([0, 16, 4, 20, 8, 24, 12, 28], dtype=torch.int64, device=packed.device)
     w4 = (q << pos).sum(-1)

@@ -280,7 +280,7 @@ def test_attention(ops, orc, B, L, past, hd, nh, causal, pads):
     n_split, ws = 0, None
     if L <= 16:
         n_split = 4
-        ws = torch.empty(ops.attention_ws_bytes(B, L, nh, hd, n_split) // 4, dtype=F32).cuda()
+        ws = ops.attention_ws(B, L, nh, hd, n_split, "cuda")
     ops.attention(q.cuda(), out, B, L, nh, nh, hd, hd ** -0.5, causal, past=past, k_past=kc, v_past=vc, past_t=Tp,
                   pad_len=pad.cuda() if pads else None, ws=ws, n_split=n_split, new_is_cache=True)
     t = torch.arange(T)[None, None, None, :]
@@ -318,7 +318,7 @@ def test_attention_decode_fused(ops, orc, B, L, past, nh, n_split, pads, dev_pas
     pad = torch.tensor(pads if pads else [0] * B, dtype=torch.int32)
     kcc, vcc = kc.cuda(), vc.transpose(2, 3).contiguous().cuda()         # V^T cache layout
     out = torch.empty((B, L, nh * hd), dtype=BF16).cuda()
-    ws = torch.empty(ops.attention_ws_bytes(B, L, nh, hd, n_split) // 4, dtype=F32).cuda()
+    ws = ops.attention_ws(B, L, nh, hd, n_split, "cuda")
     d_past = torch.tensor([past], dtype=torch.int32).cuda()
     cnt = torch.zeros(B * nh * n_split, dtype=torch.int32).cuda() if fused_merge else None
     cos_s = torch.empty((B, L, hd // 2), dtype=F32).cuda()
@@ -380,7 +380,7 @@ def test_kv_quantize_and_q8_decode(ops, orc, past, L, n_split, fused):
     cos, sin = ops.rope_table(torch.arange(T, dtype=F32).repeat(B).cuda(), inv.cuda(), rope_scaling_factor(cfg))
     cos, sin = cos.view(B, T, -1), sin.view(B, T, -1)
     out = torch.empty((B, L, nh * hd), dtype=BF16).cuda()
-    ws = torch.empty(ops.attention_ws_bytes(B, L, nh, hd, n_split) // 4, dtype=F32).cuda()
+    ws = ops.attention_ws(B, L, nh, hd, n_split, "cuda")
     cnt = torch.zeros(B * nh * n_split, dtype=torch.int32).cuda() if fused else None
     for _ in range(2 if fused else 1):
         out.fill_(float("nan"))
@@ -414,7 +414,7 @@ def test_attention_beam_view(ops, orc):
     kc, vc = g((Bc, nh, T, hd), 51), g((Bc, nh, T, hd), 52)
     kn, vn = g((B, nh, L, hd), 53), g((B, nh, L, hd), 54)
     out = torch.empty((B, L, nh * hd), dtype=BF16).cuda()
-    ws = torch.empty(ops.attention_ws_bytes(B, L, nh, hd, 2) // 4, dtype=F32).cuda()
+    ws = ops.attention_ws(B, L, nh, hd, 2, "cuda")
     Lp = 8
     knp = torch.zeros((B, nh, Lp, hd), dtype=BF16)
     vnp = torch.zeros((B, nh, hd, Lp), dtype=BF16)
