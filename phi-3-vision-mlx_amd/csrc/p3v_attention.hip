@@ -709,6 +709,17 @@ struct AttnDecP {
 // anyway, and when the bound runs out the output is NaN so that the failure is loud (api._rows raises) instead of a
 // silently wrong token.
 #define WS_SENTINEL 0xffffffffu
+#ifdef P3V_ATTN_TIMING                                         // tools/scratch/attn_timeline.py: 100 MHz timestamps per workgroup
+__device__ long long p3v_tbuf[8192 * 16];
+#define TMARK(k) do { if (threadIdx.x == 0) p3v_tbuf[(blockIdx.x + gridDim.x * blockIdx.y) * 16 + (k)] = wall_clock64(); } while (0)
+#define TVAL(k, v) do { if (threadIdx.x == 0) p3v_tbuf[(blockIdx.x + gridDim.x * blockIdx.y) * 16 + (k)] = (v); } while (0)
+extern "C" int p3v_timing_read(long long* out, int n) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(p3v_tbuf), sizeof(long long) * n) == hipSuccess ? 0 : -1;
+}
+#else
+#define TMARK(k)
+#define TVAL(k, v)
+#endif
 __device__ __forceinline__ void st_wt(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ float ld_wt(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ bool is_sentinel(float v) { return __builtin_bit_cast(uint32_t, v) == WS_SENTINEL; }
@@ -765,9 +776,10 @@ __device__ __forceinline__ void split_merge(float* base0, bf16_t* out0, size_t o
           }
         }
       }
-      if (!__any(bad)) break;
+      if (!__any(bad)) { TVAL(6, (long long)tries); break; }
       if (tries >= (1u << 18)) { *s_timeout = 1; break; }
     }
+    TMARK(4);
     if (own_q && grp == (n_split - 1) % G)                     // split n_split - 1 is the last one of its group: same order as through `ws`
       fold(own_q[HD], own_q[HD + 1], own_q[d0], two ? own_q[d0 + 64] : 0.f);
     if (G > 1) {
@@ -796,6 +808,7 @@ __device__ __forceinline__ void split_merge(float* base0, bf16_t* out0, size_t o
       out0[(size_t)q * out_qstride + d0] = f32_to_bf16(a0 * inv);
       if (two) out0[(size_t)q * out_qstride + d0 + 64] = f32_to_bf16(a1 * inv);
     }
+    TMARK(5);
     for (int s = grp; s < n_glob; s += G) {                    // sentinel back (after the output: off its path): ready for the next launch
       st_wt(base + s * sstr + d0, sentinel);
       if (two) st_wt(base + s * sstr + d0 + 64, sentinel);
@@ -1127,6 +1140,14 @@ __device__ __forceinline__ void attn_decode_body(const AttnDecP& p, const int bx
 // many partials.  LDS image: [K slice of wave 0..3: 32 keys x 192 B, chunk c of row r at c ^ ((r >> 2) & 3)]
 // [V^T tile: 96 rows x 256 B, chunk c (of 16) of row d at c ^ (d & 15): the 16 rows x 2 key groups of a ds_read_b64 lane
 // group hit 32 different 8-byte slots].  The merge scratch aliases the (dead) tile region.
+// V2 (default; V1 = the same kernel without it, P3V_ATTN_V1=1 for A/B): the per-workgroup timeline (-DP3V_ATTN_TIMING,
+// tools/scratch/attn_timeline.py) showed that everything after the DMA issue ran AFTER the whole tile had landed: memory
+// returns in order, and the compiler answers a pending `global_load_lds` with vmcnt(0) at every later wait.  V2 issues the
+// tile as `buffer_load ... lds` (counted waits stay possible), AFTER the small loads of the new rows, and hides from the
+// compiler the LDS accesses that do not depend on the tile (inline asm): Q is rotated, published and fetched while the tile
+// is in flight, S^T and the softmax start when the wave's own K slice (its six oldest DMAs, vmcnt(6)) is there and run
+// while the V^T tile is still landing.  10.9 -> 10.6 us isolated, 11.1 -> 10.65 us in the decode step.
+template <bool V2>
 __device__ __forceinline__ void attn_decode_body128(const AttnDecP& p, const int bx, const int by, const int bz, unsigned char* KV) {
   constexpr int TK = 128, WK = 32, HD = 96, KROW = HD * 2, VROWB = TK * 2, NKS = 3, NDT = 6, CPR = 12;
   constexpr int KS_BYTES = WK * KROW;                          // 6 KiB per wave = 16 x 96 fp32: the wave's O partial parks here
@@ -1140,6 +1161,7 @@ __device__ __forceinline__ void attn_decode_body128(const AttnDecP& p, const int
   unsigned char* kslice = KV + wave * KS_BYTES;
   unsigned char* vtile = KV + 4 * KS_BYTES;
 
+  TMARK(0);
   int past = p.past, pad = 0;
   if (p.d_past) asm volatile("s_load_dword %0, %1, 0x0" : "=s"(past) : "s"(p.d_past) : "memory");
   if (p.pad_len) asm volatile("s_load_dword %0, %1, 0x0" : "=s"(pad) : "s"(p.pad_len + b) : "memory");
@@ -1149,23 +1171,30 @@ __device__ __forceinline__ void attn_decode_body128(const AttnDecP& p, const int
   bf16_t* vc = p.v_cache + ((size_t)b * p.nkv + kvh) * (size_t)HD * p.cache_t;          // V^T: [hd][cache_t]
   const int kv_lo = bx * TK, kv_hi = min(p.cache_t, kv_lo + TK);
   const size_t vrow = (size_t)p.cache_t * 2;
-  {
+  auto issue_dma = [&]() {
     const int kv0 = min(kv_lo, p.cache_t - TK);
     const unsigned char* ksrc = kc + (size_t)(kv0 + WK * wave) * KROW;
+    const unsigned char* vs = (const unsigned char*)vc + (size_t)kv0 * 2;
+    // V2: MUBUF form.  The compiler's wait-count model treats a pending `global_load_lds` as a FLAT access of both memories
+    // and turns every later vmcnt wait into vmcnt(0); a pending `buffer_load ... lds` keeps counted waits possible.
+    const __amdgpu_buffer_rsrc_t rs_k = __builtin_amdgcn_make_buffer_rsrc((void*)ksrc, 0, 0xffffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_v = __builtin_amdgcn_make_buffer_rsrc((void*)vs, 0, 0xffffffff, 0x00020000);
 #pragma unroll
     for (int j = 0; j < 6; ++j) {                              // K: LDS slot i = j*64 + lane holds (row i/12, physical chunk i%12)
       const int i = j * 64 + lane, r0 = i / CPR, pc = i - r0 * CPR;
       const unsigned koff = r0 * KROW + ((pc ^ ((r0 >> 2) & 3)) << 4);
-      __builtin_amdgcn_global_load_lds((dec_gptr_t)(ksrc + koff), (dec_lptr_t)(kslice + j * 1024), 16, 0, P3V_ATTN_AUX);
+      if (V2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_k, (dec_lptr_t)(kslice + j * 1024), 16, koff, 0, 0, P3V_ATTN_AUX);
+      else __builtin_amdgcn_global_load_lds((dec_gptr_t)(ksrc + koff), (dec_lptr_t)(kslice + j * 1024), 16, 0, P3V_ATTN_AUX);
     }
-    const unsigned char* vs = (const unsigned char*)vc + (size_t)kv0 * 2;
 #pragma unroll
     for (int j = 0; j < 6; ++j) {                              // V^T: wave w brings rows 24w..24w+23, four whole 256-B rows per instruction
       const int d = 24 * wave + 4 * j + (lane >> 4);
       const unsigned voff = (unsigned)d * (unsigned)vrow + ((((unsigned)lane & 15) ^ ((unsigned)d & 15)) << 4);
-      __builtin_amdgcn_global_load_lds((dec_gptr_t)(vs + voff), (dec_lptr_t)(vtile + wave * 6144 + j * 1024), 16, 0, P3V_ATTN_AUX);
+      if (V2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_v, (dec_lptr_t)(vtile + wave * 6144 + j * 1024), 16, voff, 0, 0, P3V_ATTN_AUX);
+      else __builtin_amdgcn_global_load_lds((dec_gptr_t)(vs + voff), (dec_lptr_t)(vtile + wave * 6144 + j * 1024), 16, 0, P3V_ATTN_AUX);
     }
-  }
+  };
+  if (!V2) issue_dma();
 
   // ---- the L new rows (as attn_decode_body): rotated Q -> LDS, rotated K / V kept until the tile that holds them has landed
   const int row_w = (p.nh + 2 * p.nkv) * HD;
@@ -1189,10 +1218,16 @@ __device__ __forceinline__ void attn_decode_body128(const AttnDecP& p, const int
     const int r = tid / HD;
     v_early = vnew[(size_t)r * row_w + (tid - r * HD)];
   }
+  if (V2) issue_dma();                                         // after the (small) loads above: memory returns in order
+  TMARK(7);
+  const unsigned qs_lds = (unsigned)(size_t)(dec_lptr_t)Qs;
   if (tid < 16 * CPR) {
     u32x4_t v = {0, 0, 0, 0};
     if (rtask) v = rope_apply(qraw, tc);
-    *(u32x4_t*)(Qs + tr * KROW + ((tc ^ ((tr >> 2) & 3)) << 4)) = v;
+    if (V2)                                                    // LDS accesses the compiler must not see: it would wait for the whole tile first
+      asm volatile("ds_write_b128 %0, %1" ::"v"(qs_lds + tr * KROW + ((tc ^ ((tr >> 2) & 3)) << 4)), "v"(v) : "memory");
+    else
+      *(u32x4_t*)(Qs + tr * KROW + ((tc ^ ((tr >> 2) & 3)) << 4)) = v;
   }
 
   asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(past), "+s"(pad)::"memory");
@@ -1214,13 +1249,30 @@ __device__ __forceinline__ void attn_decode_body128(const AttnDecP& p, const int
   for (int d = 0; d < NDT; ++d) o[d] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
   const int kv0 = kv_lo;
+  TMARK(8);
   if (kv0 < kv_end) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
     bf16x8_t qf[NKS];
+    const bool has_new = kv0 + TK > past;                      // workgroup-uniform: the tile holds new positions
+    if (V2) {                                                  // Q is published and fetched while the tile is in flight
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      u32x4_t q0, q1, q2;
+      asm volatile("ds_read_b128 %0, %3\n\tds_read_b128 %1, %3 offset:64\n\tds_read_b128 %2, %3 offset:128\n\ts_waitcnt lgkmcnt(0)"
+                   : "=&v"(q0), "=&v"(q1), "=&v"(q2) : "v"(qs_lds + k_rd) : "memory");
+      qf[0] = __builtin_bit_cast(bf16x8_t, q0); qf[1] = __builtin_bit_cast(bf16x8_t, q1); qf[2] = __builtin_bit_cast(bf16x8_t, q2);
+      if (has_new) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+      }
+      TMARK(1);
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      TMARK(1);
 #pragma unroll
-    for (int ks = 0; ks < NKS; ++ks) qf[ks] = *(const bf16x8_t*)(Qs + k_rd + ks * 64);
-    if (kv0 + TK > past) {                                     // workgroup-uniform: the tile holds new positions
+      for (int ks = 0; ks < NKS; ++ks) qf[ks] = *(const bf16x8_t*)(Qs + k_rd + ks * 64);
+    }
+    TMARK(9);
+    if (has_new) {
       if (rtask) {
         const int t = past + tr, rr = t - kv0;
         if (rr >= 0 && rr < TK && t < kv_end) {
@@ -1243,13 +1295,33 @@ __device__ __forceinline__ void attn_decode_body128(const AttnDecP& p, const int
     }
 
     f32x4_t s[2];
+    if (V2 && !has_new) {
+      // this wave's K slice = its six oldest DMAs: S^T and the softmax run while the V^T tile is still landing
+      u32x4_t kf[2][NKS];
+      const unsigned ka = (unsigned)(size_t)(dec_lptr_t)kslice + k_rd;
+      asm volatile("s_waitcnt vmcnt(6)\n\t"
+                   "ds_read_b128 %0, %6\n\tds_read_b128 %1, %6 offset:64\n\tds_read_b128 %2, %6 offset:128\n\t"
+                   "ds_read_b128 %3, %6 offset:3072\n\tds_read_b128 %4, %6 offset:3136\n\tds_read_b128 %5, %6 offset:3200\n\t"
+                   "s_waitcnt lgkmcnt(0)"
+                   : "=&v"(kf[0][0]), "=&v"(kf[0][1]), "=&v"(kf[0][2]), "=&v"(kf[1][0]), "=&v"(kf[1][1]), "=&v"(kf[1][2])
+                   : "v"(ka) : "memory");
+      static_assert(16 * KROW == 3072, "second key block of the wave's slice");
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-      s[kb] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+      for (int kb = 0; kb < 2; ++kb) {
+        s[kb] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int ks = 0; ks < NKS; ++ks) {
-        const bf16x8_t kf = *(const bf16x8_t*)(kslice + kb * 16 * KROW + k_rd + ks * 64);
-        s[kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], s[kb], 0, 0, 0);
+        for (int ks = 0; ks < NKS; ++ks)
+          s[kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, kf[kb][ks]), qf[ks], s[kb], 0, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+        s[kb] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+          const bf16x8_t kf = *(const bf16x8_t*)(kslice + kb * 16 * KROW + k_rd + ks * 64);
+          s[kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], s[kb], 0, 0, 0);
+        }
       }
     }
     float m_t = -INFINITY;
@@ -1274,8 +1346,13 @@ __device__ __forceinline__ void attn_decode_body128(const AttnDecP& p, const int
       }
     l_run = rows_sum(l_t);
     m_run = m_t;
+    if (l_run == 12345.f) TVAL(15, 1);                         // consume the softmax before the mark
+    TMARK(10);
     const u32x4_t pw = {pack_bf16x2(s[0][0], s[0][1]), pack_bf16x2(s[0][2], s[0][3]), pack_bf16x2(s[1][0], s[1][1]), pack_bf16x2(s[1][2], s[1][3])};
     const bf16x8_t pf = __builtin_bit_cast(bf16x8_t, pw);
+    if (V2 && !has_new) {                                      // the V^T tile is every wave's DMA: all landed, then the barrier
+      asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    }
 #pragma unroll
     for (int d = 0; d < NDT; ++d) {
       const u32x2_t a0 = *(const u32x2_t*)(vtile + v_rd[0] + d * 16 * VROWB), a1 = *(const u32x2_t*)(vtile + v_rd[1] + d * 16 * VROWB);
@@ -1288,8 +1365,11 @@ __device__ __forceinline__ void attn_decode_body128(const AttnDecP& p, const int
   const bool merger = p.counters && bx == p.n_split - 1;       // the highest split of a (b, head) merges in-launch
   float* own = (float*)(vtile + 4096);                         // its partial: [16][HD + 2] in the dead V^T tile (merge scratch: first 4 KiB)
   static_assert(SPLIT_MERGE_SCRATCH(256) * 4 <= 4096 && 4096 + 16 * (HD + 2) * 4 <= 96 * 256, "merge scratch + own partial fit the V^T tile");
+  if (o[0][0] == 12345.f) TVAL(15, 2);
+  TMARK(11);
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __syncthreads();
+  TMARK(2);
   if (qvalid) {
     float* Ow = (float*)kslice + qi * HD;
 #pragma unroll
@@ -1320,14 +1400,16 @@ __device__ __forceinline__ void attn_decode_body128(const AttnDecP& p, const int
       if (d == 0) { st_wt(w + HD, M); st_wt(w + HD + 1, lsum); }
     }
   }
+  TMARK(3);
   if (merger)
     split_merge<256>(p.ws + ((size_t)b * p.nh + head) * p.n_split * 16 * (HD + 2), p.out + (size_t)b * p.L * (p.nh * HD) + head * HD,
                      (size_t)p.nh * HD, p.L, p.n_split, own, (float*)vtile);
 }
 
+template <bool V2>
 __global__ void __launch_bounds__(256) k_attn_decode128(AttnDecP p) {
   __shared__ __attribute__((aligned(1024))) unsigned char KV[4 * 6144 + 96 * 256];   // [K slice x 4 | V^T tile] = 48 KiB
-  attn_decode_body128(p, blockIdx.x, blockIdx.y, blockIdx.z, KV);
+  attn_decode_body128<V2>(p, blockIdx.x, blockIdx.y, blockIdx.z, KV);
 }
 
 __global__ void __launch_bounds__(256) k_attn_decode(AttnDecP p) {
@@ -1608,7 +1690,11 @@ extern "C" int p3v_attention_decode(const p3v_attn_decode_args_t* a, void* strea
   hipStream_t s = (hipStream_t)stream;
   const dim3 grid(a->n_split, a->n_heads, a->B);
   if (a->n_split * 64 >= a->cache_t) hipLaunchKernelGGL(k_attn_decode, grid, dim3(256), 0, s, p);
-  else if (a->n_split * 128 >= a->cache_t && a->cache_t % 128 == 0) hipLaunchKernelGGL(k_attn_decode128, grid, dim3(256), 0, s, p);   // 128-key tiles
+  else if (a->n_split * 128 >= a->cache_t && a->cache_t % 128 == 0) {                     // 128-key tiles
+    static const bool v1 = getenv("P3V_ATTN_V1") != nullptr;
+    if (v1) hipLaunchKernelGGL(k_attn_decode128<false>, grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(k_attn_decode128<true>, grid, dim3(256), 0, s, p);
+  }
   else hipLaunchKernelGGL(k_attn_decode_stream<64>, grid, dim3(64), 0, s, p);
   P3V_CHECK_LAUNCH();
   if (a->counters) return P3V_OK;                              // the last workgroup of every (b, head) merged in-kernel
