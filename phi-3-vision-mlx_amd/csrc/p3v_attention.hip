@@ -467,23 +467,35 @@ __global__ void __launch_bounds__(256, 2) k_attn_prefill_dma(AttnP p) {
     const int sw = HD == 96 ? (row >> 2) & 3 : (row >> 1) & 7;
     koff[jj] = row * KROW + ((pc ^ sw) << 4);
   }
-  const size_t vrow = (size_t)p.past_t * 2;
-  size_t voff[NV / 4];
+  const unsigned vrow = (unsigned)p.past_t * 2;
+  unsigned voff[NV / 4];
 #pragma unroll
   for (int jj = 0; jj < NV / 4; ++jj) {
     const int i = (wave + 4 * jj) * 64 + lane, row = i >> 3, pc = i & 7;
-    voff[jj] = (size_t)row * vrow + ((pc ^ ((row >> 1) & 7)) << 4);
+    voff[jj] = (unsigned)row * vrow + ((pc ^ ((row >> 1) & 7)) << 4);
   }
+  // MUBUF form of the LDS-DMA (a pending `global_load_lds` makes the compiler turn every later wait into vmcnt(0) /
+  // lgkmcnt(0): the fragment reads of the tile in work could not be counted while the next tile was in flight)
+  const __amdgpu_buffer_rsrc_t rs_k = __builtin_amdgcn_make_buffer_rsrc((void*)kbase, 0, 0xffffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_v = __builtin_amdgcn_make_buffer_rsrc((void*)vbase, 0, 0xffffffff, 0x00020000);
   auto stage = [&](int kv0, int buf) {
     unsigned char* Ks = smem + buf * BUF;
-    const unsigned char* ks = kbase + (size_t)kv0 * KROW;
-    const unsigned char* vs = vbase + (size_t)kv0 * 2;
+    // (every argument of the builtin is copied into a local of non-dependent type: with a type-dependent argument -- an
+    // element of an array whose size depends on HD -- the call is only checked at instantiation, fails there in the HOST pass,
+    // where the builtin does not exist, and hipcc silently drops the kernel's host stub)
+    const int so_k = kv0 * KROW, so_v = kv0 * 2;
 #pragma unroll
-    for (int jj = 0; jj < NK / 4; ++jj)
-      __builtin_amdgcn_global_load_lds((pf_gptr_t)(ks + koff[jj]), (pf_lptr_t)(Ks + (wave + 4 * jj) * 1024), 16, 0, 0);
+    for (int jj = 0; jj < NK / 4; ++jj) {
+      const unsigned vo = koff[jj];
+      pf_lptr_t dst = (pf_lptr_t)(Ks + (wave + 4 * jj) * 1024);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_k, dst, 16, vo, so_k, 0, 0);
+    }
 #pragma unroll
-    for (int jj = 0; jj < NV / 4; ++jj)
-      __builtin_amdgcn_global_load_lds((pf_gptr_t)(vs + voff[jj]), (pf_lptr_t)(Ks + KTILE + (wave + 4 * jj) * 1024), 16, 0, 0);
+    for (int jj = 0; jj < NV / 4; ++jj) {
+      const unsigned vo = voff[jj];
+      pf_lptr_t dst = (pf_lptr_t)(Ks + KTILE + (wave + 4 * jj) * 1024);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_v, dst, 16, vo, so_v, 0, 0);
+    }
   };
 
   // ---- fragment read offsets

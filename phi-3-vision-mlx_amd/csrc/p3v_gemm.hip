@@ -78,15 +78,19 @@ __global__ void __launch_bounds__(256, 2) k_gemm(GemmP p) {
 
   // ---- staging addresses: wave w issues 4 DMA pieces per operand, piece q covers tile rows (w*4+q)*8 .. +8
   const int srow = lane >> 3, schunk = lane & 7;
-  const bf16_t* a_src[4];
-  const bf16_t* b_src[4];
+  // byte offsets from p.A / p.W: the DMA is issued in its MUBUF form (`buffer_load ... lds`).  A pending `global_load_lds`
+  // is, for the compiler's wait-count model, a FLAT access of both memories, and every later s_waitcnt becomes
+  // vmcnt(0) / lgkmcnt(0): the counted lgkmcnt on the fragment reads below was silently a full wait.
+  unsigned a_src[4], b_src[4];
+  const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, 0xffffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, 0xffffffff, 0x00020000);
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int r = (wave * 4 + q) * 8 + srow;                 // tile row 0..127
     const int sw = (schunk ^ (r & 7)) * 8;                   // swizzled source chunk (elements)
     int ar = m0 + r;
     ar = ar < p.M ? ar : p.M - 1;
-    a_src[q] = p.A + (size_t)ar * p.lda + sw;
+    a_src[q] = (unsigned)(((size_t)ar * p.lda + sw) * 2);
     int br;
     if (SILU) {
       const int wcol = r >> 6, ni = (r & 63) >> 4, c = r & 15;
@@ -96,7 +100,7 @@ __global__ void __launch_bounds__(256, 2) k_gemm(GemmP p) {
       br = n0 + r;
       br = br < p.N ? br : p.N - 1;
     }
-    b_src[q] = p.W + (size_t)br * p.ldw + sw;
+    b_src[q] = (unsigned)(((size_t)br * p.ldw + sw) * 2);
   }
   const int nk = p.K / BK;
 
@@ -105,8 +109,8 @@ __global__ void __launch_bounds__(256, 2) k_gemm(GemmP p) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int piece = (wave * 4 + q) * 1024;
-      __builtin_amdgcn_global_load_lds((gptr_t)(a_src[q] + (size_t)kt * BK), (lptr_t)(base + piece), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((gptr_t)(b_src[q] + (size_t)kt * BK), (lptr_t)(base + TILE_BYTES + piece), 16, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lptr_t)(base + piece), 16, a_src[q], kt * (BK * 2), 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lptr_t)(base + TILE_BYTES + piece), 16, b_src[q], kt * (BK * 2), 0, 0);
     }
   };
 
@@ -310,6 +314,10 @@ extern "C" int p3v_gemm(const p3v_gemm_args_t* a, void* stream) {
   if (a->epilogue == P3V_EPI_PATCH && (!a->pos || a->patches_per_img <= 0)) return P3V_ERR_ARG;
   if (a->epilogue < 0 || a->epilogue > P3V_EPI_F32) return P3V_ERR_ARG;
   if (a->M == 0) return P3V_OK;
+  {                                                            // operands are addressed with 32-bit byte offsets (buffer loads)
+    const size_t w_rows = (size_t)a->N * (a->epilogue == P3V_EPI_SILU_MUL ? 2 : 1);
+    if ((size_t)a->M * a->lda * 2 >= (1ull << 32) || w_rows * a->ldw * 2 >= (1ull << 32)) return P3V_ERR_UNSUPPORTED;
+  }
   hipStream_t s = (hipStream_t)stream;
   static const bool big_tiles = !getenv("P3V_GEMM_128");
   const int rows_big = big_tiles ? gemm_big_rows(a) : 0;
