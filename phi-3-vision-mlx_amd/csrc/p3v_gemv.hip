@@ -297,32 +297,62 @@ __global__ void __launch_bounds__(256) k_gemv_mfma(GemvP p) {
 // stages that slice of x itself; the only workgroup barrier before the stream is the RMSNorm sum-of-squares exchange.
 // LDS row stride 2K + 64 bytes: the 16 (x row, chunk) slots of every ds_read_b128 lane group fall on 16 different
 // 16-byte bank groups.  K = 3072: 4 waves, 49.7 KB -> 3 workgroups / CU.  K = 8192: 8 waves, 131 KB -> 1 workgroup / CU.
-template <bool SILU, int NW, int NST>
-__global__ void __launch_bounds__(NW * 64) k_gemv_mfma8(GemvP p) {
-  constexpr int NBUF = NST < 3 ? NST : 3;
+#ifdef P3V_ATTN_TIMING                                         // tools/scratch/gemv8_timeline.py: 100 MHz timestamps per workgroup
+__device__ long long p3v_gbuf[4096 * 8];
+#define GMARK(k) do { if (threadIdx.x == 0 && blockIdx.x < 4096) p3v_gbuf[blockIdx.x * 8 + (k)] = wall_clock64(); } while (0)
+extern "C" int p3v_gemv_timing_read(long long* out, int n) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(p3v_gbuf), sizeof(long long) * n) == hipSuccess ? 0 : -1;
+}
+#else
+#define GMARK(k)
+#endif
+// Round 2: PERSISTENT over row sets.  The per-workgroup timeline (-DP3V_ATTN_TIMING, tools/scratch/gemv8_timeline.py) of the
+// one-set-per-workgroup form (qkv: 576 workgroups, 3 per CU) showed the activations arriving 2-11 us after entry (27.6 MB
+// of x reads of the same 48 KB by 2304 waves) and the RMSNorm pass over 8 x 768 values per wave costing another 3 us with
+// 12 waves per CU doing it at once: the weights had landed long before anybody could use them (16.2 us for 56.6 MB).  Now
+// a workgroup stages x ONCE and walks `sets` strided row sets (grid <= 512), a wave's whole slice of the NEXT set
+// being requested stage by stage as the stages of the current one are consumed; the K-slice partials of a set are
+// exchanged through a double-buffered 2 KB LDS block (one barrier per set).  The RMSNorm scale r of a row is a scalar: it
+// is applied to the dot products in the epilogue (as k_gemv_mfma above does), the matrix cores see bf16(x * g) -- one bf16
+// rounding of the activation, as in the reference, but no exchange of sums and no second pass over the slice before the
+// first MFMA (that pass took 3 us; the sums are exchanged by the barrier the partials need anyway).  (Two slices in
+// flight per wave -- tried: the 32 extra load instructions block the wave in issue while the queues are full and the
+// prologue behind them gets later, not earlier.)
+template <bool SILU, int NW, int NST, int DEPTH>
+__global__ void __launch_bounds__(NW * 64) k_gemv_mfma8(GemvP p, int n_sets) {
   constexpr int KQ = NST * 256, K = KQ * NW, XS = K * 2 + 64, NCH = KQ / 8;     // slice elements, LDS row stride (bytes), slice chunks
+  constexpr int ROWS = SILU ? 8 : 16;                                            // output columns per set
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ float red[NW][8];
+  __shared__ float cpart[2][NW * 2 * 8 * 8];                                     // [parity][wave][row set][weight row][x row]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4;
   const int r8 = (lane & 15) >> 1, chunk = 2 * g + (lane & 1);                   // weight row in the set / x row; 16-byte chunk of a line
-  const int n_base = blockIdx.x * (SILU ? 8 : 16), k_lo = wave * KQ;
-  const int row0 = min(n_base + r8, p.N - 1);
-  const int row1 = SILU ? p.N + row0 : min(n_base + 8 + r8, p.N - 1);
-  const bf16_t* w0 = p.W + (size_t)row0 * K + k_lo + 8 * chunk;
-  const bf16_t* w1 = p.W + (size_t)row1 * K + k_lo + 8 * chunk;
+  const int k_lo = wave * KQ;
+  auto row_ptrs = [&](int set, const bf16_t*& w0, const bf16_t*& w1) {
+    const int n_base = set * ROWS;
+    const int row0 = min(n_base + r8, p.N - 1);
+    const int row1 = SILU ? p.N + row0 : min(n_base + 8 + r8, p.N - 1);
+    w0 = p.W + (size_t)row0 * K + k_lo + 8 * chunk;
+    w1 = p.W + (size_t)row1 * K + k_lo + 8 * chunk;
+  };
+  int set = blockIdx.x;
+  const bf16_t *w0, *w1;
+  row_ptrs(set, w0, w1);
 
-  u32x4_t wa[NBUF][8];                                                           // stage = 4 lines x 2 row sets
-  auto issue = [&](int st, auto bufc) {
-    constexpr int buf = decltype(bufc)::value;
+  u32x4_t wa[DEPTH][NST][8];                                                     // stage = 4 lines x 2 row sets; DEPTH whole slices
+  auto issue = [&](const bf16_t* a0, const bf16_t* a1, auto stc, auto slotc) {
+    constexpr int st = decltype(stc)::value, slot = decltype(slotc)::value;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      wa[buf][2 * q] = __builtin_nontemporal_load((const u32x4_t*)(w0 + (st * 4 + q) * 64));
-      wa[buf][2 * q + 1] = __builtin_nontemporal_load((const u32x4_t*)(w1 + (st * 4 + q) * 64));
+      wa[slot][st][2 * q] = __builtin_nontemporal_load((const u32x4_t*)(a0 + (st * 4 + q) * 64));
+      wa[slot][st][2 * q + 1] = __builtin_nontemporal_load((const u32x4_t*)(a1 + (st * 4 + q) * 64));
     }
   };
   typedef std::integral_constant<int, 2> IC2;
+  typedef std::integral_constant<int, 3> IC3;
 
-  // ---- x slice (8 rows x NCH chunks, lanes over chunks) first, then the weight stages that fit next to it
+  // ---- x slice (8 rows x NCH chunks, lanes over chunks) first, then the weight stages of the first set
+  GMARK(0);
   unsigned char* xslice = smem + k_lo * 2;
   u32x4_t gv[2];
   float ss[8];
@@ -335,126 +365,151 @@ __global__ void __launch_bounds__(NW * 64) k_gemv_mfma8(GemvP p) {
       for (int m = 0; m < 8; ++m) xv[m][k] = *(const u32x4_t*)(p.x + (size_t)min(m, p.M - 1) * K + k_lo + 8 * c);
       gv[k] = p.norm_w ? *(const u32x4_t*)(p.norm_w + k_lo + 8 * c) : (u32x4_t){0, 0, 0, 0};
     }
-    issue(0, IC0{});
-    if constexpr (NBUF > 1) issue(1, IC1{});
+    issue(w0, w1, IC0{}, IC0{});
+    if constexpr (NST > 1) issue(w0, w1, IC1{}, IC0{});
+    if (p.norm_w) {                                                              // RMSNorm: park bf16(x * g), keep the sums of squares
 #pragma unroll
-    for (int m = 0; m < 8; ++m) {
-      ss[m] = 0.f;
+      for (int m = 0; m < 8; ++m) {
+        ss[m] = 0.f;
 #pragma unroll
-      for (int k = 0; k < 2; ++k) {
-        const int c = lane + 64 * k;
-        if (c < NCH) {
+        for (int k = 0; k < 2; ++k) {
+          const int c = lane + 64 * k;
+          if (c < NCH) {
+            u32x4_t o;
 #pragma unroll
-          for (int j = 0; j < 4; ++j) { const float a = bf16lo(xv[m][k][j]), b = bf16hi(xv[m][k][j]); ss[m] += a * a + b * b; }
-          *(u32x4_t*)(xslice + m * XS + c * 16) = m < p.M ? xv[m][k] : (u32x4_t){0, 0, 0, 0};
+            for (int j = 0; j < 4; ++j) {
+              const float a = bf16lo(xv[m][k][j]), b = bf16hi(xv[m][k][j]);
+              ss[m] += a * a + b * b;
+              o[j] = pack_bf16x2(a * bf16lo(gv[k][j]), b * bf16hi(gv[k][j]));
+            }
+            *(u32x4_t*)(xslice + m * XS + c * 16) = m < p.M ? o : (u32x4_t){0, 0, 0, 0};
+          }
         }
       }
+    } else {
+#pragma unroll
+      for (int m = 0; m < 8; ++m)
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const int c = lane + 64 * k;
+          if (c < NCH) *(u32x4_t*)(xslice + m * XS + c * 16) = m < p.M ? xv[m][k] : (u32x4_t){0, 0, 0, 0};
+        }
     }
   }
-  if constexpr (NBUF > 2) issue(2, IC2{});
-  if (p.norm_w) {
+  GMARK(1);
+  if constexpr (NST > 2) issue(w0, w1, IC2{}, IC0{});
+  if constexpr (NST > 3) issue(w0, w1, IC3{}, IC0{});
+  GMARK(2);
+  if (p.norm_w) {                                                                // sums of squares: read after the first set's barrier
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
       const float t = wave_sum(ss[m]);
       if (lane == 0) red[wave][m] = t;
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-#pragma unroll
-    for (int m = 0; m < 8; ++m) {
-      float t = 0.f;
-#pragma unroll
-      for (int w = 0; w < NW; ++w) t += red[w][m];
-      const float r = rsqrtf(t / (float)K + p.eps);
-#pragma unroll
-      for (int k = 0; k < 2; ++k) {
-        const int c = lane + 64 * k;
-        if (c < NCH) {
-          u32x4_t* px = (u32x4_t*)(xslice + m * XS + c * 16);
-          const u32x4_t v = *px;
-          u32x4_t o;
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-            o[j] = pack_bf16x2(bf16lo(v[j]) * r * bf16lo(gv[k][j]), bf16hi(v[j]) * r * bf16hi(gv[k][j]));
-          *px = o;
-        }
-      }
-    }
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                           // the slice is wave-private: no barrier
+  GMARK(3);
 
-  f32x4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
   const unsigned char* xrow = xslice + r8 * XS + chunk * 16;
-  auto compute = [&](int st, auto bufc) {
-    constexpr int buf = decltype(bufc)::value;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const bf16x8_t xb = *(const bf16x8_t*)(xrow + (st * 4 + q) * 128);
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wa[buf][2 * q]), xb, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wa[buf][2 * q + 1]), xb, acc1, 0, 0, 0);
-    }
-  };
-  // stage st lives in buffer st % NBUF; stage st + NBUF is requested right after stage st has been consumed
-  auto step = [&](auto stc) {
-    constexpr int st = decltype(stc)::value;
-    if constexpr (st < NST) {
-      compute(st, std::integral_constant<int, st % NBUF>{});
-      if constexpr (st + NBUF < NST) issue(st + NBUF, std::integral_constant<int, st % NBUF>{});
-    }
-  };
-  step(IC0{}); step(IC1{}); step(IC2{}); step(std::integral_constant<int, 3>{});
-  static_assert(NST <= 4, "unrolled for at most four stages");
-
-  // ---- C[4*(lane>>4) + e][lane&15]: with column j = 2m + h only elements e = h (weight row 2*(lane>>4)) and e = h + 2
-  // (row 2*(lane>>4) + 1) are dot products; add the two k-halves (lanes j = 2m, 2m + 1), then the NW K slices through LDS
   const bool odd = lane & 1;
-  float e[2][2] = {{odd ? acc0[1] : acc0[0], odd ? acc0[3] : acc0[2]}, {odd ? acc1[1] : acc1[0], odd ? acc1[3] : acc1[2]}};
+  int par = 0;
+  // one row set out of register slot `slot`; its registers are refilled stage by stage with the set DEPTH strides ahead
+  auto do_set = [&](auto slotc) {
+    constexpr int slot = decltype(slotc)::value;
+    const int nset = set + DEPTH * (int)gridDim.x;
+    const bool has_next = nset < n_sets;                                         // workgroup-uniform
+    const bf16_t *w0n = nullptr, *w1n = nullptr;
+    if (has_next) row_ptrs(nset, w0n, w1n);
+    f32x4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    auto step = [&](auto stc) {
+      constexpr int st = decltype(stc)::value;
+      if constexpr (st < NST) {
 #pragma unroll
-  for (int t = 0; t < 2; ++t)
-#pragma unroll
-    for (int u = 0; u < 2; ++u) e[t][u] += P3V_DPP_F32(e[t][u], 0xB1);          // quad_perm [1,0,3,2]
-  __syncthreads();                                                    // the x image is dead once every wave is past its stream
-  float* cpart = (float*)smem;                                        // [NW][2 sets][8 rows][8 x rows]
-  if (!odd) {
+        for (int q = 0; q < 4; ++q) {
+          const bf16x8_t xb = *(const bf16x8_t*)(xrow + (st * 4 + q) * 128);
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wa[slot][st][2 * q]), xb, acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wa[slot][st][2 * q + 1]), xb, acc1, 0, 0, 0);
+        }
+        if (has_next) issue(w0n, w1n, stc, slotc);
+      }
+    };
+    step(IC0{}); step(IC1{}); step(IC2{}); step(IC3{});
+    static_assert(NST <= 4, "unrolled for at most four stages");
+
+    // ---- C[4*(lane>>4) + e][lane&15]: with column j = 2m + h only elements e = h (weight row 2*(lane>>4)) and e = h + 2
+    // (row 2*(lane>>4) + 1) are dot products; add the two k-halves (lanes j = 2m, 2m + 1), then the NW K slices through LDS
+    float e[2][2] = {{odd ? acc0[1] : acc0[0], odd ? acc0[3] : acc0[2]}, {odd ? acc1[1] : acc1[0], odd ? acc1[3] : acc1[2]}};
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
-      for (int u = 0; u < 2; ++u) cpart[((wave * 2 + t) * 8 + 2 * g + u) * 8 + r8] = e[t][u];
-  }
-  __syncthreads();
-  if (tid >= (SILU ? 64 : 128)) return;
-  const int R = tid & 7, m = (tid >> 3) & 7, set = tid >> 6;
-  const int n = n_base + set * 8 + R;
-  if (m >= p.M || n >= p.N) return;
-  float v0 = 0.f, v1 = 0.f;
+      for (int u = 0; u < 2; ++u) e[t][u] += P3V_DPP_F32(e[t][u], 0xB1);        // quad_perm [1,0,3,2]
+    GMARK(4);
+    float* cp = cpart[par];
+    if (!odd) {
 #pragma unroll
-  for (int w = 0; w < NW; ++w) {
-    v0 += cpart[((w * 2 + set) * 8 + R) * 8 + m];
-    if (SILU) v1 += cpart[((w * 2 + 1) * 8 + R) * 8 + m];
-  }
-  const size_t o = (size_t)m * p.N + n;
-  if (SILU) {
-    const float gt = bf16_round(v0), up = bf16_round(v1);
-    ((bf16_t*)p.out)[o] = f32_to_bf16(bf16_round(gt * bf16_round(1.f / (1.f + __expf(-gt)))) * up);
-  } else if (p.epi == P3V_EPI_F32) {
-    ((float*)p.out)[o] = v0;
-  } else if (p.epi == P3V_EPI_RESID_BF16) {
-    ((bf16_t*)p.out)[o] = f32_to_bf16(bf16_to_f32(p.resid[o]) + bf16_round(v0));
-  } else {
-    ((bf16_t*)p.out)[o] = f32_to_bf16(v0);
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) cp[((wave * 2 + t) * 8 + 2 * g + u) * 8 + r8] = e[t][u];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                                                // (the weight loads of the sets ahead stay in flight across it)
+    GMARK(6);
+    if (tid < (SILU ? 64 : 128)) {
+      const int R = tid & 7, m = (tid >> 3) & 7, sub = tid >> 6;
+      const int n = set * ROWS + sub * 8 + R;
+      if (m < p.M && n < p.N) {
+        float v0 = 0.f, v1 = 0.f, t = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+          v0 += cp[((w * 2 + sub) * 8 + R) * 8 + m];
+          if (SILU) v1 += cp[((w * 2 + 1) * 8 + R) * 8 + m];
+          t += red[w][m];
+        }
+        if (p.norm_w) {
+          const float r = rsqrtf(t / (float)K + p.eps);
+          v0 *= r;
+          v1 *= r;
+        }
+        const size_t o = (size_t)m * p.N + n;
+        if (SILU) {
+          const float gt = bf16_round(v0), up = bf16_round(v1);
+          ((bf16_t*)p.out)[o] = f32_to_bf16(bf16_round(gt * bf16_round(1.f / (1.f + __expf(-gt)))) * up);
+        } else if (p.epi == P3V_EPI_F32) {
+          ((float*)p.out)[o] = v0;
+        } else if (p.epi == P3V_EPI_RESID_BF16) {
+          ((bf16_t*)p.out)[o] = f32_to_bf16(bf16_to_f32(p.resid[o]) + bf16_round(v0));
+        } else {
+          ((bf16_t*)p.out)[o] = f32_to_bf16(v0);
+        }
+      }
+    }
+    set += (int)gridDim.x;
+    par ^= 1;
+    return set < n_sets;
+  };
+  for (;;) {
+    if (!do_set(IC0{})) break;
+    if constexpr (DEPTH > 1) {
+      if (!do_set(IC1{})) break;
+    }
   }
 }
 
 template <bool SILU, int NW, int NST>
 static int launch_gemv_mfma8(const GemvP& p, hipStream_t s) {
+  constexpr int DEPTH = 1;                                   // register slices in flight per wave (2: see the kernel's header)
   const size_t lds = (size_t)8 * (p.K * 2 + 64);
   static bool attr_set = false;
-  if (!attr_set && lds > 48 * 1024) {
-    if (hipFuncSetAttribute((const void*)k_gemv_mfma8<SILU, NW, NST>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512) != hipSuccess)
+  if (!attr_set && lds > 40 * 1024) {
+    if (hipFuncSetAttribute((const void*)k_gemv_mfma8<SILU, NW, NST, DEPTH>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 8704) != hipSuccess)
       return P3V_ERR_HIP;
     attr_set = true;
   }
-  hipLaunchKernelGGL((k_gemv_mfma8<SILU, NW, NST>), dim3(p3v_cdiv(p.N, SILU ? 8 : 16)), dim3(NW * 64), lds, s, p);
+  // <= 256 workgroups (one per CU: 192-256 VGPRs per wave), each walking `per` strided row sets
+  // (576 sets -> 192 x 3, 1024 -> 256 x 4, 2004 -> 251 x 8, 192 -> 192 x 1)
+  static const int max_wg = gemv_env("P3V_GEMV8_WGS", 256);
+  const int n_sets = p3v_cdiv(p.N, SILU ? 8 : 16), per = p3v_cdiv(n_sets, max_wg), grid = p3v_cdiv(n_sets, per);
+  hipLaunchKernelGGL((k_gemv_mfma8<SILU, NW, NST, DEPTH>), dim3(grid), dim3(NW * 64), lds, s, p, n_sets);
   P3V_CHECK_LAUNCH();
   return P3V_OK;
 }

@@ -433,11 +433,12 @@ class Phi3VModel:
                 n_split = int(os.environ["P3V_ATTN_NSPLIT"])
             bufs["n_split"] = n_split
             bufs["ws"] = ops.attention_ws(B, L, nh, hd, n_split, self.device)
-            # ready flags of the fused split-KV merge: used with the one-tile-per-workgroup plan only (measured: -17..-22 us
-            # per step at B = 1; with the multi-tile streaming kernel the write-through partial stores cost more than the
-            # merge launch saves, and beyond ~48 splits the one merging workgroup is slower than 32 parallel ones)
+            # in-launch split-KV merge (a non-null `counters` asks for it): with the one-tile-per-workgroup plans, and with the
+            # multi-tile streaming kernel when a head has at most 4 splits (B = 8: 3 splits -- the merge launch costs 4.9 us a
+            # layer, the in-launch merge 0.5; with 24 splits at B = 1 / 32k the one merging workgroup per head is the slower
+            # way: +1.6 % per step, +4.5 % at 8k)
             mode = os.environ.get("P3V_ATTN_FUSED_MERGE", "1")
-            fused = (n_split in (tiles, tiles128) or mode == "2") and n_split <= 48 and mode != "0"
+            fused = (n_split in (tiles, tiles128) or n_split <= 4 or mode == "2") and n_split <= 48 and mode != "0"
             bufs["attn_cnt"] = torch.zeros(B * nh * n_split, dtype=I32, device=self.device) if fused else None
 
     def _layers(self, x, st, B, L, past, n_beam, bufs=None, d_past=None, last_only=False):
