@@ -193,9 +193,9 @@ typedef struct {
   const int32_t* pad_len; const int32_t* d_past; float* ws;
   int B, L, n_heads, n_kv, hd, past, cache_t, rope_bstride, n_split;
   float scale;
-  int32_t* counters; /* optional [B * n_heads * n_split] int32, zero-initialised ONCE by the caller (every launch leaves it
-                        zero): the split-KV partials are then merged by the last split of each (b, head) inside the
-                        attention launch; NULL = a separate merge launch */
+  int merge_in_launch; /* nonzero: the split-KV partials are merged by the last split of each (b, head) INSIDE the attention
+                          launch; 0 = a separate merge launch.  Either way `ws` must hold 0xFF in every byte before its first use
+                          (hipMemset) and every launch leaves it so: a partial word is valid when it is not the all-ones pattern */
 } p3v_attn_decode_args_t;
 int p3v_attention_decode(const p3v_attn_decode_args_t* args /* host */, void* stream);
 /* cos/sin rows of positions [past, past+L) of each batch row ([B, tab_t, half] tables) -> [B, L, half] */
@@ -221,8 +221,8 @@ typedef struct {
   const int32_t* pad_len; const int32_t* d_past; float* ws;
   int B, L, n_heads, n_kv, hd, past, cache_t, rope_bstride, n_split;
   float scale;
-  int32_t* counters;      /* optional, as p3v_attn_decode_args_t.counters: zeroed int32 [B * n_heads * n_split] -> the splits are
-                             merged inside the attention launch (used when there is one tile per split and n_split <= 16) */
+  int merge_in_launch;    /* as p3v_attn_decode_args_t.merge_in_launch (honoured with one tile per split and n_split <= 16 on
+                             the 64-key plan, always on the 128-key plan; otherwise the merge launch runs) */
 } p3v_attn_decode_q8_args_t;
 int p3v_attention_decode_q8(const p3v_attn_decode_q8_args_t* args /* host */, void* stream);
 

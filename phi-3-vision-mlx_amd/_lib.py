@@ -60,14 +60,14 @@ class AttnDecArgs(C.Structure):
     _fields_ = [("qkv", vp), ("cos_t", vp), ("sin_t", vp), ("k_cache", vp), ("v_cache", vp), ("out", vp),
                 ("pad_len", vp), ("d_past", vp), ("ws", vp),
                 ("B", i32), ("L", i32), ("n_heads", i32), ("n_kv", i32), ("hd", i32), ("past", i32),
-                ("cache_t", i32), ("rope_bstride", i32), ("n_split", i32), ("scale", f32), ("counters", vp)]
+                ("cache_t", i32), ("rope_bstride", i32), ("n_split", i32), ("scale", f32), ("merge_in_launch", i32)]
 
 
 class AttnDecQ8Args(C.Structure):
     _fields_ = [("qkv", vp), ("cos_t", vp), ("sin_t", vp), ("k8", vp), ("v8t", vp), ("k_scale", vp), ("v_scale", vp),
                 ("out", vp), ("pad_len", vp), ("d_past", vp), ("ws", vp),
                 ("B", i32), ("L", i32), ("n_heads", i32), ("n_kv", i32), ("hd", i32), ("past", i32),
-                ("cache_t", i32), ("rope_bstride", i32), ("n_split", i32), ("scale", f32), ("counters", vp)]
+                ("cache_t", i32), ("rope_bstride", i32), ("n_split", i32), ("scale", f32), ("merge_in_launch", i32)]
 
 
 # name -> (restype, argtypes); must list every symbol include/p3v.h declares

@@ -704,7 +704,7 @@ struct AttnDecP {
   int B, L, nh, nkv, past, cache_t, rope_bstride, n_split;   // cos/sin row of (b, new position r) = b*rope_bstride + r
   float scale;
   int chunk, grp, grp_magic;   // host-side: keys per split (multiple of 64), heads per kv head and ceil(2^16 / grp)
-  int32_t* counters;           // non-null: the last split of a (b, head) merges the partials itself (split_merge)
+  int merge;                   // nonzero: the last split of a (b, head) merges the partials itself (split_merge)
   bf16_t* out;                 // [B, L, nh * 96] (fused merge only)
 };
 
@@ -1134,7 +1134,7 @@ __device__ __forceinline__ void attn_decode_body(const AttnDecP& p, const int bx
   }
   DBG_T(7);
   DBG_W(13, false);
-  if (p.counters && bx == p.n_split - 1) {                     // in-launch merge by the highest split of the (b, head)
+  if (p.merge && bx == p.n_split - 1) {                     // in-launch merge by the highest split of the (b, head)
     __shared__ float merge_scratch[SPLIT_MERGE_SCRATCH(256)];
     split_merge<256>(p.ws + ((size_t)b * p.nh + head) * p.n_split * 16 * (HD + 2), p.out + (size_t)b * p.L * (p.nh * HD) + head * HD,
                      (size_t)p.nh * HD, p.L, p.n_split, nullptr, merge_scratch);
@@ -1374,7 +1374,7 @@ __device__ __forceinline__ void attn_decode_body128(const AttnDecP& p, const int
   }
 
   // ---- merge the four wave partials through the (dead) K slices, one (m, l, O) partial per workgroup to `ws`
-  const bool merger = p.counters && bx == p.n_split - 1;       // the highest split of a (b, head) merges in-launch
+  const bool merger = p.merge && bx == p.n_split - 1;       // the highest split of a (b, head) merges in-launch
   float* own = (float*)(vtile + 4096);                         // its partial: [16][HD + 2] in the dead V^T tile (merge scratch: first 4 KiB)
   static_assert(SPLIT_MERGE_SCRATCH(256) * 4 <= 4096 && 4096 + 16 * (HD + 2) * 4 <= 96 * 256, "merge scratch + own partial fit the V^T tile");
   if (o[0][0] == 12345.f) TVAL(15, 2);
@@ -1600,7 +1600,7 @@ __global__ void __launch_bounds__(64) k_attn_decode_stream(AttnDecP p) {
       for (int r = 0; r < 4; ++r) st_wt(w + 16 * d + 4 * g + r, o[d][r]);
     if (g == 0) { st_wt(w + HD, m_run); st_wt(w + HD + 1, l_run); }
   }
-  if (p.counters && blockIdx.x == p.n_split - 1) {
+  if (p.merge && blockIdx.x == p.n_split - 1) {
     __shared__ float merge_scratch[SPLIT_MERGE_SCRATCH(64)];
     split_merge<64>(p.ws + ((size_t)b * p.nh + head) * p.n_split * 16 * (HD + 2), p.out + (size_t)b * p.L * (p.nh * HD) + head * HD,
                     (size_t)p.nh * HD, p.L, p.n_split, nullptr, merge_scratch);
@@ -1698,7 +1698,7 @@ extern "C" int p3v_attention_decode(const p3v_attn_decode_args_t* a, void* strea
   const int chunk = ((a->cache_t + a->n_split - 1) / a->n_split + 63) & ~63;
   AttnDecP p = {a->qkv, a->cos_t, a->sin_t, a->k_cache, a->v_cache, a->pad_len, a->d_past, a->ws,
                 a->B, a->L, a->n_heads, a->n_kv, a->past, a->cache_t, a->rope_bstride, a->n_split, a->scale,
-                chunk, grp, (65536 + grp - 1) / grp, a->counters, (bf16_t*)a->out};
+                chunk, grp, (65536 + grp - 1) / grp, a->merge_in_launch, (bf16_t*)a->out};
   hipStream_t s = (hipStream_t)stream;
   const dim3 grid(a->n_split, a->n_heads, a->B);
   if (a->n_split * 64 >= a->cache_t) hipLaunchKernelGGL(k_attn_decode, grid, dim3(256), 0, s, p);
@@ -1709,7 +1709,7 @@ extern "C" int p3v_attention_decode(const p3v_attn_decode_args_t* a, void* strea
   }
   else hipLaunchKernelGGL(k_attn_decode_stream<64>, grid, dim3(64), 0, s, p);
   P3V_CHECK_LAUNCH();
-  if (a->counters) return P3V_OK;                              // the last workgroup of every (b, head) merged in-kernel
+  if (a->merge_in_launch) return P3V_OK;                       // the last workgroup of every (b, head) merged in-kernel
   hipLaunchKernelGGL(k_attn_combine2, dim3(a->B * a->n_heads * a->L), dim3(combine_threads(a->n_split)), 0, s, a->ws, a->out, a->L, a->n_heads,
                      a->hd, a->n_split);
   P3V_CHECK_LAUNCH();
@@ -1902,7 +1902,7 @@ struct AttnDecQ8P {
   int B, L, nh, nkv, past, cache_t, rope_bstride, n_split;
   float scale;
   int grp, grp_magic;          // heads per kv head and ceil(2^16 / grp) (k_attn_decode_q8s)
-  int32_t* counters;           // [B * nh * n_split] zeroed ready flags: fused split merge (k_attn_decode_q8s only), as AttnDecP
+  int merge;                   // nonzero: in-launch split merge, as AttnDecP
   bf16_t* out;                 // [B, L, nh * 96] (fused merge only)
 };
 
@@ -2353,7 +2353,7 @@ __global__ void __launch_bounds__(256) k_attn_decode_q8s(AttnDecQ8P p) {
     if (d == 0) { st_wt(w + HD, M); st_wt(w + HD + 1, lsum); }
   }
   // fused split merge (as k_attn_decode): the highest split of a (b, head) waits for the others' flags and merges
-  if (p.counters && blockIdx.x == p.n_split - 1) {
+  if (p.merge && blockIdx.x == p.n_split - 1) {
     __shared__ float merge_scratch[SPLIT_MERGE_SCRATCH(256)];
     split_merge<256>(p.ws + ((size_t)b * p.nh + head) * p.n_split * 16 * (HD + 2), p.out + (size_t)b * p.L * (p.nh * HD) + head * HD,
                      (size_t)p.nh * HD, p.L, p.n_split, nullptr, merge_scratch);
@@ -2578,7 +2578,7 @@ __global__ void __launch_bounds__(256) k_attn_decode128_q8(AttnDecQ8P p) {
     st_wt(w + d, acc);
     if (d == 0) { st_wt(w + HD, M); st_wt(w + HD + 1, lsum); }
   }
-  if (p.counters && blockIdx.x == p.n_split - 1)
+  if (p.merge && blockIdx.x == p.n_split - 1)
     split_merge<256>(p.ws + ((size_t)b * p.nh + head) * p.n_split * 16 * (HD + 2), p.out + (size_t)b * p.L * (p.nh * HD) + head * HD,
                      (size_t)p.nh * HD, p.L, p.n_split, nullptr, (float*)Kx);
 }
@@ -2592,27 +2592,27 @@ extern "C" int p3v_attention_decode_q8(const p3v_attn_decode_q8_args_t* a, void*
   const int grp = a->n_heads / a->n_kv;
   AttnDecQ8P p = {a->qkv, a->cos_t, a->sin_t, a->k8, a->v8t, a->k_scale, a->v_scale, a->pad_len, a->d_past, a->ws,
                   a->B, a->L, a->n_heads, a->n_kv, a->past, a->cache_t, a->rope_bstride, a->n_split, a->scale,
-                  grp, (65536 + grp - 1) / grp, nullptr, (bf16_t*)a->out};
+                  grp, (65536 + grp - 1) / grp, 0, (bf16_t*)a->out};
   hipStream_t s = (hipStream_t)stream;
   const dim3 grid(a->n_split, a->n_heads, a->B);
   static const bool old_only = getenv("P3V_Q8_OLD") != nullptr;   // A/B knob
-  // one tile per workgroup and at most 16 of them (contexts up to 1k): the 4-wave kernel, which with `counters` also
+  // one tile per workgroup and at most 16 of them (contexts up to 1k): the 4-wave kernel, which with `merge_in_launch` also
   // merges the splits inside the launch.  Beyond that the single-wave kernel + merge launch is as fast or faster
   // (measured at 42 tiles, config 5 decode: 1.543 ms/step against 1.560 with the 4-wave kernel + fused merge: its
   // bytes go through registers and a ds_write pass into the fp16 images, where the bf16 kernel uses LDS-DMA).
   if (!old_only && a->cache_t % 128 == 0 && a->n_split * 128 >= a->cache_t && a->n_split * 64 < a->cache_t) {   // 128-key tiles
-    p.counters = a->counters;
+    p.merge = a->merge_in_launch;
     hipLaunchKernelGGL(k_attn_decode128_q8, grid, dim3(256), 0, s, p);
     P3V_CHECK_LAUNCH();
-    if (a->counters) return P3V_OK;
+    if (a->merge_in_launch) return P3V_OK;
     hipLaunchKernelGGL(k_attn_combine2, dim3(a->B * a->n_heads * a->L), dim3(combine_threads(a->n_split)), 0, s, a->ws, a->out, a->L, a->n_heads,
                        a->hd, a->n_split);
     P3V_CHECK_LAUNCH();
     return P3V_OK;
   }
   const bool single_tile = !old_only && a->n_split * 64 >= a->cache_t && a->n_split <= 16;
-  if (single_tile && a->counters) {
-    p.counters = a->counters;
+  if (single_tile && a->merge_in_launch) {
+    p.merge = a->merge_in_launch;
     hipLaunchKernelGGL(k_attn_decode_q8s, grid, dim3(256), 0, s, p);
     P3V_CHECK_LAUNCH();
     return P3V_OK;

@@ -433,13 +433,13 @@ class Phi3VModel:
                 n_split = int(os.environ["P3V_ATTN_NSPLIT"])
             bufs["n_split"] = n_split
             bufs["ws"] = ops.attention_ws(B, L, nh, hd, n_split, self.device)
-            # in-launch split-KV merge (a non-null `counters` asks for it): with the one-tile-per-workgroup plans, and with the
+            # in-launch split-KV merge (`merge_in_launch`): with the one-tile-per-workgroup plans, and with the
             # multi-tile streaming kernel when a head has at most 4 splits (B = 8: 3 splits -- the merge launch costs 4.9 us a
             # layer, the in-launch merge 0.5; with 24 splits at B = 1 / 32k the one merging workgroup per head is the slower
             # way: +1.6 % per step, +4.5 % at 8k)
             mode = os.environ.get("P3V_ATTN_FUSED_MERGE", "1")
             fused = (n_split in (tiles, tiles128) or n_split <= 4 or mode == "2") and n_split <= 48 and mode != "0"
-            bufs["attn_cnt"] = torch.zeros(B * nh * n_split, dtype=I32, device=self.device) if fused else None
+            bufs["attn_merge"] = bool(fused)
 
     def _layers(self, x, st, B, L, past, n_beam, bufs=None, d_past=None, last_only=False):
         """Phi3DecoderLayer stack (phi.py:473-485).  `d_past` (device int32) makes every
@@ -473,7 +473,7 @@ class Phi3VModel:
                     else:
                         rc, rs, rb = st.cos[:, past:], st.sin[:, past:], st.T
                     ops.attention_decode_q8(qkv, rc, rs, rb, st.k8[i], st.v8[i], st.ks[i], st.vs[i], o, B, L, nh, nkv, hd, scale,
-                                            past, st.Tp, ws, n_split, pad_len=st.pad_len, d_past=d_past, counters=bufs.get("attn_cnt"))
+                                            past, st.Tp, ws, n_split, pad_len=st.pad_len, d_past=d_past, merge_in_launch=bufs.get("attn_merge", False))
                 else:                                           # prefill: exact attention, quantised copy stored
                     if past > 0:                                # long cached call (constrain with > 16 tokens): attend on a
                         ops.kv_dequantize(st.k8[i], st.v8[i], st.ks[i], st.vs[i], st.k_tmp, st.v_tmp, past)   # dequantised copy
@@ -492,7 +492,7 @@ class Phi3VModel:
                 else:                                           # eager: views into the prompt tables at `past`
                     rc, rs, rb = st.cos[:, past:], st.sin[:, past:], st.T
                 ops.attention_decode(qkv, rc, rs, rb, st.k[i], st.v[i], o, B, L, nh, nkv, hd, scale, past, st.Tp, ws, n_split,
-                                     pad_len=st.pad_len, d_past=d_past, counters=bufs.get("attn_cnt"))
+                                     pad_len=st.pad_len, d_past=d_past, merge_in_launch=bufs.get("attn_merge", False))
             else:
                 ops.rope_kv_append(qkv, st.cos, st.sin, q, st.k[i], st.v[i], B, L, nh, nkv, hd, past, st.Tp, True, st.T, 1)
                 ops.attention(q, o, B, L, nh, nkv, hd, scale, True, past=past, k_past=st.k[i], v_past=st.v[i],

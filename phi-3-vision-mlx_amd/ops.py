@@ -255,12 +255,12 @@ def attention(q, out, B, Lq, nh, nkv, hd, scale, causal, k_new=None, v_new=None,
 
 
 def attention_decode(qkv, cos_new, sin_new, rope_bstride, k_cache, v_cache, out, B, Lq, nh, nkv, hd, scale, past, cache_t, ws,
-                     n_split, pad_len=None, d_past=None, counters=None):
+                     n_split, pad_len=None, d_past=None, merge_in_launch=False):
     """Fused decode-step attention: head split + RoPE + KV append + split-KV attention + merge.
     cos_new/sin_new: rows of the new positions, row (b, r) at b*rope_bstride + r.
-    counters: optional zeroed int32 [B*nh*n_split] -> the split partials are merged inside the attention launch."""
+    merge_in_launch: the split partials are merged inside the attention launch (ws: see `attention_ws`)."""
     args = L.AttnDecArgs(_p(qkv), _p(cos_new), _p(sin_new), _p(k_cache), _p(v_cache), _p(out), _p(pad_len), _p(d_past), _p(ws),
-                         B, Lq, nh, nkv, hd, int(past), cache_t, rope_bstride, n_split, float(scale), _p(counters))
+                         B, Lq, nh, nkv, hd, int(past), cache_t, rope_bstride, n_split, float(scale), int(bool(merge_in_launch)))
     L.check(L.lib().p3v_attention_decode(C.byref(args), _stream()), "attention_decode")
     return out
 
@@ -280,10 +280,10 @@ def kv_dequantize(k8, v8t, k_scale, v_scale, k, vt, n_tok):
 
 
 def attention_decode_q8(qkv, cos_new, sin_new, rope_bstride, k8, v8t, k_scale, v_scale, out, B, Lq, nh, nkv, hd, scale, past,
-                        cache_t, ws, n_split, pad_len=None, d_past=None, counters=None):
-    """`attention_decode` on the int8 KV cache (counters: as there -- the split partials are merged inside the launch)."""
+                        cache_t, ws, n_split, pad_len=None, d_past=None, merge_in_launch=False):
+    """`attention_decode` on the int8 KV cache (merge_in_launch: as there)."""
     args = L.AttnDecQ8Args(_p(qkv), _p(cos_new), _p(sin_new), _p(k8), _p(v8t), _p(k_scale), _p(v_scale), _p(out), _p(pad_len),
-                           _p(d_past), _p(ws), B, Lq, nh, nkv, hd, int(past), cache_t, rope_bstride, n_split, float(scale), _p(counters))
+                           _p(d_past), _p(ws), B, Lq, nh, nkv, hd, int(past), cache_t, rope_bstride, n_split, float(scale), int(bool(merge_in_launch)))
     L.check(L.lib().p3v_attention_decode_q8(C.byref(args), _stream()), "attention_decode_q8")
     return out
 

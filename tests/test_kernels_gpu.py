@@ -320,13 +320,12 @@ def test_attention_decode_fused(ops, orc, B, L, past, nh, n_split, pads, dev_pas
     out = torch.empty((B, L, nh * hd), dtype=BF16).cuda()
     ws = ops.attention_ws(B, L, nh, hd, n_split, "cuda")
     d_past = torch.tensor([past], dtype=torch.int32).cuda()
-    cnt = torch.zeros(B * nh * n_split, dtype=torch.int32).cuda() if fused_merge else None
     cos_s = torch.empty((B, L, hd // 2), dtype=F32).cuda()
     sin_s = torch.empty_like(cos_s)
     ops.stage_rope(cos.view(B, T, -1), sin.view(B, T, -1), cos_s, sin_s, B, L, T, d_past=d_past)
     assert torch.equal(cos_s.cpu(), cos.view(B, T, -1)[:, past:past + L].cpu())
     ops.attention_decode(qkv.cuda(), cos_s, sin_s, L, kcc, vcc, out, B, L, nh, nh, hd, hd ** -0.5, 0 if dev_past else past, T, ws,
-                         n_split, pad_len=pad.cuda() if pads else None, d_past=d_past if dev_past else None, counters=cnt)
+                         n_split, pad_len=pad.cuda() if pads else None, d_past=d_past if dev_past else None, merge_in_launch=fused_merge)
     # the in-launch merge validates partials against a sentinel: every launch (merged in the launch or by the combine
     # kernel) must leave the workspace all-ones, whatever the shape that used it
     assert (ws.view(torch.int32) == -1).all()
@@ -367,8 +366,7 @@ def test_attention_decode_workspace_is_reusable_across_modes_and_shapes(ops, orc
             cos, sin = torch.rand((B, L, hd // 2)).cuda(), torch.rand((B, L, hd // 2)).cuda()
             kcc, vcc = kc.cuda(), vc.transpose(2, 3).contiguous().cuda()
             out = torch.empty((B, L, nh * hd), dtype=BF16).cuda()
-            cnt = torch.zeros(B * nh * n_split, dtype=torch.int32).cuda() if fused else None
-            ops.attention_decode(qkv.cuda(), cos, sin, L, kcc, vcc, out, B, L, nh, nh, hd, hd ** -0.5, past, T, ws, n_split, counters=cnt)
+            ops.attention_decode(qkv.cuda(), cos, sin, L, kcc, vcc, out, B, L, nh, nh, hd, hd ** -0.5, past, T, ws, n_split, merge_in_launch=fused)
             assert not torch.isnan(out.float()).any()
             assert (ws.view(torch.int32) == -1).all()
             key = (B, L, past)
@@ -412,12 +410,11 @@ def test_kv_quantize_and_q8_decode(ops, orc, past, L, n_split, fused):
     cos, sin = cos.view(B, T, -1), sin.view(B, T, -1)
     out = torch.empty((B, L, nh * hd), dtype=BF16).cuda()
     ws = ops.attention_ws(B, L, nh, hd, n_split, "cuda")
-    cnt = torch.zeros(B * nh * n_split, dtype=torch.int32).cuda() if fused else None
     for _ in range(2 if fused else 1):
         out.fill_(float("nan"))
         ops.attention_decode_q8(qkv.cuda(), cos[:, past:], sin[:, past:], T, k8, v8, ksc, vsc, out, B, L, nh, nh, hd, hd ** -0.5, past,
-                                T, ws, n_split, counters=cnt)
-    assert cnt is None or int(cnt.abs().sum()) == 0             # every flag cleared for the next launch
+                                T, ws, n_split, merge_in_launch=fused)
+    assert (ws.view(torch.int32) == -1).all()                  # every launch leaves the workspace all-sentinel
     cos_ref, sin_ref = orc.su_rope_tables(cfg, T, None)
     x = qkv.view(B, L, 3 * nh, hd).transpose(1, 2)
     cs, sn = cos_ref[:, :, past:past + L], sin_ref[:, :, past:past + L]

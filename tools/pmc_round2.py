@@ -23,8 +23,7 @@ elif which == "attn":
     out = torch.empty((B, 1, nh * hd), dtype=torch.bfloat16, device="cuda")
     n_split = T // 128
     ws = ops.attention_ws(B, 1, nh, hd, n_split, "cuda")
-    cnt = torch.zeros(B * nh * n_split, dtype=torch.int32, device="cuda")
     for i in range(18):
-        ops.attention_decode(qkv, cos, sin, 1, kc[i % 6], vc[i % 6], out, B, 1, nh, nh, hd, hd ** -0.5, past, T, ws, n_split, counters=cnt)
+        ops.attention_decode(qkv, cos, sin, 1, kc[i % 6], vc[i % 6], out, B, 1, nh, nh, hd, hd ** -0.5, past, T, ws, n_split, merge_in_launch=True)
 torch.cuda.synchronize()
 print("done")
