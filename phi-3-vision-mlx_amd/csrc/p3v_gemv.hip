@@ -544,13 +544,17 @@ extern "C" int p3v_gemv(const p3v_gemv_args_t* a, void* stream) {
   // matrix cores take over (at MT = 8 the VALU / LDS work per weight byte catches up: 4.72 ms/step at B = 8 against 4.08
   // with k_gemv_mfma and 3.27 with k_gemv_mfma8).
   static const int rows_variant = gemv_env("P3V_GEMV_ROWS", 1);
-  if (rows_variant && variant == 3 && a->M >= 2 && a->M <= 4 && a->N % 2 == 0 && a->epilogue != P3V_EPI_F32 &&
+  // smallest M the 8-row MFMA kernel takes: 2 since it became persistent with the RMSNorm scale in the epilogue (decode step
+  // at ctx 2531, B = 2 / 3 / 4: 2.08 / 2.43 / 2.66 ms with the MT-row streaming kernel, 1.99 / 2.16 / 2.35 with this one);
+  // P3V_GEMV8_MIN=5 restores the round-1 split
+  static const int rows8_min = gemv_env("P3V_GEMV8_MIN", 2);
+  if (rows_variant && variant == 3 && a->M >= 2 && a->M <= 4 && a->M < rows8_min && a->N % 2 == 0 && a->epilogue != P3V_EPI_F32 &&
       (a->K == 3072 || a->K == 8192)) {
     if (a->K == 3072) return mt == 2 ? launch_gemv3<2, 1, 6>(p, s) : launch_gemv3<4, 1, 6>(p, s);
     return mt == 2 ? launch_gemv3<2, 4, 4>(p, s) : launch_gemv3<4, 4, 4>(p, s);
   }
   static const int rows8 = gemv_env("P3V_GEMV_MFMA8", 1);
-  if (rows8 && a->M >= 5 && a->M <= 8) {
+  if (rows8 && a->M >= rows8_min && a->M <= 8) {
     const bool silu = a->epilogue == P3V_EPI_SILU_MUL;
     switch (a->K) {                                      // K = NW waves x NST stages x 256
       case 1024: return silu ? launch_gemv_mfma8<true, 4, 1>(p, s) : launch_gemv_mfma8<false, 4, 1>(p, s);
