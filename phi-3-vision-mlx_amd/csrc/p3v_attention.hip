@@ -2371,8 +2371,11 @@ __global__ void __launch_bounds__(256) k_attn_decode128_q8(AttnDecQ8P p) {
   constexpr int TK = 128, WK = 32, HD = 96, KROWB = HD, VROWB = TK, NKS = 3, NDT = 6, CPR = 12, KROW = HD * 2;
   constexpr int KS_BYTES = WK * KROWB;                         // 3 KiB of key bytes per wave
   __shared__ __attribute__((aligned(1024))) unsigned char KV[4 * 6144];   // [K bytes x 4 waves (12 KiB) | V^T bytes (12 KiB)]; later 4 x O partial
-  __shared__ __attribute__((aligned(16))) unsigned char Qs[16 * KROW];    // rotated Q, fp16
-  __shared__ __attribute__((aligned(16))) unsigned char Kx[16 * KROW], Vx[16 * KROW];   // exact new rows [r][96] bf16
+  __shared__ __attribute__((aligned(16))) unsigned char Aux[3 * 16 * KROW];   // [Qs | Kx | Vx]; after the tile: [merge scratch | own partial]
+  unsigned char* Qs = Aux;                                     // rotated Q, fp16
+  unsigned char* Kx = Aux + 16 * KROW;                         // exact new rows [r][96] bf16
+  unsigned char* Vx = Aux + 2 * 16 * KROW;
+  static_assert(SPLIT_MERGE_SCRATCH(256) * 4 <= 2176 && 2176 + 16 * (HD + 2) * 4 <= 3 * 16 * KROW, "merge scratch + own partial fit the aux block");
   __shared__ __attribute__((aligned(16))) float ksl[TK], vsl[TK];
   __shared__ float Ml[4][16][2];
   const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, qi = lane & 15;
@@ -2393,50 +2396,61 @@ __global__ void __launch_bounds__(256) k_attn_decode128_q8(AttnDecQ8P p) {
 
   const int kv_lo = blockIdx.x * TK, kv_hi = min(p.cache_t, kv_lo + TK);
   const int kvd = min(kv_lo, p.cache_t - TK);                  // tile actually fetched (an empty split fetches one it never uses)
-  {
-    const unsigned char* ksrc = kc + (size_t)(kvd + WK * wave) * KROWB;
-#pragma unroll
-    for (int j = 0; j < 3; ++j)                                // K bytes: 3 KiB per wave, linear
-      __builtin_amdgcn_global_load_lds((dec_gptr_t)(ksrc + j * 1024 + lane * 16), (dec_lptr_t)(kslice + j * 1024), 16, 0, P3V_ATTN_AUX);
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {                              // V^T bytes: wave w brings rows 24w..24w+23, 8 rows of 128 B per instruction
-      const int d = 24 * wave + 8 * j + (lane >> 3);
-      const unsigned char* src = vc + (size_t)d * p.cache_t + kvd + ((((unsigned)lane & 7) ^ ((unsigned)d & 7)) << 4);
-      __builtin_amdgcn_global_load_lds((dec_gptr_t)src, (dec_lptr_t)(vtile + wave * 3072 + j * 1024), 16, 0, P3V_ATTN_AUX);
-    }
-  }
-  // scales of the tile -> LDS (patched for new rows below), one float per thread
-  if (tid < TK) ksl[tid] = ksc[kvd + tid];
-  else vsl[tid - TK] = vsc[kvd + tid - TK];
-
-  // ---- the L new rows: Q (rotated, fp16 -> Qs), K / V exact (bf16, parked for the quantiser)
+  // ---- small loads first: the tile's scales, and the L new rows (Q / K raw for the rotation, V)
   const int row_w = (p.nh + 2 * p.nkv) * HD;
+  const int n_vnew = p.L * HD;
+  const bf16_t* vnew = p.qkv + (size_t)b * p.L * row_w + (p.nh + p.nkv + kvh) * HD;
+  bf16_t v_early = 0;
+  if (tid < n_vnew) {
+    const unsigned r = (unsigned)tid / HD;
+    v_early = vnew[r * (unsigned)row_w + ((unsigned)tid - r * HD)];
+  }
+  const float scl = tid < TK ? ksc[kvd + tid] : vsc[kvd + tid - TK];
   const float* cos_b = p.cos_t + (size_t)b * p.rope_bstride * (HD / 2);
   const float* sin_b = p.sin_t + (size_t)b * p.rope_bstride * (HD / 2);
   const int tr = tid / CPR, tc = tid - tr * CPR;
   const bool rtask = tr < p.L;
-  const int n_vnew = p.L * HD;
+  RopeRaw qraw, kraw;
+  if (rtask) {
+    const bf16_t* row = p.qkv + ((size_t)b * p.L + tr) * row_w;
+    qraw = rope_fetch(row + head * HD, tc, cos_b + tr * (HD / 2), sin_b + tr * (HD / 2));
+    kraw = qraw;
+    const bf16_t* krow = row + (p.nh + kvh) * HD;
+    kraw.x0 = *(const u32x4_t*)(krow + tc * 8);
+    kraw.x1 = *(const u32x4_t*)(krow + (tc < 6 ? tc * 8 + 48 : tc * 8 - 48));
+  }
+  // ---- tile DMA, MUBUF form, AFTER the small loads above (as k_attn_decode128 V2: memory returns in order, and a pending
+  // `global_load_lds` makes the compiler wait for everything at every later wait)
+  {
+    const unsigned char* ksrc = kc + (size_t)(kvd + WK * wave) * KROWB;
+    const __amdgpu_buffer_rsrc_t rs_k = __builtin_amdgcn_make_buffer_rsrc((void*)ksrc, 0, 0xffffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_v = __builtin_amdgcn_make_buffer_rsrc((void*)(vc + kvd), 0, 0xffffffff, 0x00020000);
+#pragma unroll
+    for (int j = 0; j < 3; ++j)                                // K bytes: 3 KiB per wave, linear
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_k, (dec_lptr_t)(kslice + j * 1024), 16, (unsigned)(j * 1024 + lane * 16), 0, 0, P3V_ATTN_AUX);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {                              // V^T bytes: wave w brings rows 24w..24w+23, 8 rows of 128 B per instruction
+      const int d = 24 * wave + 8 * j + (lane >> 3);
+      const unsigned voff = (unsigned)d * (unsigned)p.cache_t + ((((unsigned)lane & 7) ^ ((unsigned)d & 7)) << 4);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_v, (dec_lptr_t)(vtile + wave * 3072 + j * 1024), 16, voff, 0, 0, P3V_ATTN_AUX);
+    }
+  }
+  // ---- their LDS images (the tile is in flight)
+  if (tid < TK) ksl[tid] = scl;
+  else vsl[tid - TK] = scl;
   if (tid < 16 * CPR) {
     u32x4_t qv = {0, 0, 0, 0};
     if (rtask) {
-      const bf16_t* row = p.qkv + ((size_t)b * p.L + tr) * row_w;
-      const RopeRaw qraw = rope_fetch(row + head * HD, tc, cos_b + tr * (HD / 2), sin_b + tr * (HD / 2));
-      RopeRaw kraw = qraw;
-      const bf16_t* krow = row + (p.nh + kvh) * HD;
-      kraw.x0 = *(const u32x4_t*)(krow + tc * 8);
-      kraw.x1 = *(const u32x4_t*)(krow + (tc < 6 ? tc * 8 + 48 : tc * 8 - 48));
       qv = rope_apply<true>(qraw, tc);
       *(u32x4_t*)(Kx + tr * KROW + tc * 16) = rope_apply(kraw, tc);
     }
     *(u32x4_t*)(Qs + tr * KROW + ((tc ^ ((tr >> 2) & 3)) << 4)) = qv;
   }
-  {
-    const bf16_t* vnew = p.qkv + (size_t)b * p.L * row_w + (p.nh + p.nkv + kvh) * HD;
+  if (tid < n_vnew) *(bf16_t*)(Vx + (tid / HD) * KROW + (tid % HD) * 2) = v_early;
 #pragma unroll 1
-    for (int idx = tid; idx < n_vnew; idx += 256) {
-      const int r = idx / HD, d = idx - r * HD;
-      *(bf16_t*)(Vx + r * KROW + d * 2) = vnew[(size_t)r * row_w + d];
-    }
+  for (int idx = tid + 256; idx < n_vnew; idx += 256) {
+    const int r = idx / HD, d = idx - r * HD;
+    *(bf16_t*)(Vx + r * KROW + d * 2) = vnew[(size_t)r * row_w + d];
   }
 
   asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(past), "+s"(pad)::"memory");
@@ -2454,9 +2468,16 @@ __global__ void __launch_bounds__(256) k_attn_decode128_q8(AttnDecQ8P p) {
 
   const int kv0 = kv_lo;
   if (kv0 < kv_end) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wave's DMA pieces and scale loads have landed
-    __syncthreads();                                           // Qs / Kx / Vx / scales complete, every wave's slices are in LDS
-    if (kv0 + TK > past) {
+    const bool has_new = kv0 + TK > past;                      // workgroup-uniform: the tile holds new positions
+    if (!has_new) {
+      // Qs / scales are complete (barrier, no memory wait); this wave's K bytes are its three oldest DMAs: S^T and the
+      // softmax run while the V^T bytes are still landing
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier\n\ts_waitcnt vmcnt(3)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // this wave's DMA pieces have landed
+      __syncthreads();                                         // Qs / Kx / Vx / scales complete, every wave's slices are in LDS
+    }
+    if (has_new) {
 #pragma unroll 1
       for (int r = wave; r < p.L; r += 4) {                    // one new row per wave at a time
         const int t = past + r, rr = t - kv0;
@@ -2496,12 +2517,28 @@ __global__ void __launch_bounds__(256) k_attn_decode128_q8(AttnDecQ8P p) {
     qoff = Q8_OFF * rows_sum(qoff);
 
     f32x4_t s[2];
+    u32x2_t kcode[2][NKS];                                     // key row 16kb + qi, k = 32ks + 8g .. +7: eight code bytes
+    if (!has_new) {
+      // hidden from the compiler (it would wait for the V^T DMAs too: it cannot tell the two halves of `KV` apart)
+      const unsigned ka = (unsigned)(size_t)(dec_lptr_t)kslice + qi * KROWB + 8 * g;
+      static_assert(16 * KROWB == 1536, "second key block of the wave's slice");
+      asm volatile("ds_read_b64 %0, %6\n\tds_read_b64 %1, %6 offset:32\n\tds_read_b64 %2, %6 offset:64\n\t"
+                   "ds_read_b64 %3, %6 offset:1536\n\tds_read_b64 %4, %6 offset:1568\n\tds_read_b64 %5, %6 offset:1600\n\t"
+                   "s_waitcnt lgkmcnt(0)"
+                   : "=&v"(kcode[0][0]), "=&v"(kcode[0][1]), "=&v"(kcode[0][2]), "=&v"(kcode[1][0]), "=&v"(kcode[1][1]), "=&v"(kcode[1][2])
+                   : "v"(ka) : "memory");
+    } else {
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) kcode[kb][ks] = *(const u32x2_t*)(kslice + (16 * kb + qi) * KROWB + 32 * ks + 8 * g);
+    }
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
       s[kb] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int ks = 0; ks < NKS; ++ks) {                       // key row 16kb + qi, k = 32ks + 8g .. +7: eight code bytes
-        const u32x2_t kb8 = *(const u32x2_t*)(kslice + (16 * kb + qi) * KROWB + 32 * ks + 8 * g);
+      for (int ks = 0; ks < NKS; ++ks) {
+        const u32x2_t kb8 = kcode[kb][ks];
         const u32x4_t kw = {__builtin_amdgcn_perm(0x64646464u, kb8[0], 0x04010400u), __builtin_amdgcn_perm(0x64646464u, kb8[0], 0x04030402u),
                             __builtin_amdgcn_perm(0x64646464u, kb8[1], 0x04010400u), __builtin_amdgcn_perm(0x64646464u, kb8[1], 0x04030402u)};
         s[kb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, kw), qf[ks], s[kb], 0, 0, 0);
@@ -2538,6 +2575,7 @@ __global__ void __launch_bounds__(256) k_attn_decode128_q8(AttnDecQ8P p) {
     m_run = m_t;
     const u32x4_t pw = {pack_f16x2(s[0][0], s[0][1]), pack_f16x2(s[0][2], s[0][3]), pack_f16x2(s[1][0], s[1][1]), pack_f16x2(s[1][2], s[1][3])};
     const f16x8_t pf = __builtin_bit_cast(f16x8_t, pw);
+    if (!has_new) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");   // the V^T bytes are every wave's DMA
 #pragma unroll
     for (int d = 0; d < NDT; ++d) {                            // V^T row 16d + qi, keys 32w + 16kb + 4g .. +3: four code bytes per block
       const int row = 16 * d + qi;
@@ -2560,6 +2598,8 @@ __global__ void __launch_bounds__(256) k_attn_decode128_q8(AttnDecQ8P p) {
     if (g == 0) { Ml[wave][qi][0] = m_run; Ml[wave][qi][1] = l_run; }
   }
   __syncthreads();
+  const bool merger = p.merge && blockIdx.x == p.n_split - 1;  // the highest split of a (b, head) merges in-launch
+  float* own = (float*)(Aux + 2176);                           // its partial: [16][HD + 2] in the (dead) aux block, after the merge scratch
 #pragma unroll 1
   for (int idx = tid; idx < n_vnew; idx += 256) {
     const int q = idx / HD, d = idx - q * HD;
@@ -2574,13 +2614,18 @@ __global__ void __launch_bounds__(256) k_attn_decode128_q8(AttnDecQ8P p) {
       acc += c * ((const float*)(KV + k * 6144))[q * HD + d];
       lsum += c * Ml[k][q][1];
     }
-    float* w = p.ws + ((((size_t)b * p.nh + head) * p.n_split + blockIdx.x) * 16 + q) * (HD + 2);
-    st_wt(w + d, acc);
-    if (d == 0) { st_wt(w + HD, M); st_wt(w + HD + 1, lsum); }
+    if (merger) {                                              // stays in LDS: split_merge takes it from there
+      own[q * (HD + 2) + d] = acc;
+      if (d == 0) { own[q * (HD + 2) + HD] = M; own[q * (HD + 2) + HD + 1] = lsum; }
+    } else {
+      float* w = p.ws + ((((size_t)b * p.nh + head) * p.n_split + blockIdx.x) * 16 + q) * (HD + 2);
+      st_wt(w + d, acc);
+      if (d == 0) { st_wt(w + HD, M); st_wt(w + HD + 1, lsum); }
+    }
   }
-  if (p.merge && blockIdx.x == p.n_split - 1)
+  if (merger)
     split_merge<256>(p.ws + ((size_t)b * p.nh + head) * p.n_split * 16 * (HD + 2), p.out + (size_t)b * p.L * (p.nh * HD) + head * HD,
-                     (size_t)p.nh * HD, p.L, p.n_split, nullptr, (float*)Kx);
+                     (size_t)p.nh * HD, p.L, p.n_split, own, (float*)Aux);
 }
 
 extern "C" int p3v_attention_decode_q8(const p3v_attn_decode_q8_args_t* a, void* stream) {
