@@ -447,7 +447,8 @@ static int launch_gemv3_f8(const GemvF8P& p, hipStream_t s) {
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess) return P3V_ERR_HIP;
     n_cu = pr.multiProcessorCount;
   }
-  int upw = p3v_cdiv(p.units, n_cu * 8);
+  static const int wpc = getenv("P3V_GEMV_F8_WPC") ? atoi(getenv("P3V_GEMV_F8_WPC")) : 16;   // waves per CU (a stage is half the bytes of the bf16 kernel's: twice the waves keep as many in flight; 8: 1.321, 16: 1.301, 24: 1.333 ms/step)
+  int upw = p3v_cdiv(p.units, n_cu * wpc);
   if (upw < 1) upw = 1;
   const int waves = p3v_cdiv(p.units, upw);
   hipLaunchKernelGGL((k_gemv3_f8<NST, CH>), dim3(p3v_cdiv(waves, 4)), dim3(256), (size_t)p.K * 2, s, p, upw);
