@@ -141,12 +141,15 @@ class _SlotCache:
         self.state = state
 
 
+GROUP_PAD = 256          # prefill_requests: rows of padding a request may carry inside its length group
+
+
 def prefill_requests(model, reqs, max_tokens, width=None):
     """Prefill B = 1 requests of DIFFERENT lengths into one decode batch without computing on padding.
 
     A left-padded batch (`collate_requests`) runs every projection over B x longest-prompt rows: for one GPU's share of
     config 4 (4 x 2531-token image prompts + 4 text prompts of 65..233 tokens) almost half of them are padding.  Here the
-    requests are sorted by length, each group of EQUAL length is prefilled as its own batch straight into adjacent rows of a
+    requests are sorted by length, each group of equal (or, up to GROUP_PAD pad rows, nearly equal) length is prefilled as its own batch straight into adjacent rows of a
     slot state (`model.prefill_slot`: right-aligned to the longest prompt, per-row left padding and position tables -- the
     geometry `_tokenize` gives a padded row, phi.py:238-240), and decode then runs all rows as ONE graph-replayed batch.
     Returns (first tokens int32 [B, 1] in SLOT order, cache, order) with order[slot] = request index; None when the
@@ -163,8 +166,11 @@ def prefill_requests(model, reqs, max_tokens, width=None):
     g = model.decode_graph(st)
     row = 0
     while row < len(order):
-        n = 1
-        while row + n < len(order) and lens[order[row + n]] == lens[order[row]]:
+        # a group = requests of equal length, plus shorter ones whose padding inside the group stays small: a short prompt
+        # prefilled alone still streams all 7.4 GB of weights (config 4's four text prompts of 65..233 tokens cost 9.6 ms EACH
+        # that way); padded to the group's longest they share one pass (<= GROUP_PAD pad rows per request)
+        n, longest = 1, lens[order[row]]
+        while row + n < len(order) and longest - lens[order[row + n]] <= GROUP_PAD:
             n += 1
         group = [reqs[i] for i in order[row:row + n]]
         tok = model.prefill_slot(st, row, collate_requests(group) if n > 1 else group[0])

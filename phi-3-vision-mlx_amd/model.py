@@ -354,31 +354,39 @@ class Phi3VModel:
 
     @_on_device
     def prefill_slot(self, st, row, inputs, return_logits=False):
-        """Prefill one request (a B = 1 `processor(...)` result) -- or n requests of EQUAL length as one batch (`inputs` with
-        n rows and no padding, e.g. `collate_requests` of equally long prompts) -- into the batch rows row .. row+n-1 of a slot
-        state so that the LAST prompt token sits in column st.offset - 1: left padding pad = st.offset - S, position ids
-        0..S-1 from column pad on.  Keys left of `pad` (stale rows of an earlier occupant) are masked by pad_len.
-        Returns the first greedy tokens (int32 [n, 1] on the device; with return_logits also the last-position logits).
-        Each row computes what a B = 1 run of its request computes (pad invariance)."""
+        """Prefill one request (a B = 1 `processor(...)` result) -- or n requests as one batch (`collate_requests` of them:
+        equal lengths, or shorter rows left-padded inside the group) -- into the batch rows row .. row+n-1 of a slot state so
+        that every row's LAST prompt token sits in column st.offset - 1: row i gets left padding pad_i = st.offset - S_i and
+        position ids 0..S_i-1 from column pad_i on.  Keys left of pad_i (stale rows of an earlier occupant, the group's own
+        padding) are masked by pad_len.  Returns the first greedy tokens (int32 [n, 1] on the device; with return_logits also
+        the last-position logits).  Each row computes what a B = 1 run of its request computes (pad invariance)."""
         cfg = self.cfg
         ids = np.asarray(inputs["input_ids"])
         ids = ids[None] if ids.ndim == 1 else ids
         n, S = ids.shape
-        if "mask" in inputs and int(np.asarray(inputs["mask"]).sum()) != n * S:
-            raise ValueError("prefill_slot takes requests of equal length (no padding inside the group)")
-        pad = st.offset - S
-        if pad < 0:
+        lens = np.full(n, S, dtype=np.int64)
+        if "mask" in inputs:
+            m = np.asarray(inputs["mask"]).reshape(n, S)
+            lens = m.sum(1).astype(np.int64)
+            if not all(int(m[i, S - lens[i]:].sum()) == lens[i] for i in range(n)) or lens.min() < 1:
+                raise ValueError("prefill_slot takes LEFT-padded rows")
+        win = st.offset - S                                      # first column the group's batch writes
+        if win < 0:
             raise ValueError(f"prompt of {S} tokens does not fit left of column {st.offset}")
+        pads = torch.as_tensor(st.offset - lens, dtype=torch.int32)
         half = self.hd // 2
         inv_freq = 1.0 / (torch.tensor(cfg.rope_scaling["short_factor"], dtype=F32)
                           * (torch.tensor(float(cfg.rope_theta), dtype=F32) ** (torch.arange(0, self.hd, 2, dtype=F32) / self.hd)))
-        pos = (torch.arange(st.T, dtype=F32) - pad).clamp_min(0).to(self.device)
-        cos, sin = ops.rope_table(pos, inv_freq.to(self.device), rope_scaling_factor(cfg))
         rows = slice(row, row + n)
-        st.cos[rows].copy_(cos.view(1, st.T, half).expand(n, -1, -1)), st.sin[rows].copy_(sin.view(1, st.T, half).expand(n, -1, -1))
-        st.pad_len[rows].fill_(pad)
-        view = CacheState.__new__(CacheState)                   # these rows as an n-row cache at offset `pad`
-        view.__dict__.update(B=n, S=S, max_tokens=st.max_tokens, T=st.T, Tp=st.Tp, quantized=False, offset=pad, graphs={}, epoch=self.epoch,
+        uniq = np.unique(lens)
+        for L_ in uniq:                                          # one table per distinct length
+            pos = (torch.arange(st.T, dtype=F32) - float(st.offset - L_)).clamp_min(0).to(self.device)
+            cos, sin = ops.rope_table(pos, inv_freq.to(self.device), rope_scaling_factor(cfg))
+            for i in np.nonzero(lens == L_)[0]:
+                st.cos[row + i].copy_(cos.view(st.T, half)), st.sin[row + i].copy_(sin.view(st.T, half))
+        st.pad_len[rows].copy_(pads.to(self.device))
+        view = CacheState.__new__(CacheState)                   # these rows as an n-row cache at offset `win`
+        view.__dict__.update(B=n, S=S, max_tokens=st.max_tokens, T=st.T, Tp=st.Tp, quantized=False, offset=win, graphs={}, epoch=self.epoch,
                              k=st.k[:, rows], v=st.v[:, rows], cos=st.cos[rows], sin=st.sin[rows], pad_len=st.pad_len[rows])
         kw = {k: v for k, v in inputs.items() if k in ("pixel_values", "image_sizes", "positions")}
         logits, _ = self(input_ids=ids, cache=[LayerCache(view, i) for i in range(cfg.num_hidden_layers)], full_logits=False, **kw)

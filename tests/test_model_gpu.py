@@ -773,6 +773,59 @@ def test_continuous_batching_engine_matches_solo_generate():
     assert big.done.is_set() and isinstance(big.error, ValueError)
 
 
+@pytest.mark.gpu
+def test_prefill_requests_groups_nearly_equal_lengths():
+    """dist.prefill_requests pads SHORT prompts of different lengths into one prefill group (a short prompt alone still
+    streams every weight once): the image request stays its own group, the five text prompts (4..27 tokens) share one, and
+    every request's first token and decode tokens equal its B = 1 run wherever that run's top-2 margin is clear."""
+    from golden_inputs import make_image
+    from phi_3_vision_mlx_amd import dist
+    g = np.load(GOLDEN + "/tiny_oracle.npz")
+    model, proc = _tiny_with_head(False, g, "vis_")
+    norms = head_row_norms(model).to("cuda:0")
+    rel_tol = float(g["rel_tol"][0])
+    texts = ["<|user|>\nhi<|end|>\n<|assistant|>\n", "<|user|>\n" + "a longer question " * 6 + "<|end|>\n<|assistant|>\n",
+             "<|user|>\nmid size prompt here<|end|>\n<|assistant|>\n", "<|user|>\nx<|end|>\n<|assistant|>\n",
+             "<|user|>\n" + "tell me more about it " * 3 + "<|end|>\n<|assistant|>\n"]
+    reqs = [proc(t) for t in texts]
+    reqs.insert(1, proc("<|user|>\n<|image_1|>\nWhat is shown?<|end|>\n<|assistant|>\n", [make_image(336, 336, "noise", 0)]))
+    lens = sorted(int(np.asarray(r["input_ids"]).shape[-1]) for r in reqs)
+    assert len(set(lens)) >= 5 and lens[-1] - lens[-2] > dist.GROUP_PAD and lens[-2] - lens[0] <= dist.GROUP_PAD   # two groups
+    n_steps = 5
+
+    def solo(inputs):
+        tok, cache = model.greedy_prefill(n_steps, **inputs)
+        logits, _ = model(**inputs, max_tokens=n_steps)
+        toks, clear = [int(tok.item())], []
+        for step in range(n_steps):
+            lf = logits[:, -1].float()
+            v, i = lf.topk(2, dim=-1)
+            E = rel_tol * (lf / norms).abs().amax(-1)
+            clear.append(bool(((v[:, 0] - v[:, 1]) > E * (norms[i[:, 0]] + norms[i[:, 1]])).item()))
+            if step + 1 < n_steps:
+                logits, tok = model.greedy_step(tok, cache)
+                toks.append(int(tok.item()))
+        return toks, clear
+    want = [solo(r) for r in reqs]
+    calls = []
+    real = model.prefill_slot
+    model.prefill_slot = lambda st, row, inputs, **kw: (calls.append(np.asarray(inputs["input_ids"]).reshape(-1, np.asarray(inputs["input_ids"]).shape[-1]).shape), real(st, row, inputs, **kw))[1]
+    try:
+        got = dist.generate_requests(model, proc, reqs, n_steps, return_tokens=True)
+    finally:
+        model.prefill_slot = real
+    assert sorted(c[0] for c in calls) == [1, 5], calls                # the image request alone, the five text prompts together
+    same = total = 0
+    for toks, (ref, clear) in zip(got, want):
+        for step in range(min(len(toks), n_steps)):
+            total += 1
+            if toks[step] != ref[step]:
+                assert not clear[step], (step, toks, ref)           # only a near-tie may flip with the pad geometry
+                break
+            same += 1
+    assert same >= total - 4, (same, total)
+
+
 def test_http_server_on_the_engine_matches_direct_generate():
     """POST /v1/completions through the HTTP handler on top of the continuous-batching engine (text + one image request,
     concurrent clients) == direct `generate()` of each request (tiny decisive model; texts compared where the runs agree
