@@ -86,22 +86,39 @@ class ContinuousEngine:
             self.waiting = keep
         g = self.model.decode_graph(st)
         busy = bool(self._active())
-        for r in admit:
-            r.row = free.pop(0)
+        # requests of nearly equal length that get ADJACENT free rows are prefilled as one left-padded group (one pass over
+        # the weights instead of one per request; dist.GROUP_PAD bounds the padding a request may carry)
+        from .dist import GROUP_PAD
+        from .processor import collate_requests
+        admit.sort(key=lambda r: -r.S)
+        free.sort()
+        while admit:
+            run = 1
+            while run < len(free) and free[run] == free[0] + run:
+                run += 1
+            n = 1
+            while n < min(run, len(admit)) and admit[0].S - admit[n].S <= GROUP_PAD:
+                n += 1
+            group, admit = admit[:n], admit[n:]
+            row0, free = free[0], free[n:]
+            for i, r in enumerate(group):
+                r.row = row0 + i
             try:
-                tok = self.model.prefill_slot(st, r.row, r.inputs)
-            except Exception as e:                              # noqa: BLE001 -- reported to the request, the engine lives on
-                r.error = e
-                self.st.pad_len[r.row:r.row + 1].fill_(self.window)
-                r.done.set()
+                toks = self.model.prefill_slot(st, row0, collate_requests([r.inputs for r in group]) if n > 1 else group[0].inputs)
+            except Exception as e:                              # noqa: BLE001 -- reported to the requests, the engine lives on
+                for r in group:
+                    r.error = e
+                    self.st.pad_len[r.row:r.row + 1].fill_(self.window)
+                    r.done.set()
                 continue
-            g["tok"][r.row:r.row + 1].copy_(tok.reshape(-1))
-            self.rows[r.row] = r
-            self.joined_mid_flight += int(busy)
-            t = int(tok.item())
-            r.tokens.append(t)
-            if t == ID_EOS or len(r.tokens) >= r.max_tokens:
-                self._finish(r)
+            g["tok"][row0:row0 + n].copy_(toks.reshape(-1))
+            first = toks.reshape(-1).tolist()
+            for r, t in zip(group, first):
+                self.rows[r.row] = r
+                self.joined_mid_flight += int(busy)
+                r.tokens.append(t)
+                if t == ID_EOS or len(r.tokens) >= r.max_tokens:
+                    self._finish(r)
 
     def step(self):
         """Admit what fits, then one decode step for every active row.  Returns the number of active rows."""
