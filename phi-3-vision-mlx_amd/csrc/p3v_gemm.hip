@@ -36,6 +36,7 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 struct GemmP {
   const bf16_t* A; const bf16_t* W; void* out; const bf16_t* bias; const void* resid; const bf16_t* pos;
   int M, N, K, lda, ldw, ldo, ppi;
+  int kslice;   // split-K (EPI_F32 only): workgroup z covers k in [z*kslice, (z+1)*kslice) and writes fp32 partial z ([M, ldo] each)
 };
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
@@ -102,15 +103,16 @@ __global__ void __launch_bounds__(256, 2) k_gemm(GemmP p) {
     }
     b_src[q] = (unsigned)(((size_t)br * p.ldw + sw) * 2);
   }
-  const int nk = p.K / BK;
+  const int kz = p.kslice ? (int)blockIdx.z : 0;              // split-K slice (0 when not split)
+  const int nk = (p.kslice ? p.kslice : p.K) / BK, kt0 = kz * nk;
 
   auto stage = [&](int kt, int buf) {
     unsigned char* base = smem + buf * (2 * TILE_BYTES);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int piece = (wave * 4 + q) * 1024;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lptr_t)(base + piece), 16, a_src[q], kt * (BK * 2), 0, 0);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lptr_t)(base + TILE_BYTES + piece), 16, b_src[q], kt * (BK * 2), 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lptr_t)(base + piece), 16, a_src[q], (kt0 + kt) * (BK * 2), 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lptr_t)(base + TILE_BYTES + piece), 16, b_src[q], (kt0 + kt) * (BK * 2), 0, 0);
     }
   };
 
@@ -247,6 +249,7 @@ __global__ void __launch_bounds__(256, 2) k_gemm(GemmP p) {
           for (int e = 0; e < 8; ++e) v[e] += pe[e];
           oo = ((size_t)img * (p.ppi + 1) + 1 + pi) * p.ldo + n;
         }
+        if (EPI == P3V_EPI_F32) oo += (size_t)kz * p.M * p.ldo;
         *(float4*)((float*)p.out + oo) = make_float4(v[0], v[1], v[2], v[3]);
         *(float4*)((float*)p.out + oo + 4) = make_float4(v[4], v[5], v[6], v[7]);
       }
@@ -263,7 +266,7 @@ static int launch_gemm_v(const GemmP& p, hipStream_t s) {
     attr_set = true;
   }
   const int n_tile = EPI == P3V_EPI_SILU_MUL ? BN / 2 : BN;
-  dim3 grid(p3v_cdiv(p.N, n_tile), p3v_cdiv(p.M, BM));
+  dim3 grid(p3v_cdiv(p.N, n_tile), p3v_cdiv(p.M, BM), p.kslice ? p.K / p.kslice : 1);
   hipLaunchKernelGGL((k_gemm<EPI, ORD>), grid, dim3(256), GEMM_LDS, s, p);
   P3V_CHECK_LAUNCH();
   return P3V_OK;
@@ -304,6 +307,86 @@ static int gemm_big_rows(const p3v_gemm_args_t* a) {
   return best_rows;
 }
 
+// ---- split-K for prompt-sized-but-small M (17 .. 256 rows: short chat prompts, the text group of a mixed batch).  One
+// 128-row tile leaves N / 128 = 24 .. 128 workgroups, each walking the WHOLE K loop with one tile in flight: an iteration is
+// one DMA round trip (~0.6 us), so down_proj (K = 8192) took 78 us for a 50 MB weight matrix and a 17..256-token prefill
+// 8.3-9.5 ms, flat in the length.  Here S slices of K run as gridDim.z (fp32 partials [S, M, N] in a library-owned scratch)
+// and a second launch adds them in slice order (deterministic) and applies the epilogue.
+template <int EPI>
+__global__ void __launch_bounds__(256) k_splitk_reduce(const float* __restrict__ part, void* __restrict__ out, const void* __restrict__ resid,
+                                                       int M, int N, int ldp, int ldo, int S) {
+  constexpr bool SILU = EPI == P3V_EPI_SILU_MUL;             // part holds [gate | up] columns (2N), out N columns
+  const int per_row = N / 8;
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long)M * per_row) return;
+  const int m = (int)(i / per_row), n = (int)(i - (long)m * per_row) * 8;
+  float v[8] = {0, 0, 0, 0, 0, 0, 0, 0}, u[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int z = 0; z < S; ++z) {
+    const float* pr = part + ((size_t)z * M + m) * ldp + n;
+    const float4 a0 = *(const float4*)pr, a1 = *(const float4*)(pr + 4);
+    v[0] += a0.x; v[1] += a0.y; v[2] += a0.z; v[3] += a0.w; v[4] += a1.x; v[5] += a1.y; v[6] += a1.z; v[7] += a1.w;
+    if (SILU) {
+      const float4 b0 = *(const float4*)(pr + N), b1 = *(const float4*)(pr + N + 4);
+      u[0] += b0.x; u[1] += b0.y; u[2] += b0.z; u[3] += b0.w; u[4] += b1.x; u[5] += b1.y; u[6] += b1.z; u[7] += b1.w;
+    }
+  }
+  const size_t o = (size_t)m * ldo + n;
+  if (SILU) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float g = bf16_round(v[e]), up = bf16_round(u[e]);
+      v[e] = bf16_round(g * bf16_round(1.f / (1.f + __expf(-g)))) * up;
+    }
+  } else if (EPI == P3V_EPI_RESID_BF16) {
+    float r[8];
+    load8_bf16((const bf16_t*)resid + o, r);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = r[e] + bf16_round(v[e]);
+  }
+  store8_bf16((bf16_t*)out + o, v);
+}
+
+static float* splitk_scratch(size_t bytes) {                   // grow-only, one per device (prefill is not graph-captured)
+  static float* buf[16] = {};
+  static size_t cap[16] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+  if (cap[dev] < bytes) {
+    if (buf[dev]) (void)hipFree(buf[dev]);
+    buf[dev] = nullptr, cap[dev] = 0;
+    if (hipMalloc((void**)&buf[dev], bytes) != hipSuccess) return nullptr;
+    cap[dev] = bytes;
+  }
+  return buf[dev];
+}
+
+// returns P3V_ERR_UNSUPPORTED when the shape is not one for split-K
+static int gemm_splitk(const p3v_gemm_args_t* a, hipStream_t s) {
+  static const bool off = getenv("P3V_GEMM_NO_SPLITK") != nullptr;
+  const bool silu = a->epilogue == P3V_EPI_SILU_MUL;
+  static const int max_m = getenv("P3V_GEMM_SPLITK_MAX_M") ? atoi(getenv("P3V_GEMM_SPLITK_MAX_M")) : 1024;   // beyond, every projection has >= 256 tiles anyway
+  if (off || a->M <= 16 || a->M > max_m || a->N % 128 || a->K % 512) return P3V_ERR_UNSUPPORTED;
+  if (a->epilogue != P3V_EPI_NONE && a->epilogue != P3V_EPI_RESID_BF16 && !silu) return P3V_ERR_UNSUPPORTED;
+  const int w_rows = silu ? 2 * a->N : a->N;                  // SiLU: [gate; up] taken as 2N plain output columns
+  const int tiles = p3v_cdiv(a->M, BM) * (w_rows / BN);
+  int S = 1;
+  while (S < 8 && tiles * S < 256 && (a->K / (2 * S)) % BK == 0 && a->K / (2 * S) >= 4 * BK) S *= 2;
+  if (S == 1) return P3V_ERR_UNSUPPORTED;
+  float* part = splitk_scratch((size_t)S * a->M * w_rows * 4);
+  if (!part) return P3V_ERR_HIP;
+  GemmP p = {a->A, a->W, part, nullptr, nullptr, nullptr, a->M, w_rows, a->K, a->lda, a->ldw, w_rows, 0, a->K / S};
+  const int rc = launch_gemm<P3V_EPI_F32>(p, s);
+  if (rc != P3V_OK) return rc;
+  const long items = (long)a->M * (a->N / 8);
+  const dim3 grid((unsigned)p3v_cdiv(items, 256));
+  if (silu) hipLaunchKernelGGL(k_splitk_reduce<P3V_EPI_SILU_MUL>, grid, dim3(256), 0, s, part, a->out, a->resid, a->M, a->N, w_rows, a->ldo, S);
+  else if (a->epilogue == P3V_EPI_RESID_BF16)
+    hipLaunchKernelGGL(k_splitk_reduce<P3V_EPI_RESID_BF16>, grid, dim3(256), 0, s, part, a->out, a->resid, a->M, a->N, w_rows, a->ldo, S);
+  else hipLaunchKernelGGL(k_splitk_reduce<P3V_EPI_NONE>, grid, dim3(256), 0, s, part, a->out, a->resid, a->M, a->N, w_rows, a->ldo, S);
+  P3V_CHECK_LAUNCH();
+  return P3V_OK;
+}
+
 extern "C" int p3v_gemm(const p3v_gemm_args_t* a, void* stream) {
   if (!a || !a->A || !a->W || !a->out) return P3V_ERR_ARG;
   if (a->M < 0 || a->N <= 0 || a->K <= 0 || a->K % BK || a->N % 8 || a->ldo % 8) return P3V_ERR_ARG;
@@ -319,6 +402,10 @@ extern "C" int p3v_gemm(const p3v_gemm_args_t* a, void* stream) {
     if ((size_t)a->M * a->lda * 2 >= (1ull << 32) || w_rows * a->ldw * 2 >= (1ull << 32)) return P3V_ERR_UNSUPPORTED;
   }
   hipStream_t s = (hipStream_t)stream;
+  {
+    const int rc = gemm_splitk(a, s);
+    if (rc != P3V_ERR_UNSUPPORTED) return rc;
+  }
   static const bool big_tiles = !getenv("P3V_GEMM_128");
   const int rows_big = big_tiles ? gemm_big_rows(a) : 0;
   if (rows_big > 0) {

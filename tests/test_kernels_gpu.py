@@ -82,6 +82,9 @@ EPI_CASES = [
     # large-tile (256x256) path: M >= 1024, N % 256 == 0 (N % 128 for silu)
     ("none", 1100, 768, 192), ("bias", 1300, 1024, 128), ("qgelu", 1024, 512, 256), ("gelu", 1030, 256, 128),
     ("resid_f32", 2000, 1024, 192), ("resid_bf16", 2531, 3072, 256), ("silu", 1500, 640, 192), ("f32", 1025, 256, 64),
+    # split-K path (17 <= M <= 1024 with fewer than 256 tiles, N % 128 == 0, K % 512 == 0): fp32 partials per K slice + a
+    # reduce / epilogue launch -- short prompts ("resid_bf16", 300, 3072, 8192) above takes it too
+    ("none", 17, 9216, 3072), ("silu", 40, 8192, 3072), ("resid_bf16", 129, 3072, 3072), ("none", 700, 3072, 8192),
 ]
 
 
