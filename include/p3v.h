@@ -79,6 +79,11 @@ typedef struct {
   int epilogue;
   int patches_per_img; /* P3V_EPI_PATCH: P (=576) */
 } p3v_gemm_args_t;
+/* Operands are addressed with 32-bit byte offsets: M * lda * 2 and rows(W) * ldw * 2 must stay below 4 GiB
+ * (P3V_ERR_UNSUPPORTED otherwise).  Shapes with 17 <= M <= 1024 and fewer than 256 output tiles (short prompts) run split
+ * over K through a grow-only fp32 scratch the library owns, ONE PER DEVICE: calls on different streams of one device must
+ * not overlap (the model launches on one stream per device); the call may allocate, so it is not for graph capture at
+ * those shapes (P3V_GEMM_NO_SPLITK=1 turns the path off). */
 int p3v_gemm(const p3v_gemm_args_t* args /* host */, void* stream);
 
 /* ---- skinny projection for decode: y[M,N] = x[M,K] * W[N,K]^T, M <= 16, weight-streaming

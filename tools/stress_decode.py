@@ -8,7 +8,8 @@ from phi_3_vision_mlx_amd.api import load_synthetic
 ctx = int(sys.argv[1]) if len(sys.argv) > 1 else 2531
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 1500
 B = int(sys.argv[3]) if len(sys.argv) > 3 else 1
-model, _ = load_synthetic(blind_model=True, device="cuda:0")
+model, _ = load_synthetic(blind_model=True, device="cuda:0", use_quantized_cache=bool(os.environ.get("P3V_QCACHE")),
+                          quantized_fp8=bool(os.environ.get("P3V_FP8")))
 ids = np.random.default_rng(0).integers(3, 32000, (B, ctx))
 runs = []
 for rep in range(2):
