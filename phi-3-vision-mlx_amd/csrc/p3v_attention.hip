@@ -721,7 +721,7 @@ struct AttnDecP {
 // anyway, and when the bound runs out the output is NaN so that the failure is loud (api._rows raises) instead of a
 // silently wrong token.
 #define WS_SENTINEL 0xffffffffu
-#ifdef P3V_ATTN_TIMING                                         // tools/scratch/attn_timeline.py: 100 MHz timestamps per workgroup
+#ifdef P3V_ATTN_TIMING                                         // tools/attn_timeline.py: 100 MHz timestamps per workgroup
 __device__ long long p3v_tbuf[8192 * 16];
 #define TMARK(k) do { if (threadIdx.x == 0) p3v_tbuf[(blockIdx.x + gridDim.x * blockIdx.y) * 16 + (k)] = wall_clock64(); } while (0)
 #define TVAL(k, v) do { if (threadIdx.x == 0) p3v_tbuf[(blockIdx.x + gridDim.x * blockIdx.y) * 16 + (k)] = (v); } while (0)
@@ -1153,7 +1153,7 @@ __device__ __forceinline__ void attn_decode_body(const AttnDecP& p, const int bx
 // [V^T tile: 96 rows x 256 B, chunk c (of 16) of row d at c ^ (d & 15): the 16 rows x 2 key groups of a ds_read_b64 lane
 // group hit 32 different 8-byte slots].  The merge scratch aliases the (dead) tile region.
 // V2 (default; V1 = the same kernel without it, P3V_ATTN_V1=1 for A/B): the per-workgroup timeline (-DP3V_ATTN_TIMING,
-// tools/scratch/attn_timeline.py) showed that everything after the DMA issue ran AFTER the whole tile had landed: memory
+// tools/attn_timeline.py) showed that everything after the DMA issue ran AFTER the whole tile had landed: memory
 // returns in order, and the compiler answers a pending `global_load_lds` with vmcnt(0) at every later wait.  V2 issues the
 // tile as `buffer_load ... lds` (counted waits stay possible), AFTER the small loads of the new rows, and hides from the
 // compiler the LDS accesses that do not depend on the tile (inline asm): Q is rotated, published and fetched while the tile

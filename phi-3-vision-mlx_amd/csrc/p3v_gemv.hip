@@ -297,7 +297,7 @@ __global__ void __launch_bounds__(256) k_gemv_mfma(GemvP p) {
 // stages that slice of x itself; the only workgroup barrier before the stream is the RMSNorm sum-of-squares exchange.
 // LDS row stride 2K + 64 bytes: the 16 (x row, chunk) slots of every ds_read_b128 lane group fall on 16 different
 // 16-byte bank groups.  K = 3072: 4 waves, 49.7 KB -> 3 workgroups / CU.  K = 8192: 8 waves, 131 KB -> 1 workgroup / CU.
-#ifdef P3V_ATTN_TIMING                                         // tools/scratch/gemv8_timeline.py: 100 MHz timestamps per workgroup
+#ifdef P3V_ATTN_TIMING                                         // tools/gemv8_timeline.py: 100 MHz timestamps per workgroup
 __device__ long long p3v_gbuf[4096 * 8];
 #define GMARK(k) do { if (threadIdx.x == 0 && blockIdx.x < 4096) p3v_gbuf[blockIdx.x * 8 + (k)] = wall_clock64(); } while (0)
 extern "C" int p3v_gemv_timing_read(long long* out, int n) {
@@ -306,7 +306,7 @@ extern "C" int p3v_gemv_timing_read(long long* out, int n) {
 #else
 #define GMARK(k)
 #endif
-// Round 2: PERSISTENT over row sets.  The per-workgroup timeline (-DP3V_ATTN_TIMING, tools/scratch/gemv8_timeline.py) of the
+// Round 2: PERSISTENT over row sets.  The per-workgroup timeline (-DP3V_ATTN_TIMING, tools/gemv8_timeline.py) of the
 // one-set-per-workgroup form (qkv: 576 workgroups, 3 per CU) showed the activations arriving 2-11 us after entry (27.6 MB
 // of x reads of the same 48 KB by 2304 waves) and the RMSNorm pass over 8 x 768 values per wave costing another 3 us with
 // 12 waves per CU doing it at once: the weights had landed long before anybody could use them (16.2 us for 56.6 MB).  Now
