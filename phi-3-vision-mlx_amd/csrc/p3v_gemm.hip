@@ -369,8 +369,10 @@ static int gemm_splitk(const p3v_gemm_args_t* a, hipStream_t s) {
   if (a->epilogue != P3V_EPI_NONE && a->epilogue != P3V_EPI_RESID_BF16 && !silu) return P3V_ERR_UNSUPPORTED;
   const int w_rows = silu ? 2 * a->N : a->N;                  // SiLU: [gate; up] taken as 2N plain output columns
   const int tiles = p3v_cdiv(a->M, BM) * (w_rows / BN);
+  static const int max_s = getenv("P3V_GEMM_SPLITK_MAX_S") ? atoi(getenv("P3V_GEMM_SPLITK_MAX_S")) : 8;
+  static const int want = getenv("P3V_GEMM_SPLITK_WGS") ? atoi(getenv("P3V_GEMM_SPLITK_WGS")) : 256;
   int S = 1;
-  while (S < 8 && tiles * S < 256 && (a->K / (2 * S)) % BK == 0 && a->K / (2 * S) >= 4 * BK) S *= 2;
+  while (S < max_s && tiles * S < want && (a->K / (2 * S)) % BK == 0 && a->K / (2 * S) >= 2 * BK) S *= 2;
   if (S == 1) return P3V_ERR_UNSUPPORTED;
   float* part = splitk_scratch((size_t)S * a->M * w_rows * 4);
   if (!part) return P3V_ERR_HIP;
