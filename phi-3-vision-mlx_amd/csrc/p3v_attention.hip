@@ -525,6 +525,9 @@ __global__ void __launch_bounds__(256, 2) k_attn_prefill_dma(AttnP p) {
     if (kv0 <= wave_last) {                                   // wave-uniform: tiles above this wave's diagonal are skipped
       const unsigned char* Ks = smem + buf * BUF;
       f32x4_t s[2][4];
+      // the two MFMA blocks of a tile run at raised wave priority: the SIMD's other wave is usually in its softmax, and a
+      // wave that has to wait for VALU slots between its MFMAs also loses the matrix pipe (8k: 650 -> 630 us)
+      __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int st = 0; st < 4; ++st) {
         s[0][st] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
@@ -536,6 +539,7 @@ __global__ void __launch_bounds__(256, 2) k_attn_prefill_dma(AttnP p) {
           s[1][st] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[1][ks], s[1][st], 0, 0, 0);
         }
       }
+      __builtin_amdgcn_s_setprio(0);
       // every key of the tile visible to every query of the wave -> no per-element mask work (wave-uniform)
       const bool interior = kv0 + 64 <= kv_end && kv0 >= pad && past + q0 >= pad && (!p.causal || kv0 + 63 <= past + q0);
       bf16x8_t pf[2][2];
@@ -589,6 +593,7 @@ __global__ void __launch_bounds__(256, 2) k_attn_prefill_dma(AttnP p) {
           pf[u][st] = __builtin_bit_cast(bf16x8_t, pw);
         }
       }
+      __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int st = 0; st < 2; ++st)
 #pragma unroll
@@ -600,6 +605,7 @@ __global__ void __launch_bounds__(256, 2) k_attn_prefill_dma(AttnP p) {
           o[0][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[0][st], o[0][d], 0, 0, 0);
           o[1][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[1][st], o[1][d], 0, 0, 0);
         }
+      __builtin_amdgcn_s_setprio(0);
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -67,10 +67,10 @@ class CacheState:
         # when the capacity allows it)
         gran = 128
         self.Tp = (self.T + gran - 1) // gran * gran
-        if self.Tp % 512 == 0:
-            # V^T rows are Tp * 2 bytes apart: at multiples of 1 KiB the 96 rows of a tile crowd the same memory channels
-            # (measured decode step at B = 1: +3.5 % at Tp = 2560, +2 % at 3584, +1.4 % at 4096 against the neighbouring
-            # lengths) -- one spare tile of capacity moves the stride off the grid
+        if (self.Tp // gran) % 2 == 0:
+            # V^T rows are Tp * 2 bytes apart: at multiples of 512 B the 96 rows of a tile crowd the same memory channels
+            # (measured decode step at B = 1: +3.5 % at Tp = 2560, +2 % at 3584, +1.4 % at 4096, +5.7 % at 33024 = 258 tiles
+            # against the neighbouring lengths) -- an ODD number of 128-key tiles keeps the stride off that grid
             self.Tp += gran
         nl, nkv, hd = cfg.num_hidden_layers, cfg.num_key_value_heads, head_dim(cfg)
         if self.quantized:

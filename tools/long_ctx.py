@@ -11,7 +11,7 @@ lg = cache = None
 for rep in range(3):
     lg = cache = None                                          # release the previous cache first: the timed call must reuse its blocks
     torch.cuda.synchronize(); t0 = time.perf_counter()
-    lg, cache = model(input_ids=ids, max_tokens=136)
+    lg, cache = model(input_ids=ids, max_tokens=int(sys.argv[2]) if len(sys.argv) > 2 else 136)
     tok = ops.argmax(lg[:, -1].contiguous())[:, None]; tok.tolist()
     pre = time.perf_counter() - t0
 print(f"S={S}: prefill {pre*1e3:.1f} ms  ({(2*S*3.722e9 + 2*32*S*S*3072)/pre/1e12:.0f} TFLOP/s algorithmic)  mem {torch.cuda.max_memory_allocated()/1e9:.1f} GB")
