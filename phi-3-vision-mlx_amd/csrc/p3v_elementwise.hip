@@ -657,6 +657,7 @@ __global__ void __launch_bounds__(1024) k_step_end(const bf16_t* __restrict__ lo
   __shared__ ValIdx red[16];
   const int b = blockIdx.x;
   const int s = *d_step;                     // read before this workgroup takes its ticket (the last one bumps it)
+  const int past_now = *d_past;              // likewise (its round trip overlaps the scan instead of following it)
   ValIdx m = row_argmax_partial(logits + (size_t)b * n, n);
   m = block_argmax(m, red);
   if (threadIdx.x == 0) {
@@ -672,7 +673,7 @@ __global__ void __launch_bounds__(1024) k_step_end(const bf16_t* __restrict__ lo
     }
     if (last) {
       *d_step = s + 1;
-      *d_past += 1;
+      *d_past = past_now + 1;
       if (gridDim.x > 1) __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
