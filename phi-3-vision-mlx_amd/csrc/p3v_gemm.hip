@@ -21,6 +21,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <mutex>
+
 #include "p3v_common.h"
 
 #define BM 128
@@ -349,6 +351,8 @@ __global__ void __launch_bounds__(256) k_splitk_reduce(const float* __restrict__
 static float* splitk_scratch(size_t bytes) {                   // grow-only, one per device (prefill is not graph-captured)
   static float* buf[16] = {};
   static size_t cap[16] = {};
+  static std::mutex mu;                                        // allocation only; USE of one device's scratch is single-stream by contract
+  std::lock_guard<std::mutex> lock(mu);
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
   if (cap[dev] < bytes) {
