@@ -509,7 +509,13 @@ __global__ void __launch_bounds__(256, 2) k_attn_prefill_dma(AttnP p) {
 #pragma unroll
   for (int k = 0; k < 4; ++k) v_rd[k] = KTILE + qi * VROW + (((2 * k + (g >> 1)) ^ ((qi >> 1) & 7)) << 4) + (g & 1) * 8;   // + d*16*VROW
 
-  float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};
+  // The row sums l ride on the matrix cores: one extra O^T tile whose V^T fragment is a register constant (row 0 all ones,
+  // the other 15 rows zero), so l = P . 1 accumulates -- and is rescaled -- like any other output row, in lanes g = 0.
+  // 4 MFMAs per tile instead of 32 v_add + two cross-lane reductions: the kernel is VALU-bound, the matrix pipe is 70 % idle.
+  const u32x4_t ones_w = qi == 0 ? (u32x4_t){0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u} : (u32x4_t){0u, 0u, 0u, 0u};
+  const bf16x8_t ones_f = __builtin_bit_cast(bf16x8_t, ones_w);
+  float m_run[2] = {-INFINITY, -INFINITY};
+  f32x4_t ol[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
   f32x4_t o[2][NDT];
 #pragma unroll
   for (int u = 0; u < 2; ++u)
@@ -567,21 +573,15 @@ __global__ void __launch_bounds__(256, 2) k_attn_prefill_dma(AttnP p) {
         const float m_new = fmaxf(m_run[u], m_t * sc2);
         const float m_use = m_new == -INFINITY ? 0.f : m_new;
         const float alpha = __builtin_amdgcn_exp2f(m_run[u] - m_use);
-        float l_t = 0.f;
 #pragma unroll
         for (int st = 0; st < 4; ++st)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float e = __builtin_amdgcn_exp2f(fmaf(s[u][st][r], sc2, -m_use));
-            s[u][st][r] = e;
-            l_t += e;
-          }
-        l_t = rows_sum(l_t);
-        l_run[u] = l_run[u] * alpha + l_t;
+          for (int r = 0; r < 4; ++r) s[u][st][r] = __builtin_amdgcn_exp2f(fmaf(s[u][st][r], sc2, -m_use));
         m_run[u] = m_new;
         if (!__all(alpha == 1.f)) {
 #pragma unroll
           for (int d = 0; d < NDT; ++d) o[u][d] *= alpha;
+          ol[u] *= alpha;
         }
 #pragma unroll
         for (int st = 0; st < 2; ++st) {
@@ -605,14 +605,20 @@ __global__ void __launch_bounds__(256, 2) k_attn_prefill_dma(AttnP p) {
           o[0][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[0][st], o[0][d], 0, 0, 0);
           o[1][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[1][st], o[1][d], 0, 0, 0);
         }
+#pragma unroll
+      for (int st = 0; st < 2; ++st) {
+        ol[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones_f, pf[0][st], ol[0], 0, 0, 0);
+        ol[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones_f, pf[1][st], ol[1], 0, 0, 0);
+      }
       __builtin_amdgcn_s_setprio(0);
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  const float l_fin[2] = {rows_sum(ol[0][0]), rows_sum(ol[1][0])};   // the sum sits in the g = 0 lane of the query's column (all lanes take part)
 #pragma unroll
   for (int u = 0; u < 2; ++u) {
     if (!qvalid[u]) continue;
-    const float inv = l_run[u] > 0.f ? 1.f / l_run[u] : 0.f;
+    const float inv = l_fin[u] > 0.f ? 1.f / l_fin[u] : 0.f;
     bf16_t* op = p.out + ((size_t)b * p.L + (q0 + u * 16 + qi)) * (size_t)(p.nh * HD) + head * HD + 4 * g;
 #pragma unroll
     for (int d = 0; d < NDT; ++d) {

@@ -214,7 +214,8 @@ static int launch_gemv3_q4(const GemvQ4P& p, hipStream_t s) {
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess) return P3V_ERR_HIP;
     n_cu = pr.multiProcessorCount;
   }
-  int upw = p3v_cdiv(p.units, n_cu * 8);
+  static const int wpc = getenv("P3V_GEMV_Q4_WPC") ? atoi(getenv("P3V_GEMV_Q4_WPC")) : 8;   // waves per CU
+  int upw = p3v_cdiv(p.units, n_cu * wpc);
   if (upw < 1) upw = 1;
   const int waves = p3v_cdiv(p.units, upw);
   hipLaunchKernelGGL((k_gemv3_q4<NST, NP>), dim3(p3v_cdiv(waves, 4)), dim3(256), (size_t)p.K * 2 + (size_t)p.K / 4, s, p, upw);
