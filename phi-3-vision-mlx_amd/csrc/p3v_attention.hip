@@ -1164,14 +1164,13 @@ __device__ __forceinline__ void attn_decode_body(const AttnDecP& p, const int bx
 // many partials.  LDS image: [K slice of wave 0..3: 32 keys x 192 B, chunk c of row r at c ^ ((r >> 2) & 3)]
 // [V^T tile: 96 rows x 256 B, chunk c (of 16) of row d at c ^ (d & 15): the 16 rows x 2 key groups of a ds_read_b64 lane
 // group hit 32 different 8-byte slots].  The merge scratch aliases the (dead) tile region.
-// V2 (default; V1 = the same kernel without it, P3V_ATTN_V1=1 for A/B): the per-workgroup timeline (-DP3V_ATTN_TIMING,
+// Schedule (the "V2" of profiles/ and DESIGN.md; V1, the same kernel without it, is in the history): the per-workgroup timeline (-DP3V_ATTN_TIMING,
 // tools/attn_timeline.py) showed that everything after the DMA issue ran AFTER the whole tile had landed: memory
 // returns in order, and the compiler answers a pending `global_load_lds` with vmcnt(0) at every later wait.  V2 issues the
 // tile as `buffer_load ... lds` (counted waits stay possible), AFTER the small loads of the new rows, and hides from the
 // compiler the LDS accesses that do not depend on the tile (inline asm): Q is rotated, published and fetched while the tile
 // is in flight, S^T and the softmax start when the wave's own K slice (its six oldest DMAs, vmcnt(6)) is there and run
 // while the V^T tile is still landing.  10.9 -> 10.6 us isolated, 11.1 -> 10.65 us in the decode step.
-template <bool V2>
 __device__ __forceinline__ void attn_decode_body128(const AttnDecP& p, const int bx, const int by, const int bz, unsigned char* KV) {
   constexpr int TK = 128, WK = 32, HD = 96, KROW = HD * 2, VROWB = TK * 2, NKS = 3, NDT = 6, CPR = 12;
   constexpr int KS_BYTES = WK * KROW;                          // 6 KiB per wave = 16 x 96 fp32: the wave's O partial parks here
@@ -1199,7 +1198,7 @@ __device__ __forceinline__ void attn_decode_body128(const AttnDecP& p, const int
     const int kv0 = min(kv_lo, p.cache_t - TK);
     const unsigned char* ksrc = kc + (size_t)(kv0 + WK * wave) * KROW;
     const unsigned char* vs = (const unsigned char*)vc + (size_t)kv0 * 2;
-    // V2: MUBUF form.  The compiler's wait-count model treats a pending `global_load_lds` as a FLAT access of both memories
+    // MUBUF form.  The compiler's wait-count model treats a pending `global_load_lds` as a FLAT access of both memories
     // and turns every later vmcnt wait into vmcnt(0); a pending `buffer_load ... lds` keeps counted waits possible.
     const __amdgpu_buffer_rsrc_t rs_k = __builtin_amdgcn_make_buffer_rsrc((void*)ksrc, 0, 0xffffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_v = __builtin_amdgcn_make_buffer_rsrc((void*)vs, 0, 0xffffffff, 0x00020000);
@@ -1207,18 +1206,15 @@ __device__ __forceinline__ void attn_decode_body128(const AttnDecP& p, const int
     for (int j = 0; j < 6; ++j) {                              // K: LDS slot i = j*64 + lane holds (row i/12, physical chunk i%12)
       const int i = j * 64 + lane, r0 = i / CPR, pc = i - r0 * CPR;
       const unsigned koff = r0 * KROW + ((pc ^ ((r0 >> 2) & 3)) << 4);
-      if (V2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_k, (dec_lptr_t)(kslice + j * 1024), 16, koff, 0, 0, P3V_ATTN_AUX);
-      else __builtin_amdgcn_global_load_lds((dec_gptr_t)(ksrc + koff), (dec_lptr_t)(kslice + j * 1024), 16, 0, P3V_ATTN_AUX);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_k, (dec_lptr_t)(kslice + j * 1024), 16, koff, 0, 0, P3V_ATTN_AUX);
     }
 #pragma unroll
     for (int j = 0; j < 6; ++j) {                              // V^T: wave w brings rows 24w..24w+23, four whole 256-B rows per instruction
       const int d = 24 * wave + 4 * j + (lane >> 4);
       const unsigned voff = (unsigned)d * (unsigned)vrow + ((((unsigned)lane & 15) ^ ((unsigned)d & 15)) << 4);
-      if (V2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_v, (dec_lptr_t)(vtile + wave * 6144 + j * 1024), 16, voff, 0, 0, P3V_ATTN_AUX);
-      else __builtin_amdgcn_global_load_lds((dec_gptr_t)(vs + voff), (dec_lptr_t)(vtile + wave * 6144 + j * 1024), 16, 0, P3V_ATTN_AUX);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_v, (dec_lptr_t)(vtile + wave * 6144 + j * 1024), 16, voff, 0, 0, P3V_ATTN_AUX);
     }
   };
-  if (!V2) issue_dma();
 
   // ---- the L new rows (as attn_decode_body): rotated Q -> LDS, rotated K / V kept until the tile that holds them has landed
   const int row_w = (p.nh + 2 * p.nkv) * HD;
@@ -1242,16 +1238,14 @@ __device__ __forceinline__ void attn_decode_body128(const AttnDecP& p, const int
     const int r = tid / HD;
     v_early = vnew[(size_t)r * row_w + (tid - r * HD)];
   }
-  if (V2) issue_dma();                                         // after the (small) loads above: memory returns in order
+  issue_dma();                                                 // after the (small) loads above: memory returns in order
   TMARK(7);
   const unsigned qs_lds = (unsigned)(size_t)(dec_lptr_t)Qs;
   if (tid < 16 * CPR) {
     u32x4_t v = {0, 0, 0, 0};
     if (rtask) v = rope_apply(qraw, tc);
-    if (V2)                                                    // LDS accesses the compiler must not see: it would wait for the whole tile first
-      asm volatile("ds_write_b128 %0, %1" ::"v"(qs_lds + tr * KROW + ((tc ^ ((tr >> 2) & 3)) << 4)), "v"(v) : "memory");
-    else
-      *(u32x4_t*)(Qs + tr * KROW + ((tc ^ ((tr >> 2) & 3)) << 4)) = v;
+    // (an LDS access the compiler must not see: it would wait for the whole tile first)
+    asm volatile("ds_write_b128 %0, %1" ::"v"(qs_lds + tr * KROW + ((tc ^ ((tr >> 2) & 3)) << 4)), "v"(v) : "memory");
   }
 
   asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(past), "+s"(pad)::"memory");
@@ -1277,7 +1271,7 @@ __device__ __forceinline__ void attn_decode_body128(const AttnDecP& p, const int
   if (kv0 < kv_end) {
     bf16x8_t qf[NKS];
     const bool has_new = kv0 + TK > past;                      // workgroup-uniform: the tile holds new positions
-    if (V2) {                                                  // Q is published and fetched while the tile is in flight
+    {                                                          // Q is published and fetched while the tile is in flight
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
       u32x4_t q0, q1, q2;
       asm volatile("ds_read_b128 %0, %3\n\tds_read_b128 %1, %3 offset:64\n\tds_read_b128 %2, %3 offset:128\n\ts_waitcnt lgkmcnt(0)"
@@ -1288,12 +1282,6 @@ __device__ __forceinline__ void attn_decode_body128(const AttnDecP& p, const int
         __syncthreads();
       }
       TMARK(1);
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      TMARK(1);
-#pragma unroll
-      for (int ks = 0; ks < NKS; ++ks) qf[ks] = *(const bf16x8_t*)(Qs + k_rd + ks * 64);
     }
     TMARK(9);
     if (has_new) {
@@ -1319,7 +1307,7 @@ __device__ __forceinline__ void attn_decode_body128(const AttnDecP& p, const int
     }
 
     f32x4_t s[2];
-    if (V2 && !has_new) {
+    if (!has_new) {
       // this wave's K slice = its six oldest DMAs: S^T and the softmax run while the V^T tile is still landing
       u32x4_t kf[2][NKS];
       const unsigned ka = (unsigned)(size_t)(dec_lptr_t)kslice + k_rd;
@@ -1374,7 +1362,7 @@ __device__ __forceinline__ void attn_decode_body128(const AttnDecP& p, const int
     TMARK(10);
     const u32x4_t pw = {pack_bf16x2(s[0][0], s[0][1]), pack_bf16x2(s[0][2], s[0][3]), pack_bf16x2(s[1][0], s[1][1]), pack_bf16x2(s[1][2], s[1][3])};
     const bf16x8_t pf = __builtin_bit_cast(bf16x8_t, pw);
-    if (V2 && !has_new) {                                      // the V^T tile is every wave's DMA: all landed, then the barrier
+    if (!has_new) {                                            // the V^T tile is every wave's DMA: all landed, then the barrier
       asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
     }
 #pragma unroll
@@ -1430,10 +1418,9 @@ __device__ __forceinline__ void attn_decode_body128(const AttnDecP& p, const int
                      (size_t)p.nh * HD, p.L, p.n_split, own, (float*)vtile);
 }
 
-template <bool V2>
 __global__ void __launch_bounds__(256) k_attn_decode128(AttnDecP p) {
   __shared__ __attribute__((aligned(1024))) unsigned char KV[4 * 6144 + 96 * 256];   // [K slice x 4 | V^T tile] = 48 KiB
-  attn_decode_body128<V2>(p, blockIdx.x, blockIdx.y, blockIdx.z, KV);
+  attn_decode_body128(p, blockIdx.x, blockIdx.y, blockIdx.z, KV);
 }
 
 __global__ void __launch_bounds__(256) k_attn_decode(AttnDecP p) {
@@ -1714,11 +1701,7 @@ extern "C" int p3v_attention_decode(const p3v_attn_decode_args_t* a, void* strea
   hipStream_t s = (hipStream_t)stream;
   const dim3 grid(a->n_split, a->n_heads, a->B);
   if (a->n_split * 64 >= a->cache_t) hipLaunchKernelGGL(k_attn_decode, grid, dim3(256), 0, s, p);
-  else if (a->n_split * 128 >= a->cache_t && a->cache_t % 128 == 0) {                     // 128-key tiles
-    static const bool v1 = getenv("P3V_ATTN_V1") != nullptr;
-    if (v1) hipLaunchKernelGGL(k_attn_decode128<false>, grid, dim3(256), 0, s, p);
-    else hipLaunchKernelGGL(k_attn_decode128<true>, grid, dim3(256), 0, s, p);
-  }
+  else if (a->n_split * 128 >= a->cache_t && a->cache_t % 128 == 0) hipLaunchKernelGGL(k_attn_decode128, grid, dim3(256), 0, s, p);   // 128-key tiles
   else hipLaunchKernelGGL(k_attn_decode_stream<64>, grid, dim3(64), 0, s, p);
   P3V_CHECK_LAUNCH();
   if (a->merge_in_launch) return P3V_OK;                       // the last workgroup of every (b, head) merged in-kernel

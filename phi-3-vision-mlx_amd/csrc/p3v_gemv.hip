@@ -318,7 +318,7 @@ extern "C" int p3v_gemv_timing_read(long long* out, int n) {
 // first MFMA (that pass took 3 us; the sums are exchanged by the barrier the partials need anyway).  (Two slices in
 // flight per wave -- tried: the 32 extra load instructions block the wave in issue while the queues are full and the
 // prologue behind them gets later, not earlier.)
-template <bool SILU, int NW, int NST, int DEPTH>
+template <bool SILU, int NW, int NST>
 __global__ void __launch_bounds__(NW * 64) k_gemv_mfma8(GemvP p, int n_sets) {
   constexpr int KQ = NST * 256, K = KQ * NW, XS = K * 2 + 64, NCH = KQ / 8;     // slice elements, LDS row stride (bytes), slice chunks
   constexpr int ROWS = SILU ? 8 : 16;                                            // output columns per set
@@ -339,7 +339,7 @@ __global__ void __launch_bounds__(NW * 64) k_gemv_mfma8(GemvP p, int n_sets) {
   const bf16_t *w0, *w1;
   row_ptrs(set, w0, w1);
 
-  u32x4_t wa[DEPTH][NST][8];                                                     // stage = 4 lines x 2 row sets; DEPTH whole slices
+  u32x4_t wa[1][NST][8];                                                         // stage = 4 lines x 2 row sets; one whole slice
   auto issue = [&](const bf16_t* a0, const bf16_t* a1, auto stc, auto slotc) {
     constexpr int st = decltype(stc)::value, slot = decltype(slotc)::value;
 #pragma unroll
@@ -413,10 +413,10 @@ __global__ void __launch_bounds__(NW * 64) k_gemv_mfma8(GemvP p, int n_sets) {
   const unsigned char* xrow = xslice + r8 * XS + chunk * 16;
   const bool odd = lane & 1;
   int par = 0;
-  // one row set out of register slot `slot`; its registers are refilled stage by stage with the set DEPTH strides ahead
+  // one row set out of register slot `slot`; its registers are refilled stage by stage with the set one stride ahead
   auto do_set = [&](auto slotc) {
     constexpr int slot = decltype(slotc)::value;
-    const int nset = set + DEPTH * (int)gridDim.x;
+    const int nset = set + (int)gridDim.x;
     const bool has_next = nset < n_sets;                                         // workgroup-uniform
     const bf16_t *w0n = nullptr, *w1n = nullptr;
     if (has_next) row_ptrs(nset, w0n, w1n);
@@ -489,19 +489,15 @@ __global__ void __launch_bounds__(NW * 64) k_gemv_mfma8(GemvP p, int n_sets) {
   };
   for (;;) {
     if (!do_set(IC0{})) break;
-    if constexpr (DEPTH > 1) {
-      if (!do_set(IC1{})) break;
-    }
   }
 }
 
 template <bool SILU, int NW, int NST>
 static int launch_gemv_mfma8(const GemvP& p, hipStream_t s) {
-  constexpr int DEPTH = 1;                                   // register slices in flight per wave (2: see the kernel's header)
   const size_t lds = (size_t)8 * (p.K * 2 + 64);
   static bool attr_set = false;
   if (!attr_set && lds > 40 * 1024) {
-    if (hipFuncSetAttribute((const void*)k_gemv_mfma8<SILU, NW, NST, DEPTH>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 8704) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)k_gemv_mfma8<SILU, NW, NST>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 8704) != hipSuccess)
       return P3V_ERR_HIP;
     attr_set = true;
   }
@@ -509,7 +505,7 @@ static int launch_gemv_mfma8(const GemvP& p, hipStream_t s) {
   // (576 sets -> 192 x 3, 1024 -> 256 x 4, 2004 -> 251 x 8, 192 -> 192 x 1)
   static const int max_wg = gemv_env("P3V_GEMV8_WGS", 256);
   const int n_sets = p3v_cdiv(p.N, SILU ? 8 : 16), per = p3v_cdiv(n_sets, max_wg), grid = p3v_cdiv(n_sets, per);
-  hipLaunchKernelGGL((k_gemv_mfma8<SILU, NW, NST, DEPTH>), dim3(grid), dim3(NW * 64), lds, s, p, n_sets);
+  hipLaunchKernelGGL((k_gemv_mfma8<SILU, NW, NST>), dim3(grid), dim3(NW * 64), lds, s, p, n_sets);
   P3V_CHECK_LAUNCH();
   return P3V_OK;
 }
