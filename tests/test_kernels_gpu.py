@@ -351,6 +351,46 @@ def test_attention_decode_fused(ops, orc, B, L, past, nh, n_split, pads, dev_pas
     assert torch.equal(kcc[:, :, :past].cpu(), kc[:, :, :past]) and torch.equal(kcc[:, :, past + L:].cpu(), kc[:, :, past + L:])
 
 
+@pytest.mark.parametrize("seed", range(4))
+def test_attention_decode_random_shapes_merge_modes_agree(ops, seed):
+    """Fuzz of the decode attention: random (B, L, past, heads, pads) on the 64-key, 128-key and streaming plans; the
+    in-launch merge and the merge launch must agree (same partials, different summation order of the splits) and stay
+    finite, on ONE workspace that every launch must leave all-sentinel."""
+    rng = np.random.default_rng(1234 + seed)
+    hd = 96
+    ws = ops.attention_ws(4, 16, 8, hd, 64, "cuda")
+    for case in range(10):
+        B, L, nh = int(rng.integers(1, 4)), int(rng.choice([1, 1, 1, 2, 5, 16])), int(rng.choice([2, 4, 8]))
+        past = int(rng.integers(0, 3000))
+        plan = rng.choice(["t64", "t128", "stream"])
+        if plan == "t128":
+            T = (past + L + 3 + 127) // 128 * 128
+            n_split = T // 128
+        elif plan == "t64":
+            T = (past + L + 3 + 63) // 64 * 64
+            n_split = T // 64
+        else:
+            T = (past + L + 3 + 127) // 128 * 128
+            n_split = int(rng.integers(1, 5))
+        if n_split > 64:
+            continue
+        pads = rng.integers(0, max(1, past // 2 + 1), size=B).astype(np.int32) if rng.random() < 0.5 else None
+        qkv = g((B * L, 3 * nh * hd), 500 + case)
+        kc, vc = g((B, nh, T, hd), 600 + case), g((B, nh, T, hd), 700 + case)
+        torch.manual_seed(case)
+        cos, sin = torch.rand((B, L, hd // 2)).cuda(), torch.rand((B, L, hd // 2)).cuda()
+        outs = []
+        for fused in (True, False):
+            kcc, vcc = kc.cuda(), vc.transpose(2, 3).contiguous().cuda()
+            out = torch.full((B, L, nh * hd), float("nan"), dtype=BF16).cuda()
+            ops.attention_decode(qkv.cuda(), cos, sin, L, kcc, vcc, out, B, L, nh, nh, hd, hd ** -0.5, past, T, ws, n_split,
+                                 pad_len=torch.from_numpy(pads).cuda() if pads is not None else None, merge_in_launch=fused)
+            assert torch.isfinite(out.float()).all(), (case, plan, B, L, past, nh, n_split, fused)
+            assert (ws.view(torch.int32) == -1).all()
+            outs.append(out.float().cpu())
+        close(outs[0], outs[1], rtol=2 ** -7, atol=1e-2)
+
+
 def test_attention_decode_workspace_is_reusable_across_modes_and_shapes(ops, orc):
     """One workspace, used by launches of different shapes and with / without the in-launch merge, in any order: the
     partial records are validated against the 'not written yet' sentinel, so a launch that left anything else behind would
