@@ -1,6 +1,6 @@
-"""Cycle-counter breakdown of one k_attn_decode block (debug build: -DP3V_ATTN_DEBUG -> tools/libp3v_dbg.so)."""
+"""Cycle-counter breakdown of one k_attn_decode block (debug build: -DP3V_ATTN_DEBUG -> gpurun_out/libp3v_dbg.so (built by hand, never committed))."""
 import sys, os, ctypes
-os.environ["P3V_LIB"] = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libp3v_dbg.so")
+os.environ["P3V_LIB"] = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "build", "libp3v_dbg.so")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from phi_3_vision_mlx_amd import ops, _lib
