@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define P3V_VERSION 100
+#define P3V_VERSION 300
 #define P3V_OK 0
 #define P3V_ERR_ARG (-22)         /* bad shape / null pointer / unsupported size */
 #define P3V_ERR_LAUNCH (-5)       /* hipGetLastError() != hipSuccess after launch */
@@ -39,6 +39,13 @@ typedef struct {
 int p3v_version(void);
 int p3v_device_props(int device, p3v_props_t* out /* host */);
 const char* p3v_strerror(int code);
+
+/* Launch-policy knobs ("gemm_big_rows", "gemm_no_splitk", "gemv_wpc", ... -- the table in csrc/p3v_runtime.hip).  Each is
+ * read ONCE, on first use, from the environment variable P3V_<NAME IN UPPER CASE>; afterwards only these calls change
+ * it (kernel tests pin a kernel variant with them).  No launch reads the environment.  Process-wide, not thread-safe
+ * against concurrent launches: set before launching.  P3V_ERR_ARG for an unknown name. */
+int p3v_set_tuning(const char* name /* host */, int value);
+int p3v_get_tuning(const char* name /* host */, int* value /* host */);
 
 /* ---- embedding gather: nn.Embedding, phi.py:568,577.  Negative ids (image
  * slots, phi.py:270) are clamped to 0; their rows are overwritten later. */
@@ -78,13 +85,18 @@ typedef struct {
   int lda, ldw, ldo;
   int epilogue;
   int patches_per_img; /* P3V_EPI_PATCH: P (=576) */
+  void* ws;            /* caller-owned device workspace (16-byte aligned) or null */
+  int64_t ws_bytes;    /* its size; see p3v_gemm_ws_bytes */
 } p3v_gemm_args_t;
 /* Operands are addressed with 32-bit byte offsets: M * lda * 2 and rows(W) * ldw * 2 must stay below 4 GiB
  * (P3V_ERR_UNSUPPORTED otherwise).  Shapes with 17 <= M <= 1024 and fewer than 256 output tiles (short prompts) run split
- * over K through a grow-only fp32 scratch the library owns, ONE PER DEVICE: calls on different streams of one device must
- * not overlap (the model launches on one stream per device); the call may allocate, so it is not for graph capture at
- * those shapes (P3V_GEMM_NO_SPLITK=1 turns the path off). */
+ * over K through fp32 partials in `ws`: p3v_gemm_ws_bytes(M, N, K, epilogue) is the size that path needs (0 = the shape
+ * does not use a workspace).  The library never allocates, frees or synchronises: with ws == null or too small the same
+ * shape runs on the one-pass kernel (slower for short prompts, same results up to fp32 summation order).  The workspace
+ * is only live between the two launches of one call, so calls on ONE stream may share it; concurrent streams need their
+ * own.  Graph-capturable. */
 int p3v_gemm(const p3v_gemm_args_t* args /* host */, void* stream);
+int64_t p3v_gemm_ws_bytes(int M, int N, int K, int epilogue);
 
 /* ---- skinny projection for decode: y[M,N] = x[M,K] * W[N,K]^T, M <= 16, weight-streaming
  * (M == 1: VALU dot products; 2 <= M <= 16: the weight rows go straight from HBM into MFMA fragments).

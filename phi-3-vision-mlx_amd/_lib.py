@@ -25,7 +25,7 @@ class Props(C.Structure):
 class GemmArgs(C.Structure):
     _fields_ = [("A", vp), ("W", vp), ("out", vp), ("bias", vp), ("resid", vp), ("pos", vp),
                 ("M", i32), ("N", i32), ("K", i32), ("lda", i32), ("ldw", i32), ("ldo", i32),
-                ("epilogue", i32), ("patches_per_img", i32)]
+                ("epilogue", i32), ("patches_per_img", i32), ("ws", vp), ("ws_bytes", i64)]
 
 
 class GemvArgs(C.Structure):
@@ -75,10 +75,13 @@ SIGNATURES = {
     "p3v_version": (i32, []),
     "p3v_device_props": (i32, [i32, C.POINTER(Props)]),
     "p3v_strerror": (C.c_char_p, [i32]),
+    "p3v_set_tuning": (i32, [C.c_char_p, i32]),
+    "p3v_get_tuning": (i32, [C.c_char_p, C.POINTER(i32)]),
     "p3v_embed_gather": (i32, [vp, vp, vp, i32, i32, i32, vp]),
     "p3v_rmsnorm": (i32, [vp, vp, vp, i32, i32, f32, vp]),
     "p3v_layernorm": (i32, [vp, vp, vp, vp, i32, i32, i32, f32, vp]),
     "p3v_gemm": (i32, [C.POINTER(GemmArgs), vp]),
+    "p3v_gemm_ws_bytes": (i64, [i32, i32, i32, i32]),
     "p3v_gemv": (i32, [C.POINTER(GemvArgs), vp]),
     "p3v_gemv_fp8": (i32, [C.POINTER(GemvF8Args), vp]),
     "p3v_dequant_fp8": (i32, [vp, vp, vp, i32, i32, vp]),

@@ -202,8 +202,8 @@ __global__ void __launch_bounds__(256) k_attn(AttnP p) {
 
 constexpr int CMB_G = 16;   // max 64-lane groups of the split-KV merge kernel
 static inline int combine_threads(int n_split) {              // measured at 41 splits: 8 groups beat 4 and 16
-  static const char* e = getenv("P3V_COMBINE_G");             // tuning knob (4 / 8 / 16)
-  if (e) return 64 * atoi(e);
+  const int g = p3v_tuning().combine_g;                       // tuning knob (4 / 8 / 16)
+  if (g > 0) return 64 * g;
   return 64 * (n_split <= 8 ? 4 : 8);
 }
 __global__ void k_attn_combine2(const float* __restrict__ ws, bf16_t* __restrict__ out, int L, int nh, int hd, int n_split);
@@ -640,7 +640,7 @@ static int launch_attn_prefill(const AttnP& p, hipStream_t s) {
     attr_set = true;
   }
   const dim3 grid(p3v_cdiv(p.L, 128), p.nh, p.B);
-  if (p.new_is_cache && p.past_t % 64 == 0 && !getenv("P3V_ATTN_NO_DMA")) {      // every caller in the model
+  if (p.new_is_cache && p.past_t % 64 == 0 && !p3v_tuning().attn_no_dma) {      // every caller in the model
     constexpr int LDS2 = 2 * (64 * HD * 2 + HD * 128);
     static bool attr2_set = false;
     if (!attr2_set) {
@@ -684,7 +684,7 @@ extern "C" int p3v_attention(const p3v_attn_args_t* a, void* stream) {
   if (p.split_mode && !a->ws) return P3V_ERR_ARG;
   if (!p.split_mode) p.n_split = 1;
   hipStream_t s = (hipStream_t)stream;
-  if (!p.split_mode && a->L > P3V_DECODE_MAX_L && !getenv("P3V_ATTN_OLD"))
+  if (!p.split_mode && a->L > P3V_DECODE_MAX_L && !p3v_tuning().attn_old)
     return a->hd == 96 ? launch_attn_prefill<96>(p, s) : launch_attn_prefill<64>(p, s);
   dim3 grid(p.split_mode ? p.n_split : p3v_cdiv(a->L, 64), a->n_heads, a->B);
   if (a->hd == 96) hipLaunchKernelGGL(k_attn<96>, grid, dim3(256), 0, s, p);
@@ -1850,7 +1850,7 @@ extern "C" int p3v_kv_quantize(const uint16_t* k, const uint16_t* vt, uint8_t* k
                                float* v_scale, int BH, int hd, int src_t, int dst_t, int t0, int n_tok, void* stream) {
   if (!k || !vt || !k8 || !v8t || !k_scale || !v_scale || BH <= 0 || hd > 96 || hd % 2 || n_tok < 0) return P3V_ERR_ARG;
   if (n_tok == 0) return P3V_OK;
-  static const bool old_only = getenv("P3V_KVQ_OLD") != nullptr;     // A/B knob
+  const bool old_only = p3v_tuning().kvq_old != 0;     // A/B knob
   const bool whole_tiles = (long)p3v_cdiv(n_tok, 64) * 64 + t0 <= src_t;   // the vector kernel reads whole 64-token tiles
   if (!old_only && hd == 96 && t0 % 8 == 0 && src_t % 8 == 0 && dst_t % 8 == 0 && whole_tiles && !(((uintptr_t)k | (uintptr_t)vt) & 15) &&
       !(((uintptr_t)k8 | (uintptr_t)v8t) & 7))
@@ -2635,7 +2635,7 @@ extern "C" int p3v_attention_decode_q8(const p3v_attn_decode_q8_args_t* a, void*
                   grp, (65536 + grp - 1) / grp, 0, (bf16_t*)a->out};
   hipStream_t s = (hipStream_t)stream;
   const dim3 grid(a->n_split, a->n_heads, a->B);
-  static const bool old_only = getenv("P3V_Q8_OLD") != nullptr;   // A/B knob
+  const bool old_only = p3v_tuning().q8_old != 0;   // A/B knob
   // one tile per workgroup and at most 16 of them (contexts up to 1k): the 4-wave kernel, which with `merge_in_launch` also
   // merges the splits inside the launch.  Beyond that the single-wave kernel + merge launch is as fast or faster
   // (measured at 42 tiles, config 5 decode: 1.543 ms/step against 1.560 with the 4-wave kernel + fused merge: its

@@ -21,7 +21,6 @@
 #include <stdlib.h>
 #include <string.h>
 
-#include <mutex>
 
 #include "p3v_common.h"
 
@@ -288,8 +287,7 @@ static int gemm128(const p3v_gemm_args_t* a, hipStream_t s);
 static int gemm_big_rows(const p3v_gemm_args_t* a) {
   const int n_big = a->epilogue == P3V_EPI_SILU_MUL ? 128 : 256, n_small = n_big / 2;
   if (a->M < 1024 || a->N % n_big || a->epilogue == P3V_EPI_PATCH) return 0;
-  if (const char* force = getenv("P3V_GEMM_BIG_ROWS"))                                              // tests: pin the split
-    if (strcmp(force, "auto")) return min(atoi(force) / 256 * 256, a->M);                             // ("auto" = the model below)
+  if (const int force = p3v_tuning().gemm_big_rows; force >= 0) return min(force / 256 * 256, a->M);   // tests: pin the split
   const int mt = p3v_cdiv(a->M, 256), nt_big = a->N / n_big, nt_small = p3v_cdiv(a->N, n_small);
   // a short K loop leaves the big tile's 128-KiB prologue and four-pass epilogue exposed (one workgroup per CU)
   const float big_round = a->K >= 2048 ? 1.0f : 1.0f + 0.25f * (2048 - a->K) / 1024.f;
@@ -312,8 +310,9 @@ static int gemm_big_rows(const p3v_gemm_args_t* a) {
 // ---- split-K for prompt-sized-but-small M (17 .. 256 rows: short chat prompts, the text group of a mixed batch).  One
 // 128-row tile leaves N / 128 = 24 .. 128 workgroups, each walking the WHOLE K loop with one tile in flight: an iteration is
 // one DMA round trip (~0.6 us), so down_proj (K = 8192) took 78 us for a 50 MB weight matrix and a 17..256-token prefill
-// 8.3-9.5 ms, flat in the length.  Here S slices of K run as gridDim.z (fp32 partials [S, M, N] in a library-owned scratch)
-// and a second launch adds them in slice order (deterministic) and applies the epilogue.
+// 8.3-9.5 ms, flat in the length.  Here S slices of K run as gridDim.z (fp32 partials [S, M, N] in the CALLER's workspace:
+// p3v_gemm_ws_bytes() sizes it, the library never allocates) and a second launch adds them in slice order (deterministic)
+// and applies the epilogue.  Without a workspace of that size the shape runs on the one-pass kernels.
 template <int EPI>
 __global__ void __launch_bounds__(256) k_splitk_reduce(const float* __restrict__ part, void* __restrict__ out, const void* __restrict__ resid,
                                                        int M, int N, int ldp, int ldo, int S) {
@@ -348,38 +347,37 @@ __global__ void __launch_bounds__(256) k_splitk_reduce(const float* __restrict__
   store8_bf16((bf16_t*)out + o, v);
 }
 
-static float* splitk_scratch(size_t bytes) {                   // grow-only, one per device (prefill is not graph-captured)
-  static float* buf[16] = {};
-  static size_t cap[16] = {};
-  static std::mutex mu;                                        // allocation only; USE of one device's scratch is single-stream by contract
-  std::lock_guard<std::mutex> lock(mu);
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
-  if (cap[dev] < bytes) {
-    if (buf[dev]) (void)hipFree(buf[dev]);
-    buf[dev] = nullptr, cap[dev] = 0;
-    if (hipMalloc((void**)&buf[dev], bytes) != hipSuccess) return nullptr;
-    cap[dev] = bytes;
-  }
-  return buf[dev];
+// number of K slices for a shape (1 = not a split-K shape)
+static int splitk_slices(int M, int N, int K, int epilogue) {
+  const P3vTuning& t = p3v_tuning();
+  const bool silu = epilogue == P3V_EPI_SILU_MUL;
+  if (t.gemm_no_splitk || M <= 16 || M > t.gemm_splitk_max_m /* beyond, every projection has >= 256 tiles anyway */ ||
+      N % 128 || K % 512)
+    return 1;
+  if (epilogue != P3V_EPI_NONE && epilogue != P3V_EPI_RESID_BF16 && !silu) return 1;
+  const int w_rows = silu ? 2 * N : N;                        // SiLU: [gate; up] taken as 2N plain output columns
+  const int tiles = p3v_cdiv(M, BM) * (w_rows / BN);
+  int S = 1;
+  while (S < t.gemm_splitk_max_s && tiles * S < t.gemm_splitk_wgs && (K / (2 * S)) % BK == 0 && K / (2 * S) >= 2 * BK) S *= 2;
+  return S;
 }
 
-// returns P3V_ERR_UNSUPPORTED when the shape is not one for split-K
+extern "C" int64_t p3v_gemm_ws_bytes(int M, int N, int K, int epilogue) {
+  if (M <= 0 || N <= 0 || K <= 0) return 0;
+  const int S = splitk_slices(M, N, K, epilogue);
+  if (S == 1) return 0;
+  return (int64_t)S * M * (epilogue == P3V_EPI_SILU_MUL ? 2 * N : N) * 4;
+}
+
+// returns P3V_ERR_UNSUPPORTED when the shape is not one for split-K (or the caller gave no workspace for it)
 static int gemm_splitk(const p3v_gemm_args_t* a, hipStream_t s) {
-  static const bool off = getenv("P3V_GEMM_NO_SPLITK") != nullptr;
   const bool silu = a->epilogue == P3V_EPI_SILU_MUL;
-  static const int max_m = getenv("P3V_GEMM_SPLITK_MAX_M") ? atoi(getenv("P3V_GEMM_SPLITK_MAX_M")) : 1024;   // beyond, every projection has >= 256 tiles anyway
-  if (off || a->M <= 16 || a->M > max_m || a->N % 128 || a->K % 512) return P3V_ERR_UNSUPPORTED;
-  if (a->epilogue != P3V_EPI_NONE && a->epilogue != P3V_EPI_RESID_BF16 && !silu) return P3V_ERR_UNSUPPORTED;
-  const int w_rows = silu ? 2 * a->N : a->N;                  // SiLU: [gate; up] taken as 2N plain output columns
-  const int tiles = p3v_cdiv(a->M, BM) * (w_rows / BN);
-  static const int max_s = getenv("P3V_GEMM_SPLITK_MAX_S") ? atoi(getenv("P3V_GEMM_SPLITK_MAX_S")) : 8;
-  static const int want = getenv("P3V_GEMM_SPLITK_WGS") ? atoi(getenv("P3V_GEMM_SPLITK_WGS")) : 256;
-  int S = 1;
-  while (S < max_s && tiles * S < want && (a->K / (2 * S)) % BK == 0 && a->K / (2 * S) >= 2 * BK) S *= 2;
+  const int S = splitk_slices(a->M, a->N, a->K, a->epilogue);
   if (S == 1) return P3V_ERR_UNSUPPORTED;
-  float* part = splitk_scratch((size_t)S * a->M * w_rows * 4);
-  if (!part) return P3V_ERR_HIP;
+  const int w_rows = silu ? 2 * a->N : a->N;
+  if (!a->ws || a->ws_bytes < (int64_t)S * a->M * w_rows * 4) return P3V_ERR_UNSUPPORTED;
+  if ((uintptr_t)a->ws & 15) return P3V_ERR_ARG;
+  float* part = (float*)a->ws;
   GemmP p = {a->A, a->W, part, nullptr, nullptr, nullptr, a->M, w_rows, a->K, a->lda, a->ldw, w_rows, 0, a->K / S};
   const int rc = launch_gemm<P3V_EPI_F32>(p, s);
   if (rc != P3V_OK) return rc;
@@ -412,7 +410,7 @@ extern "C" int p3v_gemm(const p3v_gemm_args_t* a, void* stream) {
     const int rc = gemm_splitk(a, s);
     if (rc != P3V_ERR_UNSUPPORTED) return rc;
   }
-  static const bool big_tiles = !getenv("P3V_GEMM_128");
+  const bool big_tiles = !p3v_tuning().gemm_128;
   const int rows_big = big_tiles ? gemm_big_rows(a) : 0;
   if (rows_big > 0) {
     p3v_gemm_args_t top = *a;

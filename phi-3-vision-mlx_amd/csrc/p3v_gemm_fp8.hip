@@ -287,7 +287,7 @@ static int launch_gemm_f8(const GemmF8P& p, hipStream_t s) {
   } else {
     const long mt = p3v_cdiv(p.M, TM), wide = mt * p3v_cdiv(p.N, 256), narrow = mt * p3v_cdiv(p.N, 128);
     bool use_narrow = p.N % 256 != 0 || wide <= 160 || (wide % 256 != 0 && wide % 256 <= 64 && narrow % 256 > 128);
-    if (const char* f = getenv("P3V_GEMM_F8_NARROW")) use_narrow = p.N % 256 != 0 || atoi(f) != 0;
+    if (const int f = p3v_tuning().gemm_f8_narrow; f >= 0) use_narrow = p.N % 256 != 0 || f != 0;
     return use_narrow ? launch_gemm_f8_v<EPI, 2>(p, s) : launch_gemm_f8_v<EPI, 4>(p, s);
   }
 }

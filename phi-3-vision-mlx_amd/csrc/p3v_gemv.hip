@@ -146,11 +146,6 @@ __global__ void __launch_bounds__(256) k_gemv3(GemvP p, int units_per_wave) {
   gemv3_body<MT, NST, CH>(p, units_per_wave, blockIdx.x, smem, red);
 }
 
-static int gemv_env(const char* name, int dflt) {
-  const char* e = getenv(name);
-  return e ? atoi(e) : dflt;
-}
-
 template <int MT, int NST, int CH>
 static int launch_gemv3(const GemvP& p, hipStream_t s) {
   static int n_cu = 0;
@@ -160,7 +155,7 @@ static int launch_gemv3(const GemvP& p, hipStream_t s) {
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess) return P3V_ERR_HIP;
     n_cu = pr.multiProcessorCount;
   }
-  static const int wpc = gemv_env("P3V_GEMV_WPC", 8);    // waves per CU
+  const int wpc = p3v_tuning().gemv_wpc;    // waves per CU
   int upw = p3v_cdiv(p.units, n_cu * wpc);               // row pairs per wave
   if (upw < 1) upw = 1;
   const int waves = p3v_cdiv(p.units, upw);
@@ -503,7 +498,7 @@ static int launch_gemv_mfma8(const GemvP& p, hipStream_t s) {
   }
   // <= 256 workgroups (one per CU: 192-256 VGPRs per wave), each walking `per` strided row sets
   // (576 sets -> 192 x 3, 1024 -> 256 x 4, 2004 -> 251 x 8, 192 -> 192 x 1)
-  static const int max_wg = gemv_env("P3V_GEMV8_WGS", 256);
+  const int max_wg = p3v_tuning().gemv8_wgs;
   const int n_sets = p3v_cdiv(p.N, SILU ? 8 : 16), per = p3v_cdiv(n_sets, max_wg), grid = p3v_cdiv(n_sets, per);
   hipLaunchKernelGGL((k_gemv_mfma8<SILU, NW, NST>), dim3(grid), dim3(NW * 64), lds, s, p, n_sets);
   P3V_CHECK_LAUNCH();
@@ -530,7 +525,7 @@ extern "C" int p3v_gemv(const p3v_gemv_args_t* a, void* stream) {
   GemvP p = {a->x, a->W, a->out, a->resid, a->norm_w, a->norm_eps, a->M, a->N, a->K, a->epilogue,
              a->epilogue == P3V_EPI_SILU_MUL ? a->N : (a->N + 1) / 2};
   hipStream_t s = (hipStream_t)stream;
-  static const int variant = gemv_env("P3V_GEMV_VARIANT", 3);       // 1: generic kernel only; 3: streaming kernel where it applies
+  const int variant = p3v_tuning().gemv_variant;       // 1: generic kernel only; 3: streaming kernel where it applies
   if (variant == 3 && mt == 1 && a->N % 2 == 0 && (a->K == 3072 || a->K == 8192)) {
     if (a->K == 3072) return launch_gemv3<1, 1, 6>(p, s);
     return launch_gemv3<1, 4, 4>(p, s);                  // 8192 = 4 stages x 4 chunks: keeps 2 waves/SIMD resident
@@ -539,17 +534,17 @@ extern "C" int p3v_gemv(const p3v_gemv_args_t* a, void* stream) {
   // 16-byte chunk): measured 2.19 vs 2.94 ms/step at B = 2 and 2.64 vs 3.26 at B = 4 against k_gemv_mfma; from M = 5 on the
   // matrix cores take over (at MT = 8 the VALU / LDS work per weight byte catches up: 4.72 ms/step at B = 8 against 4.08
   // with k_gemv_mfma and 3.27 with k_gemv_mfma8).
-  static const int rows_variant = gemv_env("P3V_GEMV_ROWS", 1);
+  const int rows_variant = p3v_tuning().gemv_rows;
   // smallest M the 8-row MFMA kernel takes: 2 since it became persistent with the RMSNorm scale in the epilogue (decode step
   // at ctx 2531, B = 2 / 3 / 4: 2.08 / 2.43 / 2.66 ms with the MT-row streaming kernel, 1.99 / 2.16 / 2.35 with this one);
   // P3V_GEMV8_MIN=5 restores the round-1 split
-  static const int rows8_min = gemv_env("P3V_GEMV8_MIN", 2);
+  const int rows8_min = p3v_tuning().gemv8_min;
   if (rows_variant && variant == 3 && a->M >= 2 && a->M <= 4 && a->M < rows8_min && a->N % 2 == 0 && a->epilogue != P3V_EPI_F32 &&
       (a->K == 3072 || a->K == 8192)) {
     if (a->K == 3072) return mt == 2 ? launch_gemv3<2, 1, 6>(p, s) : launch_gemv3<4, 1, 6>(p, s);
     return mt == 2 ? launch_gemv3<2, 4, 4>(p, s) : launch_gemv3<4, 4, 4>(p, s);
   }
-  static const int rows8 = gemv_env("P3V_GEMV_MFMA8", 1);
+  const int rows8 = p3v_tuning().gemv_mfma8;
   if (rows8 && a->M >= rows8_min && a->M <= 8) {
     const bool silu = a->epilogue == P3V_EPI_SILU_MUL;
     switch (a->K) {                                      // K = NW waves x NST stages x 256
@@ -561,7 +556,7 @@ extern "C" int p3v_gemv(const p3v_gemv_args_t* a, void* stream) {
       default: break;
     }
   }
-  if (a->M >= 2 && a->K % (4 * 32 * GM_G) == 0 && !getenv("P3V_GEMV_NO_MFMA")) return launch_gemv_mfma(p, s);
+  if (a->M >= 2 && a->K % (4 * 32 * GM_G) == 0 && !p3v_tuning().gemv_no_mfma) return launch_gemv_mfma(p, s);
   if (a->M > 8 || (size_t)mt * a->K * 2 > 160 * 1024 - 256) return P3V_ERR_UNSUPPORTED;
   switch (mt) {
     case 1: return launch_gemv<1>(p, s);

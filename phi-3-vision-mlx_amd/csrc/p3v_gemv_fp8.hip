@@ -447,7 +447,7 @@ static int launch_gemv3_f8(const GemvF8P& p, hipStream_t s) {
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess) return P3V_ERR_HIP;
     n_cu = pr.multiProcessorCount;
   }
-  static const int wpc = getenv("P3V_GEMV_F8_WPC") ? atoi(getenv("P3V_GEMV_F8_WPC")) : 16;   // waves per CU (a stage is half the bytes of the bf16 kernel's: twice the waves keep as many in flight; 8: 1.321, 16: 1.301, 24: 1.333 ms/step)
+  const int wpc = p3v_tuning().gemv_f8_wpc;   // waves per CU (a stage is half the bytes of the bf16 kernel's: twice the waves keep as many in flight; 8: 1.321, 16: 1.301, 24: 1.333 ms/step)
   int upw = p3v_cdiv(p.units, n_cu * wpc);
   if (upw < 1) upw = 1;
   const int waves = p3v_cdiv(p.units, upw);
@@ -467,7 +467,7 @@ extern "C" int p3v_gemv_fp8(const p3v_gemv_fp8_args_t* a, void* stream) {
                a->epilogue == P3V_EPI_SILU_MUL ? a->N : a->N / 2};
   hipStream_t s = (hipStream_t)stream;
   if (a->M == 1) return a->K == 3072 ? launch_gemv3_f8<1, 3>(p, s) : launch_gemv3_f8<2, 4>(p, s);
-  if (a->M >= 5 && a->M <= 8 && !getenv("P3V_GEMV_NO_MFMA8")) {
+  if (a->M >= 5 && a->M <= 8 && !p3v_tuning().gemv_no_mfma8) {
     const bool silu = a->epilogue == P3V_EPI_SILU_MUL;
     if (a->K == 3072) return silu ? launch_gemv_mfma8_f8<true, 4, 6>(p, s) : launch_gemv_mfma8_f8<false, 4, 6>(p, s);
     return silu ? launch_gemv_mfma8_f8<true, 8, 8>(p, s) : launch_gemv_mfma8_f8<false, 8, 8>(p, s);

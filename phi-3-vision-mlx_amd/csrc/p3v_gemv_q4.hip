@@ -214,7 +214,7 @@ static int launch_gemv3_q4(const GemvQ4P& p, hipStream_t s) {
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess) return P3V_ERR_HIP;
     n_cu = pr.multiProcessorCount;
   }
-  static const int wpc = getenv("P3V_GEMV_Q4_WPC") ? atoi(getenv("P3V_GEMV_Q4_WPC")) : 8;   // waves per CU
+  const int wpc = p3v_tuning().gemv_q4_wpc;   // waves per CU
   int upw = p3v_cdiv(p.units, n_cu * wpc);
   if (upw < 1) upw = 1;
   const int waves = p3v_cdiv(p.units, upw);

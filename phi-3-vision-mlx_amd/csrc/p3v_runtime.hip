@@ -2,7 +2,11 @@
 // capture/replay of a launch sequence (the decode step is replayed as one
 // graph: ~170 short weight-streaming kernels per token would otherwise be
 // host-launch-bound), and HIP-event timing on the launch stream.
+#include <ctype.h>
+#include <stdlib.h>
 #include <string.h>
+
+#include <mutex>
 
 #include "p3v_common.h"
 
@@ -17,6 +21,58 @@ extern "C" const char* p3v_strerror(int code) {
     case P3V_ERR_HIP: return "HIP runtime call failed";
     default: return "unknown error";
   }
+}
+
+// ---- launch-policy knobs (p3v_common.h): one table, read from the environment once
+namespace {
+struct Knob { const char* name; int P3vTuning::*field; int dflt; };
+const Knob kKnobs[] = {
+    {"gemm_big_rows", &P3vTuning::gemm_big_rows, -1},       {"gemm_no_splitk", &P3vTuning::gemm_no_splitk, 0},
+    {"gemm_splitk_max_m", &P3vTuning::gemm_splitk_max_m, 1024}, {"gemm_splitk_max_s", &P3vTuning::gemm_splitk_max_s, 8},
+    {"gemm_splitk_wgs", &P3vTuning::gemm_splitk_wgs, 256},  {"gemm_128", &P3vTuning::gemm_128, 0},
+    {"gemm_f8_narrow", &P3vTuning::gemm_f8_narrow, -1},     {"attn_no_dma", &P3vTuning::attn_no_dma, 0},
+    {"attn_old", &P3vTuning::attn_old, 0},                  {"combine_g", &P3vTuning::combine_g, -1},
+    {"kvq_old", &P3vTuning::kvq_old, 0},                    {"q8_old", &P3vTuning::q8_old, 0},
+    {"gemv_no_mfma", &P3vTuning::gemv_no_mfma, 0},          {"gemv_no_mfma8", &P3vTuning::gemv_no_mfma8, 0},
+    {"gemv_wpc", &P3vTuning::gemv_wpc, 8},                  {"gemv8_wgs", &P3vTuning::gemv8_wgs, 256},
+    {"gemv_variant", &P3vTuning::gemv_variant, 3},          {"gemv_rows", &P3vTuning::gemv_rows, 1},
+    {"gemv8_min", &P3vTuning::gemv8_min, 2},                {"gemv_mfma8", &P3vTuning::gemv_mfma8, 1},
+    {"gemv_f8_wpc", &P3vTuning::gemv_f8_wpc, 16},           {"gemv_q4_wpc", &P3vTuning::gemv_q4_wpc, 8},
+};
+P3vTuning g_tuning;
+std::once_flag g_tuning_once;
+void tuning_init() {
+  for (const Knob& k : kKnobs) {
+    char env[64] = "P3V_";
+    size_t n = 4;
+    for (const char* c = k.name; *c && n + 1 < sizeof(env); ++c) env[n++] = (char)toupper((unsigned char)*c);
+    env[n] = 0;
+    const char* e = getenv(env);
+    // presence-only switches (P3V_GEMM_128=, P3V_ATTN_OLD=...) historically counted as "on" whatever their value
+    g_tuning.*(k.field) = !e ? k.dflt : !strcmp(e, "auto") ? -1 : (*e == 0 ? 1 : atoi(e));
+  }
+}
+}  // namespace
+
+const P3vTuning& p3v_tuning() {
+  std::call_once(g_tuning_once, tuning_init);
+  return g_tuning;
+}
+
+extern "C" int p3v_set_tuning(const char* name, int value) {
+  if (!name) return P3V_ERR_ARG;
+  std::call_once(g_tuning_once, tuning_init);
+  for (const Knob& k : kKnobs)
+    if (!strcmp(k.name, name)) { g_tuning.*(k.field) = value; return P3V_OK; }
+  return P3V_ERR_ARG;
+}
+
+extern "C" int p3v_get_tuning(const char* name, int* value) {
+  if (!name || !value) return P3V_ERR_ARG;
+  std::call_once(g_tuning_once, tuning_init);
+  for (const Knob& k : kKnobs)
+    if (!strcmp(k.name, name)) { *value = g_tuning.*(k.field); return P3V_OK; }
+  return P3V_ERR_ARG;
 }
 
 extern "C" int p3v_device_props(int device, p3v_props_t* out) {

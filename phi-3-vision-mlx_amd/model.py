@@ -120,6 +120,7 @@ class Phi3VModel:
         if self.hd != 96:
             raise ValueError(f"decoder head_dim must be 96 (got {self.hd})")
         self._state = None
+        self.hidden_hook = None                      # fn(layer, x [B*L, H], B, L) after every decoder layer (diagnostics)
         self.w8 = {}
         self.adapters = {}                           # weight key -> (lora_a, lora_b, scale), see set_adapters
         self._lora_tmp = {}                          # decode-sized (M <= 16) adapter scratch: captured graphs point at it
@@ -341,12 +342,10 @@ class Phi3VModel:
     def new_slot_state(self, slots, window):
         """A cache of `slots` batch rows and `window` columns that is not tied to one prompt batch (engine.py): every row
         has its OWN left padding and position table, so a request can be prefilled into a free row while the other rows
-        are mid-generation.  All rows start empty (pad_len = window: every key masked).  window <= the original context
-        (4096): the short RoPE factors, which is what each request alone would pick (phi.py:492)."""
-        if window > self.cfg.original_max_position_embeddings:
-            raise ValueError("the slot window must stay inside the short-RoPE regime")
-        if getattr(self.cfg, "use_quantized_cache", False):
-            raise NotImplementedError("slot states keep a bf16 KV cache (quantize_cache=True is not supported by the engine)")
+        are mid-generation.  All rows start empty (pad_len = window: every key masked).  The window fixes the RoPE regime
+        of every row (phi.py:492: one choice per call from prompt + max_tokens): window <= 4096 -> short factors, beyond
+        -> long factors; the engine admits only requests that would pick the same factors alone.  With
+        `quantize_cache=True` the rows keep the int8 KV cache (BASELINE config 5)."""
         st = self._new_state(slots, 0, window, None, None)
         st.pad_len = torch.full((slots,), window, dtype=I32, device=self.device)
         st.slots = True
@@ -375,7 +374,8 @@ class Phi3VModel:
             raise ValueError(f"prompt of {S} tokens does not fit left of column {st.offset}")
         pads = torch.as_tensor(st.offset - lens, dtype=torch.int32)
         half = self.hd // 2
-        inv_freq = 1.0 / (torch.tensor(cfg.rope_scaling["short_factor"], dtype=F32)
+        su = cfg.rope_scaling["long_factor" if st.T > cfg.original_max_position_embeddings else "short_factor"]   # as _new_state
+        inv_freq = 1.0 / (torch.tensor(su, dtype=F32)
                           * (torch.tensor(float(cfg.rope_theta), dtype=F32) ** (torch.arange(0, self.hd, 2, dtype=F32) / self.hd)))
         rows = slice(row, row + n)
         uniq = np.unique(lens)
@@ -386,8 +386,14 @@ class Phi3VModel:
                 st.cos[row + i].copy_(cos.view(st.T, half)), st.sin[row + i].copy_(sin.view(st.T, half))
         st.pad_len[rows].copy_(pads.to(self.device))
         view = CacheState.__new__(CacheState)                   # these rows as an n-row cache at offset `win`
-        view.__dict__.update(B=n, S=S, max_tokens=st.max_tokens, T=st.T, Tp=st.Tp, quantized=False, offset=win, graphs={}, epoch=self.epoch,
-                             k=st.k[:, rows], v=st.v[:, rows], cos=st.cos[rows], sin=st.sin[rows], pad_len=st.pad_len[rows])
+        view.__dict__.update(B=n, S=S, max_tokens=st.max_tokens, T=st.T, Tp=st.Tp, quantized=st.quantized, offset=win, graphs={},
+                             epoch=self.epoch, cos=st.cos[rows], sin=st.sin[rows], pad_len=st.pad_len[rows],
+                             fresh_rows=True)    # columns left of `win` hold nothing these rows may see (pad_len >= win)
+        if st.quantized:
+            view.__dict__.update(k8=st.k8[:, rows], v8=st.v8[:, rows], ks=st.ks[:, rows], vs=st.vs[:, rows],
+                                 k_tmp=st.k_tmp[rows], v_tmp=st.v_tmp[rows])
+        else:
+            view.__dict__.update(k=st.k[:, rows], v=st.v[:, rows])
         kw = {k: v for k, v in inputs.items() if k in ("pixel_values", "image_sizes", "positions")}
         logits, _ = self(input_ids=ids, cache=[LayerCache(view, i) for i in range(cfg.num_hidden_layers)], full_logits=False, **kw)
         assert view.offset == st.offset
@@ -483,7 +489,7 @@ class Phi3VModel:
                     ops.attention_decode_q8(qkv, rc, rs, rb, st.k8[i], st.v8[i], st.ks[i], st.vs[i], o, B, L, nh, nkv, hd, scale,
                                             past, st.Tp, ws, n_split, pad_len=st.pad_len, d_past=d_past, merge_in_launch=bufs.get("attn_merge", False))
                 else:                                           # prefill: exact attention, quantised copy stored
-                    if past > 0:                                # long cached call (constrain with > 16 tokens): attend on a
+                    if past > 0 and not getattr(st, "fresh_rows", False):   # long cached call (constrain with > 16 tokens): attend on a
                         ops.kv_dequantize(st.k8[i], st.v8[i], st.ks[i], st.vs[i], st.k_tmp, st.v_tmp, past)   # dequantised copy
                     ops.rope_kv_append(qkv, st.cos, st.sin, q, st.k_tmp, st.v_tmp, B, L, nh, nkv, hd, past, st.Tp, True, st.T, 1)
                     ops.attention(q, o, B, L, nh, nkv, hd, scale, True, past=past, k_past=st.k_tmp, v_past=st.v_tmp,
@@ -512,6 +518,8 @@ class Phi3VModel:
             self._proj(o, p + "self_attn.o_proj.weight", EPI_RESID_BF16, resid=x, out=x)
             self._proj(x, p + "mlp.gate_up_proj.weight", EPI_SILU_MUL, norm_w=w[p + "post_attention_layernorm.weight"], out=a, h=h)
             self._proj(a, p + "mlp.down_proj.weight", EPI_RESID_BF16, resid=x, out=x)
+            if self.hidden_hook is not None:                     # diagnostics only (tools/precision_decomp.py); never set
+                self.hidden_hook(i, x, B, x.shape[0] // B)       # while a decode graph is captured
         return x
 
     # ------------------------------------------------------------------ graph-replayed greedy decode step

@@ -61,6 +61,30 @@ def layernorm(x, w, b, eps, out_f32=False, out=None):
     return out
 
 
+def set_tuning(name, value):
+    """Pin a launch-policy knob of the library (include/p3v.h: p3v_set_tuning); returns the previous value."""
+    old = C.c_int(0)
+    L.check(L.lib().p3v_get_tuning(name.encode(), C.byref(old)), f"get_tuning({name})")
+    L.check(L.lib().p3v_set_tuning(name.encode(), int(value)), f"set_tuning({name})")
+    return old.value
+
+
+_gemm_ws = {}     # (device index, stream handle) -> grow-only byte buffer for p3v_gemm's split-K partials
+
+
+def _gemm_workspace(device, nbytes):
+    """The library never allocates (include/p3v.h): the caller owns the split-K workspace.  One grow-only torch buffer per
+    (device, stream): it is live only between the two launches of one p3v_gemm call, so launches on one stream share it."""
+    key = (device.index, _stream())
+    buf = _gemm_ws.get(key)
+    if buf is None or buf.numel() < nbytes:
+        # the old buffer may still be read by launches already queued on this stream: torch's caching allocator keeps
+        # freed blocks stream-ordered, so dropping the reference is safe
+        buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        _gemm_ws[key] = buf
+    return buf
+
+
 def gemm(a, w, epilogue=EPI_NONE, bias=None, resid=None, out=None, n_out=None, pos=None, patches_per_img=0, ldo=None):
     """nn.Linear / patch conv: out[M,N] = a[M,K] @ w[N,K]^T (+ epilogue), bf16 MFMA."""
     _chk(a, BF16, "a"), _chk(w, BF16, "w")
@@ -71,8 +95,10 @@ def gemm(a, w, epilogue=EPI_NONE, bias=None, resid=None, out=None, n_out=None, p
     f32_out = epilogue in (EPI_BIAS_RESID_F32, EPI_PATCH, EPI_F32)
     if out is None:
         out = torch.empty((M, N), dtype=F32 if f32_out else BF16, device=a.device)
+    ws_bytes = L.lib().p3v_gemm_ws_bytes(M, N, K, epilogue)
+    ws = _gemm_workspace(a.device, ws_bytes) if ws_bytes else None
     args = L.GemmArgs(_p(a), _p(w), _p(out), _p(bias), _p(resid), _p(pos), M, N, K, a.stride(0), w.stride(0),
-                      ldo if ldo is not None else N, epilogue, patches_per_img)
+                      ldo if ldo is not None else N, epilogue, patches_per_img, _p(ws), ws.numel() if ws is not None else 0)
     L.check(L.lib().p3v_gemm(C.byref(args), _stream()), "gemm")
     return out
 

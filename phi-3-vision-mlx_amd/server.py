@@ -2,7 +2,11 @@
 
     POST /v1/completions   {"prompt": str | [str, ...], "max_tokens": int (default 512)}
       -> 200 {"model": "phi-3-vision", "responses": [str, ...]}            anything else -> 404
-    (extension: "images": [null | path | URL | "data:image/...;base64,..." per prompt] -- the reference's endpoint is text-only)
+    (extension: "images": [null | "data:image/...;base64,..." per prompt] -- the reference's endpoint is text-only.
+     Only INLINE images by default: a path or URL in a request body would let any client make the server open local files
+     or fetch arbitrary URLs.  `ImagePolicy(allow_dir=..., allow_hosts=...)` / `--image-dir` / `--image-host` opt in to an
+     allow-listed directory / host list.  Images are always fetched AND decoded in the HTTP handler thread, with a timeout,
+     a byte cap and a pixel cap -- never on the engine thread -- and errors never echo the path.)
 
 with one difference in the plumbing: requests do not call the model from the HTTP thread.  They go into a queue that a
 single engine thread drains (the model object holds one in-flight sequence group).  By default every
@@ -36,14 +40,76 @@ class _Job:
         self.done, self.result, self.error = threading.Event(), None, None
 
 
-def decode_image(spec):
-    """null | path | URL | data URI -> what `generate(images=...)` takes (a PIL image for data URIs)."""
-    if spec is None or not isinstance(spec, str) or not spec.startswith("data:"):
-        return spec
-    import base64
+class ImagePolicy:
+    """What the `images` field of a request may name.  Default: inline `data:` URIs only."""
+
+    def __init__(self, allow_dir=None, allow_hosts=(), max_bytes=16 << 20, max_pixels=64 << 20, timeout_s=5.0):
+        import os
+        self.allow_dir = os.path.realpath(allow_dir) if allow_dir else None
+        self.allow_hosts = frozenset(h.lower() for h in allow_hosts)
+        self.max_bytes, self.max_pixels, self.timeout_s = int(max_bytes), int(max_pixels), float(timeout_s)
+
+
+def _open_image(raw, policy):
+    """bytes -> a fully decoded RGB PIL image (decoded HERE, in the caller's thread), under the policy's caps."""
     from io import BytesIO
     from PIL import Image
-    return Image.open(BytesIO(base64.b64decode(spec.split(",", 1)[1])))
+    if len(raw) > policy.max_bytes:
+        raise ValueError("image larger than the server's byte limit")
+    try:
+        im = Image.open(BytesIO(raw))
+        if im.width * im.height > policy.max_pixels:
+            raise ValueError("image larger than the server's pixel limit")
+        im.load()
+        return im.convert("RGB")
+    except ValueError:
+        raise
+    except Exception:                           # noqa: BLE001 -- PIL raises many types; none of them is the client's business
+        raise ValueError("image could not be decoded") from None
+
+
+def decode_image(spec, policy=None):
+    """One entry of a request's `images` list -> None or a decoded PIL image.  ValueError (-> HTTP 400) for anything the
+    policy does not allow; messages never contain the path / URL (no file-existence oracle)."""
+    policy = policy or ImagePolicy()
+    if spec is None:
+        return None
+    if not isinstance(spec, str):
+        raise ValueError("images entries must be null or strings")
+    if spec.startswith("data:"):
+        import base64
+        import binascii
+        head, _, payload = spec.partition(",")
+        if not head.endswith(";base64") or len(payload) > policy.max_bytes * 4 // 3 + 4:
+            raise ValueError("images: expected a base64 data URI within the size limit")
+        try:
+            raw = base64.b64decode(payload, validate=True)
+        except (binascii.Error, ValueError):
+            raise ValueError("images: invalid base64 payload") from None
+        return _open_image(raw, policy)
+    if spec.startswith(("http://", "https://")):
+        from urllib.parse import urlsplit
+        host = (urlsplit(spec).hostname or "").lower()
+        if host not in policy.allow_hosts:
+            raise ValueError("images: URLs are not accepted by this server (inline data: URIs only)")
+        import requests
+        try:
+            with requests.get(spec, stream=True, timeout=policy.timeout_s, allow_redirects=False) as resp:
+                resp.raise_for_status()
+                raw = resp.raw.read(policy.max_bytes + 1, decode_content=True)
+        except Exception:                       # noqa: BLE001
+            raise ValueError("images: fetch failed") from None
+        return _open_image(raw, policy)
+    if policy.allow_dir is None:
+        raise ValueError("images: file paths are not accepted by this server (inline data: URIs only)")
+    import os
+    path = os.path.realpath(os.path.join(policy.allow_dir, spec))
+    if os.path.commonpath([path, policy.allow_dir]) != policy.allow_dir or not os.path.isfile(path):
+        raise ValueError("images: not an image of the served directory")
+    if os.path.getsize(path) > policy.max_bytes:
+        raise ValueError("image larger than the server's byte limit")
+    with open(path, "rb") as f:
+        return _open_image(f.read(), policy)
 
 
 class EngineQueue:
@@ -133,7 +199,9 @@ class EngineQueue:
                 j.done.set()
 
 
-def make_handler(engine):
+def make_handler(engine, image_policy=None):
+    image_policy = image_policy or ImagePolicy()
+
     class CompletionHandler(BaseHTTPRequestHandler):
         def _send(self, code, payload):
             body = json.dumps(payload).encode("utf-8")
@@ -159,7 +227,7 @@ def make_handler(engine):
                     images = [images] if isinstance(images, str) else list(images)
                     if len(images) != len(prompts):
                         raise ValueError("images must list one entry (or null) per prompt")
-                    images = [decode_image(i) for i in images]
+                    images = [decode_image(i, image_policy) for i in images]      # fetched + decoded in THIS thread
                     images = None if all(i is None for i in images) else images
             except (ValueError, TypeError, AttributeError, OSError) as e:
                 self._send(400, {"error": str(e)})
@@ -177,10 +245,11 @@ def make_handler(engine):
     return CompletionHandler
 
 
-def serve(generate_fn, port=8000, host="", max_batch=64, **engine_kwargs):
-    """-> (httpd, engine); call httpd.serve_forever() (or run it in a thread) and engine.close() at the end."""
+def serve(generate_fn, port=8000, host="127.0.0.1", max_batch=64, image_policy=None, **engine_kwargs):
+    """-> (httpd, engine); call httpd.serve_forever() (or run it in a thread) and engine.close() at the end.
+    Binds the loopback interface unless told otherwise (`host=""` = all interfaces, as the reference's server.py:31)."""
     engine = EngineQueue(generate_fn, max_batch=max_batch, **engine_kwargs)
-    httpd = ThreadingHTTPServer((host, port), make_handler(engine))
+    httpd = ThreadingHTTPServer((host, port), make_handler(engine, image_policy))
     return httpd, engine
 
 
@@ -201,18 +270,18 @@ class ContinuousBackend:
         self.thread.join(timeout=5)
 
 
-def serve_continuous(engine, port=8000, host="", **kw):
+def serve_continuous(engine, port=8000, host="127.0.0.1", image_policy=None, **kw):
     backend = ContinuousBackend(engine, **kw)
-    return ThreadingHTTPServer((host, port), make_handler(backend)), backend
+    return ThreadingHTTPServer((host, port), make_handler(backend, image_policy)), backend
 
 
-def run(port=8000, synthetic=False, blind_model=False, merge=False, continuous=False):
+def run(port=8000, synthetic=False, blind_model=False, merge=False, continuous=False, host="127.0.0.1", image_policy=None):
     from .api import _apply_chat_template, generate, load
     preload = load(blind_model=blind_model, synthetic=synthetic or None)
     processor = preload[1]
     if continuous:
         from .engine import ContinuousEngine
-        httpd, engine = serve_continuous(ContinuousEngine(*preload), port=port)
+        httpd, engine = serve_continuous(ContinuousEngine(*preload), port=port, host=host, image_policy=image_policy)
         print(f"Starting server on port {port} (continuous batching)")
         try:
             httpd.serve_forever()
@@ -221,15 +290,20 @@ def run(port=8000, synthetic=False, blind_model=False, merge=False, continuous=F
         return
 
     def generate_fn(prompts, max_tokens, images=None):
-        if images is not None:                               # mixed image + text requests: one left-padded batch (dist.py)
+        import torch.distributed as dist
+        if images is not None or (dist.is_available() and dist.is_initialized() and len(prompts) > 1):
+            # mixed image + text requests -- and text-only batches whenever a process group exists -- go through the
+            # batch-sharded path (dist.py: one left-padded batch per rank; world size 1 = this GPU alone)
             from .dist import generate_sharded
-            return generate_sharded(prompts, images, preload=preload, max_tokens=max_tokens)
+            return generate_sharded(prompts, images if images is not None else [None] * len(prompts), preload=preload,
+                                    max_tokens=max_tokens)
         return generate(prompts if len(prompts) > 1 else prompts[0], preload=preload, max_tokens=max_tokens, verbose=False)
 
     def length_fn(prompt):
         return len(processor.tokenizer(_apply_chat_template(prompt, None, False)[0]).input_ids)
 
-    httpd, engine = serve(generate_fn, port=port, merge=merge, length_fn=length_fn, device=preload[0].device)
+    httpd, engine = serve(generate_fn, port=port, host=host, merge=merge, length_fn=length_fn, device=preload[0].device,
+                          image_policy=image_policy)
     print(f"Starting server on port {port}")
     try:
         httpd.serve_forever()
@@ -245,5 +319,8 @@ if __name__ == "__main__":
     ap.add_argument("--blind", action="store_true", help="text-only Phi-3-mini-128K")
     ap.add_argument("--merge", action="store_true", help="fold concurrent same-budget requests into one batched generate (opt-in)")
     ap.add_argument("--continuous", action="store_true", help="continuous batching engine (requests join / leave between decode steps)")
+    ap.add_argument("--host", default="127.0.0.1", help='interface to bind ("" = all, as the reference)')
+    ap.add_argument("--image-dir", default=None, help="allow `images` entries naming files under this directory")
+    ap.add_argument("--image-host", action="append", default=[], help="allow `images` URLs on this host (repeatable)")
     a = ap.parse_args()
-    run(a.port, a.synthetic, a.blind, a.merge, a.continuous)
+    run(a.port, a.synthetic, a.blind, a.merge, a.continuous, a.host, ImagePolicy(a.image_dir, a.image_host))

@@ -3,7 +3,7 @@ import sys
 
 import pytest
 
-os.environ.setdefault("P3V_GEMM_BIG_ROWS", "512")   # M >= 1024: rows [0,512) on the 256x256-tile GEMM, the rest on 128x128 (read per call)
+os.environ.setdefault("P3V_GEMM_BIG_ROWS", "512")   # M >= 1024: rows [0,512) on the 256x256-tile GEMM, the rest on 128x128 (read once by the library, csrc/p3v_runtime.hip; tests change it through ops.set_tuning)
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests", "golden")):

@@ -22,7 +22,7 @@ def test_header_symbols_are_exported_and_bound():
     for s in syms:
         assert hasattr(lib, s), f"{s} declared in include/p3v.h but not exported by libp3v.so"
     assert sorted(_lib.SIGNATURES) == syms, set(_lib.SIGNATURES) ^ set(syms)
-    assert _lib.lib().p3v_version() == 100
+    assert _lib.lib().p3v_version() == 300
     assert _lib.lib().p3v_strerror(-22).decode().startswith("invalid argument")
 
 
@@ -40,7 +40,7 @@ def test_struct_layouts_match_header_field_order():
             stmt = stmt.strip()
             if not stmt:
                 continue
-            decl = re.sub(r"^(const\s+)?(void|uint16_t|uint8_t|int32_t|float|int)\s*\*?\s*", "", stmt)
+            decl = re.sub(r"^(const\s+)?(void|uint16_t|uint8_t|int32_t|int64_t|float|int)\s*\*?\s*", "", stmt)
             names += [n.strip().lstrip("*").strip() for n in decl.split(",")]
         assert names == [f for f, _ in cls._fields_], (cname, names)
 
@@ -59,6 +59,40 @@ def test_ops_fail_loudly_without_gpu_or_library(monkeypatch):
     monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libp3v.so")
     with pytest.raises(RuntimeError, match="no CPU/PyTorch fallback"):
         _lib.lib()
+
+
+def test_library_never_allocates_or_reads_the_environment_per_launch():
+    """include/p3v.h: launches never allocate or synchronise (callers pass workspaces, e.g. p3v_gemm_ws_bytes); knobs come
+    from ONE table filled once (p3v_runtime.hip).  Checked on the sources and on the library's undefined symbols."""
+    import subprocess
+    csrc = os.path.join(ROOT, "phi-3-vision-mlx_amd", "csrc")
+    for f in os.listdir(csrc):
+        if f.endswith((".hip", ".h")):
+            src = re.sub(r"//.*", "", open(os.path.join(csrc, f)).read())
+            for banned in ("hipMalloc", "hipFree", "hipDeviceSynchronize", "hipStreamSynchronize", "hipMemcpy("):
+                assert banned not in src, (f, banned)
+            if f != "p3v_runtime.hip":
+                assert "getenv" not in src, f
+    from phi_3_vision_mlx_amd import _lib
+    und = subprocess.run(["nm", "-D", "--undefined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    for banned in ("hipMalloc", "hipFree", "hipDeviceSynchronize", "hipStreamSynchronize"):
+        assert not re.search(rf"\b{banned}\b", und), banned
+
+
+def test_tuning_table_and_gemm_workspace_size():
+    from phi_3_vision_mlx_amd import _lib
+    l = _lib.lib()
+    v = ctypes.c_int(0)
+    assert l.p3v_get_tuning(b"gemm_splitk_max_m", ctypes.byref(v)) == 0 and v.value == 1024
+    assert l.p3v_set_tuning(b"no_such_knob", 1) == -22
+    assert l.p3v_set_tuning(b"combine_g", 4) == 0 and l.p3v_get_tuning(b"combine_g", ctypes.byref(v)) == 0 and v.value == 4
+    assert l.p3v_set_tuning(b"combine_g", -1) == 0
+    # split-K shapes (17 <= M <= 1024, < 256 tiles): S slices of fp32 [M, N or 2N]; none elsewhere
+    assert l.p3v_gemm_ws_bytes(128, 3072, 8192, _lib.EPI_RESID_BF16) == 8 * 128 * 3072 * 4
+    assert l.p3v_gemm_ws_bytes(128, 8192, 3072, _lib.EPI_SILU_MUL) == 2 * 128 * 16384 * 4
+    assert l.p3v_gemm_ws_bytes(2531, 3072, 8192, _lib.EPI_RESID_BF16) == 0
+    assert l.p3v_gemm_ws_bytes(16, 3072, 8192, _lib.EPI_NONE) == 0
+    assert l.p3v_gemm_ws_bytes(128, 3072, 8192, _lib.EPI_BIAS) == 0
 
 
 def test_product_never_imports_the_oracle():

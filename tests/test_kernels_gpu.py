@@ -132,7 +132,7 @@ def test_gemm(ops, epi, M, N, K):
 
 @pytest.mark.parametrize("epi,M,N,K", [("none", 2531, 9216, 3072), ("silu", 2531, 8192, 3072), ("resid_bf16", 2531, 3072, 3072),
                                        ("resid_f32", 9809, 1024, 1024), ("bias", 9809, 3072, 1024), ("none", 4096, 4096, 512)])
-def test_gemm_round_packing(ops, monkeypatch, epi, M, N, K):
+def test_gemm_round_packing(ops, epi, M, N, K):
     """The bench request's prefill shapes with the row split p3v_gemm's round-packing model picks (no pin), then all-big
     and all-small tiles: the three must agree bit for bit (same K order, same epilogue arithmetic per element)."""
     a = g((M, K), 30).cuda()
@@ -148,16 +148,61 @@ def test_gemm_round_packing(ops, monkeypatch, epi, M, N, K):
         if epi == "resid_bf16": return ops.gemm(a, w, ops.EPI_RESID_BF16, resid=rc, out=rc)
         return ops.gemm(a, w, ops.EPI_BIAS_RESID_F32, bias=bias, resid=rc, out=rc)
 
-    monkeypatch.delenv("P3V_GEMM_BIG_ROWS", raising=False)
-    picked = run()
-    monkeypatch.setenv("P3V_GEMM_BIG_ROWS", "0")
-    small = run()
-    monkeypatch.setenv("P3V_GEMM_BIG_ROWS", "1000000")
-    big = run()
-    torch.cuda.synchronize()
+    pinned = ops.set_tuning("gemm_big_rows", -1)        # -1: the launcher's own cost model
+    try:
+        picked = run()
+        ops.set_tuning("gemm_big_rows", 0)
+        small = run()
+        ops.set_tuning("gemm_big_rows", 1000000)
+        big = run()
+        torch.cuda.synchronize()
+    finally:
+        ops.set_tuning("gemm_big_rows", pinned)
     assert torch.equal(picked, small) and torch.equal(picked, big)
     acc = a[:64].float() @ w.float().t()          # spot check of the first rows against fp32 torch
     if epi == "none": close(picked[:64], acc.to(BF16), rtol=2 ** -6, atol=2e-2)
+
+
+@pytest.mark.parametrize("epi,M,N,K", [("resid_bf16", 129, 3072, 8192), ("silu", 40, 8192, 3072), ("none", 300, 9216, 3072)])
+def test_gemm_splitk_workspace_is_the_callers(ops, epi, M, N, K):
+    """p3v_gemm never allocates: the split-K partials live in a workspace the caller sizes with p3v_gemm_ws_bytes.  With the
+    workspace the call is capturable in a hipGraph (replay == eager, bit for bit); without one the same shape runs on the
+    one-pass kernel and agrees up to fp32 summation order."""
+    import ctypes as C
+    L = ops.L
+    EPI = {"none": ops.EPI_NONE, "resid_bf16": ops.EPI_RESID_BF16, "silu": ops.EPI_SILU_MUL}[epi]
+    a = g((M, K), 50).cuda()
+    w = g(((2 * N if epi == "silu" else N), K), 51, 1.0 / math.sqrt(K)).cuda()
+    r = g((M, N), 52).cuda() if epi == "resid_bf16" else None
+    need = L.lib().p3v_gemm_ws_bytes(M, N, K, EPI)
+    assert need > 0
+    eager = ops.gemm(a, w, EPI, resid=r)
+
+    def raw(ws, out):
+        args = L.GemmArgs(a.data_ptr(), w.data_ptr(), out.data_ptr(), 0, 0 if r is None else r.data_ptr(), 0, M, N, K, K, K, N, EPI, 0,
+                          0 if ws is None else ws.data_ptr(), 0 if ws is None else ws.numel())
+        L.check(L.lib().p3v_gemm(C.byref(args), torch.cuda.current_stream().cuda_stream), "gemm")
+        return out
+
+    no_ws = raw(None, torch.empty_like(eager))
+    short = raw(torch.empty(need - 16, dtype=torch.uint8, device="cuda"), torch.empty_like(eager))     # too small: one-pass kernel
+    torch.cuda.synchronize()
+    assert torch.equal(no_ws, short)
+    close(no_ws, eager, rtol=2 ** -6, atol=2e-2)
+    ref = a.float() @ w.float().t()
+    if epi == "none": close(eager, ref.to(BF16), rtol=2 ** -6, atol=2e-2)
+
+    ws = torch.empty(need, dtype=torch.uint8, device="cuda")
+    out = torch.zeros_like(eager)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        graph = ops.Graph()
+        graph.begin()
+        raw(ws, out)
+        graph.end()
+        graph.launch()
+    side.synchronize()
+    assert torch.equal(out, eager)
 
 
 def test_gemm_asymmetric_identity(ops):
@@ -699,14 +744,15 @@ def test_quant_fp8_rows(ops, rows, K, norm):
 @pytest.mark.parametrize("narrow", [None, "0", "1"])
 @pytest.mark.parametrize("epi,M,N,K", [("none", 300, 512, 384), ("none", 2531, 9216, 3072), ("resid", 2531, 3072, 8192),
                                        ("silu", 700, 1024, 3072), ("resid", 17, 256, 128), ("none", 513, 384, 256)])
-def test_gemm_fp8(ops, monkeypatch, epi, M, N, K, narrow):
+def test_gemm_fp8(ops, request, epi, M, N, K, narrow):
     """out = epilogue(sa[m] sw[n] sum_k a8[m,k] w8[n,k]) on v_mfma_scale_f32_16x16x128_f8f6f4 vs the same products in fp32
     on the CPU (e4m3 x e4m3 products are exact in fp32; only the summation order differs).  narrow: the launcher's own
     choice of tile width / 256-wide tiles / 128-wide tiles."""
     if narrow is not None:
         if epi == "silu" and narrow == "1":
             pytest.skip("SiLU*up runs on wide tiles only")
-        monkeypatch.setenv("P3V_GEMM_F8_NARROW", narrow)
+        old = ops.set_tuning("gemm_f8_narrow", int(narrow))
+        request.addfinalizer(lambda: ops.set_tuning("gemm_f8_narrow", old))
     EPI = {"none": ops.EPI_NONE, "resid": ops.EPI_RESID_BF16, "silu": ops.EPI_SILU_MUL}[epi]
     n_rows = 2 * N if epi == "silu" else N
     a8 = _e4m3(g((M, K), 40, 1.0, F32) * 3).view(torch.uint8)          # asymmetric random codes incl. denormals / zeros

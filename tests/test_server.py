@@ -97,3 +97,83 @@ def test_max_tokens_is_clamped_and_regimes_do_not_mix(server):
     assert all(results[p] == [f"{p}|200"] for p in results) and len(results) == 4
     for prompts, mt in calls:                                   # a long-RoPE request never shares a batch with a short one
         assert len({p.startswith("L") for p in prompts}) == 1, prompts
+
+
+def _png_data_uri(w=8, h=8):
+    import base64
+    from io import BytesIO
+    import numpy as np
+    from PIL import Image
+    buf = BytesIO()
+    Image.fromarray(np.full((h, w, 3), 200, dtype=np.uint8)).save(buf, format="PNG")
+    return "data:image/png;base64," + base64.b64encode(buf.getvalue()).decode()
+
+
+def test_image_policy_inline_only_by_default(tmp_path):
+    """the HTTP `images` field must not make the server open local paths or fetch URLs (SSRF / file oracle)."""
+    from PIL import Image
+    from phi_3_vision_mlx_amd.server import ImagePolicy, decode_image
+    secret = tmp_path / "secret.png"
+    Image.new("RGB", (4, 4)).save(secret)
+    assert decode_image(None) is None
+    im = decode_image(_png_data_uri())
+    assert im.size == (8, 8) and im.mode == "RGB"
+    for spec in (str(secret), "/etc/passwd", "/nonexistent/x.png", "http://169.254.169.254/latest/meta-data", "https://example.com/a.png"):
+        with pytest.raises(ValueError) as e:
+            decode_image(spec)
+        assert spec not in str(e.value) and "secret" not in str(e.value)      # nothing about the target leaks
+    # an existing and a missing file are indistinguishable from outside
+    with pytest.raises(ValueError) as e1:
+        decode_image(str(secret))
+    with pytest.raises(ValueError) as e2:
+        decode_image(str(tmp_path / "missing.png"))
+    assert str(e1.value) == str(e2.value)
+    for bad in (7, ["x"], {"a": 1}):
+        with pytest.raises(ValueError):
+            decode_image(bad)
+    with pytest.raises(ValueError):
+        decode_image("data:image/png;base64,!!!notbase64!!!")
+    with pytest.raises(ValueError):
+        decode_image("data:image/png;base64," + "QUJD" * 10)                 # valid base64, not an image
+    with pytest.raises(ValueError):
+        decode_image(_png_data_uri(64, 64), ImagePolicy(max_pixels=1000))
+    with pytest.raises(ValueError):
+        decode_image(_png_data_uri(), ImagePolicy(max_bytes=16))
+    # opt-in directory: files inside it load, traversal out of it does not
+    pol = ImagePolicy(allow_dir=str(tmp_path))
+    assert decode_image("secret.png", pol).size == (4, 4)
+    outside = tmp_path.parent / "outside.png"
+    Image.new("RGB", (4, 4)).save(outside)
+    for spec in ("../outside.png", str(outside), "/etc/passwd"):
+        with pytest.raises(ValueError):
+            decode_image(spec, pol)
+    # opt-in hosts: any other host is still refused before a connection is made
+    with pytest.raises(ValueError, match="not accepted"):
+        decode_image("http://evil.example/x.png", ImagePolicy(allow_hosts=["images.example"]))
+
+
+def test_http_images_field_is_validated_in_the_handler():
+    from phi_3_vision_mlx_amd.server import serve
+    seen = []
+
+    def fake_generate(prompts, max_tokens, images=None):
+        seen.append(images)
+        return [f"{p}|{'img' if im is not None else 'txt'}" for p, im in zip(prompts, images or [None] * len(prompts))]
+
+    httpd, engine = serve(fake_generate, port=0)
+    assert httpd.server_address[0] == "127.0.0.1"                           # loopback unless asked otherwise
+    threading.Thread(target=httpd.serve_forever, daemon=True).start()
+    port = httpd.server_address[1]
+    try:
+        ok = _post(port, "/v1/completions", {"prompt": ["a", "b"], "images": [_png_data_uri(), None]})
+        assert ok == (200, {"model": "phi-3-vision", "responses": ["a|img", "b|txt"]})
+        assert seen[-1][0].size == (8, 8) and seen[-1][1] is None           # the engine got a DECODED image, not a string
+        for images in (["/etc/passwd"], ["http://127.0.0.1:1/x.png"], [7], [["x"]]):
+            with pytest.raises(urllib.error.HTTPError) as e:
+                _post(port, "/v1/completions", {"prompt": ["a"], "images": images})
+            assert e.value.code == 400
+            assert "passwd" not in e.value.read().decode()
+        assert len(seen) == 1                                               # none of the bad requests reached the engine
+    finally:
+        httpd.shutdown()
+        engine.close()
