@@ -73,11 +73,13 @@ def usable_cores(cap=64):
     return max(1, min(n, cap))
 
 
-def cpu_baseline(model, n_decode=4, runs=3):
+def cpu_baseline(model, n_decode=32, runs=1, warm_decode=2):
     """the CPU oracle (torch-CPU restatement of phi.py, kind "port") on BASELINE config 1 --
-    text-only, 128-token prompt, greedy, ALL layers -- on this box's host cores: 1 warm-up + `runs` timed runs, median;
-    prefill ms and decode tokens/s with the reference's definitions (phi_3_vision_mlx.py:384-403).  Bounded: `n_decode`
-    decode steps per run.  Baseline only -- never on the product path."""
+    text-only, 128-token prompt, greedy, ALL layers -- on this box's host cores: one warm-up pass (prefill + `warm_decode`
+    steps), then `runs` timed passes of prefill + `n_decode` decode steps (median); prefill ms and decode tokens/s with the
+    reference's definitions (phi_3_vision_mlx.py:384-403).  BOUNDED sample of the 128 new tokens BASELINE.md names: 32 steps
+    at ~1.8 tok/s is ~20 s of CPU work, and a decode step's cost is flat in the step index at this context (weights
+    dominate).  Baseline only -- never on the product path."""
     import numpy as np
     import torch
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -92,20 +94,34 @@ def cpu_baseline(model, n_decode=4, runs=3):
     ids = np.random.default_rng(0).integers(3, 32000, (1, 128)).astype(np.int64)
     pre, dec = [], []
     for run in range(runs + 1):
+        nd = warm_decode if run == 0 else n_decode
         t0 = time.perf_counter()
-        logits, cache = o(input_ids=ids, max_tokens=n_decode + 1)
+        logits, cache = o(input_ids=ids, max_tokens=nd + 1)
         tok = torch.argmax(logits[:, -1].float(), dim=-1)[:, None]
         t1 = time.perf_counter()
-        for _ in range(n_decode):
+        for _ in range(nd):
             logits, cache = o(input_ids=tok, cache=cache)
             tok = torch.argmax(logits[:, -1].float(), dim=-1)[:, None]
         t2 = time.perf_counter()
         if run > 0:                                               # run 0 = warm-up (builds the fp32 weight copies)
-            pre.append((t1 - t0) * 1e3), dec.append(n_decode / (t2 - t1))
+            pre.append((t1 - t0) * 1e3), dec.append(nd / (t2 - t1))
     return {"value": round(float(np.median(dec)), 3), "unit": "tokens/s", "cores": cores, "kind": "port",
             "prefill_ms": round(float(np.median(pre)), 1),
             "sample": f"BASELINE config 1 (text-only, 128-token prompt, all {cfg.num_hidden_layers} layers, fp32 attention/KV as "
-                      f"phi.py) on torch-CPU: 1 warm-up + {runs} runs, median; {n_decode} decode steps per run"}
+                      f"phi.py) on torch-CPU: 1 warm-up pass + {runs} timed pass(es); {n_decode} of the 128 decode steps per pass"}
+
+
+PMC_TRAFFIC_FILE = "r03_pmc_hbm_traffic.json"      # written by tools/pmc_round3.py from separate rocprofv3 --pmc passes
+
+
+def kernel_source_sha16():
+    """Identity of the dominant kernel's sources (the GEMV translation unit and what it includes)."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("p3v_gemv.hip", "p3v_gemv3_body.h", "p3v_common.h"):
+        with open(os.path.join(ROOT, "phi-3-vision-mlx_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
 
 
 def prefill_flops(cfg, S, n_img_tokens, n_crops):
@@ -296,9 +312,12 @@ def main():
     # runs, FETCH_SIZE x2 on gfx950); a committed measurement, not re-collected inside the timed benchmark
     traffic = None
     try:
-        if not model.w8:                                          # round-2 passes (tools/pmc_round2.sh); the kernel is round 1's
-            with open(os.path.join(ROOT, "profiles", "r02_pmc_hbm_traffic.json")) as f:
-                traffic = json.load(f)["gemv"]["hbm_bytes_per_launch_corrected"]
+        if not model.w8:
+            with open(os.path.join(ROOT, "profiles", PMC_TRAFFIC_FILE)) as f:
+                rec = json.load(f)
+            # the counters belong to ONE build of the kernel: a record taken from other sources is stale -> null
+            if rec.get("kernel_source_sha16") == kernel_source_sha16():
+                traffic = rec["gemv"]["hbm_bytes_per_launch_corrected"]
     except Exception:
         pass
     hd = cfg.hidden_size // cfg.num_attention_heads

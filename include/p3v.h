@@ -157,12 +157,15 @@ int p3v_rope_table(const float* pos, const float* inv_freq, float scale, float* 
  * then reads 8 consecutive keys per lane with one 16-byte load, like QK^T does for K).
  * cos/sin tables are [B/tab_div, tab_t, hd/2]; position of (b,l) is past+l.
  * cos_t == sin_t == NULL: no rotation, plain head split (CLIP q/k/v, phi.py:147).
- * `d_past` (device int32, may be null) overrides `past` -- used under graph replay. */
+ * `d_past` (device int32, may be null) overrides `past` -- used under graph replay.
+ * q_scale: rotated queries are multiplied by it BEFORE their one rounding to bf16 (phi.py:454 scales q before the
+ * product too); 1.0f = plain.  With q_scale = scale * log2(e) the attention call takes q_prescaled = 1 and its softmax
+ * needs no multiply per score.  Ignored (1.0) without rotation tables. */
 int p3v_rope_kv_append(const uint16_t* qkv, const float* cos_t, const float* sin_t,
                        uint16_t* q_out, uint16_t* k_dst, uint16_t* v_dst,
                        int B, int L, int n_heads, int n_kv, int hd,
                        int past, const int32_t* d_past, int dst_t, int dst_off_is_past,
-                       int tab_t, int tab_div, void* stream);
+                       int tab_t, int tab_div, float q_scale, void* stream);
 
 /* ---- attention, phi.py:454-457 (decoder, causal + left-pad, Mask4D phi.py:550-563)
  * and phi.py:148 (CLIP, no mask).  q [B, nh, L, hd]; keys/values come from two
@@ -189,6 +192,7 @@ typedef struct {
   int n_split;              /* decode path: KV splits (<=1: no split) */
   int new_is_cache;         /* 1: (k_new,v_new) ignored, rows [past,past+L) are read from (k_past,v_past) too --
                                used with d_past, when the append offset is only known on the device */
+  int q_prescaled;          /* 1: q already carries scale * log2(e) (p3v_rope_kv_append's q_scale); `scale` is then unused */
 } p3v_attn_args_t;
 int p3v_attention(const p3v_attn_args_t* args /* host */, void* stream);
 /* bytes of workspace p3v_attention needs for the decode (L<=P3V_DECODE_MAX_L) path */

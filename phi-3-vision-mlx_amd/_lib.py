@@ -48,7 +48,7 @@ class AttnArgs(C.Structure):
                 ("pad_len", vp), ("d_past", vp), ("ws", vp),
                 ("B", i32), ("L", i32), ("n_heads", i32), ("n_kv", i32), ("hd", i32),
                 ("past", i32), ("past_t", i32), ("past_div", i32), ("new_t", i32), ("pad_div", i32),
-                ("causal", i32), ("scale", f32), ("n_split", i32), ("new_is_cache", i32)]
+                ("causal", i32), ("scale", f32), ("n_split", i32), ("new_is_cache", i32), ("q_prescaled", i32)]
 
 
 class GemvQ4Args(C.Structure):
@@ -88,7 +88,7 @@ SIGNATURES = {
     "p3v_gemm_fp8": (i32, [C.POINTER(GemmF8Args), vp]),
     "p3v_quant_fp8_rows": (i32, [vp, vp, f32, vp, vp, i32, i32, vp]),
     "p3v_rope_table": (i32, [vp, vp, f32, vp, vp, i32, i32, vp]),
-    "p3v_rope_kv_append": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, i32, i32, i32, i32, vp]),
+    "p3v_rope_kv_append": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, i32, i32, i32, i32, f32, vp]),
     "p3v_attention": (i32, [C.POINTER(AttnArgs), vp]),
     "p3v_attention_decode": (i32, [C.POINTER(AttnDecArgs), vp]),
     "p3v_kv_quantize": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),

@@ -26,7 +26,9 @@ struct AttnP {
   bf16_t* out; const int32_t* pad_len; const int32_t* d_past; float* ws;
   int B, L, nh, nkv, past, past_t, past_div, new_t, pad_div, causal, split_mode, n_split, new_is_cache;
   float scale;
-  int head_group;              // k_attn_prefill_dma: heads whose query blocks are interleaved in launch order
+  int head_group;              // k_attn_prefill_dma / _pp: heads whose query blocks are interleaved in launch order
+  float sc2;                   // what S = Q.K^T is multiplied by before exp2: scale * log2(e), or 1 when Q arrives pre-scaled
+  int q_prescaled;
 };
 
 template <int HD>
@@ -45,7 +47,7 @@ __global__ void __launch_bounds__(256) k_attn(AttnP p) {
   const int past = p.d_past ? *p.d_past : p.past;
   const int total = past + p.L;
   const int pad = p.pad_len ? p.pad_len[b / p.pad_div] : 0;
-  const float sc2 = p.scale * 1.4426950408889634f;   // scale * log2(e): softmax (and the split partials) run on exp2
+  const float sc2 = p.sc2;                                     // scale * log2(e): softmax (and the split partials) run on exp2
 
   int q0, kv_begin, kv_end;
   bool active;
@@ -228,7 +230,7 @@ __global__ void __launch_bounds__(256, 2) k_attn_prefill(AttnP p) {
   const int kv_end = p.causal ? min(total, past + qb0 + 128) : total;
   const int kv_begin = pad & ~63;
   const int wave_last = p.causal ? past + q0 + 31 : total;  // last key position this wave can see
-  const float sc2 = p.scale * 1.4426950408889634f;          // scale * log2(e)
+  const float sc2 = p.sc2;                                            // scale * log2(e)
 
   bf16x8_t qf[2][NKS];
   int qpos[2];
@@ -411,7 +413,7 @@ __global__ void __launch_bounds__(256, 2) k_attn_prefill(AttnP p) {
 // (64 rows x 2*HD bytes, contiguous) and the V^T tile (HD rows x 128 bytes) go HBM/L2 -> LDS by LDS-DMA, each wave
 // issuing a quarter of the tile's 1 KiB pieces -- no staging registers, no ds_write pass, no per-tile address
 // arithmetic (k_attn_prefill spends most of its issue slots there).  Bank-conflict swizzles on the source side:
-//   192-byte K rows (HD = 96): chunk c ^ ((row >> 2) & 3);   128-byte rows (K at HD = 64, V^T): chunk c ^ ((row >> 1) & 7).
+//   192-byte K rows (HD = 96): chunk c ^ (-(row >> 2) & 3) (round 3: the round-2 form (row >> 2) & 3 was 2-way conflicted on ds_read_b128);   128-byte rows (K at HD = 64, V^T): chunk c ^ ((row >> 1) & 7).
 // Two LDS buffers, one barrier per tile; compute part and masks identical to k_attn_prefill.
 typedef const __attribute__((address_space(1))) void* pf_gptr_t;
 typedef __attribute__((address_space(3))) void* pf_lptr_t;
@@ -438,7 +440,7 @@ __global__ void __launch_bounds__(256, 2) k_attn_prefill_dma(AttnP p) {
   const int kv_end = p.causal ? min(total, past + qb0 + 128) : total;
   const int kv_begin = pad & ~63;
   const int wave_last = p.causal ? past + q0 + 31 : total;  // last key position this wave can see
-  const float sc2 = p.scale * 1.4426950408889634f;          // scale * log2(e)
+  const float sc2 = p.sc2;                                            // scale * log2(e)
 
   bf16x8_t qf[2][NKS];
   int qpos[2];
@@ -464,7 +466,7 @@ __global__ void __launch_bounds__(256, 2) k_attn_prefill_dma(AttnP p) {
 #pragma unroll
   for (int jj = 0; jj < NK / 4; ++jj) {
     const int i = (wave + 4 * jj) * 64 + lane, row = i / CPR, pc = i - row * CPR;
-    const int sw = HD == 96 ? (row >> 2) & 3 : (row >> 1) & 7;
+    const int sw = HD == 96 ? (-(row >> 2)) & 3 : (row >> 1) & 7;   // conflict-free on ds_read_b128's lane groups (see k_attn_prefill_pp)
     koff[jj] = row * KROW + ((pc ^ sw) << 4);
   }
   const unsigned vrow = (unsigned)p.past_t * 2;
@@ -502,7 +504,7 @@ __global__ void __launch_bounds__(256, 2) k_attn_prefill_dma(AttnP p) {
   unsigned k_rd[NKS];
 #pragma unroll
   for (int ks = 0; ks < NKS; ++ks) {
-    const int c = 4 * ks + g, sw = HD == 96 ? (qi >> 2) & 3 : (qi >> 1) & 7;
+    const int c = 4 * ks + g, sw = HD == 96 ? (-(qi >> 2)) & 3 : (qi >> 1) & 7;
     k_rd[ks] = qi * KROW + ((c ^ sw) << 4);                  // + st*16*KROW
   }
   unsigned v_rd[4];                                           // chunk (4 st + 2 h + g/2) ^ ((qi>>1)&7)
@@ -630,6 +632,441 @@ __global__ void __launch_bounds__(256, 2) k_attn_prefill_dma(AttnP p) {
   }
 }
 
+// =====================================================================================
+// Ping-pong prefill attention (round 3).  Where k_attn_prefill_dma lost its time (in-kernel phase counters):
+// per 64-key tile a wave spent 830 cycles on the 24 S^T MFMAs (384 matrix-pipe cycles), 2430 on the softmax (~700 VALU
+// cycles) and 1450 on the 28 PV MFMAs (448) -- neither pipe of a SIMD was busier than ~35 %: the SIMD's two waves (one of
+// each of the CU's two workgroups) drift in and out of the same phase, share the pipe they both want and leave the other
+// idle.  Here the pairing is made deterministic:
+//   * ONE workgroup of 8 waves per CU covers 256 queries of a (batch row, head); waves w and w + 4 share a SIMD.  Waves
+//     0-3 (group A) and 4-7 (group B) run the same per-tile sequence  [PV(j-1) + S^T(j)] -> [softmax(j)]  half a tile apart:
+//     in every step one wave of each SIMD is in its MATRIX phase (52 MFMAs, LDS fragment reads, DMA issue) while its
+//     partner is in its VALU phase (softmax of 32 queries x 64 keys); one s_barrier per step keeps them in anti-phase.
+//   * VALU work per score cut to the exponential itself: Q arrives PRE-SCALED by scale * log2(e) (the RoPE kernel
+//     multiplies before its one rounding to bf16 -- same relative rounding as before), the S^T accumulators START at
+//     -m (the running reference of the query's column, lane-uniform over the accumulator rows), so the MFMA result IS
+//     the exponent; the reference only moves when a tile's maximum exceeds it by more than 2^8 (wave-uniform slow path
+//     that rescales O and l once; P <= 256 in bf16 has the same relative precision) -- and on a query's first visible
+//     tile, which sets it.  Fast path per tile and wave: 32 v_exp + 16 v_cvt_pk + ~28 max / select / swap.
+//   * K / V^T tiles by LDS-DMA into a ring of three K tiles and four V^T tiles (see issue_batch for why four), 24 (HD = 96)
+//     one-KiB pieces per tile pair = 3 per wave, issued at the top of a matrix phase two tiles ahead of their use; counted
+//     vmcnt (one batch stays in flight across every barrier), never a full drain inside the loop.  The K tile is staged in a
+//     PERMUTED key order that makes every V^T fragment one ds_read_b128 (see load_k), both tiles conflict-free.
+//   * fragment reads are taken off the MFMA stream: V^T(j) is read at the top of softmax(j) (lands under the VALU work), K(j+1)
+//     at the top of the matrix phase, under the 28 PV MFMAs; the S^T accumulators start from a persistent -reference block.
+//   * every tile of K / V^T is fetched ONCE per 256 queries (128 before): half the L2 -> LDS traffic per flop.
+// What the compiler must be kept from doing (each cost 1.5-2x, found with SQ_INSTS_VALU and the in-kernel phase timeline,
+// tools/attn_pp_timeline.py): conditional updates of the accumulator arrays written as C++ (-> 600 register copies per tile:
+// in-place inline asm instead); sinking the exponentials past the asm barrier into the matrix phase (-> results pinned with
+// empty volatile asm uses); spilling lane-constant LDS offsets (reload = scratch load = vmcnt(0) = DMA drained: recomputed per
+// phase from an opaque lane id).
+// Row sums ride on the matrix cores as before (ones-row V^T fragment).
+#ifdef P3V_PP_DEBUG                                             // tools/attn_pp_timeline.py: per-wave phase timestamps of ONE workgroup
+__device__ unsigned long long p3v_ppdbg[8 * 128];
+#define PP_T(slot) do { if (blockIdx.x == P3V_PP_DEBUG && (threadIdx.x & 63) == 0 && (slot) < 127) p3v_ppdbg[(threadIdx.x >> 6) * 128 + 1 + (slot)] = __builtin_readcyclecounter(); } while (0)
+extern "C" int p3v_ppdbg_read(unsigned long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(p3v_ppdbg), sizeof(unsigned long long) * 8 * 128) == hipSuccess ? 0 : -1;
+}
+#else
+#define PP_T(slot) do { } while (0)
+#endif
+template <int HD, bool PRE>
+__global__ void __launch_bounds__(512, 1) k_attn_prefill_pp(AttnP p) {
+  constexpr int KROW = HD * 2, VROW = 128, NKS = HD / 32, NDT = HD / 16, CPR = HD / 8;
+  constexpr int KTILE = 64 * KROW, VTILE = HD * VROW, RING = 3, VRING = 4;   // ring depths: see issue_batch
+  constexpr int NK = KTILE / 1024, NV = VTILE / 1024, NPW = (NK + NV) / 8;   // DMA pieces per tile (K, V^T) and per wave and batch
+  constexpr float THR = 8.f;
+  static_assert((NK + NV) % 8 == 0, "pieces must divide over 8 waves");
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];   // K ring [RING][KTILE] | V^T ring [VRING][VTILE]
+  const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, qi = lane & 15;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), grp = wave >> 2;
+  const int nqb = (p.L + 255) >> 8, per_group = p.head_group * nqb;
+  const int hgrp = blockIdx.x / per_group, within = blockIdx.x - hgrp * per_group;
+  const int qblk = nqb - 1 - within / p.head_group;             // longest (last) query blocks first
+  const int b = blockIdx.z, head = hgrp * p.head_group + within % p.head_group, kvh = head / (p.nh / p.nkv);
+  const int past = p.d_past ? *p.d_past : p.past;
+  const int total = past + p.L;
+  const int pad = p.pad_len ? p.pad_len[b / p.pad_div] : 0;
+  const int qb0 = qblk * 256, q0 = qb0 + wave * 32;
+  const int kv_end = p.causal ? min(total, past + qb0 + 256) : total;
+  const int kv_begin = min(pad & ~63, kv_end);
+  const int NT = (kv_end - kv_begin + 63) >> 6;
+#ifdef P3V_PP_SOLO                                               // timing experiment: group B idles
+  const bool active = q0 < p.L && grp == 0;
+#else
+  const bool active = q0 < p.L;
+#endif
+  const int wave_last = p.causal ? past + q0 + 31 : total;  // last key position this wave can see
+  const float sc2 = p.sc2;                                   // !PRE only
+
+  bf16x8_t qf[2][NKS];
+  int qpos[2];
+  bool qvalid[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int qrow = q0 + u * 16 + qi;
+    qvalid[u] = qrow < p.L;
+    qpos[u] = past + qrow;
+    const bf16_t* qp = p.q + (((size_t)b * p.nh + head) * p.L + (qvalid[u] ? qrow : 0)) * HD + 8 * g;
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+      u32x4_t v = *(const u32x4_t*)(qp + 32 * ks);
+      if (!qvalid[u]) v = (u32x4_t){0, 0, 0, 0};
+      qf[u][ks] = __builtin_bit_cast(bf16x8_t, v);
+    }
+  }
+  const unsigned char* kbase = (const unsigned char*)(p.k_past + ((size_t)(b / p.past_div) * p.nkv + kvh) * (size_t)p.past_t * HD);
+  const unsigned char* vbase = (const unsigned char*)(p.v_past + ((size_t)(b / p.past_div) * p.nkv + kvh) * (size_t)HD * p.past_t);
+  const __amdgpu_buffer_rsrc_t rs_k = __builtin_amdgcn_make_buffer_rsrc((void*)kbase, 0, 0xffffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_v = __builtin_amdgcn_make_buffer_rsrc((void*)vbase, 0, 0xffffffff, 0x00020000);
+
+  // ---- this wave's DMA pieces: piece pi = wave + 8 i of the list [K_0 .. K_{NK-1}, V_0 .. V_{NV-1}]
+  const unsigned vrow = (unsigned)p.past_t * 2;
+  unsigned poff[NPW];
+#pragma unroll
+  for (int i = 0; i < NPW; ++i) {
+    const int pi = wave + 8 * i;
+    if (pi < NK) {
+      const int e = pi * 64 + lane, row = e / CPR, pc = e - row * CPR;
+      const int sw = HD == 96 ? (-(row >> 2)) & 3 : (row >> 1) & 7;
+      const int blk = row >> 4, i_ = row & 15;               // LDS row (block blk, A-operand row i_) holds key pi_key of the tile
+      const int key = 32 * (blk >> 1) + 8 * (i_ >> 2) + 4 * (blk & 1) + (i_ & 3);
+      poff[i] = key * KROW + ((pc ^ sw) << 4);
+    } else {
+      const int e = (pi - NK) * 64 + lane, row = e >> 3, pc = e & 7;
+      poff[i] = (unsigned)row * vrow + ((pc ^ ((row >> 1) & 7)) << 4);
+    }
+  }
+  // batch jb = K tile jb + 2 and V^T tile jb + 2, issued at the top of the matrix phase M(jb) (group A: step 2 jb, group B:
+  // step 2 jb + 1) and waited for by every wave before the barrier that ends step 2 jb + 3.  First readers: K(j) in M(j)
+  // (step 2j), V^T(j) in softmax(j) (step 2j + 1) -- both after the end of step 2 (j - 2) + 3.  Last readers of the slot a
+  // batch overwrites: K(jb - 1), read in M(jb - 1) (steps 2 jb - 2 / 2 jb - 1) -> three K slots; V^T(jb - 2), read in
+  // softmax(jb - 2) (steps 2 jb - 3 / 2 jb - 2) -> FOUR V^T slots (with three, group A's batch jb would land on the tile
+  // group B's softmax(jb - 1) is still reading in step 2 jb).  Prologue batches -2, -1 = tiles 0, 1 (clamped into [0, NT)).
+  auto issue_batch = [&](int jb) {
+#ifdef P3V_PP_NODMA                                              // timing experiment: tiles never move
+    return;
+#endif
+    const int tk = min(jb + 2, NT - 1), tv = tk;
+    const int ks_ = (jb + 2) % RING, vs_ = (jb + 2) % VRING;
+    const int so_k = (kv_begin + 64 * tk) * KROW, so_v = (kv_begin + 64 * tv) * 2;
+#pragma unroll
+    for (int i = 0; i < NPW; ++i) {
+      const int pi = wave + 8 * i;
+      const unsigned vo = poff[i];
+      if (pi < NK) {
+        pf_lptr_t dst = (pf_lptr_t)(smem + ks_ * KTILE + pi * 1024);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_k, dst, 16, vo, so_k, 0, 0);
+      } else {
+        pf_lptr_t dst = (pf_lptr_t)(smem + RING * KTILE + vs_ * VTILE + (pi - NK) * 1024);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_v, dst, 16, vo, so_v, 0, 0);
+      }
+    }
+  };
+
+  // ---- fragment read offsets (as k_attn_prefill_dma), RECOMPUTED at the top of every phase from a lane id the compiler
+  // cannot see through: kept live across the tile loop they are spilled (the kernel sits at the 256-register limit of two
+  // waves per SIMD), and a spill reload is a scratch load -- its compiler-inserted vmcnt(0) drains the LDS-DMA in flight
+  auto lane_now = [&]() {
+    unsigned l = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    asm volatile("" : "+v"(l));
+    return l;
+  };
+
+  const u32x4_t ones_w = qi == 0 ? (u32x4_t){0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u} : (u32x4_t){0u, 0u, 0u, 0u};
+  const bf16x8_t ones_f = __builtin_bit_cast(bf16x8_t, ones_w);
+  float m_run[2] = {0.f, 0.f};                               // reference of the exponent (finite always)
+  bool unset[2] = {true, true};                              // no visible key seen yet: the next one sets the reference
+  f32x4_t ol[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  f32x4_t o[2][NDT];
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+#pragma unroll
+    for (int d = 0; d < NDT; ++d) o[u][d] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  f32x4_t s[2][4];
+  bf16x8_t pf[2][2];
+
+  // Key order inside a tile.  The S^T accumulator rows a lane holds (rows 4g .. 4g+3 of each 16-row block) become ITS
+  // B fragment of the PV product, k index (g, 0..7) = (block 2st', rows 4g..4g+3), (block 2st'+1, rows 4g..4g+3).  The K
+  // tile is staged so that A-operand row i of block b is key 32 (b >> 1) + 8 (i >> 2) + 4 (b & 1) + (i & 3) of the tile
+  // (the DMA fetches 16-byte chunks from anywhere: a permuted row order is free): a lane's eight k values are then the
+  // EIGHT CONSECUTIVE keys 32 st' + 8 g .. + 7, and its V^T fragment is ONE ds_read_b128 (k_attn_prefill_dma: two
+  // ds_read_b64 that the compiler fuses into the half-rate ds_read2st64_b64).  Bank conflicts: none on either tile
+  // (the 16-lane service groups of ds_read_b128 are {0-3,12-15,20-27}, {4-11,16-19,28-31}, ...: the K swizzle for 192-byte
+  // rows is chunk ^ (-(row >> 2) & 3) inside aligned groups of four; k_attn_prefill_dma's (row >> 2) & 3 was 2-way
+  // conflicted on every read, SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.50).
+  f32x4_t negm[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};   // C operand of the S^T products: -reference (PRE) or 0
+  bf16x8_t kfr[4][NKS];                                      // K fragments of the tile in work (loaded under the PV MFMAs)
+  bf16x8_t vfr[2][NDT];                                      // V^T fragments (loaded under the softmax of the same tile)
+  auto load_k = [&](int j) {
+    const unsigned char* Ks = smem + (j % RING) * KTILE;
+    const unsigned ln = lane_now(), g_ = ln >> 4, qi_ = ln & 15;
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+      const unsigned c = 4 * ks + g_, sw = HD == 96 ? (0u - (qi_ >> 2)) & 3 : (qi_ >> 1) & 7;
+      const unsigned off = qi_ * KROW + ((c ^ sw) << 4);
+#pragma unroll
+      for (int st = 0; st < 4; ++st) kfr[st][ks] = *(const bf16x8_t*)(Ks + off + st * 16 * KROW);
+    }
+  };
+  auto load_v = [&](int j) {
+    const unsigned char* Vs = smem + RING * KTILE + (j % VRING) * VTILE;
+    const unsigned ln = lane_now(), g_ = ln >> 4, qi_ = ln & 15;
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+      const unsigned off = qi_ * VROW + (((4 * st + g_) ^ ((qi_ >> 1) & 7)) << 4);
+#pragma unroll
+      for (int d = 0; d < NDT; ++d) vfr[st][d] = *(const bf16x8_t*)(Vs + off + d * 16 * VROW);
+    }
+  };
+  auto qk = [&]() {                                          // S^T(j) = K_j . Q^T (- reference), K_j in kfr
+    // the first MFMA of every accumulator takes the persistent block `negm` (-reference in all four rows) as its C
+    // operand: no per-tile initialisation of the 32 accumulator registers
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks) {
+#ifdef P3V_PP_NOLDS                                              // timing experiment: no fragment reads
+        const bf16x8_t kf = qf[1][ks];
+#else
+        const bf16x8_t kf = kfr[st][ks];
+#endif
+        s[0][st] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[0][ks], ks == 0 ? negm[0] : s[0][st], 0, 0, 0);
+        s[1][st] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[1][ks], ks == 0 ? negm[1] : s[1][st], 0, 0, 0);
+      }
+    }
+  };
+  auto pv = [&]() {                                          // O^T += V^T_j . P^T(j), l += 1 . P^T(j), V^T_j in vfr
+#pragma unroll
+    for (int st = 0; st < 2; ++st)
+#pragma unroll
+      for (int d = 0; d < NDT; ++d) {
+#ifdef P3V_PP_NOLDS
+        const bf16x8_t vf = qf[0][d % NKS];
+#else
+        const bf16x8_t vf = vfr[st][d];
+#endif
+        o[0][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[0][st], o[0][d], 0, 0, 0);
+        o[1][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[1][st], o[1][d], 0, 0, 0);
+      }
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+      ol[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones_f, pf[0][st], ol[0], 0, 0, 0);
+      ol[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones_f, pf[1][st], ol[1], 0, 0, 0);
+    }
+  };
+  // Every conditional update of the big register arrays (mask, moved reference) is an IN-PLACE inline-asm instruction on
+  // the array element ("+v"): written as C++ selects / multiplies the compiler gives the updated array NEW registers and
+  // fills the common path with copies -- 600 v_mov per tile and wave in the first version of this kernel (SQ_INSTS_VALU
+  // 734 per wave-tile against 130 of real work, profiles/r03_pmc_prefill_attn.txt).
+  auto softmax = [&](int j) {
+    const int kv0 = kv_begin + 64 * j;
+    // every key of the tile visible to every query of the wave -> no per-element mask work (wave-uniform)
+    const bool interior = kv0 + 64 <= kv_end && kv0 >= pad && past + q0 >= pad && (!p.causal || kv0 + 63 <= past + q0);
+#ifdef P3V_PP_VALUPRIO
+    __builtin_amdgcn_s_setprio(2);
+#endif
+    load_v(j);                                               // lands under the VALU work below; consumed by the next matrix phase
+    float m_t[2];
+    if (!PRE) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int st = 0; st < 4; ++st)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) s[u][st][r] = fmaf(s[u][st][r], sc2, -m_run[u]);
+    }
+    if (!interior) {
+      const float ninf = -INFINITY;
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int st = 0; st < 4; ++st)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int t = kv0 + 32 * (st >> 1) + 8 * g + 4 * (st & 1) + r;      // key order of the staged tile
+            const bool vis = t < kv_end && t >= pad && (!p.causal || t <= qpos[u]) && qpos[u] >= pad;
+            const unsigned long long vm = __builtin_amdgcn_ballot_w64(vis);
+            asm("v_cndmask_b32_e64 %0, %1, %0, %2" : "+v"(s[u][st][r]) : "v"(ninf), "s"(vm));      // s = vis ? s : -inf
+          }
+    }
+    // (both 16-query halves in ONE basic block: their reduction chains are dependent instruction by instruction, the
+    //  scheduler interleaves the two)
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      float a = fmaxf(fmaxf(s[u][0][0], s[u][0][1]), s[u][0][2]);      // v_max3 chains
+      float c = fmaxf(fmaxf(s[u][0][3], s[u][1][0]), s[u][1][1]);
+      a = fmaxf(fmaxf(a, s[u][1][2]), s[u][1][3]);
+      c = fmaxf(fmaxf(c, s[u][2][0]), s[u][2][1]);
+      a = fmaxf(fmaxf(a, s[u][2][2]), s[u][2][3]);
+      c = fmaxf(fmaxf(c, s[u][3][0]), s[u][3][1]);
+      a = fmaxf(fmaxf(a, s[u][3][2]), s[u][3][3]);
+      m_t[u] = rows_max(fmaxf(a, c));
+    }
+    const bool slow = unset[0] || unset[1] || m_t[0] > THR || m_t[1] > THR;
+    if (__builtin_amdgcn_ballot_w64(slow) != 0) {               // wave-uniform: a reference moves (first tile, or a jump > 2^8)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const bool masked = m_t[u] == -INFINITY;
+        const float delta = unset[u] ? (masked ? 0.f : m_t[u]) : fmaxf(m_t[u], 0.f);
+        const float alpha = unset[u] ? 1.f : __builtin_amdgcn_exp2f(-delta);
+        unset[u] = unset[u] && masked;
+        m_run[u] += delta;
+        if (PRE) negm[u] = (f32x4_t){-m_run[u], -m_run[u], -m_run[u], -m_run[u]};
+#pragma unroll
+        for (int st = 0; st < 4; ++st)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) asm("v_sub_f32 %0, %0, %1" : "+v"(s[u][st][r]) : "v"(delta));
+#pragma unroll
+        for (int d = 0; d < NDT; ++d)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) asm("v_mul_f32 %0, %0, %1" : "+v"(o[u][d][r]) : "v"(alpha));
+#pragma unroll
+        for (int r = 0; r < 4; ++r) asm("v_mul_f32 %0, %0, %1" : "+v"(ol[u][r]) : "v"(alpha));
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+#pragma unroll
+      for (int st = 0; st < 4; ++st)
+#pragma unroll
+#ifdef P3V_PP_NOEXP                                              // timing experiment: no transcendental (single non-packed VALU op instead)
+        for (int r = 0; r < 4; ++r) asm("v_mul_f32 %0, 0.5, %0" : "+v"(s[u][st][r]));
+#else
+        for (int r = 0; r < 4; ++r) s[u][st][r] = __builtin_amdgcn_exp2f(s[u][st][r]);
+#endif
+#pragma unroll
+      for (int st = 0; st < 2; ++st) {
+        u32x4_t pw;
+        pw[0] = pack_bf16x2(s[u][2 * st][0], s[u][2 * st][1]);
+        pw[1] = pack_bf16x2(s[u][2 * st][2], s[u][2 * st][3]);
+        pw[2] = pack_bf16x2(s[u][2 * st + 1][0], s[u][2 * st + 1][1]);
+        pw[3] = pack_bf16x2(s[u][2 * st + 1][2], s[u][2 * st + 1][3]);
+        pf[u][st] = __builtin_bit_cast(bf16x8_t, pw);
+      }
+    }
+    // P is USED here as far as the optimiser can tell: without this the exponentials are sunk past the step barrier (an asm
+    // barrier orders memory operations only) into the matrix phase that consumes them
+    asm volatile("" ::"v"(pf[0][0]), "v"(pf[0][1]), "v"(pf[1][0]), "v"(pf[1][1]));
+#ifdef P3V_PP_VALUPRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
+  };
+  auto pin_s = [&]() {                                       // likewise: the S^T MFMAs belong to the phase that issued them
+    asm volatile("" ::"v"(s[0][0]), "v"(s[0][1]), "v"(s[0][2]), "v"(s[0][3]), "v"(s[1][0]), "v"(s[1][1]), "v"(s[1][2]), "v"(s[1][3]));
+  };
+  auto pin_o = [&]() {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      asm volatile("" ::"v"(ol[u]));
+#pragma unroll
+      for (int d = 0; d < NDT; ++d) asm volatile("" ::"v"(o[u][d]));
+    }
+  };
+
+  // ---- the step sequence.  Global steps 0 .. 2 NT + 1, one s_barrier after each.  A wave of group g (0 = A, 1 = B) runs
+  // its matrix phase M(j) = {issue DMA batch j; PV(j-1); S^T(j)} in step 2j + g and its VALU phase softmax(j) in step
+  // 2j + 1 + g.  A wave works on tiles j < NTw (tiles above its diagonal are skipped; monotone in j); the steady-state loop
+  // body is STRAIGHT-LINE code over the accumulators (no conditional around pv / qk / softmax: every conditional there costs
+  // register copies), the edges are peeled, and a wave that is done keeps issuing its share of the DMA and the barriers.
+  int step = 0;
+  auto end_step = [&]() {
+    // (the scheduler may move anything that is not a memory operation across an asm barrier -- it sank the whole
+    //  exponential block of the softmax into the following matrix phase: fence the instruction stream as well)
+    __builtin_amdgcn_sched_barrier(0);
+    PP_T(2 * step + 1);
+    // before the barrier that ends an ODD step every wave has batch jn - 2 (tile jn: read from the next step on) in LDS
+    // (group A issued it three steps ago, group B two); the batch issued since (jn - 1, if there was one: the last batch is
+    // NT - 3) stays in flight
+    if (step & 1) {
+      const int jn = (step + 1) >> 1;
+      if (jn <= NT - 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPW) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+#ifndef P3V_PP_NOBAR                                             // (timing experiment: no step barrier)
+    asm volatile("s_barrier" ::: "memory");
+#endif
+    ++step;
+    PP_T(2 * step);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  const int NTw = active ? max(0, min(NT, ((wave_last - kv_begin) >> 6) + 1)) : 0;
+  if (NT > 0) {
+    issue_batch(-2);
+    issue_batch(-1);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPW) : "memory");          // batch -2 (K tile 0) has landed, batch -1 flies
+    asm volatile("s_barrier" ::: "memory");
+    if (grp) end_step();                                                // group B runs one step behind group A
+    // M(0)
+    if (0 <= NT - 3) issue_batch(0);
+    if (NTw > 0) {
+#ifndef P3V_PP_NOPRIO
+      __builtin_amdgcn_s_setprio(1);
+#endif
+      load_k(0);
+      qk();
+      pin_s();
+      __builtin_amdgcn_s_setprio(0);
+    }
+    end_step();
+    for (int j = 0; j + 1 < NTw; ++j) {
+#ifndef P3V_PP_NOVALU
+      softmax(j);
+#endif
+      end_step();
+      if (j + 1 <= NT - 3) issue_batch(j + 1);
+#ifndef P3V_PP_NOPRIO
+      __builtin_amdgcn_s_setprio(1);
+#endif
+      load_k(j + 1);                                                    // 12 ds_read_b128 in flight under the 28 PV MFMAs
+      __builtin_amdgcn_sched_barrier(0);
+      pv();
+      qk();
+      pin_o();
+      pin_s();
+      __builtin_amdgcn_s_setprio(0);
+      end_step();
+    }
+    if (NTw > 0) {                                                      // last tile of this wave: softmax, then PV alone
+#ifndef P3V_PP_NOVALU
+      softmax(NTw - 1);
+#endif
+      end_step();
+      if (NTw <= NT - 3) issue_batch(NTw);
+      pv();
+      pin_o();
+      end_step();
+    }
+    while (step <= 2 * NT + 1) {                                        // done (or never had rows): DMA share + barriers only
+      const int ls = step - grp;
+      if (ls >= 0 && !(ls & 1) && (ls >> 1) <= NT - 3 && (ls >> 1) > NTw) issue_batch(ls >> 1);
+      end_step();
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  const float l_fin[2] = {rows_sum(ol[0][0]), rows_sum(ol[1][0])};   // the sum sits in the g = 0 lane of the query's column (all lanes take part)
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    if (!qvalid[u]) continue;
+    const bool ok = l_fin[u] > 0.f;                                  // a query that is itself padding: 0 (Q7)
+    const float inv = ok ? 1.f / l_fin[u] : 0.f;
+    bf16_t* op = p.out + ((size_t)b * p.L + (q0 + u * 16 + qi)) * (size_t)(p.nh * HD) + head * HD + 4 * g;
+#pragma unroll
+    for (int d = 0; d < NDT; ++d) {
+      u32x2_t w;
+      w[0] = ok ? pack_bf16x2(o[u][d][0] * inv, o[u][d][1] * inv) : 0u;
+      w[1] = ok ? pack_bf16x2(o[u][d][2] * inv, o[u][d][3] * inv) : 0u;
+      *(u32x2_t*)(op + 16 * d) = w;
+    }
+  }
+}
+
+// Which prompt-sized kernel (measured, B = 1, 32 heads x 96, causal, random data; profiles/r03_attn_prefill_kernels.txt):
+//   tokens      1024    2531     8192     32768    |  CLIP 17 x 577 (hd 64)   8 x 512
+//   dma (128 q)  29 us   80 us   609 us   7.42 ms  |   56 us                   39 us
+//   pp  (256 q)  36 us   77 us   504 us   6.30 ms  |   73 us                   49 us
+// the 8-wave kernel needs ~10 query blocks per head before its better steady state beats its coarser tail
+constexpr int P3V_ATTN_PP_MIN_L = 2048;
 template <int HD>
 static int launch_attn_prefill(const AttnP& p, hipStream_t s) {
   constexpr int LDS = 2 * (64 * (HD * 2 + 16) + HD * (64 * 2 + 16));
@@ -651,6 +1088,22 @@ static int launch_attn_prefill(const AttnP& p, hipStream_t s) {
     AttnP q = p;
     const size_t kv_bytes = (size_t)(p.past + p.L) * HD * 4;     // one head's K + V^T
     q.head_group = kv_bytes * p.nh <= (64u << 20) ? p.nh : (p.nh % 8 == 0 && kv_bytes * 8 <= (128u << 20) ? 8 : (p.nh % 4 == 0 ? 4 : p.nh));
+    const int pp = p3v_tuning().attn_pp;                         // -1: by shape; 0 / 1: pin (kernel tests run both)
+    if (pp > 0 || (pp < 0 && p.L >= P3V_ATTN_PP_MIN_L && (p.q_prescaled || HD == 64))) {   // (<96, plain>: 5 spilled registers, tests only)
+      constexpr int LDS3 = 3 * 64 * HD * 2 + 4 * HD * 128;     // K ring of 3 tiles + V^T ring of 4
+      static bool attr3_set = false;
+      if (!attr3_set) {
+        if (hipFuncSetAttribute((const void*)k_attn_prefill_pp<HD, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS3) != hipSuccess ||
+            hipFuncSetAttribute((const void*)k_attn_prefill_pp<HD, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS3) != hipSuccess)
+          return P3V_ERR_HIP;
+        attr3_set = true;
+      }
+      const dim3 grid3(p.nh * p3v_cdiv(p.L, 256), 1, p.B);
+      if (p.q_prescaled) hipLaunchKernelGGL((k_attn_prefill_pp<HD, true>), grid3, dim3(512), LDS3, s, q);
+      else hipLaunchKernelGGL((k_attn_prefill_pp<HD, false>), grid3, dim3(512), LDS3, s, q);
+      P3V_CHECK_LAUNCH();
+      return P3V_OK;
+    }
     hipLaunchKernelGGL(k_attn_prefill_dma<HD>, dim3(p.nh * p3v_cdiv(p.L, 128), 1, p.B), dim3(256), LDS2, s, q);
   } else {
     hipLaunchKernelGGL(k_attn_prefill<HD>, grid, dim3(256), LDS, s, p);
@@ -679,6 +1132,8 @@ extern "C" int p3v_attention(const p3v_attn_args_t* a, void* stream) {
   p.B = a->B; p.L = a->L; p.nh = a->n_heads; p.nkv = a->n_kv; p.past = a->past; p.past_t = a->past_t;
   p.past_div = a->past_div > 0 ? a->past_div : 1; p.new_t = a->new_t; p.pad_div = a->pad_div > 0 ? a->pad_div : 1;
   p.causal = a->causal; p.scale = a->scale;
+  p.q_prescaled = a->q_prescaled != 0;
+  p.sc2 = p.q_prescaled ? 1.f : a->scale * 1.4426950408889634f;
   p.n_split = a->n_split;
   p.split_mode = (a->L <= P3V_DECODE_MAX_L && a->n_split > 1) ? 1 : 0;
   if (p.split_mode && !a->ws) return P3V_ERR_ARG;

@@ -247,7 +247,7 @@ __global__ void __launch_bounds__(256) k_rope_kv_append(const bf16_t* __restrict
                                                         const float* __restrict__ sin_t, bf16_t* __restrict__ q_out,
                                                         bf16_t* __restrict__ k_dst, bf16_t* __restrict__ v_dst, int L,
                                                         int nh, int nkv, int hd, int past, const int32_t* d_past,
-                                                        int dst_t, int dst_off_is_past, int tab_t, int tab_div, int skip_v) {
+                                                        int dst_t, int dst_off_is_past, int tab_t, int tab_div, int skip_v, float q_scale) {
   const int tok = blockIdx.x, b = tok / L, l = tok % L;
   if (d_past) past = *d_past;
   const int half = hd >> 1, hc = half >> 3;          // 8-wide chunks per half
@@ -262,6 +262,7 @@ __global__ void __launch_bounds__(256) k_rope_kv_append(const bf16_t* __restrict
   for (int it = threadIdx.x; it < n_rot + n_v; it += blockDim.x) {
     if (it < n_rot) {
       const int head = it / hc, c = it % hc;
+      const float qs = head < nh ? q_scale : 1.f;           // queries leave pre-scaled (one rounding, after the multiply)
       const bf16_t* src = row + (size_t)head * hd + c * 8;
       u32x4_t lo = *(const u32x4_t*)src, hi = *(const u32x4_t*)(src + half);
       u32x4_t olo = lo, ohi = hi;
@@ -275,8 +276,8 @@ __global__ void __launch_bounds__(256) k_rope_kv_append(const bf16_t* __restrict
 #pragma unroll
       for (int j = 0; j < 4 && rot; ++j) {
         const float a0 = bf16lo(lo[j]), a1 = bf16hi(lo[j]), b0 = bf16lo(hi[j]), b1 = bf16hi(hi[j]);
-        olo[j] = pack_bf16x2(a0 * cs[2 * j] - b0 * sn[2 * j], a1 * cs[2 * j + 1] - b1 * sn[2 * j + 1]);
-        ohi[j] = pack_bf16x2(b0 * cs[2 * j] + a0 * sn[2 * j], b1 * cs[2 * j + 1] + a1 * sn[2 * j + 1]);
+        olo[j] = pack_bf16x2((a0 * cs[2 * j] - b0 * sn[2 * j]) * qs, (a1 * cs[2 * j + 1] - b1 * sn[2 * j + 1]) * qs);
+        ohi[j] = pack_bf16x2((b0 * cs[2 * j] + a0 * sn[2 * j]) * qs, (b1 * cs[2 * j + 1] + a1 * sn[2 * j + 1]) * qs);
       }
       bf16_t* dst;
       if (head < nh) dst = q_out + (((size_t)b * nh + head) * L + l) * hd + c * 8;
@@ -337,13 +338,14 @@ __global__ void __launch_bounds__(256) k_v_transpose_append(const bf16_t* __rest
 extern "C" int p3v_rope_kv_append(const uint16_t* qkv, const float* cos_t, const float* sin_t, uint16_t* q_out,
                                   uint16_t* k_dst, uint16_t* v_dst, int B, int L, int n_heads, int n_kv, int hd, int past,
                                   const int32_t* d_past, int dst_t, int dst_off_is_past, int tab_t, int tab_div,
-                                  void* stream) {
+                                  float q_scale, void* stream) {
   if (!qkv || !q_out || !k_dst || !v_dst || (!cos_t) != (!sin_t)) return P3V_ERR_ARG;
+  if (!(q_scale > 0.f)) return P3V_ERR_ARG;
   if (B < 0 || L < 0 || hd % 16 || hd > 96 || n_heads <= 0 || n_kv <= 0 || tab_div <= 0) return P3V_ERR_ARG;
   if (B * L == 0) return P3V_OK;
   const int bulk_v = L >= 32;                             // prefill-shaped: V goes through the LDS transpose kernel
   hipLaunchKernelGGL(k_rope_kv_append, dim3(B * L), dim3(256), 0, (hipStream_t)stream, qkv, cos_t, sin_t, q_out, k_dst,
-                     v_dst, L, n_heads, n_kv, hd, past, d_past, dst_t, dst_off_is_past, tab_t, tab_div, bulk_v);
+                     v_dst, L, n_heads, n_kv, hd, past, d_past, dst_t, dst_off_is_past, tab_t, tab_div, bulk_v, cos_t ? q_scale : 1.f);
   P3V_CHECK_LAUNCH();
   if (bulk_v) {
     hipLaunchKernelGGL(k_v_transpose_append, dim3(p3v_cdiv(L, 64), n_kv, B), dim3(256), 0, (hipStream_t)stream, qkv, v_dst, L,

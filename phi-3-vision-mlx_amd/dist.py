@@ -152,12 +152,13 @@ def prefill_requests(model, reqs, max_tokens, width=None):
     requests are sorted by length, each group of equal (or, up to GROUP_PAD pad rows, nearly equal) length is prefilled as its own batch straight into adjacent rows of a
     slot state (`model.prefill_slot`: right-aligned to the longest prompt, per-row left padding and position tables -- the
     geometry `_tokenize` gives a padded row, phi.py:238-240), and decode then runs all rows as ONE graph-replayed batch.
+    The slot window is W + max_tokens with W the longest prompt of the WHOLE request list, so the rows get the RoPE factors
+    the padded batch would pick (phi.py:492; short up to 4096, long beyond) and, with `quantize_cache=True`, the int8 cache.
     Returns (first tokens int32 [B, 1] in SLOT order, cache, order) with order[slot] = request index; None when the
-    model has no slot states or prompt + max_tokens leaves the short-RoPE window (callers then take the padded batch)."""
+    model has no slot states (callers then take the padded batch)."""
     lens = [int(np.asarray(r["input_ids"]).shape[-1]) for r in reqs]
     W = max(max(lens), width or 0)
-    if not hasattr(model, "new_slot_state") or W + max_tokens > model.cfg.original_max_position_embeddings \
-            or getattr(model.cfg, "use_quantized_cache", False):
+    if not hasattr(model, "new_slot_state"):
         return None
     from .processor import collate_requests
     order = sorted(range(len(reqs)), key=lambda i: (-lens[i], i))

@@ -491,9 +491,10 @@ class Phi3VModel:
                 else:                                           # prefill: exact attention, quantised copy stored
                     if past > 0 and not getattr(st, "fresh_rows", False):   # long cached call (constrain with > 16 tokens): attend on a
                         ops.kv_dequantize(st.k8[i], st.v8[i], st.ks[i], st.vs[i], st.k_tmp, st.v_tmp, past)   # dequantised copy
-                    ops.rope_kv_append(qkv, st.cos, st.sin, q, st.k_tmp, st.v_tmp, B, L, nh, nkv, hd, past, st.Tp, True, st.T, 1)
+                    ops.rope_kv_append(qkv, st.cos, st.sin, q, st.k_tmp, st.v_tmp, B, L, nh, nkv, hd, past, st.Tp, True, st.T, 1,
+                                       q_scale=scale * ops.Q_PRESCALE)
                     ops.attention(q, o, B, L, nh, nkv, hd, scale, True, past=past, k_past=st.k_tmp, v_past=st.v_tmp,
-                                  past_t=st.Tp, pad_len=st.pad_len, new_is_cache=True)
+                                  past_t=st.Tp, pad_len=st.pad_len, new_is_cache=True, q_prescaled=True)
                     ops.kv_quantize(st.k_tmp, st.v_tmp, st.k8[i], st.v8[i], st.ks[i], st.vs[i], past, L)
             elif n_beam > 1:
                 ops.rope_kv_append(qkv, st.cos, st.sin, q, k_new, v_new, B, L, nh, nkv, hd, past, Lp, False, st.T, n_beam)
@@ -508,9 +509,12 @@ class Phi3VModel:
                 ops.attention_decode(qkv, rc, rs, rb, st.k[i], st.v[i], o, B, L, nh, nkv, hd, scale, past, st.Tp, ws, n_split,
                                      pad_len=st.pad_len, d_past=d_past, merge_in_launch=bufs.get("attn_merge", False))
             else:
-                ops.rope_kv_append(qkv, st.cos, st.sin, q, st.k[i], st.v[i], B, L, nh, nkv, hd, past, st.Tp, True, st.T, 1)
+                # queries leave the RoPE kernel multiplied by scale * log2(e) (before their one rounding to bf16, as
+                # phi.py:454 scales q before the product): the prefill attention's softmax is then the exponential alone
+                ops.rope_kv_append(qkv, st.cos, st.sin, q, st.k[i], st.v[i], B, L, nh, nkv, hd, past, st.Tp, True, st.T, 1,
+                                   q_scale=scale * ops.Q_PRESCALE)
                 ops.attention(q, o, B, L, nh, nkv, hd, scale, True, past=past, k_past=st.k[i], v_past=st.v[i],
-                              past_t=st.Tp, pad_len=st.pad_len, new_is_cache=True)
+                              past_t=st.Tp, pad_len=st.pad_len, new_is_cache=True, q_prescaled=True)
             if last_only and i == cfg.num_hidden_layers - 1 and L > 1:
                 o = o.view(B, L, -1)[:, -1].contiguous()
                 x = x.view(B, L, -1)[:, -1].contiguous()

@@ -263,19 +263,27 @@ def rope_table(pos, inv_freq, scale):
 
 
 def rope_kv_append(qkv, cos_t, sin_t, q_out, k_dst, v_dst, B, Lq, nh, nkv, hd, past, dst_t, dst_off_is_past, tab_t=0,
-                   tab_div=1, d_past=None):
-    """split + _rotate_half + KVCache append (phi.py:443-452, 542-548)."""
+                   tab_div=1, d_past=None, q_scale=1.0):
+    """split + _rotate_half + KVCache append (phi.py:443-452, 542-548).  q_scale: rotated queries are multiplied by it
+    before their rounding to bf16 (`attention(..., q_prescaled=True)` then skips the per-score multiply)."""
     L.check(L.lib().p3v_rope_kv_append(_p(qkv), _p(cos_t), _p(sin_t), _p(q_out), _p(k_dst), _p(v_dst), B, Lq, nh, nkv, hd,
-                                       int(past), _p(d_past), dst_t, int(dst_off_is_past), tab_t, tab_div, _stream()),
+                                       int(past), _p(d_past), dst_t, int(dst_off_is_past), tab_t, tab_div, float(q_scale),
+                                       _stream()),
             "rope_kv_append")
 
 
+Q_PRESCALE = 1.4426950408889634          # log2(e): q_scale = Q_PRESCALE * softmax scale for q_prescaled attention
+
+
 def attention(q, out, B, Lq, nh, nkv, hd, scale, causal, k_new=None, v_new=None, new_t=0, past=0, k_past=None, v_past=None,
-              past_t=0, past_div=1, pad_len=None, pad_div=1, d_past=None, ws=None, n_split=0, new_is_cache=False):
+              past_t=0, past_div=1, pad_len=None, pad_div=1, d_past=None, ws=None, n_split=0, new_is_cache=False,
+              q_prescaled=False):
     """softmax((q*scale) k^T + mask) v (phi.py:454-457 / phi.py:148), mask never materialised.
-    K tensors are [B, nkv, t, hd]; V tensors are TRANSPOSED [B, nkv, hd, t] (t = past_t / new_t)."""
+    K tensors are [B, nkv, t, hd]; V tensors are TRANSPOSED [B, nkv, hd, t] (t = past_t / new_t).
+    q_prescaled: q already carries scale * log2(e) (rope_kv_append's q_scale = Q_PRESCALE * scale)."""
     args = L.AttnArgs(_p(q), _p(k_past), _p(v_past), _p(k_new), _p(v_new), _p(out), _p(pad_len), _p(d_past), _p(ws),
-                      B, Lq, nh, nkv, hd, int(past), past_t, past_div, new_t, pad_div, int(causal), float(scale), n_split, int(new_is_cache))
+                      B, Lq, nh, nkv, hd, int(past), past_t, past_div, new_t, pad_div, int(causal), float(scale), n_split, int(new_is_cache),
+                      int(bool(q_prescaled)))
     L.check(L.lib().p3v_attention(C.byref(args), _stream()), "attention")
     return out
 

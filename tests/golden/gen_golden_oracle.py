@@ -7,6 +7,7 @@ top-2 margin as a fraction of max|logit|.  The lm_head is the decisive-argmax he
 N(0, 0.02) head never allows (its top-2 gap is a few bf16 ulps of the logits; tools/precision_study.py).
 
   tiny_oracle.npz   tiny text / batch / vision models + choose / constrain traces (decision margins recorded)
+  tiny_serve_oracle.npz  7 mixed requests on the tiny vision model, each at B = 1 under one head (serving / sharding tests)
   c1_oracle.npz     FULL-SIZE Phi-3-mini-128K, BASELINE config 1 (128-token prompt, text-only): prefill + 7 decode steps
   c2_oracle.npz     FULL-SIZE Phi-3-Vision, BASELINE config 2 = bench.py's rank-0 request (2531-token prompt): prefill + 3 steps
   c4_oracle.npz     FULL-SIZE, one GPU's share of BASELINE config 4 (4 image + 4 text requests), each run on its own at
@@ -130,7 +131,7 @@ class Prefilled:
 
 def search_head(reqs, base_head, n_steps, max_seeds=20000, first_seed=0, need="all", min_distinct=1):
     """Smallest lm_head seed for which the requests' greedy runs are clear.  need = "all": every step of every request;
-    need = "prefill": the first step of every request (then the decode steps are taken as they come).
+    need = "prefill": the first step of every request (then the decode steps are taken as they come); an int: that many steps.
     min_distinct: a greedy run that repeats one token is a weak witness -- ask for some variety."""
     base = base_head.to(F32)
     for hs in range(first_seed, first_seed + max_seeds):
@@ -140,7 +141,7 @@ def search_head(reqs, base_head, n_steps, max_seeds=20000, first_seed=0, need="a
             continue                                        # cheap filter: the prefill step of every request
         out = []
         for r in reqs:
-            res = r.greedy(head, n_steps, need_clear_steps=n_steps if need == "all" else 1, norms=norms)
+            res = r.greedy(head, n_steps, need_clear_steps=n_steps if need == "all" else 1 if need == "prefill" else int(need), norms=norms)
             if res is None:
                 break
             out.append(res)
@@ -216,6 +217,29 @@ def tiny():
             pack("vis_", hs, res, out)
     np.savez_compressed(os.path.join(HERE, "tiny_oracle.npz"), **out)
     print("wrote tiny_oracle.npz")
+
+
+def tiny_serve():
+    """tiny_serve_oracle.npz: the mixed request set of golden_inputs.SERVE_TEXTS (1 image + 6 text prompts, 4..2500+ tokens)
+    on the tiny VISION model, every request run on its own at B = 1 (the reference's only image path,
+    phi_3_vision_mlx.py:377-378) under ONE lm_head: SERVE_STEPS greedy tokens + clearance per (request, step).  The head
+    seed makes the first 2 steps of every request clear (no seed in 20000 clears 3); later steps are taken as they come (a test compares a request's tokens up to its
+    first unclear step).  Pins the continuous-batching engine, the HTTP handler on it, dist.prefill_requests and
+    dist.generate_sharded to the oracle."""
+    from golden_inputs import SERVE_STEPS, serve_requests
+    cfg = make_config(tiny_config_dict(vision=True))
+    w = synth_weights(cfg, seed=0, std_scale=4.0)
+    base = w["lm_head.weight"]
+    o = orc.OraclePhi3V(cfg, w, cache_fp32=True)
+    reqs = [Prefilled(o, {k: (torch.from_numpy(np.asarray(v)) if k == "pixel_values" else v) for k, v in r.items()}, SERVE_STEPS)
+            for r in serve_requests(Phi3VProcessor(None))]
+    hs, results = search_head(reqs, base, SERVE_STEPS, need=2, min_distinct=2)
+    out = dict(COMMON, head_seed=np.asarray([hs], dtype=np.int32), n_ids=np.asarray([r.S for r in reqs], dtype=np.int32))
+    out["tokens"] = np.concatenate([r[0].numpy() for r in results]).astype(np.int32)              # [7, SERVE_STEPS]
+    out["margins"] = np.concatenate([r[2].numpy() for r in results]).astype(np.float32)
+    print(f"  tiny serve: head_seed {hs}, clear {(out['margins'] > 1.0).sum()} of {out['margins'].size}, tokens {out['tokens'].tolist()}", flush=True)
+    np.savez_compressed(os.path.join(HERE, "tiny_serve_oracle.npz"), **out)
+    print("wrote tiny_serve_oracle.npz")
 
 
 def _full_oracle(transform=None):
@@ -381,6 +405,8 @@ if __name__ == "__main__":
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
     if which in ("tiny", "all"):
         tiny()
+    if which in ("tiny_serve", "all"):
+        tiny_serve()
     if which in ("full", "all"):
         full()
     if which in ("c3", "all"):

@@ -29,6 +29,20 @@ def make_image(w, h, kind, seed):
     return Image.fromarray(a, "RGB")
 
 
+# A mixed request set for the tiny vision model (serving / sharding tests): user prompts (request 0 carries an image) and
+# the same prompts as the chat template renders them (phi_3_vision_mlx.py:346-351).  tests/golden/tiny_serve_oracle.npz
+# holds the per-request B = 1 oracle tokens.
+SERVE_PROMPTS = ["What is shown?", "hi", ("a longer question " * 6).strip(), "mid size prompt here", "x",
+                 ("tell me more about it " * 3).strip(), "last one"]
+SERVE_TEXTS = [f"<|user|>\n{'<|image_1|>' + chr(10) if i == 0 else ''}{p}<|end|>\n<|assistant|>\n" for i, p in enumerate(SERVE_PROMPTS)]
+SERVE_STEPS = 6
+
+
+def serve_requests(proc):
+    """B = 1 model inputs of SERVE_TEXTS (request 0 carries the seeded 336x336 noise image)."""
+    return [proc(t, [make_image(336, 336, "noise", 0)]) if "<|image_1|>" in t else proc(t) for t in SERVE_TEXTS]
+
+
 class _Enc:
     def __init__(self, input_ids):
         self.input_ids = input_ids

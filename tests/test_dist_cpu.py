@@ -116,6 +116,75 @@ def test_generate_sharded_world2_equals_single_process(tmp_path):
     assert all(os.path.exists(tmp_path / f"gen{r}") for r in range(world))
 
 
+class FastImageProcessor:
+    """The image stage is not what this file tests (tests/test_processor_golden.py pins it to the reference): a stand-in with
+    the real OUTPUT GEOMETRY of a 336x336 request (17 crops, 2509 image tokens -> 2531-token prompts)
+    whose pixel content is a cheap function of the image, so 64-request tables run in seconds on the CPU."""
+
+    def __call__(self, images, dtype=None):
+        px = [np.asarray(im, dtype=np.float64).mean(axis=(0, 1)) for im in images]
+        pv = np.stack([np.broadcast_to(p[None, :, None, None], (17, 3, 2, 2)) for p in px]).copy()
+        return {"pixel_values": pv, "image_sizes": [[1344, 1344]] * len(images), "num_img_tokens": [2509] * len(images)}
+
+
+def config4_table(n):
+    """BASELINE config 4's request table: n/2 single-image VQA prompts + n/2 text prompts of length ~U[16, 256]."""
+    from golden_inputs import make_image
+    rng = np.random.default_rng(4)
+    prompts, images = [], []
+    for i in range(n):
+        if (i // 8) % 2 == 0:                                # r::8 sharding then gives every rank images AND texts
+            prompts.append(f"<|image_1|>\nWhat is in image {i}?")
+            images.append(make_image(32, 32, "noise", i))
+        else:
+            prompts.append("t" * int(rng.integers(16, 257)))
+            images.append(None)
+    return prompts, images
+
+
+def _worker_config4(rank, world, port, out_dir, n):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path[:0] = [root, os.path.join(root, "tests", "golden")]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from phi_3_vision_mlx_amd import api, dist as pd
+    from phi_3_vision_mlx_amd.processor import Phi3VProcessor, collate_requests
+    proc = Phi3VProcessor(None, return_mx=False)
+    proc.img_processor = FastImageProcessor()
+    prompts, images = config4_table(n)
+    mine = (prompts, images) if rank == 0 else (["junk"], None)          # only rank 0 holds the request table
+    got = pd.generate_sharded(*mine, preload=(StubModel(), proc), max_tokens=6, max_batch=8, return_tokens=True)
+    assert len(got) == n and all(g is not None for g in got)
+    if rank == 0:                                                        # the single-process result: ONE batch of all requests
+        reqs = []
+        for p_, im in zip(prompts, images):
+            text, imgs = api._apply_chat_template(p_, im, False)
+            reqs.append(proc(text, imgs) if imgs is not None else proc(text))
+        lens = [np.asarray(r["input_ids"]).shape[-1] for r in reqs]
+        assert max(lens) > 2500 and min(lens) < 300                      # mixed image / text lengths, as config 4
+        want = pd.generate_rows(StubModel(), proc, collate_requests(reqs), 6, return_tokens=True)
+        assert got == want, [(i, g, w) for i, (g, w) in enumerate(zip(got, want)) if g != w][:3]
+        assert len({tuple(g) for g in got}) > n // 2                     # not a constant
+    boxes = [None] * world
+    dist.all_gather_object(boxes, got)
+    assert all(b == got for b in boxes)                                  # every rank ends up with the same full list
+    dist.barrier()
+    dist.destroy_process_group()
+    open(os.path.join(out_dir, f"c4_{rank}"), "w").write("ok")
+
+
+@pytest.mark.parametrize("n", [64, 13])
+def test_config4_table_over_8_ranks_equals_single_process(tmp_path, n):
+    """BASELINE config 4 as the scaling bench runs it: 64 mixed requests split r::8 over EIGHT ranks (8 per rank, uneven
+    prompt lengths 2531 vs 16..256) -- and 13 requests, so that some ranks serve 2 and some 1 -- with rank 0 alone
+    holding the table: request-ordered output on every rank == the single-process batch."""
+    world, port = 8, _free_port()
+    mp.spawn(_worker_config4, args=(world, port, str(tmp_path), n), nprocs=world, join=True)
+    assert all(os.path.exists(tmp_path / f"c4_{r}") for r in range(world))
+
+
 def test_sharding_world2_gloo(tmp_path):
     world, port = 2, _free_port()
     mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)

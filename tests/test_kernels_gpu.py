@@ -304,6 +304,12 @@ def test_rope_table_and_append(ops, orc, L, T, past):
     assert torch.equal(vc[:, :, :, past:past + L].cpu().transpose(2, 3), x[:, nh + nkv:])
     assert vc[:, :, :, :past].abs().sum().item() == 0
     assert kc[:, :, :past].abs().sum().item() == 0 and kc[:, :, past + L:].abs().sum().item() == 0
+    # q_scale: queries (only) are multiplied before their ONE rounding to bf16; keys and values are untouched
+    qs = (hd ** -0.5) * ops.Q_PRESCALE
+    q2, kc2, vc2 = torch.zeros_like(q), torch.zeros_like(kc), torch.zeros_like(vc)
+    ops.rope_kv_append(qkv.cuda(), cos, sin, q2, kc2, vc2, B, L, nh, nkv, hd, past, T, True, T, 1, q_scale=qs)
+    close(q2, (orc.rotate_half(x[:, :nh], cs, sn) * qs).to(BF16), atol=2e-3)
+    assert torch.equal(kc2, kc) and torch.equal(vc2, vc)
 
 
 def _attn_ref(orc, q, k, v, scale, allowed):
@@ -339,6 +345,106 @@ def test_attention(ops, orc, B, L, past, hd, nh, causal, pads):
     allowed = allowed.expand(B, 1, L, T)
     ref = _attn_ref(orc, q, k, v, hd ** -0.5, allowed).transpose(1, 2).reshape(B, L, nh * hd)
     close(out, ref, rtol=2 ** -6, atol=2e-2)
+
+
+def _prefill_case(ops, orc, B, L, past, hd, nh, causal, pads, prescaled, pp, spike=None, seed=40, q_std=1.0):
+    """Prompt-sized attention through p3v_attention with the kernel pinned (pp = 1: k_attn_prefill_pp, 0: k_attn_prefill_dma)
+    vs the oracle's fp32 attention.  prescaled: q goes in multiplied by scale * log2(e) and rounded once (what
+    p3v_rope_kv_append's q_scale produces); the reference then uses exactly those bf16 values divided back in fp32."""
+    T = past + L
+    Tp = (T + 63) // 64 * 64
+    scale = hd ** -0.5
+    q, k, v = g((B, nh, L, hd), seed, q_std), g((B, nh, T, hd), seed + 1), g((B, nh, T, hd), seed + 2)
+    if spike is not None:                      # one key that beats every other score of ONE query by far: the reference of
+        qb, qr, kt = spike                     # that query's exponent jumps by much more than 2^8 in the middle of the walk
+        k[qb, :, kt] = q[qb, :, qr] * 6.0
+    q_in = (q.float() * (scale * ops.Q_PRESCALE)).to(BF16) if prescaled else q
+    q_ref = q_in.float() / (scale * ops.Q_PRESCALE) if prescaled else q.float()
+    pad = torch.tensor(pads if pads else [0] * B, dtype=torch.int32)
+    out = torch.full((B, L, nh * hd), float("nan"), dtype=BF16).cuda()
+    kc = torch.zeros((B, nh, Tp, hd), dtype=BF16)
+    vc = torch.zeros((B, nh, hd, Tp), dtype=BF16)
+    kc[:, :, :T], vc[:, :, :, :T] = k, v.transpose(2, 3)
+    old = ops.set_tuning("attn_pp", pp)
+    try:
+        ops.attention(q_in.cuda(), out, B, L, nh, nh, hd, scale, causal, past=past, k_past=kc.cuda(), v_past=vc.cuda(), past_t=Tp,
+                      pad_len=pad.cuda() if pads else None, new_is_cache=True, q_prescaled=prescaled)
+        torch.cuda.synchronize()
+    finally:
+        ops.set_tuning("attn_pp", old)
+    t = torch.arange(T)[None, None, None, :]
+    qpos = (past + torch.arange(L))[None, None, :, None]
+    allowed = (t >= pad[:, None, None, None]) & (qpos >= pad[:, None, None, None])
+    if causal:
+        allowed = allowed & (t <= qpos)
+    allowed = allowed.expand(B, 1, L, T)
+    ref = _attn_ref(orc, q_ref, k, v, scale, allowed).transpose(1, 2).reshape(B, L, nh * hd)
+    valid = (qpos >= pad[:, None, None, None]).expand(B, 1, L, 1).reshape(B, L, 1).expand(B, L, nh * hd)
+    got = out.float().cpu()
+    assert torch.isfinite(got).all()
+    assert (got[~valid] == 0).all()                                     # a query that is itself padding outputs 0 (Q7)
+    close(got[valid], ref[valid], rtol=2 ** -6, atol=2e-2)
+    return got
+
+
+@pytest.mark.parametrize("pp", [1, 0], ids=["pingpong", "dma"])
+@pytest.mark.parametrize("prescaled", [True, False], ids=["prescaled", "plain"])
+@pytest.mark.parametrize("B,L,past,hd,nh,causal,pads", [
+    (1, 700, 0, 96, 2, True, None),            # 3 query blocks of 256, the last one ragged (188 rows: two idle waves)
+    (2, 300, 0, 96, 2, True, [0, 77]),         # left padding inside the first tile; pad query rows
+    (1, 257, 0, 96, 1, True, None),            # second block holds ONE query
+    (1, 40, 200, 96, 2, True, None),           # cached call: 40 new queries over 200 past keys (constrain's long steps)
+    (2, 33, 100, 96, 1, True, [3, 100]),       # row 1: every past key is padding
+    (2, 577, 0, 64, 2, False, None),           # CLIP: no mask, head_dim 64, 577 = 2 x 256 + 65
+    (1, 1100, 0, 96, 1, True, None),           # 18 tiles: ring wrap-around many times
+    (1, 64, 0, 96, 1, True, None), (1, 17, 0, 96, 2, True, None),      # one tile; fewer queries than one wave
+])
+def test_attention_prefill_kernels(ops, orc, B, L, past, hd, nh, causal, pads, prescaled, pp):
+    _prefill_case(ops, orc, B, L, past, hd, nh, causal, pads, prescaled, pp)
+
+
+@pytest.mark.parametrize("pp", [1, 0], ids=["pingpong", "dma"])
+def test_attention_prefill_long_context_spot_rows(ops, orc, pp):
+    """12288 queries x 12288 keys x 8 heads (K / V^T far larger than the L2: the LDS-DMA tiles arrive LATE, which is what
+    exposes a missing wait or a ring slot reused too early -- the first version of the ping-pong kernel passed every
+    small-shape test and failed here).  64 query rows spread over the length, all heads, against the fp32 oracle formula."""
+    B, L, nh, hd = 1, 12288, 8, 96
+    scale = hd ** -0.5
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    q = torch.randn((B, nh, L, hd), device="cuda", generator=gen).to(BF16)
+    k = torch.randn((B, nh, L, hd), device="cuda", generator=gen).to(BF16)
+    v = torch.randn((B, nh, L, hd), device="cuda", generator=gen).to(BF16)
+    q_in = (q.float() * (scale * ops.Q_PRESCALE)).to(BF16)
+    vt = v.transpose(2, 3).contiguous()
+    out = torch.full((B, L, nh * hd), float("nan"), dtype=BF16, device="cuda")
+    old = ops.set_tuning("attn_pp", pp)
+    try:
+        for _ in range(3):                                              # races are timing-dependent: a few launches
+            ops.attention(q_in, out, B, L, nh, nh, hd, scale, True, k_past=k, v_past=vt, past_t=L, new_is_cache=True, q_prescaled=True)
+        torch.cuda.synchronize()
+    finally:
+        ops.set_tuning("attn_pp", old)
+    assert torch.isfinite(out.float()).all()
+    rows = torch.cat([torch.arange(0, L, 197), torch.tensor([255, 256, 4095, 4096, L - 257, L - 1])]).unique()
+    qr = (q_in[0, :, rows].float().cpu() / (scale * ops.Q_PRESCALE))   # [nh, n, hd]
+    kf, vf = k[0].float().cpu(), v[0].float().cpu()
+    w = (qr * scale) @ kf.transpose(1, 2)                               # [nh, n, L]
+    w = w.masked_fill(torch.arange(L)[None, None, :] > rows[None, :, None], float("-inf"))
+    ref = (torch.softmax(w, dim=-1) @ vf).transpose(0, 1).reshape(len(rows), nh * hd)
+    close(out[0, rows].float().cpu(), ref, rtol=2 ** -6, atol=2e-2)
+
+
+@pytest.mark.parametrize("pp", [1, 0], ids=["pingpong", "dma"])
+def test_attention_prefill_reference_jump_and_large_scores(ops, orc, pp):
+    """The ping-pong kernel keeps a per-query reference for the exponent and moves it only when a tile's maximum exceeds it
+    by more than 2^8 (guide T13 hazard: O, l and the pending P must be rescaled exactly once).  (a) a spiked key in the
+    middle of the walk forces that slow path for ONE query while its neighbours stay on the fast path; (b) scores of
+    magnitude ~100 (log2 units) with the FIRST tile far below the later ones; (c) the first visible tile sets the reference
+    even when its scores are hugely negative (no underflow of the whole row)."""
+    _prefill_case(ops, orc, 1, 600, 0, 96, 2, True, None, True, pp, spike=(0, 450, 300))
+    _prefill_case(ops, orc, 1, 600, 0, 96, 2, True, None, False, pp, spike=(0, 599, 64))
+    _prefill_case(ops, orc, 1, 400, 0, 96, 1, True, None, True, pp, q_std=6.0, seed=90)
+    _prefill_case(ops, orc, 2, 577, 0, 64, 1, False, None, False, pp, q_std=8.0, seed=91)
 
 
 @pytest.mark.parametrize("B,L,past,nh,n_split,pads", [(1, 1, 300, 4, 5, None), (2, 1, 63, 2, 1, [0, 7]), (1, 6, 130, 2, 3, None),

@@ -1,0 +1,321 @@
+"""Serving and sharding paths against ORACLE fixtures: the
+continuous-batching engine, the HTTP handler on top of it, dist.prefill_requests and dist.generate_sharded produce, per
+request, the tokens of the request's own B = 1 oracle run -- the reference runs image prompts at B = 1 only
+(phi_3_vision_mlx.py:377-378) and its server one generate per request (server.py:17), so that run IS the reference
+behaviour of every request whatever it is batched with.
+
+Comparison rule (the fixtures', tests/golden/gen_golden_oracle.py): a free-running request is compared token by token
+up to its first step whose oracle top-2 margin is not clear under the fixture's tolerance; the fixtures' head seeds make
+the first step(s) of EVERY request clear, so every request is pinned on at least its first token."""
+import base64
+import json
+import threading
+import urllib.request
+from io import BytesIO
+
+import numpy as np
+import pytest
+import torch
+
+from test_model_gpu import GOLDEN, _full_model
+
+pytestmark = pytest.mark.gpu
+
+
+def tokens_vs_fixture(got, g, what, rows=None, min_first=1):
+    """got[i]: EOS-trimmed token list of request rows[i].  Returns the number of tokens compared (all equal)."""
+    ref, clear = g["tokens"], g["margins"] > 1.0
+    rows = range(len(got)) if rows is None else rows
+    n = 0
+    for toks, r in zip(got, rows):
+        assert clear[r, :min_first].all(), f"{what}: fixture request {r} is not clear on its first step(s)"
+        for step in range(ref.shape[1]):
+            if not clear[r, step]:
+                break
+            assert step < len(toks), f"{what}: request {r} stopped after {len(toks)} tokens, oracle continues {ref[r].tolist()}"
+            assert toks[step] == int(ref[r, step]), f"{what}: request {r} step {step}: {toks} != oracle {ref[r].tolist()}"
+            n += 1
+            if toks[step] == 32007:
+                break
+    return n
+
+
+def _tiny_serve():
+    from golden_inputs import serve_requests
+    from phi_3_vision_mlx_amd.api import load_synthetic
+    g = np.load(GOLDEN + "/tiny_serve_oracle.npz")
+    model, proc = load_synthetic(blind_model=False, tiny=True, seed=0, std_scale=4.0, device="cuda:0",
+                                 lm_head_spread=float(g["spread"][0]), lm_head_seed=int(g["head_seed"][0]))
+    reqs = serve_requests(proc)
+    assert [int(np.asarray(r["input_ids"]).shape[-1]) for r in reqs] == g["n_ids"].tolist()
+    return g, model, proc, reqs
+
+
+class IdTokenizer:
+    """Delegates encoding to the real tokenizer; decodes to the ids themselves so HTTP responses can be compared as tokens."""
+
+    def __init__(self, real):
+        self.real = real
+
+    def __call__(self, *a, **kw):
+        return self.real(*a, **kw)
+
+    def encode(self, *a, **kw):
+        return self.real.encode(*a, **kw)
+
+    def decode(self, ids, **kw):
+        return " ".join(str(int(i)) for i in ids)
+
+    def batch_decode(self, seqs, **kw):
+        return [self.decode(s) for s in seqs]
+
+
+def _png_uri(img):
+    buf = BytesIO()
+    img.save(buf, format="PNG")
+    return "data:image/png;base64," + base64.b64encode(buf.getvalue()).decode()
+
+
+def _post(port, body, timeout=300):
+    req = urllib.request.Request(f"http://127.0.0.1:{port}/v1/completions", data=json.dumps(body).encode(),
+                                 headers={"Content-Type": "application/json"})
+    with urllib.request.urlopen(req, timeout=timeout) as r:
+        return json.loads(r.read())
+
+
+def test_engine_tiny_requests_join_mid_flight_and_match_the_oracle():
+    """engine.ContinuousEngine, 3 slots, 7 requests (one image request of 2534 tokens, texts of 9..115 tokens): four arrive
+    first, three while rows are generating; every request's tokens == its own B = 1 ORACLE run."""
+    from golden_inputs import SERVE_STEPS
+    from phi_3_vision_mlx_amd.engine import ContinuousEngine
+    g, model, proc, reqs = _tiny_serve()
+    eng = ContinuousEngine(model, proc, slots=3, window=4096)
+    handles = [eng.submit(r, SERVE_STEPS) for r in reqs[:4]]
+    for _ in range(2):
+        eng.step()
+    handles += [eng.submit(r, SERVE_STEPS) for r in reqs[4:]]       # arrive while rows are generating
+    eng.run_until_idle()
+    assert all(h.done.is_set() and h.error is None for h in handles)
+    assert eng.joined_mid_flight >= 2 and eng.steps < 7 * SERVE_STEPS and eng.failures == 0     # rows really shared steps
+    n = tokens_vs_fixture([h.tokens for h in handles], g, "engine", min_first=2)
+    assert n >= 20, n
+    big = eng.submit(reqs[1], 5000)                                 # beyond the window: refused, not queued
+    assert big.done.is_set() and isinstance(big.error, ValueError)
+    print(f"tiny engine: {n} free-running tokens of 7 requests equal the oracle's")
+
+
+def test_prefill_requests_groups_nearly_equal_lengths_and_matches_the_oracle():
+    """dist.prefill_requests pads SHORT prompts of different lengths into one prefill group (a short prompt alone still
+    streams every weight once): the image request stays its own group, the six text prompts (9..115 tokens) share one; the
+    decode batch's tokens == each request's B = 1 oracle run."""
+    from golden_inputs import SERVE_STEPS
+    from phi_3_vision_mlx_amd import dist
+    g, model, proc, reqs = _tiny_serve()
+    calls = []
+    real = model.prefill_slot
+
+    def spy(st, row, inputs, **kw):
+        calls.append(np.asarray(inputs["input_ids"]).reshape(-1, np.asarray(inputs["input_ids"]).shape[-1]).shape[0])
+        return real(st, row, inputs, **kw)
+    model.prefill_slot = spy
+    try:
+        got = dist.generate_requests(model, proc, reqs, SERVE_STEPS, return_tokens=True)
+    finally:
+        model.prefill_slot = real
+    assert sorted(calls) == [1, 6], calls
+    assert tokens_vs_fixture(got, g, "prefill_requests", min_first=2) >= 20
+
+
+def test_http_handler_on_the_engine_matches_the_oracle():
+    """POST /v1/completions (concurrent clients; request 0 carries its image as a data URI) -> handler -> chat template ->
+    continuous-batching engine: the response of every request == its B = 1 oracle tokens."""
+    from golden_inputs import SERVE_PROMPTS, SERVE_STEPS, make_image
+    from phi_3_vision_mlx_amd.engine import ContinuousEngine
+    from phi_3_vision_mlx_amd.server import serve_continuous
+    g, model, proc, _ = _tiny_serve()
+    proc.tokenizer = IdTokenizer(proc.tokenizer)
+    httpd, backend = serve_continuous(ContinuousEngine(model, proc, slots=2, window=4096), port=0)
+    threading.Thread(target=httpd.serve_forever, daemon=True).start()
+    port, got = httpd.server_address[1], {}
+    bodies = [{"prompt": SERVE_PROMPTS[0], "images": [_png_uri(make_image(336, 336, "noise", 0))], "max_tokens": SERVE_STEPS},
+              {"prompt": SERVE_PROMPTS[1:4], "max_tokens": SERVE_STEPS}, {"prompt": SERVE_PROMPTS[4], "max_tokens": SERVE_STEPS},
+              {"prompt": SERVE_PROMPTS[5:7], "max_tokens": SERVE_STEPS}]
+    try:
+        ths = [threading.Thread(target=lambda i=i, b=b: got.__setitem__(i, _post(port, b))) for i, b in enumerate(bodies)]
+        [t.start() for t in ths]
+        [t.join() for t in ths]
+    finally:
+        httpd.shutdown()
+        backend.close()
+    assert all(got[i]["model"] == "phi-3-vision" for i in range(4))
+    texts = got[0]["responses"] + got[1]["responses"] + got[2]["responses"] + got[3]["responses"]
+    assert len(texts) == 7
+    toks = [[int(t) for t in s.split()] for s in texts]
+    assert tokens_vs_fixture(toks, g, "HTTP", min_first=2) >= 20
+
+
+def _c4_inputs(proc):
+    from golden_inputs import c4_share
+    share = c4_share(proc.img_processor)
+    return [dict(r, pixel_values=torch.from_numpy(r["pixel_values"]).to("cuda:0")) if "pixel_values" in r else r for r in share]
+
+
+class C4Processor:
+    """What the HTTP path needs from a processor, for BASELINE config 4's SYNTHETIC requests (random token ids have no
+    text form): the prompt "c4:<i>" names request i of the share; an image request is rebuilt FROM THE IMAGE THE CLIENT
+    SENT (decoded data URI -> the real image processor), so the picture really travels through the handler."""
+
+    def __init__(self, proc, share):
+        self.proc, self.share, self.tokenizer = proc, share, IdTokenizer(proc.tokenizer)
+
+    def __call__(self, text, images=None):
+        i = int(text.split("c4:")[1].split("<")[0])
+        r = self.share[i]
+        if images is None:
+            assert "pixel_values" not in r
+            return r
+        out = self.proc.img_processor.device_call(images, "cuda:0")
+        assert torch.equal(out["pixel_values"].cpu().float(), r["pixel_values"].cpu().float())    # the PNG round trip is lossless
+        return dict(r, pixel_values=out["pixel_values"])
+
+
+def test_c4_share_through_the_engine_and_the_http_handler_full_size():
+    """BASELINE config 4's share of one GPU at FULL size (4 single-image VQA requests of 2531 tokens + 4 text prompts of
+    65..233 tokens) through engine.ContinuousEngine with 3 slots -- staggered arrivals, every request after the third joins
+    while other rows are generating -- and then through the HTTP handler on a fresh engine: every (request, step) token ==
+    the per-request B = 1 oracle run of c4_oracle.npz wherever the fixture's margin is clear, the first token always."""
+    from phi_3_vision_mlx_amd.engine import ContinuousEngine
+    from phi_3_vision_mlx_amd.server import serve_continuous
+    g = np.load(GOLDEN + "/c4_oracle.npz")
+    model, proc = _full_model(g)
+    reqs = _c4_inputs(proc)
+    assert [r["input_ids"].shape[1] for r in reqs] == g["n_ids"].tolist()
+    n_steps = g["tokens"].shape[1]
+    eng = ContinuousEngine(model, proc, slots=3, window=4096)
+    order = [4, 0, 5, 1, 6, 2, 7, 3]                                # texts and images interleaved: the column must jump
+    handles = {}
+    for k, i in enumerate(order):
+        handles[i] = eng.submit(reqs[i], n_steps)
+        if k >= 2:
+            eng.step()                                              # one decode step between arrivals
+    eng.run_until_idle()
+    assert all(h.done.is_set() and h.error is None for h in handles.values()) and eng.failures == 0
+    assert eng.joined_mid_flight >= 3
+    n_engine = tokens_vs_fixture([handles[i].tokens for i in range(8)], g, "C4 engine")
+    assert n_engine >= 12, n_engine
+
+    from golden_inputs import vqa_request  # noqa: F401  (the share's images are rebuilt below with the same seeds)
+    from PIL import Image
+    imgs = [Image.fromarray(np.random.default_rng(s).integers(0, 256, (336, 336, 3), dtype=np.uint8)) for s in range(4)]
+    http_proc = C4Processor(proc, reqs)
+    httpd, backend = serve_continuous(ContinuousEngine(model, http_proc, slots=4, window=4096), port=0)
+    threading.Thread(target=httpd.serve_forever, daemon=True).start()
+    port, got = httpd.server_address[1], {}
+    bodies = [{"prompt": f"c4:{i}", "max_tokens": n_steps, **({"images": [_png_uri(imgs[i])]} if i < 4 else {})} for i in range(8)]
+    try:
+        ths = [threading.Thread(target=lambda i=i, b=b: got.__setitem__(i, _post(port, b))) for i, b in enumerate(bodies)]
+        [t.start() for t in ths]
+        [t.join() for t in ths]
+    finally:
+        httpd.shutdown()
+        backend.close()
+    toks = [[int(t) for t in got[i]["responses"][0].split()] for i in range(8)]
+    n_http = tokens_vs_fixture(toks, g, "C4 HTTP")
+    assert n_http >= 12, n_http
+    print(f"C4 share: engine {n_engine}, HTTP {n_http} free-running tokens equal the per-request oracle's")
+    del model, eng
+    torch.cuda.empty_cache()
+
+
+def test_engine_with_int8_kv_and_fp8_weights_vs_c5w_fixture():
+    """BASELINE config 5 through the engine: `quantize_model=True` weights (fp8, weight-only
+    arithmetic) and the int8 KV cache in the SLOT state; config 2's request joins a running row and must produce the tokens
+    of c5w_oracle.npz (an oracle applying the same quantisers) on every clear step."""
+    from golden_inputs import vqa_request
+    from phi_3_vision_mlx_amd.engine import ContinuousEngine
+    g = np.load(GOLDEN + "/c5w_oracle.npz")
+    model, proc = _full_model(g, quantized_fp8=True, use_quantized_cache=True, fp8_activations=False)
+    inp = vqa_request(proc.img_processor, 0)
+    inp["pixel_values"] = torch.from_numpy(inp["pixel_values"]).to("cuda:0")
+    n_steps = g["tokens"].shape[1]
+    eng = ContinuousEngine(model, proc, slots=2, window=4096)
+    assert eng.st.quantized
+    other = eng.submit({"input_ids": np.random.default_rng(9).integers(3, 32000, (1, 300)).astype(np.int64)}, 12)
+    eng.step(), eng.step()
+    h = eng.submit(inp, n_steps)                                    # joins while `other` is generating
+    eng.run_until_idle()
+    assert h.error is None and other.error is None and eng.joined_mid_flight >= 1 and len(other.tokens) in range(1, 13)
+    n = tokens_vs_fixture([h.tokens], g, "C5 engine")
+    assert n >= 1
+    print(f"C5 (weight-only fp8 + int8 KV) through the engine: {n} of {n_steps} tokens compared, all equal")
+    del model, eng
+    torch.cuda.empty_cache()
+
+
+def test_long_rope_engine_vs_c3_fixture_and_regime_routing():
+    """A request whose prompt + budget leaves the 4096-token window picks the LONG RoPE factors (phi.py:492): the router
+    sends it to the long-window engine, whose rows use those factors -- tokens == c3_oracle.npz (5000-token prompt); a short
+    request submitted at the same time runs on the short-factor engine (its tokens == a solo greedy run of the same model
+    here: c1's fixture was generated under another lm_head)."""
+    from phi_3_vision_mlx_amd.engine import ContinuousEngine, RegimeRouter
+    g = np.load(GOLDEN + "/c3_oracle.npz")
+    model, proc = _full_model(g, blind=True)
+    ids = np.random.default_rng(4).integers(3, 32000, (1, 5000)).astype(np.int64)
+    n_steps = g["tokens"].shape[1]
+    router = RegimeRouter([ContinuousEngine(model, proc, slots=2, window=4096), ContinuousEngine(model, proc, slots=2, window=8192)])
+    short_ids = np.random.default_rng(0).integers(3, 32000, (1, 128)).astype(np.int64)
+    hs, hl = router.submit({"input_ids": short_ids}, n_steps), router.submit({"input_ids": ids}, n_steps)
+    while router.safe_step() or router.waiting:
+        pass
+    assert hs.error is None and hl.error is None
+    assert router.engines[0].steps > 0 and router.engines[1].steps > 0
+    assert tokens_vs_fixture([hl.tokens], g, "long-RoPE engine") == n_steps          # c3: every step clear
+    tok, cache = model.greedy_prefill(n_steps, input_ids=short_ids)
+    solo = [int(tok.item())]
+    for _ in range(n_steps - 1):
+        _, tok = model.greedy_step(tok, cache)
+        solo.append(int(tok.item()))
+    assert hs.tokens[0] == solo[0]
+    del model, router
+    torch.cuda.empty_cache()
+
+
+def _sharded_worker(rank, world, port, out_dir):
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path[:0] = [root, os.path.join(root, "tests", "golden"), os.path.join(root, "tests")]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+    torch.cuda.set_device(0)                                   # both ranks share the one GPU of the test box
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from golden_inputs import SERVE_PROMPTS, SERVE_STEPS, make_image
+    from phi_3_vision_mlx_amd import dist as pd
+    from phi_3_vision_mlx_amd.api import load_synthetic
+    g = np.load(os.path.join(root, "tests", "golden", "tiny_serve_oracle.npz"))
+    model, proc = load_synthetic(blind_model=False, tiny=True, seed=0, std_scale=4.0, device="cuda:0",
+                                 lm_head_spread=float(g["spread"][0]), lm_head_seed=int(g["head_seed"][0]))
+    images = [make_image(336, 336, "noise", 0)] + [None] * (len(SERVE_PROMPTS) - 1)
+    mine = (SERVE_PROMPTS, images) if rank == 0 else (["junk"], None)
+    got = pd.generate_sharded(*mine, preload=(model, proc), max_tokens=SERVE_STEPS, max_batch=2, return_tokens=True)
+    if rank == 0:
+        torch.save(got, os.path.join(out_dir, "sharded.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_generate_sharded_two_ranks_on_one_gpu_matches_the_oracle(tmp_path):
+    """dist.generate_sharded on REAL kernels: two ranks (gloo rendezvous, both on the box's one GPU; on a node they would
+    be one per GPU over RCCL) serve the 7 mixed requests (rank 0 holds the table; chunks of 2 rows; length-bucketed prefill);
+    the request-ordered result == every request's B = 1 oracle run (tiny_serve_oracle.npz)."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_sharded_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    got = torch.load(tmp_path / "sharded.pt")
+    g = np.load(GOLDEN + "/tiny_serve_oracle.npz")
+    assert len(got) == 7
+    assert tokens_vs_fixture(got, g, "generate_sharded", min_first=2) >= 20

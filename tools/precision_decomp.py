@@ -110,7 +110,7 @@ def oracle_half(which):
     os.makedirs(DATA, exist_ok=True)
     np.savez(os.path.join(DATA, f"precision_{which}.npz"), hidden_bf16=base_h.to(BF16).view(torch.int16).numpy(),
              logits=base_lg.float().numpy())
-    variants = ("q", "k", "p", "o", "qkp", "qkpo", "QKP", "QKPo") if which == "c1" else ("qkp", "qkpo", "QKPo", "o")
+    variants = ("q", "k", "p", "o", "qkpo", "QKPo", "QKP") if which == "c1" else ("qkpo", "QKPo")
     rows = []
     for fl in variants:
         h, lg = run(fl)
