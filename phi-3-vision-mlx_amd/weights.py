@@ -139,12 +139,56 @@ def peaked_lm_head(w, spread, head_seed=0):
     return torch.ldexp(w.float(), e[:, None]).to(w.dtype)
 
 
-def synth_weights(cfg, seed=0, device="cpu", std_scale=1.0, lm_head_spread=0.0, lm_head_seed=0):
+OUTLIERS = dict(n=6, gain=64.0, kv_n=2, kv_gain=8.0)     # `outliers=True`
+
+
+def outlier_channels(cfg, n, seed=0):
+    """The seeded hidden channels that carry the heavy tail (sorted)."""
+    g = torch.Generator().manual_seed(0x0DD1E5 ^ (int(seed) * 0x9E3779B1 & _M32))
+    return torch.randperm(cfg.hidden_size, generator=g)[:n].sort().values
+
+
+def add_outliers(cfg, w, seed=0, n=6, gain=64.0, kv_n=2, kv_gain=8.0):
+    """Heavy-tailed activations, as trained decoders show them (a handful of residual-stream channels 50-100x the rest,
+    large key / value dimensions): N(0, s) weights give Gaussian activations, under which a per-row e4m3 activation scale
+    (`p3v_quant_fp8_rows`, phi_3_vision_mlx.py:291-305's quantised path), the int8 KV scales and the bf16 roundings of the
+    attention are never stressed.  In place, all factors powers of two (exact in bf16):
+      * `n` seeded hidden channels x `gain` wherever the residual stream is WRITTEN: embedding columns, o_proj / down_proj
+        output rows of every layer, the image projector's output rows (+ bias) -- so text and image tokens carry them from
+        layer 0 on and every layer keeps feeding them.  RMSNorm then spends most of its range on those channels: with
+        H = 3072, n = 6, gain = 64 the other channels of a normalised row shrink ~3x, and a per-row fp8 scale (row max / 448)
+        leaves them ~3 bits;
+      * `kv_n` dimensions per key and value head x `kv_gain` (qkv_proj output rows): per-token int8 KV scales are set by
+        those dimensions."""
+    ch = outlier_channels(cfg, n, seed).to(next(iter(w.values())).device)
+    nh, nkv = cfg.num_attention_heads, cfg.num_key_value_heads
+    hd = cfg.hidden_size // nh
+    w["model.embed_tokens.weight"][:, ch] *= gain
+    g = torch.Generator().manual_seed(0xCAFE ^ seed)
+    for i in range(cfg.num_hidden_layers):
+        p = f"model.layers.{i}."
+        w[p + "self_attn.o_proj.weight"][ch, :] *= gain
+        w[p + "mlp.down_proj.weight"][ch, :] *= gain
+        if kv_n:
+            dims = torch.randperm(hd, generator=g)[:kv_n]
+            rows = torch.cat([(nh + h) * hd + dims for h in range(2 * nkv)]).to(ch.device)     # K heads, then V heads
+            w[p + "self_attn.qkv_proj.weight"][rows, :] *= kv_gain
+    pj = "model.vision_embed_tokens.img_projection.2."
+    if pj + "weight" in w:
+        w[pj + "weight"][ch, :] *= gain
+        w[pj + "bias"][ch] *= gain
+    return w
+
+
+def synth_weights(cfg, seed=0, device="cpu", std_scale=1.0, lm_head_spread=0.0, lm_head_seed=0, outliers=None):
     """Seeded synthetic bf16 weights for every tensor of `weight_specs(cfg)`.
 
     std_scale > 1 sharpens the logits of tiny test models (wider top-2 margins);
-    lm_head_spread > 0 makes the greedy argmax decisive (`peaked_lm_head`)."""
+    lm_head_spread > 0 makes the greedy argmax decisive (`peaked_lm_head`);
+    outliers: None | True (= OUTLIERS) | dict of `add_outliers` arguments -> heavy-tailed activations."""
     w = {n: synth_tensor(n, s, k, seed, device, std_scale) for n, s, k in weight_specs(cfg)}
+    if outliers:
+        add_outliers(cfg, w, seed, **(OUTLIERS if outliers is True else outliers))
     if lm_head_spread:
         w["lm_head.weight"] = peaked_lm_head(w["lm_head.weight"], lm_head_spread, lm_head_seed)
     return w

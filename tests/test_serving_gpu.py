@@ -22,14 +22,17 @@ from test_model_gpu import GOLDEN, _full_model
 pytestmark = pytest.mark.gpu
 
 
-def tokens_vs_fixture(got, g, what, rows=None, min_first=1):
-    """got[i]: EOS-trimmed token list of request rows[i].  Returns the number of tokens compared (all equal)."""
+def tokens_vs_fixture(got, g, what, rows=None, min_first=1, budgets=None):
+    """got[i]: EOS-trimmed token list of request rows[i] (budgets[i]: its max_tokens, default = the fixture's steps).
+    Returns the number of tokens compared (all equal)."""
     ref, clear = g["tokens"], g["margins"] > 1.0
     rows = range(len(got)) if rows is None else rows
     n = 0
-    for toks, r in zip(got, rows):
+    for k, (toks, r) in enumerate(zip(got, rows)):
         assert clear[r, :min_first].all(), f"{what}: fixture request {r} is not clear on its first step(s)"
-        for step in range(ref.shape[1]):
+        budget = ref.shape[1] if budgets is None else budgets[k]
+        assert len(toks) <= budget, f"{what}: request {r} produced {len(toks)} tokens for a budget of {budget}"
+        for step in range(min(ref.shape[1], budget)):
             if not clear[r, step]:
                 break
             assert step < len(toks), f"{what}: request {r} stopped after {len(toks)} tokens, oracle continues {ref[r].tolist()}"
@@ -90,15 +93,16 @@ def test_engine_tiny_requests_join_mid_flight_and_match_the_oracle():
     from phi_3_vision_mlx_amd.engine import ContinuousEngine
     g, model, proc, reqs = _tiny_serve()
     eng = ContinuousEngine(model, proc, slots=3, window=4096)
-    handles = [eng.submit(r, SERVE_STEPS) for r in reqs[:4]]
+    budgets = [SERVE_STEPS, 3, SERVE_STEPS, SERVE_STEPS, SERVE_STEPS, 5, SERVE_STEPS]    # request 1 leaves early: its row is refilled mid-flight, and so on
+    handles = [eng.submit(r, b) for r, b in zip(reqs[:4], budgets)]
     for _ in range(2):
         eng.step()
-    handles += [eng.submit(r, SERVE_STEPS) for r in reqs[4:]]       # arrive while rows are generating
+    handles += [eng.submit(r, b) for r, b in zip(reqs[4:], budgets[4:])]       # arrive while rows are generating
     eng.run_until_idle()
     assert all(h.done.is_set() and h.error is None for h in handles)
-    assert eng.joined_mid_flight >= 2 and eng.steps < 7 * SERVE_STEPS and eng.failures == 0     # rows really shared steps
-    n = tokens_vs_fixture([h.tokens for h in handles], g, "engine", min_first=2)
-    assert n >= 20, n
+    assert eng.joined_mid_flight >= 2 and eng.steps < sum(budgets) and eng.failures == 0     # rows really shared steps
+    n = tokens_vs_fixture([h.tokens for h in handles], g, "engine", min_first=2, budgets=budgets)
+    assert n >= 16, n
     big = eng.submit(reqs[1], 5000)                                 # beyond the window: refused, not queued
     assert big.done.is_set() and isinstance(big.error, ValueError)
     print(f"tiny engine: {n} free-running tokens of 7 requests equal the oracle's")
@@ -192,17 +196,18 @@ def test_c4_share_through_the_engine_and_the_http_handler_full_size():
     assert [r["input_ids"].shape[1] for r in reqs] == g["n_ids"].tolist()
     n_steps = g["tokens"].shape[1]
     eng = ContinuousEngine(model, proc, slots=3, window=4096)
-    order = [4, 0, 5, 1, 6, 2, 7, 3]                                # texts and images interleaved: the column must jump
+    order = [0, 4, 1, 5, 2, 6, 3, 7]                                # image and text requests interleaved
+    budgets = [n_steps, n_steps, 3, n_steps, 2, n_steps, 3, n_steps]           # by request: rows free up at different steps
     handles = {}
     for k, i in enumerate(order):
-        handles[i] = eng.submit(reqs[i], n_steps)
+        handles[i] = eng.submit(reqs[i], budgets[i])
         if k >= 2:
             eng.step()                                              # one decode step between arrivals
     eng.run_until_idle()
     assert all(h.done.is_set() and h.error is None for h in handles.values()) and eng.failures == 0
     assert eng.joined_mid_flight >= 3
-    n_engine = tokens_vs_fixture([handles[i].tokens for i in range(8)], g, "C4 engine")
-    assert n_engine >= 12, n_engine
+    n_engine = tokens_vs_fixture([handles[i].tokens for i in range(8)], g, "C4 engine", budgets=budgets)
+    assert n_engine >= 10, n_engine
 
     from golden_inputs import vqa_request  # noqa: F401  (the share's images are rebuilt below with the same seeds)
     from PIL import Image
@@ -229,8 +234,8 @@ def test_c4_share_through_the_engine_and_the_http_handler_full_size():
 
 def test_engine_with_int8_kv_and_fp8_weights_vs_c5w_fixture():
     """BASELINE config 5 through the engine: `quantize_model=True` weights (fp8, weight-only
-    arithmetic) and the int8 KV cache in the SLOT state; config 2's request joins a running row and must produce the tokens
-    of c5w_oracle.npz (an oracle applying the same quantisers) on every clear step."""
+    arithmetic) and the int8 KV cache in the SLOT state; config 2's request, with a text request joining the other row between
+    its decode steps, must produce the tokens of c5w_oracle.npz (an oracle applying the same quantisers) on every clear step."""
     from golden_inputs import vqa_request
     from phi_3_vision_mlx_amd.engine import ContinuousEngine
     g = np.load(GOLDEN + "/c5w_oracle.npz")
@@ -240,10 +245,10 @@ def test_engine_with_int8_kv_and_fp8_weights_vs_c5w_fixture():
     n_steps = g["tokens"].shape[1]
     eng = ContinuousEngine(model, proc, slots=2, window=4096)
     assert eng.st.quantized
+    h = eng.submit(inp, n_steps)
+    eng.step()                                                      # prefill + first decode step of the image request alone
     other = eng.submit({"input_ids": np.random.default_rng(9).integers(3, 32000, (1, 300)).astype(np.int64)}, 12)
-    eng.step(), eng.step()
-    h = eng.submit(inp, n_steps)                                    # joins while `other` is generating
-    eng.run_until_idle()
+    eng.run_until_idle()                                            # `other` is prefilled into the free row between h's steps
     assert h.error is None and other.error is None and eng.joined_mid_flight >= 1 and len(other.tokens) in range(1, 13)
     n = tokens_vs_fixture([h.tokens], g, "C5 engine")
     assert n >= 1

@@ -122,10 +122,38 @@ def oracle_half(which):
         print(f"  {fl:6s}  {100 * ze:6.2f} %          " + "  ".join(f"{100 * d[i].item():.3f} %" for i in (0, 7, 15, 23, 31)))
 
 
+HEAVY = {"c2h": {}, "c5wh": dict(quantized_fp8=True, use_quantized_cache=True, fp8_activations=False),
+         "c5h": dict(quantized_fp8=True, use_quantized_cache=True, fp8_activations=True)}
+
+
 def hip_half(which):
+    """which: c1 | c2 (plain weights) or [tiny_]c2h | c5wh | c5h (heavy-tailed activations, tests/golden/gen_golden_oracle.py
+    `heavy`: the oracle side applies the same quantisers)."""
     from phi_3_vision_mlx_amd.api import load_synthetic
     fx = np.load(os.path.join(DATA, f"precision_{which}.npz"))
     ref_h = torch.from_numpy(fx["hidden_bf16"]).view(BF16).float()                          # [layers, KEEP, H]
+    tag = which.replace("tiny_", "")
+    if tag in HEAVY:
+        tiny = which.startswith("tiny_")
+        model, proc = load_synthetic(tiny=tiny, seed=0, device="cuda:0", outliers=True, std_scale=4.0 if tiny else 1.0, **HEAVY[tag])
+        from golden_inputs import vqa_request
+        inp = vqa_request(proc.img_processor, 0)
+        hs = []
+        model.hidden_hook = lambda i, x, B, L: hs.append(x.view(B, L, -1)[0, -KEEP:].float().cpu())
+        model(**inp, max_tokens=4, full_logits=True)
+        model.hidden_hook = None
+        h = torch.stack(hs)
+        d = (h - ref_h).norm(dim=-1) / ref_h.norm(dim=-1)
+        ch = __import__("phi_3_vision_mlx_amd.weights", fromlist=["x"]).outlier_channels(model.cfg, 6, 0)
+        rest = torch.ones(h.shape[-1], dtype=torch.bool)
+        rest[ch] = False
+        d_rest = (h - ref_h)[..., rest].norm(dim=-1) / ref_h[..., rest].norm(dim=-1)
+        print(f"\n{which}: HIP vs the oracle with the same weights / quantisers, heavy-tailed activations")
+        print(f"  outlier channels {ch.tolist()}: |x| there / median |x| = {(ref_h[-1][:, ch].abs().mean() / ref_h[-1][:, rest].abs().median()).item():.0f}x")
+        print("  residual-stream deviation |dx|/|x|, all channels, after layer " + "  ".join(f"{i}: {100 * d[i].mean().item():.3f} %" for i in sorted({0, len(d) // 4, len(d) // 2, 3 * len(d) // 4, len(d) - 1})))
+        print("  the same over the NON-outlier channels only:               " + "  ".join(f"{i}: {100 * d_rest[i].mean().item():.3f} %" for i in sorted({0, len(d) // 4, len(d) // 2, 3 * len(d) // 4, len(d) - 1})))
+        print("  per layer (non-outlier channels): " + " ".join(f"{100 * d_rest[i].mean().item():.2f}" for i in range(d.shape[0])))
+        return
     ref_lg = torch.from_numpy(fx["logits"])
     model, _ = load_synthetic(tiny=False, seed=0, device="cuda:0")
     head = fixture_head(which, model.w["lm_head.weight"].cpu())
