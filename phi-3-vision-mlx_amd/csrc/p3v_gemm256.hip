@@ -33,6 +33,8 @@ struct Gemm256P {
   int M, N, K, lda, ldw, ldo;
 };
 
+struct Tile256 { int m0, n0; int a_off[2][2], b_off[2][2]; __amdgpu_buffer_rsrc_t rs_a; };
+
 __device__ __forceinline__ float gelu_erf2(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
 
 template <int EPI, int SCHED = 0x50, int ORDER = 0>
@@ -42,72 +44,84 @@ __global__ void __launch_bounds__(512, 1) k_gemm256(Gemm256P p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // uniform: LDS-DMA bases stay in SGPRs
   const int wr = wave >> 2, wc = wave & 3;
   constexpr int n_out_tile = SILU ? TN / 2 : TN;
-  int m_t, n_t;
-  {
-    const int gx = gridDim.x, gy = gridDim.y, nwg = gx * gy, wid = blockIdx.y * gx + blockIdx.x;
+  const int gx = (p.N + n_out_tile - 1) / n_out_tile, gy = (p.M + TM - 1) / TM, nwg = gx * gy;
+
+  // ---- PERSISTENT over output tiles (round 3): workgroup b takes tiles b, b + G, b + 2G, ... (G = gridDim.x, a multiple of 8,
+  // so a workgroup's tiles keep its XCD in the XCD-aware order below).  The K-tile stream runs ACROSS tile seams: during the
+  // last K-tile of a tile the first K-tile of the workgroup's NEXT tile is requested into the other LDS buffer, and the
+  // epilogue (staged through the buffer that was just consumed) runs under that DMA -- the 64-KiB cold fetch that opened every
+  // tile (HBM latency + 4 x 16 KiB, ~2 us) was 15-20 % of a K = 1024 tile (the ViT projections) and 5 % at K = 3072.
+  using Tile = Tile256;   // (declared outside the template: a builtin called with a member of a DEPENDENT type is only checked at
+                          //  instantiation, fails there in the HOST pass -- no such builtin -- and hipcc silently drops the host stub)
+  const int srow = tid >> 3, schunk = tid & 7;
+  auto make_tile = [&](int wid, Tile& t) {
     const int q = nwg >> 3, r = nwg & 7, xcd = wid & 7, loc = wid >> 3;
     const int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
     constexpr int BAND = 4;
     const int band = id / (BAND * gx), in_band = id % (BAND * gx);
     const int rows = min(BAND, gy - band * BAND);
-    m_t = band * BAND + in_band % rows;
-    n_t = in_band / rows;
-  }
-  const int m0 = m_t * TM, n0 = n_t * n_out_tile;
-
-  // ---- DMA sources: half-tile h (128 rows), instruction q (64 rows), this thread: row tid/8, chunk tid%8.
-  // Buffer addressing (SGPR descriptor + 32-bit per-lane byte offset + SGPR K offset): a request is `s_mov m0` +
-  // `buffer_load_dwordx4 ... offen lds` with no vector ALU work at all -- with 64-bit flat addresses every one of the
-  // 8 requests per wave and K-tile carried a v_lshl_add_u64 and, before the wave id was made uniform, a
-  // v_readfirstlane + hazard nop (4096^3: 1.30 -> 1.34 PFLOP/s for the uniform wave id alone).
-  const int srow = tid >> 3, schunk = tid & 7;
-  int a_off[2][2], b_off[2][2];                                 // bytes from the tile's first A row / from W
+    const int m_t = band * BAND + in_band % rows, n_t = in_band / rows;
+    t.m0 = m_t * TM, t.n0 = n_t * n_out_tile;
+    // DMA sources: half-tile h (128 rows), instruction q (64 rows), this thread: row tid/8, chunk tid%8.
+    // Buffer addressing (SGPR descriptor + 32-bit per-lane byte offset + SGPR K offset): a request is `s_mov m0` +
+    // `buffer_load_dwordx4 ... offen lds` with no vector ALU work at all.
 #pragma unroll
-  for (int h = 0; h < 2; ++h)
+    for (int h = 0; h < 2; ++h)
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const int r = h * 128 + q * 64 + srow;
-      const int sw = (schunk ^ (r & 7)) * 8;
-      const int ar = min(m0 + r, p.M - 1) - m0;
-      a_off[h][q] = (ar * p.lda + sw) * 2;
-      int br;
-      if (SILU) {                                   // wave column group wcol (64 tile rows) = 32 gate + 32 up rows
-        const int wcol = r >> 6, ni = (r & 63) >> 4, c = r & 15;
-        br = min(n0 + wcol * 32 + (ni & 1) * 16 + c, p.N - 1) + (ni >> 1) * p.N;
-      } else {
-        br = min(n0 + r, p.N - 1);
+      for (int qq = 0; qq < 2; ++qq) {
+        const int rr = h * 128 + qq * 64 + srow;
+        const int sw = (schunk ^ (rr & 7)) * 8;
+        const int ar = min(t.m0 + rr, p.M - 1) - t.m0;
+        t.a_off[h][qq] = (ar * p.lda + sw) * 2;
+        int br;
+        if (SILU) {                                   // wave column group wcol (64 tile rows) = 32 gate + 32 up rows
+          const int wcol = rr >> 6, ni = (rr & 63) >> 4, c = rr & 15;
+          br = min(t.n0 + wcol * 32 + (ni & 1) * 16 + c, p.N - 1) + (ni >> 1) * p.N;
+        } else {
+          br = min(t.n0 + rr, p.N - 1);
+        }
+        t.b_off[h][qq] = (int)(((unsigned)br * (unsigned)p.ldw + (unsigned)sw) * 2u);   // < 2^32: checked by the launcher
       }
-      b_off[h][q] = (int)(((unsigned)br * (unsigned)p.ldw + (unsigned)sw) * 2u);   // < 2^32: checked by the launcher
-    }
-  const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A + (size_t)m0 * p.lda), 0, 0xffffffff, 0x00020000);
+    t.rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A + (size_t)t.m0 * p.lda), 0, 0xffffffff, 0x00020000);
+  };
   const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, 0xffffffff, 0x00020000);
-  auto dma_half = [&](int which, int kt, int buf) {   // which: 0 A0, 1 A1, 2 B0, 3 B1
+  auto dma_half = [&](const Tile& t, int which, int kt, int buf) {   // which: 0 A0, 1 A1, 2 B0, 3 B1
     unsigned char* base = smem + buf * BUF_BYTES + which * HALF_BYTES + wave * 1024;
     const int h = which & 1;
 #pragma unroll
-    for (int q = 0; q < 2; ++q)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(which < 2 ? rs_a : rs_w, (lptr_t)(base + q * 8192), 16,
-                                               which < 2 ? a_off[h][q] : b_off[h][q], kt * (TK * 2), 0, 0);
+    for (int q = 0; q < 2; ++q) {
+      const __amdgpu_buffer_rsrc_t rs = which < 2 ? t.rs_a : rs_w;
+      const int vo = which < 2 ? t.a_off[h][q] : t.b_off[h][q];
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)(base + q * 8192), 16, vo, kt * (TK * 2), 0, 0);
+    }
   };
 
+  const int frow = lane & 15, fchunk = lane >> 4;
+  const int nk = p.K / TK;
+  int wid = blockIdx.x;
+  if (wid >= nwg) return;
+  Tile cur_t;
+  make_tile(wid, cur_t);
+#pragma unroll
+  for (int w4 = 0; w4 < 4; ++w4) dma_half(cur_t, w4, 0, 0);
+  int gk = 0;                                                     // K-tiles consumed so far: LDS buffer = gk & 1
+  for (;;) {
+  const int m0 = cur_t.m0, n0 = cur_t.n0;
+  const bool has_next = wid + (int)gridDim.x < nwg;
   f32x4_t acc[8][4];
 #pragma unroll
   for (int i = 0; i < 8; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
-  const int frow = lane & 15, fchunk = lane >> 4;
-  const int nk = p.K / TK;
-#pragma unroll
-  for (int w4 = 0; w4 < 4; ++w4) dma_half(w4, 0, 0);
-
-  for (int kt = 0; kt < nk; ++kt) {
+  for (int kt = 0; kt < nk; ++kt, ++gk) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    const bool more = kt + 1 < nk;
-    const int nb = (kt + 1) & 1;
-    const unsigned char* ta = smem + (kt & 1) * BUF_BYTES + wr * HALF_BYTES;                      // this wave's A half
-    const unsigned char* tb = smem + (kt & 1) * BUF_BYTES + (2 + (wc >> 1)) * HALF_BYTES + (wc & 1) * 64 * 128;  // its 64 B rows
+    const bool last = kt + 1 == nk;
+    const bool more = !last || has_next;                          // something to prefetch: this tile's next K-tile, or the next tile's first
+    const int nb = (gk + 1) & 1;
+    const unsigned char* ta = smem + (gk & 1) * BUF_BYTES + wr * HALF_BYTES;                      // this wave's A half
+    const unsigned char* tb = smem + (gk & 1) * BUF_BYTES + (2 + (wc >> 1)) * HALF_BYTES + (wc & 1) * 64 * 128;  // its 64 B rows
     bf16x8_t af[4][2], af1[4][2], bf0[2][2], bf1[2][2];
     auto read_a_to = [&](int sub, bf16x8_t (&dst)[4][2]) {
 #pragma unroll
@@ -146,7 +160,14 @@ __global__ void __launch_bounds__(512, 1) k_gemm256(Gemm256P p) {
       if (more) {
 #pragma unroll
         for (int h = 0; h < 4; ++h)
-          if (((SCHED >> (2 * h)) & 3) == ph) dma_half(h, kt + 1, nb);
+          if (((SCHED >> (2 * h)) & 3) == ph) {
+            if (!last) dma_half(cur_t, h, kt + 1, nb);
+            else {                                                // the next tile's offsets are computed here, once per tile, and
+              Tile nt;                                            // die at once: kept live through the K loop they are spilled
+              make_tile(wid + gridDim.x, nt);                     // (the kernel sits at the 256-register limit)
+              dma_half(nt, h, 0, nb);
+            }
+          }
       }
     };
     if (ORDER == 2) {
@@ -189,10 +210,13 @@ __global__ void __launch_bounds__(512, 1) k_gemm256(Gemm256P p) {
     quad(1, 0, bf0);
   }
 
-  // ---- epilogue: 128 x 64 per wave, in four passes of 32 rows through a wave-private [32][68] fp32 LDS tile
+  // ---- epilogue: 128 x 64 per wave, in four passes of 32 rows through a wave-private [32][64] fp32 LDS tile that lives in
+  // the K-tile buffer just consumed (the other one is receiving the next tile's first K-tile).  No padding fits in 8 KiB per
+  // wave: 16-byte column chunk c of row r sits at chunk c ^ (r & 1) instead, which keeps the float4 read-back conflict-free.
   __syncthreads();
-  float* ct = (float*)smem + wave * (32 * CT2_LD);
+  float* ct = (float*)(smem + ((gk - 1) & 1) * BUF_BYTES) + wave * (32 * 64);
   const int ccol = lane & 15, crow = (lane >> 4) * 4;
+  auto ct_at = [&](int row, int col) { return ct + row * 64 + ((((col >> 2) ^ (row & 1)) << 2) | (col & 3)); };
 #pragma unroll
   for (int pass = 0; pass < 4; ++pass) {
 #pragma unroll
@@ -200,7 +224,7 @@ __global__ void __launch_bounds__(512, 1) k_gemm256(Gemm256P p) {
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) ct[(i * 16 + crow + r) * CT2_LD + j * 16 + ccol] = acc[pass * 2 + i][j][r];
+        for (int r = 0; r < 4; ++r) *ct_at(i * 16 + crow + r, j * 16 + ccol) = acc[pass * 2 + i][j][r];
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (SILU) {
       const int c8 = (lane & 3) * 8, n = n0 + wc * 32 + c8;
@@ -209,8 +233,8 @@ __global__ void __launch_bounds__(512, 1) k_gemm256(Gemm256P p) {
         const int row = it * 16 + (lane >> 2);
         const int m = m0 + wr * 128 + pass * 32 + row;
         if (m < p.M && n < p.N) {
-          const float4 g0 = *(const float4*)(ct + row * CT2_LD + c8), g1 = *(const float4*)(ct + row * CT2_LD + c8 + 4);
-          const float4 u0 = *(const float4*)(ct + row * CT2_LD + 32 + c8), u1 = *(const float4*)(ct + row * CT2_LD + 36 + c8);
+          const float4 g0 = *(const float4*)ct_at(row, c8), g1 = *(const float4*)ct_at(row, c8 + 4);
+          const float4 u0 = *(const float4*)ct_at(row, 32 + c8), u1 = *(const float4*)ct_at(row, 36 + c8);
           const float gs[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
           const float us[8] = {u0.x, u0.y, u0.z, u0.w, u1.x, u1.y, u1.z, u1.w};
           u32x4_t w;
@@ -241,7 +265,7 @@ __global__ void __launch_bounds__(512, 1) k_gemm256(Gemm256P p) {
         const int row = it * 8 + (lane >> 3);
         const int m = m0 + wr * 128 + pass * 32 + row;
         if (m < p.M && ncol_ok) {
-          const float4 a0 = *(const float4*)(ct + row * CT2_LD + c8), a1 = *(const float4*)(ct + row * CT2_LD + c8 + 4);
+          const float4 a0 = *(const float4*)ct_at(row, c8), a1 = *(const float4*)ct_at(row, c8 + 4);
           float v[8] = {a0.x + bias[0], a0.y + bias[1], a0.z + bias[2], a0.w + bias[3],
                         a1.x + bias[4], a1.y + bias[5], a1.z + bias[6], a1.w + bias[7]};
           const size_t o = (size_t)m * p.ldo + n;
@@ -274,6 +298,10 @@ __global__ void __launch_bounds__(512, 1) k_gemm256(Gemm256P p) {
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   }
+  if (!has_next) break;
+  wid += gridDim.x;
+  make_tile(wid, cur_t);
+  }                                                             // next tile of this workgroup
 }
 
 template <int EPI, int SCHED, int ORDER>
@@ -285,7 +313,16 @@ static int launch_gemm256_v(const Gemm256P& p, hipStream_t s) {
     attr_set = true;
   }
   const int n_tile = EPI == P3V_EPI_SILU_MUL ? TN / 2 : TN;
-  dim3 grid(p3v_cdiv(p.N, n_tile), p3v_cdiv(p.M, TM));
+  static int n_cu = 0;
+  if (!n_cu) {
+    int dev = 0;
+    hipDeviceProp_t pr;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess) return P3V_ERR_HIP;
+    n_cu = pr.multiProcessorCount / 8 * 8;                        // persistent grid: one workgroup per CU, a multiple of 8 (XCDs)
+  }
+  const int tiles = p3v_cdiv(p.N, n_tile) * p3v_cdiv(p.M, TM);
+  const int persist = p3v_tuning().gemm_persistent;                // 0: one workgroup per tile (round 2), else the persistent loop
+  dim3 grid(persist ? min(tiles, n_cu) : tiles);
   hipLaunchKernelGGL((k_gemm256<EPI, SCHED, ORDER>), grid, dim3(512), GEMM256_LDS, s, p);
   P3V_CHECK_LAUNCH();
   return P3V_OK;

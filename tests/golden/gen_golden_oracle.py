@@ -145,7 +145,7 @@ def search_head(reqs, base_head, n_steps, max_seeds=20000, first_seed=0, need="a
     for hs in range(first_seed, first_seed + max_seeds):
         head = peaked_lm_head(base, SPREAD, hs)
         norms = row_norms(head)
-        if min(clearance(orc._linear(r.h0, head)[:, -1], norms, r.rel_tol).min().item() for r in reqs) <= 1.0:
+        if need != 0 and min(clearance(orc._linear(r.h0, head)[:, -1], norms, r.rel_tol).min().item() for r in reqs) <= 1.0:
             continue                                        # cheap filter: the prefill step of every request
         out = []
         for r in reqs:
@@ -419,7 +419,10 @@ def c5(act8=True):
 # profiles/r03_heavy_tail.txt); the tiny twins (2 layers) use the tiny tolerance x the same ratio.
 DATA = os.path.join(ROOT, "tools", "data")
 HEAVY = {"c2h": dict(quant=False, act8=False), "c5wh": dict(quant=True, act8=False), "c5h": dict(quant=True, act8=True)}
-REL_TOL_HEAVY = {"c2h": 0.06, "c5wh": 0.09, "c5h": 0.30}     # provisional until measured; see the header above
+# measured |HIP - oracle| of the residual stream after the last layer (profiles/r03_heavy_tail.txt): full size c2h 3.6-3.9 %,
+# c5wh 6.0-7.0 %, c5h 24-28 %; tiny (2 layers) 1.1 % / 1.1 % / 6.8 %.  x 1.3-1.5:
+REL_TOL_HEAVY = {"c2h": 0.055, "c5wh": 0.095, "c5h": 0.38}
+REL_TOL_HEAVY_TINY = {"c2h": 0.02, "c5wh": 0.02, "c5h": 0.10}
 
 
 def heavy(tag, tiny_model=False):
@@ -447,14 +450,17 @@ def heavy(tag, tiny_model=False):
         name = ("tiny_" if tiny_model else "") + tag
         r = Prefilled(o, {k: (torch.from_numpy(v) if k == "pixel_values" else v) for k, v in inp.items()}, 4,
                       tag=None if tiny_model else name, hidden_file=os.path.join(DATA, f"precision_{name}.npz"))
-        r.rel_tol = REL_TOL_HEAVY[tag] * (0.5 if tiny_model else 1.0)
+        r.rel_tol = (REL_TOL_HEAVY_TINY if tiny_model else REL_TOL_HEAVY)[tag]
 
         def q_head(b, spread, hs):                                    # the peaked head goes through the weight quantiser too
             w8, sc = quantize_fp8_rows(plain(b.to(BF16), spread, hs))
             return w8.view(torch.float8_e4m3fn).to(F32) * sc[:, None]
         if kw["quant"]:
             peaked_lm_head = q_head
-        hs, (res,) = search_head([r], base, 4, need="prefill" if kw["act8"] else 2, min_distinct=2)
+        # W8A8 under heavy tails: two correct implementations differ by a quarter of the logit range (every e4m3 activation
+        # code that flips is a 6-12 % step of a row whose scale the outlier channels set): no token can be pinned -- the
+        # fixture then only bounds the logits (need = 0: whatever head comes first).  The others: first two steps clear.
+        hs, (res,) = search_head([r], base, 4, need=0 if kw["act8"] else 2, min_distinct=1 if kw["act8"] else 2)
     finally:
         peaked_lm_head = plain
         orc.OracleKVCache = orig

@@ -598,8 +598,52 @@ def test_c5_fp8_weights_int8_kv_vs_quantised_oracle(act8):
         n_exact += int(clear.sum())
         if step + 1 < n:
             logits, _ = model.greedy_step(ref_tok[:, step:step + 1].to("cuda:0", torch.int32), cache)
-    assert bool(torch.as_tensor(g["margins"])[:, 0].gt(1).all()) and n_exact >= 1
+    assert bool(torch.as_tensor(g["margins"])[:, 0].gt(1).all()) and n_exact == int((torch.as_tensor(g["margins"]) > 1).sum()) >= 1
     print(f"C5 {'W8A8' if act8 else 'W8A16'}: {n_exact} of {n} tokens exact (the clear steps), worst logit error {worst:.2f} x tolerance")
+    del model, cache
+    torch.cuda.empty_cache()
+
+
+HEAVY = {"c2h": {}, "c5wh": dict(quantized_fp8=True, use_quantized_cache=True, fp8_activations=False),
+         "c5h": dict(quantized_fp8=True, use_quantized_cache=True, fp8_activations=True)}
+
+
+@pytest.mark.parametrize("tiny", [True, False], ids=["tiny", "full"])
+@pytest.mark.parametrize("tag", ["c2h", "c5wh", "c5h"])
+def test_heavy_tailed_activations_fixtures(tag, tiny):
+    """Config 2's request on weights with HEAVY-TAILED activations (weights.add_outliers: six residual-stream channels x 64,
+    two key / value dimensions per head x 8 -- what trained decoders show and N(0, s) weights never do), in the three
+    arithmetic variants of the build: bf16 (c2h), fp8 weights + int8 KV (c5wh), W8A8 prompt projections + int8 KV (c5h),
+    each against an oracle with the same weights and quantisers (tests/golden/gen_golden_oracle.py `heavy`).  Every logit
+    inside the fixture's tolerance (1.3-1.5 x the measured HIP - oracle difference, profiles/r03_heavy_tail.txt), tokens
+    exact on every clear step -- the first two steps of c2h / c5wh by construction; under W8A8 the per-row e4m3 activation
+    scale is set by the outlier channels and two correct implementations differ by a quarter of the logit range, so c5h
+    pins the logits only."""
+    from golden_inputs import vqa_request
+    from phi_3_vision_mlx_amd.api import load_synthetic
+    g = np.load(f"{GOLDEN}/{'tiny_' if tiny else ''}{tag}_oracle.npz")
+    model, proc = load_synthetic(tiny=tiny, seed=0, device="cuda:0", std_scale=4.0 if tiny else 1.0, outliers=True,
+                                 lm_head_spread=float(g["spread"][0]), lm_head_seed=int(g["head_seed"][0]), **HEAVY[tag])
+    inp = vqa_request(proc.img_processor, 0)
+    assert inp["input_ids"].shape[1] == int(g["n_ids"][0])
+    inp["pixel_values"] = torch.from_numpy(inp["pixel_values"]).to("cuda:0")
+    ref_tok = torch.as_tensor(g["tokens"]).long()
+    n = ref_tok.shape[1]
+    norms = head_row_norms(model)
+    logits, cache = model(**inp, max_tokens=n)
+    n_exact, worst = 0, 0.0
+    for step in range(n):
+        got, clear, w = logits_vs_fixture(logits[:, -1], g, step, norms, f"{tag} step {step}")
+        worst = max(worst, w)
+        assert torch.equal(got.argmax(-1)[clear], ref_tok[:, step][clear]), f"{tag} step {step}"
+        n_exact += int(clear.sum())
+        if step + 1 < n:
+            logits, _ = model.greedy_step(ref_tok[:, step:step + 1].to("cuda:0", torch.int32), cache)
+    assert n_exact == int((torch.as_tensor(g["margins"]) > 1).sum())
+    if tag != "c5h":
+        assert n_exact >= 2
+    print(f"heavy tails, {'tiny' if tiny else 'full size'} {tag}: worst logit error {worst:.2f} x tolerance ({float(g['rel_tol'][0]):.3f}), "
+          f"{n_exact} of {n} tokens pinned and exact")
     del model, cache
     torch.cuda.empty_cache()
 

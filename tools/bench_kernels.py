@@ -25,9 +25,12 @@ def gemm_case(name, M, N, K, epi, f32res=False):
     kw = {}
     if epi in (ops.EPI_BIAS, ops.EPI_BIAS_QGELU, ops.EPI_BIAS_GELU, ops.EPI_BIAS_RESID_F32): kw["bias"] = bias
     if epi in (ops.EPI_BIAS_RESID_F32, ops.EPI_RESID_BF16): kw.update(resid=res, out=res)
-    ms = timeit(lambda i: ops.gemm(A, Ws[i], epi, **kw), nrot)
-    tf = 2 * M * N * K * (2 if epi == ops.EPI_SILU_MUL else 1) / ms / 1e9
-    print(f"gemm {name:28s} M={M:6d} N={N:6d} K={K:5d}  {ms*1e3:9.1f} us  {tf:8.1f} TF/s")
+    for persist in (0, 1):            # 256x256-tile kernel: one workgroup per tile / persistent workgroups with cross-tile prefetch
+        old = ops.set_tuning("gemm_persistent", persist)
+        ms = timeit(lambda i: ops.gemm(A, Ws[i], epi, **kw), nrot)
+        ops.set_tuning("gemm_persistent", old)
+        tf = 2 * M * N * K * (2 if epi == ops.EPI_SILU_MUL else 1) / ms / 1e9
+        print(f"gemm {name:28s} {'persistent' if persist else 'per-tile  '} M={M:6d} N={N:6d} K={K:5d}  {ms*1e3:9.1f} us  {tf:8.1f} TF/s", flush=True)
 
 def gemv_case(name, M, N, K, epi, norm=False):
     rows = 2 * N if epi == ops.EPI_SILU_MUL else N
