@@ -214,9 +214,15 @@ __global__ void __launch_bounds__(512, 1) k_gemm256(Gemm256P p) {
   // the K-tile buffer just consumed (the other one is receiving the next tile's first K-tile).  No padding fits in 8 KiB per
   // wave: 16-byte column chunk c of row r sits at chunk c ^ (r & 1) instead, which keeps the float4 read-back conflict-free.
   __syncthreads();
+#ifdef P3V_G256_OLD_EPI                                          // timing experiment (single-round shapes only): round-2 staging
+  float* ct = (float*)smem + wave * (32 * CT2_LD);
+  const int ccol = lane & 15, crow = (lane >> 4) * 4;
+  auto ct_at = [&](int row, int col) { return ct + row * CT2_LD + col; };
+#else
   float* ct = (float*)(smem + ((gk - 1) & 1) * BUF_BYTES) + wave * (32 * 64);
   const int ccol = lane & 15, crow = (lane >> 4) * 4;
   auto ct_at = [&](int row, int col) { return ct + row * 64 + ((((col >> 2) ^ (row & 1)) << 2) | (col & 3)); };
+#endif
 #pragma unroll
   for (int pass = 0; pass < 4; ++pass) {
 #pragma unroll

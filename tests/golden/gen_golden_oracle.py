@@ -421,8 +421,18 @@ DATA = os.path.join(ROOT, "tools", "data")
 HEAVY = {"c2h": dict(quant=False, act8=False), "c5wh": dict(quant=True, act8=False), "c5h": dict(quant=True, act8=True)}
 # measured |HIP - oracle| of the residual stream after the last layer (profiles/r03_heavy_tail.txt): full size c2h 3.6-3.9 %,
 # c5wh 6.0-7.0 %, c5h 24-28 %; tiny (2 layers) 1.1 % / 1.1 % / 6.8 %.  x 1.3-1.5:
-REL_TOL_HEAVY = {"c2h": 0.055, "c5wh": 0.095, "c5h": 0.38}
-REL_TOL_HEAVY_TINY = {"c2h": 0.02, "c5wh": 0.02, "c5h": 0.10}
+REL_TOL_HEAVY = {"c2h": 0.055, "c5wh": 0.095, "c5h": 0.17}
+REL_TOL_HEAVY_TINY = {"c2h": 0.03, "c5wh": 0.045, "c5h": 0.05}
+# Steps per fixture.  Measured z-space |HIP - oracle| per step (tools/heavy_diag.py, %): c2h 4.0 5.2 2.1 2.3; c5wh 7.3 7.8 5.4
+# 5.2; c5h 12.7 12.3 10.7 104; tiny c2h <= 1.7; tiny c5wh 3.2 3.5 3.1 8.0; tiny c5h 3.5 4.1 3.1 21.9.  The blow-ups are single
+# DECODE steps of the quantised variants: with key dimensions 8x the rest the attention logits of some tokens reach hundreds
+# (log2 units) and the softmax sits between two competing keys -- a 0.2 % difference in a score (an int8 / e4m3 code flip)
+# moves the attention output by tens of per cent (tools/heavy_diag2.py: the same input token deviates 12-15 % after LAYER 0
+# at steps 1 and 3 and 1.5 % at step 2; tools/heavy_diag3.py: every projection kernel matches the oracle's arithmetic on
+# those tokens to <= 0.01 % at full size).  Two correct implementations disagree there, so those steps are not fixture
+# material: c5h pins its first three steps' logits, tiny c5wh / c5h three; decode under heavy tails with quantised weights and
+# KV is pinned by c5wh (4 steps, tokens exact on the clear ones) and bf16 by c2h.
+HEAVY_STEPS = {"c2h": 4, "c5wh": 4, "c5h": 3, "tiny_c2h": 4, "tiny_c5wh": 3, "tiny_c5h": 3}
 
 
 def heavy(tag, tiny_model=False):
@@ -448,6 +458,7 @@ def heavy(tag, tiny_model=False):
     try:
         inp = vqa_request(Phi3VProcessor(None).img_processor, 0)
         name = ("tiny_" if tiny_model else "") + tag
+        n_steps = HEAVY_STEPS[name]
         r = Prefilled(o, {k: (torch.from_numpy(v) if k == "pixel_values" else v) for k, v in inp.items()}, 4,
                       tag=None if tiny_model else name, hidden_file=os.path.join(DATA, f"precision_{name}.npz"))
         r.rel_tol = (REL_TOL_HEAVY_TINY if tiny_model else REL_TOL_HEAVY)[tag]
@@ -460,7 +471,7 @@ def heavy(tag, tiny_model=False):
         # W8A8 under heavy tails: two correct implementations differ by a quarter of the logit range (every e4m3 activation
         # code that flips is a 6-12 % step of a row whose scale the outlier channels set): no token can be pinned -- the
         # fixture then only bounds the logits (need = 0: whatever head comes first).  The others: first two steps clear.
-        hs, (res,) = search_head([r], base, 4, need=0 if kw["act8"] else 2, min_distinct=1 if kw["act8"] else 2)
+        hs, (res,) = search_head([r], base, n_steps, need=0 if kw["act8"] else 2, min_distinct=1 if kw["act8"] else 2)
     finally:
         peaked_lm_head = plain
         orc.OracleKVCache = orig
