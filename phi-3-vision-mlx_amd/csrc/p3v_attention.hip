@@ -698,6 +698,9 @@ __global__ void __launch_bounds__(512, 1) k_attn_prefill_pp(AttnP p) {
 #endif
   const int wave_last = p.causal ? past + q0 + 31 : total;  // last key position this wave can see
   const float sc2 = p.sc2;                                   // !PRE only
+  // interior tiles of this wave: kv0 >= pad, kv0 + 64 <= kv_end, (causal) kv0 + 63 <= past + q0, and no padded query rows
+  const int j_int_lo = (past + q0 >= pad) ? ((pad > kv_begin) ? 1 : 0) : (1 << 30);
+  const int j_int_hi = min((kv_end - kv_begin) / 64 - 1, p.causal ? (past + q0 - 63 - kv_begin >= 0 ? (past + q0 - 63 - kv_begin) / 64 : -1) : (1 << 30));
 
   bf16x8_t qf[2][NKS];
   int qpos[2];
@@ -809,23 +812,22 @@ __global__ void __launch_bounds__(512, 1) k_attn_prefill_pp(AttnP p) {
       for (int st = 0; st < 4; ++st) kfr[st][ks] = *(const bf16x8_t*)(Ks + off + st * 16 * KROW);
     }
   };
-  auto load_v = [&](int j) {
+  auto load_v = [&](int j, int st) {                         // half st (keys 32 st .. 32 st + 31) of V^T(j)
     const unsigned char* Vs = smem + RING * KTILE + (j % VRING) * VTILE;
     const unsigned ln = lane_now(), g_ = ln >> 4, qi_ = ln & 15;
+    const unsigned off = qi_ * VROW + (((4 * st + g_) ^ ((qi_ >> 1) & 7)) << 4);
 #pragma unroll
-    for (int st = 0; st < 2; ++st) {
-      const unsigned off = qi_ * VROW + (((4 * st + g_) ^ ((qi_ >> 1) & 7)) << 4);
-#pragma unroll
-      for (int d = 0; d < NDT; ++d) vfr[st][d] = *(const bf16x8_t*)(Vs + off + d * 16 * VROW);
-    }
+    for (int d = 0; d < NDT; ++d) vfr[st][d] = *(const bf16x8_t*)(Vs + off + d * 16 * VROW);
   };
   auto qk = [&]() {                                          // S^T(j) = K_j . Q^T (- reference), K_j in kfr
     // the first MFMA of every accumulator takes the persistent block `negm` (-reference in all four rows) as its C
     // operand: no per-tile initialisation of the 32 accumulator registers
+    // (k-slice outermost: eight independent accumulators between two MFMAs of one chain -- with the slice innermost a chain's
+    //  next MFMA issued two slots after its predecessor, inside its 8-pass latency: SQ_WAIT_INST_ANY was 38 % of the wave cycles)
 #pragma unroll
-    for (int st = 0; st < 4; ++st) {
+    for (int ks = 0; ks < NKS; ++ks) {
 #pragma unroll
-      for (int ks = 0; ks < NKS; ++ks) {
+      for (int st = 0; st < 4; ++st) {
 #ifdef P3V_PP_NOLDS                                              // timing experiment: no fragment reads
         const bf16x8_t kf = qf[1][ks];
 #else
@@ -861,12 +863,15 @@ __global__ void __launch_bounds__(512, 1) k_attn_prefill_pp(AttnP p) {
   // 734 per wave-tile against 130 of real work, profiles/r03_pmc_prefill_attn.txt).
   auto softmax = [&](int j) {
     const int kv0 = kv_begin + 64 * j;
-    // every key of the tile visible to every query of the wave -> no per-element mask work (wave-uniform)
-    const bool interior = kv0 + 64 <= kv_end && kv0 >= pad && past + q0 >= pad && (!p.causal || kv0 + 63 <= past + q0);
+    // every key of the tile visible to every query of the wave -> no per-element mask work (wave-uniform; the tile range
+    // [j_int_lo, j_int_hi] is computed once per workgroup: two scalar compares per tile)
+    const bool interior = j >= j_int_lo && j <= j_int_hi;
 #ifdef P3V_PP_VALUPRIO
     __builtin_amdgcn_s_setprio(2);
 #endif
-    load_v(j);                                               // lands under the VALU work below; consumed by the next matrix phase
+    load_v(j, 0);                                            // first half of V^T(j): lands under the VALU work below (the second
+                                                             // half is read at the top of the matrix phase that consumes it: the
+                                                             // VALU phase is the longer of the two)
     float m_t[2];
     if (!PRE) {
 #pragma unroll
@@ -1018,6 +1023,7 @@ __global__ void __launch_bounds__(512, 1) k_attn_prefill_pp(AttnP p) {
 #ifndef P3V_PP_NOPRIO
       __builtin_amdgcn_s_setprio(1);
 #endif
+      load_v(j, 1);                                                     // second half of V^T(j): under the first 12 PV MFMAs
       load_k(j + 1);                                                    // 12 ds_read_b128 in flight under the 28 PV MFMAs
       __builtin_amdgcn_sched_barrier(0);
       pv();
@@ -1033,6 +1039,7 @@ __global__ void __launch_bounds__(512, 1) k_attn_prefill_pp(AttnP p) {
 #endif
       end_step();
       if (NTw <= NT - 3) issue_batch(NTw);
+      load_v(NTw - 1, 1);
       pv();
       pin_o();
       end_step();
@@ -1063,8 +1070,8 @@ __global__ void __launch_bounds__(512, 1) k_attn_prefill_pp(AttnP p) {
 
 // Which prompt-sized kernel (measured, B = 1, 32 heads x 96, causal, random data; profiles/r03_attn_prefill_kernels.txt):
 //   tokens      1024    2531     8192     32768    |  CLIP 17 x 577 (hd 64)   8 x 512
-//   dma (128 q)  29 us   80 us   609 us   7.42 ms  |   56 us                   39 us
-//   pp  (256 q)  36 us   77 us   504 us   6.30 ms  |   73 us                   49 us
+//   dma (128 q)  30 us   80 us   613 us   7.37 ms  |   54 us                   39 us
+//   pp  (256 q)  34 us   75 us   467 us   5.74 ms  |   69 us                   48 us       (883 / 1149 TF/s at 8k / 32k)
 // the 8-wave kernel needs ~10 query blocks per head before its better steady state beats its coarser tail
 constexpr int P3V_ATTN_PP_MIN_L = 2048;
 template <int HD>
