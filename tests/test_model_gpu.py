@@ -672,6 +672,8 @@ def test_config3_long_context_32k(full_text):
     del cache
     torch.cuda.empty_cache()
     c, _ = model(input_ids=ids, max_tokens=1)
+    # two correct orders of the same bf16 arithmetic (decode kernels on a 32768-row cache vs one 32769-row prefill) differ by
+    # 5.2 % of max|logit| on this random network (tools/c3_tol_probe.py, round 3): the bar cannot be tighter than that
     assert_logits(b[:, -1], c[:, -1], "32k decode vs prefill", rel_atol=6e-2)
 
 
