@@ -117,6 +117,29 @@ def test_graph_replayed_greedy_step_equals_eager(text):
         assert torch.equal(hist, torch.cat(eager_tok, dim=1).to(hist.dtype))
 
 
+def test_split_merge_launch_is_a_tested_fallback_of_the_in_launch_merge(text, monkeypatch):
+    """the in-launch split-KV merge relies on workgroups being dispatched in linear order (true on this runtime,
+    not a HIP guarantee) -- `P3V_ATTN_FUSED_MERGE=0` takes the separate merge launch instead.  Both plans must produce the
+    same greedy tokens and logits that agree to bf16 rounding (same partials, different summation order of the splits),
+    through the captured decode graph, at a context with several splits."""
+    model, proc, _ = text
+    from phi_3_vision_mlx_amd import ops
+    inputs, n = dict(input_ids=rand_ids(700, 17)), 6
+    runs = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("P3V_ATTN_FUSED_MERGE", mode)
+        lg, cache = model(**inputs, max_tokens=n)
+        t = ops.argmax(lg[:, -1, :].contiguous())[:, None]
+        toks, lgs = [t.cpu()], []
+        for _ in range(n - 1):
+            lg, t = model.greedy_step(t, cache)
+            toks.append(t.cpu().clone()), lgs.append(lg[:, -1].float().cpu().clone())
+        assert cache[0].state.graphs["greedy"]["bufs"]["attn_merge"] == (mode == "1")
+        runs[mode] = (torch.cat(toks, 1), torch.stack(lgs))
+    assert torch.equal(runs["1"][0], runs["0"][0])
+    assert_logits(runs["1"][1].flatten(0, 1), runs["0"][1].flatten(0, 1), "merge in launch vs merge launch", rel_atol=1e-2)
+
+
 def test_batched_left_pad(text):
     model, proc, oracle = text
     inputs = proc(["a", "hello world, this is a longer prompt", "mid size"])
