@@ -275,13 +275,17 @@ def serve_continuous(engine, port=8000, host="127.0.0.1", image_policy=None, **k
     return ThreadingHTTPServer((host, port), make_handler(backend, image_policy)), backend
 
 
-def run(port=8000, synthetic=False, blind_model=False, merge=False, continuous=False, host="127.0.0.1", image_policy=None):
+def run(port=8000, synthetic=False, blind_model=False, merge=False, continuous=False, host="127.0.0.1", image_policy=None,
+        long_window=0, slots=8):
     from .api import _apply_chat_template, generate, load
     preload = load(blind_model=blind_model, synthetic=synthetic or None)
     processor = preload[1]
     if continuous:
-        from .engine import ContinuousEngine
-        httpd, engine = serve_continuous(ContinuousEngine(*preload), port=port, host=host, image_policy=image_policy)
+        from .engine import ContinuousEngine, RegimeRouter
+        eng = ContinuousEngine(*preload, slots=slots)                 # requests with prompt + max_tokens <= 4096 (short RoPE factors)
+        if long_window > 4096:                                       # + one engine for the long-RoPE regime (phi.py:492)
+            eng = RegimeRouter([eng, ContinuousEngine(*preload, slots=max(1, slots // 2), window=long_window)])
+        httpd, engine = serve_continuous(eng, port=port, host=host, image_policy=image_policy)
         print(f"Starting server on port {port} (continuous batching)")
         try:
             httpd.serve_forever()
@@ -319,8 +323,10 @@ if __name__ == "__main__":
     ap.add_argument("--blind", action="store_true", help="text-only Phi-3-mini-128K")
     ap.add_argument("--merge", action="store_true", help="fold concurrent same-budget requests into one batched generate (opt-in)")
     ap.add_argument("--continuous", action="store_true", help="continuous batching engine (requests join / leave between decode steps)")
+    ap.add_argument("--long-window", type=int, default=0, help="with --continuous: also serve prompt + max_tokens > 4096 up to this many tokens")
+    ap.add_argument("--slots", type=int, default=8, help="with --continuous: batch rows of the engine")
     ap.add_argument("--host", default="127.0.0.1", help='interface to bind ("" = all, as the reference)')
     ap.add_argument("--image-dir", default=None, help="allow `images` entries naming files under this directory")
     ap.add_argument("--image-host", action="append", default=[], help="allow `images` URLs on this host (repeatable)")
     a = ap.parse_args()
-    run(a.port, a.synthetic, a.blind, a.merge, a.continuous, a.host, ImagePolicy(a.image_dir, a.image_host))
+    run(a.port, a.synthetic, a.blind, a.merge, a.continuous, a.host, ImagePolicy(a.image_dir, a.image_host), a.long_window, a.slots)
