@@ -648,8 +648,8 @@ __global__ void __launch_bounds__(256, 2) k_attn_prefill_dma(AttnP p) {
 //     the exponent; the reference only moves when a tile's maximum exceeds it by more than 2^8 (wave-uniform slow path
 //     that rescales O and l once; P <= 256 in bf16 has the same relative precision) -- and on a query's first visible
 //     tile, which sets it.  Fast path per tile and wave: 32 v_exp + 16 v_cvt_pk + ~28 max / select / swap.
-//   * K / V^T tiles by LDS-DMA into a ring of three K tiles and four V^T tiles (see issue_batch for why four), 24 (HD = 96)
-//     one-KiB pieces per tile pair = 3 per wave, issued at the top of a matrix phase two tiles ahead of their use; counted
+//   * K / V^T tiles by LDS-DMA into a ring of four K tiles and five V^T tiles (see issue_batch for the depths), 24 (HD = 96)
+//     one-KiB pieces per tile pair = 3 per wave, issued at the top of a VALU phase two to three tiles ahead of their use; counted
 //     vmcnt (one batch stays in flight across every barrier), never a full drain inside the loop.  The K tile is staged in a
 //     PERMUTED key order that makes every V^T fragment one ds_read_b128 (see load_k), both tiles conflict-free.
 //   * fragment reads are taken off the MFMA stream: V^T(j) is read at the top of softmax(j) (lands under the VALU work), K(j+1)
@@ -661,6 +661,9 @@ __global__ void __launch_bounds__(256, 2) k_attn_prefill_dma(AttnP p) {
 // empty volatile asm uses); spilling lane-constant LDS offsets (reload = scratch load = vmcnt(0) = DMA drained: recomputed per
 // phase from an opaque lane id).
 // Row sums ride on the matrix cores as before (ones-row V^T fragment).
+#ifndef P3V_PP_DMA_IN_VALU
+#define P3V_PP_DMA_IN_VALU 1
+#endif
 #ifdef P3V_PP_DEBUG                                             // tools/attn_pp_timeline.py: per-wave phase timestamps of ONE workgroup
 __device__ unsigned long long p3v_ppdbg[8 * 128];
 #define PP_T(slot) do { if (blockIdx.x == P3V_PP_DEBUG && (threadIdx.x & 63) == 0 && (slot) < 127) p3v_ppdbg[(threadIdx.x >> 6) * 128 + 1 + (slot)] = __builtin_readcyclecounter(); } while (0)
@@ -673,7 +676,8 @@ extern "C" int p3v_ppdbg_read(unsigned long long* out) {
 template <int HD, bool PRE>
 __global__ void __launch_bounds__(512, 1) k_attn_prefill_pp(AttnP p) {
   constexpr int KROW = HD * 2, VROW = 128, NKS = HD / 32, NDT = HD / 16, CPR = HD / 8;
-  constexpr int KTILE = 64 * KROW, VTILE = HD * VROW, RING = 3, VRING = 4;   // ring depths: see issue_batch
+  constexpr bool DV = P3V_PP_DMA_IN_VALU;                      // DMA batches issued from the VALU phase (see issue_batch)
+  constexpr int KTILE = 64 * KROW, VTILE = HD * VROW, RING = DV ? 4 : 3, VRING = DV ? 5 : 4;   // ring depths: see issue_batch
   constexpr int NK = KTILE / 1024, NV = VTILE / 1024, NPW = (NK + NV) / 8;   // DMA pieces per tile (K, V^T) and per wave and batch
   constexpr float THR = 8.f;
   static_assert((NK + NV) % 8 == 0, "pieces must divide over 8 waves");
@@ -746,6 +750,13 @@ __global__ void __launch_bounds__(512, 1) k_attn_prefill_pp(AttnP p) {
   // batch overwrites: K(jb - 1), read in M(jb - 1) (steps 2 jb - 2 / 2 jb - 1) -> three K slots; V^T(jb - 2), read in
   // softmax(jb - 2) (steps 2 jb - 3 / 2 jb - 2) -> FOUR V^T slots (with three, group A's batch jb would land on the tile
   // group B's softmax(jb - 1) is still reading in step 2 jb).  Prologue batches -2, -1 = tiles 0, 1 (clamped into [0, NT)).
+  // DV (round 3, late): the matrix phase is the longer one and a DMA issue costs its wave ~100 cycles of MFMA issue, so batch
+  // jb >= 1 is issued one step EARLIER, at the top of the wave's VALU phase softmax(jb - 1) (A: step 2 jb - 1, B: 2 jb); the
+  // slots it overwrites must then be one tile older: K(jb - 2) (last read in M(jb - 2), steps 2 jb - 4 / 2 jb - 3) -> FOUR
+  // K slots, V^T(jb - 3) (second half read in M(jb - 2)) -> FIVE V^T slots (with four, A's batch would land in step 2 jb - 1 on
+  // the tile whose second half B's M(jb - 1) reads in that step).  Each wave issues its batches in order (`next_b`); what
+  // may stay in flight across the barrier of an odd step is whatever it has issued beyond batch jn - 2 (end_step).
+  int next_b = 0;
   auto issue_batch = [&](int jb) {
 #ifdef P3V_PP_NODMA                                              // timing experiment: tiles never move
     return;
@@ -764,6 +775,14 @@ __global__ void __launch_bounds__(512, 1) k_attn_prefill_pp(AttnP p) {
         pf_lptr_t dst = (pf_lptr_t)(smem + RING * KTILE + vs_ * VTILE + (pi - NK) * 1024);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_v, dst, 16, vo, so_v, 0, 0);
       }
+    }
+  };
+
+  auto issue_at = [&](int ls) {                               // the batch a wave issues at the top of its local step ls, if any
+    const int jb = DV ? (ls == 0 ? 0 : (ls & 1) ? (ls + 1) >> 1 : -1) : ((ls & 1) ? -1 : ls >> 1);
+    if (jb == next_b && jb <= NT - 3) {
+      issue_batch(jb);
+      ++next_b;
     }
   };
 
@@ -869,6 +888,7 @@ __global__ void __launch_bounds__(512, 1) k_attn_prefill_pp(AttnP p) {
 #ifdef P3V_PP_VALUPRIO
     __builtin_amdgcn_s_setprio(2);
 #endif
+    issue_at(2 * j + 1);                                     // (DV) this wave's pieces of DMA batch j + 1
     load_v(j, 0);                                            // first half of V^T(j): lands under the VALU work below (the second
                                                              // half is read at the top of the matrix phase that consumes it: the
                                                              // VALU phase is the longer of the two)
@@ -899,6 +919,10 @@ __global__ void __launch_bounds__(512, 1) k_attn_prefill_pp(AttnP p) {
     //  scheduler interleaves the two)
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
+#ifdef P3V_PP_NOMAX
+      m_t[u] = s[u][0][0];
+      continue;
+#endif
       float a = fmaxf(fmaxf(s[u][0][0], s[u][0][1]), s[u][0][2]);      // v_max3 chains
       float c = fmaxf(fmaxf(s[u][0][3], s[u][1][0]), s[u][1][1]);
       a = fmaxf(fmaxf(a, s[u][1][2]), s[u][1][3]);
@@ -908,7 +932,11 @@ __global__ void __launch_bounds__(512, 1) k_attn_prefill_pp(AttnP p) {
       a = fmaxf(fmaxf(a, s[u][3][2]), s[u][3][3]);
       m_t[u] = rows_max(fmaxf(a, c));
     }
+#ifdef P3V_PP_NOMAX                                              // timing experiment: no reduction, no decision (first tile only)
+    const bool slow = unset[0] || unset[1];
+#else
     const bool slow = unset[0] || unset[1] || m_t[0] > THR || m_t[1] > THR;
+#endif
     if (__builtin_amdgcn_ballot_w64(slow) != 0) {               // wave-uniform: a reference moves (first tile, or a jump > 2^8)
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
@@ -984,8 +1012,9 @@ __global__ void __launch_bounds__(512, 1) k_attn_prefill_pp(AttnP p) {
     // (group A issued it three steps ago, group B two); the batch issued since (jn - 1, if there was one: the last batch is
     // NT - 3) stays in flight
     if (step & 1) {
-      const int jn = (step + 1) >> 1;
-      if (jn <= NT - 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPW) : "memory");
+      const int jn = (step + 1) >> 1, newer = next_b - (jn - 1);   // batches this wave has issued beyond jn - 2
+      if (newer >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NPW) : "memory");
+      else if (newer == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPW) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
 #ifndef P3V_PP_NOBAR                                             // (timing experiment: no step barrier)
@@ -1003,7 +1032,7 @@ __global__ void __launch_bounds__(512, 1) k_attn_prefill_pp(AttnP p) {
     asm volatile("s_barrier" ::: "memory");
     if (grp) end_step();                                                // group B runs one step behind group A
     // M(0)
-    if (0 <= NT - 3) issue_batch(0);
+    issue_at(0);
     if (NTw > 0) {
 #ifndef P3V_PP_NOPRIO
       __builtin_amdgcn_s_setprio(1);
@@ -1019,7 +1048,7 @@ __global__ void __launch_bounds__(512, 1) k_attn_prefill_pp(AttnP p) {
       softmax(j);
 #endif
       end_step();
-      if (j + 1 <= NT - 3) issue_batch(j + 1);
+      issue_at(2 * j + 2);
 #ifndef P3V_PP_NOPRIO
       __builtin_amdgcn_s_setprio(1);
 #endif
@@ -1038,7 +1067,7 @@ __global__ void __launch_bounds__(512, 1) k_attn_prefill_pp(AttnP p) {
       softmax(NTw - 1);
 #endif
       end_step();
-      if (NTw <= NT - 3) issue_batch(NTw);
+      issue_at(2 * NTw);
       load_v(NTw - 1, 1);
       pv();
       pin_o();
@@ -1046,7 +1075,7 @@ __global__ void __launch_bounds__(512, 1) k_attn_prefill_pp(AttnP p) {
     }
     while (step <= 2 * NT + 1) {                                        // done (or never had rows): DMA share + barriers only
       const int ls = step - grp;
-      if (ls >= 0 && !(ls & 1) && (ls >> 1) <= NT - 3 && (ls >> 1) > NTw) issue_batch(ls >> 1);
+      if (ls >= 0) issue_at(ls);
       end_step();
     }
   }
@@ -1071,7 +1100,7 @@ __global__ void __launch_bounds__(512, 1) k_attn_prefill_pp(AttnP p) {
 // Which prompt-sized kernel (measured, B = 1, 32 heads x 96, causal, random data; profiles/r03_attn_prefill_kernels.txt):
 //   tokens      1024    2531     8192     32768    |  CLIP 17 x 577 (hd 64)   8 x 512
 //   dma (128 q)  30 us   80 us   613 us   7.37 ms  |   54 us                   39 us
-//   pp  (256 q)  34 us   75 us   467 us   5.74 ms  |   69 us                   48 us       (883 / 1149 TF/s at 8k / 32k)
+//   pp  (256 q)  34 us   74 us   450-467 us   5.7-6.1 ms  |   69-74 us           48-50 us     (883-917 / 1080-1149 TF/s at 8k / 32k; box-dependent)
 // the 8-wave kernel needs ~10 query blocks per head before its better steady state beats its coarser tail
 constexpr int P3V_ATTN_PP_MIN_L = 2048;
 template <int HD>
@@ -1097,7 +1126,7 @@ static int launch_attn_prefill(const AttnP& p, hipStream_t s) {
     q.head_group = kv_bytes * p.nh <= (64u << 20) ? p.nh : (p.nh % 8 == 0 && kv_bytes * 8 <= (128u << 20) ? 8 : (p.nh % 4 == 0 ? 4 : p.nh));
     const int pp = p3v_tuning().attn_pp;                         // -1: by shape; 0 / 1: pin (kernel tests run both)
     if (pp > 0 || (pp < 0 && p.L >= P3V_ATTN_PP_MIN_L && (p.q_prescaled || HD == 64))) {   // (<96, plain>: 5 spilled registers, tests only)
-      constexpr int LDS3 = 3 * 64 * HD * 2 + 4 * HD * 128;     // K ring of 3 tiles + V^T ring of 4
+      constexpr int LDS3 = (P3V_PP_DMA_IN_VALU ? 4 : 3) * 64 * HD * 2 + (P3V_PP_DMA_IN_VALU ? 5 : 4) * HD * 128;   // K ring + V^T ring (issue_batch)
       static bool attr3_set = false;
       if (!attr3_set) {
         if (hipFuncSetAttribute((const void*)k_attn_prefill_pp<HD, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS3) != hipSuccess ||

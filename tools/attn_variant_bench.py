@@ -1,24 +1,37 @@
-"""Kernel time of k_attn_prefill_pp builds (tools/build_variant.sh <name> p3v_attention.hip -D...) at one shape; timing
-experiments only (several variants compute garbage)."""
-import os, sys
-os.environ["P3V_LIB"] = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "build", f"libp3v_{sys.argv[1]}.so")
+"""Kernel time of k_attn_prefill_pp builds (tools/build_variant.sh <name> p3v_attention.hip -D...) -- several builds INTERLEAVED in
+one process (the chip's clock follows its thermal state: back-to-back processes are not comparable).
+  python tools/attn_variant_bench.py v1,v2 [shape ...]     shape = B:L:heads:hd:causal"""
+import ctypes, os, sys, statistics
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from phi_3_vision_mlx_amd import ops
-L, nh, hd = int(sys.argv[2]) if len(sys.argv) > 2 else 8192, 32, 96
-pp = int(sys.argv[3]) if len(sys.argv) > 3 else 1
-q = (torch.randn(1, nh, L, hd, device="cuda") * (hd ** -0.5 * ops.Q_PRESCALE)).bfloat16()
-k = torch.randn(1, nh, L, hd, device="cuda").bfloat16()
-v = torch.randn(1, nh, hd, L, device="cuda").bfloat16()
-out = torch.empty(1, L, nh * hd, device="cuda", dtype=torch.bfloat16)
-ops.set_tuning("attn_pp", pp)
-f = lambda: ops.attention(q, out, 1, L, nh, nh, hd, hd ** -0.5, True, k_past=k, v_past=v, past_t=L, new_is_cache=True, q_prescaled=True)
-for _ in range(3): f()
-torch.cuda.synchronize()
-a, b = ops.Event(), ops.Event()
-a.record()
-for _ in range(10): f()
-b.record()
-torch.cuda.synchronize()
-ms = a.elapsed_ms(b) / 10
-print(f"{sys.argv[1]:20s} L={L} pp={pp}: {ms * 1e3:8.1f} us  {2 * nh * L * L * hd / ms / 1e9:7.1f} TF/s", flush=True)
+from phi_3_vision_mlx_amd import _lib, ops
+names = sys.argv[1].split(",")
+shapes = [tuple(int(x) for x in a.split(":")) for a in sys.argv[2:]] or [(1, 8192, 32, 96, 1)]
+libs = {}
+for n in names:
+    l = ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "build", f"libp3v_{n}.so"))
+    for name, (res, args) in _lib.SIGNATURES.items():
+        fn = getattr(l, name)
+        fn.restype, fn.argtypes = res, args
+    l.p3v_set_tuning(b"attn_pp", 1)
+    libs[n] = l
+for B, L, nh, hd, causal in shapes:
+    Tp = (L + 63) // 64 * 64
+    pre = bool(causal)
+    q = (torch.randn(B, nh, L, hd, device="cuda") * (hd ** -0.5 * ops.Q_PRESCALE if pre else 1.0)).bfloat16()
+    k = torch.randn(B, nh, Tp, hd, device="cuda").bfloat16()
+    v = torch.randn(B, nh, hd, Tp, device="cuda").bfloat16()
+    out = torch.empty(B, L, nh * hd, device="cuda", dtype=torch.bfloat16)
+    t = {n: [] for n in names}
+    for rep in range(5):
+        for n in names:
+            _lib._lib = libs[n]
+            f = lambda: ops.attention(q, out, B, L, nh, nh, hd, hd ** -0.5, bool(causal), k_past=k, v_past=v, past_t=Tp, new_is_cache=True, q_prescaled=pre)
+            f(); torch.cuda.synchronize()
+            a, b = ops.Event(), ops.Event()
+            a.record()
+            for _ in range(5 if L > 16384 else 10): f()
+            b.record(); torch.cuda.synchronize()
+            t[n].append(a.elapsed_ms(b) / (5 if L > 16384 else 10))
+    fl = 4 * B * nh * L * L * hd * (0.5 if causal else 1.0)
+    print(f"B={B} L={L} heads={nh} hd={hd} causal={causal}: " + "   ".join(f"{n} {statistics.median(t[n])*1e3:8.1f} us ({fl/statistics.median(t[n])/1e9:6.0f} TF/s)" for n in names), flush=True)
