@@ -664,14 +664,35 @@ __global__ void __launch_bounds__(256, 2) k_attn_prefill_dma(AttnP p) {
 #ifndef P3V_PP_DMA_IN_VALU
 #define P3V_PP_DMA_IN_VALU 1
 #endif
+#ifndef P3V_PP_DMA_POS
+#define P3V_PP_DMA_POS 0                                        // where in the VALU phase the DMA pieces are issued: 0 start, 1 after the maxima, 2 end
+#endif
+#ifndef P3V_PP_PRIO_LATE
+#define P3V_PP_PRIO_LATE 0
+#endif
+#ifndef P3V_PP_LATE_K
+#define P3V_PP_LATE_K 0                                         // 1: the K fragments are read after the first half of the PV MFMAs
+#endif
+#ifndef P3V_PP_V_IN_MATRIX
+#define P3V_PP_V_IN_MATRIX 1                                    // 1: both halves of the V^T fragments are read in the matrix phase
+#endif
 #ifdef P3V_PP_DEBUG                                             // tools/attn_pp_timeline.py: per-wave phase timestamps of ONE workgroup
 __device__ unsigned long long p3v_ppdbg[8 * 128];
 #define PP_T(slot) do { if (blockIdx.x == P3V_PP_DEBUG && (threadIdx.x & 63) == 0 && (slot) < 127) p3v_ppdbg[(threadIdx.x >> 6) * 128 + 1 + (slot)] = __builtin_readcyclecounter(); } while (0)
 extern "C" int p3v_ppdbg_read(unsigned long long* out) {
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(p3v_ppdbg), sizeof(unsigned long long) * 8 * 128) == hipSuccess ? 0 : -1;
 }
+// stamps INSIDE a phase: s_memtime into an SGPR pair (consumed at the end of the step only: no lgkmcnt wait at the stamp)
+__device__ unsigned long long p3v_ppdbg2[8 * 64 * 4];
+#define PP_S(k) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0" : "=s"(pp_s[k])); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define PP_S_FLUSH(step) do { if (blockIdx.x == P3V_PP_DEBUG && (threadIdx.x & 63) == 0 && (step) < 64) { for (int k_ = 0; k_ < 4; ++k_) p3v_ppdbg2[((threadIdx.x >> 6) * 64 + (step)) * 4 + k_] = pp_s[k_]; } } while (0)
+extern "C" int p3v_ppdbg2_read(unsigned long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(p3v_ppdbg2), sizeof(unsigned long long) * 8 * 64 * 4) == hipSuccess ? 0 : -1;
+}
 #else
 #define PP_T(slot) do { } while (0)
+#define PP_S(k) do { } while (0)
+#define PP_S_FLUSH(step) do { } while (0)
 #endif
 template <int HD, bool PRE>
 __global__ void __launch_bounds__(512, 1) k_attn_prefill_pp(AttnP p) {
@@ -807,6 +828,9 @@ __global__ void __launch_bounds__(512, 1) k_attn_prefill_pp(AttnP p) {
     for (int d = 0; d < NDT; ++d) o[u][d] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
   f32x4_t s[2][4];
   bf16x8_t pf[2][2];
+#ifdef P3V_PP_DEBUG
+  unsigned long long pp_s[4] = {0, 0, 0, 0};
+#endif
 
   // Key order inside a tile.  The S^T accumulator rows a lane holds (rows 4g .. 4g+3 of each 16-row block) become ITS
   // B fragment of the PV product, k index (g, 0..7) = (block 2st', rows 4g..4g+3), (block 2st'+1, rows 4g..4g+3).  The K
@@ -857,6 +881,16 @@ __global__ void __launch_bounds__(512, 1) k_attn_prefill_pp(AttnP p) {
       }
     }
   };
+  auto pv_half = [&](int st) {                               // keys 32 st .. 32 st + 31 of the tile
+#pragma unroll
+    for (int d = 0; d < NDT; ++d) {
+      const bf16x8_t vf = vfr[st][d];
+      o[0][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[0][st], o[0][d], 0, 0, 0);
+      o[1][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[1][st], o[1][d], 0, 0, 0);
+    }
+    ol[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones_f, pf[0][st], ol[0], 0, 0, 0);
+    ol[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones_f, pf[1][st], ol[1], 0, 0, 0);
+  };
   auto pv = [&]() {                                          // O^T += V^T_j . P^T(j), l += 1 . P^T(j), V^T_j in vfr
 #pragma unroll
     for (int st = 0; st < 2; ++st)
@@ -888,8 +922,13 @@ __global__ void __launch_bounds__(512, 1) k_attn_prefill_pp(AttnP p) {
 #ifdef P3V_PP_VALUPRIO
     __builtin_amdgcn_s_setprio(2);
 #endif
+#if P3V_PP_DMA_POS == 0
     issue_at(2 * j + 1);                                     // (DV) this wave's pieces of DMA batch j + 1
+#endif
+    PP_S(0);
+#if !P3V_PP_V_IN_MATRIX
     load_v(j, 0);                                            // first half of V^T(j): lands under the VALU work below (the second
+#endif
                                                              // half is read at the top of the matrix phase that consumes it: the
                                                              // VALU phase is the longer of the two)
     float m_t[2];
@@ -937,6 +976,10 @@ __global__ void __launch_bounds__(512, 1) k_attn_prefill_pp(AttnP p) {
 #else
     const bool slow = unset[0] || unset[1] || m_t[0] > THR || m_t[1] > THR;
 #endif
+#if P3V_PP_DMA_POS == 1
+    issue_at(2 * j + 1);
+#endif
+    PP_S(1);
     if (__builtin_amdgcn_ballot_w64(slow) != 0) {               // wave-uniform: a reference moves (first tile, or a jump > 2^8)
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
@@ -968,6 +1011,7 @@ __global__ void __launch_bounds__(512, 1) k_attn_prefill_pp(AttnP p) {
 #else
         for (int r = 0; r < 4; ++r) s[u][st][r] = __builtin_amdgcn_exp2f(s[u][st][r]);
 #endif
+      if (u == 1) PP_S(2);
 #pragma unroll
       for (int st = 0; st < 2; ++st) {
         u32x4_t pw;
@@ -981,6 +1025,10 @@ __global__ void __launch_bounds__(512, 1) k_attn_prefill_pp(AttnP p) {
     // P is USED here as far as the optimiser can tell: without this the exponentials are sunk past the step barrier (an asm
     // barrier orders memory operations only) into the matrix phase that consumes them
     asm volatile("" ::"v"(pf[0][0]), "v"(pf[0][1]), "v"(pf[1][0]), "v"(pf[1][1]));
+#if P3V_PP_DMA_POS == 2
+    issue_at(2 * j + 1);
+#endif
+    PP_S(3);
 #ifdef P3V_PP_VALUPRIO
     __builtin_amdgcn_s_setprio(0);
 #endif
@@ -1007,6 +1055,7 @@ __global__ void __launch_bounds__(512, 1) k_attn_prefill_pp(AttnP p) {
     // (the scheduler may move anything that is not a memory operation across an asm barrier -- it sank the whole
     //  exponential block of the softmax into the following matrix phase: fence the instruction stream as well)
     __builtin_amdgcn_sched_barrier(0);
+    PP_S_FLUSH(step);
     PP_T(2 * step + 1);
     // before the barrier that ends an ODD step every wave has batch jn - 2 (tile jn: read from the next step on) in LDS
     // (group A issued it three steps ago, group B two); the batch issued since (jn - 1, if there was one: the last batch is
@@ -1049,16 +1098,35 @@ __global__ void __launch_bounds__(512, 1) k_attn_prefill_pp(AttnP p) {
 #endif
       end_step();
       issue_at(2 * j + 2);
-#ifndef P3V_PP_NOPRIO
+#if !defined(P3V_PP_NOPRIO) && !P3V_PP_PRIO_LATE
       __builtin_amdgcn_s_setprio(1);
 #endif
+      PP_S(0);
+#if P3V_PP_V_IN_MATRIX
+      load_v(j, 0);
+#endif
       load_v(j, 1);                                                     // second half of V^T(j): under the first 12 PV MFMAs
+#if P3V_PP_LATE_K
+      __builtin_amdgcn_sched_barrier(0);
+      pv_half(0);
+      __builtin_amdgcn_sched_barrier(0);
+      load_k(j + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      pv_half(1);
+#else
       load_k(j + 1);                                                    // 12 ds_read_b128 in flight under the 28 PV MFMAs
       __builtin_amdgcn_sched_barrier(0);
+      PP_S(1);
+#if P3V_PP_PRIO_LATE
+      __builtin_amdgcn_s_setprio(1);                                    // priority for the MFMA stream only, not for the fragment reads
+#endif
       pv();
+#endif
+      PP_S(2);
       qk();
       pin_o();
       pin_s();
+      PP_S(3);
       __builtin_amdgcn_s_setprio(0);
       end_step();
     }
@@ -1068,6 +1136,9 @@ __global__ void __launch_bounds__(512, 1) k_attn_prefill_pp(AttnP p) {
 #endif
       end_step();
       issue_at(2 * NTw);
+#if P3V_PP_V_IN_MATRIX
+      load_v(NTw - 1, 0);
+#endif
       load_v(NTw - 1, 1);
       pv();
       pin_o();
@@ -1102,6 +1173,7 @@ __global__ void __launch_bounds__(512, 1) k_attn_prefill_pp(AttnP p) {
 //   dma (128 q)  30 us   80 us   613 us   7.37 ms  |   54 us                   39 us
 //   pp  (256 q)  34 us   74 us   450-467 us   5.7-6.1 ms  |   69-74 us           48-50 us     (883-917 / 1080-1149 TF/s at 8k / 32k; box-dependent)
 // the 8-wave kernel needs ~10 query blocks per head before its better steady state beats its coarser tail
+#include "p3v_attn_il.h"
 constexpr int P3V_ATTN_PP_MIN_L = 2048;
 template <int HD>
 static int launch_attn_prefill(const AttnP& p, hipStream_t s) {
@@ -1125,6 +1197,18 @@ static int launch_attn_prefill(const AttnP& p, hipStream_t s) {
     const size_t kv_bytes = (size_t)(p.past + p.L) * HD * 4;     // one head's K + V^T
     q.head_group = kv_bytes * p.nh <= (64u << 20) ? p.nh : (p.nh % 8 == 0 && kv_bytes * 8 <= (128u << 20) ? 8 : (p.nh % 4 == 0 ? 4 : p.nh));
     const int pp = p3v_tuning().attn_pp;                         // -1: by shape; 0 / 1: pin (kernel tests run both)
+    const int il = p3v_tuning().attn_il;                         // the interleaved kernel (pre-scaled Q only)
+    if (p.q_prescaled && (il > 0 || (il < 0 && pp != 0 && p.L >= P3V_ATTN_PP_MIN_L))) {
+      constexpr int LDS4 = 3 * 64 * HD * 2 + 3 * HD * 128;
+      static bool attr4_set = false;
+      if (!attr4_set) {
+        if (hipFuncSetAttribute((const void*)k_attn_prefill_il<HD>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS4) != hipSuccess) return P3V_ERR_HIP;
+        attr4_set = true;
+      }
+      hipLaunchKernelGGL((k_attn_prefill_il<HD>), dim3(p.nh * p3v_cdiv(p.L, 256), 1, p.B), dim3(512), LDS4, s, q);
+      P3V_CHECK_LAUNCH();
+      return P3V_OK;
+    }
     if (pp > 0 || (pp < 0 && p.L >= P3V_ATTN_PP_MIN_L && (p.q_prescaled || HD == 64))) {   // (<96, plain>: 5 spilled registers, tests only)
       constexpr int LDS3 = (P3V_PP_DMA_IN_VALU ? 4 : 3) * 64 * HD * 2 + (P3V_PP_DMA_IN_VALU ? 5 : 4) * HD * 128;   // K ring + V^T ring (issue_batch)
       static bool attr3_set = false;

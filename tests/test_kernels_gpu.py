@@ -348,8 +348,8 @@ def test_attention(ops, orc, B, L, past, hd, nh, causal, pads):
 
 
 def _prefill_case(ops, orc, B, L, past, hd, nh, causal, pads, prescaled, pp, spike=None, seed=40, q_std=1.0):
-    """Prompt-sized attention through p3v_attention with the kernel pinned (pp = 1: k_attn_prefill_pp, 0: k_attn_prefill_dma)
-    vs the oracle's fp32 attention.  prescaled: q goes in multiplied by scale * log2(e) and rounded once (what
+    """Prompt-sized attention through p3v_attention with the kernel pinned (pp = 2: k_attn_prefill_il [pre-scaled q only],
+    1: k_attn_prefill_pp, 0: k_attn_prefill_dma) vs the oracle's fp32 attention.  prescaled: q goes in multiplied by scale * log2(e) and rounded once (what
     p3v_rope_kv_append's q_scale produces); the reference then uses exactly those bf16 values divided back in fp32."""
     T = past + L
     Tp = (T + 63) // 64 * 64
@@ -365,13 +365,15 @@ def _prefill_case(ops, orc, B, L, past, hd, nh, causal, pads, prescaled, pp, spi
     kc = torch.zeros((B, nh, Tp, hd), dtype=BF16)
     vc = torch.zeros((B, nh, hd, Tp), dtype=BF16)
     kc[:, :, :T], vc[:, :, :, :T] = k, v.transpose(2, 3)
-    old = ops.set_tuning("attn_pp", pp)
+    if pp == 2 and not prescaled:
+        pytest.skip("the interleaved kernel takes pre-scaled q only (the launcher never picks it otherwise)")
+    old, old_il = ops.set_tuning("attn_pp", min(pp, 1)), ops.set_tuning("attn_il", int(pp == 2))
     try:
         ops.attention(q_in.cuda(), out, B, L, nh, nh, hd, scale, causal, past=past, k_past=kc.cuda(), v_past=vc.cuda(), past_t=Tp,
                       pad_len=pad.cuda() if pads else None, new_is_cache=True, q_prescaled=prescaled)
         torch.cuda.synchronize()
     finally:
-        ops.set_tuning("attn_pp", old)
+        ops.set_tuning("attn_pp", old), ops.set_tuning("attn_il", old_il)
     t = torch.arange(T)[None, None, None, :]
     qpos = (past + torch.arange(L))[None, None, :, None]
     allowed = (t >= pad[:, None, None, None]) & (qpos >= pad[:, None, None, None])
@@ -387,7 +389,7 @@ def _prefill_case(ops, orc, B, L, past, hd, nh, causal, pads, prescaled, pp, spi
     return got
 
 
-@pytest.mark.parametrize("pp", [1, 0], ids=["pingpong", "dma"])
+@pytest.mark.parametrize("pp", [2, 1, 0], ids=["interleaved", "pingpong", "dma"])
 @pytest.mark.parametrize("prescaled", [True, False], ids=["prescaled", "plain"])
 @pytest.mark.parametrize("B,L,past,hd,nh,causal,pads", [
     (1, 700, 0, 96, 2, True, None),            # 3 query blocks of 256, the last one ragged (188 rows: two idle waves)
@@ -403,7 +405,7 @@ def test_attention_prefill_kernels(ops, orc, B, L, past, hd, nh, causal, pads, p
     _prefill_case(ops, orc, B, L, past, hd, nh, causal, pads, prescaled, pp)
 
 
-@pytest.mark.parametrize("pp", [1, 0], ids=["pingpong", "dma"])
+@pytest.mark.parametrize("pp", [2, 1, 0], ids=["interleaved", "pingpong", "dma"])
 def test_attention_prefill_long_context_spot_rows(ops, orc, pp):
     """12288 queries x 12288 keys x 8 heads (K / V^T far larger than the L2: the LDS-DMA tiles arrive LATE, which is what
     exposes a missing wait or a ring slot reused too early -- the first version of the ping-pong kernel passed every
@@ -417,13 +419,13 @@ def test_attention_prefill_long_context_spot_rows(ops, orc, pp):
     q_in = (q.float() * (scale * ops.Q_PRESCALE)).to(BF16)
     vt = v.transpose(2, 3).contiguous()
     out = torch.full((B, L, nh * hd), float("nan"), dtype=BF16, device="cuda")
-    old = ops.set_tuning("attn_pp", pp)
+    old, old_il = ops.set_tuning("attn_pp", min(pp, 1)), ops.set_tuning("attn_il", int(pp == 2))
     try:
         for _ in range(3):                                              # races are timing-dependent: a few launches
             ops.attention(q_in, out, B, L, nh, nh, hd, scale, True, k_past=k, v_past=vt, past_t=L, new_is_cache=True, q_prescaled=True)
         torch.cuda.synchronize()
     finally:
-        ops.set_tuning("attn_pp", old)
+        ops.set_tuning("attn_pp", old), ops.set_tuning("attn_il", old_il)
     assert torch.isfinite(out.float()).all()
     rows = torch.cat([torch.arange(0, L, 197), torch.tensor([255, 256, 4095, 4096, L - 257, L - 1])]).unique()
     qr = (q_in[0, :, rows].float().cpu() / (scale * ops.Q_PRESCALE))   # [nh, n, hd]
@@ -434,7 +436,7 @@ def test_attention_prefill_long_context_spot_rows(ops, orc, pp):
     close(out[0, rows].float().cpu(), ref, rtol=2 ** -6, atol=2e-2)
 
 
-@pytest.mark.parametrize("pp", [1, 0], ids=["pingpong", "dma"])
+@pytest.mark.parametrize("pp", [2, 1, 0], ids=["interleaved", "pingpong", "dma"])
 def test_attention_prefill_reference_jump_and_large_scores(ops, orc, pp):
     """The ping-pong kernel keeps a per-query reference for the exponent and moves it only when a tile's maximum exceeds it
     by more than 2^8 (guide T13 hazard: O, l and the pending P must be rescaled exactly once).  (a) a spiked key in the
@@ -442,9 +444,9 @@ def test_attention_prefill_reference_jump_and_large_scores(ops, orc, pp):
     magnitude ~100 (log2 units) with the FIRST tile far below the later ones; (c) the first visible tile sets the reference
     even when its scores are hugely negative (no underflow of the whole row)."""
     _prefill_case(ops, orc, 1, 600, 0, 96, 2, True, None, True, pp, spike=(0, 450, 300))
-    _prefill_case(ops, orc, 1, 600, 0, 96, 2, True, None, False, pp, spike=(0, 599, 64))
+    _prefill_case(ops, orc, 1, 600, 0, 96, 2, True, None, pp == 2, pp, spike=(0, 599, 64))
     _prefill_case(ops, orc, 1, 400, 0, 96, 1, True, None, True, pp, q_std=6.0, seed=90)
-    _prefill_case(ops, orc, 2, 577, 0, 64, 1, False, None, False, pp, q_std=8.0, seed=91)
+    _prefill_case(ops, orc, 2, 577, 0, 64, 1, False, None, pp == 2, pp, q_std=8.0, seed=91)
 
 
 @pytest.mark.parametrize("B,L,past,nh,n_split,pads", [(1, 1, 300, 4, 5, None), (2, 1, 63, 2, 1, [0, 7]), (1, 6, 130, 2, 3, None),

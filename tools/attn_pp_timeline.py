@@ -31,3 +31,16 @@ for step in range(8, 14):
         a, b, c = t[w][1 + 2 * step], t[w][2 + 2 * step], t[w][3 + 2 * step]
         row.append(f"w{w} {b - a:5d}/{c - b:5d}")
     print(f"  step {step:2d} (+{t[0][1 + 2 * step] - t0:7d})  " + "   ".join(row))
+
+buf2 = (ctypes.c_ulonglong * (8 * 64 * 4))()
+if hasattr(lib, "p3v_ppdbg2_read"):
+    lib.p3v_ppdbg2_read.argtypes = [ctypes.c_void_p]
+    lib.p3v_ppdbg2_read(buf2)
+    print("inside a phase: cycles from the step's start to the four stamps ; phase end.  Matrix phase (A: even steps, B: odd): before the fragment reads | reads issued | PV issued | S^T issued.  VALU phase: DMA issued | maxima reduced | exponentials of both halves issued (packing of the first too) | P packed")
+    for step in range(8, 14):
+        row = []
+        for w in (0, 4):
+            st = [buf2[(w * 64 + step) * 4 + k] for k in range(4)]
+            a, b = t[w][1 + 2 * step], t[w][2 + 2 * step]
+            if st[0] >= a and st[3] <= b + 64: row.append(f"w{w} " + " ".join(f"{x - a:5d}" for x in st) + f" ;{b - a:5d}")
+        print(f"  step {step:2d}  " + "   ".join(row))

@@ -1,6 +1,6 @@
 """Kernel time of k_attn_prefill_pp builds (tools/build_variant.sh <name> p3v_attention.hip -D...) -- several builds INTERLEAVED in
 one process (the chip's clock follows its thermal state: back-to-back processes are not comparable).
-  python tools/attn_variant_bench.py v1,v2 [shape ...]     shape = B:L:heads:hd:causal"""
+  python tools/attn_variant_bench.py v1,v2[:il] [shape ...]     shape = B:L:heads:hd:causal; ":il" = k_attn_prefill_il of that build"""
 import ctypes, os, sys, statistics
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -9,11 +9,12 @@ names = sys.argv[1].split(",")
 shapes = [tuple(int(x) for x in a.split(":")) for a in sys.argv[2:]] or [(1, 8192, 32, 96, 1)]
 libs = {}
 for n in names:
-    l = ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "build", f"libp3v_{n}.so"))
+    l = ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "build", f"libp3v_{n.split(':')[0]}.so"))
     for name, (res, args) in _lib.SIGNATURES.items():
         fn = getattr(l, name)
         fn.restype, fn.argtypes = res, args
     l.p3v_set_tuning(b"attn_pp", 1)
+    l.p3v_set_tuning(b"attn_il", int(n.endswith(":il")))          # "name:il": the interleaved kernel of that build
     libs[n] = l
 for B, L, nh, hd, causal in shapes:
     Tp = (L + 63) // 64 * 64
