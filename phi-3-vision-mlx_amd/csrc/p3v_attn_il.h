@@ -33,8 +33,8 @@ extern "C" int p3v_ildbg_read(unsigned long long* out) {
 #define IL_S(k) do { } while (0)
 #define IL_FLUSH(it) do { } while (0)
 #endif
-#ifndef P3V_IL_DMA_IN_A
-#define P3V_IL_DMA_IN_A 1                                       // the DMA pieces ride in slot A's MFMA stream (0: burst after the barrier)
+#ifndef P3V_IL_HOIST_OFFSETS
+#define P3V_IL_HOIST_OFFSETS 1                                  // fragment read offsets live across the loop (0: recomputed per slot)
 #endif
 template <int HD>
 __global__ void __launch_bounds__(512, 1) k_attn_prefill_il(AttnP p) {
@@ -104,27 +104,37 @@ __global__ void __launch_bounds__(512, 1) k_attn_prefill_il(AttnP p) {
   // K tile kt -> K slot kt % 3, V^T tile vt -> V slot vt % 3.  Tile numbers past the last one fetch the last tile again (the slot
   // they land in is free by construction and nobody reads it as that tile): every wave issues the same NPW pieces every
   // iteration, so ONE counted wait -- vmcnt(NPW): everything but the newest batch -- is right from the first tile to the last.
-  auto issue = [&](int kt, int vt, bool with_v, int only = -1) {      // only >= 0: that piece of the wave's NPW alone
+  // Per piece, wave-uniform and fixed: which tensor, where in a ring slot, and the byte stride of a tile in memory (K: 64 rows,
+  // V^T: 64 columns of every row) -- a piece is then {two scalar multiply-adds, m0, one buffer_load ... lds}, no branch.
+  __amdgpu_buffer_rsrc_t p_rs[NPW];
+  int p_lds[NPW], p_stride[NPW], p_base[NPW], p_lag[NPW];
+#pragma unroll
+  for (int i = 0; i < NPW; ++i) {
+    const int pi = wave + 8 * i;
+    const bool isk = pi < NK;
+    p_rs[i] = isk ? rs_k : rs_v;
+    p_lds[i] = isk ? pi * 1024 : RING * KTILE + (pi - NK) * 1024;
+    p_stride[i] = isk ? 64 * KROW : 128;
+    p_base[i] = isk ? kv_begin * KROW : kv_begin * 2;
+    p_lag[i] = isk ? 0 : 1;                                   // a batch is K(kt) with V^T(kt - 1)
+  }
+  static_assert(KTILE == VTILE, "one slot size for both rings");
+  // piece `i` of the batch {K(kt), V^T(kt - 1)}; slot3[0 / 1] = kt % 3, (kt - 1) % 3 (kept by the caller: no division here)
+  auto issue_piece = [&](int i, int kt, int slot_k, int slot_v) {
 #ifdef P3V_IL_NODMA                                              // timing experiment: tiles never move
     return;
 #endif
-    const int tk = min(kt, NT - 1), tv = min(vt, NT - 1);
-    const int so_k = (kv_begin + 64 * tk) * KROW, so_v = (kv_begin + 64 * tv) * 2;
-    const int ks_ = kt % RING, vs_ = vt % RING;
+    const int lag = p_lag[i], t = min(kt - lag, NT - 1);
+    const int so = p_base[i] + t * p_stride[i];
+    const unsigned vo = poff[i];                             // (a builtin called on an element of a dependent-size array: hipcc 7.2
+    const __amdgpu_buffer_rsrc_t rs = p_rs[i];               //  silently drops the kernel's HOST stub -- link error, no diagnostic)
+    pf_lptr_t dst = (pf_lptr_t)(smem + p_lds[i] + (lag ? slot_v : slot_k) * KTILE);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, dst, 16, vo, so, 0, 0);
+  };
+  auto issue = [&](int kt, int vt, bool with_v, int only = -1) {      // (prologue / idle waves) the whole batch, or K alone
 #pragma unroll
-    for (int i = 0; i < NPW; ++i) {
-      if (only >= 0 && i != only) continue;
-      const int pi = wave + 8 * i;
-      const unsigned vo = poff[i];                           // (a builtin called on an element of a dependent-size array: hipcc 7.2
-                                                             //  silently drops the kernel's HOST stub -- link error, no diagnostic)
-      if (pi < NK) {
-        pf_lptr_t dst = (pf_lptr_t)(smem + ks_ * KTILE + pi * 1024);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_k, dst, 16, vo, so_k, 0, 0);
-      } else if (with_v) {
-        pf_lptr_t dst = (pf_lptr_t)(smem + RING * KTILE + vs_ * VTILE + (pi - NK) * 1024);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_v, dst, 16, vo, so_v, 0, 0);
-      }
-    }
+    for (int i = 0; i < NPW; ++i)
+      if (with_v || wave + 8 * i < NK) issue_piece(i, kt, kt % RING, (kt + RING - 1) % RING);
   };
   auto lane_now = [&]() {                                    // a lane id the compiler cannot see through (k_attn_prefill_pp)
     unsigned l = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
@@ -198,8 +208,21 @@ __global__ void __launch_bounds__(512, 1) k_attn_prefill_il(AttnP p) {
   // sched_barrier (nothing crosses), the VALU stream is written one machine instruction per statement.  (Prescribing the same
   // order with sched_group_barrier worked for the maxima and failed for the exponentials / the refills: 12 v_exp ahead of the
   // first MFMA, 9 ds_read behind the last.)
-  auto slot = [&](int u, int j, bool refill, const unsigned char* Vn, const unsigned char* Kn, int dma_kt = -1) {
+#if P3V_IL_HOIST_OFFSETS
+  unsigned voff[2], koff[NKS];                              // fragment read offsets inside a tile (lane constants, five registers)
+  {
+    voff[0] = qi * VROW + (((0 + g) ^ ((qi >> 1) & 7)) << 4);
+    voff[1] = qi * VROW + (((4 + g) ^ ((qi >> 1) & 7)) << 4);
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+      const unsigned c = 4 * ks + g, sw = HD == 96 ? (0u - (qi >> 2)) & 3 : (qi >> 1) & 7;
+      koff[ks] = qi * KROW + ((c ^ sw) << 4);
+    }
+  }
+#endif
+  auto slot = [&](int u, int j, bool refill, const unsigned char* Vn, const unsigned char* Kn, int dma_kt = -1, int dma_sk = 0, int dma_sv = 0) {
     const int uu = 1 - u;
+#if !P3V_IL_HOIST_OFFSETS
     unsigned voff[2] = {0, 0}, koff[NKS] = {};
     if (refill) {
       const unsigned ln = lane_now(), g_ = ln >> 4, qi_ = ln & 15;
@@ -211,12 +234,14 @@ __global__ void __launch_bounds__(512, 1) k_attn_prefill_il(AttnP p) {
         koff[ks] = qi_ * KROW + ((c ^ sw) << 4);
       }
     }
+#endif
     const bool interior = j >= j_int_lo && j <= j_int_hi;
     if (!interior) mask_half(u, j);
     __builtin_amdgcn_sched_barrier(0);
     // region 1: PV_uu (2 NDT + 2 MFMAs) || maximum of the 64 scores of each query of half u
-    float ma = 0.f, mc = 0.f, mx = 0.f, my = 0.f, m_t = 0.f;
-    const float* sv = (const float*)&s[u][0];                // the 16 scores of this lane, as scalars (registers: fully unrolled)
+    // (the fast path needs no cross-lane step: "some score of the wave exceeds the threshold" is a ballot over the LANES' own
+    //  maxima; the row maximum is only formed when the reference does move)
+    float ma = 0.f, mc = 0.f;
     auto max3 = [](float x, float y, float z) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(y), "v"(z)); return r; };
     auto max2 = [](float x, float y) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y)); return r; };
     auto valu1 = [&](int k) {                                // step k of the reduction: one or two instructions
@@ -226,14 +251,9 @@ __global__ void __launch_bounds__(512, 1) k_attn_prefill_il(AttnP p) {
         case 2: ma = max3(ma, s[u][2][2], s[u][2][3]); mc = max3(mc, s[u][3][0], s[u][3][1]); break;
         case 3: ma = max3(ma, s[u][3][2], s[u][3][3]); break;
         case 4: ma = max2(ma, mc); break;
-        case 5: rows_swap32(ma, mx, my); break;
-        case 6: ma = max2(mx, my); break;
-        case 7: rows_swap16(ma, mx, my); break;
-        case 8: m_t = max2(mx, my); break;
         default: break;
       }
     };
-    (void)sv;
 #pragma unroll
     for (int st = 0; st < 2; ++st) {
 #pragma unroll
@@ -247,16 +267,16 @@ __global__ void __launch_bounds__(512, 1) k_attn_prefill_il(AttnP p) {
           ol[uu] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones_f, pf[uu][st], ol[uu], 0, 0, 0);
         }
         valu1(st * (NDT + 1) + d);
-        if (P3V_IL_DMA_IN_A && dma_kt >= 0) {                // this wave's DMA pieces, one at a time between MFMAs (a burst of three
+        if (dma_kt >= 0) {                // this wave's DMA pieces, one at a time between MFMAs (a burst of three
           const int gi = st * (NDT + 1) + d;                 // right after the barrier, all eight waves at once, cost each wave ~300 cycles)
-          if (gi % 4 == 1 && gi / 4 < NPW) issue(dma_kt, dma_kt - 1, true, gi / 4);
+          if (gi % 4 == 1 && gi / 4 < NPW) issue_piece(gi / 4, dma_kt, dma_sk, dma_sv);
         }
         __builtin_amdgcn_sched_barrier(0);
       }
     }
     IL_S(u ? 1 : 5);
-    const bool slow = unset[u] || m_t > THR;
-    if (__builtin_amdgcn_ballot_w64(slow) != 0) move_reference(u, m_t);
+    const bool slow = unset[u] || ma > THR;
+    if (__builtin_amdgcn_ballot_w64(slow) != 0) move_reference(u, rows_max(ma));
     __builtin_amdgcn_sched_barrier(0);
     // region 2: S^T_uu (4 NKS MFMAs; k-slice outermost: four independent accumulators between two MFMAs of a chain) ||
     // P = 2^S of half u (16 v_exp) and its packing into the B fragments of the PV product (8 v_cvt_pk)
@@ -316,8 +336,7 @@ __global__ void __launch_bounds__(512, 1) k_attn_prefill_il(AttnP p) {
   if (NT > 0) {
     issue(0, 0, false);                                      // K(0) alone
     issue(1, 0, true);                                       // batch 0 = K(1), V^T(0)
-    if (!P3V_IL_DMA_IN_A) issue(2, 1, true);                 // batch 1
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P3V_IL_DMA_IN_A ? NPW : 2 * NPW) : "memory");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPW) : "memory");   // K(0) is in LDS, batch 0 may still fly
     asm volatile("s_barrier" ::: "memory");
     {
       const unsigned ln = lane_now(), g_ = ln >> 4, qi_ = ln & 15;
@@ -329,30 +348,28 @@ __global__ void __launch_bounds__(512, 1) k_attn_prefill_il(AttnP p) {
         for (int st = 0; st < 4; ++st) kfr[st][ks] = *(const bf16x8_t*)(smem + off + st * 16 * KROW);
       }
     }
-    int j = 0;
+    int j = 0, r0 = 0, r1 = 1, r2 = 2;                       // j % 3, (j + 1) % 3, (j + 2) % 3
     for (; j < NTw; ++j) {
       IL_S(0);
-      slot(1, j - 1, false, nullptr, nullptr, j + 2);        // A(j): softmax_1(j-1) || PV_0(j-1), S^T_0(j)   (+ DMA of K(j+2), V^T(j+1))
+      slot(1, j - 1, false, nullptr, nullptr, j + 2, r2, r1);   // A(j): softmax_1(j-1) || PV_0(j-1), S^T_0(j)   (+ DMA of K(j+2), V^T(j+1))
       IL_S(2);
       step_barrier();
       IL_S(3);
-      if (!P3V_IL_DMA_IN_A) issue(j + 3, j + 2, true);
-      IL_S(4);
-      slot(0, j, true, smem + RING * KTILE + (j % RING) * VTILE, smem + ((j + 1) % RING) * KTILE);   // B(j): softmax_0(j) || PV_1(j-1), S^T_1(j)
+      slot(0, j, true, smem + RING * KTILE + r0 * VTILE, smem + r1 * KTILE);   // B(j): softmax_0(j) || PV_1(j-1), S^T_1(j)
       IL_S(6);
       IL_FLUSH(j);
+      const int t_ = r0;
+      r0 = r1, r1 = r2, r2 = t_;
     }
     if (active) {                                            // j = NTw: what is left of the last tile: softmax_1, PV_0, then PV_1
-      slot(1, j - 1, false, nullptr, nullptr, j + 2);        // (its S^T_0 runs on the refetched last tile; nobody reads the result)
+      slot(1, j - 1, false, nullptr, nullptr, j + 2, r2, r1);   // (its S^T_0 runs on the refetched last tile; nobody reads the result)
       step_barrier();
-      if (!P3V_IL_DMA_IN_A) issue(j + 3, j + 2, true);
       pv_tail(1);
       ++j;
     }
     for (; j <= NT; ++j) {                                   // done (or never had rows): DMA share + barriers only
-      if (P3V_IL_DMA_IN_A) issue(j + 2, j + 1, true);
+      issue(j + 2, j + 1, true);
       step_barrier();
-      if (!P3V_IL_DMA_IN_A) issue(j + 3, j + 2, true);
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
