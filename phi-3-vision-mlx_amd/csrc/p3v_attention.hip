@@ -1171,10 +1171,13 @@ __global__ void __launch_bounds__(512, 1) k_attn_prefill_pp(AttnP p) {
 // Which prompt-sized kernel (measured, B = 1, 32 heads x 96, causal, random data; profiles/r03_attn_prefill_kernels.txt):
 //   tokens      1024    2531     8192     32768    |  CLIP 17 x 577 (hd 64)   8 x 512
 //   dma (128 q)  30 us   80 us   613 us   7.37 ms  |   54 us                   39 us
-//   pp  (256 q)  34 us   74 us   450-467 us   5.7-6.1 ms  |   69-74 us           48-50 us     (883-917 / 1080-1149 TF/s at 8k / 32k; box-dependent)
-// the 8-wave kernel needs ~10 query blocks per head before its better steady state beats its coarser tail
+//   pp  (256 q)  34 us   68-74 us   430-467 us   5.7-6.1 ms  |   69-74 us        48-50 us     (883-960 / 1080-1149 TF/s at 8k / 32k; box-dependent)
+//   il  (256 q)  31 us   58-63 us   373-388 us   5.23-5.45 ms    (pre-scaled Q only)               (1063-1106 / 1212-1261 TF/s)
+// the 8-wave kernels need a few query blocks per head before their better steady state beats their coarser tail: il from 1280
+// tokens (35 us against 37), pp (what is left for it: plain Q, head dim 64) from 2048
 #include "p3v_attn_il.h"
 constexpr int P3V_ATTN_PP_MIN_L = 2048;
+constexpr int P3V_ATTN_IL_MIN_L = 1280;                          // tools/attn_short_probe.py: il 35 us / dma 37 us at 1280, 31 / 29 at 1024
 template <int HD>
 static int launch_attn_prefill(const AttnP& p, hipStream_t s) {
   constexpr int LDS = 2 * (64 * (HD * 2 + 16) + HD * (64 * 2 + 16));
@@ -1198,7 +1201,7 @@ static int launch_attn_prefill(const AttnP& p, hipStream_t s) {
     q.head_group = kv_bytes * p.nh <= (64u << 20) ? p.nh : (p.nh % 8 == 0 && kv_bytes * 8 <= (128u << 20) ? 8 : (p.nh % 4 == 0 ? 4 : p.nh));
     const int pp = p3v_tuning().attn_pp;                         // -1: by shape; 0 / 1: pin (kernel tests run both)
     const int il = p3v_tuning().attn_il;                         // the interleaved kernel (pre-scaled Q only)
-    if (p.q_prescaled && (il > 0 || (il < 0 && pp != 0 && p.L >= P3V_ATTN_PP_MIN_L))) {
+    if (p.q_prescaled && (il > 0 || (il < 0 && pp != 0 && p.L >= P3V_ATTN_IL_MIN_L))) {   // (pp = 0 pins the dma kernel)
       constexpr int LDS4 = 3 * 64 * HD * 2 + 3 * HD * 128;
       static bool attr4_set = false;
       if (!attr4_set) {

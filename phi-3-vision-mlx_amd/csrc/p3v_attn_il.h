@@ -9,18 +9,27 @@
 //   * VALU instructions placed BETWEEN the MFMAs of the same wave are nearly free: 26 MFMAs + 47 VALU + 12 ds_read_b128,
 //     hand-interleaved, two waves per SIMD: 436-460 cycles per 26 MFMAs (416 of matrix-pipe time) -- 90 % of the matrix peak.
 // So each WAVE is software-pipelined over its own two 16-query halves, half a tile apart: while the matrix pipe works on half u'
-// (PV of the previous tile, then S^T of the next), the vector instructions of the softmax of half u are interleaved between
-// those MFMAs; then the roles swap.  Per tile and wave:
-//   slot A(j):  VALU softmax_1(j-1)  ||  MFMA  PV_0(j-1) , S^T_0(j)
+// (PV of the previous tile, then S^T of the next), the vector instructions of the softmax of half u sit between those MFMAs;
+// then the roles swap.  Per tile and wave:
+//   slot A(j):  VALU softmax_1(j-1)  ||  MFMA  PV_0(j-1) , S^T_0(j)     + this wave's DMA pieces of K(j+2), V^T(j+1), one at a
+//                                                                         time between the MFMAs (a burst of three right after
+//                                                                         the barrier, eight waves at once, cost ~300 cycles)
 //   -- s_barrier B_j (tiles K(j+1), V^T(j) are in LDS for everybody; the tiles read before it are free) --
-//   slot B(j):  VALU softmax_0(j)    ||  MFMA  PV_1(j-1) , S^T_1(j)     + this wave's DMA pieces of K(j+3), V^T(j+2)
+//   slot B(j):  VALU softmax_0(j)    ||  MFMA  PV_1(j-1) , S^T_1(j)
 //               + the fragment registers are refilled IN PLACE behind their last use: V^T(j) behind PV_1(j-1), K(j+1) behind S^T_1(j)
-// Each slot is two scheduling regions (maxima of the 16 x 64 scores || first 14 MFMAs; exponentials and packing || last 12),
-// split by the rare wave-uniform branch that moves the reference (first visible tile, or a jump > 2^8); the instruction order
-// inside a region is the source order, group by group (one MFMA, its fragment refill, two VALU; see `slot`).  Register set, LDS
-// fragment traffic (24 ds_read_b128 per tile and wave), key-permuted K staging and the deferred reference are the ping-pong
-// kernel's; ONE barrier per tile instead of two, rings of 3 + 3 tiles (72 KB at head dim 96).  The first and last tile run
-// the same code on neutral operands (P = 0, V = 0, S = -inf) instead of peeled copies.
+// Each slot is two regions (the lanes' maxima over their 16 scores || 14 MFMAs; 16 v_exp + 8 v_cvt_pk || 12 MFMAs), split by the
+// rare wave-uniform branch that moves the reference (first visible tile, or a jump > 2^8).  The fast path needs NO cross-lane
+// step ("some score exceeds the threshold" is a ballot over the lanes' own maxima): 9 + 24 VALU per slot, 80 VALU + 52 MFMA +
+// 24 ds_read_b128 + 3 LDS-DMA + 51 SALU per tile and wave (235 instructions; ping-pong: 188 VALU + 90 SALU).  Register set
+// (250-256 VGPRs, no spill), LDS fragment traffic, key-permuted K staging and the deferred reference are the ping-pong kernel's;
+// ONE barrier per tile instead of two, rings of 3 + 3 tiles (72 KB at head dim 96), one counted wait (vmcnt(NPW)) from the first
+// tile to the last: every wave issues its NPW pieces every iteration, tile numbers past the end refetch the last tile into a
+// free slot.  The first and last tile run the same code on neutral operands (P = 0, V = 0, S = -inf) instead of peeled copies.
+// Measured, B = 1, 32 heads x 96, causal (profiles/r03_attn_prefill_kernels.txt; interleaved with the ping-pong kernel in one
+// process): 2531 tokens 63 us (pp 73), 8k 373-383 us = 1077-1106 TF/s (pp 430), 32k 5.23-5.37 ms = 1229-1261 TF/s (pp 5.87-5.96).
+// Where the rest goes (SQ counters, profiles/r03_pmc_prefill_attn.txt; timing experiments P3V_IL_NO*): the matrix stream
+// alone runs the 32k case in 3.84 ms, everything else alone in 3.75 ms, both in 5.39 ms -- half overlapped.  Per wave-tile
+// 2890 cycles: 880 parked (barrier: the first four waves arrive ~600 cycles early every tile), 900 issue stalls, 1100 issuing.
 // Q must arrive pre-scaled (scale * log2 e folded in by the RoPE kernel): the only caller is the prompt path.
 #ifdef P3V_IL_DEBUG                                              // tools/attn_il_timeline.py: per-wave stamps of ONE workgroup
 __device__ unsigned long long p3v_ildbg[8 * 64 * 8];
@@ -120,7 +129,7 @@ __global__ void __launch_bounds__(512, 1) k_attn_prefill_il(AttnP p) {
   }
   static_assert(KTILE == VTILE, "one slot size for both rings");
   // piece `i` of the batch {K(kt), V^T(kt - 1)}; slot3[0 / 1] = kt % 3, (kt - 1) % 3 (kept by the caller: no division here)
-  auto issue_piece = [&](int i, int kt, int slot_k, int slot_v) {
+  auto issue_piece = [&](int i, int kt, int slot_k, int slot_v) __attribute__((always_inline)) {
 #ifdef P3V_IL_NODMA                                              // timing experiment: tiles never move
     return;
 #endif
@@ -131,12 +140,12 @@ __global__ void __launch_bounds__(512, 1) k_attn_prefill_il(AttnP p) {
     pf_lptr_t dst = (pf_lptr_t)(smem + p_lds[i] + (lag ? slot_v : slot_k) * KTILE);
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, dst, 16, vo, so, 0, 0);
   };
-  auto issue = [&](int kt, int vt, bool with_v, int only = -1) {      // (prologue / idle waves) the whole batch, or K alone
+  auto issue = [&](int kt, int vt, bool with_v, int only = -1) __attribute__((always_inline)) {      // (prologue / idle waves) the whole batch, or K alone
 #pragma unroll
     for (int i = 0; i < NPW; ++i)
       if (with_v || wave + 8 * i < NK) issue_piece(i, kt, kt % RING, (kt + RING - 1) % RING);
   };
-  auto lane_now = [&]() {                                    // a lane id the compiler cannot see through (k_attn_prefill_pp)
+  auto lane_now = [&]() __attribute__((always_inline)) {                                    // a lane id the compiler cannot see through (k_attn_prefill_pp)
     unsigned l = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
     asm volatile("" : "+v"(l));
     return l;
@@ -172,7 +181,7 @@ __global__ void __launch_bounds__(512, 1) k_attn_prefill_il(AttnP p) {
   }
 
   // ---- pieces of a slot.  u = the half whose softmax is in work (VALU), uu = 1 - u the half on the matrix pipe.
-  auto mask_half = [&](int u, int j) {                      // (rare) tile j of half u has invisible keys: -inf in place
+  auto mask_half = [&](int u, int j) __attribute__((always_inline)) {                      // (rare) tile j of half u has invisible keys: -inf in place
     const int kv0 = kv_begin + 64 * j;
     const float ninf = -INFINITY;
 #pragma unroll
@@ -185,7 +194,7 @@ __global__ void __launch_bounds__(512, 1) k_attn_prefill_il(AttnP p) {
         asm("v_cndmask_b32_e64 %0, %1, %0, %2" : "+v"(s[u][st][r]) : "v"(ninf), "s"(vm));      // s = vis ? s : -inf
       }
   };
-  auto move_reference = [&](int u, float m_t) {             // (rare, wave-uniform) in-place: see k_attn_prefill_pp
+  auto move_reference = [&](int u, float m_t) __attribute__((always_inline)) {             // (rare, wave-uniform) in-place: see k_attn_prefill_pp
     const bool masked = m_t == -INFINITY;
     const float delta = unset[u] ? (masked ? 0.f : m_t) : fmaxf(m_t, 0.f);
     const float alpha = unset[u] ? 1.f : __builtin_amdgcn_exp2f(-delta);
@@ -220,7 +229,7 @@ __global__ void __launch_bounds__(512, 1) k_attn_prefill_il(AttnP p) {
     }
   }
 #endif
-  auto slot = [&](int u, int j, bool refill, const unsigned char* Vn, const unsigned char* Kn, int dma_kt = -1, int dma_sk = 0, int dma_sv = 0) {
+  auto slot = [&](int u, int j, bool refill, const unsigned char* Vn, const unsigned char* Kn, int dma_kt = -1, int dma_sk = 0, int dma_sv = 0) __attribute__((always_inline)) {
     const int uu = 1 - u;
 #if !P3V_IL_HOIST_OFFSETS
     unsigned voff[2] = {0, 0}, koff[NKS] = {};
@@ -244,7 +253,7 @@ __global__ void __launch_bounds__(512, 1) k_attn_prefill_il(AttnP p) {
     float ma = 0.f, mc = 0.f;
     auto max3 = [](float x, float y, float z) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(y), "v"(z)); return r; };
     auto max2 = [](float x, float y) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y)); return r; };
-    auto valu1 = [&](int k) {                                // step k of the reduction: one or two instructions
+    auto valu1 = [&](int k) __attribute__((always_inline)) {                                // step k of the reduction: one or two instructions
       switch (k) {
         case 0: ma = max3(s[u][0][0], s[u][0][1], s[u][0][2]); mc = max3(s[u][0][3], s[u][1][0], s[u][1][1]); break;
         case 1: ma = max3(ma, s[u][1][2], s[u][1][3]); mc = max3(mc, s[u][2][0], s[u][2][1]); break;
@@ -259,14 +268,22 @@ __global__ void __launch_bounds__(512, 1) k_attn_prefill_il(AttnP p) {
 #pragma unroll
       for (int d = 0; d <= NDT; ++d) {
         if (d < NDT) {
+#ifdef P3V_IL_NOMFMA                                             // timing experiment: no matrix work (an in-place no-op keeps the operands used)
+          asm volatile("" : "+v"(o[uu][d]) : "v"(vfr[st][d]), "v"(pf[uu][st]));
+#else
           o[uu][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfr[st][d], pf[uu][st], o[uu][d], 0, 0, 0);
+#endif
 #ifndef P3V_IL_NOLDS                                             // (timing experiment: no fragment refills)
           if (refill) vfr[st][d] = *(const bf16x8_t*)(Vn + voff[st] + d * 16 * VROW);
 #endif
         } else {
+#ifndef P3V_IL_NOMFMA
           ol[uu] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones_f, pf[uu][st], ol[uu], 0, 0, 0);
+#endif
         }
+#ifndef P3V_IL_NOVALU                                            // (timing experiment: no softmax work)
         valu1(st * (NDT + 1) + d);
+#endif
         if (dma_kt >= 0) {                // this wave's DMA pieces, one at a time between MFMAs (a burst of three
           const int gi = st * (NDT + 1) + d;                 // right after the barrier, all eight waves at once, cost each wave ~300 cycles)
           if (gi % 4 == 1 && gi / 4 < NPW) issue_piece(gi / 4, dma_kt, dma_sk, dma_sv);
@@ -280,44 +297,65 @@ __global__ void __launch_bounds__(512, 1) k_attn_prefill_il(AttnP p) {
     __builtin_amdgcn_sched_barrier(0);
     // region 2: S^T_uu (4 NKS MFMAs; k-slice outermost: four independent accumulators between two MFMAs of a chain) ||
     // P = 2^S of half u (16 v_exp) and its packing into the B fragments of the PV product (8 v_cvt_pk)
+    // (the machine code follows this order only roughly -- pure instructions are placed before the sched_barriers exist:
+    //  v_exp in fours, the 8 v_cvt_pk behind the last MFMA.  Forcing the exact order with data ties (empty asm taking one
+    //  instruction's result and the next one's operand) was measured 1.3 % SLOWER: not the lever)
     u32x4_t pw[2];
-    auto valu2 = [&](int k) {                                // group k of 4 NKS: all the work in the first 12 (NKS = 2: 8) groups
-      constexpr int NG = 4 * NKS, NE = NG >= 12 ? 8 : 4, EPG = 16 / NE;      // groups that carry exponentials; exponentials per group
-      if (k < NE) {
-#pragma unroll
-#ifdef P3V_IL_NOEXP                                              // timing experiment: a plain VALU op in place of the transcendental
-        for (int e = EPG * k; e < EPG * (k + 1); ++e) asm("v_mul_f32 %0, 0.5, %0" : "+v"(s[u][e >> 2][e & 3]));
-#else
-        for (int e = EPG * k; e < EPG * (k + 1); ++e) s[u][e >> 2][e & 3] = __builtin_amdgcn_exp2f(s[u][e >> 2][e & 3]);
-#endif
-      } else if (k < NE + (NG - NE >= 4 ? 4 : NG - NE)) {
-        constexpr int NC = NG - NE >= 4 ? 4 : NG - NE, CPG = 8 / NC;           // packing groups; v_cvt_pk per group
-#pragma unroll
-        for (int c = CPG * (k - NE); c < CPG * (k - NE + 1); ++c) {           // word c of [st' = c >> 2][c & 3]
-          const int st2 = c >> 2, w = c & 3, blk = 2 * st2 + (w >> 1), r0 = 2 * (w & 1);
-          pw[st2][w] = pack_bf16x2(s[u][blk][r0], s[u][blk][r0 + 1]);
-        }
-      }
-    };
+    constexpr int NG = 4 * NKS, NE = NG >= 12 ? 8 : 4, EPG = 16 / NE;        // groups that carry exponentials; exponentials per group
+    constexpr int NC = NG - NE >= 4 ? 4 : NG - NE, CPG = 8 / NC;             // packing groups; v_cvt_pk per group
+    static_assert(EPG == 2 || EPG == 4, "two or four exponentials per group");
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks)
 #pragma unroll
       for (int st = 0; st < 4; ++st) {
+        const int k = 4 * ks + st;
+        if (u == 1 && k == 4) IL_S(4);
+        if (u == 1 && k == 8) IL_S(7);
+#ifdef P3V_IL_NOMFMA
+        asm volatile("" : "+v"(s[uu][st]) : "v"(kfr[st][ks]), "v"(qf[uu][ks]));
+#else
         s[uu][st] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr[st][ks], qf[uu][ks], ks == 0 ? negm[uu] : s[uu][st], 0, 0, 0);
+#endif
 #ifndef P3V_IL_NOLDS
         if (refill) kfr[st][ks] = *(const bf16x8_t*)(Kn + koff[ks] + st * 16 * KROW);
 #endif
-        valu2(4 * ks + st);
+#ifdef P3V_IL_NOVALU
+        if (false) {
+#else
+        if (k < NE) {
+#endif
+          const int eb = (EPG * k) >> 2, e0 = (EPG * k) & 3;                   // EPG consecutive scores (same accumulator block)
+#pragma unroll
+          for (int e = e0; e < e0 + EPG; ++e) {
+#ifdef P3V_IL_NOEXP                                              // timing experiment: a plain VALU op in place of the transcendental
+            asm("v_mul_f32 %0, 0.5, %0" : "+v"(s[u][eb][e]));
+#else
+            s[u][eb][e] = __builtin_amdgcn_exp2f(s[u][eb][e]);
+#endif
+          }
+#ifdef P3V_IL_NOVALU
+        } else if (false) {
+#else
+        } else if (k < NE + NC) {
+#endif
+#pragma unroll
+          for (int c = CPG * (k - NE); c < CPG * (k - NE + 1); ++c) {         // word c of [st' = c >> 2][c & 3]
+            const int st2 = c >> 2, w = c & 3, blk = 2 * st2 + (w >> 1), r0 = 2 * (w & 1);
+            pw[st2][w] = pack_bf16x2(s[u][blk][r0], s[u][blk][r0 + 1]);
+          }
+        }
         __builtin_amdgcn_sched_barrier(0);
       }
+#ifndef P3V_IL_NOVALU
     pf[u][0] = __builtin_bit_cast(bf16x8_t, pw[0]);
     pf[u][1] = __builtin_bit_cast(bf16x8_t, pw[1]);
+#endif
     // P and S^T are USED here as far as the optimiser can tell (their real uses sit behind the barrier / in the next slot:
     // without this the exponentials are sunk there, out of the MFMA stream they are meant to hide in)
     asm volatile("" ::"v"(pf[u][0]), "v"(pf[u][1]), "v"(s[uu][0]), "v"(s[uu][1]), "v"(s[uu][2]), "v"(s[uu][3]));
     __builtin_amdgcn_sched_barrier(0);
   };
-  auto pv_tail = [&](int uu) {                               // PV of half uu alone (the last tile's second half)
+  auto pv_tail = [&](int uu) __attribute__((always_inline)) {                               // PV of half uu alone (the last tile's second half)
 #pragma unroll
     for (int st = 0; st < 2; ++st) {
 #pragma unroll
@@ -325,7 +363,7 @@ __global__ void __launch_bounds__(512, 1) k_attn_prefill_il(AttnP p) {
       ol[uu] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones_f, pf[uu][st], ol[uu], 0, 0, 0);
     }
   };
-  auto step_barrier = [&]() {                               // B_j: everything but this wave's newest batch has landed
+  auto step_barrier = [&]() __attribute__((always_inline)) {                               // B_j: everything but this wave's newest batch has landed
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPW) : "memory");
     asm volatile("s_barrier" ::: "memory");
@@ -348,28 +386,34 @@ __global__ void __launch_bounds__(512, 1) k_attn_prefill_il(AttnP p) {
         for (int st = 0; st < 4; ++st) kfr[st][ks] = *(const bf16x8_t*)(smem + off + st * 16 * KROW);
       }
     }
-    int j = 0, r0 = 0, r1 = 1, r2 = 2;                       // j % 3, (j + 1) % 3, (j + 2) % 3
-    for (; j < NTw; ++j) {
-      IL_S(0);
-      slot(1, j - 1, false, nullptr, nullptr, j + 2, r2, r1);   // A(j): softmax_1(j-1) || PV_0(j-1), S^T_0(j)   (+ DMA of K(j+2), V^T(j+1))
-      IL_S(2);
-      step_barrier();
-      IL_S(3);
-      slot(0, j, true, smem + RING * KTILE + r0 * VTILE, smem + r1 * KTILE);   // B(j): softmax_0(j) || PV_1(j-1), S^T_1(j)
-      IL_S(6);
-      IL_FLUSH(j);
-      const int t_ = r0;
-      r0 = r1, r1 = r2, r2 = t_;
-    }
-    if (active) {                                            // j = NTw: what is left of the last tile: softmax_1, PV_0, then PV_1
-      slot(1, j - 1, false, nullptr, nullptr, j + 2, r2, r1);   // (its S^T_0 runs on the refetched last tile; nobody reads the result)
-      step_barrier();
-      pv_tail(1);
-      ++j;
-    }
-    for (; j <= NT; ++j) {                                   // done (or never had rows): DMA share + barriers only
-      issue(j + 2, j + 1, true);
-      step_barrier();
+    // (Measured and dropped: waves 4-7 half an iteration BEHIND waves 0-3 -- their barrier in front of slot A instead of behind
+    //  it, so that every wave runs one slot A and one slot B between two barriers and nobody parks at the barrier -- 1-2 %
+    //  slower; two copies of the loop for it cost 46 spilled registers.)
+    {
+      int j = 0, r0 = 0, r1 = 1, r2 = 2;                     // j % 3, (j + 1) % 3, (j + 2) % 3
+      for (; j < NTw; ++j) {
+        IL_S(0);
+        // A(j): softmax_1(j-1) || PV_0(j-1), S^T_0(j)   + this wave's DMA pieces of K(j+2), V^T(j+1)
+        slot(1, j - 1, false, nullptr, nullptr, j + 2, r2, r1);
+        IL_S(2);
+        step_barrier();
+        IL_S(3);
+        slot(0, j, true, smem + RING * KTILE + r0 * VTILE, smem + r1 * KTILE);   // B(j): softmax_0(j) || PV_1(j-1), S^T_1(j)
+        IL_S(6);
+        IL_FLUSH(j);
+        const int t_ = r0;
+        r0 = r1, r1 = r2, r2 = t_;
+      }
+      if (active) {                                          // j = NTw: what is left of the last tile: softmax_1, PV_0, then PV_1
+        slot(1, j - 1, false, nullptr, nullptr, j + 2, r2, r1);   // (its S^T_0 runs on the refetched last tile; nobody reads the result)
+        step_barrier();
+        pv_tail(1);
+        ++j;
+      }
+      for (; j <= NT; ++j) {                                 // done (or never had rows): DMA share + barriers only
+        issue(j + 2, 0, true);
+        step_barrier();
+      }
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

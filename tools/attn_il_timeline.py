@@ -21,9 +21,9 @@ lib.p3v_ildbg_read.argtypes = [ctypes.c_void_p]
 lib.p3v_ildbg_read(buf)
 t = lambda w, it, k: buf[(w * 64 + it) * 8 + k]
 print("variant", os.environ.get("IL_VARIANT", "ildbg"), "L", L)
-print("iteration: per wave  A.region1 | A.end | barrier | DMA | B.region1 | B.end   (cycles from the iteration's start) ; iteration length")
+print("iteration: per wave  A.region1 | A.region2 after 4 and 8 of its 12 MFMAs | A.end | barrier | B.region1 | B.end   (cycles from the iteration's start) ; iteration length")
 for it in range(8, 14):
     for w in (0, 1, 4, 5):
         a = t(w, it, 0)
         nxt = t(w, it + 1, 0)
-        print(f"  it {it:2d} w{w}: " + " ".join(f"{t(w, it, k) - a:5d}" for k in (1, 2, 3, 4, 5, 6)) + f" ; {nxt - a:5d}")
+        print(f"  it {it:2d} w{w}: " + " ".join(f"{t(w, it, k) - a:5d}" for k in (1, 4, 7, 2, 3, 5, 6)) + f" ; {nxt - a:5d}")

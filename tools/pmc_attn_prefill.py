@@ -8,7 +8,8 @@ q = (torch.randn(1, nh, L, hd, device="cuda") * (hd ** -0.5 * ops.Q_PRESCALE)).b
 k = torch.randn(1, nh, L, hd, device="cuda").bfloat16()
 v = torch.randn(1, nh, hd, L, device="cuda").bfloat16()
 out = torch.empty(1, L, nh * hd, device="cuda", dtype=torch.bfloat16)
-ops.set_tuning("attn_pp", pp)
+ops.set_tuning("attn_pp", min(pp, 1))
+ops.set_tuning("attn_il", int(pp == 2))                          # pp = 2: k_attn_prefill_il
 for _ in range(4):
     ops.attention(q, out, 1, L, nh, nh, hd, hd ** -0.5, True, k_past=k, v_past=v, past_t=L, new_is_cache=True, q_prescaled=True)
 torch.cuda.synchronize()
