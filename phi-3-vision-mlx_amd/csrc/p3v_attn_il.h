@@ -155,7 +155,9 @@ __global__ void __launch_bounds__(512, 1) k_attn_prefill_il(AttnP p) {
   const bf16x8_t ones_f = __builtin_bit_cast(bf16x8_t, ones_w);
   const bf16x8_t zero_f = __builtin_bit_cast(bf16x8_t, (u32x4_t){0u, 0u, 0u, 0u});
   float m_run[2] = {0.f, 0.f};                               // reference of the exponent (finite always)
-  bool unset[2] = {true, true};                              // no visible key seen yet: the next one sets the reference
+  unsigned long long unset[2] = {~0ull, ~0ull};              // lane mask: no visible key seen yet, the next one sets the reference
+                                                             // (a MASK, not a per-lane bool: the fast path's test is then one v_cmp and
+                                                             //  one s_or; as a bool the ballot is re-materialised with two more VALU)
   f32x4_t ol[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
   f32x4_t o[2][NDT];
 #pragma unroll
@@ -196,11 +198,14 @@ __global__ void __launch_bounds__(512, 1) k_attn_prefill_il(AttnP p) {
   };
   auto move_reference = [&](int u, float m_t) __attribute__((always_inline)) {             // (rare, wave-uniform) in-place: see k_attn_prefill_pp
     const bool masked = m_t == -INFINITY;
-    const float delta = unset[u] ? (masked ? 0.f : m_t) : fmaxf(m_t, 0.f);
-    const float alpha = unset[u] ? 1.f : __builtin_amdgcn_exp2f(-delta);
-    unset[u] = unset[u] && masked;
+    const bool un = (unset[u] >> lane_now()) & 1;
+    const float delta = un ? (masked ? 0.f : m_t) : fmaxf(m_t, 0.f);
+    const float alpha = un ? 1.f : __builtin_amdgcn_exp2f(-delta);
+    unset[u] &= __builtin_amdgcn_ballot_w64(masked);
     m_run[u] += delta;
-    negm[u] = (f32x4_t){-m_run[u], -m_run[u], -m_run[u], -m_run[u]};
+    const float nm = -m_run[u];                              // (in place: a new value of negm costs the FAST path four register copies per slot)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) asm("v_mov_b32 %0, %1" : "+v"(negm[u][r]) : "v"(nm));
 #pragma unroll
     for (int st = 0; st < 4; ++st)
 #pragma unroll
@@ -292,8 +297,7 @@ __global__ void __launch_bounds__(512, 1) k_attn_prefill_il(AttnP p) {
       }
     }
     IL_S(u ? 1 : 5);
-    const bool slow = unset[u] || ma > THR;
-    if (__builtin_amdgcn_ballot_w64(slow) != 0) move_reference(u, rows_max(ma));
+    if ((unset[u] | __builtin_amdgcn_ballot_w64(ma > THR)) != 0) move_reference(u, rows_max(ma));
     __builtin_amdgcn_sched_barrier(0);
     // region 2: S^T_uu (4 NKS MFMAs; k-slice outermost: four independent accumulators between two MFMAs of a chain) ||
     // P = 2^S of half u (16 v_exp) and its packing into the B fragments of the PV product (8 v_cvt_pk)

@@ -20,17 +20,25 @@ def slot(variant):
             n = (nv * (k + 1)) // 26 - (nv * k) // 26
             for _ in range(n):
                 lines.append(valu[vi]); vi += 1
-        if variant == "full" and k % 2 == 0 and k < 24:
+        if variant not in ("mfma", "nolds") and k % 2 == 0 and k < 24:
             tgt = 60 + 4 * ((k // 2 + 3) % 6)
             lines.append(f"ds_read_b128 v[{tgt}:{tgt + 3}], v150 offset:{(k // 2) * 1024}")
-    if variant == "full": lines.append("s_waitcnt lgkmcnt(0)")
+        if variant == "salu":                                   # the compiled loop carries ~25 scalar instructions per slot
+            lines.append(f"s_add_u32 s{20 + k % 4}, s{20 + k % 4}, 1")
+        if variant == "waitcnt":                                # ... and a counted wait in front of every MFMA
+            lines.append(f"s_waitcnt lgkmcnt({min(15, 6)})")
+        if variant == "branch" and k % 8 == 4:                  # ... and 3 taken branches per slot
+            lines += ["s_cmp_eq_u32 s20, s20", f"s_cbranch_scc1 .Lsb_{variant}_{k}%=", "s_nop 0", f".Lsb_{variant}_{k}%=:"]
+        if variant == "barrier" and k == 13:                    # one s_barrier per slot
+            lines.append("s_barrier")
+    if variant not in ("mfma", "nolds"): lines.append("s_waitcnt lgkmcnt(0)")
     return lines
 src = r'''#include <hip/hip_runtime.h>
 #include <cstdio>
 '''
-for variant in ("mfma", "nolds", "full"):
+for variant in ("mfma", "nolds", "full", "salu", "waitcnt", "branch", "barrier"):
     body = "\\n\t".join(slot(variant))
-    clob = ", ".join(f'"v{i}"' for i in range(0, 152))
+    clob = ", ".join([f'"v{i}"' for i in range(0, 152)] + ['"s20"', '"s21"', '"s22"', '"s23"', '"scc"'])
     src += f'''
 __global__ __launch_bounds__(512, 1) void k_{variant}(float* out, int iters) {{
   __shared__ float lds[16384];
@@ -72,6 +80,10 @@ int main() {
     run("26 MFMA", k_mfma, out, t);
     run("26 MFMA + 47 VALU", k_nolds, out, t);
     run("26 MFMA + 47 VALU + 12 ds_read_b128", k_full, out, t);
+    run("  + 26 SALU", k_salu, out, t);
+    run("  + s_waitcnt lgkmcnt before every MFMA", k_waitcnt, out, t);
+    run("  + 3 taken branches", k_branch, out, t);
+    run("  + 1 s_barrier", k_barrier, out, t);
   }
   return 0;
 }
