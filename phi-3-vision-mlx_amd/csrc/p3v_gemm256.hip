@@ -37,6 +37,17 @@ struct Tile256 { int m0, n0; int a_off[2][2], b_off[2][2]; __amdgpu_buffer_rsrc_
 
 __device__ __forceinline__ float gelu_erf2(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
 
+#ifdef P3V_G256_DEBUG                                            // tools/gemm256_timeline.py: per-wave stamps inside the K loop of ONE workgroup
+__device__ unsigned long long p3v_g256dbg[8 * 64 * 8];
+#define G_S(k) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0" : "=s"(g_s[k])); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define G_FLUSH(it) do { if (blockIdx.x == P3V_G256_DEBUG && (threadIdx.x & 63) == 0 && (it) < 64) { for (int k_ = 0; k_ < 8; ++k_) p3v_g256dbg[((threadIdx.x >> 6) * 64 + (it)) * 8 + k_] = g_s[k_]; } } while (0)
+extern "C" int p3v_g256dbg_read(unsigned long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(p3v_g256dbg), sizeof(unsigned long long) * 8 * 64 * 8) == hipSuccess ? 0 : -1;
+}
+#else
+#define G_S(k) do { } while (0)
+#define G_FLUSH(it) do { } while (0)
+#endif
 template <int EPI, int SCHED = 0x50, int ORDER = 0>
 __global__ void __launch_bounds__(512, 1) k_gemm256(Gemm256P p) {
   constexpr bool SILU = EPI == P3V_EPI_SILU_MUL;
@@ -114,9 +125,15 @@ __global__ void __launch_bounds__(512, 1) k_gemm256(Gemm256P p) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
+#ifdef P3V_G256_DEBUG
+  unsigned long long g_s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
   for (int kt = 0; kt < nk; ++kt, ++gk) {
+    G_S(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    G_S(1);
     __syncthreads();
+    G_S(2);
     const bool last = kt + 1 == nk;
     const bool more = !last || has_next;                          // something to prefetch: this tile's next K-tile, or the next tile's first
     const int nb = (gk + 1) & 1;
@@ -170,6 +187,11 @@ __global__ void __launch_bounds__(512, 1) k_gemm256(Gemm256P p) {
           }
       }
     };
+    // (Measured and removed, round 3: the eight LDS-DMA pieces of a wave SPREAD over the first two quads, one piece every four
+    //  MFMAs, instead of two bursts of four in front of them -- 18-30 % SLOWER on every shape.  tools/gemm256_timeline.py: a
+    //  piece costs its wave ~80-150 cycles of instruction issue wherever it stands (580-750 cycles for 12 fragment reads + 4
+    //  pieces, ~300 for 8 + 4, against 1024 for the K-tile's 64 MFMAs); inside a quad those cycles come out of the wave's own
+    //  MFMA stream, in front of it the partner wave's MFMAs cover most of them.)
     if (ORDER == 2) {
       // software-pipelined fragment reads: the fragments of phase p+1 are requested BEFORE the MFMAs of phase p (second A
       // fragment buffer, 224 of 256 registers), so only the first reads after the barrier expose their LDS latency
@@ -178,15 +200,21 @@ __global__ void __launch_bounds__(512, 1) k_gemm256(Gemm256P p) {
       dma_phase(0);
       read_b(1, bf1);
       __builtin_amdgcn_sched_barrier(0);
+      G_S(3);
       quad_from(0, 0, af, bf0);
       __builtin_amdgcn_sched_barrier(0);
+      G_S(4);
       read_a_to(1, af1);
       dma_phase(1);
       __builtin_amdgcn_sched_barrier(0);
+      G_S(5);
       quad_from(0, 1, af, bf1);
       __builtin_amdgcn_sched_barrier(0);
+      G_S(6);
       quad_from(1, 1, af1, bf1);
       quad_from(1, 0, af1, bf0);
+      G_S(7);
+      G_FLUSH(kt);
       continue;
     }
     // phase 0
