@@ -11,9 +11,8 @@
 // So each WAVE is software-pipelined over its own two 16-query halves, half a tile apart: while the matrix pipe works on half u'
 // (PV of the previous tile, then S^T of the next), the vector instructions of the softmax of half u sit between those MFMAs;
 // then the roles swap.  Per tile and wave:
-//   slot A(j):  VALU softmax_1(j-1)  ||  MFMA  PV_0(j-1) , S^T_0(j)     + this wave's DMA pieces of K(j+2), V^T(j+1), one at a
-//                                                                         time between the MFMAs (a burst of three right after
-//                                                                         the barrier, eight waves at once, cost ~300 cycles)
+//   slot A(j):  this wave's DMA pieces of K(j+2), V^T(j+1), then
+//               VALU softmax_1(j-1)  ||  MFMA  PV_0(j-1) , S^T_0(j)
 //   -- s_barrier B_j (tiles K(j+1), V^T(j) are in LDS for everybody; the tiles read before it are free) --
 //   slot B(j):  VALU softmax_0(j)    ||  MFMA  PV_1(j-1) , S^T_1(j)
 //               + the fragment registers are refilled IN PLACE behind their last use: V^T(j) behind PV_1(j-1), K(j+1) behind S^T_1(j)
@@ -41,6 +40,12 @@ extern "C" int p3v_ildbg_read(unsigned long long* out) {
 #else
 #define IL_S(k) do { } while (0)
 #define IL_FLUSH(it) do { } while (0)
+#endif
+#ifndef P3V_IL_DMA_FRONT
+#define P3V_IL_DMA_FRONT 1                                      // where slot A issues the wave's DMA pieces: 1 in front of its MFMAs, 0 one every
+                                                                // four MFMAs (1-2 % slower: a piece holds its wave's instruction stream ~80
+                                                                // cycles wherever it stands -- inside the stream they come out of the wave's own
+                                                                // MFMA issue, in front the partner wave covers them), 2 behind region 1 (= 1)
 #endif
 #ifndef P3V_IL_HOIST_OFFSETS
 #define P3V_IL_HOIST_OFFSETS 1                                  // fragment read offsets live across the loop (0: recomputed per slot)
@@ -252,6 +257,13 @@ __global__ void __launch_bounds__(512, 1) k_attn_prefill_il(AttnP p) {
     const bool interior = j >= j_int_lo && j <= j_int_hi;
     if (!interior) mask_half(u, j);
     __builtin_amdgcn_sched_barrier(0);
+#if P3V_IL_DMA_FRONT == 1
+    if (dma_kt >= 0) {
+#pragma unroll
+      for (int i = 0; i < NPW; ++i) issue_piece(i, dma_kt, dma_sk, dma_sv);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#endif
     // region 1: PV_uu (2 NDT + 2 MFMAs) || maximum of the 64 scores of each query of half u
     // (the fast path needs no cross-lane step: "some score of the wave exceeds the threshold" is a ballot over the LANES' own
     //  maxima; the row maximum is only formed when the reference does move)
@@ -291,7 +303,11 @@ __global__ void __launch_bounds__(512, 1) k_attn_prefill_il(AttnP p) {
 #endif
         if (dma_kt >= 0) {                // this wave's DMA pieces, one at a time between MFMAs (a burst of three
           const int gi = st * (NDT + 1) + d;                 // right after the barrier, all eight waves at once, cost each wave ~300 cycles)
+#if P3V_IL_DMA_FRONT == 0
           if (gi % 4 == 1 && gi / 4 < NPW) issue_piece(gi / 4, dma_kt, dma_sk, dma_sv);
+#elif P3V_IL_DMA_FRONT == 2
+          if (gi >= 2 * NDT + 2 - NPW) issue_piece(gi - (2 * NDT + 2 - NPW), dma_kt, dma_sk, dma_sv);   // behind the region's last MFMAs
+#endif
         }
         __builtin_amdgcn_sched_barrier(0);
       }
