@@ -192,6 +192,9 @@ __global__ void __launch_bounds__(512, 1) k_gemm256(Gemm256P p) {
     //  piece costs its wave ~80-150 cycles of instruction issue wherever it stands (580-750 cycles for 12 fragment reads + 4
     //  pieces, ~300 for 8 + 4, against 1024 for the K-tile's 64 MFMAs); inside a quad those cycles come out of the wave's own
     //  MFMA stream, in front of it the partner wave's MFMAs cover most of them.)
+    // (Likewise measured and removed: the SIMD partners' DMA bursts at different places -- waves 0-3 in front of quads 0 / 1,
+    //  waves 4-7 behind them -- so that the two waves of a SIMD are not both in their "reads + 4 pieces" stretch right after
+    //  the barrier: 4-13 % slower on the big-tile shapes.)
     if (ORDER == 2) {
       // software-pipelined fragment reads: the fragments of phase p+1 are requested BEFORE the MFMAs of phase p (second A
       // fragment buffer, 224 of 256 registers), so only the first reads after the barrier expose their LDS latency
