@@ -664,15 +664,6 @@ __global__ void __launch_bounds__(256, 2) k_attn_prefill_dma(AttnP p) {
 #ifndef P3V_PP_DMA_IN_VALU
 #define P3V_PP_DMA_IN_VALU 1
 #endif
-#ifndef P3V_PP_DMA_POS
-#define P3V_PP_DMA_POS 0                                        // where in the VALU phase the DMA pieces are issued: 0 start, 1 after the maxima, 2 end
-#endif
-#ifndef P3V_PP_PRIO_LATE
-#define P3V_PP_PRIO_LATE 0
-#endif
-#ifndef P3V_PP_LATE_K
-#define P3V_PP_LATE_K 0                                         // 1: the K fragments are read after the first half of the PV MFMAs
-#endif
 #ifndef P3V_PP_V_IN_MATRIX
 #define P3V_PP_V_IN_MATRIX 1                                    // 1: both halves of the V^T fragments are read in the matrix phase
 #endif
@@ -881,16 +872,6 @@ __global__ void __launch_bounds__(512, 1) k_attn_prefill_pp(AttnP p) {
       }
     }
   };
-  auto pv_half = [&](int st) {                               // keys 32 st .. 32 st + 31 of the tile
-#pragma unroll
-    for (int d = 0; d < NDT; ++d) {
-      const bf16x8_t vf = vfr[st][d];
-      o[0][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[0][st], o[0][d], 0, 0, 0);
-      o[1][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[1][st], o[1][d], 0, 0, 0);
-    }
-    ol[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones_f, pf[0][st], ol[0], 0, 0, 0);
-    ol[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones_f, pf[1][st], ol[1], 0, 0, 0);
-  };
   auto pv = [&]() {                                          // O^T += V^T_j . P^T(j), l += 1 . P^T(j), V^T_j in vfr
 #pragma unroll
     for (int st = 0; st < 2; ++st)
@@ -922,9 +903,7 @@ __global__ void __launch_bounds__(512, 1) k_attn_prefill_pp(AttnP p) {
 #ifdef P3V_PP_VALUPRIO
     __builtin_amdgcn_s_setprio(2);
 #endif
-#if P3V_PP_DMA_POS == 0
-    issue_at(2 * j + 1);                                     // (DV) this wave's pieces of DMA batch j + 1
-#endif
+    issue_at(2 * j + 1);                                     // (DV) this wave's pieces of DMA batch j + 1 (later in the phase: no gain / -4 %)
     PP_S(0);
 #if !P3V_PP_V_IN_MATRIX
     load_v(j, 0);                                            // first half of V^T(j): lands under the VALU work below (the second
@@ -976,9 +955,6 @@ __global__ void __launch_bounds__(512, 1) k_attn_prefill_pp(AttnP p) {
 #else
     const bool slow = unset[0] || unset[1] || m_t[0] > THR || m_t[1] > THR;
 #endif
-#if P3V_PP_DMA_POS == 1
-    issue_at(2 * j + 1);
-#endif
     PP_S(1);
     if (__builtin_amdgcn_ballot_w64(slow) != 0) {               // wave-uniform: a reference moves (first tile, or a jump > 2^8)
 #pragma unroll
@@ -1025,9 +1001,6 @@ __global__ void __launch_bounds__(512, 1) k_attn_prefill_pp(AttnP p) {
     // P is USED here as far as the optimiser can tell: without this the exponentials are sunk past the step barrier (an asm
     // barrier orders memory operations only) into the matrix phase that consumes them
     asm volatile("" ::"v"(pf[0][0]), "v"(pf[0][1]), "v"(pf[1][0]), "v"(pf[1][1]));
-#if P3V_PP_DMA_POS == 2
-    issue_at(2 * j + 1);
-#endif
     PP_S(3);
 #ifdef P3V_PP_VALUPRIO
     __builtin_amdgcn_s_setprio(0);
@@ -1098,7 +1071,7 @@ __global__ void __launch_bounds__(512, 1) k_attn_prefill_pp(AttnP p) {
 #endif
       end_step();
       issue_at(2 * j + 2);
-#if !defined(P3V_PP_NOPRIO) && !P3V_PP_PRIO_LATE
+#ifndef P3V_PP_NOPRIO
       __builtin_amdgcn_s_setprio(1);
 #endif
       PP_S(0);
@@ -1106,22 +1079,10 @@ __global__ void __launch_bounds__(512, 1) k_attn_prefill_pp(AttnP p) {
       load_v(j, 0);
 #endif
       load_v(j, 1);                                                     // second half of V^T(j): under the first 12 PV MFMAs
-#if P3V_PP_LATE_K
-      __builtin_amdgcn_sched_barrier(0);
-      pv_half(0);
-      __builtin_amdgcn_sched_barrier(0);
-      load_k(j + 1);
-      __builtin_amdgcn_sched_barrier(0);
-      pv_half(1);
-#else
-      load_k(j + 1);                                                    // 12 ds_read_b128 in flight under the 28 PV MFMAs
-      __builtin_amdgcn_sched_barrier(0);
-      PP_S(1);
-#if P3V_PP_PRIO_LATE
-      __builtin_amdgcn_s_setprio(1);                                    // priority for the MFMA stream only, not for the fragment reads
-#endif
+      load_k(j + 1);                                                    // 12 ds_read_b128 in flight under the 28 PV MFMAs (reading them
+      __builtin_amdgcn_sched_barrier(0);                                //  behind the first 14 instead, or raising the priority only for
+      PP_S(1);                                                          //  the MFMAs: no change / -2 %)
       pv();
-#endif
       PP_S(2);
       qk();
       pin_o();
