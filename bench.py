@@ -89,6 +89,15 @@ def cpu_baseline(model, n_decode=32, runs=1, warm_decode=2):
     torch.set_num_threads(cores)
     w = {k: v.cpu() for k, v in model.w.items() if k.startswith("model.layers.") or k in
          ("model.embed_tokens.weight", "model.norm.weight", "lm_head.weight")}
+    # a quantised build (--config5, 4-bit) keeps no bf16 copy of its decoder projections: the baseline's oracle gets the
+    # dequantised values (its TIMING is what is reported; config 1 on bf16-valued weights either way)
+    from phi_3_vision_mlx_amd import ops
+    for k, (q, sc) in getattr(model, "w8", {}).items():
+        if k not in w and (k.startswith("model.layers.") or k == "lm_head.weight"):
+            w[k] = ops.dequant_fp8(q, sc).cpu()
+    for k, (q, sb) in getattr(model, "w4", {}).items():
+        if k not in w and (k.startswith("model.layers.") or k == "lm_head.weight"):
+            w[k] = ops.dequant_q4(q, sb).cpu()
     o = orc.OraclePhi3V(cfg, w, cache_fp32=True)
     o.vision = False
     ids = np.random.default_rng(0).integers(3, 32000, (1, 128)).astype(np.int64)
