@@ -26,6 +26,7 @@ decode steps of the rows already generating and leave at their own EOS / budget 
 """
 import json
 import queue
+import os
 import threading
 from http.server import BaseHTTPRequestHandler, ThreadingHTTPServer
 
@@ -281,16 +282,28 @@ def run(port=8000, synthetic=False, blind_model=False, merge=False, continuous=F
     preload = load(blind_model=blind_model, synthetic=synthetic or None)
     processor = preload[1]
     if continuous:
+        import torch.distributed as dist
         from .engine import ContinuousEngine, RegimeRouter
         eng = ContinuousEngine(*preload, slots=slots)                 # requests with prompt + max_tokens <= 4096 (short RoPE factors)
         if long_window > 4096:                                       # + one engine for the long-RoPE regime (phi.py:492)
             eng = RegimeRouter([eng, ContinuousEngine(*preload, slots=max(1, slots // 2), window=long_window)])
+        world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        front = None
+        if world > 1:                                                # one engine per rank (= per GPU), rank 0 dispatches (fleet.py)
+            from . import fleet
+            groups = fleet.make_groups()
+            if dist.get_rank() != 0:
+                fleet.worker(eng, groups)
+                return
+            eng = front = fleet.EngineFleet(eng, groups, world)
         httpd, engine = serve_continuous(eng, port=port, host=host, image_policy=image_policy)
-        print(f"Starting server on port {port} (continuous batching)")
+        print(f"Starting server on port {port} (continuous batching{f', {world} engines' if world > 1 else ''})")
         try:
             httpd.serve_forever()
         finally:
             engine.close()
+            if front is not None:
+                front.close()
         return
 
     def generate_fn(prompts, max_tokens, images=None):
@@ -329,4 +342,10 @@ if __name__ == "__main__":
     ap.add_argument("--image-dir", default=None, help="allow `images` entries naming files under this directory")
     ap.add_argument("--image-host", action="append", default=[], help="allow `images` URLs on this host (repeatable)")
     a = ap.parse_args()
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:               # python -m torch.distributed.run --nproc-per-node N -m ...server --continuous
+        import torch
+        import torch.distributed as dist
+        if torch.cuda.is_available():
+            torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        dist.init_process_group("gloo")                          # requests and token lists only: host memory (fleet.py)
     run(a.port, a.synthetic, a.blind, a.merge, a.continuous, a.host, ImagePolicy(a.image_dir, a.image_host), a.long_window, a.slots)

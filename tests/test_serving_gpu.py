@@ -324,3 +324,58 @@ def test_generate_sharded_two_ranks_on_one_gpu_matches_the_oracle(tmp_path):
     g = np.load(GOLDEN + "/tiny_serve_oracle.npz")
     assert len(got) == 7
     assert tokens_vs_fixture(got, g, "generate_sharded", min_first=2) >= 20
+
+
+def _fleet_worker(rank, world, port, out_dir):
+    import os
+    import sys
+    import threading
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path[:0] = [root, os.path.join(root, "tests", "golden"), os.path.join(root, "tests")]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+    torch.cuda.set_device(0)                                   # both ranks share the one GPU of the test box
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from golden_inputs import SERVE_STEPS, serve_requests
+    from phi_3_vision_mlx_amd import fleet
+    from phi_3_vision_mlx_amd.api import load_synthetic
+    from phi_3_vision_mlx_amd.engine import ContinuousEngine
+    g = np.load(os.path.join(root, "tests", "golden", "tiny_serve_oracle.npz"))
+    model, proc = load_synthetic(blind_model=False, tiny=True, seed=0, std_scale=4.0, device="cuda:0",
+                                 lm_head_spread=float(g["spread"][0]), lm_head_seed=int(g["head_seed"][0]))
+    eng = ContinuousEngine(model, proc, slots=2, window=4096)
+    groups = fleet.make_groups()
+    if rank:
+        fleet.worker(eng, groups)
+        dist.destroy_process_group()
+        return
+    front = fleet.EngineFleet(eng, groups, world)
+    stop = threading.Event()
+    stepper = threading.Thread(target=front.serve_forever, args=(stop,), daemon=True)
+    stepper.start()
+    handles = [front.submit(r, SERVE_STEPS) for r in serve_requests(proc)]
+    ok = all(h.done.wait(300) for h in handles)
+    torch.save({"ok": ok, "errors": [repr(h.error) for h in handles], "tokens": [list(h.tokens) for h in handles],
+                "sent": list(front.sent)}, os.path.join(out_dir, "fleet.pt"))
+    front.close()
+    stop.set()
+    stepper.join(10)
+    dist.destroy_process_group()
+
+
+def test_engine_fleet_two_ranks_on_one_gpu_matches_the_oracle(tmp_path):
+    """fleet.EngineFleet on REAL kernels: two ranks (gloo, both on the box's one GPU; on a node one per GPU), each stepping
+    its own 2-slot continuous-batching engine; rank 0 dispatches the 7 mixed requests (the image request's pre-processed crops
+    travel to the other rank when it is picked); every request's tokens == its own B = 1 oracle run, whichever rank ran it."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_fleet_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    got = torch.load(tmp_path / "fleet.pt")
+    assert got["ok"] and all(e == "None" for e in got["errors"]), got["errors"]
+    assert sum(got["sent"]) == 7 and min(got["sent"]) >= 2, got["sent"]     # both engines served requests
+    g = np.load(GOLDEN + "/tiny_serve_oracle.npz")
+    assert tokens_vs_fixture(got["tokens"], g, "engine fleet", min_first=2) >= 20
