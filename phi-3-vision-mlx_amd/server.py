@@ -333,6 +333,7 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--port", type=int, default=8000)
     ap.add_argument("--synthetic", action="store_true", help="seeded random weights instead of models/phi3_v")
+    ap.add_argument("--tiny", action="store_true", help="with --synthetic: the 2-layer test model (smoke tests)")
     ap.add_argument("--blind", action="store_true", help="text-only Phi-3-mini-128K")
     ap.add_argument("--merge", action="store_true", help="fold concurrent same-budget requests into one batched generate (opt-in)")
     ap.add_argument("--continuous", action="store_true", help="continuous batching engine (requests join / leave between decode steps)")
@@ -346,6 +347,6 @@ if __name__ == "__main__":
         import torch
         import torch.distributed as dist
         if torch.cuda.is_available():
-            torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+            torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count())   # (fewer GPUs than ranks: shared)
         dist.init_process_group("gloo")                          # requests and token lists only: host memory (fleet.py)
-    run(a.port, a.synthetic, a.blind, a.merge, a.continuous, a.host, ImagePolicy(a.image_dir, a.image_host), a.long_window, a.slots)
+    run(a.port, "tiny" if a.synthetic and a.tiny else a.synthetic, a.blind, a.merge, a.continuous, a.host, ImagePolicy(a.image_dir, a.image_host), a.long_window, a.slots)

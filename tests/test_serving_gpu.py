@@ -379,3 +379,68 @@ def test_engine_fleet_two_ranks_on_one_gpu_matches_the_oracle(tmp_path):
     assert sum(got["sent"]) == 7 and min(got["sent"]) >= 2, got["sent"]     # both engines served requests
     g = np.load(GOLDEN + "/tiny_serve_oracle.npz")
     assert tokens_vs_fixture(got["tokens"], g, "engine fleet", min_first=2) >= 20
+
+
+def test_server_cli_under_torchrun_two_ranks_serves_http(tmp_path):
+    """The command INTEGRATION.md gives for a node -- `python -m torch.distributed.run --nproc-per-node 2 -m ...server
+    --continuous` -- on the tiny synthetic model (both ranks on the box's one GPU): rank 0 answers HTTP, rank 1 runs
+    fleet.worker; eight concurrent text requests all come back 200 with text, and the same prompt gives the same text
+    whichever rank served it."""
+    import json
+    import os
+    import signal
+    import socket
+    import subprocess
+    import sys
+    import threading
+    import time
+    import urllib.request
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def free_port():
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        p = s.getsockname()[1]
+        s.close()
+        return p
+    http_port, master_port = free_port(), free_port()
+    log = open(tmp_path / "server.log", "w")
+    proc = subprocess.Popen([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                             "--master-port", str(master_port), "-m", "phi_3_vision_mlx_amd.server", "--continuous", "--synthetic", "--tiny",
+                             "--port", str(http_port), "--slots", "2"], cwd=root, stdout=log, stderr=subprocess.STDOUT, start_new_session=True)
+    try:
+        def post(prompt, max_tokens=6):
+            req = urllib.request.Request(f"http://127.0.0.1:{http_port}/v1/completions", method="POST",
+                                         data=json.dumps({"prompt": prompt, "max_tokens": max_tokens}).encode(),
+                                         headers={"Content-Type": "application/json"})
+            with urllib.request.urlopen(req, timeout=120) as r:
+                return r.status, json.loads(r.read())
+        deadline = time.time() + 240
+        while True:                                            # wait for the listener (both ranks load the model first)
+            assert proc.poll() is None, open(tmp_path / "server.log").read()[-2000:]
+            try:
+                socket.create_connection(("127.0.0.1", http_port), timeout=1).close()
+                break
+            except OSError:
+                assert time.time() < deadline, open(tmp_path / "server.log").read()[-2000:]
+                time.sleep(0.5)
+        prompts = [f"question number {i % 4} about the weather" for i in range(8)]      # every prompt twice
+        out = [None] * len(prompts)
+
+        def one(i):
+            out[i] = post(prompts[i])
+        threads = [threading.Thread(target=one, args=(i,)) for i in range(len(prompts))]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join(180)
+        assert all(o is not None and o[0] == 200 for o in out), out
+        texts = [o[1]["responses"][0] for o in out]                                     # the reference's response shape (server.py:22-25)
+        assert all(isinstance(t, str) for t in texts) and all(texts[i] == texts[i + 4] for i in range(4)), texts
+    finally:
+        os.killpg(proc.pid, signal.SIGTERM)                    # the process group this test started (torchrun + its two ranks)
+        try:
+            proc.wait(30)
+        except subprocess.TimeoutExpired:
+            os.killpg(proc.pid, signal.SIGKILL)
+        log.close()
