@@ -45,7 +45,10 @@ class RemoteRequest(Request):
 
     def cancel(self):
         Request.cancel(self)
-        self.fleet._send_to(self.rank, ("cancel", self.rid))
+        try:
+            self.fleet._send_to(self.rank, ("cancel", self.rid))
+        except Exception:                                        # noqa: BLE001  the peer is gone: its receiver fails the request
+            pass
 
 
 class EngineFleet:
@@ -85,12 +88,23 @@ class EngineFleet:
             self.next_id += 1
             self.pending[h.rid] = h
             self.load[dst] += 1
-        self._send_to(dst, ("submit", h.rid, inputs, int(max_tokens)))
+        try:
+            self._send_to(dst, ("submit", h.rid, inputs, int(max_tokens)))
+        except Exception as e:                                   # noqa: BLE001  the request never left: fail it here
+            with self.lock:
+                self.pending.pop(h.rid, None)
+                self.load[dst] = 1 << 30
+            h.fail(RuntimeError(f"rank {dst} is unreachable ({type(e).__name__}: {e})"))
         return h
 
     def _receive(self, rank):
+        why = "stopped"
         while True:
-            msg = _recv(rank, self.up)
+            try:
+                msg = _recv(rank, self.up)
+            except Exception as e:                               # noqa: BLE001  the peer died / the group was torn down
+                why = f"is unreachable ({type(e).__name__}: {e})"
+                break
             if msg[0] == "bye":
                 break
             _, rid, tokens, err = msg
@@ -104,12 +118,13 @@ class EngineFleet:
                 h.done.set()
             else:
                 h.fail(_ERRORS.get(err[0], RuntimeError)(f"rank {rank}: {err[1]}"))
-        with self.lock:                                          # the worker is gone: nobody will answer what it still held
+        with self.lock:                                          # the worker is gone: nobody will answer what it still held,
+            self.load[rank] = 1 << 30                            # and nothing more goes there
             lost = [h for h in self.pending.values() if h.rank == rank]
             for h in lost:
                 self.pending.pop(h.rid, None)
         for h in lost:
-            h.fail(RuntimeError(f"rank {rank} stopped before the request finished"))
+            h.fail(RuntimeError(f"rank {rank} {why} before the request finished"))
 
     # ---- the engine surface the HTTP backend drives (server.ContinuousBackend): rank 0 steps its own engine
     @property
