@@ -417,7 +417,7 @@ __global__ void __launch_bounds__(256, 2) k_attn_prefill(AttnP p) {
 // Two LDS buffers, one barrier per tile; compute part and masks identical to k_attn_prefill.
 typedef const __attribute__((address_space(1))) void* pf_gptr_t;
 typedef __attribute__((address_space(3))) void* pf_lptr_t;
-template <int HD>
+template <int HD, bool PRE>                                    // PRE: Q arrives multiplied by scale * log2(e) (p3v_rope_kv_append's q_scale)
 __global__ void __launch_bounds__(256, 2) k_attn_prefill_dma(AttnP p) {
   constexpr int KROW = HD * 2, VROW = 128, NKS = HD / 32, NDT = HD / 16, CPR = HD / 8;
   constexpr int KTILE = 64 * KROW, VTILE = HD * VROW, BUF = KTILE + VTILE;
@@ -516,7 +516,9 @@ __global__ void __launch_bounds__(256, 2) k_attn_prefill_dma(AttnP p) {
   // 4 MFMAs per tile instead of 32 v_add + two cross-lane reductions: the kernel is VALU-bound, the matrix pipe is 70 % idle.
   const u32x4_t ones_w = qi == 0 ? (u32x4_t){0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u} : (u32x4_t){0u, 0u, 0u, 0u};
   const bf16x8_t ones_f = __builtin_bit_cast(bf16x8_t, ones_w);
-  float m_run[2] = {-INFINITY, -INFINITY};
+  float m_run[2] = {0.f, 0.f};                               // reference of the exponent (finite always), in log2 units
+  unsigned long long unset[2] = {~0ull, ~0ull};              // lanes whose query has not seen a visible key yet: the next one sets the reference
+  f32x4_t negm[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};   // (PRE) -reference, the C operand of the S^T products
   f32x4_t ol[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
   f32x4_t o[2][NDT];
 #pragma unroll
@@ -538,8 +540,8 @@ __global__ void __launch_bounds__(256, 2) k_attn_prefill_dma(AttnP p) {
       __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int st = 0; st < 4; ++st) {
-        s[0][st] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-        s[1][st] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        s[0][st] = PRE ? negm[0] : (f32x4_t){0.f, 0.f, 0.f, 0.f};   // PRE: the accumulators START at -reference: the product IS the exponent
+        s[1][st] = PRE ? negm[1] : (f32x4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) {
           const bf16x8_t kf = *(const bf16x8_t*)(Ks + k_rd[ks] + st * 16 * KROW);
@@ -551,40 +553,68 @@ __global__ void __launch_bounds__(256, 2) k_attn_prefill_dma(AttnP p) {
       // every key of the tile visible to every query of the wave -> no per-element mask work (wave-uniform)
       const bool interior = kv0 + 64 <= kv_end && kv0 >= pad && past + q0 >= pad && (!p.causal || kv0 + 63 <= past + q0);
       bf16x8_t pf[2][2];
+      // Softmax with a DEFERRED reference (round 3, as k_attn_prefill_pp / _il): the exponent is taken against the query's
+      // running reference m_run, which moves only on the query's first visible tile and when a score exceeds it by more than
+      // 2^8 (wave-uniform slow path: O, l and the tile's scores are rescaled once, in place).  The classic form -- row maximum
+      // across lanes, new maximum, rescale factor and 28 multiplies on EVERY tile -- was ~280 VALU instructions per tile and
+      // wave against 36-52 MFMAs: the kernel was VALU-bound (the fast path now: 16 max + 32 v_exp + 16 v_cvt_pk, + 32 fma unless Q is pre-scaled).
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
-        float m_t = -INFINITY;
-        if (interior) {
+        if (!PRE) {
 #pragma unroll
           for (int st = 0; st < 4; ++st)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) m_t = fmaxf(m_t, s[u][st][r]);
-        } else {
+            for (int r = 0; r < 4; ++r) s[u][st][r] = fmaf(s[u][st][r], sc2, -m_run[u]);
+        }
+        if (!interior) {
+          const float ninf = -INFINITY;
 #pragma unroll
           for (int st = 0; st < 4; ++st)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               const int t = kv0 + 16 * st + 4 * g + r;
               const bool vis = t < kv_end && t >= pad && (!p.causal || t <= qpos[u]) && qpos[u] >= pad;
-              const float v = vis ? s[u][st][r] : -INFINITY;
-              s[u][st][r] = v;
-              m_t = fmaxf(m_t, v);
+              const unsigned long long vm = __builtin_amdgcn_ballot_w64(vis);
+              asm("v_cndmask_b32_e64 %0, %1, %0, %2" : "+v"(s[u][st][r]) : "v"(ninf), "s"(vm));      // s = vis ? s : -inf
             }
         }
-        m_t = rows_max(m_t);
-        const float m_new = fmaxf(m_run[u], m_t * sc2);
-        const float m_use = m_new == -INFINITY ? 0.f : m_new;
-        const float alpha = __builtin_amdgcn_exp2f(m_run[u] - m_use);
+        float ma, mc;                                          // this LANE's maximum over its 16 scores (no cross-lane step on the fast path)
+        asm("v_max3_f32 %0, %1, %2, %3" : "=v"(ma) : "v"(s[u][0][0]), "v"(s[u][0][1]), "v"(s[u][0][2]));
+        asm("v_max3_f32 %0, %1, %2, %3" : "=v"(mc) : "v"(s[u][0][3]), "v"(s[u][1][0]), "v"(s[u][1][1]));
+        asm("v_max3_f32 %0, %0, %1, %2" : "+v"(ma) : "v"(s[u][1][2]), "v"(s[u][1][3]));
+        asm("v_max3_f32 %0, %0, %1, %2" : "+v"(mc) : "v"(s[u][2][0]), "v"(s[u][2][1]));
+        asm("v_max3_f32 %0, %0, %1, %2" : "+v"(ma) : "v"(s[u][2][2]), "v"(s[u][2][3]));
+        asm("v_max3_f32 %0, %0, %1, %2" : "+v"(mc) : "v"(s[u][3][0]), "v"(s[u][3][1]));
+        asm("v_max3_f32 %0, %0, %1, %2" : "+v"(ma) : "v"(s[u][3][2]), "v"(s[u][3][3]));
+        asm("v_max_f32 %0, %0, %1" : "+v"(ma) : "v"(mc));
+        if ((unset[u] | __builtin_amdgcn_ballot_w64(ma > 8.f)) != 0) {       // rare, wave-uniform: a reference moves
+          const float m_t = rows_max(ma);
+          const bool masked = m_t == -INFINITY;
+          const bool un = (unset[u] >> lane) & 1;
+          const float delta = un ? (masked ? 0.f : m_t) : fmaxf(m_t, 0.f);
+          const float alpha = un ? 1.f : __builtin_amdgcn_exp2f(-delta);
+          unset[u] &= __builtin_amdgcn_ballot_w64(masked);
+          m_run[u] += delta;
+          if (PRE) {
+            const float nm = -m_run[u];                        // (in place: a new value would cost the fast path register copies)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) asm("v_mov_b32 %0, %1" : "+v"(negm[u][r]) : "v"(nm));
+          }
+#pragma unroll
+          for (int st = 0; st < 4; ++st)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) asm("v_sub_f32 %0, %0, %1" : "+v"(s[u][st][r]) : "v"(delta));
+#pragma unroll
+          for (int d = 0; d < NDT; ++d)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) asm("v_mul_f32 %0, %0, %1" : "+v"(o[u][d][r]) : "v"(alpha));
+#pragma unroll
+          for (int r = 0; r < 4; ++r) asm("v_mul_f32 %0, %0, %1" : "+v"(ol[u][r]) : "v"(alpha));
+        }
 #pragma unroll
         for (int st = 0; st < 4; ++st)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) s[u][st][r] = __builtin_amdgcn_exp2f(fmaf(s[u][st][r], sc2, -m_use));
-        m_run[u] = m_new;
-        if (!__all(alpha == 1.f)) {
-#pragma unroll
-          for (int d = 0; d < NDT; ++d) o[u][d] *= alpha;
-          ol[u] *= alpha;
-        }
+          for (int r = 0; r < 4; ++r) s[u][st][r] = __builtin_amdgcn_exp2f(s[u][st][r]);
 #pragma unroll
         for (int st = 0; st < 2; ++st) {
           u32x4_t pw;
@@ -1134,11 +1164,12 @@ __global__ void __launch_bounds__(512, 1) k_attn_prefill_pp(AttnP p) {
 //   dma (128 q)  30 us   80 us   613 us   7.37 ms  |   54 us                   39 us
 //   pp  (256 q)  34 us   68-74 us   430-467 us   5.7-6.1 ms  |   69-74 us        48-50 us     (883-960 / 1080-1149 TF/s at 8k / 32k; box-dependent)
 //   il  (256 q)  31 us   58-63 us   373-388 us   5.23-5.45 ms    (pre-scaled Q only)               (1063-1106 / 1212-1261 TF/s)
-// the 8-wave kernels need a few query blocks per head before their better steady state beats their coarser tail: il from 1280
-// tokens (35 us against 37), pp (what is left for it: plain Q, head dim 64) from 2048
+// the 8-wave kernels need a few query blocks per head before their better steady state beats their coarser tail: il from 1792
+// tokens, pp (what is left for it: plain Q, head dim 64) from 3072 -- both later than before the 128-query kernel got the
+// deferred-reference softmax too (-10 % on it: 1024 tokens 30.4 -> 26-27 us, CLIP 62 -> 55 us)
 #include "p3v_attn_il.h"
-constexpr int P3V_ATTN_PP_MIN_L = 2048;
-constexpr int P3V_ATTN_IL_MIN_L = 1280;                          // tools/attn_short_probe.py: il 35 us / dma 37 us at 1280, 31 / 29 at 1024
+constexpr int P3V_ATTN_PP_MIN_L = 3072;                          // tools/attn_short_probe.py (after the dma kernel's deferred-reference softmax):
+constexpr int P3V_ATTN_IL_MIN_L = 1792;                          // dma / pp / il  44.5 / 51.5 / 44.3 us at 1792, 65.2 / 67.5 / 58.3 at 2531, 82.3 / 79.0 / 68.7 at 3072
 template <int HD>
 static int launch_attn_prefill(const AttnP& p, hipStream_t s) {
   constexpr int LDS = 2 * (64 * (HD * 2 + 16) + HD * (64 * 2 + 16));
@@ -1153,7 +1184,8 @@ static int launch_attn_prefill(const AttnP& p, hipStream_t s) {
     constexpr int LDS2 = 2 * (64 * HD * 2 + HD * 128);
     static bool attr2_set = false;
     if (!attr2_set) {
-      if (hipFuncSetAttribute((const void*)k_attn_prefill_dma<HD>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS2) != hipSuccess)
+      if (hipFuncSetAttribute((const void*)k_attn_prefill_dma<HD, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS2) != hipSuccess ||
+          hipFuncSetAttribute((const void*)k_attn_prefill_dma<HD, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS2) != hipSuccess)
         return P3V_ERR_HIP;
       attr2_set = true;
     }
@@ -1188,7 +1220,8 @@ static int launch_attn_prefill(const AttnP& p, hipStream_t s) {
       P3V_CHECK_LAUNCH();
       return P3V_OK;
     }
-    hipLaunchKernelGGL(k_attn_prefill_dma<HD>, dim3(p.nh * p3v_cdiv(p.L, 128), 1, p.B), dim3(256), LDS2, s, q);
+    if (p.q_prescaled) hipLaunchKernelGGL((k_attn_prefill_dma<HD, true>), dim3(p.nh * p3v_cdiv(p.L, 128), 1, p.B), dim3(256), LDS2, s, q);
+    else hipLaunchKernelGGL((k_attn_prefill_dma<HD, false>), dim3(p.nh * p3v_cdiv(p.L, 128), 1, p.B), dim3(256), LDS2, s, q);
   } else {
     hipLaunchKernelGGL(k_attn_prefill<HD>, grid, dim3(256), LDS, s, p);
   }

@@ -279,6 +279,13 @@ __global__ void __launch_bounds__(256) k_rope_kv_append(const bf16_t* __restrict
         olo[j] = pack_bf16x2((a0 * cs[2 * j] - b0 * sn[2 * j]) * qs, (a1 * cs[2 * j + 1] - b1 * sn[2 * j + 1]) * qs);
         ohi[j] = pack_bf16x2((b0 * cs[2 * j] + a0 * sn[2 * j]) * qs, (b1 * cs[2 * j + 1] + a1 * sn[2 * j + 1]) * qs);
       }
+      if (!rot && qs != 1.f) {                                // plain head split (CLIP) with pre-scaled queries
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          olo[j] = pack_bf16x2(bf16lo(lo[j]) * qs, bf16hi(lo[j]) * qs);
+          ohi[j] = pack_bf16x2(bf16lo(hi[j]) * qs, bf16hi(hi[j]) * qs);
+        }
+      }
       bf16_t* dst;
       if (head < nh) dst = q_out + (((size_t)b * nh + head) * L + l) * hd + c * 8;
       else dst = k_dst + (((size_t)b * nkv + (head - nh)) * dst_t + dpos) * hd + c * 8;
@@ -345,7 +352,7 @@ extern "C" int p3v_rope_kv_append(const uint16_t* qkv, const float* cos_t, const
   if (B * L == 0) return P3V_OK;
   const int bulk_v = L >= 32;                             // prefill-shaped: V goes through the LDS transpose kernel
   hipLaunchKernelGGL(k_rope_kv_append, dim3(B * L), dim3(256), 0, (hipStream_t)stream, qkv, cos_t, sin_t, q_out, k_dst,
-                     v_dst, L, n_heads, n_kv, hd, past, d_past, dst_t, dst_off_is_past, tab_t, tab_div, bulk_v, cos_t ? q_scale : 1.f);
+                     v_dst, L, n_heads, n_kv, hd, past, d_past, dst_t, dst_off_is_past, tab_t, tab_div, bulk_v, q_scale);
   P3V_CHECK_LAUNCH();
   if (bulk_v) {
     hipLaunchKernelGGL(k_v_transpose_append, dim3(p3v_cdiv(L, 64), n_kv, B), dim3(256), 0, (hipStream_t)stream, qkv, v_dst, L,

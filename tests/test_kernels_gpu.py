@@ -310,6 +310,14 @@ def test_rope_table_and_append(ops, orc, L, T, past):
     ops.rope_kv_append(qkv.cuda(), cos, sin, q2, kc2, vc2, B, L, nh, nkv, hd, past, T, True, T, 1, q_scale=qs)
     close(q2, (orc.rotate_half(x[:, :nh], cs, sn) * qs).to(BF16), atol=2e-3)
     assert torch.equal(kc2, kc) and torch.equal(vc2, vc)
+    # the plain head split (null tables: the ViT's q / k / v, phi.py:147) with and without q_scale: q = bf16(q * q_scale), bit for bit
+    q3, kc3, vc3 = torch.zeros_like(q), torch.zeros_like(kc), torch.zeros_like(vc)
+    ops.rope_kv_append(qkv.cuda(), None, None, q3, kc3, vc3, B, L, nh, nkv, hd, past, T, True)
+    assert torch.equal(q3.cpu(), x[:, :nh]) and torch.equal(kc3[:, :, past:past + L].cpu(), x[:, nh:nh + nkv])
+    q4 = torch.zeros_like(q)
+    ops.rope_kv_append(qkv.cuda(), None, None, q4, kc3, vc3, B, L, nh, nkv, hd, past, T, True, q_scale=qs)
+    assert torch.equal(q4.cpu(), (x[:, :nh].float() * np.float32(qs)).to(BF16))
+    assert torch.equal(kc3[:, :, past:past + L].cpu(), x[:, nh:nh + nkv]) and torch.equal(vc3, vc)
 
 
 def _attn_ref(orc, q, k, v, scale, allowed):
@@ -438,7 +446,7 @@ def test_attention_prefill_long_context_spot_rows(ops, orc, pp):
 
 @pytest.mark.parametrize("seed", range(10))
 def test_attention_prefill_interleaved_random_shapes(ops, orc, seed):
-    """k_attn_prefill_il over seeded random shapes (the launcher only takes it from 1280 tokens; pinned here it must hold for
+    """k_attn_prefill_il over seeded random shapes (the launcher only takes it from 1792 tokens; pinned here it must hold for
     any length): 1..700 new queries over 0..400 cached keys, 1-3 rows with random left padding (sometimes a whole row's past),
     causal or not, head dim 96 / 64, 1-3 heads, modest or large score magnitudes -- first / last tile on neutral operands, idle
     waves, ragged last tile, ring wrap-around and the reference path all get hit in some combination."""

@@ -13,7 +13,7 @@ for n in names:
     for name, (res, args) in _lib.SIGNATURES.items():
         fn = getattr(l, name)
         fn.restype, fn.argtypes = res, args
-    l.p3v_set_tuning(b"attn_pp", 1)
+    l.p3v_set_tuning(b"attn_pp", int(not n.endswith(":dma")))      # "name:dma": the 128-query kernel of that build
     l.p3v_set_tuning(b"attn_il", int(n.endswith(":il")))          # "name:il": the interleaved kernel of that build
     libs[n] = l
 for B, L, nh, hd, causal in shapes:
