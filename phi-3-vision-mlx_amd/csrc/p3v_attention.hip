@@ -516,7 +516,7 @@ __global__ void __launch_bounds__(256, 2) k_attn_prefill_dma(AttnP p) {
   // 4 MFMAs per tile instead of 32 v_add + two cross-lane reductions: the kernel is VALU-bound, the matrix pipe is 70 % idle.
   const u32x4_t ones_w = qi == 0 ? (u32x4_t){0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u} : (u32x4_t){0u, 0u, 0u, 0u};
   const bf16x8_t ones_f = __builtin_bit_cast(bf16x8_t, ones_w);
-  float m_run[2] = {0.f, 0.f};                               // reference of the exponent (finite always), in log2 units
+  float m_run[2] = {PRE ? 0.f : -INFINITY, PRE ? 0.f : -INFINITY};   // PRE: reference of the exponent (finite always), log2 units; else: running maximum
   unsigned long long unset[2] = {~0ull, ~0ull};              // lanes whose query has not seen a visible key yet: the next one sets the reference
   f32x4_t negm[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};   // (PRE) -reference, the C operand of the S^T products
   f32x4_t ol[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
@@ -553,19 +553,20 @@ __global__ void __launch_bounds__(256, 2) k_attn_prefill_dma(AttnP p) {
       // every key of the tile visible to every query of the wave -> no per-element mask work (wave-uniform)
       const bool interior = kv0 + 64 <= kv_end && kv0 >= pad && past + q0 >= pad && (!p.causal || kv0 + 63 <= past + q0);
       bf16x8_t pf[2][2];
-      // Softmax with a DEFERRED reference (round 3, as k_attn_prefill_pp / _il): the exponent is taken against the query's
-      // running reference m_run, which moves only on the query's first visible tile and when a score exceeds it by more than
-      // 2^8 (wave-uniform slow path: O, l and the tile's scores are rescaled once, in place).  The classic form -- row maximum
-      // across lanes, new maximum, rescale factor and 28 multiplies on EVERY tile -- was ~280 VALU instructions per tile and
-      // wave against 36-52 MFMAs: the kernel was VALU-bound (the fast path now: 16 max + 32 v_exp + 16 v_cvt_pk, + 32 fma unless Q is pre-scaled).
+      // PRE (pre-scaled Q: the decoder's prompts): softmax with a DEFERRED reference, as k_attn_prefill_pp / _il -- the S^T
+      // accumulators started at -reference, so the product IS the exponent; the reference moves only on the query's first
+      // visible tile and when a score exceeds it by more than 2^8 (wave-uniform slow path: O, l and the tile's scores are
+      // rescaled once, in place).  Fast path: 16 max + 32 v_exp + 16 v_cvt_pk against ~280 VALU of the classic form below
+      // (row maximum across lanes, new maximum, rescale factor and 28 multiplies on EVERY tile).
+      // Plain Q (the ViT, external callers) keeps the classic form: the deferred form was built for it too (CLIP 62 -> 55 us)
+      // and withdrawn -- correct and bit-stable once its multiply-add was written in place (as `s = fmaf(s, sc2, -m)` the
+      // compiler put the results into the registers the last S^T MFMA had read and the output became NON-DETERMINISTIC:
+      // 16-query halves wrong by up to 0.8 in some launches, tools/attn_determinism.py), but a different rounding sequence in
+      // the ViT moves the heavy-tailed fixtures' logit error by +-40 % (chaotic amplification, profiles/r03_heavy_tail.txt)
+      // past tolerances calibrated on one implementation.
+      if constexpr (PRE) {
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
-        if (!PRE) {
-#pragma unroll
-          for (int st = 0; st < 4; ++st)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) s[u][st][r] = fmaf(s[u][st][r], sc2, -m_run[u]);
-        }
         if (!interior) {
           const float ninf = -INFINITY;
 #pragma unroll
@@ -624,6 +625,52 @@ __global__ void __launch_bounds__(256, 2) k_attn_prefill_dma(AttnP p) {
           pw[3] = pack_bf16x2(s[u][2 * st + 1][2], s[u][2 * st + 1][3]);
           pf[u][st] = __builtin_bit_cast(bf16x8_t, pw);
         }
+      }
+      } else {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        float m_t = -INFINITY;
+        if (interior) {
+#pragma unroll
+          for (int st = 0; st < 4; ++st)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) m_t = fmaxf(m_t, s[u][st][r]);
+        } else {
+#pragma unroll
+          for (int st = 0; st < 4; ++st)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int t = kv0 + 16 * st + 4 * g + r;
+              const bool vis = t < kv_end && t >= pad && (!p.causal || t <= qpos[u]) && qpos[u] >= pad;
+              const float v = vis ? s[u][st][r] : -INFINITY;
+              s[u][st][r] = v;
+              m_t = fmaxf(m_t, v);
+            }
+        }
+        m_t = rows_max(m_t);
+        const float m_new = fmaxf(m_run[u], m_t * sc2);
+        const float m_use = m_new == -INFINITY ? 0.f : m_new;
+        const float alpha = __builtin_amdgcn_exp2f(m_run[u] - m_use);
+#pragma unroll
+        for (int st = 0; st < 4; ++st)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) s[u][st][r] = __builtin_amdgcn_exp2f(fmaf(s[u][st][r], sc2, -m_use));
+        m_run[u] = m_new;
+        if (!__all(alpha == 1.f)) {
+#pragma unroll
+          for (int d = 0; d < NDT; ++d) o[u][d] *= alpha;
+          ol[u] *= alpha;
+        }
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+          u32x4_t pw;
+          pw[0] = pack_bf16x2(s[u][2 * st][0], s[u][2 * st][1]);
+          pw[1] = pack_bf16x2(s[u][2 * st][2], s[u][2 * st][3]);
+          pw[2] = pack_bf16x2(s[u][2 * st + 1][0], s[u][2 * st + 1][1]);
+          pw[3] = pack_bf16x2(s[u][2 * st + 1][2], s[u][2 * st + 1][3]);
+          pf[u][st] = __builtin_bit_cast(bf16x8_t, pw);
+        }
+      }
       }
       __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -1159,17 +1206,14 @@ __global__ void __launch_bounds__(512, 1) k_attn_prefill_pp(AttnP p) {
   }
 }
 
-// Which prompt-sized kernel (measured, B = 1, 32 heads x 96, causal, random data; profiles/r03_attn_prefill_kernels.txt):
-//   tokens      1024    2531     8192     32768    |  CLIP 17 x 577 (hd 64)   8 x 512
-//   dma (128 q)  30 us   80 us   613 us   7.37 ms  |   54 us                   39 us
-//   pp  (256 q)  34 us   68-74 us   430-467 us   5.7-6.1 ms  |   69-74 us        48-50 us     (883-960 / 1080-1149 TF/s at 8k / 32k; box-dependent)
-//   il  (256 q)  31 us   58-63 us   373-388 us   5.23-5.45 ms    (pre-scaled Q only)               (1063-1106 / 1212-1261 TF/s)
-// the 8-wave kernels need a few query blocks per head before their better steady state beats their coarser tail: il from 1792
-// tokens, pp (what is left for it: plain Q, head dim 64) from 3072 -- both later than before the 128-query kernel got the
-// deferred-reference softmax too (-10 % on it: 1024 tokens 30.4 -> 26-27 us, CLIP 62 -> 55 us)
+// Which prompt-sized kernel (measured, 32 heads x 96, causal, random data; profiles/r03_attn_prefill_kernels.txt; the table the
+// launcher's rules come from sits at the rules, in launch_attn_prefill):
+//   dma (128 queries, 4 waves, two workgroups per CU): every plain-Q call (the ViT, cached calls) below 3072 tokens, pre-scaled
+//       prompts of several rows up to ~4600 tokens -- since it got the deferred-reference softmax: 946 TF/s at 8k (round 2: 606-623);
+//   il  (interleaved; 128 or 256 queries): pre-scaled prompts -- ONE row from 768 tokens, several rows from ~4600, everything from 6144;
+//   pp  (ping-pong, 256 queries): what is left for it -- plain Q or head dim 64 from 3072 tokens.
 #include "p3v_attn_il.h"
-constexpr int P3V_ATTN_PP_MIN_L = 3072;                          // tools/attn_short_probe.py (after the dma kernel's deferred-reference softmax):
-constexpr int P3V_ATTN_IL_MIN_L = 1792;                          // dma / pp / il  44.5 / 51.5 / 44.3 us at 1792, 65.2 / 67.5 / 58.3 at 2531, 82.3 / 79.0 / 68.7 at 3072
+constexpr int P3V_ATTN_PP_MIN_L = 3072;                          // tools/attn_short_probe.py: dma / pp 65.2 / 67.5 us at 2531, 82.3 / 79.0 at 3072
 template <int HD>
 static int launch_attn_prefill(const AttnP& p, hipStream_t s) {
   constexpr int LDS = 2 * (64 * (HD * 2 + 16) + HD * (64 * 2 + 16));
@@ -1194,14 +1238,28 @@ static int launch_attn_prefill(const AttnP& p, hipStream_t s) {
     q.head_group = kv_bytes * p.nh <= (64u << 20) ? p.nh : (p.nh % 8 == 0 && kv_bytes * 8 <= (128u << 20) ? 8 : (p.nh % 4 == 0 ? 4 : p.nh));
     const int pp = p3v_tuning().attn_pp;                         // -1: by shape; 0 / 1: pin (kernel tests run both)
     const int il = p3v_tuning().attn_il;                         // the interleaved kernel (pre-scaled Q only)
-    if (p.q_prescaled && (il > 0 || (il < 0 && pp != 0 && p.L >= P3V_ATTN_IL_MIN_L))) {   // (pp = 0 pins the dma kernel)
+    // Which kernel for a pre-scaled prompt (tools/attn_il4_probe.py, 32 heads x 96, causal, us; dma / il 4 waves / il 8 waves):
+    //   B = 1:  512: 15.9 / 16.4 / 22.2   768: 21.1 / 20.1 / 26.6   1280: 32.3 / 27.1 / 34.8   2531: 64.6 / 52.6 / 58.8
+    //           3072: 81.4 / 74.6 / 69.5   4096: 119 / 114 / 108    8192: 436 / 403 / 377
+    //   B = 2:  1280: 40.0 / 36.5 / 40.3   2531: 91.8 / 99.8 / 106   4096: 221 / 219 / 228   5120: 343 / 320 / 328
+    //   B = 8:  1280: 112 / 127 / 142      2531: 385 / 396 / 414
+    // -> long prompts: 256-query workgroups (half the L2 -> LDS bytes per flop); ONE row of a few thousand tokens: 128-query
+    //    workgroups of the interleaved kernel (best balance, two workgroups per CU); several rows: the 128-query kernel.
+    const bool il_auto = p.L >= 6144 || (p.B == 1 ? p.L >= 768 : p.L >= 4608);
+    if (p.q_prescaled && (il > 0 || (il < 0 && pp != 0 && il_auto))) {   // (pp = 0 pins the dma kernel)
       constexpr int LDS4 = 3 * 64 * HD * 2 + 3 * HD * 128;
       static bool attr4_set = false;
       if (!attr4_set) {
-        if (hipFuncSetAttribute((const void*)k_attn_prefill_il<HD>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS4) != hipSuccess) return P3V_ERR_HIP;
+        if (hipFuncSetAttribute((const void*)k_attn_prefill_il<HD, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS4) != hipSuccess ||
+            hipFuncSetAttribute((const void*)k_attn_prefill_il<HD, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS4) != hipSuccess)
+          return P3V_ERR_HIP;
         attr4_set = true;
       }
-      hipLaunchKernelGGL((k_attn_prefill_il<HD>), dim3(p.nh * p3v_cdiv(p.L, 256), 1, p.B), dim3(512), LDS4, s, q);
+      // 128-query workgroups (two per CU) while 256-query ones would leave the launch bounded by its longest block
+      const int nw = p3v_tuning().attn_il_waves;
+      const bool small = nw == 4 || (nw < 0 && p.L < (p.B == 1 ? 2816 : 6144));
+      if (small) hipLaunchKernelGGL((k_attn_prefill_il<HD, 4>), dim3(p.nh * p3v_cdiv(p.L, 128), 1, p.B), dim3(256), LDS4, s, q);
+      else hipLaunchKernelGGL((k_attn_prefill_il<HD, 8>), dim3(p.nh * p3v_cdiv(p.L, 256), 1, p.B), dim3(512), LDS4, s, q);
       P3V_CHECK_LAUNCH();
       return P3V_OK;
     }

@@ -47,25 +47,29 @@ extern "C" int p3v_ildbg_read(unsigned long long* out) {
                                                                 // cycles wherever it stands -- inside the stream they come out of the wave's own
                                                                 // MFMA issue, in front the partner wave covers them), 2 behind region 1 (= 1)
 #endif
-template <int HD>
-__global__ void __launch_bounds__(512, 1) k_attn_prefill_il(AttnP p) {
+// NW = waves per workgroup: 8 (256 queries, one workgroup per CU) or 4 (128 queries, TWO workgroups per CU -- each with its own
+// 72 KB of rings -- for prompts of a few thousand tokens, where 256-query blocks leave the launch bounded by its longest block:
+// 2531 tokens are 10 blocks of 4..40 tiles per head, 320 workgroups for 256 CUs).  The price of NW = 4: every tile is fetched
+// per 128 queries, twice the DMA pieces per wave.
+template <int HD, int NW>
+__global__ void __launch_bounds__(64 * NW, 8 / NW) k_attn_prefill_il(AttnP p) {
   constexpr int KROW = HD * 2, VROW = 128, NKS = HD / 32, NDT = HD / 16, CPR = HD / 8;
   constexpr int KTILE = 64 * KROW, VTILE = HD * VROW, RING = 3;
-  constexpr int NK = KTILE / 1024, NV = VTILE / 1024, NPW = (NK + NV) / 8;   // DMA pieces per tile (K, V^T); per wave and batch
+  constexpr int NK = KTILE / 1024, NV = VTILE / 1024, NPW = (NK + NV) / NW, QB = 32 * NW;   // DMA pieces per tile (K, V^T); per wave and batch
   constexpr float THR = 8.f;
-  static_assert((NK + NV) % 8 == 0, "pieces must divide over 8 waves");
+  static_assert((NK + NV) % NW == 0 && (NW == 4 || NW == 8), "pieces must divide over the waves");
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];   // K ring [3][KTILE] | V^T ring [3][VTILE]
   const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, qi = lane & 15;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int nqb = (p.L + 255) >> 8, per_group = p.head_group * nqb;
+  const int nqb = (p.L + QB - 1) / QB, per_group = p.head_group * nqb;
   const int hgrp = blockIdx.x / per_group, within = blockIdx.x - hgrp * per_group;
   const int qblk = nqb - 1 - within / p.head_group;             // longest (last) query blocks first
   const int b = blockIdx.z, head = hgrp * p.head_group + within % p.head_group, kvh = head / (p.nh / p.nkv);
   const int past = p.d_past ? *p.d_past : p.past;
   const int total = past + p.L;
   const int pad = p.pad_len ? p.pad_len[b / p.pad_div] : 0;
-  const int qb0 = qblk * 256, q0 = qb0 + wave * 32;
-  const int kv_end = p.causal ? min(total, past + qb0 + 256) : total;
+  const int qb0 = qblk * QB, q0 = qb0 + wave * 32;
+  const int kv_end = p.causal ? min(total, past + qb0 + QB) : total;
   const int kv_begin = min(pad & ~63, kv_end);
   const int NT = (kv_end - kv_begin + 63) >> 6;
   const bool active = q0 < p.L;
@@ -95,12 +99,12 @@ __global__ void __launch_bounds__(512, 1) k_attn_prefill_il(AttnP p) {
   const __amdgpu_buffer_rsrc_t rs_k = __builtin_amdgcn_make_buffer_rsrc((void*)kbase, 0, 0xffffffff, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_v = __builtin_amdgcn_make_buffer_rsrc((void*)vbase, 0, 0xffffffff, 0x00020000);
 
-  // ---- this wave's DMA pieces: piece pi = wave + 8 i of the list [K_0 .. K_{NK-1}, V_0 .. V_{NV-1}] (layout: k_attn_prefill_pp)
+  // ---- this wave's DMA pieces: piece pi = wave + NW i of the list [K_0 .. K_{NK-1}, V_0 .. V_{NV-1}] (layout: k_attn_prefill_pp)
   const unsigned vrow = (unsigned)p.past_t * 2;
   unsigned poff[NPW];
 #pragma unroll
   for (int i = 0; i < NPW; ++i) {
-    const int pi = wave + 8 * i;
+    const int pi = wave + NW * i;
     if (pi < NK) {
       const int e = pi * 64 + lane, row = e / CPR, pc = e - row * CPR;
       const int sw = HD == 96 ? (-(row >> 2)) & 3 : (row >> 1) & 7;
@@ -121,7 +125,7 @@ __global__ void __launch_bounds__(512, 1) k_attn_prefill_il(AttnP p) {
   int p_lds[NPW], p_stride[NPW], p_base[NPW], p_lag[NPW];
 #pragma unroll
   for (int i = 0; i < NPW; ++i) {
-    const int pi = wave + 8 * i;
+    const int pi = wave + NW * i;
     const bool isk = pi < NK;
     p_rs[i] = isk ? rs_k : rs_v;
     p_lds[i] = isk ? pi * 1024 : RING * KTILE + (pi - NK) * 1024;
@@ -145,7 +149,7 @@ __global__ void __launch_bounds__(512, 1) k_attn_prefill_il(AttnP p) {
   auto issue = [&](int kt, int vt, bool with_v, int only = -1) __attribute__((always_inline)) {      // (prologue / idle waves) the whole batch, or K alone
 #pragma unroll
     for (int i = 0; i < NPW; ++i)
-      if (with_v || wave + 8 * i < NK) issue_piece(i, kt, kt % RING, (kt + RING - 1) % RING);
+      if (with_v || wave + NW * i < NK) issue_piece(i, kt, kt % RING, (kt + RING - 1) % RING);
   };
   auto lane_now = [&]() __attribute__((always_inline)) {                                    // a lane id the compiler cannot see through (k_attn_prefill_pp)
     unsigned l = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));

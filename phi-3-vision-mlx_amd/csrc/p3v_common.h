@@ -119,7 +119,7 @@ struct P3vTuning {
   int gemm_big_rows;        // rows given to the 256x256-tile GEMM (-1: cost model)
   int gemm_no_splitk, gemm_splitk_max_m, gemm_splitk_max_s, gemm_splitk_wgs, gemm_128, gemm_persistent;
   int gemm_f8_narrow;       // -1: by shape, 0 / 1: pin the fp8 tile width
-  int attn_no_dma, attn_old, attn_pp, attn_il, combine_g, kvq_old, q8_old;
+  int attn_no_dma, attn_old, attn_pp, attn_il, attn_il_waves, combine_g, kvq_old, q8_old;
   int gemv_no_mfma, gemv_no_mfma8, gemv_wpc, gemv8_wgs, gemv_variant, gemv_rows, gemv8_min, gemv_mfma8, gemv_f8_wpc, gemv_q4_wpc;
 };
 const P3vTuning& p3v_tuning();

@@ -33,7 +33,8 @@ const Knob kKnobs[] = {
     {"gemm_persistent", &P3vTuning::gemm_persistent, 1},
     {"gemm_f8_narrow", &P3vTuning::gemm_f8_narrow, -1},     {"attn_no_dma", &P3vTuning::attn_no_dma, 0},
     {"attn_old", &P3vTuning::attn_old, 0},                  {"attn_pp", &P3vTuning::attn_pp, -1},
-    {"attn_il", &P3vTuning::attn_il, -1},                   {"combine_g", &P3vTuning::combine_g, -1},
+    {"attn_il", &P3vTuning::attn_il, -1},                   {"attn_il_waves", &P3vTuning::attn_il_waves, -1},
+                      {"combine_g", &P3vTuning::combine_g, -1},
     {"kvq_old", &P3vTuning::kvq_old, 0},                    {"q8_old", &P3vTuning::q8_old, 0},
     {"gemv_no_mfma", &P3vTuning::gemv_no_mfma, 0},          {"gemv_no_mfma8", &P3vTuning::gemv_no_mfma8, 0},
     {"gemv_wpc", &P3vTuning::gemv_wpc, 8},                  {"gemv8_wgs", &P3vTuning::gemv8_wgs, 256},

@@ -1,0 +1,21 @@
+import sys, torch, collections
+sys.path.insert(0, "/root/repo")
+from phi_3_vision_mlx_amd import ops
+B, L, nh, hd, causal, pre = 17, 577, 16, 64, False, False
+torch.manual_seed(0)
+q = torch.randn(B, nh, L, hd, device="cuda").bfloat16()
+Tp = (L + 63) // 64 * 64
+k = torch.randn(B, nh, Tp, hd, device="cuda").bfloat16(); v = torch.randn(B, nh, hd, Tp, device="cuda").bfloat16()
+ops.set_tuning("attn_pp", 0); ops.set_tuning("attn_il", 0)
+outs = []
+for r in range(6):
+    out = torch.full((B, L, nh * hd), float("nan"), device="cuda", dtype=torch.bfloat16)
+    ops.attention(q, out, B, L, nh, nh, hd, hd ** -0.5, causal, k_past=k, v_past=v, past_t=Tp, new_is_cache=True, q_prescaled=pre)
+    torch.cuda.synchronize(); outs.append(out.clone())
+ref = (torch.softmax((q.float() @ k[:, :, :L].float().transpose(-1, -2)) * hd ** -0.5, -1) @ v[:, :, :, :L].float().transpose(-1, -2)).transpose(1, 2).reshape(B, L, nh * hd)
+for r, o in enumerate(outs):
+    d = (o.view(torch.int16) != outs[0].view(torch.int16)).view(B, L, nh, hd)
+    err = (o.float() - ref).abs().max().item()
+    idx = d.any(-1).nonzero()
+    rows = collections.Counter((int(i[1]) // 32) for i in idx)
+    print(f"run {r}: max err vs fp32 {err:.4f}; differing (b,row,head) {len(idx)}; by 32-row wave slot: {dict(sorted(rows.items()))}; heads {sorted(set(int(i[2]) for i in idx))[:20]} rows sample {sorted(set(int(i[1]) for i in idx))[:12]}")
