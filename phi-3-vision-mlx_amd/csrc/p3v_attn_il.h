@@ -24,8 +24,9 @@
 // ONE barrier per tile instead of two, rings of 3 + 3 tiles (72 KB at head dim 96), one counted wait (vmcnt(NPW)) from the first
 // tile to the last: every wave issues its NPW pieces every iteration, tile numbers past the end refetch the last tile into a
 // free slot.  The first and last tile run the same code on neutral operands (P = 0, V = 0, S = -inf) instead of peeled copies.
-// Measured, B = 1, 32 heads x 96, causal (profiles/r03_attn_prefill_kernels.txt; interleaved with the ping-pong kernel in one
-// process): 2531 tokens 63 us (pp 73), 8k 373-383 us = 1077-1106 TF/s (pp 430), 32k 5.23-5.37 ms = 1229-1261 TF/s (pp 5.87-5.96).
+// Measured, B = 1, 32 heads x 96, causal (profiles/r03_attn_prefill_kernels.txt; alternated with the other kernels in one
+// process): 2531 tokens 50.7-56 us with 128-query workgroups (256-query: 57-63; pp 68-76; dma 65-73), 8k 371-391 us = 1055-1111 TF/s
+// (pp 430-465), 32k 5.15-5.42 ms = 1216-1281 TF/s (pp 5.83-6.17).
 // Where the rest goes (SQ counters, profiles/r03_pmc_prefill_attn.txt; timing experiments P3V_IL_NO*): the matrix stream
 // alone runs the 32k case in 3.84 ms, everything else alone in 3.75 ms, both in 5.39 ms -- half overlapped.  Per wave-tile
 // 2890 cycles: 880 parked (barrier: the first four waves arrive ~600 cycles early every tile), 900 issue stalls, 1100 issuing.
