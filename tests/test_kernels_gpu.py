@@ -205,6 +205,33 @@ def test_gemm_splitk_workspace_is_the_callers(ops, epi, M, N, K):
     assert torch.equal(out, eager)
 
 
+@pytest.mark.parametrize("M,N,K,epi", [(2531, 9216, 3072, "none"), (2531, 3072, 8192, "resid"), (2531, 8192, 3072, "silu"), (9809, 4096, 1024, "none"),
+                                       (300, 3072, 3072, "resid"), (1, 9216, 3072, "gemv"), (8, 3072, 8192, "gemv")])
+def test_matrix_kernels_are_deterministic(ops, M, N, K, epi):
+    """Ten launches of the prompt-sized GEMMs (both tile sizes, round packing, split-K) and of the skinny GEMVs on the same inputs
+    give the same bits.  (The attention kernels have their own, test_attention_prefill_kernels_are_deterministic: that is where
+    a launch-to-launch difference was once found.)"""
+    x = g((M, K), 70).cuda()
+    w = (g(((2 * N if epi == "silu" else N), K), 71) * 0.05).cuda()
+    res = g((M, N), 72).cuda()
+    first = None
+    for rep in range(10):
+        if epi == "gemv":
+            out = ops.gemv(x, w, ops.EPI_NONE)
+        elif epi == "resid":
+            out = ops.gemm(x, w, ops.EPI_RESID_BF16, resid=res)
+        elif epi == "silu":
+            out = ops.gemm(x, w, ops.EPI_SILU_MUL)
+        else:
+            out = ops.gemm(x, w, ops.EPI_NONE)
+        torch.cuda.synchronize()
+        if first is None:
+            first = out.clone()
+            assert torch.isfinite(first.float()).all()
+        else:
+            assert torch.equal(out.view(torch.int16), first.view(torch.int16)), f"launch {rep} differs"
+
+
 def test_gemm_asymmetric_identity(ops):
     """A = I against an asymmetric W: catches a transposed C write (guide rule 16)."""
     K = 128
