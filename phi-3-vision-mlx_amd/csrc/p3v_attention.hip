@@ -1209,8 +1209,8 @@ __global__ void __launch_bounds__(512, 1) k_attn_prefill_pp(AttnP p) {
 // Which prompt-sized kernel (measured, 32 heads x 96, causal, random data; profiles/r03_attn_prefill_kernels.txt; the table the
 // launcher's rules come from sits at the rules, in launch_attn_prefill):
 //   dma (128 queries, 4 waves, two workgroups per CU): every plain-Q call (the ViT, cached calls) below 3072 tokens, pre-scaled
-//       prompts of several rows up to ~4600 tokens -- since it got the deferred-reference softmax: 946 TF/s at 8k (round 2: 606-623);
-//   il  (interleaved; 128 or 256 queries): pre-scaled prompts -- ONE row from 768 tokens, several rows from ~4600, everything from 6144;
+//       prompts of several rows up to ~3500 tokens -- since it got the deferred-reference softmax: 946 TF/s at 8k (round 2: 606-623);
+//   il  (interleaved; 128 or 256 queries): pre-scaled prompts -- ONE row from 768 tokens, several rows from 3584, everything from 6144;
 //   pp  (ping-pong, 256 queries): what is left for it -- plain Q or head dim 64 from 3072 tokens.
 #include "p3v_attn_il.h"
 constexpr int P3V_ATTN_PP_MIN_L = 3072;                          // tools/attn_short_probe.py: dma / pp 65.2 / 67.5 us at 2531, 82.3 / 79.0 at 3072
@@ -1242,10 +1242,11 @@ static int launch_attn_prefill(const AttnP& p, hipStream_t s) {
     //   B = 1:  512: 15.9 / 16.4 / 22.2   768: 21.1 / 20.1 / 26.6   1280: 32.3 / 27.1 / 34.8   2531: 64.6 / 52.6 / 58.8
     //           3072: 81.4 / 74.6 / 69.5   4096: 119 / 114 / 108    8192: 436 / 403 / 377
     //   B = 2:  1280: 40.0 / 36.5 / 40.3   2531: 91.8 / 99.8 / 106   4096: 221 / 219 / 228   5120: 343 / 320 / 328
+    //   B = 4:  2531: 168 / 183 / 190      3072: 252 / 254 / 271   4096: 426 / 410 / 418   6144: 939 / 886 / 893   8192: 1614 / 1504 / 1477
     //   B = 8:  1280: 112 / 127 / 142      2531: 385 / 396 / 414
     // -> long prompts: 256-query workgroups (half the L2 -> LDS bytes per flop); ONE row of a few thousand tokens: 128-query
-    //    workgroups of the interleaved kernel (best balance, two workgroups per CU); several rows: the 128-query kernel.
-    const bool il_auto = p.L >= 6144 || (p.B == 1 ? p.L >= 768 : p.L >= 4608);
+    //    workgroups of the interleaved kernel (best balance, two workgroups per CU); several rows: the 128-query kernel up to ~3500 tokens.
+    const bool il_auto = p.L >= 6144 || (p.B == 1 ? p.L >= 768 : p.L >= 3584);
     if (p.q_prescaled && (il > 0 || (il < 0 && pp != 0 && il_auto))) {   // (pp = 0 pins the dma kernel)
       constexpr int LDS4 = 3 * 64 * HD * 2 + 3 * HD * 128;
       static bool attr4_set = false;

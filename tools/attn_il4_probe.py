@@ -18,8 +18,9 @@ def t(B, L, mode, nh=32, hd=96):
             for _ in range(20): f()
             b.record(); torch.cuda.synchronize(); ts[m].append(a.elapsed_ms(b) / 20 * 1e3)
     return {m: statistics.median(v) for m, v in ts.items()}
-for B in (1, 2, 8):
-    for L in (128, 256, 384, 512, 768, 1024, 1280, 2531, 3072, 4096, 5120):
-        if B == 8 and L > 2531: continue
+import sys
+CASES = [(int(a.split(":")[0]), int(a.split(":")[1])) for a in sys.argv[1:]] or [(B, L) for B in (1, 2, 8) for L in (128, 256, 384, 512, 768, 1024, 1280, 2531, 3072, 4096, 5120) if not (B == 8 and L > 2531)]
+for B, L in CASES:
+    if True:
         r = t(B, L, 0)
         print(f"B={B} L={L:5d}: dma {r['dma']:7.1f}   il4 {r['il4']:7.1f}   il8 {r['il8']:7.1f} us", flush=True)
