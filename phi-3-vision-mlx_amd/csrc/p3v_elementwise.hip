@@ -243,12 +243,12 @@ extern "C" int p3v_rope_table(const float* pos, const float* inv_freq, float sca
 // ---------------------------------------------------------------- split + RoPE + KV append
 // one block per token (b,l); work item = 8 consecutive dims of the low half paired with the
 // same 8 dims of the high half (q and k heads), or one 8-wide chunk of v.
-__global__ void __launch_bounds__(256) k_rope_kv_append(const bf16_t* __restrict__ qkv, const float* __restrict__ cos_t,
-                                                        const float* __restrict__ sin_t, bf16_t* __restrict__ q_out,
-                                                        bf16_t* __restrict__ k_dst, bf16_t* __restrict__ v_dst, int L,
-                                                        int nh, int nkv, int hd, int past, const int32_t* d_past,
-                                                        int dst_t, int dst_off_is_past, int tab_t, int tab_div, int skip_v, float q_scale) {
-  const int tok = blockIdx.x, b = tok / L, l = tok % L;
+__device__ __forceinline__ void rope_kv_append_token(int tok, const bf16_t* __restrict__ qkv, const float* __restrict__ cos_t,
+                                                    const float* __restrict__ sin_t, bf16_t* __restrict__ q_out,
+                                                    bf16_t* __restrict__ k_dst, bf16_t* __restrict__ v_dst, int L,
+                                                    int nh, int nkv, int hd, int past, const int32_t* d_past,
+                                                    int dst_t, int dst_off_is_past, int tab_t, int tab_div, int skip_v, float q_scale) {
+  const int b = tok / L, l = tok % L;
   if (d_past) past = *d_past;
   const int half = hd >> 1, hc = half >> 3;          // 8-wide chunks per half
   const int pos = past + l;
@@ -304,14 +304,23 @@ __global__ void __launch_bounds__(256) k_rope_kv_append(const bf16_t* __restrict
   }
 }
 
+__global__ void __launch_bounds__(256) k_rope_kv_append(const bf16_t* __restrict__ qkv, const float* __restrict__ cos_t,
+                                                        const float* __restrict__ sin_t, bf16_t* __restrict__ q_out,
+                                                        bf16_t* __restrict__ k_dst, bf16_t* __restrict__ v_dst, int L,
+                                                        int nh, int nkv, int hd, int past, const int32_t* d_past,
+                                                        int dst_t, int dst_off_is_past, int tab_t, int tab_div, int skip_v, float q_scale) {
+  rope_kv_append_token(blockIdx.x, qkv, cos_t, sin_t, q_out, k_dst, v_dst, L, nh, nkv, hd, past, d_past, dst_t, dst_off_is_past, tab_t,
+                       tab_div, skip_v, q_scale);
+}
+
 // V rows of 64 tokens x one kv head -> V^T columns, transposed through LDS so that both the qkv reads (192 B
 // per token) and the cache writes (128 B per d row) are full-line vector accesses.
-__global__ void __launch_bounds__(256) k_v_transpose_append(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ v_dst, int L,
-                                                            int nh, int nkv, int hd, int past, const int32_t* d_past,
-                                                            int dst_t, int dst_off_is_past) {
+__device__ __forceinline__ void v_transpose_append_tile(int xb, int head, int b, const bf16_t* __restrict__ qkv, bf16_t* __restrict__ v_dst,
+                                                        int L, int nh, int nkv, int hd, int past, const int32_t* d_past, int dst_t,
+                                                        int dst_off_is_past) {
   __shared__ __attribute__((aligned(16))) bf16_t tile[64 * (96 + 8)];
   const int ld = hd + 8, cpr = hd >> 3;
-  const int l0 = blockIdx.x * 64, head = blockIdx.y, b = blockIdx.z;
+  const int l0 = xb * 64;
   if (d_past) past = *d_past;
   const int row_w = (nh + 2 * nkv) * hd;
   for (int i = threadIdx.x; i < 64 * cpr; i += 256) {
@@ -342,6 +351,24 @@ __global__ void __launch_bounds__(256) k_v_transpose_append(const bf16_t* __rest
   }
 }
 
+// Prompt-sized calls: ONE launch for both -- the first B * L workgroups split / rotate one token each, the remaining
+// ceil(L / 64) * nkv * B transpose one 64-token V tile each (two launches before: a kernel boundary is ~2.4 us, and the two
+// memory streams overlap).
+__global__ void __launch_bounds__(256) k_rope_kv_vt(const bf16_t* __restrict__ qkv, const float* __restrict__ cos_t,
+                                                    const float* __restrict__ sin_t, bf16_t* __restrict__ q_out,
+                                                    bf16_t* __restrict__ k_dst, bf16_t* __restrict__ v_dst, int B, int L,
+                                                    int nh, int nkv, int hd, int past, const int32_t* d_past,
+                                                    int dst_t, int dst_off_is_past, int tab_t, int tab_div, float q_scale) {
+  const int n_tok = B * L;
+  if ((int)blockIdx.x < n_tok) {
+    rope_kv_append_token(blockIdx.x, qkv, cos_t, sin_t, q_out, k_dst, v_dst, L, nh, nkv, hd, past, d_past, dst_t, dst_off_is_past, tab_t,
+                         tab_div, 1, q_scale);
+  } else {
+    const int t = blockIdx.x - n_tok, nx = (L + 63) >> 6;
+    v_transpose_append_tile(t % nx, (t / nx) % nkv, t / (nx * nkv), qkv, v_dst, L, nh, nkv, hd, past, d_past, dst_t, dst_off_is_past);
+  }
+}
+
 extern "C" int p3v_rope_kv_append(const uint16_t* qkv, const float* cos_t, const float* sin_t, uint16_t* q_out,
                                   uint16_t* k_dst, uint16_t* v_dst, int B, int L, int n_heads, int n_kv, int hd, int past,
                                   const int32_t* d_past, int dst_t, int dst_off_is_past, int tab_t, int tab_div,
@@ -351,14 +378,14 @@ extern "C" int p3v_rope_kv_append(const uint16_t* qkv, const float* cos_t, const
   if (B < 0 || L < 0 || hd % 16 || hd > 96 || n_heads <= 0 || n_kv <= 0 || tab_div <= 0) return P3V_ERR_ARG;
   if (B * L == 0) return P3V_OK;
   const int bulk_v = L >= 32;                             // prefill-shaped: V goes through the LDS transpose kernel
-  hipLaunchKernelGGL(k_rope_kv_append, dim3(B * L), dim3(256), 0, (hipStream_t)stream, qkv, cos_t, sin_t, q_out, k_dst,
-                     v_dst, L, n_heads, n_kv, hd, past, d_past, dst_t, dst_off_is_past, tab_t, tab_div, bulk_v, q_scale);
-  P3V_CHECK_LAUNCH();
   if (bulk_v) {
-    hipLaunchKernelGGL(k_v_transpose_append, dim3(p3v_cdiv(L, 64), n_kv, B), dim3(256), 0, (hipStream_t)stream, qkv, v_dst, L,
-                       n_heads, n_kv, hd, past, d_past, dst_t, dst_off_is_past);
-    P3V_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_rope_kv_vt, dim3(B * L + p3v_cdiv(L, 64) * n_kv * B), dim3(256), 0, (hipStream_t)stream, qkv, cos_t, sin_t, q_out,
+                       k_dst, v_dst, B, L, n_heads, n_kv, hd, past, d_past, dst_t, dst_off_is_past, tab_t, tab_div, q_scale);
+  } else {
+    hipLaunchKernelGGL(k_rope_kv_append, dim3(B * L), dim3(256), 0, (hipStream_t)stream, qkv, cos_t, sin_t, q_out, k_dst,
+                       v_dst, L, n_heads, n_kv, hd, past, d_past, dst_t, dst_off_is_past, tab_t, tab_div, 0, q_scale);
   }
+  P3V_CHECK_LAUNCH();
   return P3V_OK;
 }
 
