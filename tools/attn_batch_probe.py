@@ -1,3 +1,4 @@
+"""dma / dma (pre-scaled) / interleaved kernel at the ViT's shape and at a few batched decoder shapes."""
 import sys, statistics, torch
 sys.path.insert(0, "/root/repo")
 from phi_3_vision_mlx_amd import ops

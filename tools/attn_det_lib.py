@@ -1,3 +1,5 @@
+"""Ten launches of the 128-query attention kernel at the ViT's shape with the library given as argv[1] (P3V_LIB): number of
+output words that differ from the first launch, per launch.  Used to bisect the non-deterministic plain-Q softmax (round 3)."""
 import sys, os, ctypes, torch
 sys.path.insert(0, "/root/repo")
 os.environ["P3V_LIB"] = sys.argv[1]

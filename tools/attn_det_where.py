@@ -1,3 +1,5 @@
+"""Where do launches of the 128-query kernel at the ViT's shape differ from the first one (which 32-row wave slots, heads, rows),
+and how far is each launch from the fp32 reference?  (round 3: whole 16-query halves, up to 0.8.)"""
 import sys, torch, collections
 sys.path.insert(0, "/root/repo")
 from phi_3_vision_mlx_amd import ops

@@ -1,3 +1,5 @@
+"""Five repeats of every prompt-sized attention kernel on the same inputs at five shapes: number of output words that differ from
+the first launch (must be 0; the test suite's version: test_attention_prefill_kernels_are_deterministic)."""
 import sys, torch
 sys.path.insert(0, "/root/repo")
 from phi_3_vision_mlx_amd import ops

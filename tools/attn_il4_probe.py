@@ -1,3 +1,5 @@
+"""The table behind the attention launcher's rules: 128-query kernel / interleaved kernel with 4 waves / with 8 waves, pre-scaled
+causal prompts, alternated in one process.  argv: B:L pairs (default: a sweep over B = 1, 2, 8)."""
 import os, sys, statistics
 sys.path.insert(0, "/root/repo")
 import torch

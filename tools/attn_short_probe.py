@@ -1,3 +1,4 @@
+"""dma / ping-pong / interleaved (8 waves) kernel over prompt lengths 512 .. 4096, B = 1, pinned and alternated."""
 import sys, os, statistics, torch
 sys.path.insert(0, "/root/repo")
 from phi_3_vision_mlx_amd import ops
