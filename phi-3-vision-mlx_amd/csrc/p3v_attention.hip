@@ -565,6 +565,12 @@ __global__ void __launch_bounds__(256, 2) k_attn_prefill_dma(AttnP p) {
       // the ViT moves the heavy-tailed fixtures' logit error by +-40 % (chaotic amplification, profiles/r03_heavy_tail.txt)
       // past tolerances calibrated on one implementation.
       if constexpr (PRE) {
+      // (the first readers of the S^T accumulators below are INLINE-ASM instructions: hipcc pads the MFMA -> reader wait states
+      //  -- 12 for this 8-pass MFMA, guide 5.7 item 2 -- only for instructions it emits itself.  Today ~70 instructions of mask
+      //  / interior arithmetic sit in between; the explicit pad keeps that from being an accident of the code layout.)
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_nop 7\n\ts_nop 4");
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         if (!interior) {
