@@ -160,7 +160,8 @@ int p3v_rope_table(const float* pos, const float* inv_freq, float scale, float* 
  * `d_past` (device int32, may be null) overrides `past` -- used under graph replay.
  * q_scale: rotated queries are multiplied by it BEFORE their one rounding to bf16 (phi.py:454 scales q before the
  * product too); 1.0f = plain.  With q_scale = scale * log2(e) the attention call takes q_prescaled = 1 and its softmax
- * needs no multiply per score.  Ignored (1.0) without rotation tables. */
+ * needs no multiply per score.  Applies to the plain head split as well (q = bf16(q * q_scale), bit for bit; the ViT path
+ * does not use it: tests only).  Prompt-sized calls (L >= 32) run the split / rotation and the V transpose as ONE launch. */
 int p3v_rope_kv_append(const uint16_t* qkv, const float* cos_t, const float* sin_t,
                        uint16_t* q_out, uint16_t* k_dst, uint16_t* v_dst,
                        int B, int L, int n_heads, int n_kv, int hd,
