@@ -16,7 +16,7 @@ th.start()
 reqs = []
 t0 = time.perf_counter()
 for i in range(n_req):
-    S = int(rng.choice([6, 20, 60, 150, 400, 900]))
+    S = int(rng.choice([6, 20, 60, 150, 400, 900, 1500, 2600]))   # 900+: the interleaved prompt kernel (one row per prefill group)
     ids = rng.integers(3, 32000, (1, S)).astype(np.int64)
     n = int(rng.integers(3, 40))
     reqs.append((ids, n, eng.submit({"input_ids": ids}, n)))
