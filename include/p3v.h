@@ -52,7 +52,8 @@ int p3v_get_tuning(const char* name /* host */, int* value /* host */);
 int p3v_embed_gather(const int32_t* ids, const uint16_t* table, uint16_t* out,
                      int n_tok, int hidden, int vocab, void* stream);
 
-/* ---- nn.RMSNorm, phi.py:478-479,571: y = x*rsqrt(mean(x^2)+eps)*w, bf16 io, fp32 math */
+/* ---- nn.RMSNorm (= mx.fast.rms_norm), phi.py:478-479,571: y = bf16(bf16(x*rsqrt(mean(x^2)+eps)) * w) -- fp32 statistics, the
+ *      normalised row is rounded to bf16 before the weight multiply (pinned by tests/golden/ref_model_tiny.npz) */
 int p3v_rmsnorm(const uint16_t* x, const uint16_t* w, uint16_t* y, int rows, int hidden, float eps, void* stream);
 
 /* ---- nn.LayerNorm, phi.py:165,167,212: fp32 in (ViT residual stream); bf16 out (feeds a
@@ -261,7 +262,8 @@ int p3v_hd_merge(const float* feats, const uint16_t* sub_gn, const uint16_t* glb
 
 /* ---- argmax over the last axis of bf16 logits (first maximum wins), phi_3_vision_mlx.py:386,392 */
 int p3v_argmax(const uint16_t* logits, int32_t* out, int rows, int n, int64_t row_stride, void* stream);
-/* ---- nn.log_softmax, phi_3_vision_mlx.py:92,476,511,541: bf16 io, fp32 math */
+/* ---- nn.log_softmax = x - logsumexp(x), phi_3_vision_mlx.py:92,476,511,541: bf16 io; the fp32 log-sum-exp is rounded to bf16
+ *      (it is an array of its own in the reference) and the subtraction rounds once more */
 int p3v_log_softmax(const uint16_t* x, uint16_t* y, int rows, int n, void* stream);
 /* ---- top-k (k<=8) by (-value, index), replaces mx.argpartition phi_3_vision_mlx.py:507 */
 int p3v_topk(const uint16_t* x, int32_t* idx_out, int rows, int n, int k, int64_t row_stride, void* stream);

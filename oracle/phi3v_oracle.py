@@ -47,10 +47,11 @@ def _linear(x, w, b=None):
 
 
 def rms_norm(x, w, eps):
-    """nn.RMSNorm (phi.py:478-479,571): fp32 internal, output in x.dtype."""
+    """nn.RMSNorm (phi.py:478-479,571) = mx.fast.rms_norm: fp32 statistics, the normalised row is rounded to x.dtype and
+    THEN multiplied by the weight in x.dtype -- `w * astype(x * rsqrt(mean(x^2) + eps), T)`, two roundings for bf16 x."""
     xf = x.to(F32)
-    y = xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + eps) * w.to(F32)
-    return y.to(x.dtype)
+    n = (xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + eps)).to(x.dtype)
+    return n * w.to(x.dtype)
 
 
 def layer_norm(x, w, b, eps):
@@ -342,8 +343,16 @@ ID_EOS = 32007
 
 
 def log_softmax(x):
-    """nn.log_softmax: fp32 internal, result in x.dtype."""
-    return torch.log_softmax(x.to(F32), dim=-1).to(x.dtype)
+    """nn.log_softmax(x) = x - mx.logsumexp(x, keepdims=True) (MLX's composite): the log-sum-exp is accumulated in fp32,
+    ROUNDED to x.dtype, and the subtraction rounds once more -- for bf16 logits every entry of a row carries the same
+    rounding of the normaliser (it cancels inside a row, not between rows)."""
+    lse = torch.logsumexp(x.to(F32), dim=-1, keepdim=True).to(x.dtype)
+    return x - lse
+
+
+def mean_last(x):
+    """mx.mean over the last axis (MLX's composite): sum (fp32 accumulate, rounded to x.dtype) * (1/n rounded to x.dtype)."""
+    return _sum_last(x) * torch.tensor(1.0 / x.shape[-1], dtype=x.dtype)
 
 
 def greedy_generate(model, dict_input, max_tokens, stop_on_eos=True):
@@ -444,7 +453,7 @@ def constrain_one(model, dict_input, constraint, id_constraint, use_beam=False, 
         s0 = logits[ar(arg_beam.shape[0])[:, None], beam_idx, arg_beam].reshape(-1)[:, None]
         s1 = bl[ar(bl.shape[0])[:, None], ar(beam.shape[1] - 1)[None, :], beam[:, 1:]]
         beam_score_all = torch.cat([s0, s1], dim=1)
-        mean = _div(_sum_last(beam_score_all), beam_score_all.shape[1])
+        mean = mean_last(beam_score_all)                                   # `_beam_score.mean(axis=1)` (:513)
         amax = torch.argmax(mean.reshape(-1, n_beam).to(F32), dim=-1)
         _note("beam_pick", _gap(mean.reshape(-1, n_beam)), arg_beam[ar(amax.shape[0]), amax])
         beam_token = arg_beam[ar(amax.shape[0]), amax]

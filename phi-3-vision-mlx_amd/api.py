@@ -392,6 +392,12 @@ def _div(x, n):
     return (x.float() / n).to(x.dtype)
 
 
+def _mean_last(x):
+    """`x.mean(axis=-1)` as MLX composes it: sum (rounded to x.dtype) times 1/n (rounded to x.dtype), rounded once more
+    (reference phi_3_vision_mlx.py:513 on bf16 scores; tests/golden/mlx_shim.py `mean`)."""
+    return _sum_last(x) * torch.tensor(1.0 / x.shape[-1], dtype=x.dtype)
+
+
 def _already(a2, a1):
     """reference phi_3_vision_mlx.py:495-498: 1 where the row does NOT yet end with a1."""
     if a2.shape[1] < a1.shape[0]:
@@ -443,7 +449,7 @@ def constrain_tokens(model, dict_input, constraint, id_constraint, use_beam=Fals
         s0 = lp[ar(Bn, device=dev)[:, None], beam_idx, arg_beam.to(dev)].cpu().reshape(-1)[:, None]
         s1 = pick(bl, ar(C_), beam[:, 1:])
         score_all = torch.cat([s0, s1], dim=1)
-        mean = _div(_sum_last(score_all), score_all.shape[1])
+        mean = _mean_last(score_all)
         am = torch.argmax(mean.reshape(-1, n_beam).float(), dim=-1)
         _note("beam_pick", arg_beam[ar(Bn), am])
         return token, arg_beam[ar(Bn), am], score_all.reshape(Bn, n_beam, -1)[ar(Bn), am]

@@ -39,6 +39,13 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
 __device__ __forceinline__ float bf16lo(uint32_t w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float bf16hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
 
+// nn.RMSNorm = mx.fast.rms_norm (phi.py:478-479, 571): w * astype(x * rsqrt(mean x^2 + eps), bf16) -- the normalised value is
+// rounded to bf16 BEFORE the weight multiply, which rounds again (HF's Phi3RMSNorm does the same).  One bf16 pair at a time.
+__device__ __forceinline__ uint32_t rms_pair(uint32_t x2, float r, uint32_t g2) {
+  const uint32_t n = pack_bf16x2(bf16lo(x2) * r, bf16hi(x2) * r);
+  return pack_bf16x2(bf16lo(n) * bf16lo(g2), bf16hi(n) * bf16hi(g2));
+}
+
 // cross-row all-reduce over the four 16-lane rows of a wave (lanes sharing lane & 15), on gfx950's
 // v_permlane{16,32}_swap: swap(x, x) leaves {row r, row r^1} pairs in the two results, so one max / add finishes a
 // butterfly step without the LDS crossbar latency of ds_bpermute.

@@ -46,7 +46,7 @@ __global__ void __launch_bounds__(256) k_rmsnorm(const u32x4_t* __restrict__ x, 
   for (int c = lane; c < chunks; c += 64) {
     u32x4_t v = xr[c], g = w[c], o;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) o[j] = pack_bf16x2(bf16lo(v[j]) * r * bf16lo(g[j]), bf16hi(v[j]) * r * bf16hi(g[j]));
+    for (int j = 0; j < 4; ++j) o[j] = rms_pair(v[j], r, g[j]);
     yr[c] = o;
   }
 }
@@ -82,7 +82,7 @@ __global__ void __launch_bounds__(256) k_rmsnorm_r(const u32x4_t* __restrict__ x
     if (c < chunks) {
       u32x4_t o;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) o[j] = pack_bf16x2(bf16lo(v[i][j]) * r * bf16lo(g[i][j]), bf16hi(v[i][j]) * r * bf16hi(g[i][j]));
+      for (int j = 0; j < 4; ++j) o[j] = rms_pair(v[i][j], r, g[i][j]);
       yr[c] = o;
     }
   }
@@ -580,7 +580,8 @@ __global__ void __launch_bounds__(1024) k_log_softmax(const bf16_t* __restrict__
   float s = 0.f;
   for (int i = threadIdx.x; i < n; i += blockDim.x) s += expf(bf16_to_f32(r[i]) - m);
   s = block_sum(s, red);
-  const float lse = m + logf(s);
+  // nn.log_softmax(x) = x - mx.logsumexp(x): the normaliser is itself a bf16 array before the subtraction rounds again
+  const float lse = bf16_round(m + logf(s));
   for (int i = threadIdx.x; i < n; i += blockDim.x) o[i] = f32_to_bf16(bf16_to_f32(r[i]) - lse);
 }
 

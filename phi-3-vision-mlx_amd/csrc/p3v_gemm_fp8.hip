@@ -351,7 +351,7 @@ __global__ void __launch_bounds__(256) k_quant_fp8_rows(const u32x4_t* __restric
     if (NORM && c < chunks) {
       const u32x4_t w = g[c];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) v[i][j] = pack_bf16x2(bf16lo(v[i][j]) * r * bf16lo(w[j]), bf16hi(v[i][j]) * r * bf16hi(w[j]));
+      for (int j = 0; j < 4; ++j) v[i][j] = rms_pair(v[i][j], r, w[j]);
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) amax = fmaxf(amax, fmaxf(fabsf(bf16lo(v[i][j])), fabsf(bf16hi(v[i][j]))));

@@ -44,7 +44,7 @@ __global__ void __launch_bounds__(256) k_gemv(GemvP p) {
         u32x4_t o;
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-          o[j] = pack_bf16x2(bf16lo(v[j]) * r * bf16lo(gw[j]), bf16hi(v[j]) * r * bf16hi(gw[j]));
+          o[j] = rms_pair(v[j], r, gw[j]);
         xs[m * chunks + c] = live ? o : (u32x4_t){0, 0, 0, 0};
       }
     } else {

@@ -103,7 +103,7 @@ __device__ __forceinline__ void gemv3_body(const GemvP& p, int units_per_wave, i
         if (p.norm_w) {
 #pragma unroll
           for (int j = 0; j < 4; ++j)
-            o[j] = pack_bf16x2(bf16lo(xv[m][k][j]) * r * bf16lo(gv[k][j]), bf16hi(xv[m][k][j]) * r * bf16hi(gv[k][j]));
+            o[j] = rms_pair(xv[m][k][j], r, gv[k][j]);
         }
         xs[m * CHUNKS + c] = m < p.M ? o : (u32x4_t){0, 0, 0, 0};
       }

@@ -103,7 +103,7 @@ __global__ void __launch_bounds__(256) k_gemv3_f8(GemvF8P p, int units_per_wave)
       if (p.norm_w) {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-          o[j] = pack_bf16x2(bf16lo(xv[k][j]) * r * bf16lo(gv[k][j]), bf16hi(xv[k][j]) * r * bf16hi(gv[k][j]));
+          o[j] = rms_pair(xv[k][j], r, gv[k][j]);
       }
       xs[c] = o;
     }
@@ -333,7 +333,7 @@ __global__ void __launch_bounds__(NW * 64) k_gemv_mfma8_f8(GemvF8P p) {
           u32x4_t o;
 #pragma unroll
           for (int j = 0; j < 4; ++j)
-            o[j] = pack_bf16x2(bf16lo(v[j]) * r * bf16lo(gv[k][j]), bf16hi(v[j]) * r * bf16hi(gv[k][j]));
+            o[j] = rms_pair(v[j], r, gv[k][j]);
           *px = o;
         }
       }

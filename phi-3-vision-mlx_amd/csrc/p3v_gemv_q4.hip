@@ -111,7 +111,7 @@ __global__ void __launch_bounds__(256) k_gemv3_q4(GemvQ4P p, int units_per_wave)
       if (p.norm_w) {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-          o[j] = pack_bf16x2(bf16lo(xv[k][j]) * r * bf16lo(gv[k][j]), bf16hi(xv[k][j]) * r * bf16hi(gv[k][j]));
+          o[j] = rms_pair(xv[k][j], r, gv[k][j]);
       }
       xs[c] = o;
     }

@@ -371,7 +371,7 @@ def argmax(logits2d, out=None):
 
 
 def log_softmax(x):
-    """nn.log_softmax over the last axis, bf16 in/out, fp32 math."""
+    """nn.log_softmax over the last axis: x - bf16(logsumexp(x)), rounded to bf16 (the reference's composite)."""
     _chk(x, BF16, "x")
     n = x.shape[-1]
     y = torch.empty_like(x)

@@ -1,0 +1,257 @@
+"""Golden vectors from the REFERENCE'S OWN model and loop code, executed over the functional MLX stand-in.
+
+Runs only in the build container (needs /root/reference; `ref_env.py` explains how it is imported and why nothing of it
+travels).  What executes is the reference's `_load` -> `Phi3VForCausalLM` / `Phi3ForCausalLM` (phi.py:135-617: CLIP tower, HD
+merge + projector + scatter, SuRoPE, KVCache incl. rewind and beam view, Mask4D, decoder) and its `_generate`,
+`_choose_from`, `_constrain` loops with its own processors (phi_3_vision_mlx.py:257-274, 376-409, 466-619; phi.py:228-372)
+on the TINY synthetic checkpoint (config.tiny_config_dict, weights.synth_weights: data, written to an HF-layout directory
+that the reference loads itself).  Output: `ref_model_tiny.npz` + `ref_model_tiny.json`, same layout as the oracle fixtures
+(per greedy step: token, full last-position logits as bf16 bits, clearance) so tests/test_model_gpu.py's `run_fixture`
+checks the HIP path against them unchanged, and tests/test_refmodel.py checks the oracle against them.
+
+The lm_head seeds are searched with the oracle (fast, replayable decode) so that every step is clear; the reference is then
+run under that head and the clearance is recomputed from ITS logits.
+
+    python tests/golden/gen_golden_refmodel.py
+"""
+import hashlib
+import json
+import os
+import shutil
+import sys
+import time
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+for p in (ROOT, os.path.join(ROOT, "oracle"), HERE):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+import phi3v_oracle as orc  # noqa: E402
+import ref_env  # noqa: E402
+from gen_golden_oracle import REL_TOL, SPREAD, Prefilled, bits, clearance, row_norms, search_head  # noqa: E402
+from golden_inputs import make_image  # noqa: E402
+from phi_3_vision_mlx_amd.config import make_config, tiny_config_dict  # noqa: E402
+from phi_3_vision_mlx_amd.processor import ByteTokenizer, Phi3FProcessor, Phi3VProcessor  # noqa: E402
+from phi_3_vision_mlx_amd.weights import peaked_lm_head, save_adapter, save_safetensors_dir, synth_weights  # noqa: E402
+
+TMP = os.environ.get("P3V_REF_TMP", "/tmp/p3v_refmodel")
+TINY_PROMPTS = ["<|user|>\nPick A or B.<|end|>\n<|assistant|>\n", "<|user|>\nName a colour of the sky.<|end|>\n<|assistant|>\n"]
+VIS_PROMPT = "<|user|>\n<|image_1|>\nWhat is shown?<|end|>\n<|assistant|>\n"
+VIS2_PROMPT = "<|user|>\n<|image_1|>\n<|image_2|>\nCompare the two.<|end|>\n<|assistant|>\n"
+LONG_PROMPT = "<|user|>\n" + ("the quick brown fox jumps over the lazy dog. " * 92) + "<|end|>\n<|assistant|>\n"     # > 4096 ids -> long factors
+CONSTRAINT = (3, " The answer is")
+IMAGES = {"sq": (336, 336, "noise", 0), "land": (640, 480, "smooth", 1)}
+LORA = dict(targets=["self_attn.qkv_proj", "mlp.down_proj"], layers=1, rank=2, alpha=4.0, scale=1.5)
+
+
+def img(name):
+    return make_image(*IMAGES[name])
+
+
+# name -> (blind?, prompt, image names, steps)
+CASES = {
+    "text": (True, TINY_PROMPTS[0], None, 8),
+    "batch": (True, TINY_PROMPTS, None, 6),
+    "long": (True, LONG_PROMPT, None, 3),
+    "vis": (False, VIS_PROMPT, ["sq"], 4),
+    "visns": (False, VIS_PROMPT, ["land"], 4),
+    "vis2": (False, VIS2_PROMPT, ["sq", "land"], 4),
+}
+
+
+class Ref:
+    """One reference model (blind or vision) loaded by the reference's `_load`, with a swappable lm_head."""
+
+    def __init__(self, blind, adapter_path=None):
+        self.blind = blind
+        self.d = tiny_config_dict(vision=not blind)
+        self.cfg = make_config(self.d)
+        self.w = synth_weights(self.cfg, seed=0, std_scale=4.0)
+        self.base = self.w["lm_head.weight"]
+        self.dir = os.path.join(TMP, "blind" if blind else "vision")
+        shutil.rmtree(self.dir, ignore_errors=True)
+        save_safetensors_dir(self.w, self.d, self.dir)
+        self.mx, self.phi, self.loops = ref_env.load_reference()
+        self.model, self.proc = ref_env.load_model(self.dir, ByteTokenizer(), clip_cfg=self.d.get("clip"), adapter_path=adapter_path)
+        self.oracle = orc.OraclePhi3V(self.cfg, dict(self.w), cache_fp32=True)
+        self.my_proc = (Phi3FProcessor if blind else Phi3VProcessor)(None)
+
+    def head(self, hs):
+        h = peaked_lm_head(self.base, SPREAD, int(hs))
+        self.model.lm_head.weight = self.mx.array(h)
+        self.oracle.w["lm_head.weight"] = h
+        self.oracle._f32.pop("lm_head.weight", None)
+        return h
+
+
+def as_t(a):
+    return a._t if hasattr(a, "_t") else torch.as_tensor(np.asarray(a))
+
+
+def generate_case(r, name, out, meta):
+    blind, prompt, images, n = CASES[name]
+    imgs = [img(i) for i in images] if images else None
+    # inputs from the REFERENCE's processor; the build's processor must produce the same model inputs
+    ref_in = r.proc(prompt, imgs)
+    my_in = r.my_proc(prompt, imgs) if imgs else r.my_proc(prompt)
+    ids = as_t(ref_in["input_ids"]).long()
+    assert torch.equal(ids, torch.as_tensor(np.asarray(my_in["input_ids"])).long()), f"{name}: processors disagree on input_ids"
+    # head seed: oracle search (every step clear), then the reference under that head
+    o_in = {k: (torch.from_numpy(np.asarray(v)) if k == "pixel_values" else v) for k, v in my_in.items()}
+    hs, _ = search_head([Prefilled(r.oracle, o_in, n)], r.base, n, min_distinct=2)
+    for attempt in range(20):
+        head = r.head(hs)
+        rec = ref_env.Recorder(r.model)
+        t0 = time.time()
+        texts = r.loops._generate(rec, r.proc, prompt, imgs, max_tokens=n, verbose=False, stream=False, mute=True)
+        lgs = torch.stack([c["logits"]._t[:, -1] for c in rec.calls], 1)                       # [B, n, V] bf16
+        toks = torch.argmax(lgs.float(), dim=-1)
+        fed = torch.cat([as_t(c["input_ids"]).long() for c in rec.calls[1:]], 1)
+        assert torch.equal(fed, toks[:, :-1]), f"{name}: the loop fed other tokens than its own argmax"
+        mg = clearance(lgs, row_norms(head), REL_TOL)
+        if mg.min().item() > 1.0 and lgs.shape[1] == n:
+            break
+        hs, _ = search_head([Prefilled(r.oracle, o_in, n)], r.base, n, min_distinct=2, first_seed=hs + 1)
+    else:
+        raise RuntimeError(f"{name}: no head seed is clear under the reference's logits")
+    out[name + "_head_seed"] = np.asarray([hs], dtype=np.int32)
+    out[name + "_tokens"] = toks.numpy().astype(np.int32)
+    out[name + "_logits_bf16"] = bits(lgs)
+    out[name + "_margins"] = mg.numpy().astype(np.float32)
+    out[name + "_input_ids"] = ids.numpy().astype(np.int32)
+    m = {"prompt_chars": len(prompt) if isinstance(prompt, str) else [len(p) for p in prompt], "S": int(ids.shape[1]), "steps": n,
+         "texts": texts, "images": images, "offset_after": int(rec.calls[-1]["offset"])}
+    if "pids" in ref_in:
+        out[name + "_pids"] = as_t(ref_in["pids"]).numpy().astype(np.int32)
+        out[name + "_mask"] = as_t(ref_in["mask"]).numpy().astype(np.int32)
+    if imgs:
+        pv = np.ascontiguousarray(np.asarray(as_t(ref_in["pixel_values"]).numpy(), dtype=np.float32))
+        m["pixel_values_f32_sha256"] = hashlib.sha256(pv.tobytes()).hexdigest()
+        m["image_sizes"] = as_t(ref_in["image_sizes"]).tolist()
+        pos = as_t(ref_in["positions"])
+        m["positions_first_last"] = [pos[0].tolist(), pos[-1].tolist()]
+        m["n_positions"] = int(pos.shape[0])
+    meta[name] = m
+    print(f"  {name}: S={ids.shape[1]} head_seed {hs} tokens {toks.tolist()} min clearance {mg.min().item():.2f} "
+          f"({time.time() - t0:.1f}s per reference run)", flush=True)
+
+
+def digest_calls(calls, idc):
+    """Compact record of every model call of a loop: the ids it was fed, its arguments, and per (row, position) the top-8
+    logits (values + ids), the fp32 log-sum-exp and the logits of the constraint ids -- what the loop's decisions read."""
+    L = max(as_t(c["input_ids"]).shape[1] for c in calls)
+    B = max(as_t(c["input_ids"]).shape[0] for c in calls)
+    n = len(calls)
+    ids = np.full((n, B, L), -1, dtype=np.int32)
+    args = np.zeros((n, 4), dtype=np.int32)                      # rows, L, advance_offset (-1 = None), n_beam
+    P = min(L, len(idc) + 1)
+    topv = np.zeros((n, B, P, 8), dtype=np.uint16)
+    topi = np.zeros((n, B, P, 8), dtype=np.int32)
+    lse = np.zeros((n, B, P), dtype=np.float32)
+    cons = np.zeros((n, B, P, len(idc)), dtype=np.uint16)
+    for k, c in enumerate(calls):
+        t = as_t(c["input_ids"]).long()
+        b, l = t.shape
+        ids[k, :b, :l] = t.numpy()
+        args[k] = (b, l, -1 if c["advance_offset"] is None else c["advance_offset"], c["n_beam"])
+        lg = c["logits"]._t                                          # [b, l, V]
+        lg = lg[:, -P:] if l > P else lg
+        v, i = torch.sort(lg.float(), dim=-1, descending=True, stable=True)
+        p = lg.shape[1]
+        topv[k, :b, :p] = bits(v[..., :8].to(torch.bfloat16))
+        topi[k, :b, :p] = i[..., :8].numpy()
+        lse[k, :b, :p] = torch.logsumexp(lg.float(), dim=-1).numpy()
+        cons[k, :b, :p] = bits(lg[..., torch.as_tensor(idc).long()])
+    return dict(ids=ids, args=args, topv=topv, topi=topi, lse=lse, cons=cons)
+
+
+def loops_case(r, out, meta):
+    """choose + constrain (plain / beam) through the reference's loops on the blind model."""
+    proc, my = r.proc, r.my_proc
+    idc = my.tokenizer.encode(CONSTRAINT[1], add_special_tokens=False)[1:]
+    opts = my([f" {c}" for c in "ABCDE"])["input_ids"][:, -1]
+    # a head under which the option pick of `choose` is clear (as tiny_oracle.npz's); the constrain loops' score comparisons
+    # are never clear in that sense (means of log-probabilities differ by ~2 % of max|logit|), so their decisions are recorded
+    # as they come: the oracle is bit-exact to this path on CPU, and the GPU test walks a live oracle's decisions.
+    oi = torch.as_tensor(opts).long()
+    for hs in range(4000):
+        head = r.head(hs)
+        lg, _ = r.oracle(**my(TINY_PROMPTS), max_tokens=0)
+        lf, nn_ = lg[:, -1].float(), row_norms(head)
+        v2, i2 = lf[:, oi].topk(2, dim=-1)
+        E = REL_TOL * (lf / nn_).abs().amax(-1)
+        m = ((v2[:, 0] - v2[:, 1]) / (E * (nn_[oi][i2[:, 0]] + nn_[oi][i2[:, 1]]))).min().item()
+        if m > 1.0:
+            break
+    else:
+        raise RuntimeError("no clear choose seed")
+    out["loops_head_seed"] = np.asarray([hs], dtype=np.int32)
+    out["loops_choose_clearance"] = np.asarray([m], dtype=np.float32)
+    meta["loops"] = {"head_seed": hs, "choose_clearance": m, "constraint": list(CONSTRAINT), "prompts": TINY_PROMPTS}
+    meta["loops"]["choose"] = r.loops._choose_from(r.model, proc, TINY_PROMPTS, "ABCDE", mute=True)
+    meta["loops"]["choose_single"] = r.loops._choose_from(r.model, proc, TINY_PROMPTS[1], "ABCDE", mute=True)
+    for ub in (False, True):
+        ps = TINY_PROMPTS if not ub else TINY_PROMPTS[:1] * 2
+        rec = ref_env.Recorder(r.model)
+        full = r.loops._constrain(rec, proc, list(ps), [CONSTRAINT], return_full_text=True, mute=True, use_beam=ub, verbose=False)
+        cont = r.loops._constrain(r.model, proc, list(ps), [CONSTRAINT, "AB"], mute=True, use_beam=ub, verbose=False)
+        meta["loops"][f"constrain_beam{int(ub)}"] = {"full_text": full, "with_choice": cont, "n_calls": len(rec.calls)}
+        for k, v in digest_calls(rec.calls, idc).items():
+            out[f"constrain_beam{int(ub)}_{k}"] = v
+        print(f"  constrain beam={ub}: {len(rec.calls)} model calls, texts {[t[-24:] for t in full]}", flush=True)
+    print(f"  loops: head_seed {hs}, choose clearance {m:.2f}, choose {meta['loops']['choose']}", flush=True)
+
+
+def lora_case(out, meta):
+    """The reference's adapter path: `_load(adapter_path=...)` -> `_linear_to_lora_layers` + `LoRALinear.__call__`
+    (phi_3_vision_mlx.py:234-245, 266-271; phi.py:96-133) on seeded lora_a / lora_b."""
+    d = tiny_config_dict(vision=False)
+    cfg = make_config(d)
+    g = torch.Generator().manual_seed(5)
+    n_layers = cfg.num_hidden_layers
+    shapes = {"self_attn.qkv_proj": (cfg.hidden_size, 3 * cfg.hidden_size), "mlp.down_proj": (cfg.intermediate_size, cfg.hidden_size)}
+    tensors = {}
+    for i in range(n_layers - LORA["layers"], n_layers):
+        for t in LORA["targets"]:
+            fi, fo = shapes[t]
+            tensors[f"model.layers.{i}.{t}.lora_a"] = (torch.randn(fi, LORA["rank"], generator=g) * 0.05).float()
+            tensors[f"model.layers.{i}.{t}.lora_b"] = (torch.randn(LORA["rank"], fo, generator=g) * 0.05).float()
+    ad = os.path.join(TMP, "adapter")
+    shutil.rmtree(ad, ignore_errors=True)
+    lcfg = {"model_path": os.path.join(TMP, "blind"), "adapter_path": ad, "lora_layers": LORA["layers"], "lora_targets": LORA["targets"],
+            "lora_parameters": {"rank": LORA["rank"], "alpha": LORA["alpha"], "dropout": 0.0, "scale": LORA["scale"]}}
+    save_adapter(ad, lcfg, tensors)
+    r = Ref(True, adapter_path=ad)
+    from phi_3_vision_mlx_amd.weights import load_adapter, resolve_adapter
+    r.oracle.adapters = resolve_adapter(cfg, *load_adapter(ad))
+    for k, v in tensors.items():
+        out["lora_" + k.replace(".", "__")] = v.numpy()
+    meta["lora_adapter"] = {k: v for k, v in lcfg.items() if k not in ("model_path", "adapter_path")}
+    CASES["lora"] = (True, TINY_PROMPTS[1], None, 4)
+    generate_case(r, "lora", out, meta)
+
+
+def main():
+    t0 = time.time()
+    os.makedirs(TMP, exist_ok=True)
+    out = dict(rel_tol=np.asarray([REL_TOL], dtype=np.float32), spread=np.asarray([SPREAD], dtype=np.float32))
+    meta = {"generator": "tests/golden/gen_golden_refmodel.py", "reference": "phi.py + phi_3_vision_mlx.py over tests/golden/mlx_shim.py"}
+    rb = Ref(True)
+    for name in ("text", "batch", "long"):
+        generate_case(rb, name, out, meta)
+    loops_case(rb, out, meta)
+    rv = Ref(False)
+    for name in ("vis", "visns", "vis2"):
+        generate_case(rv, name, out, meta)
+    lora_case(out, meta)
+    np.savez_compressed(os.path.join(HERE, "ref_model_tiny.npz"), **out)
+    with open(os.path.join(HERE, "ref_model_tiny.json"), "w") as f:
+        json.dump(meta, f, indent=1)
+    print(f"wrote ref_model_tiny.npz/.json in {time.time() - t0:.0f}s")
+
+
+if __name__ == "__main__":
+    main()
