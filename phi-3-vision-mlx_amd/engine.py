@@ -168,9 +168,13 @@ class ContinuousEngine:
         self.waiting = collections.deque(r for r in self.waiting if not r.cancelled)
         if not self.waiting:
             return [], []
-        if not self._active():                                  # idle: the column follows the OLDEST waiting prompts
+        if not self._active():
+            # idle: the column follows the OLDEST waiting prompts -- but never so far right that the HEAD request no longer
+            # fits (column + its max_tokens <= window).  The head itself always qualifies (`accepts`), so an idle engine
+            # admits at least the head: a blocked / draining head cannot keep everybody out for ever.
             first = list(self.waiting)[:self.slots]
-            st.offset = max(r.S for r in first)
+            head = first[0]
+            st.offset = max(r.S for r in first if r.S == head.S or r.S + head.max_tokens <= self.window)
         free = [i for i, r in enumerate(self.rows) if r is None]
         admit, keep, draining = [], collections.deque(), False
         for r in self.waiting:

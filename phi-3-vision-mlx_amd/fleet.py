@@ -21,10 +21,19 @@ from .engine import Request, _generate_text
 _ERRORS = {"ValueError": ValueError, "TimeoutError": TimeoutError, "TypeError": TypeError}   # what the HTTP handler tells apart
 
 
-def make_groups():
-    """(rank 0 -> workers, workers -> rank 0): two gloo groups over all ranks.  Collective: every rank calls it once."""
+IDLE_TIMEOUT_DAYS = 3650      # a server may sit idle for any length of time: a blocking recv must not expire (gloo's default: 30 min)
+
+
+def make_groups(timeout=None):
+    """(rank 0 -> workers, workers -> rank 0): two gloo groups over all ranks.  Collective: every rank calls it once.
+    The groups carry blocking point-to-point receives that wait for the NEXT REQUEST, so their timeout is "never": gloo tears
+    the pair down when a receive times out (the next send fails with "Connection closed by peer" -- measured, so a timeout
+    cannot be caught and retried), while a peer that really dies still surfaces at once as a closed connection."""
+    import datetime
+
     import torch.distributed as dist
-    return dist.new_group(backend="gloo"), dist.new_group(backend="gloo")
+    timeout = timeout or datetime.timedelta(days=IDLE_TIMEOUT_DAYS)
+    return dist.new_group(backend="gloo", timeout=timeout), dist.new_group(backend="gloo", timeout=timeout)
 
 
 def _send(obj, dst, group):
@@ -68,9 +77,9 @@ class EngineFleet:
             t.start()
 
     # ---- request side (any thread)
-    def _send_to(self, rank, msg):
+    def _send_to(self, rank, msg, force=False):
         with self.send_locks[rank]:
-            if not self.closed:
+            if force or not self.closed:
                 _send(msg, rank, self.down)
 
     def submit(self, inputs, max_tokens):
@@ -142,9 +151,14 @@ class EngineFleet:
 
     def close(self, timeout=10.0):
         """Tell every worker to stop (each answers "bye" once its engine thread is down)."""
+        self.closed = True                                       # first: nothing new goes out, a failing stop cannot leave us open
         for r in range(1, self.world):
-            self._send_to(r, ("stop",))
-        self.closed = True
+            if self.load[r] >= 1 << 30:                          # already known dead
+                continue
+            try:
+                self._send_to(r, ("stop",), force=True)
+            except Exception:                                    # noqa: BLE001  a dead peer: its receiver thread has failed its requests
+                pass
         for t in self.receivers:
             t.join(timeout)
 
@@ -169,7 +183,8 @@ def worker(engine, groups, poll_s=0.002):
                 err = None if h.error is None else (type(h.error).__name__, str(h.error))
                 _send(("done", rid, [int(t) for t in h.tokens], err), 0, up)
             if closing.is_set() and idle and not done:
-                return
+                _send(("bye",), 0, up)                            # from THIS thread: the only sender on `up`, so the size / payload
+                return                                           # pairs of two messages can never interleave
             if not done:
                 time.sleep(poll_s)
 
@@ -196,5 +211,4 @@ def worker(engine, groups, poll_s=0.002):
         if not h.done.is_set():
             h.fail(RuntimeError("worker stopped"))
     closing.set()
-    reporter.join(10.0)
-    _send(("bye",), 0, up)
+    reporter.join()

@@ -552,12 +552,14 @@ class Phi3VModel:
             self._proj(g["x"], "lm_head.weight", norm_w=w["model.norm.weight"], out=g["logits"])
             ops.step_end(g["logits"], g["next_tok"], g["tok"], g["history"], g["d_step"], g["d_past"], g["ticket"])
         g["d_past"].fill_(st.offset)
-        step()                                                   # warm-up run (sets func attributes, pages code in)
+        g["gemm_ws"] = {}                                        # B > 16 rows: the projections are split-K GEMMs; their workspace
+        with ops.owned_gemm_workspace(g["gemm_ws"], frozen=False):   # belongs to the graph (sized here, baked in below)
+            step()                                               # warm-up run (sets func attributes, pages code in)
         torch.cuda.synchronize()
         graph = ops.Graph()
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
+        with torch.cuda.stream(side), ops.owned_gemm_workspace(g["gemm_ws"], frozen=True):
             graph.begin()
             step()
             graph.end()

@@ -4,6 +4,7 @@ torch is used for device memory and the current stream only; every function
 here launches a hand-written gfx950 kernel from ``csrc/`` and nothing else.
 Each op names the MLX call site of the reference it replaces.
 """
+import contextlib
 import ctypes as C
 
 import torch
@@ -72,9 +73,36 @@ def set_tuning(name, value):
 _gemm_ws = {}     # (device index, stream handle) -> grow-only byte buffer for p3v_gemm's split-K partials
 
 
+_ws_owner = None     # (holder dict, frozen?) while a hipGraph is being built: the GRAPH owns its split-K workspace
+
+
+@contextlib.contextmanager
+def owned_gemm_workspace(holder, frozen):
+    """Route every split-K workspace request inside the block to `holder["buf"]` (a dict the caller keeps alive as long as the
+    graph).  frozen=False (the warm-up run): the buffer is allocated / grown as needed.  frozen=True (the capture): no allocation
+    may happen under hipStreamBeginCapture, and the pointer is baked into the graph -- a request the warm-up did not size
+    raises instead.  (the per-(device, stream) buffer below was first allocated on the capture's side stream,
+    i.e. under capture, and a later regrow would have freed what the graph still writes to.)"""
+    global _ws_owner
+    prev, _ws_owner = _ws_owner, (holder, frozen)
+    try:
+        yield holder
+    finally:
+        _ws_owner = prev
+
+
 def _gemm_workspace(device, nbytes):
     """The library never allocates (include/p3v.h): the caller owns the split-K workspace.  One grow-only torch buffer per
     (device, stream): it is live only between the two launches of one p3v_gemm call, so launches on one stream share it."""
+    if _ws_owner is not None:
+        holder, frozen = _ws_owner
+        buf = holder.get("buf")
+        if buf is None or buf.numel() < nbytes:
+            if frozen:
+                raise RuntimeError(f"split-K workspace of {nbytes} bytes requested under graph capture (warm-up sized "
+                                   f"{0 if buf is None else buf.numel()})")
+            buf = holder["buf"] = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        return buf
     key = (device.index, _stream())
     buf = _gemm_ws.get(key)
     if buf is None or buf.numel() < nbytes:

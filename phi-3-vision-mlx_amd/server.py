@@ -344,6 +344,11 @@ if __name__ == "__main__":
     ap.add_argument("--image-host", action="append", default=[], help="allow `images` URLs on this host (repeatable)")
     a = ap.parse_args()
     if int(os.environ.get("WORLD_SIZE", "1")) > 1:               # python -m torch.distributed.run --nproc-per-node N -m ...server --continuous
+        if not a.continuous:
+            # the one-shot paths have no worker loop: every rank would bind the same port and rank 0's batches would wait in
+            # generate_sharded for ranks that never join
+            ap.error("WORLD_SIZE > 1 needs --continuous (one engine per rank, rank 0 serves HTTP); "
+                     "for one-shot batch sharding call dist.generate_sharded from a torchrun script instead")
         import torch
         import torch.distributed as dist
         if torch.cuda.is_available():

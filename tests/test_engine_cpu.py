@@ -237,3 +237,23 @@ def test_regime_router_sends_each_request_to_its_own_rope_regime():
     assert b.error is None and len(b.tokens) > 0 and long_.steps > 0
     direct = short.submit(req(4090, 2), 50)                 # the wrong engine refuses instead of silently using short factors
     assert isinstance(direct.error, ValueError)
+
+
+def test_idle_engine_always_admits_the_head_request():
+    """a head request that needs nearly the whole window (small prompt, huge max_tokens) next to a
+    longer prompt.  Once the engine is idle the column must be set so that the HEAD fits -- before the fix it followed the
+    longest of the oldest waiters, the head stayed blocked, draining kept everybody else out and `steps` stopped."""
+    m = SlotStub()
+    e = ContinuousEngine(m, None, slots=2, window=4096, patience=5)
+    a = e.submit(req(10, 1), 4000)                           # fits only with the column at <= 96
+    c = e.submit(req(500, 2), 12)
+    for _ in range(8):
+        e.step()
+    late = e.submit(req(400, 3), 5)
+    for _ in range(6000):
+        if a.done.is_set() and c.done.is_set() and late.done.is_set():
+            break
+        e.step()
+    for r, (inp, mt) in ((a, (req(10, 1), 4000)), (c, (req(500, 2), 12)), (late, (req(400, 3), 5))):
+        assert r.done.is_set() and r.error is None
+        assert r.tokens == solo(inp, mt)

@@ -35,7 +35,9 @@ def _worker(rank, world, port, out_dir):
     from phi_3_vision_mlx_amd import fleet
     from phi_3_vision_mlx_amd.engine import ContinuousEngine
     eng = ContinuousEngine(SlotStub(), None, slots=2, window=4096)
-    groups = fleet.make_groups()
+    import time
+    assert fleet.IDLE_TIMEOUT_DAYS >= 365      # blocking recvs wait for the next request -- they must never expire
+    groups = fleet.make_groups()               # (gloo closes the pair on a recv timeout: it cannot be caught and retried)
     if rank:
         fleet.worker(eng, groups)
         open(os.path.join(out_dir, f"worker{rank}"), "w").write("ok")
@@ -47,6 +49,7 @@ def _worker(rank, world, port, out_dir):
     stepper.start()
     # 9 requests of different lengths and budgets, submitted at once: spread over the ranks by outstanding load (ties to the
     # lowest rank; a rank that finishes early gets more)
+    time.sleep(1.0)          # an idle spell before the first request
     shapes = [(20 + 7 * i, 5 + (i % 4)) for i in range(9)]
     hs = [front.submit(_req(n, 100 + i), m) for i, (n, m) in enumerate(shapes)]
     assert all(h.done.wait(60) for h in hs) and all(h.error is None for h in hs), [h.error for h in hs]
