@@ -13,12 +13,16 @@ barriers, the max-over-ranks of the timed span and the token gather.
 A "step" = one greedy decode step (one new token per sequence) through the
 same graph-replayed path `generate()` uses; timing definitions follow the
 reference (phi_3_vision_mlx.py:384-403): prefill = first `model(**inputs)` +
-argmax + sync, timer started AFTER preprocessing.  `value` is the device rate
-(K graph replays between two syncs); `generate_loop` is the same K steps through
-`_generate`'s own loop (per-token D2H copy + Streamer + TokenStopper, :390-400).
+argmax + sync, timer started AFTER preprocessing.
 Synthetic data: seeded random weights of the real architecture, one seeded
 random 336x336 image (-> 1344x1344 HD, 17 crops, 2509 image tokens) + 20
 random text tokens.  Prints ONE JSON line on rank 0.
+
+`value` is the REFERENCE-DEFINED rate: (gen_len - 1) / gen_time over the K timed steps through `_generate`'s own loop
+(per-token D2H copy = the reference's mx.eval, Streamer, TokenStopper, detokenisation; phi_3_vision_mlx.py:390-403);
+`device_rate` is the same K steps as back-to-back graph replays between two syncs (what the kernels sustain).
+At N = 1 the line also carries `configs`: BASELINE configs[0], [2], [3] (one GPU's share) and [4] measured in the same
+process with the same definitions, each with its own roofline fractions (`--no-configs` skips them).
 """
 import argparse
 import json
@@ -40,6 +44,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--prefill-reps", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-configs", action="store_true", help="skip the `configs` object (the other BASELINE configs, N = 1 only)")
+    ap.add_argument("--configs-steps", type=int, default=32, help="timed decode steps per entry of `configs`")
     ap.add_argument("--config4", action="store_true", help="BASELINE configs[3]: 8 mixed image+text requests per GPU, batched (B = 8)")
     ap.add_argument("--config5", action="store_true", help="BASELINE configs[4]: fp8 (e4m3) weights, W8A8 prefill on the fp8 MFMA, int8 KV cache")
     ap.add_argument("--fp8-weight-only", action="store_true", help="with --config5: fp8_activations=False (dequantise + bf16 MFMA prefill)")
@@ -73,13 +79,13 @@ def usable_cores(cap=64):
     return max(1, min(n, cap))
 
 
-def cpu_baseline(model, n_decode=32, runs=1, warm_decode=2):
+def cpu_baseline(model, n_decode=32, runs=3, warm_decode=2):
     """the CPU oracle (torch-CPU restatement of phi.py, kind "port") on BASELINE config 1 --
     text-only, 128-token prompt, greedy, ALL layers -- on this box's host cores: one warm-up pass (prefill + `warm_decode`
     steps), then `runs` timed passes of prefill + `n_decode` decode steps (median); prefill ms and decode tokens/s with the
     reference's definitions (phi_3_vision_mlx.py:384-403).  BOUNDED sample of the 128 new tokens BASELINE.md names: 32 steps
-    at ~1.8 tok/s is ~20 s of CPU work, and a decode step's cost is flat in the step index at this context (weights
-    dominate).  Baseline only -- never on the product path."""
+    per pass at ~1.7 tok/s (3 passes ~ 60 s of CPU work in all); a decode step's cost is flat in the step index at this
+    context (weights dominate).  Baseline only -- never on the product path."""
     import numpy as np
     import torch
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -146,6 +152,122 @@ def prefill_flops(cfg, S, n_img_tokens, n_crops):
         vit = (c["num_hidden_layers"] - 1) * (2.0 * T * (4 * D * D + 2 * D * DI) + 4.0 * T * T * D) + 2.0 * (T - 1) * 3 * P * P * D
         f += n_crops * vit + 2.0 * n_img_tokens * (4 * cfg.img_processor["image_dim_out"] * H + H * H)
     return f
+
+
+def decode_bytes(model, cfg, valid_tokens, B, steps_done, kv_elt):
+    """Algorithmic HBM bytes of one decode step: every decoder + lm_head weight once (in its storage format) +
+    the K / V rows of every live position."""
+    hd = cfg.hidden_size // cfg.num_attention_heads
+    kv = 2 * cfg.num_hidden_layers * cfg.num_key_value_heads * hd * kv_elt * (valid_tokens + B * steps_done)
+    w = sum(v.numel() * 2 for k, v in model.w.items() if k.startswith("model.layers.") or k == "lm_head.weight") \
+        + sum(v[0].numel() for v in model.w8.values())
+    return w + kv
+
+
+def measure_request_set(model, processor, reqs, steps, warmup, prefill_reps, kv_elt=2):
+    """One entry of `configs` (single GPU): `reqs` = B = 1 model inputs; prefill (median of `prefill_reps` after one warm-up;
+    several requests: the length-bucketed batch prefill of dist.prefill_requests) + `steps` timed greedy steps twice -- through
+    `_generate`'s loop (reference-defined rate) and as bare graph replays (device rate).  Definitions as the headline's."""
+    import numpy as np
+    import torch
+    from phi_3_vision_mlx_amd import api, ops
+    from phi_3_vision_mlx_amd.dist import prefill_requests
+    cfg = model.cfg
+    B = len(reqs)
+    max_tokens = 2 * (warmup + steps) + 8
+    pms = []
+    for rep in range(prefill_reps + 1):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        if B > 1:
+            token, cache, _ = prefill_requests(model, reqs, max_tokens)
+        else:
+            logits, cache = model(**reqs[0], max_tokens=max_tokens)
+            token = ops.argmax(logits[:, -1, :].contiguous())[:, None]
+        first = token.tolist()
+        if rep:
+            pms.append((time.perf_counter() - t0) * 1e3)
+        if rep < prefill_reps:
+            del cache
+    prefill = float(np.median(pms))
+    for _ in range(warmup):
+        _, token = model.greedy_step(token, cache)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        _, token = model.greedy_step(token, cache)
+    torch.cuda.synchronize()
+    dev_s = (time.perf_counter() - t0) / steps
+    streamer, stopper = api.Streamer(processor, False, True), api.TokenStopper(processor, B)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    streamer(api._rows(token))
+    for _ in range(steps):
+        _, token = model.greedy_step(token, cache)
+        rows = api._rows(token)
+        streamer(rows)
+        if stopper(rows):
+            break
+    _, gen_len = streamer.end()
+    torch.cuda.synchronize()
+    gen_s = time.perf_counter() - t0
+    lens = [int(np.asarray(r["input_ids"]).shape[-1]) for r in reqs]
+    valid = sum(lens)
+    nbytes = decode_bytes(model, cfg, valid, B, warmup + steps // 2, kv_elt)
+    flops = 0.0
+    for r in reqs:
+        ids = np.asarray(r["input_ids"])
+        n_img = int((ids < 0).sum())
+        n_crops = int(sum(h * w + 1 for h, w in (np.asarray(r["image_sizes"]) // 336).tolist())) if "image_sizes" in r else 0
+        flops += prefill_flops(cfg, ids.shape[-1], n_img, n_crops)
+    del cache
+    return {
+        "batch": B, "prompt_tokens": lens if B > 1 else lens[0], "steps": steps, "prefill_ms": round(prefill, 3),
+        "decode_tokens_per_s": round((gen_len - 1) / gen_s, 2), "device_tokens_per_s": round(B / dev_s, 2),
+        "ms_per_step": round(dev_s * 1e3, 4), "first_token": first,
+        "roofline_decode": {"bound": "hbm", "algorithmic_GB_per_step": round(nbytes / 1e9, 3), "achieved": round(nbytes / dev_s / 1e9, 1),
+                            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(nbytes / dev_s / 1e9 / HBM_PEAK_GBS, 4)},
+        "roofline_prefill": {"bound": "mfma", "algorithmic_TFLOP": round(flops / 1e12, 2), "achieved": round(flops / (prefill * 1e-3) / 1e12, 1),
+                             "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(flops / (prefill * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4)},
+    }
+
+
+def other_configs(model, processor, dev, args):
+    """BASELINE.json configs[0], [2], [3] (one GPU's share) and [4] on this GPU, driver-timed inside the default run."""
+    import numpy as np
+    import torch
+    from phi_3_vision_mlx_amd.api import load_synthetic
+    from phi_3_vision_mlx_amd.workloads import c4_share, vqa_request
+    ip = processor.img_processor
+    K, W = args.configs_steps, 4
+    rng = np.random.default_rng(0)
+    out = {}
+    t_all = time.perf_counter()
+    # configs[0]: text-only, 128-token prompt (the CPU reference's case; same decoder weights as the blind model)
+    ids = rng.integers(3, 32000, (1, 128)).astype(np.int64)
+    out["c1_text_128"] = dict(measure_request_set(model, processor, [{"input_ids": ids}], max(K, 64), W, 3),
+                              workload="BASELINE configs[0]: text-only greedy, 128-token prompt, B=1")
+    # configs[2]: 32k-token long-context prefill + decode (long RoPE factors)
+    S3 = 5000 if args.tiny else 32768
+    ids = np.random.default_rng(4).integers(3, 32000, (1, S3)).astype(np.int64)
+    out["c3_long_32k"] = dict(measure_request_set(model, processor, [{"input_ids": ids}], K, W, 2),
+                              workload=f"BASELINE configs[2]: {S3}-token text prompt (Su/LongRoPE long factors), prefill + decode at that context, B=1")
+    torch.cuda.empty_cache()
+    # configs[3]: one GPU's share of the 64-request mixed batch: 4 single-image VQA + 4 text prompts as one B = 8 decode batch
+    reqs = c4_share(ip, 0, device=dev)
+    out["c4_share_b8"] = dict(measure_request_set(model, processor, reqs, K, W, 2),
+                              workload="BASELINE configs[3], one GPU's share (8 of 64 requests): 4 single-image VQA (2531 tokens) + 4 text "
+                                       "prompts (16..256 tokens), length-bucketed prefill, one B=8 decode batch; x8 GPUs = the config")
+    # configs[4]: fp8 weights (W8A8 prompt projections on the fp8 MFMA) + int8 KV on the headline request
+    m5, p5 = load_synthetic(blind_model=False, tiny=args.tiny, seed=0, device=dev, quantized_fp8=True, use_quantized_cache=True)
+    r5 = measure_request_set(m5, p5, [vqa_request(p5.img_processor, 0, device=dev)], max(K, 64), W, 3, kv_elt=1)
+    r5["roofline_prefill"]["peak_note"] = "bf16 dense peak; the decoder projections run on the fp8 MFMA (2x that peak), the ViT stays bf16"
+    out["c5_fp8_int8kv"] = dict(r5, workload="BASELINE configs[4]: configs[1]'s request with e4m3 decoder weights (per-row scales), e4m3 "
+                                           "prompt activations (fp8 MFMA), int8 KV cache", dtype="fp8(e4m3)+int8kv")
+    del m5
+    torch.cuda.empty_cache()
+    out["seconds"] = round(time.perf_counter() - t_all, 1)
+    return out
 
 
 def main():
@@ -267,6 +389,7 @@ def main():
         if stopper(rows):                                         # EOS (32007) from random weights: not expected
             break
     _, gen_len = streamer.end()
+    barrier()
     gen_elapsed = time.perf_counter() - t0
     gen_tps = (gen_len - 1) / gen_elapsed
     if world > 1:
@@ -278,7 +401,15 @@ def main():
         hist = hist.cpu() if share else hist
         gathered = [torch.empty_like(hist) for _ in range(world)] if rank == 0 else None
         dist.gather(hist, gathered, dst=0)                        # token gather over RCCL (request boundary only)
-    tokens_per_s = world * B * args.steps / elapsed
+    tokens_per_s = world * B * args.steps / elapsed                # device rate: K graph replays between two syncs
+    rccl = None
+    if world > 1:                                                 # how many ranks really joined, counted on DEVICE tensors over RCCL
+        one = torch.ones(1, device="cpu" if share else dev)
+        dist.all_reduce(one)
+        per_rank = [torch.zeros(1, device="cpu" if share else dev) for _ in range(world)]
+        dist.all_gather(per_rank, torch.tensor([B * args.steps / elapsed], device="cpu" if share else dev))
+        rccl = {"backend": dist.get_backend(), "ranks": int(one.item()), "world_size": dist.get_world_size(),
+                "per_rank_tokens_per_s": [round(float(t.item()), 2) for t in per_rank]}
 
     # ---- roofline of the dominant decode kernel (gate_up GEMV + fused RMSNorm + SiLU*up): the 32 layers' launches
     #      replayed as one hipGraph on the launch stream (exactly the launches of a B = 1 decode step, weights of every
@@ -352,15 +483,19 @@ def main():
         metric = metric.replace("bf16", "fp8 weights + int8 KV")
     out = {
         "metric": metric,
-        "value": round(tokens_per_s, 2), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(step_s * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "value": round(world * gen_tps, 2), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(gen_elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "value_definition": "reference-defined rate: (gen_len - 1) / gen_time over the K timed steps through _generate's loop -- per-token "
+                            "D2H copy (the reference's mx.eval), Streamer, TokenStopper, detokenisation (phi_3_vision_mlx.py:390-403); "
+                            "whole-job aggregate = n_gpus x the slowest rank's rate",
+        "device_rate": {"tokens_per_s": round(tokens_per_s, 2), "ms_per_step": round(step_s * 1e3, 4),
+                        "definition": "the same K steps as back-to-back graph replays between two syncs (no per-token host work)"},
+        "rccl": rccl,
         "dtype": "fp8(e4m3)+int8kv" if args.config5 else "bf16", "data": "synthetic",
         "config": {"workload": workload, "parallelism": f"batch-sharded replicas x{world}", "batch_per_gpu": int(B), "tiny": bool(args.tiny)},
         "prefill_ms": round(prefill, 3), "prefill_tokens": int(valid), "preprocess_ms": round(host_pre_ms, 1),
         "preprocess": "host" if host_pre else "device",
-        "generate_loop": {"tokens_per_s": round(world * gen_tps, 2), "definition": "(gen_len - 1) / gen_time over the same steps through "
-                          "_generate's loop: per-token D2H copy + Streamer + TokenStopper + detokenisation (phi_3_vision_mlx.py:390-403)"},
-        "decode_step_hbm": {"algorithmic_GB_per_token": round((w_bytes + kv_bytes) / 1e9, 3),
+        "decode_step_hbm": {"span": "device-rate step", "algorithmic_GB_per_token": round((w_bytes + kv_bytes) / 1e9, 3),
                             "achieved_GBps": round((w_bytes + kv_bytes) / step_s / 1e9, 1),
                             "frac_of_peak": round((w_bytes + kv_bytes) / step_s / 1e9 / HBM_PEAK_GBS, 4)},
         "roofline": {"bound": "hbm", "kernel": ("k_gemv3_f8" if model.w8 else "k_gemv3<1,1,6>") + " (RMSNorm + gate_up_proj + SiLU*up), 32 launches per B=1 step", "achieved": round(achieved, 1),
@@ -377,6 +512,8 @@ def main():
         out["cpu_baseline"] = cpu_baseline(model)
     elif rank == 0:
         out["cpu_baseline"] = None
+    if rank == 0 and world == 1 and not args.no_configs and not (args.config4 or args.config5):
+        out["configs"] = other_configs(model, processor, dev, args)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -36,14 +36,74 @@ def shard_text_batch(processor, prompts, rank, world):
     return idx, {k: np.ascontiguousarray(np.asarray(v)[idx]) for k, v in full.items()}
 
 
-def broadcast_requests(requests, src=0, group=None):
-    """Rank `src`'s request table becomes everybody's (ncclBroadcast of a pickled blob)."""
+def _coll_device(group=None):
+    """Where collective payloads live: the current GPU under RCCL (backend "nccl"), host memory under gloo."""
+    return torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+
+
+def pack_requests(prompts, images):
+    """(prompts, images) -> (table int64 [3 + n + 3 * n_img], payload uint8): the request table as two flat tensors.
+    images[i]: None | one image | a list of images, each a PIL image / path / URL as `generate` takes them (decoded HERE,
+    on the rank that holds the table, to RGB uint8 pixels).  table = [n, n_img, text_bytes | per prompt: utf-8 length |
+    per image: prompt index, height, width]; payload = the prompts' utf-8 bytes, then every image's H x W x 3 pixels."""
+    from .api import _load_image
+    n = len(prompts)
+    images = list(images) if images is not None else [None] * n
+    texts = [p.encode("utf-8") for p in prompts]
+    rows, pix = [], []
+    for i, entry in enumerate(images):
+        for im in ([] if entry is None else entry if isinstance(entry, (list, tuple)) else [entry]):
+            a = np.ascontiguousarray(np.asarray(_load_image(im).convert("RGB"), dtype=np.uint8))
+            rows += [i, a.shape[0], a.shape[1]]
+            pix.append(a.reshape(-1))
+    table = np.asarray([n, len(rows) // 3, sum(len(t) for t in texts)] + [len(t) for t in texts] + rows, dtype=np.int64)
+    payload = np.concatenate([np.frombuffer(b"".join(texts), dtype=np.uint8)] + pix) if (texts or pix) else np.zeros(0, np.uint8)
+    return torch.from_numpy(table), torch.from_numpy(payload.copy())
+
+
+def unpack_requests(table, payload):
+    """Inverse of `pack_requests`: (prompts, images) with images[i] = None | PIL image | list of PIL images."""
+    from PIL import Image
+    t, buf = table.cpu().numpy(), payload.cpu().numpy()
+    n, n_img, text_bytes = (int(v) for v in t[:3])
+    lens, rows = t[3:3 + n], t[3 + n:3 + n + 3 * n_img].reshape(n_img, 3)
+    prompts, off = [], 0
+    for ln in lens:
+        prompts.append(bytes(buf[off:off + int(ln)]).decode("utf-8"))
+        off += int(ln)
+    assert off == text_bytes
+    per = [[] for _ in range(n)]
+    for i, h, w in rows:
+        k = int(h) * int(w) * 3
+        per[int(i)].append(Image.fromarray(buf[off:off + k].reshape(int(h), int(w), 3).copy(), "RGB"))
+        off += k
+    images = [None if not p else p[0] if len(p) == 1 else p for p in per]
+    return prompts, (images if n_img else None)
+
+
+def broadcast_requests(prompts, images, src=0, group=None):
+    """Rank `src`'s request table becomes everybody's: three broadcasts -- the two tensor sizes, the int64 table, the uint8
+    payload (prompt text + decoded RGB pixels) -- on the collective's own device (RCCL: device tensors over xGMI; no pickle,
+    no PIL object on the wire).  A 336 x 336 image is 339 KB; config 4's 32 images ~ 11 MB, once per call."""
     rank, world = _world(group)
     if world == 1:
-        return requests
-    box = [requests if rank == src else None]
-    dist.broadcast_object_list(box, src=src, group=group)
-    return box[0]
+        return list(prompts), (list(images) if images is not None else None)
+    dev = _coll_device(group)
+    if rank == src:
+        table, payload = pack_requests(prompts, images)
+        sizes = torch.tensor([table.numel(), payload.numel()], dtype=torch.int64)
+    else:
+        table = payload = None
+        sizes = torch.zeros(2, dtype=torch.int64)
+    sizes = sizes.to(dev)
+    dist.broadcast(sizes, src=src, group=group)
+    n_t, n_p = (int(v) for v in sizes.cpu().tolist())
+    table = table.to(dev) if rank == src else torch.empty(n_t, dtype=torch.int64, device=dev)
+    payload = payload.to(dev) if rank == src else torch.empty(n_p, dtype=torch.uint8, device=dev)
+    dist.broadcast(table, src=src, group=group)
+    if n_p:
+        dist.broadcast(payload, src=src, group=group)
+    return unpack_requests(table, payload)
 
 
 def gather_results(local_idx, local_results, n_total, group=None):
@@ -106,7 +166,7 @@ def generate_sharded(prompts, images=None, preload=None, max_tokens=512, group=N
     """Batched `generate()` over all ranks -- BASELINE config 4 (mixed image + text requests).
 
     `prompts`: list of str.  `images`: None, or a list with one entry (an image / path / URL as `generate` takes it, or
-    None) per prompt.  Rank 0's request table is broadcast (the images travel with it, pickled: ~340 KB per 336x336 image);
+    None) per prompt.  Rank 0's request table is broadcast (`broadcast_requests`: text + decoded RGB pixels as one uint8 tensor, ~340 KB per 336x336 image);
     rank r serves requests r, r+W, ... in chunks of `max_batch` rows.  A chunk -- image and text requests alike -- runs as
     ONE left-padded batch (`processor.collate_requests`: batched ViT, one prefill, graph-replayed batched decode), padded
     to the longest prompt of the WHOLE request list so that the pad geometry and the one-shot short / long RoPE choice
@@ -117,7 +177,7 @@ def generate_sharded(prompts, images=None, preload=None, max_tokens=512, group=N
     from . import api
     from .processor import collate_requests
     rank, world = _world(group)
-    prompts, images = broadcast_requests((list(prompts), list(images) if images is not None else None), group=group)
+    prompts, images = broadcast_requests(list(prompts), list(images) if images is not None else None, group=group)
     n = len(prompts)
     images = images if images is not None else [None] * n
     model, processor = preload

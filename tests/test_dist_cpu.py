@@ -26,8 +26,14 @@ def _worker(rank, world, port, out_dir):
     from phi_3_vision_mlx_amd import dist as pd
     from phi_3_vision_mlx_amd.processor import Phi3FProcessor
     prompts = [f"prompt number {i} " + "x" * (3 * i) for i in range(7)]
-    got = pd.broadcast_requests(prompts if rank == 0 else ["garbage"])
-    assert got == prompts
+    from golden_inputs import make_image
+    imgs = [make_image(336, 336, "noise", 0), None, [make_image(64, 48, "smooth", 1), make_image(20, 30, "noise", 2)]] + [None] * 4
+    got_p, got_i = pd.broadcast_requests(*((prompts, imgs) if rank == 0 else (["garbage"], None)))
+    assert got_p == prompts and got_i[1] is None and got_i[3] is None and len(got_i) == 7
+    assert np.array_equal(np.asarray(got_i[0]), np.asarray(imgs[0])) and got_i[0].mode == "RGB"       # pixels, not pickles
+    assert isinstance(got_i[2], list) and all(np.array_equal(np.asarray(a), np.asarray(b)) for a, b in zip(got_i[2], imgs[2]))
+    got_p, got_i = pd.broadcast_requests(*((prompts[:2] + ["unicode \u00e9\u4e2d"], None) if rank == 0 else ([], None)))
+    assert got_p == prompts[:2] + ["unicode \u00e9\u4e2d"] and got_i is None
     # sharded work + ordered gather
     res = pd.run_sharded(len(prompts), lambda idx: [prompts[i].upper() for i in idx])
     assert res == [p.upper() for p in prompts]
@@ -193,6 +199,9 @@ def test_sharding_world2_gloo(tmp_path):
 
 def test_single_process_fallbacks():
     from phi_3_vision_mlx_amd import dist as pd
+    table, payload = pd.pack_requests(["a", "bc"], [None, None])
+    assert table.dtype == torch.int64 and payload.dtype == torch.uint8 and pd.unpack_requests(table, payload) == (["a", "bc"], None)
+    assert pd.broadcast_requests(["x"], None) == (["x"], None)
     assert pd.shard_indices(10, 1, 4) == [1, 5, 9]
     assert pd.run_sharded(3, lambda idx: [i * i for i in idx]) == [0, 1, 4]
     t = torch.zeros(2, 3, dtype=torch.int32)

@@ -59,7 +59,12 @@ def test_embed_gather(ops, n, H):
 def test_rmsnorm(ops, orc, rows, H):
     x, w = g((rows, H), 2, 3.0), g((H,), 3, 0.1) + 1
     out = ops.rmsnorm(x.cuda(), w.cuda(), 1e-5)
-    close(out, orc.rms_norm(x, w, 1e-5), atol=1e-3)
+    ref = orc.rms_norm(x, w, 1e-5)
+    # mx.fast.rms_norm rounds the normalised row to bf16 BEFORE the weight multiply (pinned by tests/golden/ref_model_tiny.npz):
+    # the kernel reproduces both roundings -- bit-exact but for the rare entry where the device's rsqrt (1 fp32 ulp off
+    # torch's) tips the first rounding, which the second one can stretch to two bf16 ulps
+    close(out, ref, rtol=2 ** -6, atol=1e-3)
+    assert (out.cpu() == ref).float().mean().item() > 0.999
 
 
 @pytest.mark.parametrize("rows,H,f32", [(3, 1024, False), (577, 1024, True), (9, 128, False)])
@@ -818,7 +823,7 @@ def test_graph_replay(ops):
         gr.launch()
     s.synchronize()
     import phi3v_oracle as orc_
-    close(y, orc_.rms_norm(x.cpu(), w.cpu(), 1e-5), atol=1e-3)
+    close(y, orc_.rms_norm(x.cpu(), w.cpu(), 1e-5), rtol=2 ** -6, atol=1e-3)
 
 
 @pytest.mark.parametrize("B", [1, 5])
@@ -906,7 +911,7 @@ def test_gemv_q4_and_dequant(ops, N, K, epi, norm):
     nw = (g((K,), 402) * 0.1 + 1) if norm else None
     xin = x.float()
     if norm:
-        xin = (xin * torch.rsqrt(xin.pow(2).mean(-1, keepdim=True) + 1e-5) * nw.float()).to(BF16).float()
+        xin = ((xin * torch.rsqrt(xin.pow(2).mean(-1, keepdim=True) + 1e-5)).to(BF16) * nw).float()      # mx.fast.rms_norm: two roundings
     y = xin @ wd.t()
     res = g((1, N), 403)
     e = {"none": EPI_NONE, "resid": EPI_RESID_BF16, "silu": EPI_SILU_MUL, "f32": EPI_F32}[epi]
@@ -935,7 +940,7 @@ def test_quant_fp8_rows(ops, rows, K, norm):
     q, s = ops.quant_fp8_rows(x.cuda(), None if w is None else w.cuda(), 1e-5)
     h = x.float()
     if norm:
-        h = (h * torch.rsqrt(h.pow(2).mean(-1, keepdim=True) + 1e-5) * w.float()).to(BF16).float()
+        h = ((h * torch.rsqrt(h.pow(2).mean(-1, keepdim=True) + 1e-5)).to(BF16) * w).float()      # mx.fast.rms_norm: two roundings
     amax = h.abs().amax(-1)
     s_ref = torch.where(amax > 0, amax / 448.0, torch.ones_like(amax))
     q_ref = _e4m3(h * (1.0 / s_ref)[:, None]).view(torch.uint8)

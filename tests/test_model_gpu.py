@@ -31,7 +31,10 @@ def vis():
     return _mk(False)
 
 
-def assert_logits(got, ref, what="", rel_atol=1.25e-2):
+def assert_logits(got, ref, what="", rel_atol=1.5e-2):
+    """(1.25e-2 until round 4: RMSNorm now rounds twice on both sides, as mx.fast.rms_norm does -- one more bf16 rounding per
+    norm at which two correct implementations can part by an ulp; the tiny model's worst step went from 0.9 to 1.2 x the
+    old bound.)"""
     got, ref = got.float().cpu(), ref.float().cpu()
     assert got.shape == ref.shape, (got.shape, ref.shape)
     atol = rel_atol * ref.abs().max().item()

@@ -285,20 +285,24 @@ def test_long_rope_engine_vs_c3_fixture_and_regime_routing():
     torch.cuda.empty_cache()
 
 
-def _sharded_worker(rank, world, port, out_dir):
+def _sharded_worker(rank, world, port, out_dir, backend="gloo"):
     import os
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path[:0] = [root, os.path.join(root, "tests", "golden"), os.path.join(root, "tests")]
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     import torch.distributed as dist
-    torch.cuda.set_device(0)                                   # both ranks share the one GPU of the test box
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    local = rank if backend == "nccl" else 0                   # gloo: both ranks share the one GPU of the test box
+    torch.cuda.set_device(local)
+    if backend == "nccl":                                      # one rank per GPU over RCCL / xGMI (2-GPU boxes only)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local}"))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     from golden_inputs import SERVE_PROMPTS, SERVE_STEPS, make_image
     from phi_3_vision_mlx_amd import dist as pd
     from phi_3_vision_mlx_amd.api import load_synthetic
     g = np.load(os.path.join(root, "tests", "golden", "tiny_serve_oracle.npz"))
-    model, proc = load_synthetic(blind_model=False, tiny=True, seed=0, std_scale=4.0, device="cuda:0",
+    model, proc = load_synthetic(blind_model=False, tiny=True, seed=0, std_scale=4.0, device=f"cuda:{local}",
                                  lm_head_spread=float(g["spread"][0]), lm_head_seed=int(g["head_seed"][0]))
     images = [make_image(336, 336, "noise", 0)] + [None] * (len(SERVE_PROMPTS) - 1)
     mine = (SERVE_PROMPTS, images) if rank == 0 else (["junk"], None)
@@ -324,6 +328,43 @@ def test_generate_sharded_two_ranks_on_one_gpu_matches_the_oracle(tmp_path):
     g = np.load(GOLDEN + "/tiny_serve_oracle.npz")
     assert len(got) == 7
     assert tokens_vs_fixture(got, g, "generate_sharded", min_first=2) >= 20
+
+
+needs_two_gpus = pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs >= 2 GPUs (RCCL over xGMI); the test box has one")
+
+
+@needs_two_gpus
+def test_generate_sharded_two_gpus_over_rccl_matches_the_oracle(tmp_path):
+    """The same request table, one rank per GPU, backend "nccl" (= RCCL): the table is broadcast as device tensors, the
+    results come back through RCCL collectives, and the request-ordered tokens == every request's B = 1 oracle run.  Skipped
+    on 1-GPU boxes; on a multi-GPU node it runs with zero code changes."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_sharded_worker, args=(2, port, str(tmp_path), "nccl"), nprocs=2, join=True)
+    got = torch.load(tmp_path / "sharded.pt")
+    g = np.load(GOLDEN + "/tiny_serve_oracle.npz")
+    assert len(got) == 7
+    assert tokens_vs_fixture(got, g, "generate_sharded over RCCL", min_first=2) >= 20
+
+
+@needs_two_gpus
+def test_bench_two_gpus_reports_its_rccl_ranks():
+    """`bench.py --gpus 2` (the driver's scaling command, tiny model): one JSON line whose `rccl` object shows both ranks joined
+    an all-reduce on DEVICE tensors over the nccl backend, with a per-rank rate each."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--tiny", "--steps", "8", "--warmup", "2",
+                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["rccl"]["backend"] == "nccl" and line["rccl"]["ranks"] == 2
+    assert len(line["rccl"]["per_rank_tokens_per_s"]) == 2 and min(line["rccl"]["per_rank_tokens_per_s"]) > 0
 
 
 def _fleet_worker(rank, world, port, out_dir):
