@@ -209,7 +209,10 @@ int64_t p3v_attention_ws_bytes(int B, int L, int n_heads, int hd, int n_split);
  * (b, r) = b*rope_bstride + r, r in [0, L) (either a view into the prompt tables at `past`, or
  * the compact buffers p3v_stage_rope fills when `past` only lives on the device);
  * ws >= p3v_attention_ws_bytes(B, L, nh, hd, n_split) even when n_split == 1.  hd == 96.
- * Key ranges of the splits are a static function of cache_t, so loads start before d_past arrives. */
+ * Key ranges of the splits are a static function of cache_t, so loads start before d_past arrives.
+ * `past` with d_past != NULL: a LOWER BOUND of *d_past known when the launch is recorded (a captured decode step: the prompt
+ * length), or negative for "none".  The 128-key kernel requests tiles below the bound at once; tiles at or beyond it wait
+ * for *d_past and fetch nothing when they lie wholly past the live keys (the capacity is prompt + max_tokens). */
 typedef struct {
   const uint16_t* qkv; const float* cos_t; const float* sin_t;
   uint16_t* k_cache; uint16_t* v_cache; uint16_t* out;

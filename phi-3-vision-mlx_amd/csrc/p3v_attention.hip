@@ -1823,6 +1823,12 @@ __device__ __forceinline__ void attn_decode_body128(const AttnDecP& p, const int
 
   TMARK(0);
   int past = p.past, pad = 0;
+  // With d_past, p.past is a LOWER BOUND of the cache length (the prompt length when the graph was captured; negative = no
+  // bound known: every tile is requested at once, as in round 3): a
+  // tile that starts below it is certainly live and is requested at once; one at or beyond it may lie wholly past the live
+  // keys (the cache CAPACITY is prompt + max_tokens, rounded up to the tile) -- it waits for the length and fetches nothing
+  // when dead.  (Round 3 fetched every tile of the capacity: 1.06x the live bytes at the bench shape, 1.2x with max_tokens = 512.)
+  const int past_lb = p.past;
   if (p.d_past) asm volatile("s_load_dword %0, %1, 0x0" : "=s"(past) : "s"(p.d_past) : "memory");
   if (p.pad_len) asm volatile("s_load_dword %0, %1, 0x0" : "=s"(pad) : "s"(p.pad_len + b) : "memory");
 
@@ -1875,7 +1881,8 @@ __device__ __forceinline__ void attn_decode_body128(const AttnDecP& p, const int
     const int r = tid / HD;
     v_early = vnew[(size_t)r * row_w + (tid - r * HD)];
   }
-  issue_dma();                                                 // after the (small) loads above: memory returns in order
+  const bool surely_live = p.d_past ? (past_lb < 0 || bx * TK < past_lb) : bx * TK < past_lb + p.L;   // no d_past: the length is exact
+  if (surely_live) issue_dma();                                // after the (small) loads above: memory returns in order
   TMARK(7);
   const unsigned qs_lds = (unsigned)(size_t)(dec_lptr_t)Qs;
   if (tid < 16 * CPR) {
@@ -1887,6 +1894,7 @@ __device__ __forceinline__ void attn_decode_body128(const AttnDecP& p, const int
 
   asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(past), "+s"(pad)::"memory");
   const int total = past + p.L;
+  if (!surely_live && bx * TK < total) issue_dma();            // (the waits below count from the most recent requests: unchanged)
   const int kv_end = min(total, kv_hi);
   const int qpos = past + qi;
   const bool qvalid = qi < p.L;

@@ -274,8 +274,10 @@ class Phi3VModel:
             h = ops.layernorm(x2, w[lp + "layer_norm1.weight"], w[lp + "layer_norm1.bias"], eps)
             wq, bq = self.clip_qkv[j]
             qkv = ops.gemm(h, wq, EPI_BIAS, bias=bq)
-            ops.rope_kv_append(qkv, None, None, q, k, v, n, T, nh, nh, 64, 0, Tp, False)
-            ops.attention(q, o, n, T, nh, nh, 64, 64 ** -0.5, False, k_past=k, v_past=v, past_t=Tp, new_is_cache=True)
+            # head split; the queries leave it multiplied by scale * log2(e) like the decoder's (the attention's softmax is then the
+            # bare exp2: k_attn_prefill_dma<64, PRE> 59 -> 49 us per layer at 17 crops, tools/clip_attn_probe.py)
+            ops.rope_kv_append(qkv, None, None, q, k, v, n, T, nh, nh, 64, 0, Tp, False, q_scale=64 ** -0.5 * ops.Q_PRESCALE)
+            ops.attention(q, o, n, T, nh, nh, 64, 64 ** -0.5, False, k_past=k, v_past=v, past_t=Tp, new_is_cache=True, q_prescaled=True)
             ops.gemm(o, w[lp + "self_attn.out_proj.weight"], EPI_BIAS_RESID_F32, bias=w[lp + "self_attn.out_proj.bias"],
                      resid=x2, out=x2)
             h = ops.layernorm(x2, w[lp + "layer_norm2.weight"], w[lp + "layer_norm2.bias"], eps)
@@ -506,7 +508,10 @@ class Phi3VModel:
                     rc, rs, rb = bufs["rope_cos"], bufs["rope_sin"], L
                 else:                                           # eager: views into the prompt tables at `past`
                     rc, rs, rb = st.cos[:, past:], st.sin[:, past:], st.T
-                ops.attention_decode(qkv, rc, rs, rb, st.k[i], st.v[i], o, B, L, nh, nkv, hd, scale, past, st.Tp, ws, n_split,
+                # (captured step: `past` is read from d_past; the host value passed along is a LOWER BOUND of it -- the kernel fetches
+                #  tiles below it at once and lets the others wait for the length, so tiles beyond the live keys cost nothing)
+                ops.attention_decode(qkv, rc, rs, rb, st.k[i], st.v[i], o, B, L, nh, nkv, hd, scale,
+                                     past if d_past is None else bufs.get("past_lb", -1), st.Tp, ws, n_split,
                                      pad_len=st.pad_len, d_past=d_past, merge_in_launch=bufs.get("attn_merge", False))
             else:
                 # queries leave the RoPE kernel multiplied by scale * log2(e) (before their one rounding to bf16, as
@@ -541,6 +546,9 @@ class Phi3VModel:
                  next_tok=torch.zeros((B,), dtype=I32, device=dev), ticket=torch.zeros((1,), dtype=I32, device=dev))
         bufs = self._alloc_bufs(B, 1)
         self._split_plan(bufs, B, 1, st.Tp, st.quantized)          # the single-tile kernel needs one split per tile of CAPACITY
+        # the cache length only grows under a captured step (greedy_step rebuilds the graph if it ever finds it below this); a
+        # slot state's column moves both ways (engine.py), so it gets no bound
+        bufs["past_lb"] = -1 if getattr(st, "slots", False) else int(st.offset)
         bufs["rope_cos"] = torch.empty((B, 1, self.hd // 2), dtype=F32, device=dev)
         bufs["rope_sin"] = torch.empty_like(bufs["rope_cos"])
         g["bufs"] = bufs
@@ -588,6 +596,8 @@ class Phi3VModel:
             st.graphs.clear()
             st.epoch = self.epoch
         g = st.graphs.get("greedy")
+        if g is not None and st.offset < g["bufs"].get("past_lb", -1):   # the cache was rewound below the captured lower bound
+            g = None
         if g is None:
             g = st.graphs["greedy"] = self._build_decode_graph(st)
             g["host_tok"] = None
