@@ -425,8 +425,10 @@ class Phi3VModel:
             h=torch.empty((M, H), dtype=BF16, device=dev), n_split=0, ws=None)
         return bufs
 
-    def _split_plan(self, bufs, B, L, T, quantized=False):
-        """Split-KV plan for the decode-shaped attention (L <= 16): enough blocks to fill 256 CUs."""
+    def _split_plan(self, bufs, B, L, T, quantized=False, serving=False):
+        """Split-KV plan for the decode-shaped attention (L <= 16): enough blocks to fill 256 CUs.
+        serving: the plan is for a slot state of the continuous-batching engine (a long-lived server) -- the in-launch merge is
+        then used only when EVERY workgroup of the launch is resident at once (no assumption about dispatch order at all)."""
         nh, hd = self.cfg.num_attention_heads, self.hd
         if L <= ops.L.DECODE_MAX_L:
             # 64-key tiles.  Up to ~4096 workgroups: ONE tile per 4-wave workgroup (the kernel then lasts a single
@@ -455,6 +457,14 @@ class Phi3VModel:
             # way: +1.6 % per step, +4.5 % at 8k)
             mode = os.environ.get("P3V_ATTN_FUSED_MERGE", "1")
             fused = (n_split in (tiles, tiles128) or n_split <= 4 or mode == "2") and n_split <= 48 and mode != "0"
+            # The merging workgroup of a (row, head) waits -- bounded, NaN-poisoned on expiry -- for partials of workgroups that
+            # the hardware dispatches before it (linear order; observed, not documented).  When the whole grid is resident at once
+            # (128-key tiles: 3 workgroups per CU, 64-key: 5) nothing depends on that order.  A server takes the separate merge
+            # launch wherever the grid is larger (B = 8: +4.9 us per layer); one-shot generate() keeps the faster in-launch form,
+            # whose failure mode is loud (api._rows raises).  P3V_ATTN_FUSED_MERGE=2 forces it everywhere.
+            if serving and fused and mode != "2":
+                per_cu = 3 if n_split == tiles128 else 5
+                fused = B * nh * n_split <= per_cu * ops.device_props(torch.device(self.device).index or 0)["cu_count"]
             bufs["attn_merge"] = bool(fused)
 
     def _layers(self, x, st, B, L, past, n_beam, bufs=None, d_past=None, last_only=False):
@@ -545,7 +555,7 @@ class Phi3VModel:
                  logits=torch.empty((B, cfg.vocab_size), dtype=BF16, device=dev),
                  next_tok=torch.zeros((B,), dtype=I32, device=dev), ticket=torch.zeros((1,), dtype=I32, device=dev))
         bufs = self._alloc_bufs(B, 1)
-        self._split_plan(bufs, B, 1, st.Tp, st.quantized)          # the single-tile kernel needs one split per tile of CAPACITY
+        self._split_plan(bufs, B, 1, st.Tp, st.quantized, serving=getattr(st, "serving", False))   # one split per tile of CAPACITY
         # the cache length only grows under a captured step (greedy_step rebuilds the graph if it ever finds it below this); a
         # slot state's column moves both ways (engine.py), so it gets no bound
         bufs["past_lb"] = -1 if getattr(st, "slots", False) else int(st.offset)

@@ -4,6 +4,8 @@ import ctypes
 import os
 import re
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -102,3 +104,12 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "phi3v_oracle" not in src and "import oracle" not in src and "from oracle" not in src, f
+
+
+@pytest.mark.skipif(os.environ.get("P3V_ASAN") != "1", reason="opt-in (P3V_ASAN=1): a ~50 s AddressSanitizer host build of libp3v.so")
+def test_asan_host_build_of_the_launchers():
+    """`-fsanitize=address` HOST build of the extension; its launchers' argument validation, workspace
+    sizing and tuning table are driven without a GPU (tools/asan_host_check.cpp).  profiles/r04_asan_host_check.txt holds a run."""
+    import subprocess
+    r = subprocess.run(["bash", os.path.join(ROOT, "tools", "asan_host_build.sh")], capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0 and "all launcher argument paths clean" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]

@@ -285,6 +285,50 @@ def test_long_rope_engine_vs_c3_fixture_and_regime_routing():
     torch.cuda.empty_cache()
 
 
+def test_mixed_batch_with_two_images_and_a_non_square_image_vs_the_oracle():
+    """One decode batch of four requests no earlier test combined: a prompt with TWO images (336x336 +
+    640x480; phi.py:400-415 advances `positions` per image), a 640x480 image alone (13 live crops), a 336x336 image and a text
+    prompt -- length-bucketed prefill into one batch (dist.generate_requests), every row against the request's own B = 1 run of
+    a LIVE oracle (itself pinned to the reference on exactly these image cases, tests/test_refmodel.py).  Tokens are compared on
+    every clear step up to a row's first unclear one; every row's first token must be clear and equal."""
+    import phi3v_oracle as orc
+    from golden_inputs import make_image
+    from phi_3_vision_mlx_amd import dist as pd
+    from phi_3_vision_mlx_amd.api import load_synthetic
+    spread, rel_tol, n = 4.0, 0.03, 5
+    sq, land = make_image(336, 336, "noise", 0), make_image(640, 480, "smooth", 1)
+    texts = ["<|user|>\n<|image_1|>\n<|image_2|>\nCompare the two.<|end|>\n<|assistant|>\n", "<|user|>\n<|image_1|>\nWhat is shown?<|end|>\n<|assistant|>\n",
+             "<|user|>\n<|image_1|>\nAnd this one?<|end|>\n<|assistant|>\n", "<|user|>\nName a colour of the sky.<|end|>\n<|assistant|>\n"]
+    imgs = [[sq, land], [land], [sq], None]
+    for hs in range(40):                                      # a head under which every request's FIRST step is clear (host search, cheap)
+        model, proc = load_synthetic(blind_model=False, tiny=True, seed=0, std_scale=4.0, device="cuda:0", lm_head_spread=spread, lm_head_seed=hs)
+        oracle = orc.OraclePhi3V(model.cfg, {k: v.cpu() for k, v in model.w.items()}, cache_fp32=True)
+        reqs = [proc(t, im) if im is not None else proc(t) for t, im in zip(texts, imgs)]
+        norms = oracle.w["lm_head.weight"].float().norm(dim=-1).clamp_min(1e-30)
+        ref_tok, ref_clear = [], []
+        for r in reqs:
+            o_in = {k: (torch.from_numpy(np.asarray(v)) if k == "pixel_values" else v) for k, v in r.items()}
+            tk, lg = orc.greedy_generate(oracle, o_in, n, stop_on_eos=False)
+            lf = lg[0].float()
+            v, i = lf.topk(2, dim=-1)
+            E = rel_tol * (lf / norms).abs().amax(-1)
+            ref_tok.append(tk[0].tolist()), ref_clear.append(((v[:, 0] - v[:, 1]) > E * (norms[i[:, 0]] + norms[i[:, 1]])).tolist())
+        if all(c[0] for c in ref_clear):
+            break
+    else:
+        pytest.fail("no head seed makes every first step clear")
+    got = pd.generate_requests(model, proc, reqs, n, return_tokens=True)
+    compared = 0
+    for k, (toks, ref, clear) in enumerate(zip(got, ref_tok, ref_clear)):
+        for step in range(n):
+            if not clear[step]:
+                break
+            assert toks[step] == ref[step], f"request {k} step {step}: batch row {toks} != B = 1 oracle {ref}"
+            compared += 1
+    assert compared >= 8, compared
+    print(f"mixed batch (two-image, 640x480, 336x336, text): {compared} tokens on clear steps equal the per-request oracle (head seed {hs})")
+
+
 def _sharded_worker(rank, world, port, out_dir, backend="gloo"):
     import os
     import sys
