@@ -286,8 +286,8 @@ def test_long_rope_engine_vs_c3_fixture_and_regime_routing():
 
 
 def test_mixed_batch_with_two_images_and_a_non_square_image_vs_the_oracle():
-    """One decode batch of four requests no earlier test combined: a prompt with TWO images (336x336 +
-    640x480; phi.py:400-415 advances `positions` per image), a 640x480 image alone (13 live crops), a 336x336 image and a text
+    """One decode batch of four requests no earlier test combined: a prompt with TWO images (both 640x480,
+    different content; phi.py:400-415 advances `positions` per image), a 640x480 image alone (13 live crops), a 336x336 image and a text
     prompt -- length-bucketed prefill into one batch (dist.generate_requests), every row against the request's own B = 1 run of
     a LIVE oracle (itself pinned to the reference on exactly these image cases, tests/test_refmodel.py).  Tokens are compared on
     every clear step up to a row's first unclear one; every row's first token must be clear and equal."""
@@ -296,19 +296,19 @@ def test_mixed_batch_with_two_images_and_a_non_square_image_vs_the_oracle():
     from phi_3_vision_mlx_amd import dist as pd
     from phi_3_vision_mlx_amd.api import load_synthetic
     spread, rel_tol, n = 4.0, 0.03, 5
-    sq, land = make_image(336, 336, "noise", 0), make_image(640, 480, "smooth", 1)
+    sq, land, land2 = make_image(336, 336, "noise", 0), make_image(640, 480, "smooth", 1), make_image(640, 480, "noise", 5)
     texts = ["<|user|>\n<|image_1|>\n<|image_2|>\nCompare the two.<|end|>\n<|assistant|>\n", "<|user|>\n<|image_1|>\nWhat is shown?<|end|>\n<|assistant|>\n",
              "<|user|>\n<|image_1|>\nAnd this one?<|end|>\n<|assistant|>\n", "<|user|>\nName a colour of the sky.<|end|>\n<|assistant|>\n"]
-    imgs = [[sq, land], [land], [sq], None]
+    imgs = [[land, land2], [land], [sq], None]       # two 640x480 images: 2 x 1921 image tokens, the batch stays in the short-RoPE regime
     for hs in range(40):                                      # a head under which every request's FIRST step is clear (host search, cheap)
         model, proc = load_synthetic(blind_model=False, tiny=True, seed=0, std_scale=4.0, device="cuda:0", lm_head_spread=spread, lm_head_seed=hs)
         oracle = orc.OraclePhi3V(model.cfg, {k: v.cpu() for k, v in model.w.items()}, cache_fp32=True)
         reqs = [proc(t, im) if im is not None else proc(t) for t, im in zip(texts, imgs)]
+        assert max(int(np.asarray(r["input_ids"]).shape[-1]) for r in reqs) + n <= 4096      # ONE RoPE regime (phi.py:492), as per request
         norms = oracle.w["lm_head.weight"].float().norm(dim=-1).clamp_min(1e-30)
         ref_tok, ref_clear = [], []
         for r in reqs:
-            o_in = {k: (torch.from_numpy(np.asarray(v)) if k == "pixel_values" else v) for k, v in r.items()}
-            tk, lg = orc.greedy_generate(oracle, o_in, n, stop_on_eos=False)
+            tk, lg = orc.greedy_generate(oracle, dict(r), n, stop_on_eos=False)   # (the oracle takes the device crops to the host itself)
             lf = lg[0].float()
             v, i = lf.topk(2, dim=-1)
             E = rel_tol * (lf / norms).abs().amax(-1)
