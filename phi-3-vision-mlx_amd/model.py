@@ -276,8 +276,9 @@ class Phi3VModel:
             qkv = ops.gemm(h, wq, EPI_BIAS, bias=bq)
             # head split; the queries leave it multiplied by scale * log2(e) like the decoder's (the attention's softmax is then the
             # bare exp2: k_attn_prefill_dma<64, PRE> 59 -> 49 us per layer at 17 crops, tools/clip_attn_probe.py)
-            ops.rope_kv_append(qkv, None, None, q, k, v, n, T, nh, nh, 64, 0, Tp, False, q_scale=64 ** -0.5 * ops.Q_PRESCALE)
-            ops.attention(q, o, n, T, nh, nh, 64, 64 ** -0.5, False, k_past=k, v_past=v, past_t=Tp, new_is_cache=True, q_prescaled=True)
+            pre = os.environ.get("P3V_VIT_PLAIN_Q") != "1"
+            ops.rope_kv_append(qkv, None, None, q, k, v, n, T, nh, nh, 64, 0, Tp, False, q_scale=64 ** -0.5 * ops.Q_PRESCALE if pre else 1.0)
+            ops.attention(q, o, n, T, nh, nh, 64, 64 ** -0.5, False, k_past=k, v_past=v, past_t=Tp, new_is_cache=True, q_prescaled=pre)
             ops.gemm(o, w[lp + "self_attn.out_proj.weight"], EPI_BIAS_RESID_F32, bias=w[lp + "self_attn.out_proj.bias"],
                      resid=x2, out=x2)
             h = ops.layernorm(x2, w[lp + "layer_norm2.weight"], w[lp + "layer_norm2.bias"], eps)

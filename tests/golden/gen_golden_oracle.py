@@ -469,18 +469,14 @@ DATA = os.path.join(ROOT, "tools", "data")
 HEAVY = {"c2h": dict(quant=False, act8=False), "c5wh": dict(quant=True, act8=False), "c5h": dict(quant=True, act8=True)}
 # measured |HIP - oracle| of the residual stream after the last layer (profiles/r03_heavy_tail.txt): full size c2h 3.6-3.9 %,
 # c5wh 6.0-7.0 %, c5h 24-28 %; tiny (2 layers) 1.1 % / 1.1 % / 6.8 %.  x 1.3-1.5:
-REL_TOL_HEAVY = {"c2h": 0.055, "c5wh": 0.095, "c5h": 0.17}
-REL_TOL_HEAVY_TINY = {"c2h": 0.03, "c5wh": 0.045, "c5h": 0.05}
-# Steps per fixture.  Measured z-space |HIP - oracle| per step (tools/heavy_diag.py, %): c2h 4.0 5.2 2.1 2.3; c5wh 7.3 7.8 5.4
-# 5.2; c5h 12.7 12.3 10.7 104; tiny c2h <= 1.7; tiny c5wh 3.2 3.5 3.1 8.0; tiny c5h 3.5 4.1 3.1 21.9.  The blow-ups are single
-# DECODE steps of the quantised variants: with key dimensions 8x the rest the attention logits of some tokens reach hundreds
-# (log2 units) and the softmax sits between two competing keys -- a 0.2 % difference in a score (an int8 / e4m3 code flip)
-# moves the attention output by tens of per cent (tools/heavy_diag2.py: the same input token deviates 12-15 % after LAYER 0
-# at steps 1 and 3 and 1.5 % at step 2; tools/heavy_diag3.py: every projection kernel matches the oracle's arithmetic on
-# those tokens to <= 0.01 % at full size).  Two correct implementations disagree there, so those steps are not fixture
-# material: c5h pins its first three steps' logits, tiny c5wh / c5h three; decode under heavy tails with quantised weights and
-# KV is pinned by c5wh (4 steps, tokens exact on the clear ones) and bf16 by c2h.
-HEAVY_STEPS = {"c2h": 4, "c5wh": 4, "c5h": 3, "tiny_c2h": 4, "tiny_c5wh": 3, "tiny_c5h": 3}
+# Round 4: RMSNorm rounds twice on both sides (mx.fast.rms_norm's semantics, pinned by ref_model_tiny.npz).  Under heavy tails the
+# extra rounding of the NORMALISED OUTLIER channels (a 1-ulp flip there is a quarter of a typical entry) raised the spread between
+# correct implementations -- measured HIP vs oracle per step, two equally correct ViT softmax variants (tools/heavy_diag.py,
+# profiles/r04_heavy_tail.txt): c2h 4.7 7.7 3.4 3.8 | 5.7 7.9 3.0 3.5 %; c5wh 3.9 9.0 3.9 5.1 | 4.3 12.8 4.8 4.6 %; c5h 23.8 13.7 64 |
+# 20.2 11.8 65 %; tiny c2h <= 2.6, c5wh <= 4.0, c5h <= 4.6 %.  Tolerances = 1.25-1.3 x the worst of either variant:
+REL_TOL_HEAVY = {"c2h": 0.10, "c5wh": 0.16, "c5h": 0.30}
+REL_TOL_HEAVY_TINY = {"c2h": 0.035, "c5wh": 0.055, "c5h": 0.06}
+HEAVY_STEPS = {"c2h": 4, "c5wh": 4, "c5h": 2, "tiny_c2h": 4, "tiny_c5wh": 3, "tiny_c5h": 3}     # c5h: its third step blows up (64 %) since round 4
 
 
 def heavy(tag, tiny_model=False):

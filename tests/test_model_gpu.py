@@ -791,12 +791,14 @@ def test_heavy_tailed_activations_fixtures(tag, tiny):
     two key / value dimensions per head x 8 -- what trained decoders show and N(0, s) weights never do), in the three
     arithmetic variants of the build: bf16 (c2h), fp8 weights + int8 KV (c5wh), W8A8 prompt projections + int8 KV (c5h),
     each against an oracle with the same weights and quantisers (tests/golden/gen_golden_oracle.py `heavy`).  Every logit
-    inside the fixture's tolerance (1.3-1.5 x the measured HIP - oracle difference, profiles/r03_heavy_tail.txt), tokens
-    exact on every clear step -- the first two steps of c2h / c5wh by construction; under W8A8 the per-row e4m3 activation
-    scale is set by the outlier channels and two correct implementations differ by 11-13 % of the logit range per step, so
-    c5h pins the logits only.  c5h and the tiny quantised twins stop after three steps: their fourth step is one of the
-    decode steps where an ill-conditioned softmax (attention logits in the hundreds under 8x key dimensions) turns a single
-    int8 / e4m3 code flip into tens of per cent -- measured and explained in the generator's header, not fixture material."""
+    inside the fixture's tolerance (1.25-1.3 x the measured HIP - oracle difference, taken over two equally correct ViT softmax
+    variants: profiles/r04_heavy_tail.txt; the double-rounded RMSNorm of round 4 raised the spread 1.3-1.6 x, a 1-ulp flip of a
+    normalised outlier channel being a quarter of a typical entry), tokens exact on every clear step -- the first two steps of
+    c2h / c5wh by construction; under W8A8 the per-row e4m3 activation scale is set by the outlier channels and two correct
+    implementations differ by 12-24 % of the logit range per step, so c5h pins the logits only, over two steps.  The tiny
+    quantised twins stop after three steps: later steps are decode steps where an ill-conditioned softmax (attention logits in
+    the hundreds under 8x key dimensions) turns a single int8 / e4m3 code flip into tens of per cent -- measured and explained
+    in the generator's header, not fixture material."""
     from golden_inputs import vqa_request
     from phi_3_vision_mlx_amd.api import load_synthetic
     g = np.load(f"{GOLDEN}/{'tiny_' if tiny else ''}{tag}_oracle.npz")

@@ -76,7 +76,8 @@ def test_regression_fixture_tiny(tiny):
             toks, lgs = orc.greedy_generate(o, dict(inputs), n, stop_on_eos=False)
             assert np.array_equal(toks.numpy(), GOLD[key + "tokens"])
             ref = _from_bits(GOLD[key + "logits_bf16"])                 # the fixture projected the last row only: a different
-            assert (lgs.float() - ref).abs().le(2.0 ** -7 * ref.abs() + 1e-30).all()   # GEMM blocking may flip a last bf16 bit
+            # GEMM blocking may flip a last bf16 bit; entries that cancel to ~0 carry the fp32 sum's absolute noise instead
+            assert (lgs.float() - ref).abs().le(2.0 ** -7 * ref.abs() + 2.0 ** -18 * ref.abs().max()).all()
             from gen_golden_oracle import clearance, row_norms        # the fixture's tolerance model (row-normalised logits)
             cl = clearance(lgs, row_norms(o.w["lm_head.weight"]), rel_tol)
             assert np.allclose(cl.numpy(), GOLD[key + "margins"], rtol=0.1) and cl.min().item() > 1.0
