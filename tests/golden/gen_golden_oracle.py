@@ -139,6 +139,20 @@ class Prefilled:
         return torch.cat(toks, 1), torch.stack(lgs, 1), torch.stack(mgs, 1)
 
 
+def conditioning(r, head_f32, toks, n_steps):
+    """How far every decode step of a fixture moves when the rotated q / k are rounded to bf16 (teacher-forced on `toks`):
+    per step, max_v |z_v - z'_v| / max_v |z_v| -- the fixture tolerance's own unit."""
+    norms = row_norms(head_f32)
+    base = r.greedy(head_f32, n_steps, teacher=toks, norms=norms)[1].to(F32)
+    plain_rot = orc.rotate_half
+    orc.rotate_half = lambda x, c, s_: plain_rot(x, c, s_).to(BF16).to(F32)
+    try:
+        pert = r.greedy(head_f32, n_steps, teacher=toks, norms=norms)[1].to(F32)
+    finally:
+        orc.rotate_half = plain_rot
+    return [float((((base[:, t] - pert[:, t]).abs() / norms).amax(-1) / (base[:, t] / norms).abs().amax(-1)).max()) for t in range(n_steps)]
+
+
 def search_head(reqs, base_head, n_steps, max_seeds=20000, first_seed=0, need="all", min_distinct=1):
     """Smallest lm_head seed for which the requests' greedy runs are clear.  need = "all": every step of every request;
     need = "prefill": the first step of every request (then the decode steps are taken as they come); an int: that many steps.
@@ -473,8 +487,11 @@ HEAVY = {"c2h": dict(quant=False, act8=False), "c5wh": dict(quant=True, act8=Fal
 # extra rounding of the NORMALISED OUTLIER channels (a 1-ulp flip there is a quarter of a typical entry) raised the spread between
 # correct implementations -- measured HIP vs oracle per step, two equally correct ViT softmax variants (tools/heavy_diag.py,
 # profiles/r04_heavy_tail.txt): c2h 4.7 7.7 3.4 3.8 | 5.7 7.9 3.0 3.5 %; c5wh 3.9 9.0 3.9 5.1 | 4.3 12.8 4.8 4.6 %; c5h 23.8 13.7 64 |
-# 20.2 11.8 65 %; tiny c2h <= 2.6, c5wh <= 4.0, c5h <= 4.6 %.  Tolerances = 1.25-1.3 x the worst of either variant:
-REL_TOL_HEAVY = {"c2h": 0.10, "c5wh": 0.16, "c5h": 0.30}
+# 20.2 11.8 65 %; tiny c2h <= 2.6, c5wh <= 4.0, c5h <= 4.6 %.  The 7.7-12.8 % steps of c2h / c5wh turned out to be ILL-CONDITIONED
+# decode steps (`conditioning` below: they move by > half the tolerance under a bf16 rounding of q / k alone); on heads whose steps
+# are all well-conditioned by that test the build measures 4.6-8.5 % (c2h, two heads) and 7.4-8.8 % (c5wh).  Tolerances = 1.2-1.25 x
+# the worst of those; c5h (W8A8) 1.25 x its 23.8 %:
+REL_TOL_HEAVY = {"c2h": 0.10, "c5wh": 0.11, "c5h": 0.30}
 REL_TOL_HEAVY_TINY = {"c2h": 0.035, "c5wh": 0.055, "c5h": 0.06}
 HEAVY_STEPS = {"c2h": 4, "c5wh": 4, "c5h": 2, "tiny_c2h": 4, "tiny_c5wh": 3, "tiny_c5h": 3}     # c5h: its third step blows up (64 %) since round 4
 
@@ -515,7 +532,22 @@ def heavy(tag, tiny_model=False):
         # W8A8 under heavy tails: two correct implementations differ by a quarter of the logit range (every e4m3 activation
         # code that flips is a 6-12 % step of a row whose scale the outlier channels set): no token can be pinned -- the
         # fixture then only bounds the logits (need = 0: whatever head comes first).  The others: first two steps clear.
-        hs, (res,) = search_head([r], base, n_steps, need=0 if kw["act8"] else 2, min_distinct=1 if kw["act8"] else 2)
+        first = 0
+        while True:
+            hs, (res,) = search_head([r], base, n_steps, need=0 if kw["act8"] else 2, min_distinct=1 if kw["act8"] else 2, first_seed=first)
+            if kw["act8"]:
+                break
+            # Round 4: a heavy-tail DECODE step can be ill-conditioned whatever the arithmetic (key dimensions at 8x push some
+            # attention logits into the hundreds; a softmax between two competing keys turns a 0.4 % change of a score into tens of
+            # per cent at the logits).  Such a step is not fixture material for ANY correct implementation, and which steps they are
+            # depends on the tokens the head picks.  Objective, GPU-independent test: replay the fixture's steps with the rotated
+            # q / k rounded to bf16 (the one rounding every bf16 attention makes) and require every step to move by < half the
+            # tolerance; else take the next head.
+            cond = conditioning(r, peaked_lm_head(base.to(F32), SPREAD, hs), res[0], n_steps)
+            print(f"  head {hs}: conditioning per step (z-space change under bf16 q / k, x tolerance) {[round(c / r.rel_tol, 2) for c in cond]}", flush=True)
+            if max(cond) < 0.5 * r.rel_tol:
+                break
+            first = hs + 1
     finally:
         peaked_lm_head = plain
         orc.OracleKVCache = orig

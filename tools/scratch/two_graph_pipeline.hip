@@ -11,7 +11,7 @@
 #include <cstring>
 #include <vector>
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-constexpr int D = 4096, NS = 160, NWB = 24, TPB = 512, NBLK = 256, CH = D / 8 / 64;   // 8 16-byte chunks per lane and row
+constexpr int D = 4096, NS = 160, NWB = 24, TPB = 576, NBLK = 256, CH = D / 8 / 64;     // 8 computing waves + 1 poller wave   // 8 16-byte chunks per lane and row
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at line %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
 __device__ __forceinline__ float lo(unsigned x) { return __builtin_bit_cast(float, x << 16); }
 __device__ __forceinline__ float hi(unsigned x) { return __builtin_bit_cast(float, x & 0xffff0000u); }
@@ -26,33 +26,49 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 
 template <bool POLL>
-__global__ void __launch_bounds__(TPB) k_stage(const u32x4* __restrict__ W, const unsigned* xin, unsigned* xout, int* err) {
+__global__ void __launch_bounds__(TPB) k_stage(const u32x4* __restrict__ W, const unsigned* xin, unsigned* xout, int* err, long long* stamp) {
   __shared__ u32x4 xs[D / 8];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int row0 = blockIdx.x * 16 + wave * 2;
-  // (a) this wave's two weight rows: requested before anything else
+  const bool st = stamp && tid == 0 && (blockIdx.x == 0 || blockIdx.x == NBLK - 1);
+  long long* sp = stamp + (blockIdx.x ? 4 : 0);
+  if (st) sp[0] = wall_clock64();
+  // (a) this wave's two weight rows: requested before anything else (waves 0..7)
   u32x4 w[2][CH];
+  if (wave < 8) {
 #pragma unroll
-  for (int r = 0; r < 2; ++r)
+    for (int r = 0; r < 2; ++r)
 #pragma unroll
-    for (int c = 0; c < CH; ++c) w[r][c] = __builtin_nontemporal_load(W + (size_t)(row0 + r) * (D / 8) + c * 64 + lane);
-  // (b) the input vector: 16 bytes per thread
-  u32x4 xv;
-  if (POLL) {
-    int tries = 0;
-    for (;;) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) xv[j] = __hip_atomic_load(xin + tid * 4 + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const bool bad = xv[0] == 0xffffffffu || xv[1] == 0xffffffffu || xv[2] == 0xffffffffu || xv[3] == 0xffffffffu;
-      if (!__syncthreads_or(bad)) break;
-      if (++tries > 400000) { if (tid == 0) atomicExch(err, 1); break; }
-      __builtin_amdgcn_s_sleep(4);
-    }
-  } else {
-    xv = *(const u32x4*)(xin + tid * 4);
+      for (int c = 0; c < CH; ++c) w[r][c] = __builtin_nontemporal_load(W + (size_t)(row0 + r) * (D / 8) + c * 64 + lane);
   }
-  xs[tid] = xv;
+  // (b) the input vector.  POLL: by the NINTH wave alone -- memory returns a wave's loads in order, so a poll issued behind 16 weight
+  //     loads would come back only when the weights have landed (and show what the memory held when it was SERVICED, long before)
+  if (POLL) {
+    if (wave == 8) {
+      unsigned* xw = (unsigned*)xs;
+      int tries = 0;
+      for (;;) {
+        unsigned v[32];
+        bool bad = false;
+#pragma unroll
+        for (int j = 0; j < 32; ++j) v[j] = __hip_atomic_load(xin + j * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int j = 0; j < 32; ++j) bad |= v[j] == 0xffffffffu;
+        if (!__any(bad)) {
+#pragma unroll
+          for (int j = 0; j < 32; ++j) xw[j * 64 + lane] = v[j];
+          break;
+        }
+        if (++tries > 400000) { if (lane == 0) atomicExch(err, 1); break; }
+        __builtin_amdgcn_s_sleep(2);
+      }
+    }
+  } else if (tid < 512) {
+    xs[tid] = *(const u32x4*)(xin + tid * 4);
+  }
   __syncthreads();
+  if (st) sp[1] = wall_clock64();
+  if (wave == 8) return;
   // (c) two dot products per wave
   float acc[2] = {0.f, 0.f};
 #pragma unroll
@@ -69,6 +85,7 @@ __global__ void __launch_bounds__(TPB) k_stage(const u32x4* __restrict__ W, cons
     if (POLL) __hip_atomic_store(xout + (row0 >> 1), o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     else xout[row0 >> 1] = o;
   }
+  if (st) sp[2] = wall_clock64();
 }
 
 int main() {
@@ -92,6 +109,9 @@ int main() {
   CK(hipMalloc(&x, (NS + 1) * xw * 4));
   CK(hipMalloc(&err, 4));
   CK(hipMemset(err, 0, 4));
+  long long* stamps;
+  CK(hipMalloc(&stamps, NS * 8 * 8));
+  CK(hipMemset(stamps, 0, NS * 8 * 8));
   std::vector<unsigned> hx(xw);
   for (auto& v : hx) v = 0x3c003c00u;                              // bf16 (0.0078, 0.0078)
   hipStream_t s1, s2;
@@ -102,8 +122,8 @@ int main() {
     hipGraphExec_t ge;
     CK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
     for (int i = first; i < NS; i += step) {
-      if (poll) hipLaunchKernelGGL(k_stage<true>, dim3(NBLK), dim3(TPB), 0, s, W[i % NWB], x + i * xw, x + (i + 1) * xw, err);
-      else hipLaunchKernelGGL(k_stage<false>, dim3(NBLK), dim3(TPB), 0, s, W[i % NWB], x + i * xw, x + (i + 1) * xw, err);
+      if (poll) hipLaunchKernelGGL(k_stage<true>, dim3(NBLK), dim3(TPB), 0, s, W[i % NWB], x + i * xw, x + (i + 1) * xw, err, stamps + i * 8);
+      else hipLaunchKernelGGL(k_stage<false>, dim3(NBLK), dim3(TPB), 0, s, W[i % NWB], x + i * xw, x + (i + 1) * xw, err, stamps + i * 8);
     }
     CK(hipStreamEndCapture(s, &g));
     CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
@@ -143,6 +163,12 @@ int main() {
     CK(hipMemcpy(out.data(), x + NS * xw, xw * 4, hipMemcpyDeviceToHost));
     int herr;
     CK(hipMemcpy(&herr, err, 4, hipMemcpyDeviceToHost));
+    std::vector<long long> hs(NS * 8);
+    CK(hipMemcpy(hs.data(), stamps, NS * 8 * 8, hipMemcpyDeviceToHost));
+    printf("  timeline of stages 40..47 (100 MHz ticks from stage 40's entry; first / last workgroup: entry, x ready, done):\n");
+    for (int i = 40; i < 48; ++i)
+      printf("    stage %d: wg0 %5lld %5lld %5lld   wg255 %5lld %5lld %5lld\n", i, hs[i * 8] - hs[320], hs[i * 8 + 1] - hs[320], hs[i * 8 + 2] - hs[320],
+             hs[i * 8 + 4] - hs[320], hs[i * 8 + 5] - hs[320], hs[i * 8 + 6] - hs[320]);
     printf("%-44s %8.3f ms for %d stages = %6.2f us per stage (%5.2f TB/s)%s\n", name, best, NS, best * 1e3 / NS,
            (double)D * D * 2 * NS / (best * 1e-3) / 1e12, herr ? "  [POLL TIMEOUT]" : "");
   };
