@@ -285,6 +285,58 @@ def _last_logits(logits):
     return logits[:, -1, :].contiguous()
 
 
+def greedy_loop(model, token, cache, n_steps, streamer, token_stopper, logit_stopper=None, mask=None, pids=None):
+    """The decode loop of `_generate` (reference phi_3_vision_mlx.py:390-398): `n_steps` greedy steps after the prefill token,
+    every token handed to the streamer and the stoppers in order, stops as the reference stops.
+
+    With the graph-replayed step and no logit stopper the loop is ONE STEP AHEAD of the host: step i + 1 is enqueued (its input
+    token never leaves the device) before the host reads token i, so the per-token work the reference does after `mx.eval` --
+    D2H copy, Streamer, TokenStopper -- runs while the GPU computes the next step.  Tokens, texts and stop step are identical;
+    when a stop fires one speculative step has been enqueued and is dropped.  With a logit stopper (it reads step i's logits
+    on the host before deciding) or an eager model the loop is the reference's, one sync per token."""
+    graph_step = getattr(model, "greedy_step", None)
+    ahead = graph_step is not None and (logit_stopper is None or not logit_stopper.early_stop) and torch.is_tensor(token) and token.is_cuda
+    if not ahead:
+        for _ in range(n_steps):
+            if graph_step is not None:
+                logits, token = graph_step(token, cache)
+            else:
+                logits, cache = model(input_ids=token, cache=cache, mask=mask, pids=pids)
+                token = model_ops.argmax(_last_logits(logits))[:, None]
+            rows = _rows(token)                                     # ONE D2H copy per step, shared by the streamer and the stopper
+            streamer(rows)
+            if logit_stopper is not None and logit_stopper(logits):
+                break
+            if token_stopper(rows):
+                break
+        return token
+    B = token.shape[0]
+    host = [torch.empty((B,), dtype=torch.int32).pin_memory() for _ in range(2)]
+    pending = None                                                  # (event, pinned buffer) of the step the host has not read yet
+
+    def take(p):
+        p[0].synchronize()
+        rows = p[1].tolist()
+        if min(rows) < 0:
+            raise RuntimeError(f"device step failed: NaN logits (token ids {rows})")
+        streamer(rows)
+        return token_stopper(rows)
+    for i in range(n_steps):
+        _, token = graph_step(token, cache)                         # enqueue step i
+        # stream-ordered copy, before the next replay overwrites the buffer.  (Measured alternative: the token copied from the
+        # graph's history buffer on a SIDE stream, so that the replays run back to back -- the cross-stream events cost more
+        # than the ~18 us of idle GPU the in-line copy leaves per step: 500 against 550 tok/s at config 2.)
+        host[i & 1].copy_(token.reshape(-1), non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        if pending is not None and take(pending):                   # host work of step i - 1 under the GPU's step i
+            return token
+        pending = (ev, host[i & 1])
+    if pending is not None:
+        take(pending)
+    return token
+
+
 def _generate(model, processor, prompt, images=None, max_tokens=512, verbose=True, return_tps=False, early_stop=False,
               stream=True, mute=False):
     """Greedy decoding loop (reference phi_3_vision_mlx.py:376-409)."""
@@ -300,19 +352,7 @@ def _generate(model, processor, prompt, images=None, max_tokens=512, verbose=Tru
     token = model_ops.argmax(_last_logits(logits))[:, None]
     streamer(_rows(token))                                      # D2H copy = the per-token sync the reference has (mx.eval)
     prompt_time = tic()
-    graph_step = getattr(model, "greedy_step", None)        # one hipGraph launch per token (HIP model)
-    for i in range(max_tokens - 1):
-        if graph_step is not None:
-            logits, token = graph_step(token, cache)
-        else:
-            logits, cache = model(input_ids=token, cache=cache, mask=mask, pids=pids)
-            token = model_ops.argmax(_last_logits(logits))[:, None]
-        rows = _rows(token)                                     # ONE D2H copy per step, shared by the streamer and the stopper
-        streamer(rows)
-        if logit_stopper(logits):
-            break
-        if token_stopper(rows):
-            break
+    greedy_loop(model, token, cache, max_tokens - 1, streamer, token_stopper, logit_stopper, mask, pids)
     result, gen_len = streamer.end()
     gen_time = tic()
     prompt_len = dict_input["input_ids"].size

@@ -251,12 +251,7 @@ def generate_requests(model, processor, reqs, max_tokens, return_tokens=False, w
     streamer = api.Streamer(processor, False, True)
     stopper = api.TokenStopper(processor, len(reqs))
     streamer(api._rows(token))
-    for _ in range(max_tokens - 1):
-        _, token = model.greedy_step(token, cache)
-        rows = api._rows(token)
-        streamer(rows)
-        if stopper(rows):
-            break
+    api.greedy_loop(model, token, cache, max_tokens - 1, streamer, stopper)
     if return_tokens:
         per_slot = [list(r) for r in zip(*streamer.list_tokens)]
         per_slot = [(r[:r.index(api.ID_EOS) + 1] if api.ID_EOS in r else r) for r in per_slot]
@@ -275,12 +270,7 @@ def generate_rows(model, processor, rows, max_tokens, return_tokens=False):
     streamer = api.Streamer(processor, False, True)
     stopper = api.TokenStopper(processor, np.asarray(rows["input_ids"]).shape[0])
     streamer(api._rows(token))
-    for _ in range(max_tokens - 1):
-        _, token = model.greedy_step(token, cache)
-        rows = api._rows(token)
-        streamer(rows)
-        if stopper(rows):
-            break
+    api.greedy_loop(model, token, cache, max_tokens - 1, streamer, stopper)
     if return_tokens:
         per_row = [list(r) for r in zip(*streamer.list_tokens)]
         return [(r[:r.index(api.ID_EOS) + 1] if api.ID_EOS in r else r) for r in per_row]

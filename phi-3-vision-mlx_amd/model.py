@@ -616,6 +616,7 @@ class Phi3VModel:
             g["tok"].copy_(token.reshape(-1).to(self.device, I32))   # first step / caller-chosen token
         g["d_past"].fill_(st.offset) if g.get("synced_offset") != st.offset else None
         g["graph"].launch()
+        g["n_replays"] = g.get("n_replays", 0) + 1              # replay r wrote its token to history[:, r - 1] (while it fits)
         st.offset += 1
         g["synced_offset"] = st.offset
         g["host_tok"] = g["next_tok"].view(-1, 1)
