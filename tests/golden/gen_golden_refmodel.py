@@ -253,5 +253,84 @@ def main():
     print(f"wrote ref_model_tiny.npz/.json in {time.time() - t0:.0f}s")
 
 
+class TableTokenizer:
+    """A tokenizer stand-in for the FULL-SIZE runs: `table` maps whole strings (a prompt, or the chunks `_merge` cuts a prompt
+    into, phi.py:265) to prepared id lists, so that the reference's processors + `_generate` run on exactly the ids of the
+    oracle fixtures (random ids up to 32000 have no spelling in the byte tokenizer).  Decoding returns the ids as text."""
+
+    def __init__(self, table):
+        self.table = table
+
+    def __call__(self, texts, **kw):
+        return ByteTokenizer.__call__.__globals__["_Enc"](self.table[texts] if isinstance(texts, str) else [self.table[t] for t in texts])
+
+    def decode(self, ids, **kw):
+        return " ".join(str(int(i)) for i in ids)
+
+    def batch_decode(self, seqs, **kw):
+        return [self.decode(s) for s in seqs]
+
+
+def full():
+    """`ref_model_full.npz`: the reference's own code at FULL size (3072 / 32 layers / 32 heads / vocab 32064; CLIP ViT-L/14-336, 17
+    crops) on the requests of c1_oracle.npz (128 random ids) and c2_oracle.npz (bench.py's image request, 2531 ids), under those
+    fixtures' lm_head seeds: prefill + 3 (c1) / 2 (c2) greedy steps through `_generate`.  Pins the full-size HIP path to the
+    reference directly (tests/test_model_gpu.py::test_reference_model_fixture_full_size) and shows oracle == reference at full
+    size by comparing with the oracle fixtures of the same requests (tests/test_refmodel.py)."""
+    from gen_golden_oracle import REL_TOL_LONG, REL_TOL_SHORT
+    from golden_inputs import vqa_request
+    from phi_3_vision_mlx_amd.config import phi3v_config_dict
+    torch.set_num_threads(8)
+    out = dict(spread=np.asarray([SPREAD], dtype=np.float32))
+    meta = {"generator": "tests/golden/gen_golden_refmodel.py full"}
+    d = phi3v_config_dict(vision=True)
+    cfg = make_config(d)
+    t0 = time.time()
+    w = synth_weights(cfg, seed=0)
+    base = w["lm_head.weight"]
+    path = os.path.join(TMP, "full_vision")
+    shutil.rmtree(path, ignore_errors=True)
+    save_safetensors_dir(w, d, path)
+    print(f"weights written {time.time() - t0:.0f}s", flush=True)
+    g1, g2 = np.load(os.path.join(HERE, "c1_oracle.npz")), np.load(os.path.join(HERE, "c2_oracle.npz"))
+    inp2 = vqa_request(Phi3VProcessor(None).img_processor, 0)
+    ids2 = np.asarray(inp2["input_ids"])[0]
+    n_img = int((ids2 < 0).sum())
+    first_neg = int(np.argmax(ids2 < 0))
+    table = {"<C1>": [int(t) for t in g1["ids"][0]], "A": [int(t) for t in ids2[:first_neg]], "B": [int(t) for t in ids2[first_neg + n_img:]]}
+    mx, phi, loops = ref_env.load_reference()
+    model, proc = ref_env.load_model(path, TableTokenizer(table), clip_cfg=d["clip"])
+    del w
+    from PIL import Image
+    img = Image.fromarray(np.random.default_rng(0).integers(0, 256, (336, 336, 3), dtype=np.uint8))      # vqa_request's image (seed 0)
+    for name, prompt, imgs, n, hs, rel_tol, ref_ids in (("c1", "<C1>", None, 4, int(g1["head_seed"][0]), REL_TOL_SHORT, g1["ids"]),
+                                                       ("c2", "A<|image_1|>B", [img], 3, int(g2["head_seed"][0]), REL_TOL_LONG, ids2[None])):
+        head = peaked_lm_head(base, SPREAD, hs)
+        model.lm_head.weight = mx.array(head)
+        rec = ref_env.Recorder(model)
+        t0 = time.time()
+        texts = loops._generate(rec, proc, prompt, imgs, max_tokens=n, verbose=False, stream=False, mute=True)
+        ids = as_t(rec.calls[0]["input_ids"]).long()
+        assert np.array_equal(ids.numpy(), np.asarray(ref_ids)), f"{name}: the reference's processor built other ids than the fixture's request"
+        lgs = torch.stack([c["logits"]._t[:, -1] for c in rec.calls], 1)
+        toks = torch.argmax(lgs.float(), dim=-1)
+        mg = clearance(lgs, row_norms(head), rel_tol)
+        out[name + "_head_seed"] = np.asarray([hs], dtype=np.int32)
+        out[name + "_rel_tol"] = np.asarray([rel_tol], dtype=np.float32)
+        out[name + "_tokens"] = toks.numpy().astype(np.int32)
+        out[name + "_logits_bf16"] = bits(lgs)
+        out[name + "_margins"] = mg.numpy().astype(np.float32)
+        meta[name] = {"S": int(ids.shape[1]), "steps": n, "texts": texts, "seconds": round(time.time() - t0)}
+        print(f"  {name}: S={ids.shape[1]} tokens {toks.tolist()} min clearance {mg.min().item():.2f} ({time.time() - t0:.0f}s)", flush=True)
+    np.savez_compressed(os.path.join(HERE, "ref_model_full.npz"), **out)
+    with open(os.path.join(HERE, "ref_model_full.json"), "w") as f:
+        json.dump(meta, f, indent=1)
+    shutil.rmtree(path, ignore_errors=True)
+    print("wrote ref_model_full.npz/.json")
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "full":
+        full()
+    else:
+        main()

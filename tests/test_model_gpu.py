@@ -528,6 +528,28 @@ def test_reference_model_fixture(name, tmp_path):
     assert texts == meta[name]["texts"], (texts, meta[name]["texts"])
 
 
+@pytest.mark.parametrize("name", ["c1", "c2"])
+def test_reference_model_fixture_full_size(name):
+    """The FULL-SIZE HIP path against the reference's own code, no oracle in between: `ref_model_full.npz` = the reference's `_load`
+    + processors + `_generate` + `Phi3VForCausalLM` (over the MLX stand-in, tests/golden/gen_golden_refmodel.py full) on BASELINE
+    config 1's 128-token prompt and on bench.py's config-2 image request (17 CLIP crops, 2531 tokens).  Every logit of every step
+    within the config's tolerance, every token exact, teacher-forced and free-running."""
+    from golden_inputs import vqa_request
+    from phi_3_vision_mlx_amd.api import load_synthetic
+    g = np.load(GOLDEN + "/ref_model_full.npz")
+    model, proc = load_synthetic(blind_model=name == "c1", tiny=False, seed=0, device="cuda:0", lm_head_spread=float(g["spread"][0]),
+                                 lm_head_seed=int(g[name + "_head_seed"][0]))
+    if name == "c1":
+        inp = {"input_ids": np.load(GOLDEN + "/c1_oracle.npz")["ids"]}
+    else:
+        inp = vqa_request(proc.img_processor, 0)
+        inp["pixel_values"] = torch.from_numpy(inp["pixel_values"]).to("cuda:0")
+    view = {"rel_tol": g[name + "_rel_tol"], "tokens": g[name + "_tokens"], "logits_bf16": g[name + "_logits_bf16"], "margins": g[name + "_margins"]}
+    run_fixture(model, inp, view, "", f"reference-composed full size {name}")
+    del model
+    torch.cuda.empty_cache()
+
+
 def test_reference_choose_fixture():
     """`_choose_from` (phi_3_vision_mlx.py:466-487) under a head whose option margins are clear: the reference's picks."""
     from phi_3_vision_mlx_amd import api
