@@ -234,6 +234,98 @@ def lora_case(out, meta):
     generate_case(r, "lora", out, meta)
 
 
+Q4_CASES = {"q4text": (TINY_PROMPTS[1], None, 4), "q4vis": (VIS_PROMPT, ["sq"], 3)}
+
+
+def q4_case(out, meta):
+    """The reference's 4-bit path end to end: its `_quantize` (phi_3_vision_mlx.py:291-305: `nn.quantize(model, 64, 4)` + save of
+    `quantized_model.safetensors` + config['quantized'] / ['sanitized']) writes the checkpoint from the tiny bf16 directory, its
+    `_load` reads it back (`nn.quantize` BEFORE `load_weights`, :264) and `_generate` runs on `QuantizedLinear` /
+    `QuantizedEmbedding`.  Recorded: which tensors the reference quantises (names, shapes, dtypes, sha256 of every tensor of the
+    file it wrote) and the greedy logits of a text and an image prompt.  The affine group format itself is `weights.mlx_quantize`'s
+    statement of mx.quantize (the stand-in reuses it): what this pins is everything AROUND it -- traversal, naming, file layout,
+    config keys, load order, which layers run quantised (every Linear incl. the ViT's and the projector's, both embeddings and the
+    CLIP position table; not the patch convolution, not the norms)."""
+    import gen_golden_oracle as ggo
+    from safetensors.torch import load_file
+    from phi_3_vision_mlx_amd.weights import mlx_dequantize, mlx_quantize
+    d = tiny_config_dict(vision=True)
+    cfg = make_config(d)
+    w = synth_weights(cfg, seed=0, std_scale=4.0)
+    base = w["lm_head.weight"]
+    mx, phi, loops = ref_env.load_reference()
+    import types
+    phi.Phi3ImageEmbedding.CLIP_VIT_LARGE_PATCH14_336_CONFIG = types.SimpleNamespace(**d["clip"])     # tiny CLIP geometry (as ref_env.load_model)
+    src, dst = os.path.join(TMP, "q4_src"), os.path.join(TMP, "q4_dst")
+    my = Phi3VProcessor(None)
+
+    def q4_head(b, spread, hs):                                     # what the head is after the reference's quantiser: fp32 scale * q + bias
+        return mlx_dequantize(*mlx_quantize(peaked_lm_head(b.to(torch.bfloat16), spread, hs))).float()
+
+    def oracle_weights(path):
+        t = load_file(os.path.join(path, "quantized_model.safetensors"))
+        ow = {}
+        for k, v in t.items():
+            if k.endswith(".scales") or k.endswith(".biases"):
+                continue
+            base_k = k[:-len(".weight")] if k.endswith(".weight") else None
+            if base_k is not None and base_k + ".scales" in t:
+                deq = mlx_dequantize(v, t[base_k + ".scales"], t[base_k + ".biases"])
+                ow[k] = deq.to(torch.bfloat16) if "embed" in k and "vision_embed_tokens.img_projection" not in k and "patch" not in k \
+                    and ("embed_tokens.weight" in k or "position_embedding" in k) else deq      # embeddings leave mx.dequantize as bf16
+            elif "patch_embedding.weight" in k:
+                ow[k] = v.permute(0, 3, 1, 2).contiguous()            # sanitized file: OHWI -> the oracle's OIHW
+            else:
+                ow[k] = v
+        return t, ow
+    for name, (prompt, images, n) in Q4_CASES.items():
+        imgs = [img(i) for i in images] if images else None
+        my_in = my(prompt, imgs) if imgs else my(prompt)
+        # head seed: oracle on the dequantised checkpoint (seed-independent part quantised once), every step clear
+        shutil.rmtree(src, ignore_errors=True), shutil.rmtree(dst, ignore_errors=True)
+        save_safetensors_dir(w, d, src)
+        loops._quantize(from_path=src, to_path=dst)
+        _, ow = oracle_weights(dst)
+        o = orc.OraclePhi3V(cfg, ow, cache_fp32=True)
+        o_in = {k: (torch.from_numpy(np.asarray(v)) if k == "pixel_values" else v) for k, v in my_in.items()}
+        plain = ggo.peaked_lm_head
+        ggo.peaked_lm_head = q4_head
+        try:
+            r = Prefilled(o, o_in, n)
+            r.rel_tol = 0.045
+            hs, _ = search_head([r], base, n, min_distinct=2)
+        finally:
+            ggo.peaked_lm_head = plain
+        # the reference on a checkpoint whose bf16 source carries that head
+        w2 = dict(w)
+        w2["lm_head.weight"] = peaked_lm_head(base, SPREAD, hs)
+        shutil.rmtree(src, ignore_errors=True), shutil.rmtree(dst, ignore_errors=True)
+        save_safetensors_dir(w2, d, src)
+        loops._quantize(from_path=src, to_path=dst)
+        tens, _ = oracle_weights(dst)
+        model, proc = ref_env.load_model(dst, ByteTokenizer(), clip_cfg=d["clip"])
+        rec = ref_env.Recorder(model)
+        loops._generate(rec, proc, prompt, imgs, max_tokens=n, verbose=False, stream=False, mute=True)
+        lgs = torch.stack([c["logits"]._t[:, -1] for c in rec.calls], 1)
+        toks = torch.argmax(lgs.float(), dim=-1)
+        mg = clearance(lgs, row_norms(q4_head(base, SPREAD, hs)), 0.045)
+        assert mg.min().item() > 1.0, f"{name}: not clear under the reference's logits ({mg.tolist()})"
+        out[name + "_head_seed"] = np.asarray([hs], dtype=np.int32)
+        out[name + "_tokens"] = toks.numpy().astype(np.int32)
+        out[name + "_logits_bf16"] = bits(lgs)
+        out[name + "_margins"] = mg.numpy().astype(np.float32)
+        out[name + "_rel_tol"] = np.asarray([0.045], dtype=np.float32)
+        with open(os.path.join(dst, "config.json")) as f:
+            qcfg = json.load(f)
+        meta[name] = {"S": int(np.asarray(my_in["input_ids"]).shape[1]), "steps": n, "images": images,
+                      "config_flags": {k: qcfg.get(k) for k in ("quantized", "sanitized")},
+                      "file": "quantized_model.safetensors",
+                      "tensors": {k: [str(v.dtype).replace("torch.", ""), list(v.shape), hashlib.sha256(v.contiguous().view(torch.uint8).numpy().tobytes()).hexdigest()]
+                                  for k, v in sorted(tens.items())}}
+        nq = sum(1 for k in tens if k.endswith(".scales"))
+        print(f"  {name}: head_seed {hs}, {nq} quantised tensors of {len(tens)}, tokens {toks.tolist()}, min clearance {mg.min().item():.2f}", flush=True)
+
+
 def main():
     t0 = time.time()
     os.makedirs(TMP, exist_ok=True)
@@ -247,6 +339,7 @@ def main():
     for name in ("vis", "visns", "vis2"):
         generate_case(rv, name, out, meta)
     lora_case(out, meta)
+    q4_case(out, meta)
     np.savez_compressed(os.path.join(HERE, "ref_model_tiny.npz"), **out)
     with open(os.path.join(HERE, "ref_model_tiny.json"), "w") as f:
         json.dump(meta, f, indent=1)
@@ -330,7 +423,19 @@ def full():
 
 
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "full":
+    if len(sys.argv) > 1 and sys.argv[1] == "q4":                   # only the 4-bit cases, merged into the existing fixture
+        out, meta = {}, {}
+        q4_case(out, meta)
+        g = dict(np.load(os.path.join(HERE, "ref_model_tiny.npz")))
+        g.update(out)
+        np.savez_compressed(os.path.join(HERE, "ref_model_tiny.npz"), **g)
+        with open(os.path.join(HERE, "ref_model_tiny.json")) as f:
+            m = json.load(f)
+        m.update(meta)
+        with open(os.path.join(HERE, "ref_model_tiny.json"), "w") as f:
+            json.dump(m, f, indent=1)
+        print("merged the q4 cases into ref_model_tiny.npz/.json")
+    elif len(sys.argv) > 1 and sys.argv[1] == "full":
         full()
     else:
         main()

@@ -26,7 +26,8 @@ Two places where MLX's result is implementation-defined get a deterministic defi
       arithmetic and undefined under Metal fast-math.  Here such a row is all zeros.  Valid rows do not depend on the
       choice: pad KEYS always carry -inf, so any FINITE pad-row output gives them exactly zero weight downstream.
   Q9  `mx.argpartition(-x, kth)[:, :kth]` returns the kth smallest in unspecified order; here ordered by (value, index).
-Not implemented (raise): mx.quantize / dequantize, nn.quantize, optimizers, value_and_grad -- off the pinned path.
+mx.quantize / dequantize / quantized_matmul and nn.quantize (QuantizedLinear, QuantizedEmbedding) follow MLX's affine group
+format as `weights.mlx_quantize` restates it.  Not implemented (raise): optimizers, value_and_grad -- off the pinned path.
 """
 import builtins as _b
 import importlib.machinery
@@ -617,7 +618,35 @@ def _unsupported(name):
     return f
 
 
-quantize, dequantize = _unsupported("mx.quantize"), _unsupported("mx.dequantize")
+def _q():
+    """MLX's affine group quantiser lives in the package as data-preparation code (`weights.mlx_quantize` restates mx.quantize's
+    kernel: per group of `group_size` inputs w ~ scale * q + bias, the range end of larger magnitude exact, 32 / bits codes per
+    uint32 with element k at bits [bits * k, bits * (k + 1))); the stand-in reuses it so that there is ONE statement of the format."""
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    from phi_3_vision_mlx_amd import weights
+    return weights
+
+
+def quantize(w, group_size=64, bits=4):
+    packed, scales, biases = _q().mlx_quantize(_arr(w)._t, group_size, bits)
+    return array(packed), array(scales), array(biases)          # (uint32 bit patterns carried in int32)
+
+
+def dequantize(w, scales, biases, group_size=64, bits=4):
+    """scale * q + bias, in the scales' dtype (one rounding for bf16 scales)."""
+    out = _q().mlx_dequantize(_arr(w)._t, _arr(scales)._t, _arr(biases)._t, group_size, bits)
+    return array(out.to(_arr(scales)._t.dtype))
+
+
+def quantized_matmul(x, w, scales, biases, transpose=True, group_size=64, bits=4):
+    """x @ dequantize(w).T with the dequantised values and the accumulation in fp32; result in x.dtype."""
+    wd = _q().mlx_dequantize(_arr(w)._t, _arr(scales)._t, _arr(biases)._t, group_size, bits)
+    xt = _arr(x)._t
+    return array(torch.matmul(xt.float(), wd.t() if transpose else wd).to(xt.dtype))
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -815,11 +844,17 @@ class Linear(Module):
             return addmm(self.bias, x, self.weight.T)
         return matmul(x, self.weight.T)
 
+    def to_quantized(self, group_size=64, bits=4):
+        return QuantizedLinear.from_linear(self, group_size, bits)
+
 
 class Embedding(Module):
     def __init__(self, num_embeddings, dims):
         super().__init__()
         self.weight = zeros((num_embeddings, dims))
+
+    def to_quantized(self, group_size=64, bits=4):
+        return QuantizedEmbedding.from_embedding(self, group_size, bits)
 
     def __call__(self, x):
         return self.weight[x]
@@ -895,8 +930,73 @@ class Dropout(Module):
 
 
 class QuantizedLinear(Module):
-    def __init__(self, *a, **k):
-        raise NotImplementedError("mlx shim: QuantizedLinear is off the pinned path")
+    def __init__(self, input_dims, output_dims, bias=True, group_size=64, bits=4):
+        super().__init__()
+        self.group_size, self.bits = group_size, bits
+        self.weight, self.scales, self.biases = quantize(zeros((output_dims, input_dims)), group_size, bits)
+        if bias:
+            self.bias = zeros((output_dims,))
+
+    def __call__(self, x):
+        y = quantized_matmul(x, self.weight, self.scales, self.biases, True, self.group_size, self.bits)
+        return y + self.bias if "bias" in vars(self) else y
+
+    @classmethod
+    def from_linear(cls, lin, group_size=64, bits=4):
+        out_d, in_d = lin.weight.shape
+        q = cls.__new__(cls)
+        Module.__init__(q)
+        q.group_size, q.bits = group_size, bits
+        q.weight, q.scales, q.biases = quantize(lin.weight, group_size, bits)
+        if "bias" in vars(lin):
+            q.bias = lin.bias
+        return q
+
+
+class QuantizedEmbedding(Module):
+    def __init__(self, num_embeddings, dims, group_size=64, bits=4):
+        super().__init__()
+        self.group_size, self.bits = group_size, bits
+        self.weight, self.scales, self.biases = quantize(zeros((num_embeddings, dims)), group_size, bits)
+
+    def __call__(self, x):
+        idx = _index(x) if isinstance(x, array) else x
+        return dequantize(array(self.weight._t[idx].reshape(-1, self.weight.shape[1])), array(self.scales._t[idx].reshape(-1, self.scales.shape[1])),
+                          array(self.biases._t[idx].reshape(-1, self.biases.shape[1])), self.group_size, self.bits).reshape(*x.shape, -1)
+
+    @classmethod
+    def from_embedding(cls, emb, group_size=64, bits=4):
+        q = cls.__new__(cls)
+        Module.__init__(q)
+        q.group_size, q.bits = group_size, bits
+        q.weight, q.scales, q.biases = quantize(emb.weight, group_size, bits)
+        return q
+
+
+def nn_quantize(model, group_size=64, bits=4, class_predicate=None):
+    """nn.quantize: every module with `to_quantized` (Linear, Embedding) for which the predicate holds is replaced in place."""
+    class_predicate = class_predicate or (lambda _, m: hasattr(m, "to_quantized"))
+
+    def walk(parent, key, v, path):
+        if isinstance(v, Module):
+            if class_predicate(path, v) and hasattr(v, "to_quantized"):
+                new = v.to_quantized(group_size, bits)
+                if isinstance(parent, (list, dict)):
+                    parent[key] = new
+                else:
+                    setattr(parent, key, new)
+                return
+            for k2, u in list(v._public().items()):
+                walk(v, k2, u, f"{path}.{k2}" if path else k2)
+        elif isinstance(v, list):
+            for i, u in enumerate(v):
+                walk(v, i, u, f"{path}.{i}")
+        elif isinstance(v, dict):
+            for k2, u in list(v.items()):
+                walk(v, k2, u, f"{path}.{k2}")
+    for k, v in list(model._public().items()):
+        walk(model, k, v, k)
+    return model
 
 
 def gelu(x):
@@ -986,7 +1086,7 @@ def install():
                   "flatten", "reshape", "transpose", "swapaxes", "pad", "triu", "tril", "where", "sum", "mean", "max", "min", "all",
                   "any", "argmax", "argmin", "argsort", "argpartition", "sort", "exp", "log", "cos", "sin", "sqrt", "rsqrt", "tanh",
                   "erf", "sigmoid", "abs", "square", "maximum", "minimum", "isinf", "isnan", "stop_gradient", "logsumexp", "softmax",
-                  "take", "load", "save_safetensors", "quantize", "dequantize"]
+                  "take", "load", "save_safetensors", "quantize", "dequantize", "quantized_matmul"]
     for n in core_names:
         setattr(core, n, getattr(me, n))
     fast = mk("mlx.core.fast")
@@ -998,11 +1098,11 @@ def install():
     rnd.uniform = lambda low=0.0, high=1.0, shape=(), dtype=float32: array((torch.rand(tuple(shape), generator=_gen) * (high - low) + low).to(dtype.t))
     rnd.normal = lambda shape=(), dtype=float32, loc=0.0, scale=1.0: array((torch.randn(tuple(shape), generator=_gen) * scale + loc).to(dtype.t))
     core.random = rnd
-    for n in ("Module", "Linear", "Embedding", "RMSNorm", "LayerNorm", "Conv2d", "GELU", "Dropout", "QuantizedLinear", "gelu", "gelu_approx",
+    for n in ("Module", "Linear", "Embedding", "RMSNorm", "LayerNorm", "Conv2d", "GELU", "Dropout", "QuantizedLinear", "QuantizedEmbedding", "gelu", "gelu_approx",
               "gelu_fast_approx", "silu", "relu", "log_softmax"):
         setattr(nn, n, getattr(me, n))
     nn.softmax = nn_softmax
-    nn.quantize = _unsupported("nn.quantize")
+    nn.quantize = nn_quantize
     nn.value_and_grad = _unsupported("nn.value_and_grad")
     nn.losses = types.SimpleNamespace(cross_entropy=_unsupported("nn.losses.cross_entropy"))
     nn.functional = types.SimpleNamespace()

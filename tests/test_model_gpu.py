@@ -397,6 +397,9 @@ def head_row_norms(model):
     """fp32 L2 norms of the lm_head rows the model really multiplies by (bf16, or e4m3 x scale for quantize_model)."""
     if "lm_head.weight" in model.w:
         return model.w["lm_head.weight"].float().norm(dim=-1).cpu().clamp_min(1e-30)
+    if "lm_head.weight" in getattr(model, "w4", {}):                 # 4-bit head: the values scale * q + bias the GEMV multiplies by
+        from phi_3_vision_mlx_amd import ops
+        return ops.dequant_q4(*model.w4["lm_head.weight"]).float().norm(dim=-1).cpu().clamp_min(1e-30)
     w8, sc = model.w8["lm_head.weight"]
     return (w8.view(torch.float8_e4m3fn).float().norm(dim=-1) * sc).cpu().clamp_min(1e-30)
 
@@ -548,6 +551,27 @@ def test_reference_model_fixture_full_size(name):
     run_fixture(model, inp, view, "", f"reference-composed full size {name}")
     del model
     torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("name", ["q4text", "q4vis"])
+def test_reference_written_4bit_checkpoint(name, tmp_path):
+    """Row f4 on the GPU against the reference's own 4-bit writer / reader: the checkpoint `_quantize` wrote (rebuilt here bit for
+    bit, every tensor's sha256 checked: tests/golden/q4_ckpt.py) is loaded by `api._load` -- decoder projections and lm_head stay
+    4-bit (`p3v_gemv_q4` / `p3v_dequant_q4`), embeddings, ViT and projector are dequantised -- and must reproduce what the
+    reference's `_load` + `_generate` computed on `QuantizedLinear` / `QuantizedEmbedding`: logits inside 4.5 %, tokens exact."""
+    import q4_ckpt
+    from golden_inputs import make_image
+    from phi_3_vision_mlx_amd import api
+    g, meta = _ref_fixture()
+    q4_ckpt.build(str(tmp_path), meta[name], g[name + "_head_seed"][0], float(g["spread"][0]))
+    model, proc = api._load(model_path=str(tmp_path), device="cuda:0")
+    assert len(model.w4) == 2 * 4 + 1 and "lm_head.weight" not in model.w
+    if name == "q4text":
+        inputs = proc(REF_PROMPTS[1])
+    else:
+        inputs = proc(REF_CASES["vis"][1], [make_image(*REF_IMAGES["sq"])])
+    view = {"rel_tol": g[name + "_rel_tol"], "tokens": g[name + "_tokens"], "logits_bf16": g[name + "_logits_bf16"], "margins": g[name + "_margins"]}
+    run_fixture(model, inputs, view, "", f"reference 4-bit checkpoint {name}")
 
 
 def test_reference_choose_fixture():

@@ -146,6 +146,52 @@ def test_full_size_oracle_fixtures_equal_the_reference_composed_ones():
         assert (g[name + "_margins"][:, :n] > 1.0).all()
 
 
+@pytest.mark.parametrize("name", ["q4text", "q4vis"])
+def test_reference_written_4bit_checkpoint_loader_and_oracle(fx, tmp_path, name):
+    """Row f4 against the reference's own writer and reader: `_quantize` (phi_3_vision_mlx.py:291-305) wrote the checkpoint, `_load`
+    (`nn.quantize` before `load_weights`, :264) read it back and `_generate` ran on it (fixture).  Here: (1) the same bytes come out
+    of the seeded weights + `weights.mlx_quantize` (sha256 of every tensor of the reference-written file); (2) the build's loader
+    takes the directory: decoder projections + lm_head stay 4-bit (`Q4Weight`), both embeddings, the CLIP position table, the ViT's
+    and the projector's Linears are dequantised, the sanitised patch convolution is permuted back; (3) the oracle on the
+    dequantised values (fp32 scale * q + bias, what MLX's quantised matmul accumulates; bf16 for embedding rows) reproduces the
+    reference's logits -- bit for bit on the text prompt, to 2^-6 of the row's largest logit on the image prompt (fp32 tower)."""
+    import q4_ckpt
+    from phi_3_vision_mlx_amd.weights import Q4Weight, load_safetensors_dir, mlx_dequantize
+    g, meta = fx
+    cfg_d, tensors = q4_ckpt.build(str(tmp_path), meta[name], g[name + "_head_seed"][0], float(g["spread"][0]))
+    cfg = make_config(cfg_d)
+    assert cfg.quantized == {"group_size": 64, "bits": 4} and cfg.sanitized is True
+    loaded = load_safetensors_dir(str(tmp_path), cfg)
+    q4 = {k for k, v in loaded.items() if isinstance(v, Q4Weight)}
+    assert q4 == {k for k in loaded if k == "lm_head.weight" or (k.startswith("model.layers.") and k.endswith("_proj.weight"))}
+    assert loaded["model.embed_tokens.weight"].dtype == torch.bfloat16
+    pe = "model.vision_embed_tokens.img_processor.vision_model.embeddings.patch_embedding.weight"
+    assert tuple(loaded[pe].shape) == (128, 3, 14, 14)
+    ow = {}
+    for k, v in loaded.items():                                   # the oracle's weights: exact dequantised values where MLX multiplies by them
+        base = k[:-len(".weight")]
+        if isinstance(v, Q4Weight):
+            ow[k] = mlx_dequantize(*v)
+        elif base + ".scales" in tensors and "embed_tokens" not in k and "position_embedding" not in k:
+            ow[k] = mlx_dequantize(tensors[k], tensors[base + ".scales"], tensors[base + ".biases"])
+        else:
+            ow[k] = v
+    oracle = orc.OraclePhi3V(cfg, ow, cache_fp32=True)
+    blind, prompt, images = (None, TINY_PROMPTS[1], None) if name == "q4text" else (None, VIS_PROMPT, ["sq"])
+    proc = Phi3VProcessor(None)
+    imgs = [make_image(*IMAGES[i]) for i in images] if images else None
+    inp = proc(prompt, imgs) if imgs else proc(prompt)
+    n = g[name + "_tokens"].shape[1]
+    o_in = {k: (torch.from_numpy(np.asarray(v)) if k == "pixel_values" else v) for k, v in inp.items()}
+    toks, lgs = orc.greedy_generate(oracle, o_in, n, stop_on_eos=False)
+    assert np.array_equal(toks.numpy(), g[name + "_tokens"])
+    ref = _from_bits(g[name + "_logits_bf16"]).float()
+    if images is None:
+        assert np.array_equal(_bits(lgs), g[name + "_logits_bf16"]), "4-bit text path: oracle not bit-exact to the reference's QuantizedLinear run"
+    else:
+        assert ((lgs.float() - ref).abs() / (2.0 ** -6 * ref.abs().amax(-1, keepdim=True))).max().item() <= 1.0     # <= 2-3 bf16 ulps of the largest logit
+
+
 class Rec:
     """Records every call of the oracle model the way tests/golden/ref_env.Recorder records the reference's."""
 
