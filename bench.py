@@ -382,6 +382,7 @@ def main():
     barrier()
     gen_elapsed = time.perf_counter() - t0
     gen_tps = (gen_len - 1) / gen_elapsed
+    local_elapsed = elapsed                                        # this rank's own span (the reported one is the max over ranks)
     if world > 1:
         t = torch.tensor([elapsed, prefill, gen_elapsed], device="cpu" if share else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -397,7 +398,7 @@ def main():
         one = torch.ones(1, device="cpu" if share else dev)
         dist.all_reduce(one)
         per_rank = [torch.zeros(1, device="cpu" if share else dev) for _ in range(world)]
-        dist.all_gather(per_rank, torch.tensor([B * args.steps / elapsed], device="cpu" if share else dev))
+        dist.all_gather(per_rank, torch.tensor([B * args.steps / local_elapsed], device="cpu" if share else dev))
         rccl = {"backend": dist.get_backend(), "ranks": int(one.item()), "world_size": dist.get_world_size(),
                 "per_rank_tokens_per_s": [round(float(t.item()), 2) for t in per_rank]}
 
