@@ -389,7 +389,7 @@ def main():
         elapsed, prefill, gen_elapsed = t.tolist()
         gen_tps = (gen_len - 1) / gen_elapsed
         hist = cache[0].state.graphs["greedy"]["history"]
-        hist = hist.cpu() if share else hist
+        hist = hist.cpu() if share else hist.to(dev)                # (the graph keeps it in pinned host memory)
         gathered = [torch.empty_like(hist) for _ in range(world)] if rank == 0 else None
         dist.gather(hist, gathered, dst=0)                        # token gather over RCCL (request boundary only)
     tokens_per_s = world * B * args.steps / elapsed                # device rate: K graph replays between two syncs

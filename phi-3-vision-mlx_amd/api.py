@@ -321,17 +321,24 @@ def greedy_loop(model, token, cache, n_steps, streamer, token_stopper, logit_sto
             raise RuntimeError(f"device step failed: NaN logits (token ids {rows})")
         streamer(rows)
         return token_stopper(rows)
+    st = cache[0].state
     for i in range(n_steps):
         _, token = graph_step(token, cache)                         # enqueue step i
-        # stream-ordered copy, before the next replay overwrites the buffer.  (Measured alternative: the token copied from the
-        # graph's history buffer on a SIDE stream, so that the replays run back to back -- the cross-stream events cost more
-        # than the ~18 us of idle GPU the in-line copy leaves per step: 500 against 550 tok/s at config 2.)
-        host[i & 1].copy_(token.reshape(-1), non_blocking=True)
+        g = st.graphs["greedy"]
+        k, hist = g["n_replays"] - 1, g["history"]
         ev = torch.cuda.Event()
-        ev.record()
+        if k < hist.shape[1] and not hist.is_cuda:
+            # the step wrote its tokens into pinned host memory itself (history[:, k], model._build_decode_graph): nothing to copy,
+            # the replays run back to back (an in-line D2H copy node costs the step ~18 us of idle GPU: 550 -> 556 tok/s at config 2)
+            ev.record()
+            src = hist[:, k]
+        else:
+            host[i & 1].copy_(token.reshape(-1), non_blocking=True) # stream-ordered copy, before the next replay overwrites the buffer
+            ev.record()
+            src = host[i & 1]
         if pending is not None and take(pending):                   # host work of step i - 1 under the GPU's step i
             return token
-        pending = (ev, host[i & 1])
+        pending = (ev, src)
     if pending is not None:
         take(pending)
     return token

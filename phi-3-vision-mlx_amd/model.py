@@ -551,7 +551,9 @@ class Phi3VModel:
         cfg, w, B, dev = self.cfg, self.w, st.B, self.device
         g = dict(tok=torch.zeros((B,), dtype=I32, device=dev), d_past=torch.zeros((1,), dtype=I32, device=dev),
                  d_step=torch.zeros((1,), dtype=I32, device=dev),
-                 history=torch.zeros((B, max(1, st.max_tokens) + 1), dtype=I32, device=dev),
+                 # the step's tokens land in PINNED HOST memory straight from `k_step_end` (one 4-byte store per row and step):
+                 # the host loop reads them after the step's event, no D2H copy node sits between two replays (api.greedy_loop)
+                 history=torch.zeros((B, max(1, st.max_tokens) + 1), dtype=I32).pin_memory(),
                  x=torch.empty((B, cfg.hidden_size), dtype=BF16, device=dev),
                  logits=torch.empty((B, cfg.vocab_size), dtype=BF16, device=dev),
                  next_tok=torch.zeros((B,), dtype=I32, device=dev), ticket=torch.zeros((1,), dtype=I32, device=dev))
