@@ -462,11 +462,11 @@ def main():
     if args.config4:
         workload = (f"BASELINE configs[3], one GPU's share per rank: {B} requests = {n_crops // 17} single-image VQA (2531 tokens) + "
                     f"{B - n_crops // 17} text prompts (16..256 tokens) as one left-padded batch; greedy, EOS suppressed")
-        metric = "decode tokens/sec (+ prefill ms), Phi-3-Vision bf16, batched mixed image+text generate (config 4 share)"
+        metric = "decode tokens/sec through generate()'s loop (reference-defined; bare graph replays: device_rate) + prefill ms, Phi-3-Vision bf16, batched mixed image+text generate (config 4 share)"
     else:
         workload = ("Phi-3-Vision single 336x336 image VQA (BASELINE configs[1]); 17 crops, "
                     f"{n_img} image tokens + 22 text tokens, prompt {S}, B=1 per GPU, greedy, EOS suppressed")
-        metric = "decode tokens/sec (+ prefill ms), Phi-3-Vision bf16 1-image VQA"
+        metric = "decode tokens/sec through generate()'s loop (reference-defined; bare graph replays: device_rate) + prefill ms, Phi-3-Vision bf16 1-image VQA"
     if args.config5:
         workload += ("; BASELINE configs[4]: e4m3 decoder weights (per-row scales), " +
                      ("bf16 activations (weight-only)" if args.fp8_weight_only else "e4m3 activations in the prompt-sized projections (fp8 MFMA)") +
