@@ -311,7 +311,7 @@ def greedy_loop(model, token, cache, n_steps, streamer, token_stopper, logit_sto
                 break
         return token
     B = token.shape[0]
-    host = [torch.empty((B,), dtype=torch.int32).pin_memory() for _ in range(2)]
+    host = []                                                       # pinned staging buffers of the copy fallback (rarely needed)
     pending = None                                                  # (event, pinned buffer) of the step the host has not read yet
 
     def take(p):
@@ -332,7 +332,9 @@ def greedy_loop(model, token, cache, n_steps, streamer, token_stopper, logit_sto
             # the replays run back to back (an in-line D2H copy node costs the step ~18 us of idle GPU: 550 -> 556 tok/s at config 2)
             ev.record()
             src = hist[:, k]
-        else:
+        else:                                                       # (history full, or kept on the device by another model class)
+            if not host:
+                host = [torch.empty((B,), dtype=torch.int32).pin_memory() for _ in range(2)]
             host[i & 1].copy_(token.reshape(-1), non_blocking=True) # stream-ordered copy, before the next replay overwrites the buffer
             ev.record()
             src = host[i & 1]
