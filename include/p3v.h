@@ -222,8 +222,16 @@ typedef struct {
   int merge_in_launch; /* nonzero: the split-KV partials are merged by the last split of each (b, head) INSIDE the attention
                           launch; 0 = a separate merge launch.  Either way `ws` must hold 0xFF in every byte before its first use
                           (hipMemset) and every launch leaves it so: a partial word is valid when it is not the all-ones pattern */
+  /* optional (round 4): the layer's o_proj + residual in the SAME launch (phi.py:460, 483), for shapes
+   * p3v_attention_decode_can_fuse_oproj() accepts.  o_proj_w [o_n, n_heads * hd] bf16; o_proj_x [o_n] bf16 is the residual row,
+   * updated in place: x += bf16(W_o . attention output), bit-identical to p3v_gemv with P3V_EPI_RESID_BF16 on `out`.  `out` must
+   * hold 0xFF in every byte when the launch starts (the projecting workgroups poll its words); `o_rearm` (n_heads * hd bf16) is
+   * set to 0xFF by the launch: callers alternate two output buffers between consecutive layers.  NULL o_proj_w = plain attention. */
+  const uint16_t* o_proj_w; uint16_t* o_proj_x; uint16_t* o_rearm; int o_n;
 } p3v_attn_decode_args_t;
 int p3v_attention_decode(const p3v_attn_decode_args_t* args /* host */, void* stream);
+/* 1 when the fused attention + o_proj launch takes this shape on this device (host query, no launch) */
+int p3v_attention_decode_can_fuse_oproj(int B, int L, int n_heads, int hd, int n_split, int cache_t, int o_n, int merge_in_launch);
 /* cos/sin rows of positions [past, past+L) of each batch row ([B, tab_t, half] tables) -> [B, L, half] */
 int p3v_stage_rope(const float* cos_t, const float* sin_t, int past, const int32_t* d_past,
                    float* cos_out, float* sin_out, int B, int L, int tab_t, int half_dim, void* stream);

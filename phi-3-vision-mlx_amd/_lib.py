@@ -60,7 +60,8 @@ class AttnDecArgs(C.Structure):
     _fields_ = [("qkv", vp), ("cos_t", vp), ("sin_t", vp), ("k_cache", vp), ("v_cache", vp), ("out", vp),
                 ("pad_len", vp), ("d_past", vp), ("ws", vp),
                 ("B", i32), ("L", i32), ("n_heads", i32), ("n_kv", i32), ("hd", i32), ("past", i32),
-                ("cache_t", i32), ("rope_bstride", i32), ("n_split", i32), ("scale", f32), ("merge_in_launch", i32)]
+                ("cache_t", i32), ("rope_bstride", i32), ("n_split", i32), ("scale", f32), ("merge_in_launch", i32),
+                ("o_proj_w", vp), ("o_proj_x", vp), ("o_rearm", vp), ("o_n", i32)]       # optional fused o_proj + residual
 
 
 class AttnDecQ8Args(C.Structure):
@@ -91,6 +92,7 @@ SIGNATURES = {
     "p3v_rope_kv_append": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, i32, i32, i32, i32, f32, vp]),
     "p3v_attention": (i32, [C.POINTER(AttnArgs), vp]),
     "p3v_attention_decode": (i32, [C.POINTER(AttnDecArgs), vp]),
+    "p3v_attention_decode_can_fuse_oproj": (i32, [i32, i32, i32, i32, i32, i32, i32, i32]),
     "p3v_kv_quantize": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "p3v_kv_dequantize": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "p3v_attention_decode_q8": (i32, [C.POINTER(AttnDecQ8Args), vp]),

@@ -20,6 +20,7 @@
 #include <stdlib.h>
 
 #include "p3v_common.h"
+#include "p3v_gemv3_body.h"      // dot8: the fused o_proj of k_attn_decode128_o repeats k_gemv3's arithmetic exactly
 
 struct AttnP {
   const bf16_t* q; const bf16_t* k_past; const bf16_t* v_past; const bf16_t* k_new; const bf16_t* v_new;
@@ -1355,6 +1356,11 @@ struct AttnDecP {
   int chunk, grp, grp_magic;   // host-side: keys per split (multiple of 64), heads per kv head and ceil(2^16 / grp)
   int merge;                   // nonzero: the last split of a (b, head) merges the partials itself (split_merge)
   bf16_t* out;                 // [B, L, nh * 96] (fused merge only)
+  // fused o_proj + residual (k_attn_decode128_o only; B = L = 1, nh * 96 = 3072): see attn_decode_body128<true>
+  const bf16_t* o_w;           // o_proj weight [o_n, nh * 96]
+  bf16_t* o_x;                 // residual stream row [o_n]: x += bf16(W_o . attention output), in place
+  bf16_t* o_rearm;             // the OTHER attention-output buffer: set to the all-ones sentinel by this launch
+  int o_n;
 };
 
 // ---- fused split-KV merge ("last workgroup merges") without flags.  `ws` holds the SENTINEL bit pattern (all ones: a
@@ -1391,7 +1397,7 @@ __device__ __forceinline__ bool is_sentinel(float v) { return __builtin_bit_cast
 #define SPLIT_MERGE_SCRATCH(NT) ((NT) / 64 * 130 + 2)          // floats: pm[G], pl[G], part[G][128], timeout flag
 template <int NT>
 __device__ __forceinline__ void split_merge(float* base0, bf16_t* out0, size_t out_qstride, int L, int n_split,
-                                            const float* own, float* scratch) {
+                                            const float* own, float* scratch, bool wt_out = false) {
   constexpr int HD = 96, G = NT / 64;
   float* pm = scratch;
   float* pl = scratch + G;
@@ -1449,7 +1455,28 @@ __device__ __forceinline__ void split_merge(float* base0, bf16_t* out0, size_t o
       part[grp][d0] = a0;
       if (two) part[grp][d0 + 64] = a1;
       __syncthreads();
-      if (t < HD) {
+      if (wt_out) {
+        // consumers in the SAME launch poll these words (fused o_proj): same arithmetic per element, two elements per thread,
+        // one write-through 4-byte store.  (Writing four copies of the row for the consumers to spread over -- they all re-read
+        // it past the caches -- changed nothing measurable: tools/attn_o_timeline.py.)
+        if (t < HD / 2) {
+          const bool poison = *s_timeout != 0;
+          float M = pm[0];
+#pragma unroll
+          for (int k = 1; k < G; ++k) M = fmaxf(M, pm[k]);
+          const float Mu = M == -INFINITY ? 0.f : M;
+          float acc0 = 0.f, acc1 = 0.f, lsum = 0.f;
+#pragma unroll
+          for (int k = 0; k < G; ++k) {
+            const float c = __builtin_amdgcn_exp2f(pm[k] - Mu);
+            acc0 += c * part[k][2 * t];
+            acc1 += c * part[k][2 * t + 1];
+            lsum += c * pl[k];
+          }
+          const uint32_t wv = poison ? 0x7fc07fc0u : pack_bf16x2(lsum > 0.f ? acc0 / lsum : 0.f, lsum > 0.f ? acc1 / lsum : 0.f);
+          __hip_atomic_store((uint32_t*)(out0 + (size_t)q * out_qstride) + t, wv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      } else if (t < HD) {
         const bool poison = *s_timeout != 0;
         float M = pm[0];
 #pragma unroll
@@ -1808,6 +1835,18 @@ __device__ __forceinline__ void attn_decode_body(const AttnDecP& p, const int bx
 // compiler the LDS accesses that do not depend on the tile (inline asm): Q is rotated, published and fetched while the tile
 // is in flight, S^T and the softmax start when the wave's own K slice (its six oldest DMAs, vmcnt(6)) is there and run
 // while the V^T tile is still landing.  10.9 -> 10.6 us isolated, 11.1 -> 10.65 us in the decode step.
+// FO (k_attn_decode128_o; B = L = 1, every workgroup of the launch resident at once): the layer's o_proj + residual rides in the
+// same launch.  The first o_n / 8 non-merging workgroups each own four row PAIRS of W_o (one per wave): once their attention tile
+// is consumed they request those rows (12 x 16 bytes per lane, non-temporal -- HBM is otherwise idle while the splits are merged),
+// store their partial, then poll the merged attention output words (all-ones sentinel, as the split merge polls its partials; the
+// merging workgroups publish them with write-through stores) and finish  x += bf16(W_o . o)  with EXACTLY k_gemv3<1, 1, 6>'s
+// arithmetic (lane l holds chunks l, l + 64, ..; dot8 in chunk order; DPP wave sum; resid + bf16 round), so the step's results do
+// not depend on whether the projection was fused.  One launch (~5 us) and its boundary leave the layer.  The attention output
+// lives in two buffers used by alternate layers: a launch re-arms the one it does not use.
+#ifndef P3V_FO_SLEEP
+#define P3V_FO_SLEEP 4
+#endif
+template <bool FO = false>
 __device__ __forceinline__ void attn_decode_body128(const AttnDecP& p, const int bx, const int by, const int bz, unsigned char* KV) {
   constexpr int TK = 128, WK = 32, HD = 96, KROW = HD * 2, VROWB = TK * 2, NKS = 3, NDT = 6, CPR = 12;
   constexpr int KS_BYTES = WK * KROW;                          // 6 KiB per wave = 16 x 96 fp32: the wave's O partial parks here
@@ -2027,6 +2066,19 @@ __device__ __forceinline__ void attn_decode_body128(const AttnDecP& p, const int
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __syncthreads();
   TMARK(2);
+  // fused o_proj: this wave's row pair is requested once the partial is stored (below): requested here, 18.9 MB of weight
+  // loads compete with the other workgroups' K/V tiles and the whole attention phase runs 0.6 us later (tools/attn_o_timeline.py)
+  u32x4_t ow[2][6];
+  uint32_t ores = 0;
+  const int o_wl = by * (p.n_split - 1) + bx;                  // rank among the non-merging workgroups
+  const bool o_worker = FO && !merger && bx < p.n_split - 1 && o_wl * 8 < p.o_n;
+  const int o_u = o_wl * 4 + wave;                             // row pair (2 o_u, 2 o_u + 1)
+  if (FO) {
+    if (bx == 0 && by == 0) {                                  // re-arm the other layer parity's buffer (nobody reads it in this launch)
+      uint32_t* ra = (uint32_t*)p.o_rearm;
+      for (int i = tid; i < p.nh * HD / 2; i += 256) ra[i] = 0xffffffffu;
+    }
+  }
   if (qvalid) {
     float* Ow = (float*)kslice + qi * HD;
 #pragma unroll
@@ -2058,14 +2110,91 @@ __device__ __forceinline__ void attn_decode_body128(const AttnDecP& p, const int
     }
   }
   TMARK(3);
+  if (FO) {
+    if (o_worker) {
+      const u32x4_t* w0 = (const u32x4_t*)(p.o_w + (size_t)(2 * o_u) * (p.nh * HD)) + lane;
+      const u32x4_t* w1 = (const u32x4_t*)(p.o_w + (size_t)(2 * o_u + 1) * (p.nh * HD)) + lane;
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        ow[0][j] = __builtin_nontemporal_load(w0 + j * 64);
+        ow[1][j] = __builtin_nontemporal_load(w1 + j * 64);
+      }
+      ores = *(const uint32_t*)(p.o_x + 2 * o_u);
+    }
+  }
   if (merger)
     split_merge<256>(p.ws + ((size_t)b * p.nh + head) * p.n_split * 16 * (HD + 2), p.out + (size_t)b * p.L * (p.nh * HD) + head * HD,
-                     (size_t)p.nh * HD, p.L, p.n_split, own, (float*)vtile);
+                     (size_t)p.nh * HD, p.L, p.n_split, own, (float*)vtile, FO);
+  if (FO && o_worker) {                                        // (workgroup-uniform)
+    // Wait for the merged attention output.  1536 waves polling all 1536 words would flood the memory side with uncached
+    // 4-byte loads and starve the very workgroups that produce them (measured: every wave timed out); so ONE wave per
+    // workgroup watches one word per head (the last word each merging workgroup stores) and sleeps between looks, the others
+    // wait at the barrier; then the four waves fetch a quarter of the vector each into LDS (every wave fetching all of it: 18 MB
+    // of uncached reads out of one 6 KB region, +2 us), re-fetching the rare straggler word.
+    __shared__ int o_timeout;
+    const uint32_t* src = (const uint32_t*)p.out;
+    if (wave == 0) {
+      bool to = false;
+      for (unsigned tries = 0;; ++tries) {
+        const uint32_t c = lane < p.nh ? __hip_atomic_load(src + lane * (HD / 2) + HD / 2 - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+        if (!__any((c & 0xffffu) == 0xffffu || (c >> 16) == 0xffffu)) break;
+        if (tries >= (1u << 16)) { to = true; break; }
+        __builtin_amdgcn_s_sleep(P3V_FO_SLEEP);
+      }
+      if (lane == 0) o_timeout = to;
+    }
+    TMARK(12);
+    __syncthreads();
+    // every wave fetches a quarter of the vector (6 words per lane) into LDS, re-fetching the rare straggler word
+    uint32_t* xs = (uint32_t*)KV;                              // the K/V tiles are dead by now (barrier above)
+    bool timeout = o_timeout != 0;
+    {
+      const int NW = p.nh * HD / 2 / 4;                        // words per wave: 384
+      uint32_t xv[6];
+      for (unsigned tries = 0; !timeout; ++tries) {
+        bool bad = false;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) xv[j] = __hip_atomic_load(src + wave * NW + j * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int j = 0; j < 6; ++j) bad |= (xv[j] & 0xffffu) == 0xffffu || (xv[j] >> 16) == 0xffffu;
+        if (!__any(bad)) break;
+        if (tries >= (1u << 12)) timeout = true;
+        __builtin_amdgcn_s_sleep(2);
+      }
+#pragma unroll
+      for (int j = 0; j < 6; ++j) xs[wave * NW + j * 64 + lane] = xv[j];
+      if (timeout && lane == 0) o_timeout = 1;
+    }
+    __syncthreads();
+    timeout = o_timeout != 0;
+    u32x4_t xa[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) xa[j] = ((const u32x4_t*)xs)[j * 64 + lane];
+    TMARK(13);
+    float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      a0 = dot8(ow[0][j], xa[j], a0);
+      a1 = dot8(ow[1][j], xa[j], a1);
+    }
+    a0 = wave_sum(a0);
+    a1 = wave_sum(a1);
+    if (lane == 0) {
+      const float v0 = bf16lo(ores) + bf16_round(a0), v1 = bf16hi(ores) + bf16_round(a1);
+      *(uint32_t*)(p.o_x + 2 * o_u) = timeout ? 0x7fc07fc0u : pack_bf16x2(v0, v1);     // NaN: loud (api._rows raises)
+    }
+    TMARK(14);
+  }
 }
 
 __global__ void __launch_bounds__(256) k_attn_decode128(AttnDecP p) {
   __shared__ __attribute__((aligned(1024))) unsigned char KV[4 * 6144 + 96 * 256];   // [K slice x 4 | V^T tile] = 48 KiB
-  attn_decode_body128(p, blockIdx.x, blockIdx.y, blockIdx.z, KV);
+  attn_decode_body128<false>(p, blockIdx.x, blockIdx.y, blockIdx.z, KV);
+}
+
+__global__ void __launch_bounds__(256) k_attn_decode128_o(AttnDecP p) {            // + the layer's o_proj + residual (body128<true>)
+  __shared__ __attribute__((aligned(1024))) unsigned char KV[4 * 6144 + 96 * 256];
+  attn_decode_body128<true>(p, blockIdx.x, blockIdx.y, blockIdx.z, KV);
 }
 
 __global__ void __launch_bounds__(256) k_attn_decode(AttnDecP p) {
@@ -2333,6 +2462,23 @@ extern "C" int p3v_debug_read(unsigned long long* out) {
 }
 #endif
 
+// The fused form needs: one row, one new token, a 3072-wide attention output (k_gemv3<1, 1, 6>'s shape), the 128-key plan with the
+// in-launch merge, enough non-merging workgroups for the o_n / 8 row-pair quartets, and EVERY workgroup of the launch resident at
+// once (3 per CU) -- the polling workgroups then cannot keep a producer from being scheduled.
+extern "C" int p3v_attention_decode_can_fuse_oproj(int B, int L, int n_heads, int hd, int n_split, int cache_t, int o_n, int merge_in_launch) {
+  if (B != 1 || L != 1 || hd != 96 || n_heads * hd != 3072 || o_n <= 0 || o_n % 8 || !merge_in_launch) return 0;
+  if (!(n_split * 128 >= cache_t && cache_t % 128 == 0 && n_split * 64 < cache_t) || n_split < 2) return 0;
+  if ((long)(n_split - 1) * n_heads * 8 < o_n) return 0;
+  static int n_cu = 0;
+  if (!n_cu) {
+    int dev = 0;
+    hipDeviceProp_t pr;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess) return 0;
+    n_cu = pr.multiProcessorCount;
+  }
+  return (long)B * n_heads * n_split <= 3L * n_cu;
+}
+
 extern "C" int p3v_attention_decode(const p3v_attn_decode_args_t* a, void* stream) {
   if (!a || !a->qkv || !a->cos_t || !a->sin_t || !a->k_cache || !a->v_cache || !a->out || !a->ws) return P3V_ERR_ARG;
   if (a->hd != 96) return P3V_ERR_UNSUPPORTED;
@@ -2342,9 +2488,17 @@ extern "C" int p3v_attention_decode(const p3v_attn_decode_args_t* a, void* strea
   const int chunk = ((a->cache_t + a->n_split - 1) / a->n_split + 63) & ~63;
   AttnDecP p = {a->qkv, a->cos_t, a->sin_t, a->k_cache, a->v_cache, a->pad_len, a->d_past, a->ws,
                 a->B, a->L, a->n_heads, a->n_kv, a->past, a->cache_t, a->rope_bstride, a->n_split, a->scale,
-                chunk, grp, (65536 + grp - 1) / grp, a->merge_in_launch, (bf16_t*)a->out};
+                chunk, grp, (65536 + grp - 1) / grp, a->merge_in_launch, (bf16_t*)a->out,
+                a->o_proj_w, (bf16_t*)a->o_proj_x, (bf16_t*)a->o_rearm, a->o_n};
   hipStream_t s = (hipStream_t)stream;
   const dim3 grid(a->n_split, a->n_heads, a->B);
+  if (a->o_proj_w) {                                           // attention + o_proj + residual in one launch
+    if (!p3v_attention_decode_can_fuse_oproj(a->B, a->L, a->n_heads, a->hd, a->n_split, a->cache_t, a->o_n, a->merge_in_launch)) return P3V_ERR_UNSUPPORTED;
+    if (!a->o_proj_x || !a->o_rearm || ((uintptr_t)a->o_proj_w | (uintptr_t)a->o_proj_x | (uintptr_t)a->o_rearm) & 15) return P3V_ERR_ARG;
+    hipLaunchKernelGGL(k_attn_decode128_o, grid, dim3(256), 0, s, p);
+    P3V_CHECK_LAUNCH();
+    return P3V_OK;
+  }
   if (a->n_split * 64 >= a->cache_t) hipLaunchKernelGGL(k_attn_decode, grid, dim3(256), 0, s, p);
   else if (a->n_split * 128 >= a->cache_t && a->cache_t % 128 == 0) hipLaunchKernelGGL(k_attn_decode128, grid, dim3(256), 0, s, p);   // 128-key tiles
   else hipLaunchKernelGGL(k_attn_decode_stream<64>, grid, dim3(64), 0, s, p);

@@ -426,6 +426,19 @@ class Phi3VModel:
             h=torch.empty((M, H), dtype=BF16, device=dev), n_split=0, ws=None)
         return bufs
 
+    def _plan_fused_oproj(self, bufs, B, L, T):
+        """B = L = 1 decode on plain bf16 weights: attention + o_proj + residual as ONE launch per layer (k_attn_decode128_o,
+        p3v_attention.hip) where the library takes the shape.  The attention output then lives in two buffers that alternate
+        layers use, both all-ones (= "not written yet") between launches; P3V_ATTN_FUSE_OPROJ=0 switches it off."""
+        cfg = self.cfg
+        ok = (os.environ.get("P3V_ATTN_FUSE_OPROJ", "1") != "0" and B == 1 and L == 1 and bufs.get("attn_merge", False)
+              and not self.adapters and not self.w8 and not self.w4
+              and ops.attention_decode_can_fuse_oproj(B, L, cfg.num_attention_heads, self.hd, bufs["n_split"], T, cfg.hidden_size, True))
+        bufs["fuse_o"] = bool(ok)
+        if ok:
+            for k in ("o_f", "o_f2"):                            # all-ones = "not written yet"
+                bufs[k] = torch.full((1, cfg.num_attention_heads * self.hd), -1, dtype=torch.int16, device=self.device).view(BF16)
+
     def _split_plan(self, bufs, B, L, T, quantized=False, serving=False):
         """Split-KV plan for the decode-shaped attention (L <= 16): enough blocks to fill 256 CUs.
         serving: the plan is for a slot state of the continuous-batching engine (a long-lived server) -- the in-launch merge is
@@ -483,6 +496,8 @@ class Phi3VModel:
             bufs = self._alloc_bufs(B, L)
             self._split_plan(bufs, B, L, st.Tp, st.quantized)     # the CAPACITY, as the captured graph plans: same kernel, same
                                                                 # split boundaries -> eager and replayed steps agree bit for bit
+            if L <= ops.L.DECODE_MAX_L and not st.quantized and n_beam == 1:
+                self._plan_fused_oproj(bufs, B, L, st.Tp)
         q, o, qkv, a, h, n_split, ws = (bufs[k] for k in ("q", "o", "qkv", "a", "h", "n_split", "ws"))
         if st.quantized and n_beam > 1:
             raise NotImplementedError("Beam Search is not yet compatible with Quantized Cache")       # as phi.py:525
@@ -521,9 +536,17 @@ class Phi3VModel:
                     rc, rs, rb = st.cos[:, past:], st.sin[:, past:], st.T
                 # (captured step: `past` is read from d_past; the host value passed along is a LOWER BOUND of it -- the kernel fetches
                 #  tiles below it at once and lets the others wait for the length, so tiles beyond the live keys cost nothing)
-                ops.attention_decode(qkv, rc, rs, rb, st.k[i], st.v[i], o, B, L, nh, nkv, hd, scale,
-                                     past if d_past is None else bufs.get("past_lb", -1), st.Tp, ws, n_split,
-                                     pad_len=st.pad_len, d_past=d_past, merge_in_launch=bufs.get("attn_merge", False))
+                fuse_o = bufs.get("fuse_o", False)
+                if fuse_o:                                      # + o_proj + residual in the same launch: x += bf16(W_o . o)
+                    o_i, o_other = (bufs["o_f"], bufs["o_f2"]) if i % 2 == 0 else (bufs["o_f2"], bufs["o_f"])
+                    ops.attention_decode(qkv, rc, rs, rb, st.k[i], st.v[i], o_i, B, L, nh, nkv, hd, scale,
+                                         past if d_past is None else bufs.get("past_lb", -1), st.Tp, ws, n_split,
+                                         pad_len=st.pad_len, d_past=d_past, merge_in_launch=True,
+                                         o_proj_w=w[p + "self_attn.o_proj.weight"], o_proj_x=x, o_rearm=o_other)
+                else:
+                    ops.attention_decode(qkv, rc, rs, rb, st.k[i], st.v[i], o, B, L, nh, nkv, hd, scale,
+                                         past if d_past is None else bufs.get("past_lb", -1), st.Tp, ws, n_split,
+                                         pad_len=st.pad_len, d_past=d_past, merge_in_launch=bufs.get("attn_merge", False))
             else:
                 # queries leave the RoPE kernel multiplied by scale * log2(e) (before their one rounding to bf16, as
                 # phi.py:454 scales q before the product): the prefill attention's softmax is then the exponential alone
@@ -535,7 +558,8 @@ class Phi3VModel:
                 o = o.view(B, L, -1)[:, -1].contiguous()
                 x = x.view(B, L, -1)[:, -1].contiguous()
                 a, h = a[:B], h[:B]
-            self._proj(o, p + "self_attn.o_proj.weight", EPI_RESID_BF16, resid=x, out=x)
+            if not (bufs.get("fuse_o", False) and L <= ops.L.DECODE_MAX_L and not st.quantized and n_beam == 1):
+                self._proj(o, p + "self_attn.o_proj.weight", EPI_RESID_BF16, resid=x, out=x)
             self._proj(x, p + "mlp.gate_up_proj.weight", EPI_SILU_MUL, norm_w=w[p + "post_attention_layernorm.weight"], out=a, h=h)
             self._proj(a, p + "mlp.down_proj.weight", EPI_RESID_BF16, resid=x, out=x)
             if self.hidden_hook is not None:                     # diagnostics only (tools/precision_decomp.py); never set
@@ -562,6 +586,8 @@ class Phi3VModel:
         # the cache length only grows under a captured step (greedy_step rebuilds the graph if it ever finds it below this); a
         # slot state's column moves both ways (engine.py), so it gets no bound
         bufs["past_lb"] = -1 if getattr(st, "slots", False) else int(st.offset)
+        if not st.quantized and not getattr(st, "slots", False):
+            self._plan_fused_oproj(bufs, B, 1, st.Tp)
         bufs["rope_cos"] = torch.empty((B, 1, self.hd // 2), dtype=F32, device=dev)
         bufs["rope_sin"] = torch.empty_like(bufs["rope_cos"])
         g["bufs"] = bufs

@@ -316,13 +316,25 @@ def attention(q, out, B, Lq, nh, nkv, hd, scale, causal, k_new=None, v_new=None,
     return out
 
 
+def attention_decode_can_fuse_oproj(B, Lq, nh, hd, n_split, cache_t, o_n, merge_in_launch):
+    """Does the fused attention + o_proj + residual launch take this shape on this device (include/p3v.h)?"""
+    return bool(L.lib().p3v_attention_decode_can_fuse_oproj(B, Lq, nh, hd, n_split, cache_t, o_n, int(bool(merge_in_launch))))
+
+
 def attention_decode(qkv, cos_new, sin_new, rope_bstride, k_cache, v_cache, out, B, Lq, nh, nkv, hd, scale, past, cache_t, ws,
-                     n_split, pad_len=None, d_past=None, merge_in_launch=False):
+                     n_split, pad_len=None, d_past=None, merge_in_launch=False, o_proj_w=None, o_proj_x=None, o_rearm=None):
     """Fused decode-step attention: head split + RoPE + KV append + split-KV attention + merge.
     cos_new/sin_new: rows of the new positions, row (b, r) at b*rope_bstride + r.
-    merge_in_launch: the split partials are merged inside the attention launch (ws: see `attention_ws`)."""
+    merge_in_launch: the split partials are merged inside the attention launch (ws: see `attention_ws`).
+    o_proj_w / o_proj_x / o_rearm: also the layer's o_proj + residual, x += bf16(W_o . out), in the same launch (`out` must be
+    all 0xFF on entry; `o_rearm`, the other layer parity's output buffer, is set to 0xFF): see p3v_attn_decode_args_t."""
+    if o_proj_w is not None:
+        _chk(o_proj_w, BF16, "o_proj_w"), _chk(o_proj_x, BF16, "o_proj_x"), _chk(o_rearm, BF16, "o_rearm")
+        if out.numel() < nh * hd or o_rearm.numel() < nh * hd:
+            raise ValueError("fused o_proj: out and o_rearm are [n_heads * hd] rows")
     args = L.AttnDecArgs(_p(qkv), _p(cos_new), _p(sin_new), _p(k_cache), _p(v_cache), _p(out), _p(pad_len), _p(d_past), _p(ws),
-                         B, Lq, nh, nkv, hd, int(past), cache_t, rope_bstride, n_split, float(scale), int(bool(merge_in_launch)))
+                         B, Lq, nh, nkv, hd, int(past), cache_t, rope_bstride, n_split, float(scale), int(bool(merge_in_launch)),
+                         _p(o_proj_w), _p(o_proj_x), _p(o_rearm), 0 if o_proj_w is None else o_proj_w.shape[0])
     L.check(L.lib().p3v_attention_decode(C.byref(args), _stream()), "attention_decode")
     return out
 

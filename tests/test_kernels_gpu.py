@@ -609,6 +609,44 @@ def test_attention_decode_fused(ops, orc, B, L, past, nh, n_split, pads, dev_pas
     assert torch.equal(kcc[:, :, :past].cpu(), kc[:, :, :past]) and torch.equal(kcc[:, :, past + L:].cpu(), kc[:, :, past + L:])
 
 
+@pytest.mark.parametrize("past,cap,dev_past", [(2531, 2688, True), (300, 1664, False), (2559, 2688, True), (1000, 1792, True)])
+def test_attention_decode_with_fused_oproj_is_bit_identical_to_two_launches(ops, past, cap, dev_past):
+    """k_attn_decode128_o: attention + o_proj + residual in ONE launch (B = L = 1, 32 heads x 96) against the two launches it
+    replaces -- p3v_attention_decode then p3v_gemv(P3V_EPI_RESID_BF16): the residual row, the attention output and the appended
+    K / V must be BIT-IDENTICAL (the projecting waves repeat k_gemv3's arithmetic exactly), ten launches in a row give the same
+    bits, the other output buffer is re-armed (all 0xFFFF) and the split workspace is left all-ones."""
+    B, L, nh, hd, H = 1, 1, 32, 96, 3072
+    T, n_split = cap, cap // 128
+    assert ops.attention_decode_can_fuse_oproj(B, L, nh, hd, n_split, T, H, True)
+    assert not ops.attention_decode_can_fuse_oproj(2, L, nh, hd, n_split, T, H, True)        # B = 1 only
+    assert not ops.attention_decode_can_fuse_oproj(B, L, nh, hd, n_split, T, H, False)       # needs the in-launch merge
+    qkv = g((1, 3 * nh * hd), 145).cuda()
+    kc0, vc0 = g((B, nh, T, hd), 146).cuda(), g((B, nh, hd, T), 147).cuda()
+    wo = (g((H, nh * hd), 148) * 0.05).cuda()
+    x0 = g((1, H), 149).cuda()
+    cos, sin = torch.rand((B, 1, hd // 2), device="cuda"), torch.rand((B, 1, hd // 2), device="cuda")
+    d_past = torch.tensor([past], dtype=torch.int32).cuda()
+    ws = ops.attention_ws(B, L, nh, hd, n_split, "cuda")
+    kw = dict(d_past=d_past if dev_past else None, merge_in_launch=True)
+    hp = past - 40 if dev_past else past                         # (with d_past: a lower bound of the length, not the length)
+    # two launches
+    k1, v1, o1, x1 = kc0.clone(), vc0.clone(), torch.empty((1, 1, H), dtype=BF16, device="cuda"), x0.clone()
+    ops.attention_decode(qkv, cos, sin, 1, k1, v1, o1, B, L, nh, nh, hd, hd ** -0.5, hp, T, ws, n_split, **kw)
+    ops.gemv(o1.view(1, H), wo, ops.EPI_RESID_BF16, resid=x1, out=x1)
+    # one launch, ten times
+    for rep in range(10):
+        k2, v2, x2 = kc0.clone(), vc0.clone(), x0.clone()
+        o2 = torch.full((1, 1, H), -1, dtype=torch.int16, device="cuda").view(BF16)
+        other = torch.zeros((1, 1, H), dtype=BF16, device="cuda")
+        ops.attention_decode(qkv, cos, sin, 1, k2, v2, o2, B, L, nh, nh, hd, hd ** -0.5, hp, T, ws, n_split, **kw,
+                             o_proj_w=wo, o_proj_x=x2, o_rearm=other)
+        assert torch.equal(o2.view(torch.int16), o1.view(torch.int16)), f"rep {rep}: attention output differs"
+        assert torch.equal(x2.view(torch.int16), x1.view(torch.int16)), f"rep {rep}: residual row differs from attention + gemv"
+        assert torch.equal(k2, k1) and torch.equal(v2, v1)
+        assert (other.view(torch.int16) == -1).all() and (ws.view(torch.int32) == -1).all()
+    assert not torch.isnan(x1.float()).any() and (x1.float() - x0.float()).abs().max().item() > 0.01
+
+
 @pytest.mark.parametrize("seed", range(4))
 def test_attention_decode_random_shapes_merge_modes_agree(ops, seed):
     """Fuzz of the decode attention: random (B, L, past, heads, pads) on the 64-key, 128-key and streaming plans; the
