@@ -2469,14 +2469,17 @@ extern "C" int p3v_attention_decode_can_fuse_oproj(int B, int L, int n_heads, in
   if (B != 1 || L != 1 || hd != 96 || n_heads * hd != 3072 || o_n <= 0 || o_n % 8 || !merge_in_launch) return 0;
   if (!(n_split * 128 >= cache_t && cache_t % 128 == 0 && n_split * 64 < cache_t) || n_split < 2) return 0;
   if ((long)(n_split - 1) * n_heads * 8 < o_n) return 0;
-  static int n_cu = 0;
-  if (!n_cu) {
-    int dev = 0;
+  // every workgroup of the launch must be resident at once (the projecting ones wait for the merging ones): ask the runtime how
+  // many of THIS kernel fit a CU rather than assume the 3 that its 52 KB of LDS and ~100 VGPRs give today
+  static long capacity = 0;
+  if (!capacity) {
+    int dev = 0, per_cu = 0;
     hipDeviceProp_t pr;
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess) return 0;
-    n_cu = pr.multiProcessorCount;
-  }
-  return (long)B * n_heads * n_split <= 3L * n_cu;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_attn_decode128_o, 256, 0) != hipSuccess || per_cu < 1) return 0;
+    capacity = (long)per_cu * (pr.multiProcessorCount - 8);   // 8 CUs of head-room: a grid of exactly the queried capacity
+  }                                                           // did not co-reside in tools/scratch/persistent_chain.hip
+  return (long)B * n_heads * n_split <= capacity;
 }
 
 extern "C" int p3v_attention_decode(const p3v_attn_decode_args_t* a, void* stream) {
