@@ -2,7 +2,7 @@
 // resident for all stages; between stages a grid-wide barrier, and -- the point -- each wave requests its NEXT stage's weight
 // rows BEFORE it waits at the barrier, so HBM keeps streaming while the hand-over (write-through stores, barrier, uncached
 // re-read of the vector) is in flight.  Compared with the same stages as one graph of plain dependent launches.
-// Stage = y = tanh(W x), W D x D bf16 (33.5 MB at D = 4096); 512 workgroups x 4 waves, 2 rows per wave.
+// Stage = y = tanh(W x), W 4096 x 3072 bf16 (25.2 MB), the next stage reads the first 3072 outputs; 512 workgroups x 4 waves, 2 rows per wave.
 //   hipcc --offload-arch=gfx950 -O3 -o persistent_chain persistent_chain.hip && ./persistent_chain
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -10,7 +10,8 @@
 #include <cstring>
 #include <vector>
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-constexpr int D = 4096, NS = 160, NWB = 24, TPB = 256, NBLK = 512, NCW = TPB / 64, CH = D / 8 / 64;     // 8 16-byte chunks per lane and row
+constexpr int D = 3072, NR = 4096, NS = 160, NWB = 24, TPB = 256, NBLK = 512, NCW = TPB / 64, CH = D / 8 / 64;   // K = D, NR rows; 6 chunks per lane and row
+constexpr int XS = NR / 2;                                      // words between the vectors of consecutive stages (a stage reads the first D / 2)
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at line %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
 __device__ __forceinline__ float lo(unsigned x) { return __builtin_bit_cast(float, x << 16); }
 __device__ __forceinline__ float hi(unsigned x) { return __builtin_bit_cast(float, x & 0xffff0000u); }
@@ -107,14 +108,14 @@ __global__ void __launch_bounds__(TPB + 64, 4) k_chain(const u32x4* const* __res
       if (st && lane == 0) sp[1] = wall_clock64();
       // ---- the vector, past the caches, into LDS
       unsigned* xw = (unsigned*)xs;
-      const unsigned* src = x + (size_t)s * XW;
+      const unsigned* src = x + (size_t)s * XS;
 #pragma unroll 1
-      for (int j0 = 0; j0 < XW / 64; j0 += 16) {
-        unsigned v[16];
+      for (int j0 = 0; j0 < XW / 64; j0 += 4) {
+        unsigned v[4];
 #pragma unroll
-        for (int j = 0; j < 16; ++j) v[j] = __hip_atomic_load(src + (j0 + j) * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int j = 0; j < 4; ++j) v[j] = __hip_atomic_load(src + (j0 + j) * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
-        for (int j = 0; j < 16; ++j) xw[(j0 + j) * 64 + lane] = v[j];
+        for (int j = 0; j < 4; ++j) xw[(j0 + j) * 64 + lane] = v[j];
       }
       if (st && lane == 0) sp[2] = wall_clock64();
     }
@@ -123,12 +124,13 @@ __global__ void __launch_bounds__(TPB + 64, 4) k_chain(const u32x4* const* __res
       if (!PREFETCH && s > 0) load_rows(w, PW[s % NWB], row0, lane);
       const unsigned o = dot_rows(w, xs, lane);
       if (lane == 0) outw[wave] = o;
+      __builtin_amdgcn_sched_barrier(0);                             // (or the next stage's loads are hoisted above the reduction: 2 x 64 registers)
       // next stage's rows: requested now, they travel while the barrier resolves
       if (PREFETCH && s + 1 < NS) load_rows(w, PW[(s + 1) % NWB], row0, lane);
     }
     __syncthreads();                                                  // B: outputs are in LDS, xs is free again
     if (wave == NCW) {
-      if (lane < NCW) __hip_atomic_store(x + (size_t)(s + 1) * XW + bx * NCW + lane, outw[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (lane < NCW) __hip_atomic_store(x + (size_t)(s + 1) * XS + bx * NCW + lane, outw[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // write-through stores acknowledged
       if (lane == 0 && s + 1 < NS) {
         if (MODE == 0) __hip_atomic_fetch_add(sync + s, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -142,7 +144,7 @@ __global__ void __launch_bounds__(TPB + 64, 4) k_chain(const u32x4* const* __res
 
 int main() {
   setvbuf(stdout, nullptr, _IONBF, 0);
-  std::vector<unsigned short> hw((size_t)D * D);
+  std::vector<unsigned short> hw((size_t)NR * D);
   srand(1);
   for (auto& v : hw) {
     const float f = ((rand() & 0xffff) / 65536.f - 0.5f) * 0.06f;
@@ -153,9 +155,9 @@ int main() {
   Ptrs P;
   for (int i = 0; i < NWB; ++i) {
     u32x4* w;
-    CK(hipMalloc(&w, (size_t)D * D * 2));
+    CK(hipMalloc(&w, (size_t)NR * D * 2));
     for (size_t k = 0; k < hw.size(); k += 977) hw[k] ^= (unsigned short)(i + 1);
-    CK(hipMemcpy(w, hw.data(), (size_t)D * D * 2, hipMemcpyHostToDevice));
+    CK(hipMemcpy(w, hw.data(), (size_t)NR * D * 2, hipMemcpyHostToDevice));
     P.W[i] = w;
   }
   const u32x4** dW;
@@ -164,13 +166,13 @@ int main() {
   unsigned *x, *sync;
   int* err;
   long long* stamps;
-  const size_t xw = D / 2, sync_words = (size_t)NS * (NBLK + 64);
+  const size_t xw = XS, sync_words = (size_t)NS * (NBLK + 64);
   CK(hipMalloc(&x, (NS + 1) * xw * 4));
   CK(hipMalloc(&sync, sync_words * 4));
   CK(hipMalloc(&err, 4));
   CK(hipMemset(err, 0, 4));
   CK(hipMalloc(&stamps, NS * 8 * 8));
-  std::vector<unsigned> hx(xw, 0x3c003c00u);
+  std::vector<unsigned> hx(D / 2, 0x3c003c00u);
   hipStream_t s1;
   CK(hipStreamCreate(&s1));
   int occ = 0;
@@ -204,7 +206,7 @@ int main() {
     float best = 1e9f;
     for (int rep = 0; rep < 6; ++rep) {
       CK(hipMemsetAsync(x, 0, (NS + 1) * xw * 4, s1));
-      CK(hipMemcpyAsync(x, hx.data(), xw * 4, hipMemcpyHostToDevice, s1));
+      CK(hipMemcpyAsync(x, hx.data(), D / 2 * 4, hipMemcpyHostToDevice, s1));
       CK(hipMemsetAsync(stamps, 0, NS * 8 * 8, s1));
       CK(hipStreamSynchronize(s1));
       CK(hipEventRecord(e0, s1));
@@ -220,7 +222,7 @@ int main() {
     CK(hipMemcpy(&herr, err, 4, hipMemcpyDeviceToHost));
     CK(hipMemset(err, 0, 4));
     printf("%-58s %8.3f ms for %d stages = %6.2f us per stage (%5.2f TB/s)%s\n", name, best, NS, best * 1e3 / NS,
-           (double)D * D * 2 * NS / (best * 1e-3) / 1e12, herr ? "  [BARRIER TIMEOUT]" : "");
+           (double)NR * D * 2 * NS / (best * 1e-3) / 1e12, herr ? "  [BARRIER TIMEOUT]" : "");
     if (mode > 0) {
       std::vector<long long> hs(NS * 8);
       CK(hipMemcpy(hs.data(), stamps, NS * 8 * 8, hipMemcpyDeviceToHost));
