@@ -257,8 +257,13 @@ typedef struct {
   float scale;
   int merge_in_launch;    /* as p3v_attn_decode_args_t.merge_in_launch (honoured with one tile per split and n_split <= 16 on
                              the 64-key plan, always on the 128-key plan; otherwise the merge launch runs) */
+  /* optional (round 4), as p3v_attn_decode_args_t's o_proj_* fields but for e4m3 weights: o_proj_w8 [o_n, n_heads * hd] bytes with
+   * one fp32 scale per row; x += bf16(scale * (W8 . attention output)), bit-identical to p3v_gemv_fp8 with P3V_EPI_RESID_BF16.
+   * For shapes p3v_attention_decode_q8_can_fuse_oproj() accepts; `out` all 0xFF on entry, `o_rearm` set to 0xFF. */
+  const uint8_t* o_proj_w8; const float* o_proj_scale; uint16_t* o_proj_x; uint16_t* o_rearm; int o_n;
 } p3v_attn_decode_q8_args_t;
 int p3v_attention_decode_q8(const p3v_attn_decode_q8_args_t* args /* host */, void* stream);
+int p3v_attention_decode_q8_can_fuse_oproj(int B, int L, int n_heads, int hd, int n_split, int cache_t, int o_n, int merge_in_launch);
 
 /* ---- CLIP patch unfold: pixel_values [N,3,S,S] f32 -> patches [N*P, kpad] bf16, (c,ky,kx) order, zero padded */
 int p3v_im2col_patches(const float* pix, uint16_t* patches, int n_img, int img, int patch, int kpad, void* stream);

@@ -68,7 +68,8 @@ class AttnDecQ8Args(C.Structure):
     _fields_ = [("qkv", vp), ("cos_t", vp), ("sin_t", vp), ("k8", vp), ("v8t", vp), ("k_scale", vp), ("v_scale", vp),
                 ("out", vp), ("pad_len", vp), ("d_past", vp), ("ws", vp),
                 ("B", i32), ("L", i32), ("n_heads", i32), ("n_kv", i32), ("hd", i32), ("past", i32),
-                ("cache_t", i32), ("rope_bstride", i32), ("n_split", i32), ("scale", f32), ("merge_in_launch", i32)]
+                ("cache_t", i32), ("rope_bstride", i32), ("n_split", i32), ("scale", f32), ("merge_in_launch", i32),
+                ("o_proj_w8", vp), ("o_proj_scale", vp), ("o_proj_x", vp), ("o_rearm", vp), ("o_n", i32)]   # optional fused o_proj (e4m3)
 
 
 # name -> (restype, argtypes); must list every symbol include/p3v.h declares
@@ -96,6 +97,7 @@ SIGNATURES = {
     "p3v_kv_quantize": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "p3v_kv_dequantize": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "p3v_attention_decode_q8": (i32, [C.POINTER(AttnDecQ8Args), vp]),
+    "p3v_attention_decode_q8_can_fuse_oproj": (i32, [i32, i32, i32, i32, i32, i32, i32, i32]),
     "p3v_stage_rope": (i32, [vp, vp, i32, vp, vp, vp, i32, i32, i32, i32, vp]),
     "p3v_attention_ws_bytes": (i64, [i32, i32, i32, i32, i32]),
     "p3v_im2col_patches": (i32, [vp, vp, i32, i32, i32, i32, vp]),

@@ -21,6 +21,7 @@
 
 #include "p3v_common.h"
 #include "p3v_gemv3_body.h"      // dot8: the fused o_proj of k_attn_decode128_o repeats k_gemv3's arithmetic exactly
+#include "p3v_dot_f8.h"          // dot16_f8: ... and k_attn_decode128_q8_o repeats k_gemv3_f8's
 
 struct AttnP {
   const bf16_t* q; const bf16_t* k_past; const bf16_t* v_past; const bf16_t* k_new; const bf16_t* v_new;
@@ -1846,6 +1847,99 @@ __device__ __forceinline__ void attn_decode_body(const AttnDecP& p, const int bx
 #ifndef P3V_FO_SLEEP
 #define P3V_FO_SLEEP 4
 #endif
+// The projection half of the fused decode launches (k_attn_decode128_o, k_attn_decode128_q8_o): workgroup `o_wl` of the launch's
+// non-merging workgroups owns rows [8 o_wl, 8 o_wl + 8) of W_o, one row pair per wave, requested when the workgroup's partial has
+// been stored.  F8: e4m3 weights with one fp32 scale per row (k_gemv3_f8's arithmetic), else bf16 (k_gemv3's).  `lds`: >= 6 KB
+// that nobody else uses any more.
+struct FoP { const void* o_w; const float* o_scale; bf16_t* o_x; const bf16_t* out; int nh; };
+template <bool F8>
+__device__ __forceinline__ void fo_project(const FoP f, const int o_wl, unsigned char* lds) {
+  constexpr int HD = 96, NJ = F8 ? 3 : 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int o_u = o_wl * 4 + wave;                             // row pair (2 o_u, 2 o_u + 1)
+  const size_t row_bytes = (size_t)f.nh * HD * (F8 ? 1 : 2);
+  u32x4_t ow[2][NJ];
+  const u32x4_t* w0 = (const u32x4_t*)((const unsigned char*)f.o_w + (size_t)(2 * o_u) * row_bytes) + lane;
+  const u32x4_t* w1 = (const u32x4_t*)((const unsigned char*)f.o_w + (size_t)(2 * o_u + 1) * row_bytes) + lane;
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    ow[0][j] = __builtin_nontemporal_load(w0 + j * 64);
+    ow[1][j] = __builtin_nontemporal_load(w1 + j * 64);
+  }
+  const uint32_t ores = *(const uint32_t*)(f.o_x + 2 * o_u);
+  const float osc0 = F8 ? f.o_scale[2 * o_u] : 1.f, osc1 = F8 ? f.o_scale[2 * o_u + 1] : 1.f;
+  {
+    // Wait for the merged attention output.  1536 waves polling all 1536 words would flood the memory side with uncached
+    // 4-byte loads and starve the very workgroups that produce them (measured: every wave timed out); so ONE wave per
+    // workgroup watches one word per head (the last word each merging workgroup stores) and sleeps between looks, the others
+    // wait at the barrier; then the four waves fetch a quarter of the vector each into LDS (every wave fetching all of it: 18 MB
+    // of uncached reads out of one 6 KB region, +2 us), re-fetching the rare straggler word.
+    __shared__ int o_timeout;
+    const uint32_t* src = (const uint32_t*)f.out;
+    if (wave == 0) {
+      bool to = false;
+      for (unsigned tries = 0;; ++tries) {
+        const uint32_t c = lane < f.nh ? __hip_atomic_load(src + lane * (HD / 2) + HD / 2 - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+        if (!__any((c & 0xffffu) == 0xffffu || (c >> 16) == 0xffffu)) break;
+        if (tries >= (1u << 16)) { to = true; break; }
+        __builtin_amdgcn_s_sleep(P3V_FO_SLEEP);
+      }
+      if (lane == 0) o_timeout = to;
+    }
+    TMARK(12);
+    __syncthreads();
+    // every wave fetches a quarter of the vector (6 words per lane) into LDS, re-fetching the rare straggler word
+    uint32_t* xs = (uint32_t*)lds;                              // the K/V tiles are dead by now (barrier above)
+    bool timeout = o_timeout != 0;
+    {
+      const int NW = f.nh * HD / 2 / 4;                        // words per wave: 384
+      uint32_t xv[6];
+      for (unsigned tries = 0; !timeout; ++tries) {
+        bool bad = false;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) xv[j] = __hip_atomic_load(src + wave * NW + j * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int j = 0; j < 6; ++j) bad |= (xv[j] & 0xffffu) == 0xffffu || (xv[j] >> 16) == 0xffffu;
+        if (!__any(bad)) break;
+        if (tries >= (1u << 12)) timeout = true;
+        __builtin_amdgcn_s_sleep(2);
+      }
+#pragma unroll
+      for (int j = 0; j < 6; ++j) xs[wave * NW + j * 64 + lane] = xv[j];
+      if (timeout && lane == 0) o_timeout = 1;
+    }
+    __syncthreads();
+    timeout = o_timeout != 0;
+    float a0 = 0.f, a1 = 0.f;
+    if (F8) {                                                  // k_gemv3_f8<1, 3>: weight chunk c = 64 j + lane meets x chunks 2c, 2c + 1
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const u32x4_t xa = ((const u32x4_t*)xs)[2 * (j * 64 + lane)], xb = ((const u32x4_t*)xs)[2 * (j * 64 + lane) + 1];
+        a0 = dot16_f8(ow[0][j], xa, xb, a0);
+        a1 = dot16_f8(ow[1][j], xa, xb, a1);
+      }
+      TMARK(13);
+      a0 = wave_sum(a0) * osc0;
+      a1 = wave_sum(a1) * osc1;
+    } else {                                                   // k_gemv3<1, 1, 6>: chunk 64 j + lane
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        const u32x4_t xa = ((const u32x4_t*)xs)[j * 64 + lane];
+        a0 = dot8(ow[0][j], xa, a0);
+        a1 = dot8(ow[1][j], xa, a1);
+      }
+      TMARK(13);
+      a0 = wave_sum(a0);
+      a1 = wave_sum(a1);
+    }
+    if (lane == 0) {
+      const float v0 = bf16lo(ores) + bf16_round(a0), v1 = bf16hi(ores) + bf16_round(a1);
+      *(uint32_t*)(f.o_x + 2 * o_u) = timeout ? 0x7fc07fc0u : pack_bf16x2(v0, v1);     // NaN: loud (api._rows raises)
+    }
+    TMARK(14);
+  }
+}
+
 template <bool FO = false>
 __device__ __forceinline__ void attn_decode_body128(const AttnDecP& p, const int bx, const int by, const int bz, unsigned char* KV) {
   constexpr int TK = 128, WK = 32, HD = 96, KROW = HD * 2, VROWB = TK * 2, NKS = 3, NDT = 6, CPR = 12;
@@ -2068,11 +2162,8 @@ __device__ __forceinline__ void attn_decode_body128(const AttnDecP& p, const int
   TMARK(2);
   // fused o_proj: this wave's row pair is requested once the partial is stored (below): requested here, 18.9 MB of weight
   // loads compete with the other workgroups' K/V tiles and the whole attention phase runs 0.6 us later (tools/attn_o_timeline.py)
-  u32x4_t ow[2][6];
-  uint32_t ores = 0;
   const int o_wl = by * (p.n_split - 1) + bx;                  // rank among the non-merging workgroups
   const bool o_worker = FO && !merger && bx < p.n_split - 1 && o_wl * 8 < p.o_n;
-  const int o_u = o_wl * 4 + wave;                             // row pair (2 o_u, 2 o_u + 1)
   if (FO) {
     if (bx == 0 && by == 0) {                                  // re-arm the other layer parity's buffer (nobody reads it in this launch)
       uint32_t* ra = (uint32_t*)p.o_rearm;
@@ -2110,81 +2201,10 @@ __device__ __forceinline__ void attn_decode_body128(const AttnDecP& p, const int
     }
   }
   TMARK(3);
-  if (FO) {
-    if (o_worker) {
-      const u32x4_t* w0 = (const u32x4_t*)(p.o_w + (size_t)(2 * o_u) * (p.nh * HD)) + lane;
-      const u32x4_t* w1 = (const u32x4_t*)(p.o_w + (size_t)(2 * o_u + 1) * (p.nh * HD)) + lane;
-#pragma unroll
-      for (int j = 0; j < 6; ++j) {
-        ow[0][j] = __builtin_nontemporal_load(w0 + j * 64);
-        ow[1][j] = __builtin_nontemporal_load(w1 + j * 64);
-      }
-      ores = *(const uint32_t*)(p.o_x + 2 * o_u);
-    }
-  }
   if (merger)
     split_merge<256>(p.ws + ((size_t)b * p.nh + head) * p.n_split * 16 * (HD + 2), p.out + (size_t)b * p.L * (p.nh * HD) + head * HD,
                      (size_t)p.nh * HD, p.L, p.n_split, own, (float*)vtile, FO);
-  if (FO && o_worker) {                                        // (workgroup-uniform)
-    // Wait for the merged attention output.  1536 waves polling all 1536 words would flood the memory side with uncached
-    // 4-byte loads and starve the very workgroups that produce them (measured: every wave timed out); so ONE wave per
-    // workgroup watches one word per head (the last word each merging workgroup stores) and sleeps between looks, the others
-    // wait at the barrier; then the four waves fetch a quarter of the vector each into LDS (every wave fetching all of it: 18 MB
-    // of uncached reads out of one 6 KB region, +2 us), re-fetching the rare straggler word.
-    __shared__ int o_timeout;
-    const uint32_t* src = (const uint32_t*)p.out;
-    if (wave == 0) {
-      bool to = false;
-      for (unsigned tries = 0;; ++tries) {
-        const uint32_t c = lane < p.nh ? __hip_atomic_load(src + lane * (HD / 2) + HD / 2 - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-        if (!__any((c & 0xffffu) == 0xffffu || (c >> 16) == 0xffffu)) break;
-        if (tries >= (1u << 16)) { to = true; break; }
-        __builtin_amdgcn_s_sleep(P3V_FO_SLEEP);
-      }
-      if (lane == 0) o_timeout = to;
-    }
-    TMARK(12);
-    __syncthreads();
-    // every wave fetches a quarter of the vector (6 words per lane) into LDS, re-fetching the rare straggler word
-    uint32_t* xs = (uint32_t*)KV;                              // the K/V tiles are dead by now (barrier above)
-    bool timeout = o_timeout != 0;
-    {
-      const int NW = p.nh * HD / 2 / 4;                        // words per wave: 384
-      uint32_t xv[6];
-      for (unsigned tries = 0; !timeout; ++tries) {
-        bool bad = false;
-#pragma unroll
-        for (int j = 0; j < 6; ++j) xv[j] = __hip_atomic_load(src + wave * NW + j * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-        for (int j = 0; j < 6; ++j) bad |= (xv[j] & 0xffffu) == 0xffffu || (xv[j] >> 16) == 0xffffu;
-        if (!__any(bad)) break;
-        if (tries >= (1u << 12)) timeout = true;
-        __builtin_amdgcn_s_sleep(2);
-      }
-#pragma unroll
-      for (int j = 0; j < 6; ++j) xs[wave * NW + j * 64 + lane] = xv[j];
-      if (timeout && lane == 0) o_timeout = 1;
-    }
-    __syncthreads();
-    timeout = o_timeout != 0;
-    u32x4_t xa[6];
-#pragma unroll
-    for (int j = 0; j < 6; ++j) xa[j] = ((const u32x4_t*)xs)[j * 64 + lane];
-    TMARK(13);
-    float a0 = 0.f, a1 = 0.f;
-#pragma unroll
-    for (int j = 0; j < 6; ++j) {
-      a0 = dot8(ow[0][j], xa[j], a0);
-      a1 = dot8(ow[1][j], xa[j], a1);
-    }
-    a0 = wave_sum(a0);
-    a1 = wave_sum(a1);
-    if (lane == 0) {
-      const float v0 = bf16lo(ores) + bf16_round(a0), v1 = bf16hi(ores) + bf16_round(a1);
-      *(uint32_t*)(p.o_x + 2 * o_u) = timeout ? 0x7fc07fc0u : pack_bf16x2(v0, v1);     // NaN: loud (api._rows raises)
-    }
-    TMARK(14);
-  }
+  if (FO && o_worker) fo_project<false>(FoP{p.o_w, nullptr, p.o_x, p.out, p.nh}, o_wl, KV);
 }
 
 __global__ void __launch_bounds__(256) k_attn_decode128(AttnDecP p) {
@@ -2701,6 +2721,8 @@ struct AttnDecQ8P {
   int grp, grp_magic;          // heads per kv head and ceil(2^16 / grp) (k_attn_decode_q8s)
   int merge;                   // nonzero: in-launch split merge, as AttnDecP
   bf16_t* out;                 // [B, L, nh * 96] (fused merge only)
+  // fused o_proj + residual on e4m3 weights (k_attn_decode128_q8<true> only), as AttnDecP's
+  const uint8_t* o_w; const float* o_scale; bf16_t* o_x; bf16_t* o_rearm; int o_n;
 };
 
 // 16 offset-binary bytes -> 16 FP16 values 1024 + byte: a byte dropped into the mantissa of 0x6400 (= 1024.0) is exactly
@@ -3164,6 +3186,7 @@ __global__ void __launch_bounds__(256) k_attn_decode_q8s(AttnDecQ8P p) {
 // v_perm_b32.  Scales ride in registers (two float4 per lane and operand).  New rows: rotated exactly, quantised one row
 // per wave (the step attends over what it stores, phi.py:545-546), patched into the byte tile + scale registers' LDS
 // copy + the cache.  In-launch split merge as the bf16 kernel.
+template <bool FO>                                             // FO: + the layer's o_proj (e4m3 weights) + residual, as k_attn_decode128_o
 __global__ void __launch_bounds__(256) k_attn_decode128_q8(AttnDecQ8P p) {
   constexpr int TK = 128, WK = 32, HD = 96, KROWB = HD, VROWB = TK, NKS = 3, NDT = 6, CPR = 12, KROW = HD * 2;
   constexpr int KS_BYTES = WK * KROWB;                         // 3 KiB of key bytes per wave
@@ -3422,7 +3445,31 @@ __global__ void __launch_bounds__(256) k_attn_decode128_q8(AttnDecQ8P p) {
   }
   if (merger)
     split_merge<256>(p.ws + ((size_t)b * p.nh + head) * p.n_split * 16 * (HD + 2), p.out + (size_t)b * p.L * (p.nh * HD) + head * HD,
-                     (size_t)p.nh * HD, p.L, p.n_split, own, (float*)Aux);
+                     (size_t)p.nh * HD, p.L, p.n_split, own, (float*)Aux, FO);
+  if (FO) {
+    if (blockIdx.x == 0 && blockIdx.y == 0) {                  // re-arm the other layer parity's buffer (nobody reads it in this launch)
+      uint32_t* ra = (uint32_t*)p.o_rearm;
+      for (int i = tid; i < p.nh * HD / 2; i += 256) ra[i] = 0xffffffffu;
+    }
+    const int o_wl = blockIdx.y * (p.n_split - 1) + blockIdx.x;   // rank among the non-merging workgroups
+    if (!merger && (int)blockIdx.x < p.n_split - 1 && o_wl * 8 < p.o_n)
+      fo_project<true>(FoP{p.o_w, p.o_scale, p.o_x, p.out, p.nh}, o_wl, KV);
+  }
+}
+
+extern "C" int p3v_attention_decode_q8_can_fuse_oproj(int B, int L, int n_heads, int hd, int n_split, int cache_t, int o_n, int merge_in_launch) {
+  if (B != 1 || L != 1 || hd != 96 || n_heads * hd != 3072 || o_n <= 0 || o_n % 8 || !merge_in_launch) return 0;
+  if (!(n_split * 128 >= cache_t && cache_t % 128 == 0 && n_split * 64 < cache_t) || n_split < 2) return 0;
+  if ((long)(n_split - 1) * n_heads * 8 < o_n || p3v_tuning().q8_old) return 0;
+  static long capacity = 0;                                    // every workgroup resident at once: see p3v_attention_decode_can_fuse_oproj
+  if (!capacity) {
+    int dev = 0, per_cu = 0;
+    hipDeviceProp_t pr;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess) return 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_attn_decode128_q8<true>, 256, 0) != hipSuccess || per_cu < 1) return 0;
+    capacity = (long)per_cu * (pr.multiProcessorCount - 8);
+  }
+  return (long)B * n_heads * n_split <= capacity;
 }
 
 extern "C" int p3v_attention_decode_q8(const p3v_attn_decode_q8_args_t* a, void* stream) {
@@ -3434,7 +3481,7 @@ extern "C" int p3v_attention_decode_q8(const p3v_attn_decode_q8_args_t* a, void*
   const int grp = a->n_heads / a->n_kv;
   AttnDecQ8P p = {a->qkv, a->cos_t, a->sin_t, a->k8, a->v8t, a->k_scale, a->v_scale, a->pad_len, a->d_past, a->ws,
                   a->B, a->L, a->n_heads, a->n_kv, a->past, a->cache_t, a->rope_bstride, a->n_split, a->scale,
-                  grp, (65536 + grp - 1) / grp, 0, (bf16_t*)a->out};
+                  grp, (65536 + grp - 1) / grp, 0, (bf16_t*)a->out, nullptr, nullptr, nullptr, nullptr, 0};
   hipStream_t s = (hipStream_t)stream;
   const dim3 grid(a->n_split, a->n_heads, a->B);
   const bool old_only = p3v_tuning().q8_old != 0;   // A/B knob
@@ -3444,7 +3491,17 @@ extern "C" int p3v_attention_decode_q8(const p3v_attn_decode_q8_args_t* a, void*
   // bytes go through registers and a ds_write pass into the fp16 images, where the bf16 kernel uses LDS-DMA).
   if (!old_only && a->cache_t % 128 == 0 && a->n_split * 128 >= a->cache_t && a->n_split * 64 < a->cache_t) {   // 128-key tiles
     p.merge = a->merge_in_launch;
-    hipLaunchKernelGGL(k_attn_decode128_q8, grid, dim3(256), 0, s, p);
+    if (a->o_proj_w8) {                                        // attention + o_proj (e4m3) + residual in one launch
+      if (!p3v_attention_decode_q8_can_fuse_oproj(a->B, a->L, a->n_heads, a->hd, a->n_split, a->cache_t, a->o_n, a->merge_in_launch))
+        return P3V_ERR_UNSUPPORTED;
+      if (!a->o_proj_scale || !a->o_proj_x || !a->o_rearm || ((uintptr_t)a->o_proj_w8 | (uintptr_t)a->o_proj_x | (uintptr_t)a->o_rearm) & 15)
+        return P3V_ERR_ARG;
+      p.o_w = a->o_proj_w8; p.o_scale = a->o_proj_scale; p.o_x = (bf16_t*)a->o_proj_x; p.o_rearm = (bf16_t*)a->o_rearm; p.o_n = a->o_n;
+      hipLaunchKernelGGL(k_attn_decode128_q8<true>, grid, dim3(256), 0, s, p);
+      P3V_CHECK_LAUNCH();
+      return P3V_OK;
+    }
+    hipLaunchKernelGGL(k_attn_decode128_q8<false>, grid, dim3(256), 0, s, p);
     P3V_CHECK_LAUNCH();
     if (a->merge_in_launch) return P3V_OK;
     hipLaunchKernelGGL(k_attn_combine2, dim3(a->B * a->n_heads * a->L), dim3(combine_threads(a->n_split)), 0, s, a->ws, a->out, a->L, a->n_heads,

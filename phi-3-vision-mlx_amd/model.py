@@ -426,14 +426,17 @@ class Phi3VModel:
             h=torch.empty((M, H), dtype=BF16, device=dev), n_split=0, ws=None)
         return bufs
 
-    def _plan_fused_oproj(self, bufs, B, L, T):
-        """B = L = 1 decode on plain bf16 weights: attention + o_proj + residual as ONE launch per layer (k_attn_decode128_o,
-        p3v_attention.hip) where the library takes the shape.  The attention output then lives in two buffers that alternate
-        layers use, both all-ones (= "not written yet") between launches; P3V_ATTN_FUSE_OPROJ=0 switches it off."""
+    def _plan_fused_oproj(self, bufs, B, L, T, quantized=False):
+        """B = L = 1 decode: attention + o_proj + residual as ONE launch per layer where the library takes the shape -- on plain
+        bf16 weights and a bf16 cache (k_attn_decode128_o), or on e4m3 weights and the int8 cache (config 5: k_attn_decode128_q8<true>);
+        p3v_attention.hip.  The attention output then lives in two buffers that alternate layers use, both all-ones (= "not written
+        yet") between launches; P3V_ATTN_FUSE_OPROJ=0 switches it off."""
         cfg = self.cfg
+        can = ops.attention_decode_q8_can_fuse_oproj if quantized else ops.attention_decode_can_fuse_oproj
+        o_key = "model.layers.0.self_attn.o_proj.weight"
         ok = (os.environ.get("P3V_ATTN_FUSE_OPROJ", "1") != "0" and B == 1 and L == 1 and bufs.get("attn_merge", False)
-              and not self.adapters and not self.w8 and not self.w4
-              and ops.attention_decode_can_fuse_oproj(B, L, cfg.num_attention_heads, self.hd, bufs["n_split"], T, cfg.hidden_size, True))
+              and not self.adapters and not self.w4 and (o_key in self.w8) == bool(quantized)
+              and can(B, L, cfg.num_attention_heads, self.hd, bufs["n_split"], T, cfg.hidden_size, True))
         bufs["fuse_o"] = bool(ok)
         if ok:
             for k in ("o_f", "o_f2"):                            # all-ones = "not written yet"
@@ -496,8 +499,8 @@ class Phi3VModel:
             bufs = self._alloc_bufs(B, L)
             self._split_plan(bufs, B, L, st.Tp, st.quantized)     # the CAPACITY, as the captured graph plans: same kernel, same
                                                                 # split boundaries -> eager and replayed steps agree bit for bit
-            if L <= ops.L.DECODE_MAX_L and not st.quantized and n_beam == 1:
-                self._plan_fused_oproj(bufs, B, L, st.Tp)
+            if L <= ops.L.DECODE_MAX_L and n_beam == 1:
+                self._plan_fused_oproj(bufs, B, L, st.Tp, st.quantized)
         q, o, qkv, a, h, n_split, ws = (bufs[k] for k in ("q", "o", "qkv", "a", "h", "n_split", "ws"))
         if st.quantized and n_beam > 1:
             raise NotImplementedError("Beam Search is not yet compatible with Quantized Cache")       # as phi.py:525
@@ -514,8 +517,14 @@ class Phi3VModel:
                         rc, rs, rb = bufs["rope_cos"], bufs["rope_sin"], L
                     else:
                         rc, rs, rb = st.cos[:, past:], st.sin[:, past:], st.T
-                    ops.attention_decode_q8(qkv, rc, rs, rb, st.k8[i], st.v8[i], st.ks[i], st.vs[i], o, B, L, nh, nkv, hd, scale,
-                                            past, st.Tp, ws, n_split, pad_len=st.pad_len, d_past=d_past, merge_in_launch=bufs.get("attn_merge", False))
+                    kq, o_i = {}, o
+                    if bufs.get("fuse_o", False):               # + o_proj (e4m3) + residual in the same launch
+                        o_i, o_other = (bufs["o_f"], bufs["o_f2"]) if i % 2 == 0 else (bufs["o_f2"], bufs["o_f"])
+                        w8o = self.w8[p + "self_attn.o_proj.weight"]
+                        kq = dict(o_proj_w8=w8o[0], o_proj_scale=w8o[1], o_proj_x=x, o_rearm=o_other)
+                    ops.attention_decode_q8(qkv, rc, rs, rb, st.k8[i], st.v8[i], st.ks[i], st.vs[i], o_i, B, L, nh, nkv, hd, scale,
+                                            past, st.Tp, ws, n_split, pad_len=st.pad_len, d_past=d_past,
+                                            merge_in_launch=bufs.get("attn_merge", False), **kq)
                 else:                                           # prefill: exact attention, quantised copy stored
                     if past > 0 and not getattr(st, "fresh_rows", False):   # long cached call (constrain with > 16 tokens): attend on a
                         ops.kv_dequantize(st.k8[i], st.v8[i], st.ks[i], st.vs[i], st.k_tmp, st.v_tmp, past)   # dequantised copy
@@ -558,7 +567,7 @@ class Phi3VModel:
                 o = o.view(B, L, -1)[:, -1].contiguous()
                 x = x.view(B, L, -1)[:, -1].contiguous()
                 a, h = a[:B], h[:B]
-            if not (bufs.get("fuse_o", False) and L <= ops.L.DECODE_MAX_L and not st.quantized and n_beam == 1):
+            if not (bufs.get("fuse_o", False) and L <= ops.L.DECODE_MAX_L and n_beam == 1):
                 self._proj(o, p + "self_attn.o_proj.weight", EPI_RESID_BF16, resid=x, out=x)
             self._proj(x, p + "mlp.gate_up_proj.weight", EPI_SILU_MUL, norm_w=w[p + "post_attention_layernorm.weight"], out=a, h=h)
             self._proj(a, p + "mlp.down_proj.weight", EPI_RESID_BF16, resid=x, out=x)
@@ -586,8 +595,8 @@ class Phi3VModel:
         # the cache length only grows under a captured step (greedy_step rebuilds the graph if it ever finds it below this); a
         # slot state's column moves both ways (engine.py), so it gets no bound
         bufs["past_lb"] = -1 if getattr(st, "slots", False) else int(st.offset)
-        if not st.quantized and not getattr(st, "slots", False):
-            self._plan_fused_oproj(bufs, B, 1, st.Tp)
+        if not getattr(st, "slots", False):
+            self._plan_fused_oproj(bufs, B, 1, st.Tp, st.quantized)
         bufs["rope_cos"] = torch.empty((B, 1, self.hd // 2), dtype=F32, device=dev)
         bufs["rope_sin"] = torch.empty_like(bufs["rope_cos"])
         g["bufs"] = bufs

@@ -321,6 +321,11 @@ def attention_decode_can_fuse_oproj(B, Lq, nh, hd, n_split, cache_t, o_n, merge_
     return bool(L.lib().p3v_attention_decode_can_fuse_oproj(B, Lq, nh, hd, n_split, cache_t, o_n, int(bool(merge_in_launch))))
 
 
+def attention_decode_q8_can_fuse_oproj(B, Lq, nh, hd, n_split, cache_t, o_n, merge_in_launch):
+    """Does the fused int8-KV attention + fp8 o_proj + residual launch take this shape on this device (include/p3v.h)?"""
+    return bool(L.lib().p3v_attention_decode_q8_can_fuse_oproj(B, Lq, nh, hd, n_split, cache_t, o_n, int(bool(merge_in_launch))))
+
+
 def attention_decode(qkv, cos_new, sin_new, rope_bstride, k_cache, v_cache, out, B, Lq, nh, nkv, hd, scale, past, cache_t, ws,
                      n_split, pad_len=None, d_past=None, merge_in_launch=False, o_proj_w=None, o_proj_x=None, o_rearm=None):
     """Fused decode-step attention: head split + RoPE + KV append + split-KV attention + merge.
@@ -354,10 +359,17 @@ def kv_dequantize(k8, v8t, k_scale, v_scale, k, vt, n_tok):
 
 
 def attention_decode_q8(qkv, cos_new, sin_new, rope_bstride, k8, v8t, k_scale, v_scale, out, B, Lq, nh, nkv, hd, scale, past,
-                        cache_t, ws, n_split, pad_len=None, d_past=None, merge_in_launch=False):
-    """`attention_decode` on the int8 KV cache (merge_in_launch: as there)."""
+                        cache_t, ws, n_split, pad_len=None, d_past=None, merge_in_launch=False, o_proj_w8=None, o_proj_scale=None,
+                        o_proj_x=None, o_rearm=None):
+    """`attention_decode` on the int8 KV cache (merge_in_launch: as there).  o_proj_w8 / o_proj_scale / o_proj_x / o_rearm: also
+    the layer's o_proj on e4m3 weights + residual in the same launch (as attention_decode's o_proj_*; see p3v.h)."""
+    if o_proj_w8 is not None:
+        _chk(o_proj_w8, torch.uint8, "o_proj_w8"), _chk(o_proj_scale, F32, "o_proj_scale"), _chk(o_proj_x, BF16, "o_proj_x"), _chk(o_rearm, BF16, "o_rearm")
+        if tuple(o_proj_w8.shape) != (o_proj_scale.numel(), nh * hd) or out.numel() < nh * hd or o_rearm.numel() < nh * hd:
+            raise ValueError("fused o_proj (fp8): o_proj_w8 is [o_n, n_heads * hd] with o_n row scales; out and o_rearm are rows")
     args = L.AttnDecQ8Args(_p(qkv), _p(cos_new), _p(sin_new), _p(k8), _p(v8t), _p(k_scale), _p(v_scale), _p(out), _p(pad_len),
-                           _p(d_past), _p(ws), B, Lq, nh, nkv, hd, int(past), cache_t, rope_bstride, n_split, float(scale), int(bool(merge_in_launch)))
+                           _p(d_past), _p(ws), B, Lq, nh, nkv, hd, int(past), cache_t, rope_bstride, n_split, float(scale), int(bool(merge_in_launch)),
+                           _p(o_proj_w8), _p(o_proj_scale), _p(o_proj_x), _p(o_rearm), 0 if o_proj_w8 is None else o_proj_w8.shape[0])
     L.check(L.lib().p3v_attention_decode_q8(C.byref(args), _stream()), "attention_decode_q8")
     return out
 

@@ -773,6 +773,47 @@ def test_kv_quantize_and_q8_decode(ops, orc, past, L, n_split, fused):
     assert (v8.cpu()[:, :, :, past].float() - (torch.round(x[:, 2 * nh:, 0].float() / (x[:, 2 * nh:, 0].float().abs().amax(-1, keepdim=True) / 127)) + 128)).abs().max() <= 1
 
 
+@pytest.mark.parametrize("past,cap,dev_past", [(2531, 2688, True), (300, 1664, False), (2559, 2688, True)])
+def test_q8_attention_decode_with_fused_fp8_oproj_is_bit_identical_to_two_launches(ops, past, cap, dev_past):
+    """k_attn_decode128_q8<true> (config 5): int8-KV attention + e4m3 o_proj + residual in ONE launch against
+    p3v_attention_decode_q8 then p3v_gemv_fp8(P3V_EPI_RESID_BF16): residual row, attention output, appended bytes and scales
+    bit-identical, ten launches in a row the same, the other output buffer re-armed, the workspace left all-ones."""
+    B, L, nh, hd, H = 1, 1, 32, 96, 3072
+    T, n_split = cap, cap // 128
+    assert ops.attention_decode_q8_can_fuse_oproj(B, L, nh, hd, n_split, T, H, True)
+    assert not ops.attention_decode_q8_can_fuse_oproj(2, L, nh, hd, n_split, T, H, True)
+    qkv = g((1, 3 * nh * hd), 155).cuda()
+    k, v = g((B, nh, T, hd), 156).cuda(), g((B, nh, hd, T), 157).cuda()
+    k8_0 = torch.full((B, nh, T, hd), 128, dtype=torch.uint8).cuda()
+    v8_0 = torch.full((B, nh, hd, T), 128, dtype=torch.uint8).cuda()
+    ks0, vs0 = torch.ones((B, nh, T)).cuda(), torch.ones((B, nh, T)).cuda()
+    ops.kv_quantize(k, v, k8_0, v8_0, ks0, vs0, 0, past)
+    w8, wsc = ops.quantize_fp8_rows((g((H, nh * hd), 158) * 0.05).cuda())
+    x0 = g((1, H), 159).cuda()
+    cos, sin = torch.rand((B, 1, hd // 2), device="cuda"), torch.rand((B, 1, hd // 2), device="cuda")
+    d_past = torch.tensor([past], dtype=torch.int32).cuda()
+    ws = ops.attention_ws(B, L, nh, hd, n_split, "cuda")
+    kw = dict(d_past=d_past if dev_past else None, merge_in_launch=True)
+    def fresh():
+        return k8_0.clone(), v8_0.clone(), ks0.clone(), vs0.clone()
+    k1, v1, ks1, vs1 = fresh()
+    o1, x1 = torch.empty((1, 1, H), dtype=BF16, device="cuda"), x0.clone()
+    ops.attention_decode_q8(qkv, cos, sin, 1, k1, v1, ks1, vs1, o1, B, L, nh, nh, hd, hd ** -0.5, past, T, ws, n_split, **kw)
+    ops.gemv_fp8(o1.view(1, H), w8, wsc, ops.EPI_RESID_BF16, resid=x1, out=x1)
+    for rep in range(10):
+        k2, v2, ks2, vs2 = fresh()
+        x2 = x0.clone()
+        o2 = torch.full((1, 1, H), -1, dtype=torch.int16, device="cuda").view(BF16)
+        other = torch.zeros((1, 1, H), dtype=BF16, device="cuda")
+        ops.attention_decode_q8(qkv, cos, sin, 1, k2, v2, ks2, vs2, o2, B, L, nh, nh, hd, hd ** -0.5, past, T, ws, n_split, **kw,
+                                o_proj_w8=w8, o_proj_scale=wsc, o_proj_x=x2, o_rearm=other)
+        assert torch.equal(o2.view(torch.int16), o1.view(torch.int16)), f"rep {rep}: attention output differs"
+        assert torch.equal(x2.view(torch.int16), x1.view(torch.int16)), f"rep {rep}: residual row differs from attention + gemv_fp8"
+        assert torch.equal(k2, k1) and torch.equal(v2, v1) and torch.equal(ks2, ks1) and torch.equal(vs2, vs1)
+        assert (other.view(torch.int16) == -1).all() and (ws.view(torch.int32) == -1).all()
+    assert not torch.isnan(x1.float()).any() and (x1.float() - x0.float()).abs().max().item() > 0.01
+
+
 def test_attention_beam_view(ops, orc):
     """n_beam: keys [0,past) come from cache row b//n_beam, new keys from a scratch (phi.py:523-527)."""
     Bc, nb, L, past, nh, hd = 2, 3, 4, 50, 2, 96
