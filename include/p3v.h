@@ -227,7 +227,10 @@ typedef struct {
    * updated in place: x += bf16(W_o . attention output), bit-identical to p3v_gemv with P3V_EPI_RESID_BF16 on `out`.  `out` must
    * hold 0xFF in every byte when the launch starts (the projecting workgroups poll its words); `o_rearm` (n_heads * hd bf16) is
    * set to 0xFF by the launch: callers alternate two output buffers between consecutive layers.  NULL o_proj_w = plain attention. */
-  const uint16_t* o_proj_w; uint16_t* o_proj_x; uint16_t* o_rearm; int o_n;
+  const void* o_proj_w; uint16_t* o_proj_x; uint16_t* o_rearm; int o_n;
+  /* ... or on MLX 4-bit group-64 weights (the device layout p3v_gemv_q4 takes): o_proj_w = W4 [o_n, n_heads * hd / 8] u32 and
+   * o_proj_sb != NULL = its scale | bias words [o_n, n_heads * hd / 64]; bit-identical to p3v_gemv_q4 with P3V_EPI_RESID_BF16. */
+  const uint32_t* o_proj_sb;
 } p3v_attn_decode_args_t;
 int p3v_attention_decode(const p3v_attn_decode_args_t* args /* host */, void* stream);
 /* 1 when the fused attention + o_proj launch takes this shape on this device (host query, no launch) */

@@ -61,7 +61,8 @@ class AttnDecArgs(C.Structure):
                 ("pad_len", vp), ("d_past", vp), ("ws", vp),
                 ("B", i32), ("L", i32), ("n_heads", i32), ("n_kv", i32), ("hd", i32), ("past", i32),
                 ("cache_t", i32), ("rope_bstride", i32), ("n_split", i32), ("scale", f32), ("merge_in_launch", i32),
-                ("o_proj_w", vp), ("o_proj_x", vp), ("o_rearm", vp), ("o_n", i32)]       # optional fused o_proj + residual
+                ("o_proj_w", vp), ("o_proj_x", vp), ("o_rearm", vp), ("o_n", i32),       # optional fused o_proj + residual
+                ("o_proj_sb", vp)]                                                       #   ... on 4-bit group-64 weights
 
 
 class AttnDecQ8Args(C.Structure):

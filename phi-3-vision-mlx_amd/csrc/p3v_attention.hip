@@ -21,7 +21,8 @@
 
 #include "p3v_common.h"
 #include "p3v_gemv3_body.h"      // dot8: the fused o_proj of k_attn_decode128_o repeats k_gemv3's arithmetic exactly
-#include "p3v_dot_f8.h"          // dot16_f8: ... and k_attn_decode128_q8_o repeats k_gemv3_f8's
+#include "p3v_dot_f8.h"          // dot16_f8: ... k_attn_decode128_q8<true> repeats k_gemv3_f8's
+#include "p3v_dot_q4.h"          // dot8_q4: ... and k_attn_decode128_o4 repeats k_gemv3_q4's
 
 struct AttnP {
   const bf16_t* q; const bf16_t* k_past; const bf16_t* v_past; const bf16_t* k_new; const bf16_t* v_new;
@@ -1358,7 +1359,8 @@ struct AttnDecP {
   int merge;                   // nonzero: the last split of a (b, head) merges the partials itself (split_merge)
   bf16_t* out;                 // [B, L, nh * 96] (fused merge only)
   // fused o_proj + residual (k_attn_decode128_o only; B = L = 1, nh * 96 = 3072): see attn_decode_body128<true>
-  const bf16_t* o_w;           // o_proj weight [o_n, nh * 96]
+  const void* o_w;             // o_proj weight [o_n, nh * 96]: bf16, or 4-bit group-64 (device layout, with o_sb) in k_attn_decode128_o4
+  const void* o_sb;            //   its scale | bias words [o_n, nh * 96 / 64] (4-bit only)
   bf16_t* o_x;                 // residual stream row [o_n]: x += bf16(W_o . attention output), in place
   bf16_t* o_rearm;             // the OTHER attention-output buffer: set to the all-ones sentinel by this launch
   int o_n;
@@ -1849,25 +1851,41 @@ __device__ __forceinline__ void attn_decode_body(const AttnDecP& p, const int bx
 #endif
 // The projection half of the fused decode launches (k_attn_decode128_o, k_attn_decode128_q8_o): workgroup `o_wl` of the launch's
 // non-merging workgroups owns rows [8 o_wl, 8 o_wl + 8) of W_o, one row pair per wave, requested when the workgroup's partial has
-// been stored.  F8: e4m3 weights with one fp32 scale per row (k_gemv3_f8's arithmetic), else bf16 (k_gemv3's).  `lds`: >= 6 KB
-// that nobody else uses any more.
-struct FoP { const void* o_w; const float* o_scale; bf16_t* o_x; const bf16_t* out; int nh; };
-template <bool F8>
+// been stored.  KIND: FO_BF16 (k_gemv3's arithmetic), FO_F8 (e4m3 weights, one fp32 scale per row: k_gemv3_f8's) or FO_Q4 (MLX
+// 4-bit group-64 in the device layout of p3v_gemv_q4.hip, `o_scale` = its SB words: k_gemv3_q4's).  `lds`: >= 7 KB that nobody
+// else uses any more.
+enum { FO_NONE = 0, FO_BF16 = 1, FO_F8 = 2, FO_Q4 = 3 };
+struct FoP { const void* o_w; const void* o_scale; bf16_t* o_x; const bf16_t* out; int nh; };
+template <int KIND>
 __device__ __forceinline__ void fo_project(const FoP f, const int o_wl, unsigned char* lds) {
-  constexpr int HD = 96, NJ = F8 ? 3 : 6;
+  constexpr bool F8 = KIND == FO_F8, Q4 = KIND == FO_Q4;
+  constexpr int HD = 96, NJ = KIND == FO_BF16 ? 6 : 3;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int o_u = o_wl * 4 + wave;                             // row pair (2 o_u, 2 o_u + 1)
-  const size_t row_bytes = (size_t)f.nh * HD * (F8 ? 1 : 2);
-  u32x4_t ow[2][NJ];
-  const u32x4_t* w0 = (const u32x4_t*)((const unsigned char*)f.o_w + (size_t)(2 * o_u) * row_bytes) + lane;
-  const u32x4_t* w1 = (const u32x4_t*)((const unsigned char*)f.o_w + (size_t)(2 * o_u + 1) * row_bytes) + lane;
+  const int Kd = f.nh * HD;
+  const size_t row_bytes = (size_t)Kd * (Q4 ? 1 : F8 ? 2 : 4) / 2;
+  u32x4_t ow[2][Q4 ? 1 : NJ];                                  // bf16 / e4m3: 16-byte chunks
+  u32x2_t oq[2][Q4 ? 3 : 1];                                   // 4-bit: 16-weight pieces (8 bytes) + their scale | bias words
+  uint32_t osb[2][Q4 ? 3 : 1];
+  const unsigned char* r0p = (const unsigned char*)f.o_w + (size_t)(2 * o_u) * row_bytes;
+  if (Q4) {
+    const uint32_t* s0 = (const uint32_t*)f.o_scale + (size_t)(2 * o_u) * (Kd / 64) + (lane >> 2);
 #pragma unroll
-  for (int j = 0; j < NJ; ++j) {
-    ow[0][j] = __builtin_nontemporal_load(w0 + j * 64);
-    ow[1][j] = __builtin_nontemporal_load(w1 + j * 64);
+    for (int j = 0; j < 3; ++j) {
+      oq[0][j] = __builtin_nontemporal_load((const u32x2_t*)r0p + j * 64 + lane);
+      oq[1][j] = __builtin_nontemporal_load((const u32x2_t*)(r0p + row_bytes) + j * 64 + lane);
+      osb[0][j] = s0[j * 16];
+      osb[1][j] = s0[Kd / 64 + j * 16];
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      ow[0][j] = __builtin_nontemporal_load((const u32x4_t*)r0p + j * 64 + lane);
+      ow[1][j] = __builtin_nontemporal_load((const u32x4_t*)(r0p + row_bytes) + j * 64 + lane);
+    }
   }
   const uint32_t ores = *(const uint32_t*)(f.o_x + 2 * o_u);
-  const float osc0 = F8 ? f.o_scale[2 * o_u] : 1.f, osc1 = F8 ? f.o_scale[2 * o_u + 1] : 1.f;
+  const float osc0 = F8 ? ((const float*)f.o_scale)[2 * o_u] : 1.f, osc1 = F8 ? ((const float*)f.o_scale)[2 * o_u + 1] : 1.f;
   {
     // Wait for the merged attention output.  1536 waves polling all 1536 words would flood the memory side with uncached
     // 4-byte loads and starve the very workgroups that produce them (measured: every wave timed out); so ONE wave per
@@ -1911,7 +1929,32 @@ __device__ __forceinline__ void fo_project(const FoP f, const int o_wl, unsigned
     __syncthreads();
     timeout = o_timeout != 0;
     float a0 = 0.f, a1 = 0.f;
-    if (F8) {                                                  // k_gemv3_f8<1, 3>: weight chunk c = 64 j + lane meets x chunks 2c, 2c + 1
+    if (Q4) {                                                  // k_gemv3_q4<1, 3>: piece pc = 64 j + lane, X = sum of its 16 activations
+      float* xsum = (float*)(lds + 6144);
+      if (tid < 192) {
+        const u32x4_t a = ((const u32x4_t*)xs)[2 * tid], b = ((const u32x4_t*)xs)[2 * tid + 1];
+        float t = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) t += (bf16lo(a[j]) + bf16hi(a[j])) + (bf16lo(b[j]) + bf16hi(b[j]));
+        xsum[tid] = t;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const int pc = j * 64 + lane;
+        const u32x4_t xa = ((const u32x4_t*)xs)[2 * pc], xb = ((const u32x4_t*)xs)[2 * pc + 1];
+        const float X = xsum[pc], X128 = 128.f * X;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const float D = dot8_q4(oq[h][j][1], xb, dot8_q4(oq[h][j][0], xa, 0.f));
+          const float c = bf16lo(osb[h][j]) * (D - X128) + bf16hi(osb[h][j]) * X;
+          if (h == 0) a0 += c; else a1 += c;
+        }
+      }
+      TMARK(13);
+      a0 = wave_sum(a0);
+      a1 = wave_sum(a1);
+    } else if (F8) {                                           // k_gemv3_f8<1, 3>: weight chunk c = 64 j + lane meets x chunks 2c, 2c + 1
 #pragma unroll
       for (int j = 0; j < 3; ++j) {
         const u32x4_t xa = ((const u32x4_t*)xs)[2 * (j * 64 + lane)], xb = ((const u32x4_t*)xs)[2 * (j * 64 + lane) + 1];
@@ -1940,7 +1983,7 @@ __device__ __forceinline__ void fo_project(const FoP f, const int o_wl, unsigned
   }
 }
 
-template <bool FO = false>
+template <int FO = 0>                                          // FO_NONE, FO_BF16 or FO_Q4: the o_proj weights' format
 __device__ __forceinline__ void attn_decode_body128(const AttnDecP& p, const int bx, const int by, const int bz, unsigned char* KV) {
   constexpr int TK = 128, WK = 32, HD = 96, KROW = HD * 2, VROWB = TK * 2, NKS = 3, NDT = 6, CPR = 12;
   constexpr int KS_BYTES = WK * KROW;                          // 6 KiB per wave = 16 x 96 fp32: the wave's O partial parks here
@@ -2203,18 +2246,23 @@ __device__ __forceinline__ void attn_decode_body128(const AttnDecP& p, const int
   TMARK(3);
   if (merger)
     split_merge<256>(p.ws + ((size_t)b * p.nh + head) * p.n_split * 16 * (HD + 2), p.out + (size_t)b * p.L * (p.nh * HD) + head * HD,
-                     (size_t)p.nh * HD, p.L, p.n_split, own, (float*)vtile, FO);
-  if (FO && o_worker) fo_project<false>(FoP{p.o_w, nullptr, p.o_x, p.out, p.nh}, o_wl, KV);
+                     (size_t)p.nh * HD, p.L, p.n_split, own, (float*)vtile, FO != 0);
+  if (FO && o_worker) fo_project<FO>(FoP{p.o_w, p.o_sb, p.o_x, p.out, p.nh}, o_wl, KV);
 }
 
 __global__ void __launch_bounds__(256) k_attn_decode128(AttnDecP p) {
   __shared__ __attribute__((aligned(1024))) unsigned char KV[4 * 6144 + 96 * 256];   // [K slice x 4 | V^T tile] = 48 KiB
-  attn_decode_body128<false>(p, blockIdx.x, blockIdx.y, blockIdx.z, KV);
+  attn_decode_body128<FO_NONE>(p, blockIdx.x, blockIdx.y, blockIdx.z, KV);
 }
 
 __global__ void __launch_bounds__(256) k_attn_decode128_o(AttnDecP p) {            // + the layer's o_proj + residual (body128<true>)
   __shared__ __attribute__((aligned(1024))) unsigned char KV[4 * 6144 + 96 * 256];
-  attn_decode_body128<true>(p, blockIdx.x, blockIdx.y, blockIdx.z, KV);
+  attn_decode_body128<FO_BF16>(p, blockIdx.x, blockIdx.y, blockIdx.z, KV);
+}
+
+__global__ void __launch_bounds__(256) k_attn_decode128_o4(AttnDecP p) {           // the same on MLX 4-bit group-64 o_proj weights
+  __shared__ __attribute__((aligned(1024))) unsigned char KV[4 * 6144 + 96 * 256];
+  attn_decode_body128<FO_Q4>(p, blockIdx.x, blockIdx.y, blockIdx.z, KV);
 }
 
 __global__ void __launch_bounds__(256) k_attn_decode(AttnDecP p) {
@@ -2512,13 +2560,18 @@ extern "C" int p3v_attention_decode(const p3v_attn_decode_args_t* a, void* strea
   AttnDecP p = {a->qkv, a->cos_t, a->sin_t, a->k_cache, a->v_cache, a->pad_len, a->d_past, a->ws,
                 a->B, a->L, a->n_heads, a->n_kv, a->past, a->cache_t, a->rope_bstride, a->n_split, a->scale,
                 chunk, grp, (65536 + grp - 1) / grp, a->merge_in_launch, (bf16_t*)a->out,
-                a->o_proj_w, (bf16_t*)a->o_proj_x, (bf16_t*)a->o_rearm, a->o_n};
+                a->o_proj_w, a->o_proj_sb, (bf16_t*)a->o_proj_x, (bf16_t*)a->o_rearm, a->o_n};
   hipStream_t s = (hipStream_t)stream;
   const dim3 grid(a->n_split, a->n_heads, a->B);
   if (a->o_proj_w) {                                           // attention + o_proj + residual in one launch
     if (!p3v_attention_decode_can_fuse_oproj(a->B, a->L, a->n_heads, a->hd, a->n_split, a->cache_t, a->o_n, a->merge_in_launch)) return P3V_ERR_UNSUPPORTED;
     if (!a->o_proj_x || !a->o_rearm || ((uintptr_t)a->o_proj_w | (uintptr_t)a->o_proj_x | (uintptr_t)a->o_rearm) & 15) return P3V_ERR_ARG;
-    hipLaunchKernelGGL(k_attn_decode128_o, grid, dim3(256), 0, s, p);
+    if (a->o_proj_sb) {                                        // 4-bit group-64 o_proj weights
+      if ((uintptr_t)a->o_proj_sb & 3) return P3V_ERR_ARG;
+      hipLaunchKernelGGL(k_attn_decode128_o4, grid, dim3(256), 0, s, p);
+    } else {
+      hipLaunchKernelGGL(k_attn_decode128_o, grid, dim3(256), 0, s, p);
+    }
     P3V_CHECK_LAUNCH();
     return P3V_OK;
   }
@@ -3453,7 +3506,7 @@ __global__ void __launch_bounds__(256) k_attn_decode128_q8(AttnDecQ8P p) {
     }
     const int o_wl = blockIdx.y * (p.n_split - 1) + blockIdx.x;   // rank among the non-merging workgroups
     if (!merger && (int)blockIdx.x < p.n_split - 1 && o_wl * 8 < p.o_n)
-      fo_project<true>(FoP{p.o_w, p.o_scale, p.o_x, p.out, p.nh}, o_wl, KV);
+      fo_project<FO_F8>(FoP{p.o_w, p.o_scale, p.o_x, p.out, p.nh}, o_wl, KV);
   }
 }
 

@@ -427,15 +427,15 @@ class Phi3VModel:
         return bufs
 
     def _plan_fused_oproj(self, bufs, B, L, T, quantized=False):
-        """B = L = 1 decode: attention + o_proj + residual as ONE launch per layer where the library takes the shape -- on plain
-        bf16 weights and a bf16 cache (k_attn_decode128_o), or on e4m3 weights and the int8 cache (config 5: k_attn_decode128_q8<true>);
-        p3v_attention.hip.  The attention output then lives in two buffers that alternate layers use, both all-ones (= "not written
+        """B = L = 1 decode: attention + o_proj + residual as ONE launch per layer where the library takes the shape -- on bf16 or
+        MLX 4-bit weights and a bf16 cache (k_attn_decode128_o / _o4), or on e4m3 weights and the int8 cache (config 5:
+        k_attn_decode128_q8<true>); p3v_attention.hip.  The attention output then lives in two buffers that alternate layers use, both all-ones (= "not written
         yet") between launches; P3V_ATTN_FUSE_OPROJ=0 switches it off."""
         cfg = self.cfg
         can = ops.attention_decode_q8_can_fuse_oproj if quantized else ops.attention_decode_can_fuse_oproj
         o_key = "model.layers.0.self_attn.o_proj.weight"
         ok = (os.environ.get("P3V_ATTN_FUSE_OPROJ", "1") != "0" and B == 1 and L == 1 and bufs.get("attn_merge", False)
-              and not self.adapters and not self.w4 and (o_key in self.w8) == bool(quantized)
+              and not self.adapters and (o_key in self.w8) == bool(quantized) and not (quantized and o_key in self.w4)
               and can(B, L, cfg.num_attention_heads, self.hd, bufs["n_split"], T, cfg.hidden_size, True))
         bufs["fuse_o"] = bool(ok)
         if ok:
@@ -548,10 +548,11 @@ class Phi3VModel:
                 fuse_o = bufs.get("fuse_o", False)
                 if fuse_o:                                      # + o_proj + residual in the same launch: x += bf16(W_o . o)
                     o_i, o_other = (bufs["o_f"], bufs["o_f2"]) if i % 2 == 0 else (bufs["o_f2"], bufs["o_f"])
+                    q4o = self.w4.get(p + "self_attn.o_proj.weight")
+                    kw_o = dict(o_proj_w=q4o[0], o_proj_sb=q4o[1]) if q4o is not None else dict(o_proj_w=w[p + "self_attn.o_proj.weight"])
                     ops.attention_decode(qkv, rc, rs, rb, st.k[i], st.v[i], o_i, B, L, nh, nkv, hd, scale,
                                          past if d_past is None else bufs.get("past_lb", -1), st.Tp, ws, n_split,
-                                         pad_len=st.pad_len, d_past=d_past, merge_in_launch=True,
-                                         o_proj_w=w[p + "self_attn.o_proj.weight"], o_proj_x=x, o_rearm=o_other)
+                                         pad_len=st.pad_len, d_past=d_past, merge_in_launch=True, o_proj_x=x, o_rearm=o_other, **kw_o)
                 else:
                     ops.attention_decode(qkv, rc, rs, rb, st.k[i], st.v[i], o, B, L, nh, nkv, hd, scale,
                                          past if d_past is None else bufs.get("past_lb", -1), st.Tp, ws, n_split,

@@ -327,19 +327,27 @@ def attention_decode_q8_can_fuse_oproj(B, Lq, nh, hd, n_split, cache_t, o_n, mer
 
 
 def attention_decode(qkv, cos_new, sin_new, rope_bstride, k_cache, v_cache, out, B, Lq, nh, nkv, hd, scale, past, cache_t, ws,
-                     n_split, pad_len=None, d_past=None, merge_in_launch=False, o_proj_w=None, o_proj_x=None, o_rearm=None):
+                     n_split, pad_len=None, d_past=None, merge_in_launch=False, o_proj_w=None, o_proj_x=None, o_rearm=None,
+                     o_proj_sb=None):
     """Fused decode-step attention: head split + RoPE + KV append + split-KV attention + merge.
     cos_new/sin_new: rows of the new positions, row (b, r) at b*rope_bstride + r.
     merge_in_launch: the split partials are merged inside the attention launch (ws: see `attention_ws`).
     o_proj_w / o_proj_x / o_rearm: also the layer's o_proj + residual, x += bf16(W_o . out), in the same launch (`out` must be
-    all 0xFF on entry; `o_rearm`, the other layer parity's output buffer, is set to 0xFF): see p3v_attn_decode_args_t."""
+    all 0xFF on entry; `o_rearm`, the other layer parity's output buffer, is set to 0xFF): see p3v_attn_decode_args_t.
+    o_proj_sb: o_proj_w is then the 4-bit group-64 W4 [o_n, K / 8] (int32) of `gemv_q4` and o_proj_sb its scale | bias words."""
     if o_proj_w is not None:
-        _chk(o_proj_w, BF16, "o_proj_w"), _chk(o_proj_x, BF16, "o_proj_x"), _chk(o_rearm, BF16, "o_rearm")
+        if o_proj_sb is not None:
+            _chk(o_proj_w, I32, "o_proj_w"), _chk(o_proj_sb, I32, "o_proj_sb")
+            if tuple(o_proj_w.shape) != (o_proj_sb.shape[0], nh * hd // 8) or o_proj_sb.shape[1] != nh * hd // 64:
+                raise ValueError("fused o_proj (4-bit): o_proj_w is [o_n, K / 8], o_proj_sb [o_n, K / 64]")
+        else:
+            _chk(o_proj_w, BF16, "o_proj_w")
+        _chk(o_proj_x, BF16, "o_proj_x"), _chk(o_rearm, BF16, "o_rearm")
         if out.numel() < nh * hd or o_rearm.numel() < nh * hd:
             raise ValueError("fused o_proj: out and o_rearm are [n_heads * hd] rows")
     args = L.AttnDecArgs(_p(qkv), _p(cos_new), _p(sin_new), _p(k_cache), _p(v_cache), _p(out), _p(pad_len), _p(d_past), _p(ws),
                          B, Lq, nh, nkv, hd, int(past), cache_t, rope_bstride, n_split, float(scale), int(bool(merge_in_launch)),
-                         _p(o_proj_w), _p(o_proj_x), _p(o_rearm), 0 if o_proj_w is None else o_proj_w.shape[0])
+                         _p(o_proj_w), _p(o_proj_x), _p(o_rearm), 0 if o_proj_w is None else o_proj_w.shape[0], _p(o_proj_sb))
     L.check(L.lib().p3v_attention_decode(C.byref(args), _stream()), "attention_decode")
     return out
 

@@ -42,7 +42,7 @@ def test_struct_layouts_match_header_field_order():
             stmt = stmt.strip()
             if not stmt:
                 continue
-            decl = re.sub(r"^(const\s+)?(void|uint16_t|uint8_t|int32_t|int64_t|float|int)\s*\*?\s*", "", stmt)
+            decl = re.sub(r"^(const\s+)?(void|uint16_t|uint8_t|uint32_t|int32_t|int64_t|float|int)\s*\*?\s*", "", stmt)
             names += [n.strip().lstrip("*").strip() for n in decl.split(",")]
         assert names == [f for f, _ in cls._fields_], (cname, names)
 

@@ -773,6 +773,38 @@ def test_kv_quantize_and_q8_decode(ops, orc, past, L, n_split, fused):
     assert (v8.cpu()[:, :, :, past].float() - (torch.round(x[:, 2 * nh:, 0].float() / (x[:, 2 * nh:, 0].float().abs().amax(-1, keepdim=True) / 127)) + 128)).abs().max() <= 1
 
 
+@pytest.mark.parametrize("past,cap,dev_past", [(2531, 2688, True), (300, 1664, False)])
+def test_attention_decode_with_fused_4bit_oproj_is_bit_identical_to_two_launches(ops, past, cap, dev_past):
+    """k_attn_decode128_o4: the fused launch on MLX 4-bit group-64 o_proj weights (the reference's quantize_model format, device
+    layout of weights.q4_repack) against p3v_attention_decode + p3v_gemv_q4(P3V_EPI_RESID_BF16): bit-identical, ten times."""
+    from phi_3_vision_mlx_amd.weights import mlx_quantize, q4_repack
+    B, L, nh, hd, H = 1, 1, 32, 96, 3072
+    T, n_split = cap, cap // 128
+    qkv = g((1, 3 * nh * hd), 165).cuda()
+    kc0, vc0 = g((B, nh, T, hd), 166).cuda(), g((B, nh, hd, T), 167).cuda()
+    w4, sb = (t.cuda() for t in q4_repack(*mlx_quantize(g((H, nh * hd), 168) * 0.05)))
+    x0 = g((1, H), 169).cuda()
+    cos, sin = torch.rand((B, 1, hd // 2), device="cuda"), torch.rand((B, 1, hd // 2), device="cuda")
+    d_past = torch.tensor([past], dtype=torch.int32).cuda()
+    ws = ops.attention_ws(B, L, nh, hd, n_split, "cuda")
+    kw = dict(d_past=d_past if dev_past else None, merge_in_launch=True)
+    hp = past - 40 if dev_past else past
+    k1, v1, o1, x1 = kc0.clone(), vc0.clone(), torch.empty((1, 1, H), dtype=BF16, device="cuda"), x0.clone()
+    ops.attention_decode(qkv, cos, sin, 1, k1, v1, o1, B, L, nh, nh, hd, hd ** -0.5, hp, T, ws, n_split, **kw)
+    ops.gemv_q4(o1.view(1, H), w4, sb, ops.EPI_RESID_BF16, resid=x1, out=x1)
+    for rep in range(10):
+        k2, v2, x2 = kc0.clone(), vc0.clone(), x0.clone()
+        o2 = torch.full((1, 1, H), -1, dtype=torch.int16, device="cuda").view(BF16)
+        other = torch.zeros((1, 1, H), dtype=BF16, device="cuda")
+        ops.attention_decode(qkv, cos, sin, 1, k2, v2, o2, B, L, nh, nh, hd, hd ** -0.5, hp, T, ws, n_split, **kw,
+                             o_proj_w=w4, o_proj_sb=sb, o_proj_x=x2, o_rearm=other)
+        assert torch.equal(o2.view(torch.int16), o1.view(torch.int16)), f"rep {rep}: attention output differs"
+        assert torch.equal(x2.view(torch.int16), x1.view(torch.int16)), f"rep {rep}: residual row differs from attention + gemv_q4"
+        assert torch.equal(k2, k1) and torch.equal(v2, v1)
+        assert (other.view(torch.int16) == -1).all() and (ws.view(torch.int32) == -1).all()
+    assert not torch.isnan(x1.float()).any() and (x1.float() - x0.float()).abs().max().item() > 0.01
+
+
 @pytest.mark.parametrize("past,cap,dev_past", [(2531, 2688, True), (300, 1664, False), (2559, 2688, True)])
 def test_q8_attention_decode_with_fused_fp8_oproj_is_bit_identical_to_two_launches(ops, past, cap, dev_past):
     """k_attn_decode128_q8<true> (config 5): int8-KV attention + e4m3 o_proj + residual in ONE launch against
