@@ -2544,7 +2544,11 @@ extern "C" int p3v_attention_decode_can_fuse_oproj(int B, int L, int n_heads, in
     int dev = 0, per_cu = 0;
     hipDeviceProp_t pr;
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess) return 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_attn_decode128_o, 256, 0) != hipSuccess || per_cu < 1) return 0;
+    int per_cu4 = 0;                                           // (the bf16 and the 4-bit form of the launch: the smaller of the two)
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_attn_decode128_o, 256, 0) != hipSuccess ||
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu4, k_attn_decode128_o4, 256, 0) != hipSuccess) return 0;
+    per_cu = min(per_cu, per_cu4);
+    if (per_cu < 1) return 0;
     capacity = (long)per_cu * (pr.multiProcessorCount - 8);   // 8 CUs of head-room: a grid of exactly the queried capacity
   }                                                           // did not co-reside in tools/scratch/persistent_chain.hip
   return (long)B * n_heads * n_split <= capacity;
