@@ -118,6 +118,15 @@ __device__ __forceinline__ float block_max(float v, float* red) {
 }
 
 static inline int p3v_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+// Row-streaming waves per 4-wave GEMV workgroup: 4, or 3 (the fourth only helps with the prologue) when that spreads the launch's
+// `waves` more evenly over the CUs -- 1536 waves as 384 workgroups put two on half of the CUs and one on the others, and the launch
+// lasts as long as the doubly loaded ones; as 512 x 3 every CU carries the same (tools/gemv_timeline.py).  forced: tuning knob.
+static inline int p3v_gemv_wpw(int waves, int n_cu, int forced) {
+  if (forced == 3 || forced == 4) return forced;
+  const float w3 = (float)p3v_cdiv(p3v_cdiv(waves, 3), n_cu) * 3.f * n_cu / (float)waves;
+  const float w4 = (float)p3v_cdiv(p3v_cdiv(waves, 4), n_cu) * 4.f * n_cu / (float)waves;
+  return w3 < w4 - 0.05f ? 3 : 4;
+}
 
 // Launch-policy knobs.  Filled ONCE from P3V_<UPPER-CASE NAME> environment variables the first time a launcher asks
 // (p3v_runtime.hip), changed afterwards only through p3v_set_tuning() (kernel tests and A/B scripts pin a variant with
@@ -127,6 +136,6 @@ struct P3vTuning {
   int gemm_no_splitk, gemm_splitk_max_m, gemm_splitk_max_s, gemm_splitk_wgs, gemm_128, gemm_persistent;
   int gemm_f8_narrow;       // -1: by shape, 0 / 1: pin the fp8 tile width
   int attn_no_dma, attn_old, attn_pp, attn_il, attn_il_waves, combine_g, kvq_old, q8_old;
-  int gemv_no_mfma, gemv_no_mfma8, gemv_wpc, gemv8_wgs, gemv_variant, gemv_rows, gemv8_min, gemv_mfma8, gemv_f8_wpc, gemv_q4_wpc;
+  int gemv_no_mfma, gemv_no_mfma8, gemv_wpc, gemv8_wgs, gemv_variant, gemv_rows, gemv8_min, gemv_mfma8, gemv_f8_wpc, gemv_q4_wpc, gemv_wpw;
 };
 const P3vTuning& p3v_tuning();

@@ -139,11 +139,22 @@ static int launch_gemv(const GemvP& p, hipStream_t s) {
 //     the epilogue travels with the stage (no dependent load at the end of a row);
 //   * grid = ~8 waves per CU, each wave owning a contiguous run of row pairs (a pure
 //     streaming read on this chip peaks at 2 blocks x 256 threads per CU, see tools/stream_floor.hip).
+#ifdef P3V_GEMV_TIMING                                         // tools/gemv_timeline.py: 100 MHz stamps per wave (entry, exit)
+__device__ long long p3v_gemv_tbuf[4096 * 2];
+extern "C" int p3v_gemv_timing_read(long long* out, int n) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(p3v_gemv_tbuf), sizeof(long long) * n) == hipSuccess ? 0 : -1;
+}
+#define GMARK(k) do { if ((threadIdx.x & 63) == 0 && blockIdx.x < 1024) p3v_gemv_tbuf[(blockIdx.x * 4 + (threadIdx.x >> 6)) * 2 + (k)] = wall_clock64(); } while (0)
+#else
+#define GMARK(k)
+#endif
 template <int MT, int NST, int CH>
-__global__ void __launch_bounds__(256) k_gemv3(GemvP p, int units_per_wave) {
+__global__ void __launch_bounds__(256) k_gemv3(GemvP p, int units_per_wave, int wpw) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ float red[8];
-  gemv3_body<MT, NST, CH>(p, units_per_wave, blockIdx.x, smem, red);
+  GMARK(0);
+  gemv3_body<MT, NST, CH>(p, units_per_wave, blockIdx.x, smem, red, wpw);
+  GMARK(1);
 }
 
 template <int MT, int NST, int CH>
@@ -159,6 +170,7 @@ static int launch_gemv3(const GemvP& p, hipStream_t s) {
   int upw = p3v_cdiv(p.units, n_cu * wpc);               // row pairs per wave
   if (upw < 1) upw = 1;
   const int waves = p3v_cdiv(p.units, upw);
+  const int wpw_ = p3v_gemv_wpw(waves, n_cu, p3v_tuning().gemv_wpw);   // 4 or 3 row-streaming waves per workgroup
   const size_t lds = (size_t)MT * p.K * 2;
   static bool attr_set = false;
   if (!attr_set && lds > 48 * 1024) {
@@ -166,7 +178,7 @@ static int launch_gemv3(const GemvP& p, hipStream_t s) {
       return P3V_ERR_HIP;
     attr_set = true;
   }
-  hipLaunchKernelGGL((k_gemv3<MT, NST, CH>), dim3(p3v_cdiv(waves, 4)), dim3(256), lds, s, p, upw);
+  hipLaunchKernelGGL((k_gemv3<MT, NST, CH>), dim3(p3v_cdiv(waves, wpw_)), dim3(256), lds, s, p, upw, wpw_);
   P3V_CHECK_LAUNCH();
   return P3V_OK;
 }

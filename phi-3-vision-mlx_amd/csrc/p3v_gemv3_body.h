@@ -30,15 +30,18 @@ __device__ __forceinline__ float dot8(u32x4_t w, u32x4_t x, float acc) {
 typedef std::integral_constant<int, 0> IC0;
 typedef std::integral_constant<int, 1> IC1;
 
+// wpw: waves of the 4-wave workgroup that take rows (4, or 3: wave 3 then only helps with the prologue).  1536 streaming waves
+// (qkv, o_proj, down) as 384 four-wave workgroups put two workgroups on half of the CUs and one on the others, and the launch
+// lasts as long as the doubly loaded CUs; 512 workgroups x 3 waves load every CU alike (tools/gemv_timeline.py).
 template <int MT, int NST, int CH>
-__device__ __forceinline__ void gemv3_body(const GemvP& p, int units_per_wave, int bx, unsigned char* smem, float* red) {
+__device__ __forceinline__ void gemv3_body(const GemvP& p, int units_per_wave, int bx, unsigned char* smem, float* red, int wpw = 4) {
   constexpr int CHUNKS = NST * CH * 64;                 // 16-byte chunks per row (K = 8 * CHUNKS)
   constexpr int XC = (CHUNKS + 255) / 256;              // x chunks per thread
   u32x4_t* xs = (u32x4_t*)smem;                         // [MT][CHUNKS] bf16 x (normalised)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const bool silu = p.epi == P3V_EPI_SILU_MUL;
   const bool has_res = p.epi == P3V_EPI_RESID_BF16;
-  const int u_begin = min(p.units, (bx * 4 + wave) * units_per_wave);
+  const int u_begin = wave < wpw ? min(p.units, (bx * wpw + wave) * units_per_wave) : p.units;
   const int u_end = min(p.units, u_begin + units_per_wave);
   const int n_st = (u_end - u_begin) * NST;
 

@@ -23,7 +23,7 @@ struct GemvF8P {
 
 // ---------------------------------------------------------------- M = 1 streaming (see k_gemv3)
 template <int NST, int CH>
-__global__ void __launch_bounds__(256) k_gemv3_f8(GemvF8P p, int units_per_wave) {
+__global__ void __launch_bounds__(256) k_gemv3_f8(GemvF8P p, int units_per_wave, int wpw) {
   constexpr int CHUNKS = NST * CH * 64;                 // 16-byte weight chunks per row (K = 16 * CHUNKS)
   constexpr int XCH = CHUNKS * 2;                       // 16-byte x chunks
   constexpr int XC = (XCH + 255) / 256;
@@ -32,7 +32,7 @@ __global__ void __launch_bounds__(256) k_gemv3_f8(GemvF8P p, int units_per_wave)
   u32x4_t* xs = (u32x4_t*)smem;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const bool silu = p.epi == P3V_EPI_SILU_MUL, has_res = p.epi == P3V_EPI_RESID_BF16;
-  const int u_begin = min(p.units, (blockIdx.x * 4 + wave) * units_per_wave);
+  const int u_begin = wave < wpw ? min(p.units, (blockIdx.x * wpw + wave) * units_per_wave) : p.units;   // (wpw: see p3v_gemv_wpw)
   const int u_end = min(p.units, u_begin + units_per_wave);
   const int n_st = (u_end - u_begin) * NST;
 
@@ -434,7 +434,8 @@ static int launch_gemv3_f8(const GemvF8P& p, hipStream_t s) {
   int upw = p3v_cdiv(p.units, n_cu * wpc);
   if (upw < 1) upw = 1;
   const int waves = p3v_cdiv(p.units, upw);
-  hipLaunchKernelGGL((k_gemv3_f8<NST, CH>), dim3(p3v_cdiv(waves, 4)), dim3(256), (size_t)p.K * 2, s, p, upw);
+  const int wpw = p3v_gemv_wpw(waves, n_cu, p3v_tuning().gemv_wpw);
+  hipLaunchKernelGGL((k_gemv3_f8<NST, CH>), dim3(p3v_cdiv(waves, wpw)), dim3(256), (size_t)p.K * 2, s, p, upw, wpw);
   P3V_CHECK_LAUNCH();
   return P3V_OK;
 }

@@ -28,7 +28,7 @@ typedef std::integral_constant<int, 0> QC0;
 typedef std::integral_constant<int, 1> QC1;
 // NST stages x NP 16-weight pieces per lane per row: K = NST * NP * 64 * 16
 template <int NST, int NP>
-__global__ void __launch_bounds__(256) k_gemv3_q4(GemvQ4P p, int units_per_wave) {
+__global__ void __launch_bounds__(256) k_gemv3_q4(GemvQ4P p, int units_per_wave, int wpw) {
   constexpr int PIECES = NST * NP * 64;                 // 16-weight pieces per row
   constexpr int K = PIECES * 16, XCH = K / 8;           // 16-byte x chunks
   constexpr int XC = (XCH + 255) / 256;
@@ -38,7 +38,7 @@ __global__ void __launch_bounds__(256) k_gemv3_q4(GemvQ4P p, int units_per_wave)
   float* xsum = (float*)(smem + K * 2);                 // [PIECES] sum of the 16 activations of a piece
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const bool silu = p.epi == P3V_EPI_SILU_MUL, has_res = p.epi == P3V_EPI_RESID_BF16;
-  const int u_begin = min(p.units, (blockIdx.x * 4 + wave) * units_per_wave);
+  const int u_begin = wave < wpw ? min(p.units, (blockIdx.x * wpw + wave) * units_per_wave) : p.units;   // (wpw: see p3v_gemv_wpw)
   const int u_end = min(p.units, u_begin + units_per_wave);
   const int n_st = (u_end - u_begin) * NST;
 
@@ -201,7 +201,8 @@ static int launch_gemv3_q4(const GemvQ4P& p, hipStream_t s) {
   int upw = p3v_cdiv(p.units, n_cu * wpc);
   if (upw < 1) upw = 1;
   const int waves = p3v_cdiv(p.units, upw);
-  hipLaunchKernelGGL((k_gemv3_q4<NST, NP>), dim3(p3v_cdiv(waves, 4)), dim3(256), (size_t)p.K * 2 + (size_t)p.K / 4, s, p, upw);
+  const int wpw = p3v_gemv_wpw(waves, n_cu, p3v_tuning().gemv_wpw);
+  hipLaunchKernelGGL((k_gemv3_q4<NST, NP>), dim3(p3v_cdiv(waves, wpw)), dim3(256), (size_t)p.K * 2 + (size_t)p.K / 4, s, p, upw, wpw);
   P3V_CHECK_LAUNCH();
   return P3V_OK;
 }

@@ -41,6 +41,7 @@ const Knob kKnobs[] = {
     {"gemv_variant", &P3vTuning::gemv_variant, 3},          {"gemv_rows", &P3vTuning::gemv_rows, 1},
     {"gemv8_min", &P3vTuning::gemv8_min, 2},                {"gemv_mfma8", &P3vTuning::gemv_mfma8, 1},
     {"gemv_f8_wpc", &P3vTuning::gemv_f8_wpc, 16},           {"gemv_q4_wpc", &P3vTuning::gemv_q4_wpc, 8},
+    {"gemv_wpw", &P3vTuning::gemv_wpw, 0},
 };
 P3vTuning g_tuning;
 std::once_flag g_tuning_once;
