@@ -55,3 +55,10 @@ for name, (N, K, epi) in shapes.items():
     ng = g.max() + 1
     print("    exit by workgroup octile (g * 8 // n):  " + "  ".join("%.2f" % ex[(g * 8 // ng) == k].mean() for k in range(8)))
     print("    workgroups %d" % ng)
+    order = np.argsort(-ex)[:24]
+    print("    slowest waves (workgroup:wave exit): " + "  ".join("%d:%d %.1f" % (g[i], idx[i] % 4, ex[i]) for i in order))
+    wgm = np.array([ex[g == k].max() for k in range(ng)])
+    cu = np.arange(ng) % 256                                  # workgroup k and k + 256 share a CU if the dispatch is breadth-first
+    both = np.array([wgm[cu == c].max() for c in range(min(256, ng))])
+    print("    per CU (last exit of its workgroups): min %.2f  mean %.2f  p90 %.2f  max %.2f; by XCD (cu %% 8): " % (both.min(), both.mean(), np.percentile(both, 90), both.max())
+          + "  ".join("%.2f" % both[np.arange(len(both)) % 8 == k].mean() for k in range(8)))
