@@ -11,13 +11,18 @@ op for op and with the reference's dtype flow:
   * the vision tower and projector run on fp32 activations (phi.py:279, 309);
   * logits are bf16 (phi.py:608).
 
-PARITY STATUS: **parity unpinned by the reference** for the model math -- the
-reference's arithmetic lives in the un-vendored `mlx==0.15.0` wheel, which is
-not installable here, and the reference's own tests (test.py) assert nothing
-numeric.  This file is an audited line-by-line
-restatement; each function cites the phi.py lines it follows.  The NumPy image
-preprocessing, by contrast, IS pinned: tests/golden/ holds vectors generated
-by importing the reference's `Phi3VImageProcessor` (tests/golden/gen_golden_ref.py).
+PARITY STATUS: **pinned to the reference's own code** (round 4).  The reference's arithmetic
+lives in the un-vendored `mlx==0.15.0` wheel, which is not installable here, so
+`tests/golden/ref_env.py` imports the reference's `phi.py` / `phi_3_vision_mlx.py` where they
+lie over a functional stand-in for the MLX API (`tests/golden/mlx_shim.py`: documented MLX
+semantics, no import of this file), `tests/golden/gen_golden_refmodel.py` runs the reference's
+`_load`, `_generate`, `_choose_from`, `_constrain` through it and commits the outputs
+(`tests/golden/ref_model_{tiny,full,wc}.*`), and `tests/test_refmodel.py` holds this oracle to
+them: text paths bit for bit (every logit of every step, cache contents, every model call
+of the constrain loops), image paths token-exact with logits inside 2^-7 of the row's maximum.
+What stays unpinned is the bits of MLX's Metal kernels (reduction order): nobody can run them
+here.  The NumPy image preprocessing is pinned separately (tests/golden/gen_golden_ref.py).
+Each function cites the phi.py lines it follows.
 
 MLX op semantics restated from the MLX documentation (not in-tree):
   nn.gelu_fast_approx(x) = x*sigmoid(1.702x); nn.GELU() = exact erf GELU;

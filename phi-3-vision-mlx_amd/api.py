@@ -292,7 +292,8 @@ def greedy_loop(model, token, cache, n_steps, streamer, token_stopper, logit_sto
     With the graph-replayed step and no logit stopper the loop is ONE STEP AHEAD of the host: step i + 1 is enqueued (its input
     token never leaves the device) before the host reads token i, so the per-token work the reference does after `mx.eval` --
     D2H copy, Streamer, TokenStopper -- runs while the GPU computes the next step.  Tokens, texts and stop step are identical;
-    when a stop fires one speculative step has been enqueued and is dropped.  With a logit stopper (it reads step i's logits
+    when a stop fires one speculative step has been enqueued: it is dropped -- the cache offset is rewound past it and the
+    STOP step's token is returned, so cache and return value are what the one-sync-per-token loop leaves.  With a logit stopper (it reads step i's logits
     on the host before deciding) or an eager model the loop is the reference's, one sync per token."""
     graph_step = getattr(model, "greedy_step", None)
     ahead = graph_step is not None and (logit_stopper is None or not logit_stopper.early_stop) and torch.is_tensor(token) and token.is_cuda
@@ -314,11 +315,18 @@ def greedy_loop(model, token, cache, n_steps, streamer, token_stopper, logit_sto
     host = []                                                       # pinned staging buffers of the copy fallback (rarely needed)
     pending = None                                                  # (event, pinned buffer) of the step the host has not read yet
 
+    debug = os.environ.get("P3V_DEBUG_STEP") == "1"
+    taken = []
+
     def take(p):
         p[0].synchronize()
+        if debug and p[2] is not None:                              # the pinned-history read trusts n_replays == the device's step
+            g_, k_ = p[2]                                           # counter; a direct graph.launch() or a d_step reset breaks that
+            assert int(g_["d_step"].item()) >= k_ + 1, f"history column {k_} read, device step counter {int(g_['d_step'].item())}"
         rows = p[1].tolist()
         if min(rows) < 0:
             raise RuntimeError(f"device step failed: NaN logits (token ids {rows})")
+        taken[:] = rows
         streamer(rows)
         return token_stopper(rows)
     st = cache[0].state
@@ -331,16 +339,17 @@ def greedy_loop(model, token, cache, n_steps, streamer, token_stopper, logit_sto
             # the step wrote its tokens into pinned host memory itself (history[:, k], model._build_decode_graph): nothing to copy,
             # the replays run back to back (an in-line D2H copy node costs the step ~18 us of idle GPU: 550 -> 556 tok/s at config 2)
             ev.record()
-            src = hist[:, k]
+            src, chk = hist[:, k], (g, k)
         else:                                                       # (history full, or kept on the device by another model class)
             if not host:
                 host = [torch.empty((B,), dtype=torch.int32).pin_memory() for _ in range(2)]
             host[i & 1].copy_(token.reshape(-1), non_blocking=True) # stream-ordered copy, before the next replay overwrites the buffer
             ev.record()
-            src = host[i & 1]
+            src, chk = host[i & 1], None
         if pending is not None and take(pending):                   # host work of step i - 1 under the GPU's step i
-            return token
-        pending = (ev, src)
+            st.offset -= 1                                          # drop the speculative step i: its K/V row lies beyond the offset
+            return torch.tensor(taken, dtype=torch.int32, device=token.device).view(-1, 1)
+        pending = (ev, src, chk)
     if pending is not None:
         take(pending)
     return token

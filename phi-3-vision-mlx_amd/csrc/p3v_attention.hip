@@ -2539,18 +2539,22 @@ extern "C" int p3v_attention_decode_can_fuse_oproj(int B, int L, int n_heads, in
   if ((long)(n_split - 1) * n_heads * 8 < o_n) return 0;
   // every workgroup of the launch must be resident at once (the projecting ones wait for the merging ones): ask the runtime how
   // many of THIS kernel fit a CU rather than assume the 3 that its 52 KB of LDS and ~100 VGPRs give today
-  static long capacity = 0;
-  if (!capacity) {
-    int dev = 0, per_cu = 0;
+  // (cached PER DEVICE: ADVICE r04 -- a process-wide value was whatever the first device that asked had)
+  static long capacity_of[P3V_MAX_DEVICES] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= P3V_MAX_DEVICES) return 0;
+  if (!capacity_of[dev]) {
+    int per_cu = 0;
     hipDeviceProp_t pr;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess) return 0;
+    if (hipGetDeviceProperties(&pr, dev) != hipSuccess) return 0;
     int per_cu4 = 0;                                           // (the bf16 and the 4-bit form of the launch: the smaller of the two)
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_attn_decode128_o, 256, 0) != hipSuccess ||
         hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu4, k_attn_decode128_o4, 256, 0) != hipSuccess) return 0;
     per_cu = min(per_cu, per_cu4);
     if (per_cu < 1) return 0;
-    capacity = (long)per_cu * (pr.multiProcessorCount - 8);   // 8 CUs of head-room: a grid of exactly the queried capacity
-  }                                                           // did not co-reside in tools/scratch/persistent_chain.hip
+    capacity_of[dev] = (long)per_cu * (pr.multiProcessorCount - 8);   // 8 CUs of head-room: a grid of exactly the queried capacity
+  }                                                                   // did not co-reside in tools/scratch/persistent_chain.hip
+  const long capacity = capacity_of[dev];
   return (long)B * n_heads * n_split <= capacity;
 }
 
@@ -3518,14 +3522,17 @@ extern "C" int p3v_attention_decode_q8_can_fuse_oproj(int B, int L, int n_heads,
   if (B != 1 || L != 1 || hd != 96 || n_heads * hd != 3072 || o_n <= 0 || o_n % 8 || !merge_in_launch) return 0;
   if (!(n_split * 128 >= cache_t && cache_t % 128 == 0 && n_split * 64 < cache_t) || n_split < 2) return 0;
   if ((long)(n_split - 1) * n_heads * 8 < o_n || p3v_tuning().q8_old) return 0;
-  static long capacity = 0;                                    // every workgroup resident at once: see p3v_attention_decode_can_fuse_oproj
-  if (!capacity) {
-    int dev = 0, per_cu = 0;
+  static long capacity_of[P3V_MAX_DEVICES] = {0};              // every workgroup resident at once: see p3v_attention_decode_can_fuse_oproj
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= P3V_MAX_DEVICES) return 0;
+  if (!capacity_of[dev]) {
+    int per_cu = 0;
     hipDeviceProp_t pr;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess) return 0;
+    if (hipGetDeviceProperties(&pr, dev) != hipSuccess) return 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_attn_decode128_q8<true>, 256, 0) != hipSuccess || per_cu < 1) return 0;
-    capacity = (long)per_cu * (pr.multiProcessorCount - 8);
+    capacity_of[dev] = (long)per_cu * (pr.multiProcessorCount - 8);
   }
+  const long capacity = capacity_of[dev];
   return (long)B * n_heads * n_split <= capacity;
 }
 

@@ -14,6 +14,7 @@ typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;  // 16-byte load u
 typedef __attribute__((ext_vector_type(2))) uint32_t u32x2_t;
 
 #define P3V_WAVE 64
+#define P3V_MAX_DEVICES 64          // per-device caches of launch properties
 
 #define P3V_CHECK_LAUNCH()                                   \
   do {                                                       \

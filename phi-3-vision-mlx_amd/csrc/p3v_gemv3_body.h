@@ -1,5 +1,6 @@
-// Body of the streaming M = 1 GEMV (k_gemv3, p3v_gemv.hip).  (The fused-launch experiments that shared it -- a GEMV chain and
-// a qkv-projection + attention launch, both bit-exact and both slower than separate launches -- live in tools/experiments/.)
+// Body of the streaming M = 1 GEMV (k_gemv3, p3v_gemv.hip), shared with the o_proj stage of the fused attention launch
+// (fo_project, p3v_attention.hip).  (Two more fused launches once shared it -- a GEMV chain and a qkv-projection + attention launch,
+// both bit-exact, both slower than separate launches; removed in round 4, described in DESIGN.md section 3.1.)
 #pragma once
 #include <type_traits>
 

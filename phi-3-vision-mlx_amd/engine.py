@@ -91,6 +91,7 @@ class ContinuousEngine:
 
     def _new_state(self):
         self.st = self.model.new_slot_state(self.slots, self.window)
+        self.model.serving = True                               # (the owner is a server: model.py)
         self.st.serving = True                                  # long-lived: the split-KV merge must not lean on dispatch order (model._split_plan)
         self.cache = [type("L", (), {"state": self.st})()]      # greedy_step reads cache[0].state
 

@@ -125,6 +125,10 @@ class Phi3VModel:
         self.adapters = {}                           # weight key -> (lora_a, lora_b, scale), see set_adapters
         self._lora_tmp = {}                          # decode-sized (M <= 16) adapter scratch: captured graphs point at it
         self._lora_flat = None                       # ONE grow-only scratch for prefill-sized calls (not graph-captured)
+        # A long-lived owner that may share the GPU with other streams / processes (server.py) sets this: the decode step then
+        # uses no launch that needs all of its workgroups resident at once (the fused attention + o_proj launch, the in-launch
+        # split-KV merge on grids larger than the machine) -- ADVICE r04.  One-shot generate() on an exclusive GPU keeps them.
+        self.serving = os.environ.get("P3V_SHARED_GPU", "0") == "1"
         self.epoch = 0                               # bumped whenever captured decode graphs become stale
         self._states = weakref.WeakSet()             # every live CacheState (their graphs bake pointers into this model)
         # quantize_model=True (fp8): prompt-sized projections run W8A8 on the fp8 MFMA unless fp8_activations=False
@@ -434,7 +438,11 @@ class Phi3VModel:
         cfg = self.cfg
         can = ops.attention_decode_q8_can_fuse_oproj if quantized else ops.attention_decode_can_fuse_oproj
         o_key = "model.layers.0.self_attn.o_proj.weight"
+        # The launch of layer i re-arms the OTHER buffer, so the two alternate cleanly only over an EVEN number of layers (an odd
+        # stack would hand layer 0 of the next step the buffer the last layer just filled: stale words read as "written").
+        # It also needs the GPU to itself (every workgroup resident at once): not for a server-owned model.
         ok = (os.environ.get("P3V_ATTN_FUSE_OPROJ", "1") != "0" and B == 1 and L == 1 and bufs.get("attn_merge", False)
+              and cfg.num_hidden_layers % 2 == 0 and not self.serving
               and not self.adapters and (o_key in self.w8) == bool(quantized) and not (quantized and o_key in self.w4)
               and can(B, L, cfg.num_attention_heads, self.hd, bufs["n_split"], T, cfg.hidden_size, True))
         bufs["fuse_o"] = bool(ok)
@@ -497,7 +505,7 @@ class Phi3VModel:
         scale = hd ** -0.5
         if bufs is None:
             bufs = self._alloc_bufs(B, L)
-            self._split_plan(bufs, B, L, st.Tp, st.quantized)     # the CAPACITY, as the captured graph plans: same kernel, same
+            self._split_plan(bufs, B, L, st.Tp, st.quantized, serving=getattr(st, "serving", False) or self.serving)   # the CAPACITY, as the captured graph plans: same kernel, same
                                                                 # split boundaries -> eager and replayed steps agree bit for bit
             if L <= ops.L.DECODE_MAX_L and n_beam == 1:
                 self._plan_fused_oproj(bufs, B, L, st.Tp, st.quantized)
@@ -592,7 +600,7 @@ class Phi3VModel:
                  logits=torch.empty((B, cfg.vocab_size), dtype=BF16, device=dev),
                  next_tok=torch.zeros((B,), dtype=I32, device=dev), ticket=torch.zeros((1,), dtype=I32, device=dev))
         bufs = self._alloc_bufs(B, 1)
-        self._split_plan(bufs, B, 1, st.Tp, st.quantized, serving=getattr(st, "serving", False))   # one split per tile of CAPACITY
+        self._split_plan(bufs, B, 1, st.Tp, st.quantized, serving=getattr(st, "serving", False) or self.serving)   # one split per tile of CAPACITY
         # the cache length only grows under a captured step (greedy_step rebuilds the graph if it ever finds it below this); a
         # slot state's column moves both ways (engine.py), so it gets no bound
         bufs["past_lb"] = -1 if getattr(st, "slots", False) else int(st.offset)

@@ -342,9 +342,13 @@ def attention_decode(qkv, cos_new, sin_new, rope_bstride, k_cache, v_cache, out,
                 raise ValueError("fused o_proj (4-bit): o_proj_w is [o_n, K / 8], o_proj_sb [o_n, K / 64]")
         else:
             _chk(o_proj_w, BF16, "o_proj_w")
+            if o_proj_w.dim() != 2 or o_proj_w.shape[1] != nh * hd:      # (the kernel reads o_n rows of n_heads * hd bf16)
+                raise ValueError(f"fused o_proj: o_proj_w must be [o_n, {nh * hd}], got {tuple(o_proj_w.shape)}")
         _chk(o_proj_x, BF16, "o_proj_x"), _chk(o_rearm, BF16, "o_rearm")
         if out.numel() < nh * hd or o_rearm.numel() < nh * hd:
             raise ValueError("fused o_proj: out and o_rearm are [n_heads * hd] rows")
+        if o_proj_x.numel() < o_proj_w.shape[0]:                         # x[0 : o_n] is updated in place
+            raise ValueError(f"fused o_proj: o_proj_x holds {o_proj_x.numel()} values, the projection writes {o_proj_w.shape[0]}")
     args = L.AttnDecArgs(_p(qkv), _p(cos_new), _p(sin_new), _p(k_cache), _p(v_cache), _p(out), _p(pad_len), _p(d_past), _p(ws),
                          B, Lq, nh, nkv, hd, int(past), cache_t, rope_bstride, n_split, float(scale), int(bool(merge_in_launch)),
                          _p(o_proj_w), _p(o_proj_x), _p(o_rearm), 0 if o_proj_w is None else o_proj_w.shape[0], _p(o_proj_sb))
@@ -375,6 +379,8 @@ def attention_decode_q8(qkv, cos_new, sin_new, rope_bstride, k8, v8t, k_scale, v
         _chk(o_proj_w8, torch.uint8, "o_proj_w8"), _chk(o_proj_scale, F32, "o_proj_scale"), _chk(o_proj_x, BF16, "o_proj_x"), _chk(o_rearm, BF16, "o_rearm")
         if tuple(o_proj_w8.shape) != (o_proj_scale.numel(), nh * hd) or out.numel() < nh * hd or o_rearm.numel() < nh * hd:
             raise ValueError("fused o_proj (fp8): o_proj_w8 is [o_n, n_heads * hd] with o_n row scales; out and o_rearm are rows")
+        if o_proj_x.numel() < o_proj_w8.shape[0]:
+            raise ValueError(f"fused o_proj (fp8): o_proj_x holds {o_proj_x.numel()} values, the projection writes {o_proj_w8.shape[0]}")
     args = L.AttnDecQ8Args(_p(qkv), _p(cos_new), _p(sin_new), _p(k8), _p(v8t), _p(k_scale), _p(v_scale), _p(out), _p(pad_len),
                            _p(d_past), _p(ws), B, Lq, nh, nkv, hd, int(past), cache_t, rope_bstride, n_split, float(scale), int(bool(merge_in_launch)),
                            _p(o_proj_w8), _p(o_proj_scale), _p(o_proj_x), _p(o_rearm), 0 if o_proj_w8 is None else o_proj_w8.shape[0])

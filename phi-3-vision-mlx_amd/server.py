@@ -281,6 +281,7 @@ def run(port=8000, synthetic=False, blind_model=False, merge=False, continuous=F
     from .api import _apply_chat_template, generate, load
     preload = load(blind_model=blind_model, synthetic=synthetic or None)
     processor = preload[1]
+    preload[0].serving = True            # a server does not own the GPU: no launch that needs its whole grid resident at once (model.py)
     if continuous:
         import torch.distributed as dist
         from .engine import ContinuousEngine, RegimeRouter

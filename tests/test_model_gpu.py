@@ -916,6 +916,38 @@ def test_full_size_decode_equals_prefill_property(full_text):
     assert_logits(b[:, -1], c[:, -1], "full-size decode vs prefill", rel_atol=6e-2)   # 32 layers: see _check_topk
 
 
+@pytest.mark.parametrize("layers,serving", [(3, False), (2, False), (2, True)], ids=["odd-stack", "even-stack", "even-stack-server"])
+def test_fused_oproj_decode_needs_an_even_stack_and_an_exclusive_gpu(layers, serving, monkeypatch):
+    """the fused attention + o_proj launch of layer i re-arms the OTHER parity's output buffer, so an odd number of
+    layers would hand layer 0 of the next step a buffer still holding the last layer's words; and it needs every workgroup of its
+    grid resident at once, which a server-owned model cannot promise.  Full-width truncations (3 and 2 layers), a context inside
+    the fused range, graph-replayed steps against eager steps with the fusion switched off: bit-identical tokens and logits, the
+    odd stack and the server-owned model without the fused launch."""
+    from phi_3_vision_mlx_amd import ops
+    from phi_3_vision_mlx_amd.api import load_synthetic
+    model, _ = load_synthetic(blind_model=True, seed=3, num_hidden_layers=layers, device="cuda:0")
+    model.serving = serving
+    ids = rand_ids(1800, 21)
+    l0, cache = model(input_ids=ids, max_tokens=12)
+    tok = ops.argmax(l0[:, -1, :].contiguous())[:, None]
+    got = []
+    t = tok
+    for _ in range(8):                                       # graph replays (the second step onwards would read the stale buffer)
+        lg, t = model.greedy_step(t, cache)
+        got.append((lg.clone(), t.clone()))
+    fused = cache[0].state.graphs["greedy"]["bufs"]["fuse_o"]
+    assert fused == (layers % 2 == 0 and not serving)
+    monkeypatch.setenv("P3V_ATTN_FUSE_OPROJ", "0")
+    _, cache2 = model(input_ids=ids, max_tokens=12)
+    t = tok
+    for i in range(8):                                       # eager steps, separate o_proj launch
+        lg, cache2 = model(input_ids=t, cache=cache2)
+        t = ops.argmax(lg[:, -1, :].contiguous())[:, None]
+        assert torch.equal(lg.view(-1), got[i][0].view(-1)), f"step {i}: logits differ"
+        assert torch.equal(t.view(-1), got[i][1].view(-1)), f"step {i}: token differs"
+    assert torch.isfinite(got[-1][0].float()).all()
+
+
 def _synth_adapter(cfg, targets, layers, rank, seed=5):
     """A 'trained' adapter: lora_a ~ U(-1/sqrt(in), 1/sqrt(in)) as LoRALinear.__init__ (phi.py:121-126), lora_b non-zero."""
     gen = torch.Generator().manual_seed(seed)

@@ -2,8 +2,8 @@
 # Round-4 PMC passes (separate passes, kernel-trace only, per MI355X_MICROARCH.md):
 #   * HBM traffic of the dominant decode kernel (gate_up GEMV) and of the decode attention -> gpurun_out/pmc_r4_hbm_traffic.json
 #     (with the kernel-source hash bench.py checks before it quotes `roofline.traffic`)
-
-
+set -euo pipefail                      # a failed pass must not leave a valid-looking JSON with zero traffic behind
+: "${GRAFT_REPO_ROOT:?run on the GPU box through gpurun (GRAFT_REPO_ROOT is the repo copy)}"
 export TMPDIR=/tmp
 OUT=$PWD/gpurun_out/pmc_r4
 rm -rf $OUT; mkdir -p $OUT
@@ -31,6 +31,8 @@ lines = []
 for tag, key, alg in (("gemv", "k_gemv3", 2 * 8192 * 3072 * 2), ("attn", "k_attn_decode128", 2 * 2541 * 32 * 96 * 2)):
     f = [v for k, d in counters(tag + "_fetch").items() if key in k for v in d.get("FETCH_SIZE", [])]
     w = [v for k, d in counters(tag + "_write").items() if key in k for v in d.get("WRITE_SIZE", [])]
+    if len(f) <= 4 or len(w) <= 4 or sum(f[4:]) == 0:
+        sys.exit(f"{tag}: {len(f)} FETCH_SIZE / {len(w)} WRITE_SIZE launches counted -- a pass failed; nothing written")
     fk = sum(f[4:]) / max(1, len(f[4:])); wk = sum(w[4:]) / max(1, len(w[4:]))
     res[tag] = {"kernel": key, "FETCH_SIZE_KiB_per_launch": fk, "WRITE_SIZE_KiB_per_launch": wk, "algorithmic_bytes_per_launch": alg,
                 "hbm_bytes_per_launch_corrected": int((2 * fk + wk) * 1024), "launches": len(f),
