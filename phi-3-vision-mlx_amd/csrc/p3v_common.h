@@ -40,6 +40,12 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
 __device__ __forceinline__ float bf16lo(uint32_t w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float bf16hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
 
+// sigmoid for the SiLU / quick-GELU epilogues: v_exp_f32 + v_rcp_f32 (1 ulp) instead of an IEEE division (~10 VALU instructions per
+// element: the quick-GELU epilogue of the ViT's fc1 spent 30 us per launch on it, tools/scratch/epi_abl.py).  Every kernel uses
+// THIS form, so the GEMM / GEMV / split-K paths keep agreeing bit for bit; against an exact division the result of the
+// following bf16 rounding differs in ~2^-15 of the elements.
+__device__ __forceinline__ float p3v_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
+
 // nn.RMSNorm = mx.fast.rms_norm (phi.py:478-479, 571): w * astype(x * rsqrt(mean x^2 + eps), bf16) -- the normalised value is
 // rounded to bf16 BEFORE the weight multiply, which rounds again (HF's Phi3RMSNorm does the same).  One bf16 pair at a time.
 __device__ __forceinline__ uint32_t rms_pair(uint32_t x2, float r, uint32_t g2) {
@@ -135,6 +141,7 @@ static inline int p3v_gemv_wpw(int waves, int n_cu, int forced) {
 struct P3vTuning {
   int gemm_big_rows;        // rows given to the 256x256-tile GEMM (-1: cost model)
   int gemm_no_splitk, gemm_splitk_max_m, gemm_splitk_max_s, gemm_splitk_wgs, gemm_128, gemm_persistent;
+  int gemm_pp;              // 256x256-tile GEMM: 1 ping-pong K loop (p3v_gemm256pp.hip), 0 the round-2..4 loop (p3v_gemm256.hip)
   int gemm_f8_narrow;       // -1: by shape, 0 / 1: pin the fp8 tile width
   int attn_no_dma, attn_old, attn_pp, attn_il, attn_il_waves, combine_g, kvq_old, q8_old;
   int gemv_no_mfma, gemv_no_mfma8, gemv_wpc, gemv8_wgs, gemv_variant, gemv_rows, gemv8_min, gemv_mfma8, gemv_f8_wpc, gemv_q4_wpc, gemv_wpw;

@@ -12,10 +12,11 @@
 //             DMA destination is lane-linear; the same XOR on the ds_read_b128
 //             side) -> conflict-free fragment reads
 //   epilogue  compile-time variant (bias / quick-GELU / erf-GELU / residual /
-//             SiLU*up / patch-embed row remap).  The accumulators go through a
-//             wave-private LDS tile so that every lane loads/stores 8 consecutive
-//             columns: 16-byte bf16 stores, full 128-byte lines per 8 lanes
-//             (the MFMA C layout itself would give 2-byte stores at a row stride).
+//             SiLU*up / patch-embed row remap), straight from the accumulators: the
+//             MFMAs take the W fragment FIRST, so a lane holds 4 consecutive columns
+//             of one output row; bf16 outputs pair two column blocks with
+//             v_permlane16_swap -> 16-byte stores of 8 consecutive columns, no LDS
+//             staging (rounds 1-4 went through a wave-private LDS tile).
 //
 // Roofline: MFMA-bound for M >= ~512 (2*M*N*K flops vs (M+N)*K*2 bytes).
 #include <stdlib.h>
@@ -28,8 +29,7 @@
 #define BN 128
 #define BK 64
 #define TILE_BYTES (BM * BK * 2)   // 16 KiB per operand tile
-#define CT_LD 68                   // fp32 row stride of the wave's 64x64 epilogue tile (2-way write conflicts only)
-#define GEMM_LDS (4 * 64 * CT_LD * 4)   // 69632 B >= 4 * TILE_BYTES
+#define GEMM_LDS (4 * TILE_BYTES)   // two stages of an A and a W tile: 64 KiB -> two workgroups per CU
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
@@ -158,7 +158,7 @@ __global__ void __launch_bounds__(256, 2) k_gemm(GemmP p) {
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[kk][i], bfr[kk][j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[kk][j], af[kk][i], acc[i][j], 0, 0, 0);   // W first: transposed block
       if (ORD == 2 && kk == 0) {
         __builtin_amdgcn_sched_barrier(0);
         if (kt + 1 < nk) stage(kt + 1, (kt + 1) & 1);
@@ -167,92 +167,109 @@ __global__ void __launch_bounds__(256, 2) k_gemm(GemmP p) {
     }
   }
 
-  // ---- epilogue: MFMA C layout (col = lane&15, row = (lane>>4)*4 + r) -> wave-private LDS tile -> rows of 8 columns
-  __syncthreads();                                            // every wave is done with the staging buffers
-  float* ct = (float*)smem + wave * (64 * CT_LD);
-  {
-    const int ccol = lane & 15, crow = (lane >> 4) * 4;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) ct[(i * 16 + crow + r) * CT_LD + j * 16 + ccol] = acc[i][j][r];
-  }
-  __syncthreads();
-
+  // ---- epilogue straight from the accumulators (round 5; rounds 1-4 staged the tile through LDS between two barriers).  The
+  // MFMAs take the W fragment first, so a 16 x 16 block comes out transposed: lane (c = lane & 15, q = lane >> 4) holds the four
+  // consecutive columns 4q .. 4q+3 of output row c.  fp32 outputs store them as they are (16 bytes); bf16 outputs first trade
+  // packed halves of two neighbouring column blocks between lanes q and q ^ 1 (v_permlane16_swap): 8 consecutive columns per lane.
+  const int fc = lane & 15, fq = lane >> 4;
+  const int mrow0 = m0 + wr * 64 + fc;                         // + i * 16
   if (SILU) {
     // wave tile columns: [0,32) gate, [32,64) up for output columns n0 + wc*32 + [0,32)
-    const int c8 = (lane & 3) * 8;
-    const int n = n0 + wc * 32 + c8;
+    const int n = n0 + wc * 32 + (fq & 1) * 16 + (fq >> 1) * 8;
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      const int row = it * 16 + (lane >> 2);
-      const int m = m0 + wr * 64 + row;
-      if (m < p.M && n < p.N) {
-        const float4 g0 = *(const float4*)(ct + row * CT_LD + c8), g1 = *(const float4*)(ct + row * CT_LD + c8 + 4);
-        const float4 u0 = *(const float4*)(ct + row * CT_LD + 32 + c8), u1 = *(const float4*)(ct + row * CT_LD + 36 + c8);
-        const float gs[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
-        const float us[8] = {u0.x, u0.y, u0.z, u0.w, u1.x, u1.y, u1.z, u1.w};
-        float o[8];
+    for (int i = 0; i < 4; ++i) {
+      uint32_t pk[2][2];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
+      for (int j = 0; j < 2; ++j) {
+        float o4[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
           // reference rounds gate/up to bf16 (Linear output) and every elementwise op after it (phi.py:469-471)
-          const float g = bf16_round(gs[e]), u = bf16_round(us[e]);
-          o[e] = bf16_round(g * bf16_round(1.f / (1.f + __expf(-g)))) * u;
+          const float g = bf16_round(acc[i][j][r]), u = bf16_round(acc[i][2 + j][r]);
+          o4[r] = bf16_round(g * bf16_round(p3v_sigmoid(g))) * u;
         }
-        store8_bf16((bf16_t*)p.out + (size_t)m * p.ldo + n, o);
+        pk[j][0] = pack_bf16x2(o4[0], o4[1]), pk[j][1] = pack_bf16x2(o4[2], o4[3]);
       }
+      u32x4_t w;
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        auto sw = __builtin_amdgcn_permlane16_swap(pk[0][k], pk[1][k], false, false);
+        w[k] = sw[0], w[2 + k] = sw[1];
+      }
+      const int m = mrow0 + i * 16;
+      if (m < p.M && n < p.N) *(u32x4_t*)((bf16_t*)p.out + (size_t)m * p.ldo + n) = w;
     }
     return;
   }
 
-  const int c8 = (lane & 7) * 8;
-  const int n = n0 + wc * 64 + c8;
-  float bias[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  const bool ncol_ok = n < p.N;
-  if (ncol_ok && p.bias) load8_bf16(p.bias + n, bias);
+  float bias[4][4];
 #pragma unroll
-  for (int it = 0; it < 8; ++it) {
-    const int row = it * 8 + (lane >> 3);
-    const int m = m0 + wr * 64 + row;
-    if (m < p.M && ncol_ok) {
-      const float4 a0 = *(const float4*)(ct + row * CT_LD + c8), a1 = *(const float4*)(ct + row * CT_LD + c8 + 4);
-      float v[8] = {a0.x + bias[0], a0.y + bias[1], a0.z + bias[2], a0.w + bias[3],
-                    a1.x + bias[4], a1.y + bias[5], a1.z + bias[6], a1.w + bias[7]};
-      const size_t o = (size_t)m * p.ldo + n;
-      if (EPI == P3V_EPI_NONE || EPI == P3V_EPI_BIAS) {
-        store8_bf16((bf16_t*)p.out + o, v);
-      } else if (EPI == P3V_EPI_BIAS_QGELU) {
+  for (int j = 0; j < 4; ++j) {
+    const int n = n0 + wc * 64 + j * 16 + fq * 4;
+    u32x2_t bw = {0u, 0u};
+    if (p.bias && n < p.N) bw = *(const u32x2_t*)(p.bias + n);
+    bias[j][0] = bf16lo(bw[0]), bias[j][1] = bf16hi(bw[0]), bias[j][2] = bf16lo(bw[1]), bias[j][3] = bf16hi(bw[1]);
+  }
+  if (EPI == P3V_EPI_BIAS_RESID_F32 || EPI == P3V_EPI_F32 || EPI == P3V_EPI_PATCH) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = v[e] / (1.f + __expf(-1.702f * v[e]));
-        store8_bf16((bf16_t*)p.out + o, v);
-      } else if (EPI == P3V_EPI_BIAS_GELU) {
+    for (int i = 0; i < 4; ++i) {
+      const int m = mrow0 + i * 16;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = gelu_erf(v[e]);
-        store8_bf16((bf16_t*)p.out + o, v);
-      } else if (EPI == P3V_EPI_RESID_BF16) {
-        float r[8];
-        load8_bf16((const bf16_t*)p.resid + o, r);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = r[e] + bf16_round(v[e]);
-        store8_bf16((bf16_t*)p.out + o, v);
-      } else if (EPI == P3V_EPI_BIAS_RESID_F32 || EPI == P3V_EPI_F32 || EPI == P3V_EPI_PATCH) {
-        size_t oo = o;
-        if (EPI == P3V_EPI_BIAS_RESID_F32) {
-          const float4 r0 = *(const float4*)((const float*)p.resid + o), r1 = *(const float4*)((const float*)p.resid + o + 4);
-          v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w; v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
-        } else if (EPI == P3V_EPI_PATCH) {
-          const int img = m / p.ppi, pi = m % p.ppi;
-          float pe[8];
-          load8_bf16(p.pos + (size_t)(1 + pi) * p.N + n, pe);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] += pe[e];
-          oo = ((size_t)img * (p.ppi + 1) + 1 + pi) * p.ldo + n;
+      for (int j = 0; j < 4; ++j) {
+        const int n = n0 + wc * 64 + j * 16 + fq * 4;
+        if (m < p.M && n < p.N) {
+          const size_t o = (size_t)m * p.ldo + n;
+          size_t oo = o;
+          float4 v = make_float4(acc[i][j][0] + bias[j][0], acc[i][j][1] + bias[j][1], acc[i][j][2] + bias[j][2], acc[i][j][3] + bias[j][3]);
+          if (EPI == P3V_EPI_BIAS_RESID_F32) {
+            const float4 r4 = *(const float4*)((const float*)p.resid + o);
+            v.x += r4.x, v.y += r4.y, v.z += r4.z, v.w += r4.w;
+          } else if (EPI == P3V_EPI_PATCH) {
+            const int img = m / p.ppi, pi = m % p.ppi;
+            const u32x2_t pw = *(const u32x2_t*)(p.pos + (size_t)(1 + pi) * p.N + n);
+            v.x += bf16lo(pw[0]), v.y += bf16hi(pw[0]), v.z += bf16lo(pw[1]), v.w += bf16hi(pw[1]);
+            oo = ((size_t)img * (p.ppi + 1) + 1 + pi) * p.ldo + n;
+          }
+          if (EPI == P3V_EPI_F32) oo += (size_t)kz * p.M * p.ldo;
+          *(float4*)((float*)p.out + oo) = v;
         }
-        if (EPI == P3V_EPI_F32) oo += (size_t)kz * p.M * p.ldo;
-        *(float4*)((float*)p.out + oo) = make_float4(v[0], v[1], v[2], v[3]);
-        *(float4*)((float*)p.out + oo + 4) = make_float4(v[4], v[5], v[6], v[7]);
+      }
+    }
+    return;
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = mrow0 + i * 16;
+#pragma unroll
+    for (int jp = 0; jp < 2; ++jp) {
+      uint32_t pk[2][2];
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+        const int j = 2 * jp + jj;
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          v[r] = acc[i][j][r] + bias[j][r];
+          if (EPI == P3V_EPI_BIAS_QGELU) v[r] = v[r] * p3v_sigmoid(1.702f * v[r]);
+          else if (EPI == P3V_EPI_BIAS_GELU) v[r] = gelu_erf(v[r]);
+        }
+        pk[jj][0] = pack_bf16x2(v[0], v[1]), pk[jj][1] = pack_bf16x2(v[2], v[3]);
+      }
+      u32x4_t w;
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        auto sw = __builtin_amdgcn_permlane16_swap(pk[0][k], pk[1][k], false, false);
+        w[k] = sw[0], w[2 + k] = sw[1];
+      }
+      const int n = n0 + wc * 64 + (2 * jp + (fq & 1)) * 16 + (fq >> 1) * 8;
+      if (m < p.M && n < p.N) {
+        const size_t o = (size_t)m * p.ldo + n;
+        if (EPI == P3V_EPI_RESID_BF16) {                       // out = resid + bf16(acc): the packed words ARE bf16(acc)
+          const u32x4_t rw = *(const u32x4_t*)((const bf16_t*)p.resid + o);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) w[k] = pack_bf16x2(bf16lo(rw[k]) + bf16lo(w[k]), bf16hi(rw[k]) + bf16hi(w[k]));
+        }
+        *(u32x4_t*)((bf16_t*)p.out + o) = w;
       }
     }
   }
@@ -336,7 +353,7 @@ __global__ void __launch_bounds__(256) k_splitk_reduce(const float* __restrict__
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const float g = bf16_round(v[e]), up = bf16_round(u[e]);
-      v[e] = bf16_round(g * bf16_round(1.f / (1.f + __expf(-g)))) * up;
+      v[e] = bf16_round(g * bf16_round(p3v_sigmoid(g))) * up;
     }
   } else if (EPI == P3V_EPI_RESID_BF16) {
     float r[8];

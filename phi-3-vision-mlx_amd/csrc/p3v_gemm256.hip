@@ -12,30 +12,15 @@
 //   before the MFMAs of phase p (second A-fragment buffer, 256 registers, no spill), +1.5-2 % at 4096^3 / 8192^3
 //   (1.28 -> 1.30, 1.32 -> 1.34 PFLOP/s).  One vmcnt(0) + barrier per K-tile.  No barrier inside a tile: the waves
 //   de-phase, one wave's fragment reads overlap another's MFMAs.
-//   Same XOR-swizzled LDS image and the same epilogues as p3v_gemm.hip (through a wave-private LDS tile).
+//   Same XOR-swizzled LDS image and the same epilogues as p3v_gemm.hip; round 5: stored straight from the accumulators.
 #include <stdlib.h>
 
-#include "p3v_common.h"
+#include "p3v_gemm256_epi.h"
 
-#define TM 256
-#define TN 256
-#define TK 64
-#define HALF_BYTES (128 * TK * 2)     // 16 KiB
 #define BUF_BYTES (4 * HALF_BYTES)    // A0 A1 B0 B1
-#define CT2_LD 68
-#define GEMM256_LDS (2 * BUF_BYTES)   // 128 KiB (epilogue: 8 waves x 64x68 fp32 = 136 KiB would not fit -> two passes of 32 rows)
-
-typedef const __attribute__((address_space(1))) void* gptr_t;
-typedef __attribute__((address_space(3))) void* lptr_t;
-
-struct Gemm256P {
-  const bf16_t* A; const bf16_t* W; void* out; const bf16_t* bias; const void* resid;
-  int M, N, K, lda, ldw, ldo;
-};
+#define GEMM256_LDS (2 * BUF_BYTES)   // 128 KiB
 
 struct Tile256 { int m0, n0; int a_off[2][2], b_off[2][2]; __amdgpu_buffer_rsrc_t rs_a; };
-
-__device__ __forceinline__ float gelu_erf2(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
 
 #ifdef P3V_G256_DEBUG                                            // tools/gemm256_timeline.py: per-wave stamps inside the K loop of ONE workgroup
 __device__ unsigned long long p3v_g256dbg[8 * 64 * 8];
@@ -167,8 +152,8 @@ __global__ void __launch_bounds__(512, 1) k_gemm256(Gemm256P p) {
         for (int i = 0; i < 4; ++i)
 #pragma unroll
           for (int j = 0; j < 2; ++j)
-            acc[asub * 4 + i][bsub * 2 + j] =
-                __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][kk], bf[j][kk], acc[asub * 4 + i][bsub * 2 + j], 0, 0, 0);
+            acc[asub * 4 + i][bsub * 2 + j] =        // (W fragment first: the block comes out TRANSPOSED, see the epilogue)
+                __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[j][kk], a[i][kk], acc[asub * 4 + i][bsub * 2 + j], 0, 0, 0);
       __builtin_amdgcn_s_setprio(0);
     };
     auto quad = [&](int asub, int bsub, bf16x8_t (&bf)[2][2]) { quad_from(asub, bsub, af, bf); };
@@ -241,100 +226,7 @@ __global__ void __launch_bounds__(512, 1) k_gemm256(Gemm256P p) {
     quad(1, 0, bf0);
   }
 
-  // ---- epilogue: 128 x 64 per wave, in four passes of 32 rows through a wave-private [32][64] fp32 LDS tile that lives in
-  // the K-tile buffer just consumed (the other one is receiving the next tile's first K-tile).  No padding fits in 8 KiB per
-  // wave: 16-byte column chunk c of row r sits at chunk c ^ (r & 1) instead, which keeps the float4 read-back conflict-free.
-  __syncthreads();
-#ifdef P3V_G256_OLD_EPI                                          // timing experiment (single-round shapes only): round-2 staging
-  float* ct = (float*)smem + wave * (32 * CT2_LD);
-  const int ccol = lane & 15, crow = (lane >> 4) * 4;
-  auto ct_at = [&](int row, int col) { return ct + row * CT2_LD + col; };
-#else
-  float* ct = (float*)(smem + ((gk - 1) & 1) * BUF_BYTES) + wave * (32 * 64);
-  const int ccol = lane & 15, crow = (lane >> 4) * 4;
-  auto ct_at = [&](int row, int col) { return ct + row * 64 + ((((col >> 2) ^ (row & 1)) << 2) | (col & 3)); };
-#endif
-#pragma unroll
-  for (int pass = 0; pass < 4; ++pass) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) *ct_at(i * 16 + crow + r, j * 16 + ccol) = acc[pass * 2 + i][j][r];
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    if (SILU) {
-      const int c8 = (lane & 3) * 8, n = n0 + wc * 32 + c8;
-#pragma unroll
-      for (int it = 0; it < 2; ++it) {
-        const int row = it * 16 + (lane >> 2);
-        const int m = m0 + wr * 128 + pass * 32 + row;
-        if (m < p.M && n < p.N) {
-          const float4 g0 = *(const float4*)ct_at(row, c8), g1 = *(const float4*)ct_at(row, c8 + 4);
-          const float4 u0 = *(const float4*)ct_at(row, 32 + c8), u1 = *(const float4*)ct_at(row, 36 + c8);
-          const float gs[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
-          const float us[8] = {u0.x, u0.y, u0.z, u0.w, u1.x, u1.y, u1.z, u1.w};
-          u32x4_t w;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            float o2[2];
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-              const float g = bf16_round(gs[2 * e + h]), u = bf16_round(us[2 * e + h]);
-              o2[h] = bf16_round(g * bf16_round(1.f / (1.f + __expf(-g)))) * u;
-            }
-            w[e] = pack_bf16x2(o2[0], o2[1]);
-          }
-          *(u32x4_t*)((bf16_t*)p.out + (size_t)m * p.ldo + n) = w;
-        }
-      }
-    } else {
-      const int c8 = (lane & 7) * 8, n = n0 + wc * 64 + c8;
-      const bool ncol_ok = n < p.N;
-      float bias[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-      if (ncol_ok && p.bias) {
-        const u32x4_t bw = *(const u32x4_t*)(p.bias + n);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { bias[2 * j] = bf16lo(bw[j]); bias[2 * j + 1] = bf16hi(bw[j]); }
-      }
-#pragma unroll
-      for (int it = 0; it < 4; ++it) {
-        const int row = it * 8 + (lane >> 3);
-        const int m = m0 + wr * 128 + pass * 32 + row;
-        if (m < p.M && ncol_ok) {
-          const float4 a0 = *(const float4*)ct_at(row, c8), a1 = *(const float4*)ct_at(row, c8 + 4);
-          float v[8] = {a0.x + bias[0], a0.y + bias[1], a0.z + bias[2], a0.w + bias[3],
-                        a1.x + bias[4], a1.y + bias[5], a1.z + bias[6], a1.w + bias[7]};
-          const size_t o = (size_t)m * p.ldo + n;
-          if (EPI == P3V_EPI_BIAS_QGELU) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = v[e] / (1.f + __expf(-1.702f * v[e]));
-          } else if (EPI == P3V_EPI_BIAS_GELU) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = gelu_erf2(v[e]);
-          } else if (EPI == P3V_EPI_RESID_BF16) {
-            const u32x4_t rw = *(const u32x4_t*)((const bf16_t*)p.resid + o);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { v[2 * j] = bf16lo(rw[j]) + bf16_round(v[2 * j]); v[2 * j + 1] = bf16hi(rw[j]) + bf16_round(v[2 * j + 1]); }
-          }
-          if (EPI == P3V_EPI_BIAS_RESID_F32 || EPI == P3V_EPI_F32) {
-            if (EPI == P3V_EPI_BIAS_RESID_F32) {
-              const float4 r0 = *(const float4*)((const float*)p.resid + o), r1 = *(const float4*)((const float*)p.resid + o + 4);
-              v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w; v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
-            }
-            *(float4*)((float*)p.out + o) = make_float4(v[0], v[1], v[2], v[3]);
-            *(float4*)((float*)p.out + o + 4) = make_float4(v[4], v[5], v[6], v[7]);
-          } else {
-            u32x4_t w;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) w[j] = pack_bf16x2(v[2 * j], v[2 * j + 1]);
-            *(u32x4_t*)((bf16_t*)p.out + o) = w;
-          }
-        }
-      }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  }
+  gemm256_epilogue<EPI>(p, acc, m0, n0, wr, wc, lane);      // straight from the accumulators: p3v_gemm256_epi.h
   if (!has_next) break;
   wid += gridDim.x;
   make_tile(wid, cur_t);
@@ -368,12 +260,18 @@ static int launch_gemm256_v(const Gemm256P& p, hipStream_t s) {
 template <int EPI>
 static int launch_gemm256(const Gemm256P& p, hipStream_t s) { return launch_gemm256_v<EPI, 0x50, 2>(p, s); }
 
+int p3v_gemm256pp_try(const p3v_gemm_args_t* a, hipStream_t s);   // p3v_gemm256pp.hip: the same tile with the ping-pong K loop
+
 // called by p3v_gemm (which decides how many rows get the big tile); returns P3V_ERR_UNSUPPORTED to fall back
 int p3v_gemm256_try(const p3v_gemm_args_t* a, hipStream_t s) {
   const int n_tile = a->epilogue == P3V_EPI_SILU_MUL ? TN / 2 : TN;
   if (a->N % n_tile || a->K % TK || a->epilogue == P3V_EPI_PATCH) return P3V_ERR_UNSUPPORTED;
   const size_t w_rows = (size_t)a->N * (a->epilogue == P3V_EPI_SILU_MUL ? 2 : 1);
   if (w_rows * a->ldw * 2 >= ((size_t)1 << 32) || (size_t)256 * a->lda * 2 >= ((size_t)1 << 31)) return P3V_ERR_UNSUPPORTED;  // 32-bit buffer offsets
+  if (p3v_tuning().gemm_pp) {
+    const int rc = p3v_gemm256pp_try(a, s);
+    if (rc != P3V_ERR_UNSUPPORTED) return rc;
+  }
   const Gemm256P p = {a->A, a->W, a->out, a->bias, a->resid, a->M, a->N, a->K, a->lda, a->ldw, a->ldo};
   switch (a->epilogue) {
     case P3V_EPI_NONE: return launch_gemm256<P3V_EPI_NONE>(p, s);
