@@ -141,7 +141,6 @@ static inline int p3v_gemv_wpw(int waves, int n_cu, int forced) {
 struct P3vTuning {
   int gemm_big_rows;        // rows given to the 256x256-tile GEMM (-1: cost model)
   int gemm_no_splitk, gemm_splitk_max_m, gemm_splitk_max_s, gemm_splitk_wgs, gemm_128, gemm_persistent;
-  int gemm_pp;              // 256x256-tile GEMM: 1 ping-pong K loop (p3v_gemm256pp.hip), 0 the round-2..4 loop (p3v_gemm256.hip)
   int gemm_f8_narrow;       // -1: by shape, 0 / 1: pin the fp8 tile width
   int attn_no_dma, attn_old, attn_pp, attn_il, attn_il_waves, combine_g, kvq_old, q8_old;
   int gemv_no_mfma, gemv_no_mfma8, gemv_wpc, gemv8_wgs, gemv_variant, gemv_rows, gemv8_min, gemv_mfma8, gemv_f8_wpc, gemv_q4_wpc, gemv_wpw;

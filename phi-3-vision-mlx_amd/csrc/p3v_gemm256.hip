@@ -101,6 +101,7 @@ __global__ void __launch_bounds__(512, 1) k_gemm256(Gemm256P p) {
 #pragma unroll
   for (int w4 = 0; w4 < 4; ++w4) dma_half(cur_t, w4, 0, 0);
   int gk = 0;                                                     // K-tiles consumed so far: LDS buffer = gk & 1
+  bool landed = false;                                            // this wave's pieces of the K-tile about to be consumed are already in LDS
   for (;;) {
   const int m0 = cur_t.m0, n0 = cur_t.n0;
   const bool has_next = wid + (int)gridDim.x < nwg;
@@ -115,9 +116,11 @@ __global__ void __launch_bounds__(512, 1) k_gemm256(Gemm256P p) {
 #endif
   for (int kt = 0; kt < nk; ++kt, ++gk) {
     G_S(0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // (first K-tile of a later tile: waited for BEFORE the previous tile's stores were issued, below -- a vmcnt(0) here would
+    //  wait for those stores to drain; so the barrier is the raw one, __syncthreads() would add that wait back)
+    if (!(kt == 0 && landed)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     G_S(1);
-    __syncthreads();
+    __builtin_amdgcn_s_barrier();
     G_S(2);
     const bool last = kt + 1 == nk;
     const bool more = !last || has_next;                          // something to prefetch: this tile's next K-tile, or the next tile's first
@@ -226,6 +229,13 @@ __global__ void __launch_bounds__(512, 1) k_gemm256(Gemm256P p) {
     quad(1, 0, bf0);
   }
 
+  // The next tile's first K-tile was requested during the last K-tile above: wait for it NOW, ahead of the epilogue's stores.  The
+  // vector-memory counter cannot tell loads from stores, so behind the stores the same wait would last until they have drained
+  // (all 256 CUs store at once: the HBM write rate, 5-10 us per tile); this way the next tile's first 64 MFMAs run under the drain.
+  if (has_next) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    landed = true;
+  }
   gemm256_epilogue<EPI>(p, acc, m0, n0, wr, wc, lane);      // straight from the accumulators: p3v_gemm256_epi.h
   if (!has_next) break;
   wid += gridDim.x;
@@ -260,18 +270,12 @@ static int launch_gemm256_v(const Gemm256P& p, hipStream_t s) {
 template <int EPI>
 static int launch_gemm256(const Gemm256P& p, hipStream_t s) { return launch_gemm256_v<EPI, 0x50, 2>(p, s); }
 
-int p3v_gemm256pp_try(const p3v_gemm_args_t* a, hipStream_t s);   // p3v_gemm256pp.hip: the same tile with the ping-pong K loop
-
 // called by p3v_gemm (which decides how many rows get the big tile); returns P3V_ERR_UNSUPPORTED to fall back
 int p3v_gemm256_try(const p3v_gemm_args_t* a, hipStream_t s) {
   const int n_tile = a->epilogue == P3V_EPI_SILU_MUL ? TN / 2 : TN;
   if (a->N % n_tile || a->K % TK || a->epilogue == P3V_EPI_PATCH) return P3V_ERR_UNSUPPORTED;
   const size_t w_rows = (size_t)a->N * (a->epilogue == P3V_EPI_SILU_MUL ? 2 : 1);
   if (w_rows * a->ldw * 2 >= ((size_t)1 << 32) || (size_t)256 * a->lda * 2 >= ((size_t)1 << 31)) return P3V_ERR_UNSUPPORTED;  // 32-bit buffer offsets
-  if (p3v_tuning().gemm_pp) {
-    const int rc = p3v_gemm256pp_try(a, s);
-    if (rc != P3V_ERR_UNSUPPORTED) return rc;
-  }
   const Gemm256P p = {a->A, a->W, a->out, a->bias, a->resid, a->M, a->N, a->K, a->lda, a->ldw, a->ldo};
   switch (a->epilogue) {
     case P3V_EPI_NONE: return launch_gemm256<P3V_EPI_NONE>(p, s);
