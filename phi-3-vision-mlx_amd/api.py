@@ -236,16 +236,16 @@ def _attach_adapter(model, adapter_path, model_path=None):
 
 
 def load_synthetic(blind_model=False, tiny=False, seed=0, device=None, std_scale=1.0, adapter_path=None, lm_head_spread=0.0,
-                   lm_head_seed=0, outliers=None, **kwargs):
+                   lm_head_seed=0, outliers=None, residual_scale=None, **kwargs):
     """Seeded random weights of the real (or tiny) architecture -- no checkpoint needed.
     lm_head_spread / lm_head_seed: decisive-argmax head of the parity fixtures (weights.peaked_lm_head);
-    outliers: heavy-tailed activations (weights.add_outliers)."""
+    outliers: heavy-tailed activations (weights.add_outliers); residual_scale: the well-conditioned checkpoint (weights.synth_weights)."""
     from .model import Phi3VModel
     d = tiny_config_dict(vision=not blind_model) if tiny else phi3v_config_dict(vision=not blind_model)
     cfg = make_config(d, **kwargs)
     device = device or f"cuda:{torch.cuda.current_device()}"
     model = Phi3VModel(cfg, synth_weights(cfg, seed=seed, device=device, std_scale=std_scale, lm_head_spread=lm_head_spread,
-                                          lm_head_seed=lm_head_seed, outliers=outliers), device=device)
+                                          lm_head_seed=lm_head_seed, outliers=outliers, residual_scale=residual_scale), device=device)
     if adapter_path:
         _attach_adapter(model, adapter_path)
     return model, _make_processor(cfg, None)

@@ -186,7 +186,7 @@ __global__ void __launch_bounds__(256, 2) k_gemm(GemmP p) {
         for (int r = 0; r < 4; ++r) {
           // reference rounds gate/up to bf16 (Linear output) and every elementwise op after it (phi.py:469-471)
           const float g = bf16_round(acc[i][j][r]), u = bf16_round(acc[i][2 + j][r]);
-          o4[r] = bf16_round(g * bf16_round(p3v_sigmoid(g))) * u;
+          o4[r] = bf16_round(g * bf16_round(1.f / (1.f + __expf(-g)))) * u;
         }
         pk[j][0] = pack_bf16x2(o4[0], o4[1]), pk[j][1] = pack_bf16x2(o4[2], o4[3]);
       }
@@ -353,7 +353,7 @@ __global__ void __launch_bounds__(256) k_splitk_reduce(const float* __restrict__
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const float g = bf16_round(v[e]), up = bf16_round(u[e]);
-      v[e] = bf16_round(g * bf16_round(p3v_sigmoid(g))) * up;
+      v[e] = bf16_round(g * bf16_round(1.f / (1.f + __expf(-g)))) * up;
     }
   } else if (EPI == P3V_EPI_RESID_BF16) {
     float r[8];

@@ -50,7 +50,7 @@ __device__ __forceinline__ void gemm256_epilogue(const Gemm256P& p, f32x4_t (&ac
         for (int r = 0; r < 4; ++r) {
           // reference rounds gate/up to bf16 (Linear output) and every elementwise op after it (phi.py:469-471)
           const float g = bf16_round(acc[i][j][r]), u = bf16_round(acc[i][2 + j][r]);
-          o4[r] = bf16_round(g * bf16_round(p3v_sigmoid(g))) * u;
+          o4[r] = bf16_round(g * bf16_round(1.f / (1.f + __expf(-g)))) * u;
         }
         pk[j][0] = pack_bf16x2(o4[0], o4[1]), pk[j][1] = pack_bf16x2(o4[2], o4[3]);
       }

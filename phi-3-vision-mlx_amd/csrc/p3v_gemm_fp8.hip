@@ -219,7 +219,7 @@ __global__ void __launch_bounds__(512, 1) k_gemm256_f8(GemmF8P p) {
             for (int h = 0; h < 2; ++h) {
               // gate / up are bf16 Linear outputs, every elementwise op after them rounds to bf16 (phi.py:469-471)
               const float g = bf16_round(gs[2 * e + h] * (s * sg[2 * e + h])), u = bf16_round(us[2 * e + h] * (s * su[2 * e + h]));
-              o2[h] = bf16_round(g * bf16_round(p3v_sigmoid(g))) * u;
+              o2[h] = bf16_round(g * bf16_round(1.f / (1.f + __expf(-g)))) * u;
             }
             w[e] = pack_bf16x2(o2[0], o2[1]);
           }

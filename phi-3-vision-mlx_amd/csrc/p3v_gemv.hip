@@ -94,7 +94,7 @@ __global__ void __launch_bounds__(256) k_gemv(GemvP p) {
         if (m >= p.M) break;
         if (silu) {
           const float g = bf16_round(a0[m]), up = bf16_round(a1[m]);
-          const float s = bf16_round(g * bf16_round(p3v_sigmoid(g)));
+          const float s = bf16_round(g * bf16_round(1.f / (1.f + __expf(-g))));
           ((bf16_t*)p.out)[(size_t)m * p.N + u] = f32_to_bf16(s * up);
         } else {
           for (int h = 0; h < (has1 ? 2 : 1); ++h) {
@@ -271,7 +271,7 @@ __global__ void __launch_bounds__(256) k_gemv_mfma(GemvP p) {
     if (SILU) {
       const float v1 = ((cpart[0][1][e] + cpart[1][1][e]) + (cpart[2][1][e] + cpart[3][1][e])) * rs;
       const float gt = bf16_round(v0), up = bf16_round(v1);
-      ((bf16_t*)p.out)[o] = f32_to_bf16(bf16_round(gt * bf16_round(p3v_sigmoid(gt))) * up);
+      ((bf16_t*)p.out)[o] = f32_to_bf16(bf16_round(gt * bf16_round(1.f / (1.f + __expf(-gt)))) * up);
     } else if (p.epi == P3V_EPI_F32) {
       ((float*)p.out)[o] = v0;
     } else if (p.epi == P3V_EPI_RESID_BF16) {
@@ -480,7 +480,7 @@ __global__ void __launch_bounds__(NW * 64) k_gemv_mfma8(GemvP p, int n_sets) {
         const size_t o = (size_t)m * p.N + n;
         if (SILU) {
           const float gt = bf16_round(v0), up = bf16_round(v1);
-          ((bf16_t*)p.out)[o] = f32_to_bf16(bf16_round(gt * bf16_round(p3v_sigmoid(gt))) * up);
+          ((bf16_t*)p.out)[o] = f32_to_bf16(bf16_round(gt * bf16_round(1.f / (1.f + __expf(-gt)))) * up);
         } else if (p.epi == P3V_EPI_F32) {
           ((float*)p.out)[o] = v0;
         } else if (p.epi == P3V_EPI_RESID_BF16) {

@@ -142,7 +142,7 @@ __device__ __forceinline__ void gemv3_body(const GemvP& p, int units_per_wave, i
           if (m < p.M) {
             if (silu) {
               const float g = bf16_round(a0[m]), up = bf16_round(a1[m]);
-              const float sg = bf16_round(g * bf16_round(p3v_sigmoid(g)));
+              const float sg = bf16_round(g * bf16_round(1.f / (1.f + __expf(-g))));
               bf16_t* dst = (bf16_t*)p.out + (size_t)m * p.N + u;
               *dst = f32_to_bf16(sg * up);
             } else if (p.epi == P3V_EPI_F32) {

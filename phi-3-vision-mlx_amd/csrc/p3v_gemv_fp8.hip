@@ -112,7 +112,7 @@ __global__ void __launch_bounds__(256) k_gemv3_f8(GemvF8P p, int units_per_wave,
       if (lane == 0) {
         if (silu) {
           const float g = bf16_round(a0), up = bf16_round(a1);
-          ((bf16_t*)p.out)[u] = f32_to_bf16(bf16_round(g * bf16_round(p3v_sigmoid(g))) * up);
+          ((bf16_t*)p.out)[u] = f32_to_bf16(bf16_round(g * bf16_round(1.f / (1.f + __expf(-g)))) * up);
         } else if (p.epi == P3V_EPI_F32) {
           ((float*)p.out)[2 * u] = a0;
           ((float*)p.out)[2 * u + 1] = a1;
@@ -232,7 +232,7 @@ __global__ void __launch_bounds__(256) k_gemv_mfma_f8(GemvF8P p) {
     if (SILU) {
       const float v1 = ((cpart[0][1][e] + cpart[1][1][e]) + (cpart[2][1][e] + cpart[3][1][e])) * rs * p.wscale[n + p.N];
       const float gt = bf16_round(v0), up = bf16_round(v1);
-      ((bf16_t*)p.out)[o] = f32_to_bf16(bf16_round(gt * bf16_round(p3v_sigmoid(gt))) * up);
+      ((bf16_t*)p.out)[o] = f32_to_bf16(bf16_round(gt * bf16_round(1.f / (1.f + __expf(-gt)))) * up);
     } else if (p.epi == P3V_EPI_F32) {
       ((float*)p.out)[o] = v0;
     } else if (p.epi == P3V_EPI_RESID_BF16) {
@@ -368,7 +368,7 @@ __global__ void __launch_bounds__(NW * 64) k_gemv_mfma8_f8(GemvF8P p) {
   if (SILU) {
     v1 *= p.wscale[n + p.N];
     const float gt = bf16_round(v0), up = bf16_round(v1);
-    ((bf16_t*)p.out)[o] = f32_to_bf16(bf16_round(gt * bf16_round(p3v_sigmoid(gt))) * up);
+    ((bf16_t*)p.out)[o] = f32_to_bf16(bf16_round(gt * bf16_round(1.f / (1.f + __expf(-gt)))) * up);
   } else if (p.epi == P3V_EPI_F32) {
     ((float*)p.out)[o] = v0;
   } else if (p.epi == P3V_EPI_RESID_BF16) {

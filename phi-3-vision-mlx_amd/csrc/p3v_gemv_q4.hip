@@ -136,7 +136,7 @@ __global__ void __launch_bounds__(256) k_gemv3_q4(GemvQ4P p, int units_per_wave,
       if (lane == 0) {
         if (silu) {
           const float g = bf16_round(a0), up = bf16_round(a1);
-          ((bf16_t*)p.out)[u] = f32_to_bf16(bf16_round(g * bf16_round(p3v_sigmoid(g))) * up);
+          ((bf16_t*)p.out)[u] = f32_to_bf16(bf16_round(g * bf16_round(1.f / (1.f + __expf(-g)))) * up);
         } else if (p.epi == P3V_EPI_F32) {
           ((float*)p.out)[2 * u] = a0;
           ((float*)p.out)[2 * u + 1] = a1;

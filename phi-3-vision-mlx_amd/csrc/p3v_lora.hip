@@ -62,7 +62,7 @@ __global__ void __launch_bounds__(256) k_lora_up(const bf16_t* __restrict__ y, c
   };
   if (MODE == 2) {
     const float g = upd(n), u = upd(n + n_out);
-    out[(size_t)m * n_out + n] = f32_to_bf16(bf16_round(g * bf16_round(p3v_sigmoid(g))) * u);
+    out[(size_t)m * n_out + n] = f32_to_bf16(bf16_round(g * bf16_round(1.f / (1.f + __expf(-g)))) * u);
   } else {
     const float v = upd(n);
     out[(size_t)m * N + n] = f32_to_bf16(MODE == 1 ? bf16_to_f32(resid[(size_t)m * N + n]) + v : v);

@@ -5,7 +5,8 @@ position ids, reference phi.py:238-239, 553-559), so the path shards by REQUEST:
 one process per GPU (`torchrun`), replicated weights, rank r serves requests
 ``r, r+W, r+2W, ...``.  RCCL (``backend="nccl"``) over xGMI is used only at request
 boundaries -- the request table, an optional one-time weight broadcast, and the
-gather of results -- kilobytes per call, never per token; there is no tensor
+gather of results -- kilobytes per call, never per token, and always as TENSORS on the
+collective's own device (no pickled object crosses RCCL); there is no tensor
 parallelism.  Every helper also runs on gloo/CPU (tests/test_dist_cpu.py).
 
 Left-pad geometry and the one-shot short/long RoPE choice (Q2) depend on the
@@ -106,20 +107,56 @@ def broadcast_requests(prompts, images, src=0, group=None):
     return unpack_requests(table, payload)
 
 
-def gather_results(local_idx, local_results, n_total, group=None):
-    """All ranks end up with the full, request-ordered result list."""
+def _all_gather_ragged(t, group=None):
+    """1-D tensors of different lengths, one per rank -> list of them (two tensor collectives: the lengths, then the data padded
+    to the longest; on the collective's own device)."""
     rank, world = _world(group)
+    dev = _coll_device(group)
+    n = torch.tensor([t.numel()], dtype=torch.int64, device=dev)
+    ns = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(ns, n, group=group)
+    ns = [int(v.item()) for v in ns]
+    width = max(max(ns), 1)
+    mine = torch.zeros(width, dtype=t.dtype, device=dev)
+    mine[:t.numel()] = t.to(dev)
+    bufs = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(bufs, mine, group=group)
+    return [b[:k].cpu() for b, k in zip(bufs, ns)]
+
+
+def pack_results(local_idx, local_results):
+    """This rank's results as ONE int32 tensor: [n, kind | request ids | lengths | payload], kind 0 = texts (payload: utf-8 bytes,
+    one per word), 1 = token lists.  (Round 5: the result gather used to pickle Python objects through all_gather_object.)"""
+    res = list(local_results)
+    is_text = [isinstance(r, str) for r in res]
+    if res and any(is_text) != all(is_text):
+        raise TypeError("gather_results: a rank's results are all texts or all token lists")
+    kind = 0 if (not res or is_text[0]) else 1
+    seqs = [list(r.encode("utf-8")) if kind == 0 else [int(v) for v in r] for r in res]
+    flat = [len(res), kind] + [int(i) for i in local_idx] + [len(q) for q in seqs] + [v for q in seqs for v in q]
+    return torch.tensor(flat, dtype=torch.int32)
+
+
+def unpack_results(t, out):
+    v = t.tolist()
+    n, kind = v[0], v[1]
+    idx, lens, off = v[2:2 + n], v[2 + n:2 + 2 * n], 2 + 2 * n
+    for i, ln in zip(idx, lens):
+        seq = v[off:off + ln]
+        out[i] = bytes(seq).decode("utf-8") if kind == 0 else seq
+        off += ln
+
+
+def gather_results(local_idx, local_results, n_total, group=None):
+    """All ranks end up with the full, request-ordered result list (texts or token lists): tensor collectives only."""
+    rank, world = _world(group)
+    out = [None] * n_total
     if world == 1:
-        out = [None] * n_total
         for i, r in zip(local_idx, local_results):
             out[i] = r
         return out
-    boxes = [None] * world
-    dist.all_gather_object(boxes, (list(local_idx), list(local_results)), group=group)
-    out = [None] * n_total
-    for idx, res in boxes:
-        for i, r in zip(idx, res):
-            out[i] = r
+    for t in _all_gather_ragged(pack_results(local_idx, local_results), group):
+        unpack_results(t, out)
     return out
 
 
@@ -156,9 +193,9 @@ def _all_max(value, group=None):
     rank, world = _world(group)
     if world == 1:
         return value
-    box = [None] * world
-    dist.all_gather_object(box, int(value), group=group)
-    return max(box)
+    t = torch.tensor([int(value)], dtype=torch.int64, device=_coll_device(group))
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return int(t.item())
 
 
 def generate_sharded(prompts, images=None, preload=None, max_tokens=512, group=None, max_batch=8, apply_chat_template=True,

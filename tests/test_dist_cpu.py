@@ -98,6 +98,10 @@ def _worker_generate(rank, world, port, out_dir):
     prompts = [f"question {i} " + "y" * (5 * i) for i in range(7)]
     images = [make_image(336, 336, "noise", 3), None, None, make_image(640, 480, "smooth", 1), None, None, None]
     mine = (prompts, images) if rank == 0 else (["junk"], None)          # only rank 0 holds the request table
+
+    def no_pickle(*a, **k):                                               # (round 5) nothing on this path may pickle objects through a collective
+        raise AssertionError("object collective used: the batch-sharded path moves tensors only")
+    dist.all_gather_object = dist.broadcast_object_list = dist.gather_object = no_pickle
     got = pd.generate_sharded(*mine, preload=(StubModel(), proc), max_tokens=6, max_batch=2, return_tokens=True)
     # single-process result: every request collated into one batch
     reqs = []
@@ -109,6 +113,8 @@ def _worker_generate(rank, world, port, out_dir):
     assert any(r[-1] == 32007 and len(r) < 6 for r in got) and any(len(r) == 6 for r in got)
     texts = pd.generate_sharded(*mine, preload=(StubModel(), proc), max_tokens=4)
     assert isinstance(texts, list) and len(texts) == 7 and all(isinstance(t, str) for t in texts)
+    uni = pd.gather_results([rank], ["r\u00e9sum\u00e9 \u2713 %d" % rank], world)      # non-ASCII text survives the byte packing
+    assert uni == ["r\u00e9sum\u00e9 \u2713 0", "r\u00e9sum\u00e9 \u2713 1"], uni
     dist.barrier()
     dist.destroy_process_group()
     open(os.path.join(out_dir, f"gen{rank}"), "w").write("ok")

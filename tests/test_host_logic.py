@@ -232,16 +232,18 @@ def test_mlx_int4_format_round_trip_and_checkpoint_loading(tmp_path):
     assert torch.equal(got["model.norm.weight"], ws["model.norm.weight"])
 
 
-def test_mlx_quantize_documented_example():
-    """tests/golden/mlx_quantize_doc_example.json: a hand-worked instance of the affine group quantisation mx.quantize
+@pytest.mark.parametrize("name", ["mlx_quantize_doc_example.json", "mlx_quantize_doc_example2.json"])
+def test_mlx_quantize_documented_example(name):
+    """tests/golden/mlx_quantize_doc_example*.json: hand-worked instances of the affine group quantisation mx.quantize
     documents (formula, 8 four-bit codes per uint32 with element k in bits [4k, 4k+4), the larger-magnitude end of the range
-    represented exactly).  It pins what the loader ASSUMES about `quantized_model.safetensors` (phi_3_vision_mlx.py:297-305);
-    no MLX-written file exists in this environment to pin it harder."""
+    represented exactly).  Example 1: positive scale, bias = minimum; example 2 (round 5, derived independently of the loader's
+    code): NEGATIVE scale, bias = maximum, scrambled code order.  They pin what the loader ASSUMES about
+    `quantized_model.safetensors` (phi_3_vision_mlx.py:297-305); no MLX-written file exists in this environment to pin it harder."""
     import json
     import os
     import torch
     from phi_3_vision_mlx_amd.weights import mlx_dequantize, mlx_quantize, mlx_unpack
-    ex = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "mlx_quantize_doc_example.json")))
+    ex = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name)))
     w = torch.tensor(ex["weights"], dtype=torch.float32)
     packed = torch.tensor([[int(h, 16) for h in row] for row in ex["packed_hex"]], dtype=torch.int64)
     packed = torch.where(packed >= 2 ** 31, packed - 2 ** 32, packed).to(torch.int32)

@@ -29,9 +29,23 @@ agg = collections.OrderedDict(); gaps = []
 tot = 0
 for a, b in steps:
     seg = dec[a:b]
+    # Which projection a GEMV launch is cannot be read off its name (qkv, gate_up and lm_head share an instantiation and a grid): it
+    # is labelled by its PLACE in the step -- per layer the order is qkv, attention (+ o_proj), [o_proj], gate_up, down; the last
+    # projection of the step is the lm_head (the roofline rows must be separable from this file alone).
+    proj = [k for k, r in enumerate(seg) if "k_gemv" in r["Kernel_Name"]]
+    attn = [k for k, r in enumerate(seg) if "k_attn_decode" in r["Kernel_Name"]]
+    per_layer = max(1, (len(proj) - 1) // max(1, len(attn)))
+    names = ["qkv", "gate_up", "down"] if per_layer == 3 else ["qkv", "o_proj", "gate_up", "down"] if per_layer == 4 else None
+    role = {}
+    if names:
+        for n_, k in enumerate(proj[:-1]):
+            role[k] = names[n_ % per_layer]
+        role[proj[-1]] = "lm_head"
     for k, r in enumerate(seg):
         d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
-        key = (r["Kernel_Name"].replace("void ", "").split("(")[0][:40], r["Grid_Size_X"] if "Grid_Size_X" in r else r.get("Grid_Size", ""))
+        nm = r["Kernel_Name"].replace("void ", "").split("(")[0][:40]
+        if k in role: nm = f"{nm} [{role[k]}]"
+        key = (nm, r["Grid_Size_X"] if "Grid_Size_X" in r else r.get("Grid_Size", ""))
         agg.setdefault(key, []).append(d)
         if k > 0: gaps.append((int(r["Start_Timestamp"]) - int(seg[k - 1]["End_Timestamp"])) / 1e3)
     tot += (int(seg[-1]["End_Timestamp"]) - int(seg[0]["Start_Timestamp"])) / 1e3
@@ -39,7 +53,7 @@ n = len(steps)
 lines = [f"decode step (in-graph, rocprofv3 kernel trace, {n} steps averaged): {tot/n:.1f} us/step, "
          f"{len(dec[steps[0][0]:steps[0][1]])} kernels/step, mean gap {sum(gaps)/len(gaps):.2f} us, total gaps {sum(gaps)/n:.1f} us/step"]
 for (name, grid), v in agg.items():
-    lines.append(f"  {name:40s} grid {grid:>8s}  calls/step {len(v)/n:5.1f}  avg {sum(v)/len(v):8.2f} us  total/step {sum(v)/n:8.1f} us")
+    lines.append(f"  {name:52s} grid {grid:>8s}  calls/step {len(v)/n:5.1f}  avg {sum(v)/len(v):8.2f} us  total/step {sum(v)/n:8.1f} us")
 open(f"{out}/../trace_{tag}_summary.txt", "w").write("\n".join(lines) + "\n")
 print("\n".join(lines))
 PY
