@@ -479,7 +479,10 @@ def main():
         "value_definition": "reference-defined rate: (gen_len - 1) / gen_time over the K timed steps through _generate's loop "
                             "(api.greedy_loop) -- per-token D2H copy, Streamer, TokenStopper, detokenisation (phi_3_vision_mlx.py:390-403); the "
                             "loop runs one graph-replayed step ahead of the host, so that host work overlaps the next step; "
-                            "whole-job aggregate = n_gpus x the slowest rank's rate",
+                            "whole-job aggregate = n_gpus x the slowest rank's rate.  Batches (B > 1, the config-4 share): gen_len counts "
+                            "B tokens per step INCLUDING the B first tokens the prefill produced while gen_time starts after the prefill, "
+                            "so the figure is (B * (K + 1) - 1) / gen_time -- slightly above the device rate B * K / time by construction "
+                            "(phi_3_vision_mlx.py:77,401-403), not a faster step",
         "device_rate": {"tokens_per_s": round(tokens_per_s, 2), "ms_per_step": round(step_s * 1e3, 4),
                         "definition": "the same K steps as back-to-back graph replays between two syncs (no per-token host work)"},
         "rccl": rccl,

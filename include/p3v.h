@@ -169,6 +169,22 @@ int p3v_rope_kv_append(const uint16_t* qkv, const float* cos_t, const float* sin
                        int past, const int32_t* d_past, int dst_t, int dst_off_is_past,
                        int tab_t, int tab_div, float q_scale, void* stream);
 
+/* ---- the qkv projection with the split, the rotation and the KV append in its EPILOGUE (round 5):
+ *      p3v_gemm_qkv(g, s) == p3v_gemm(g) into a scratch [M, N] + p3v_rope_kv_append(scratch, ...) with s's arguments, bit for bit, in the
+ *      GEMM's launches alone (phi.py:437-452 / 140-147: `qkv_proj` + `split` + `_rotate_half` + KVCache append; CLIP: q/k/v projections
+ *      + head split).  g: A [B*L, K], W [(nh + 2 nkv) * hd, K] (q rows, k rows, v rows), epilogue P3V_EPI_NONE or P3V_EPI_BIAS; out /
+ *      resid / ws unused.  Prompt-sized inputs only: P3V_ERR_UNSUPPORTED (nothing launched) unless M >= 1024, hd % 32 == 0,
+ *      (hd / 2) % 16 == 0, whole 128-column tiles per region, an 8-aligned append offset and dst_t, and B == 1 or L % 8 == 0 --
+ *      callers then run the two calls. */
+typedef struct {
+  const float* cos_t; const float* sin_t;          /* as p3v_rope_kv_append; both null: plain head split */
+  uint16_t* q_out; uint16_t* k_dst; uint16_t* v_dst;
+  int B, L, n_heads, n_kv, hd;
+  int past, dst_t, dst_off_is_past, tab_t, tab_div;
+  float q_scale;
+} p3v_qkv_split_t;
+int p3v_gemm_qkv(const p3v_gemm_args_t* gemm /* host */, const p3v_qkv_split_t* split /* host */, void* stream);
+
 /* ---- attention, phi.py:454-457 (decoder, causal + left-pad, Mask4D phi.py:550-563)
  * and phi.py:148 (CLIP, no mask).  q [B, nh, L, hd]; keys/values come from two
  * segments: positions [0,past) from (k_past,v_past) batch row b/past_div
@@ -251,6 +267,15 @@ int p3v_kv_quantize(const uint16_t* k, const uint16_t* vt, uint8_t* k8, uint8_t*
  * For cached calls with more than 16 new tokens on the int8 cache (they attend through p3v_attention on this copy). */
 int p3v_kv_dequantize(const uint8_t* k8, const uint8_t* v8t, const float* k_scale, const float* v_scale, uint16_t* k,
                       uint16_t* vt, int BH, int hd, int src_t, int dst_t, int n_tok, void* stream);
+
+/* ---- the reference's OWN quantised cache, as an opt-in (load(..., quantize_cache=True, cache_format="mlx4")): phi.py:528-540 -- on the
+ * first call mx.quantize(keys.reshape(B*N, -1), group_size=32) (4 bits): every token's hd values are hd / 32 affine groups; later
+ * calls attend on mx.dequantize of them, later tokens stay unquantised.  Tokens [0, n_tok) of a bf16 K [BH, cache_t, hd] /
+ * V^T [BH, hd, cache_t] pair -> codes k4 / v4 [BH, n_tok, hd / 32, 4] (uint32, MLX's packing: code k of a word at bits [4k, 4k+4)),
+ * k_sb / v_sb [BH, n_tok, hd / 32, 2] fp32 (scale, bias), and the rows REWRITTEN IN PLACE with scale * q + bias (one rounding to
+ * bf16): what every later call of the reference attends on.  hd % 32 == 0. */
+int p3v_kv_quantize_mlx4(uint16_t* k, uint16_t* vt, uint32_t* k4, uint32_t* v4, float* k_sb, float* v_sb, int BH, int hd,
+                         int cache_t, int n_tok, void* stream);
 
 typedef struct {
   const uint16_t* qkv; const float* cos_t; const float* sin_t;

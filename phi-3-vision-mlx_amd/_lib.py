@@ -28,6 +28,12 @@ class GemmArgs(C.Structure):
                 ("epilogue", i32), ("patches_per_img", i32), ("ws", vp), ("ws_bytes", i64)]
 
 
+class QkvSplit(C.Structure):
+    _fields_ = [("cos_t", vp), ("sin_t", vp), ("q_out", vp), ("k_dst", vp), ("v_dst", vp),
+                ("B", i32), ("L", i32), ("n_heads", i32), ("n_kv", i32), ("hd", i32),
+                ("past", i32), ("dst_t", i32), ("dst_off_is_past", i32), ("tab_t", i32), ("tab_div", i32), ("q_scale", f32)]
+
+
 class GemvArgs(C.Structure):
     _fields_ = [("x", vp), ("W", vp), ("out", vp), ("resid", vp), ("norm_w", vp), ("norm_eps", f32),
                 ("M", i32), ("N", i32), ("K", i32), ("epilogue", i32)]
@@ -97,6 +103,8 @@ SIGNATURES = {
     "p3v_attention_decode_can_fuse_oproj": (i32, [i32, i32, i32, i32, i32, i32, i32, i32]),
     "p3v_kv_quantize": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "p3v_kv_dequantize": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
+    "p3v_gemm_qkv": (i32, [vp, vp, vp]),
+    "p3v_kv_quantize_mlx4": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "p3v_attention_decode_q8": (i32, [C.POINTER(AttnDecQ8Args), vp]),
     "p3v_attention_decode_q8_can_fuse_oproj": (i32, [i32, i32, i32, i32, i32, i32, i32, i32]),
     "p3v_stage_rope": (i32, [vp, vp, i32, vp, vp, vp, i32, i32, i32, i32, vp]),
@@ -145,6 +153,9 @@ def lib():
             fn.restype, fn.argtypes = res, args
         _lib = l
     return _lib
+
+
+ERR_UNSUPPORTED = -95        # P3V_ERR_UNSUPPORTED (include/p3v.h)
 
 
 def check(code, what=""):

@@ -40,6 +40,18 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
 __device__ __forceinline__ float bf16lo(uint32_t w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float bf16hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
 
+// _rotate_half on one (d, d + hd/2) pair of the bf16 projection outputs a, b (phi.py:419-423, 443-452: q * cos + rotate_half(q) * sin
+// in fp32), the query scale applied before the one rounding that follows.  ONE definition for the stand-alone kernel
+// (p3v_rope_kv_append) and the fused qkv epilogue (p3v_gemm_qkv.h), with the products pinned as separately rounded values (the empty
+// asm keeps hipcc's fp-contract from fusing one of them into the subtraction -- it chose differently in the two kernels: 1e-5 of
+// the elements apart by one ulp): multiply, multiply, add, as the reference's array expression evaluates it.
+__device__ __forceinline__ void p3v_rope_pair(float a, float b, float cs, float sn, float qs, float& o1, float& o2) {
+  float ac = a * cs, bs = b * sn, bc = b * cs, as = a * sn;
+  asm volatile("" : "+v"(ac), "+v"(bs), "+v"(bc), "+v"(as));
+  o1 = (ac - bs) * qs;
+  o2 = (bc + as) * qs;
+}
+
 // sigmoid of the quick-GELU epilogue (the ViT's fc1, fp32 tower): v_exp_f32 + v_rcp_f32 (1 ulp) instead of an IEEE division (~10 VALU
 // instructions per element: that epilogue spent 30 us per launch on it, tools/scratch/epi_abl.py).  The decoder's SiLU keeps the
 // exact division: its result is rounded to bf16 at once, where the oracle's torch.sigmoid and a 1-ulp reciprocal part ways in
@@ -142,6 +154,7 @@ static inline int p3v_gemv_wpw(int waves, int n_cu, int forced) {
 struct P3vTuning {
   int gemm_big_rows;        // rows given to the 256x256-tile GEMM (-1: cost model)
   int gemm_no_splitk, gemm_splitk_max_m, gemm_splitk_max_s, gemm_splitk_wgs, gemm_128, gemm_persistent;
+  int gemm_no_qkv_fuse;     // 1: p3v_gemm_qkv reports P3V_ERR_UNSUPPORTED (callers then run p3v_gemm + p3v_rope_kv_append)
   int gemm_f8_narrow;       // -1: by shape, 0 / 1: pin the fp8 tile width
   int attn_no_dma, attn_old, attn_pp, attn_il, attn_il_waves, combine_g, kvq_old, q8_old;
   int gemv_no_mfma, gemv_no_mfma8, gemv_wpc, gemv8_wgs, gemv_variant, gemv_rows, gemv8_min, gemv_mfma8, gemv_f8_wpc, gemv_q4_wpc, gemv_wpw;

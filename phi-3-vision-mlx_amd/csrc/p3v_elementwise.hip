@@ -276,8 +276,11 @@ __device__ __forceinline__ void rope_kv_append_token(int tok, const bf16_t* __re
 #pragma unroll
       for (int j = 0; j < 4 && rot; ++j) {
         const float a0 = bf16lo(lo[j]), a1 = bf16hi(lo[j]), b0 = bf16lo(hi[j]), b1 = bf16hi(hi[j]);
-        olo[j] = pack_bf16x2((a0 * cs[2 * j] - b0 * sn[2 * j]) * qs, (a1 * cs[2 * j + 1] - b1 * sn[2 * j + 1]) * qs);
-        ohi[j] = pack_bf16x2((b0 * cs[2 * j] + a0 * sn[2 * j]) * qs, (b1 * cs[2 * j + 1] + a1 * sn[2 * j + 1]) * qs);
+        float x0, y0, x1, y1;
+        p3v_rope_pair(a0, b0, cs[2 * j], sn[2 * j], qs, x0, y0);
+        p3v_rope_pair(a1, b1, cs[2 * j + 1], sn[2 * j + 1], qs, x1, y1);
+        olo[j] = pack_bf16x2(x0, x1);
+        ohi[j] = pack_bf16x2(y0, y1);
       }
       if (!rot && qs != 1.f) {                                // plain head split (CLIP) with pre-scaled queries
 #pragma unroll
@@ -385,6 +388,91 @@ extern "C" int p3v_rope_kv_append(const uint16_t* qkv, const float* cos_t, const
     hipLaunchKernelGGL(k_rope_kv_append, dim3(B * L), dim3(256), 0, (hipStream_t)stream, qkv, cos_t, sin_t, q_out, k_dst,
                        v_dst, L, n_heads, n_kv, hd, past, d_past, dst_t, dst_off_is_past, tab_t, tab_div, 0, q_scale);
   }
+  P3V_CHECK_LAUNCH();
+  return P3V_OK;
+}
+
+// ---------------------------------------------------------------- MLX 4-bit prompt cache (quantize_cache=True, cache_format="mlx4")
+// The reference's quantised KV cache (phi.py:528-540): on the FIRST call the keys / values of every (batch row, kv head) are
+// flattened to one row of S * hd values and mx.quantize'd with group_size 32, 4 bits -- i.e. every token's 96 dims are three
+// groups -- and every later call attends on mx.dequantize of that (later tokens stay unquantised).  One thread per (row, token,
+// group): the MLX affine group quantiser (weights.mlx_quantize: the larger-magnitude end of the range is represented exactly,
+// scale and bias stay fp32 as they do for the reference's fp32 keys), the codes in MLX's packing (code k of a word at bits
+// [4k, 4k+4)), and the group written BACK dequantised (scale * q + bias, one rounding to bf16): the cache rows then hold exactly
+// what the reference attends on from the second call on, and the decode kernels read them as they are.
+__global__ void __launch_bounds__(256) k_kv_quantize_mlx4(bf16_t* __restrict__ k, bf16_t* __restrict__ vt, uint32_t* __restrict__ k4,
+                                                          uint32_t* __restrict__ v4, float* __restrict__ k_sb, float* __restrict__ v_sb,
+                                                          int hd, int cache_t, int n_tok, long total) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int gpt = hd >> 5;                                        // groups per token (3)
+  const int t = (int)(i % n_tok);                                 // token fastest: the V^T accesses of a wave are then contiguous
+  const long r = i / n_tok;
+  const int g = (int)(r % gpt);
+  const long row2 = r / gpt;                                      // [K rows | V rows]
+  const long BH = total / ((long)n_tok * gpt * 2);
+  const bool is_v = row2 >= BH;
+  const long row = is_v ? row2 - BH : row2;
+  float w[32];
+  if (!is_v) {
+    const u32x4_t* src = (const u32x4_t*)(k + ((size_t)row * cache_t + t) * hd + g * 32);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const u32x4_t v = src[c];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { w[c * 8 + 2 * j] = bf16lo(v[j]); w[c * 8 + 2 * j + 1] = bf16hi(v[j]); }
+    }
+  } else {
+#pragma unroll
+    for (int d = 0; d < 32; ++d) w[d] = bf16_to_f32(vt[((size_t)row * hd + g * 32 + d) * cache_t + t]);
+  }
+  float w_max = w[0], w_min = w[0];
+#pragma unroll
+  for (int d = 1; d < 32; ++d) { w_max = fmaxf(w_max, w[d]); w_min = fminf(w_min, w[d]); }
+  const bool mask = fabsf(w_min) > fabsf(w_max);
+  float scale = fmaxf((w_max - w_min) / 15.f, 1e-7f);
+  scale = mask ? scale : -scale;
+  const float edge = mask ? w_min : w_max;
+  const float q0 = rintf(edge / scale);
+  if (q0 != 0.f) scale = edge / q0;
+  const float bias = q0 == 0.f ? 0.f : edge;
+  uint32_t words[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+  for (int d = 0; d < 32; ++d) {
+    const float q = fminf(fmaxf(rintf((w[d] - bias) / scale), 0.f), 15.f);
+    words[d >> 3] |= (uint32_t)q << (4 * (d & 7));
+    float prod = scale * q;                               // two roundings, as mx.dequantize's multiply-then-add: the empty asm keeps
+    asm volatile("" : "+v"(prod));                        // hipcc (fp-contract=fast) from fusing them into one fma
+    w[d] = prod + bias;
+  }
+  uint32_t* c4 = (is_v ? v4 : k4) + (((size_t)row * n_tok + t) * gpt + g) * 4;
+  *(u32x4_t*)c4 = (u32x4_t){words[0], words[1], words[2], words[3]};
+  float* sb = (is_v ? v_sb : k_sb) + (((size_t)row * n_tok + t) * gpt + g) * 2;
+  sb[0] = scale, sb[1] = bias;
+  if (!is_v) {
+    u32x4_t* dst = (u32x4_t*)(k + ((size_t)row * cache_t + t) * hd + g * 32);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      u32x4_t v;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = pack_bf16x2(w[c * 8 + 2 * j], w[c * 8 + 2 * j + 1]);
+      dst[c] = v;
+    }
+  } else {
+#pragma unroll
+    for (int d = 0; d < 32; ++d) vt[((size_t)row * hd + g * 32 + d) * cache_t + t] = f32_to_bf16(w[d]);
+  }
+}
+
+extern "C" int p3v_kv_quantize_mlx4(uint16_t* k, uint16_t* vt, uint32_t* k4, uint32_t* v4, float* k_sb, float* v_sb, int BH, int hd,
+                                    int cache_t, int n_tok, void* stream) {
+  if (!k || !vt || !k4 || !v4 || !k_sb || !v_sb) return P3V_ERR_ARG;
+  if (BH < 0 || n_tok < 0 || hd <= 0 || hd % 32 || n_tok > cache_t) return P3V_ERR_ARG;
+  if (((uintptr_t)k | (uintptr_t)k4 | (uintptr_t)v4) & 15) return P3V_ERR_ARG;
+  const long total = (long)BH * n_tok * (hd / 32) * 2;
+  if (total == 0) return P3V_OK;
+  hipLaunchKernelGGL(k_kv_quantize_mlx4, dim3((unsigned)p3v_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, k, vt, k4, v4, k_sb,
+                     v_sb, hd, cache_t, n_tok, total);
   P3V_CHECK_LAUNCH();
   return P3V_OK;
 }

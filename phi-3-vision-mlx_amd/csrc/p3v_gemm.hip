@@ -23,7 +23,9 @@
 #include <string.h>
 
 
-#include "p3v_common.h"
+#include "p3v_gemm_qkv.h"
+
+#define P3V_EPI_QKV 100                // internal: qkv projection with split + RoPE + KV append in the epilogue (p3v_gemm_qkv.h)
 
 #define BM 128
 #define BN 128
@@ -38,6 +40,7 @@ struct GemmP {
   const bf16_t* A; const bf16_t* W; void* out; const bf16_t* bias; const void* resid; const bf16_t* pos;
   int M, N, K, lda, ldw, ldo, ppi;
   int kslice;   // split-K (EPI_F32 only): workgroup z covers k in [z*kslice, (z+1)*kslice) and writes fp32 partial z ([M, ldo] each)
+  QkvP q;       // P3V_EPI_QKV only
 };
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
@@ -56,7 +59,7 @@ __device__ __forceinline__ void store8_bf16(bf16_t* p, const float* v) {
 
 template <int EPI, int ORD = 0>
 __global__ void __launch_bounds__(256, 2) k_gemm(GemmP p) {
-  constexpr bool SILU = EPI == P3V_EPI_SILU_MUL;
+  constexpr bool SILU = EPI == P3V_EPI_SILU_MUL, QKV = EPI == P3V_EPI_QKV;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // uniform: LDS-DMA bases stay in SGPRs
   const int wr = wave >> 1, wc = wave & 1;
@@ -76,7 +79,18 @@ __global__ void __launch_bounds__(256, 2) k_gemm(GemmP p) {
     n_t = in_band / rows;
   }
   const int m0 = m_t * BM;
-  const int n0 = n_t * n_out_tile;
+  int n0 = n_t * n_out_tile;
+  // P3V_EPI_QKV (p3v_gemm_qkv.h): column tiles 0 .. nq-1 are Q, then K (both fetched in rotation-pair order), then V, whose tiles
+  // are computed with the operand roles swapped (W rows on the tile's A side, tokens on its B side)
+  bool swapped = false, is_k = false;
+  int row0 = 0;
+  if (QKV) {
+    const int nq_t = p.q.nh * p.q.hd / BN, nk_t = p.q.nkv * p.q.hd / BN;
+    swapped = n_t >= nq_t + nk_t;
+    is_k = !swapped && n_t >= nq_t;
+    row0 = swapped ? (p.q.nh + p.q.nkv) * p.q.hd : is_k ? p.q.nh * p.q.hd : 0;
+    n0 = (n_t - (swapped ? nq_t + nk_t : is_k ? nq_t : 0)) * BN;       // first column INSIDE the region
+  }
 
   // ---- staging addresses: wave w issues 4 DMA pieces per operand, piece q covers tile rows (w*4+q)*8 .. +8
   const int srow = lane >> 3, schunk = lane & 7;
@@ -84,25 +98,33 @@ __global__ void __launch_bounds__(256, 2) k_gemm(GemmP p) {
   // is, for the compiler's wait-count model, a FLAT access of both memories, and every later s_waitcnt becomes
   // vmcnt(0) / lgkmcnt(0): the counted lgkmcnt on the fragment reads below was silently a full wait.
   unsigned a_src[4], b_src[4];
-  const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, 0xffffffff, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, 0xffffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, 0xffffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_ww = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, 0xffffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_a = QKV && swapped ? rs_ww : rs_x, rs_w = QKV && swapped ? rs_x : rs_ww;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int r = (wave * 4 + q) * 8 + srow;                 // tile row 0..127
     const int sw = (schunk ^ (r & 7)) * 8;                   // swizzled source chunk (elements)
     int ar = m0 + r;
     ar = ar < p.M ? ar : p.M - 1;
-    a_src[q] = (unsigned)(((size_t)ar * p.lda + sw) * 2);
     int br;
     if (SILU) {
       const int wcol = r >> 6, ni = (r & 63) >> 4, c = r & 15;
       br = n0 + wcol * 32 + (ni & 1) * 16 + c;
       br = (br < p.N ? br : p.N - 1) + (ni >> 1) * p.N;      // up rows live N rows below the gate rows
+    } else if (QKV) {
+      br = qkv_pair_row(p.q, row0, n0 >> 1, r);
     } else {
       br = n0 + r;
       br = br < p.N ? br : p.N - 1;
     }
-    b_src[q] = (unsigned)(((size_t)br * p.ldw + sw) * 2);
+    if (QKV && swapped) {                                    // A side: W rows row0 + n0 + r; B side: token rows (clamped)
+      a_src[q] = (unsigned)(((size_t)(row0 + n0 + r) * p.ldw + sw) * 2);
+      b_src[q] = (unsigned)(((size_t)ar * p.lda + sw) * 2);
+    } else {
+      a_src[q] = (unsigned)(((size_t)ar * p.lda + sw) * 2);
+      b_src[q] = (unsigned)(((size_t)br * p.ldw + sw) * 2);
+    }
   }
   const int kz = p.kslice ? (int)blockIdx.z : 0;              // split-K slice (0 when not split)
   const int nk = (p.kslice ? p.kslice : p.K) / BK, kt0 = kz * nk;
@@ -171,6 +193,11 @@ __global__ void __launch_bounds__(256, 2) k_gemm(GemmP p) {
   // MFMAs take the W fragment first, so a 16 x 16 block comes out transposed: lane (c = lane & 15, q = lane >> 4) holds the four
   // consecutive columns 4q .. 4q+3 of output row c.  fp32 outputs store them as they are (16 bytes); bf16 outputs first trade
   // packed halves of two neighbouring column blocks between lanes q and q ^ 1 (v_permlane16_swap): 8 consecutive columns per lane.
+  if constexpr (QKV) {
+    if (!swapped) qkv_epilogue_rot<4>(p.q, acc, p.bias, is_k, row0, (n0 >> 1) + wc * 32, m0 + wr * 64, p.M, lane);
+    else qkv_epilogue_vt<4>(p.q, acc, p.bias ? p.bias + row0 : nullptr, n0 + wr * 64, m0 + wc * 64, p.M, lane);
+    return;
+  }
   const int fc = lane & 15, fq = lane >> 4;
   const int mrow0 = m0 + wr * 64 + fc;                         // + i * 16
   if (SILU) {
@@ -395,7 +422,7 @@ static int gemm_splitk(const p3v_gemm_args_t* a, hipStream_t s) {
   if (!a->ws || a->ws_bytes < (int64_t)S * a->M * w_rows * 4) return P3V_ERR_UNSUPPORTED;
   if ((uintptr_t)a->ws & 15) return P3V_ERR_ARG;
   float* part = (float*)a->ws;
-  GemmP p = {a->A, a->W, part, nullptr, nullptr, nullptr, a->M, w_rows, a->K, a->lda, a->ldw, w_rows, 0, a->K / S};
+  GemmP p = {a->A, a->W, part, nullptr, nullptr, nullptr, a->M, w_rows, a->K, a->lda, a->ldw, w_rows, 0, a->K / S, {}};
   const int rc = launch_gemm<P3V_EPI_F32>(p, s);
   if (rc != P3V_OK) return rc;
   const long items = (long)a->M * (a->N / 8);
@@ -450,7 +477,7 @@ extern "C" int p3v_gemm(const p3v_gemm_args_t* a, void* stream) {
 
 static int gemm128(const p3v_gemm_args_t* a, hipStream_t s) {
   const GemmP p = {a->A, a->W, a->out, a->bias, a->resid, a->pos,
-                   a->M, a->N, a->K, a->lda, a->ldw, a->ldo, a->patches_per_img};
+                   a->M, a->N, a->K, a->lda, a->ldw, a->ldo, a->patches_per_img, 0, {}};
   switch (a->epilogue) {
     case P3V_EPI_NONE: return launch_gemm<P3V_EPI_NONE>(p, s);
     case P3V_EPI_BIAS: return launch_gemm<P3V_EPI_BIAS>(p, s);
@@ -463,4 +490,46 @@ static int gemm128(const p3v_gemm_args_t* a, hipStream_t s) {
     case P3V_EPI_F32: return launch_gemm<P3V_EPI_F32>(p, s);
     default: return P3V_ERR_ARG;
   }
+}
+
+// ---- the qkv projection with the head split, the rotation and the KV append in its epilogue (p3v_gemm_qkv.h)
+int p3v_gemm256_qkv(const p3v_gemm_args_t* a, const QkvP& q, hipStream_t s);   // p3v_gemm256.hip
+
+extern "C" int p3v_gemm_qkv(const p3v_gemm_args_t* a, const p3v_qkv_split_t* sp, void* stream) {
+  if (!a || !sp || !a->A || !a->W || !sp->q_out || !sp->k_dst || !sp->v_dst || (!sp->cos_t) != (!sp->sin_t)) return P3V_ERR_ARG;
+  if (a->epilogue != P3V_EPI_NONE && a->epilogue != P3V_EPI_BIAS) return P3V_ERR_ARG;
+  if (a->epilogue == P3V_EPI_BIAS && !a->bias) return P3V_ERR_ARG;
+  const int nh = sp->n_heads, nkv = sp->n_kv, hd = sp->hd, half = hd / 2;
+  if (sp->B <= 0 || sp->L <= 0 || nh <= 0 || nkv <= 0 || hd <= 0 || sp->tab_div <= 0 || !(sp->q_scale > 0.f)) return P3V_ERR_ARG;
+  if (a->M != sp->B * sp->L || a->N != (nh + 2 * nkv) * hd || a->K % BK || a->lda < a->K || a->ldw < a->K || a->lda % 8 || a->ldw % 8) return P3V_ERR_ARG;
+  if (((uintptr_t)a->A | (uintptr_t)a->W | (uintptr_t)a->bias | (uintptr_t)sp->q_out | (uintptr_t)sp->k_dst | (uintptr_t)sp->v_dst |
+       (uintptr_t)sp->cos_t | (uintptr_t)sp->sin_t) & 15)
+    return P3V_ERR_ARG;
+  // what the fused epilogue needs (anything else: P3V_ERR_UNSUPPORTED, the caller runs p3v_gemm + p3v_rope_kv_append):
+  // prompt-sized M; rotation pairs in blocks of 16 inside a head; whole 128-column tiles per region; 8-token runs of V^T stores
+  // that neither straddle a batch row nor start off a 16-byte boundary
+  const int dpos0 = sp->dst_off_is_past ? sp->past : 0;
+  if (a->M < 1024 || hd % 32 || half % 16 || (nh * hd) % BN || (nkv * hd) % BN || dpos0 % 8 || sp->dst_t % 8 || (sp->B > 1 && sp->L % 8) ||
+      p3v_tuning().gemm_128 || p3v_tuning().gemm_no_qkv_fuse)
+    return P3V_ERR_UNSUPPORTED;
+  if ((size_t)a->M * a->lda * 2 >= (1ull << 32) || (size_t)a->N * a->ldw * 2 >= (1ull << 32)) return P3V_ERR_UNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream;
+  QkvP q = {sp->cos_t, sp->sin_t, sp->q_out, sp->k_dst, sp->v_dst, sp->L, nh, nkv, hd, sp->past, dpos0, sp->dst_t, sp->tab_t, sp->tab_div, 0,
+            sp->q_scale};
+  p3v_gemm_args_t plain = *a;
+  plain.epilogue = P3V_EPI_NONE;                                // (the row packing below prices the plain bf16 epilogue)
+  int rows_big = (nh * hd) % 256 || (nkv * hd) % 256 ? 0 : gemm_big_rows(&plain);
+  if (rows_big > 0) {
+    p3v_gemm_args_t top = *a;
+    top.M = rows_big;
+    const int rc = p3v_gemm256_qkv(&top, q, s);
+    if (rc == P3V_ERR_UNSUPPORTED) rows_big = 0;
+    else if (rc != P3V_OK) return rc;
+  }
+  if (rows_big < a->M) {
+    q.m_base = rows_big;
+    const GemmP p = {a->A + (size_t)rows_big * a->lda, a->W, nullptr, a->bias, nullptr, nullptr, a->M - rows_big, a->N, a->K, a->lda, a->ldw, 0, 0, 0, q};
+    return launch_gemm<P3V_EPI_QKV>(p, s);
+  }
+  return P3V_OK;
 }

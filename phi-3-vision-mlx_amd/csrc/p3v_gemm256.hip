@@ -20,7 +20,10 @@
 #define BUF_BYTES (4 * HALF_BYTES)    // A0 A1 B0 B1
 #define GEMM256_LDS (2 * BUF_BYTES)   // 128 KiB
 
-struct Tile256 { int m0, n0; int a_off[2][2], b_off[2][2]; __amdgpu_buffer_rsrc_t rs_a; };
+struct Tile256 {
+  int m0, n0; int a_off[2][2], b_off[2][2]; __amdgpu_buffer_rsrc_t rs_a;
+  int swapped, is_k, row0;              // P3V_EPI_QKV: V tile (operand roles swapped) / K region / first W row of the region
+};
 
 #ifdef P3V_G256_DEBUG                                            // tools/gemm256_timeline.py: per-wave stamps inside the K loop of ONE workgroup
 __device__ unsigned long long p3v_g256dbg[8 * 64 * 8];
@@ -35,12 +38,14 @@ extern "C" int p3v_g256dbg_read(unsigned long long* out) {
 #endif
 template <int EPI, int SCHED = 0x50, int ORDER = 0>
 __global__ void __launch_bounds__(512, 1) k_gemm256(Gemm256P p) {
-  constexpr bool SILU = EPI == P3V_EPI_SILU_MUL;
+  constexpr bool SILU = EPI == P3V_EPI_SILU_MUL, QKV = EPI == P3V_EPI_QKV;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // uniform: LDS-DMA bases stay in SGPRs
   const int wr = wave >> 2, wc = wave & 3;
   constexpr int n_out_tile = SILU ? TN / 2 : TN;
   const int gx = (p.N + n_out_tile - 1) / n_out_tile, gy = (p.M + TM - 1) / TM, nwg = gx * gy;
+  // (P3V_EPI_QKV: N = (nh + 2 nkv) * hd; column tiles 0 .. nq-1 are Q, then K, then V -- p3v_gemm_qkv.h)
+  const int nq_t = QKV ? p.q.nh * p.q.hd / TN : 0, nk_t = QKV ? p.q.nkv * p.q.hd / TN : 0;
 
   // ---- PERSISTENT over output tiles (round 3): workgroup b takes tiles b, b + G, b + 2G, ... (G = gridDim.x, a multiple of 8,
   // so a workgroup's tiles keep its XCD in the XCD-aware order below).  The K-tile stream runs ACROSS tile seams: during the
@@ -58,6 +63,13 @@ __global__ void __launch_bounds__(512, 1) k_gemm256(Gemm256P p) {
     const int rows = min(BAND, gy - band * BAND);
     const int m_t = band * BAND + in_band % rows, n_t = in_band / rows;
     t.m0 = m_t * TM, t.n0 = n_t * n_out_tile;
+    t.swapped = t.is_k = t.row0 = 0;
+    if (QKV) {
+      t.swapped = n_t >= nq_t + nk_t;
+      t.is_k = !t.swapped && n_t >= nq_t;
+      t.row0 = t.swapped ? (p.q.nh + p.q.nkv) * p.q.hd : t.is_k ? p.q.nh * p.q.hd : 0;
+      t.n0 = (n_t - (t.swapped ? nq_t + nk_t : t.is_k ? nq_t : 0)) * TN;        // first column INSIDE the region
+    }
     // DMA sources: half-tile h (128 rows), instruction q (64 rows), this thread: row tid/8, chunk tid%8.
     // Buffer addressing (SGPR descriptor + 32-bit per-lane byte offset + SGPR K offset): a request is `s_mov m0` +
     // `buffer_load_dwordx4 ... offen lds` with no vector ALU work at all.
@@ -68,25 +80,35 @@ __global__ void __launch_bounds__(512, 1) k_gemm256(Gemm256P p) {
         const int rr = h * 128 + qq * 64 + srow;
         const int sw = (schunk ^ (rr & 7)) * 8;
         const int ar = min(t.m0 + rr, p.M - 1) - t.m0;
-        t.a_off[h][qq] = (ar * p.lda + sw) * 2;
         int br;
         if (SILU) {                                   // wave column group wcol (64 tile rows) = 32 gate + 32 up rows
           const int wcol = rr >> 6, ni = (rr & 63) >> 4, c = rr & 15;
           br = min(t.n0 + wcol * 32 + (ni & 1) * 16 + c, p.N - 1) + (ni >> 1) * p.N;
+        } else if (QKV) {                             // Q / K: pair order (both halves of a rotation pair in one lane)
+          br = qkv_pair_row(p.q, t.row0, t.n0 >> 1, rr);
         } else {
           br = min(t.n0 + rr, p.N - 1);
         }
-        t.b_off[h][qq] = (int)(((unsigned)br * (unsigned)p.ldw + (unsigned)sw) * 2u);   // < 2^32: checked by the launcher
+        if (QKV && t.swapped) {
+          // V tile: the tile's rows are the 256 W rows row0 + n0 .. (A side), its columns the tokens m0 .. (B side)
+          t.a_off[h][qq] = (rr * p.ldw + sw) * 2;                                                  // from W + (row0 + n0) * ldw
+          t.b_off[h][qq] = (int)(((unsigned)(t.m0 + ar) * (unsigned)p.lda + (unsigned)sw) * 2u);    // from A, clamped token row
+        } else {
+          t.a_off[h][qq] = (ar * p.lda + sw) * 2;
+          t.b_off[h][qq] = (int)(((unsigned)br * (unsigned)p.ldw + (unsigned)sw) * 2u);   // < 2^32: checked by the launcher
+        }
       }
-    t.rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A + (size_t)t.m0 * p.lda), 0, 0xffffffff, 0x00020000);
+    t.rs_a = QKV && t.swapped ? __builtin_amdgcn_make_buffer_rsrc((void*)(p.W + (size_t)(t.row0 + t.n0) * p.ldw), 0, 0xffffffff, 0x00020000)
+                              : __builtin_amdgcn_make_buffer_rsrc((void*)(p.A + (size_t)t.m0 * p.lda), 0, 0xffffffff, 0x00020000);
   };
   const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, 0xffffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, 0xffffffff, 0x00020000);   // (V tiles: tokens on the B side)
   auto dma_half = [&](const Tile& t, int which, int kt, int buf) {   // which: 0 A0, 1 A1, 2 B0, 3 B1
     unsigned char* base = smem + buf * BUF_BYTES + which * HALF_BYTES + wave * 1024;
     const int h = which & 1;
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
-      const __amdgpu_buffer_rsrc_t rs = which < 2 ? t.rs_a : rs_w;
+      const __amdgpu_buffer_rsrc_t rs = which < 2 ? t.rs_a : (QKV && t.swapped) ? rs_x : rs_w;
       const int vo = which < 2 ? t.a_off[h][q] : t.b_off[h][q];
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)(base + q * 8192), 16, vo, kt * (TK * 2), 0, 0);
     }
@@ -236,7 +258,12 @@ __global__ void __launch_bounds__(512, 1) k_gemm256(Gemm256P p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     landed = true;
   }
-  gemm256_epilogue<EPI>(p, acc, m0, n0, wr, wc, lane);      // straight from the accumulators: p3v_gemm256_epi.h
+  if constexpr (QKV) {
+    if (!cur_t.swapped) qkv_epilogue_rot<8>(p.q, acc, p.bias, cur_t.is_k, cur_t.row0, (n0 >> 1) + wc * 32, m0 + wr * 128, p.M, lane);
+    else qkv_epilogue_vt<8>(p.q, acc, p.bias ? p.bias + cur_t.row0 : nullptr, n0 + wr * 128, m0 + wc * 64, p.M, lane);
+  } else {
+    gemm256_epilogue<EPI>(p, acc, m0, n0, wr, wc, lane);    // straight from the accumulators: p3v_gemm256_epi.h
+  }
   if (!has_next) break;
   wid += gridDim.x;
   make_tile(wid, cur_t);
@@ -270,13 +297,21 @@ static int launch_gemm256_v(const Gemm256P& p, hipStream_t s) {
 template <int EPI>
 static int launch_gemm256(const Gemm256P& p, hipStream_t s) { return launch_gemm256_v<EPI, 0x50, 2>(p, s); }
 
+// the qkv projection with split + RoPE + KV append in the epilogue (p3v_gemm_qkv, p3v_gemm.hip): rows of `a` on big tiles
+int p3v_gemm256_qkv(const p3v_gemm_args_t* a, const QkvP& q, hipStream_t s) {
+  if (a->N % TN || a->K % TK || (q.nh * q.hd) % TN || (q.nkv * q.hd) % TN) return P3V_ERR_UNSUPPORTED;
+  if ((size_t)a->N * a->ldw * 2 >= ((size_t)1 << 32) || (size_t)a->M * a->lda * 2 >= ((size_t)1 << 32)) return P3V_ERR_UNSUPPORTED;
+  const Gemm256P p = {a->A, a->W, nullptr, a->bias, nullptr, a->M, a->N, a->K, a->lda, a->ldw, 0, q};
+  return launch_gemm256<P3V_EPI_QKV>(p, s);
+}
+
 // called by p3v_gemm (which decides how many rows get the big tile); returns P3V_ERR_UNSUPPORTED to fall back
 int p3v_gemm256_try(const p3v_gemm_args_t* a, hipStream_t s) {
   const int n_tile = a->epilogue == P3V_EPI_SILU_MUL ? TN / 2 : TN;
   if (a->N % n_tile || a->K % TK || a->epilogue == P3V_EPI_PATCH) return P3V_ERR_UNSUPPORTED;
   const size_t w_rows = (size_t)a->N * (a->epilogue == P3V_EPI_SILU_MUL ? 2 : 1);
   if (w_rows * a->ldw * 2 >= ((size_t)1 << 32) || (size_t)256 * a->lda * 2 >= ((size_t)1 << 31)) return P3V_ERR_UNSUPPORTED;  // 32-bit buffer offsets
-  const Gemm256P p = {a->A, a->W, a->out, a->bias, a->resid, a->M, a->N, a->K, a->lda, a->ldw, a->ldo};
+  const Gemm256P p = {a->A, a->W, a->out, a->bias, a->resid, a->M, a->N, a->K, a->lda, a->ldw, a->ldo, {}};
   switch (a->epilogue) {
     case P3V_EPI_NONE: return launch_gemm256<P3V_EPI_NONE>(p, s);
     case P3V_EPI_BIAS: return launch_gemm256<P3V_EPI_BIAS>(p, s);

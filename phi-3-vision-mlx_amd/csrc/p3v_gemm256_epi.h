@@ -1,6 +1,8 @@
 // Shared by the two 256 x 256-tile GEMM kernels (p3v_gemm256.hip, p3v_gemm256pp.hip): launch parameters and the epilogue.
 #pragma once
-#include "p3v_common.h"
+#include "p3v_gemm_qkv.h"
+
+#define P3V_EPI_QKV 100                // internal: the qkv projection with split + RoPE + KV append in the epilogue (p3v_gemm_qkv.h)
 
 #define TM 256
 #define TN 256
@@ -13,6 +15,7 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 struct Gemm256P {
   const bf16_t* A; const bf16_t* W; void* out; const bf16_t* bias; const void* resid;
   int M, N, K, lda, ldw, ldo;
+  QkvP q;                                // P3V_EPI_QKV only
 };
 
 __device__ __forceinline__ float gelu_erf2(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }

@@ -1,0 +1,138 @@
+// The qkv projection with the head split, the rotation and the KV append in its epilogue (round 5): p3v_gemm_qkv =
+// p3v_gemm(qkv_proj) + p3v_rope_kv_append in the launches of the GEMM alone.  Shared by the 256 x 256 and the 128 x 128 tile kernels.
+//
+// What makes it fit the accumulator layout (a lane holds 4 consecutive output columns of one row, p3v_gemm256_epi.h):
+//   * Q and K tiles: _rotate_half pairs dimension d with d + hd/2 (phi.py:419-423).  The tile's W rows are fetched in PAIR order --
+//     a wave's 64 tile columns are 32 consecutive pairs: blocks 0, 1 their first halves, blocks 2, 3 their second halves (the DMA takes
+//     any W row for any tile row: the same trick as the SiLU epilogue's gate / up rows) -- so both halves of a pair sit in ONE lane
+//     (acc[i][j][r] and acc[i][j + 2][r]) and the rotation is lane-local.  16 pairs never straddle a head (hd/2 = 48 or 32).
+//   * V tiles: the cache keeps V TRANSPOSED ([.., hd, t]).  These tiles are computed with the operand roles swapped -- W rows fill the
+//     tile's A side, the tokens its B side (the tile is square and the K loop does not care) -- so a lane holds 4 consecutive TOKENS of
+//     one V dimension, and 8 after the v_permlane16_swap: one 16-byte store into a V^T row.
+// Arithmetic: exactly p3v_gemm's + p3v_rope_kv_append's (the Linear output rounded to bf16, rotation in fp32 on those values,
+// q_scale before the one rounding): bit-identical to the two launches (tests/test_kernels_gpu.py::test_gemm_qkv_fused).
+#pragma once
+#include "p3v_common.h"
+
+struct QkvP {
+  const float* cos_t; const float* sin_t;        // [B / tab_div, tab_t, hd / 2] or both null: plain head split (CLIP)
+  bf16_t* q_out; bf16_t* k_dst; bf16_t* v_dst;   // [B, nh, L, hd], [B, nkv, dst_t, hd], [B, nkv, hd, dst_t]
+  int L, nh, nkv, hd, past, dpos0, dst_t, tab_t, tab_div;
+  int m_base;                                    // global token index of this launch's row 0 (rows after a big / small split)
+  float q_scale;
+};
+
+// W row fetched for tile column `rr` (0 .. tile width - 1) of a Q / K tile whose first pair is p0; row0 = first W row of the region
+__device__ __forceinline__ int qkv_pair_row(const QkvP& q, int row0, int p0, int rr) {
+  const int half = q.hd >> 1;
+  const int wcol = rr >> 6, ni = (rr & 63) >> 4, c = rr & 15;
+  const int P = p0 + wcol * 32 + (ni & 1) * 16 + c;
+  return row0 + (P / half) * q.hd + P % half + (ni >> 1) * half;
+}
+
+// Q / K tile: acc[i][j] = block row i (16 tokens from m_first), blocks 0, 1 = first halves of pairs pw .. pw + 31, blocks 2, 3 = second
+template <int NI>
+__device__ __forceinline__ void qkv_epilogue_rot(const QkvP& q, f32x4_t (&acc)[NI][4], const bf16_t* bias, bool is_k, int row0, int pw,
+                                                 int m_first, int M, int lane) {
+  const int fc = lane & 15, fq = lane >> 4, half = q.hd >> 1;
+  const bool rot = q.cos_t != nullptr;
+  const float qs = is_k ? 1.f : q.q_scale;
+  int head[2], d0[2];
+  float b1[2][4], b2[2][4];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int P = pw + j * 16 + fq * 4;
+    head[j] = P / half, d0[j] = P % half;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) b1[j][r] = b2[j][r] = 0.f;
+    if (bias) {
+      const u32x2_t w1 = *(const u32x2_t*)(bias + row0 + head[j] * q.hd + d0[j]);
+      const u32x2_t w2 = *(const u32x2_t*)(bias + row0 + head[j] * q.hd + d0[j] + half);
+      b1[j][0] = bf16lo(w1[0]), b1[j][1] = bf16hi(w1[0]), b1[j][2] = bf16lo(w1[1]), b1[j][3] = bf16hi(w1[1]);
+      b2[j][0] = bf16lo(w2[0]), b2[j][1] = bf16hi(w2[0]), b2[j][2] = bf16lo(w2[1]), b2[j][3] = bf16hi(w2[1]);
+    }
+  }
+  // the block this lane stores after the swap: jj = fq & 1, its columns 8 * (fq >> 1) .. + 8
+  const int Ps = pw + (fq & 1) * 16, head_s = Ps / half, d_s = Ps % half + (fq >> 1) * 8;
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int m = m_first + i * 16 + fc;
+    const int mg = q.m_base + (m < M ? m : M - 1), b = mg / q.L, l = mg - b * q.L;
+    const float* ct = rot ? q.cos_t + ((size_t)(b / q.tab_div) * q.tab_t + q.past + l) * half : nullptr;
+    const float* st = rot ? q.sin_t + ((size_t)(b / q.tab_div) * q.tab_t + q.past + l) * half : nullptr;
+    uint32_t pk1[2][2], pk2[2][2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      float cs[4] = {1.f, 1.f, 1.f, 1.f}, sn[4] = {0.f, 0.f, 0.f, 0.f};
+      if (rot) {
+        const float4 c4 = *(const float4*)(ct + d0[j]), s4 = *(const float4*)(st + d0[j]);
+        cs[0] = c4.x, cs[1] = c4.y, cs[2] = c4.z, cs[3] = c4.w, sn[0] = s4.x, sn[1] = s4.y, sn[2] = s4.z, sn[3] = s4.w;
+      }
+      float o1[4], o2[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float a0 = bf16_round(acc[i][j][r] + b1[j][r]), a1 = bf16_round(acc[i][j + 2][r] + b2[j][r]);   // the Linear's bf16 output
+        if (rot) {
+          p3v_rope_pair(a0, a1, cs[r], sn[r], qs, o1[r], o2[r]);
+        } else {
+          o1[r] = qs != 1.f ? a0 * qs : a0;
+          o2[r] = qs != 1.f ? a1 * qs : a1;
+        }
+      }
+      pk1[j][0] = pack_bf16x2(o1[0], o1[1]), pk1[j][1] = pack_bf16x2(o1[2], o1[3]);
+      pk2[j][0] = pack_bf16x2(o2[0], o2[1]), pk2[j][1] = pack_bf16x2(o2[2], o2[3]);
+    }
+    u32x4_t w1, w2;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      auto s1 = __builtin_amdgcn_permlane16_swap(pk1[0][k], pk1[1][k], false, false);
+      w1[k] = s1[0], w1[2 + k] = s1[1];
+      auto s2 = __builtin_amdgcn_permlane16_swap(pk2[0][k], pk2[1][k], false, false);
+      w2[k] = s2[0], w2[2 + k] = s2[1];
+    }
+    if (m < M) {
+      bf16_t* dst = is_k ? q.k_dst + (((size_t)b * q.nkv + head_s) * q.dst_t + q.dpos0 + l) * q.hd
+                         : q.q_out + (((size_t)b * q.nh + head_s) * q.L + l) * q.hd;
+      *(u32x4_t*)(dst + d_s) = w1;
+      *(u32x4_t*)(dst + d_s + half) = w2;
+    }
+  }
+}
+
+// V tile (operand roles swapped): acc[i][j] = block row i of 16 V dimensions from fv_first (index into [nkv * hd]), block column j of
+// 16 tokens from t_first.  bias_v = bias + first W row of the V region, or null.
+template <int NI>
+__device__ __forceinline__ void qkv_epilogue_vt(const QkvP& q, f32x4_t (&acc)[NI][4], const bf16_t* bias_v, int fv_first, int t_first,
+                                                int M, int lane) {
+  const int fc = lane & 15, fq = lane >> 4;
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int fv = fv_first + i * 16 + fc, head = fv / q.hd, d = fv - head * q.hd;
+    const float bv = bias_v ? bf16_to_f32(bias_v[fv]) : 0.f;
+#pragma unroll
+    for (int jp = 0; jp < 2; ++jp) {
+      uint32_t pk[2][2];
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+        const int j = 2 * jp + jj;
+        pk[jj][0] = pack_bf16x2(acc[i][j][0] + bv, acc[i][j][1] + bv), pk[jj][1] = pack_bf16x2(acc[i][j][2] + bv, acc[i][j][3] + bv);
+      }
+      u32x4_t w;
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        auto sw = __builtin_amdgcn_permlane16_swap(pk[0][k], pk[1][k], false, false);
+        w[k] = sw[0], w[2 + k] = sw[1];
+      }
+      const int t = t_first + (2 * jp + (fq & 1)) * 16 + (fq >> 1) * 8;      // 8 consecutive tokens t .. t + 7 (one batch row: launcher)
+      if (t < M) {
+        const int mg = q.m_base + t, b = mg / q.L, l = mg - b * q.L;
+        bf16_t* dst = q.v_dst + (((size_t)b * q.nkv + head) * q.hd + d) * (size_t)q.dst_t + q.dpos0 + l;
+        if (t + 8 <= M) {
+          *(u32x4_t*)dst = w;
+        } else {                                               // the ragged end of the prompt
+          for (int e = 0; e < M - t; ++e) dst[e] = (bf16_t)(w[e >> 1] >> (16 * (e & 1)));
+        }
+      }
+    }
+  }
+}

@@ -30,7 +30,7 @@ const Knob kKnobs[] = {
     {"gemm_big_rows", &P3vTuning::gemm_big_rows, -1},       {"gemm_no_splitk", &P3vTuning::gemm_no_splitk, 0},
     {"gemm_splitk_max_m", &P3vTuning::gemm_splitk_max_m, 1024}, {"gemm_splitk_max_s", &P3vTuning::gemm_splitk_max_s, 8},
     {"gemm_splitk_wgs", &P3vTuning::gemm_splitk_wgs, 256},  {"gemm_128", &P3vTuning::gemm_128, 0},
-    {"gemm_persistent", &P3vTuning::gemm_persistent, 1},
+    {"gemm_persistent", &P3vTuning::gemm_persistent, 1},     {"gemm_no_qkv_fuse", &P3vTuning::gemm_no_qkv_fuse, 0},
     {"gemm_f8_narrow", &P3vTuning::gemm_f8_narrow, -1},     {"attn_no_dma", &P3vTuning::attn_no_dma, 0},
     {"attn_old", &P3vTuning::attn_old, 0},                  {"attn_pp", &P3vTuning::attn_pp, -1},
     {"attn_il", &P3vTuning::attn_il, -1},                   {"attn_il_waves", &P3vTuning::attn_il_waves, -1},

@@ -63,6 +63,15 @@ class CacheState:
         self.B, self.S, self.max_tokens = B, S, max_tokens
         self.T = S + max(max_tokens, 0)
         self.quantized = bool(getattr(cfg, "use_quantized_cache", False))
+        # cache_format="mlx4" (opt-in): the reference's OWN quantised cache -- MLX 4-bit group-32 codes of the PROMPT's K / V, later
+        # tokens unquantised (phi.py:528-540).  The codes are kept in the reference's format (k4 / v4 + scale | bias), and the
+        # bf16 cache rows hold their dequantised values, which is what every later call of the reference attends on: the decode
+        # path is then the plain bf16 one.  (Default for quantize_cache=True: int8 for all tokens, BASELINE config 5.)
+        self.mlx4 = self.quantized and getattr(cfg, "cache_format", "int8") == "mlx4"
+        if self.quantized and getattr(cfg, "cache_format", "int8") not in ("int8", "mlx4"):
+            raise ValueError(f"cache_format must be 'int8' or 'mlx4', got {cfg.cache_format!r}")
+        if self.mlx4:
+            self.quantized = False
         # row/column stride of the caches: whole 128-key tiles (the decode attention takes one 128-key tile per workgroup
         # when the capacity allows it)
         gran = 128
@@ -85,6 +94,13 @@ class CacheState:
         else:
             self.k = torch.empty((nl, B, nkv, self.Tp, hd), dtype=BF16, device=device)    # K   [.., t, hd]
             self.v = torch.zeros((nl, B, nkv, hd, self.Tp), dtype=BF16, device=device)    # V^T [.., hd, t] (zero: tail keys stay finite)
+        if self.mlx4:
+            g = hd // 32
+            self.k4 = torch.zeros((nl, B, nkv, max(S, 1), g, 4), dtype=I32, device=device)
+            self.v4 = torch.zeros_like(self.k4)
+            self.k_sb = torch.zeros((nl, B, nkv, max(S, 1), g, 2), dtype=F32, device=device)
+            self.v_sb = torch.zeros_like(self.k_sb)
+            self.mlx4_tokens = 0                                # prompt tokens held as codes (set by the first call)
         self.offset = 0
         self.cos = self.sin = self.pad_len = None
         self.graphs = {}
@@ -277,11 +293,15 @@ class Phi3VModel:
             lp = V_PREFIX + f"encoder.layers.{j}."
             h = ops.layernorm(x2, w[lp + "layer_norm1.weight"], w[lp + "layer_norm1.bias"], eps)
             wq, bq = self.clip_qkv[j]
-            qkv = ops.gemm(h, wq, EPI_BIAS, bias=bq)
             # head split; the queries leave it multiplied by scale * log2(e) like the decoder's (the attention's softmax is then the
-            # bare exp2: k_attn_prefill_dma<64, PRE> 59 -> 49 us per layer at 17 crops, tools/clip_attn_probe.py)
+            # bare exp2: k_attn_prefill_dma<64, PRE> 59 -> 49 us per layer at 17 crops, tools/clip_attn_probe.py).  Round 5: the
+            # projection's epilogue does the split (q scaled, K rows, V^T columns) where the library takes the shape.
             pre = os.environ.get("P3V_VIT_PLAIN_Q") != "1"
-            ops.rope_kv_append(qkv, None, None, q, k, v, n, T, nh, nh, 64, 0, Tp, False, q_scale=64 ** -0.5 * ops.Q_PRESCALE if pre else 1.0)
+            qs = 64 ** -0.5 * ops.Q_PRESCALE if pre else 1.0
+            if not (os.environ.get("P3V_QKV_FUSE", "1") != "0"
+                    and ops.gemm_qkv(h, wq, None, None, q, k, v, n, T, nh, nh, 64, 0, Tp, False, q_scale=qs, bias=bq)):
+                qkv = ops.gemm(h, wq, EPI_BIAS, bias=bq)
+                ops.rope_kv_append(qkv, None, None, q, k, v, n, T, nh, nh, 64, 0, Tp, False, q_scale=qs)
             ops.attention(q, o, n, T, nh, nh, 64, 64 ** -0.5, False, k_past=k, v_past=v, past_t=Tp, new_is_cache=True, q_prescaled=pre)
             ops.gemm(o, w[lp + "self_attn.out_proj.weight"], EPI_BIAS_RESID_F32, bias=w[lp + "self_attn.out_proj.bias"],
                      resid=x2, out=x2)
@@ -510,15 +530,29 @@ class Phi3VModel:
             if L <= ops.L.DECODE_MAX_L and n_beam == 1:
                 self._plan_fused_oproj(bufs, B, L, st.Tp, st.quantized)
         q, o, qkv, a, h, n_split, ws = (bufs[k] for k in ("q", "o", "qkv", "a", "h", "n_split", "ws"))
-        if st.quantized and n_beam > 1:
+        mlx4 = getattr(st, "mlx4", False)
+        if (st.quantized or mlx4) and n_beam > 1:
             raise NotImplementedError("Beam Search is not yet compatible with Quantized Cache")       # as phi.py:525
+        mlx4_first = mlx4 and past == 0 and st.mlx4_tokens == 0 and L <= st.k4.shape[3]             # the call that fills the cache (phi.py:531-533)
         if n_beam > 1:                                          # beams: K/V of this call go to a scratch, cache is read-only
             Lp = (L + 7) // 8 * 8
             k_new = torch.empty((B, nkv, Lp, hd), dtype=BF16, device=self.device)
             v_new = torch.zeros((B, nkv, hd, Lp), dtype=BF16, device=self.device)
         for i in range(cfg.num_hidden_layers):
             p = f"model.layers.{i}."
-            self._proj(x, p + "self_attn.qkv_proj.weight", norm_w=w[p + "input_layernorm.weight"], out=qkv, h=h)
+            # Prompt-sized calls on bf16 weights: the qkv projection writes rotated Q, the K cache rows and the V^T cache columns from
+            # its own epilogue (ops.gemm_qkv: bit-identical to the projection + rope_kv_append, one launch sequence instead of two).
+            fused_qkv = False
+            k_w = p + "self_attn.qkv_proj.weight"
+            if (L > ops.L.DECODE_MAX_L and n_beam == 1 and k_w in w and k_w not in self.adapters and M >= 1024
+                    and os.environ.get("P3V_QKV_FUSE", "1") != "0"):
+                kd, vd = (st.k_tmp, st.v_tmp) if st.quantized else (st.k[i], st.v[i])
+                if not (st.quantized and past > 0 and not getattr(st, "fresh_rows", False)):
+                    hn = ops.rmsnorm(x, w[p + "input_layernorm.weight"], eps, out=h)
+                    fused_qkv = ops.gemm_qkv(hn, w[k_w], st.cos, st.sin, q, kd, vd, B, L, nh, nkv, hd, past, st.Tp, True, st.T, 1,
+                                             q_scale=scale * ops.Q_PRESCALE)
+            if not fused_qkv:
+                self._proj(x, p + "self_attn.qkv_proj.weight", norm_w=w[p + "input_layernorm.weight"], out=qkv, h=h)
             if st.quantized:
                 if L <= ops.L.DECODE_MAX_L:
                     if d_past is not None:
@@ -536,8 +570,9 @@ class Phi3VModel:
                 else:                                           # prefill: exact attention, quantised copy stored
                     if past > 0 and not getattr(st, "fresh_rows", False):   # long cached call (constrain with > 16 tokens): attend on a
                         ops.kv_dequantize(st.k8[i], st.v8[i], st.ks[i], st.vs[i], st.k_tmp, st.v_tmp, past)   # dequantised copy
-                    ops.rope_kv_append(qkv, st.cos, st.sin, q, st.k_tmp, st.v_tmp, B, L, nh, nkv, hd, past, st.Tp, True, st.T, 1,
-                                       q_scale=scale * ops.Q_PRESCALE)
+                    if not fused_qkv:
+                        ops.rope_kv_append(qkv, st.cos, st.sin, q, st.k_tmp, st.v_tmp, B, L, nh, nkv, hd, past, st.Tp, True, st.T, 1,
+                                           q_scale=scale * ops.Q_PRESCALE)
                     ops.attention(q, o, B, L, nh, nkv, hd, scale, True, past=past, k_past=st.k_tmp, v_past=st.v_tmp,
                                   past_t=st.Tp, pad_len=st.pad_len, new_is_cache=True, q_prescaled=True)
                     ops.kv_quantize(st.k_tmp, st.v_tmp, st.k8[i], st.v8[i], st.ks[i], st.vs[i], past, L)
@@ -568,10 +603,14 @@ class Phi3VModel:
             else:
                 # queries leave the RoPE kernel multiplied by scale * log2(e) (before their one rounding to bf16, as
                 # phi.py:454 scales q before the product): the prefill attention's softmax is then the exponential alone
-                ops.rope_kv_append(qkv, st.cos, st.sin, q, st.k[i], st.v[i], B, L, nh, nkv, hd, past, st.Tp, True, st.T, 1,
-                                   q_scale=scale * ops.Q_PRESCALE)
+                if not fused_qkv:
+                    ops.rope_kv_append(qkv, st.cos, st.sin, q, st.k[i], st.v[i], B, L, nh, nkv, hd, past, st.Tp, True, st.T, 1,
+                                       q_scale=scale * ops.Q_PRESCALE)
                 ops.attention(q, o, B, L, nh, nkv, hd, scale, True, past=past, k_past=st.k[i], v_past=st.v[i],
                               past_t=st.Tp, pad_len=st.pad_len, new_is_cache=True, q_prescaled=True)
+            if mlx4_first:                                      # this layer attended on the exact keys (phi.py:533); from now on: the codes
+                ops.kv_quantize_mlx4(st.k[i], st.v[i], st.k4[i, :, :, :L], st.v4[i, :, :, :L], st.k_sb[i, :, :, :L], st.v_sb[i, :, :, :L], L) \
+                    if L == st.k4.shape[3] else self._mlx4_partial(st, i, L)
             if last_only and i == cfg.num_hidden_layers - 1 and L > 1:
                 o = o.view(B, L, -1)[:, -1].contiguous()
                 x = x.view(B, L, -1)[:, -1].contiguous()
@@ -582,7 +621,19 @@ class Phi3VModel:
             self._proj(a, p + "mlp.down_proj.weight", EPI_RESID_BF16, resid=x, out=x)
             if self.hidden_hook is not None:                     # diagnostics only (tools/precision_decomp.py); never set
                 self.hidden_hook(i, x, B, x.shape[0] // B)       # while a decode graph is captured
+        if mlx4_first:
+            st.mlx4_tokens = L
         return x
+
+    def _mlx4_partial(self, st, i, L):
+        """(first call shorter than the state's prompt length: contiguous code buffers of its own size)"""
+        if st.k4.shape[3] != L:
+            nl, B, nkv, _, g, _ = st.k4.shape
+            st.k4 = torch.zeros((nl, B, nkv, L, g, 4), dtype=I32, device=self.device)
+            st.v4 = torch.zeros_like(st.k4)
+            st.k_sb = torch.zeros((nl, B, nkv, L, g, 2), dtype=F32, device=self.device)
+            st.v_sb = torch.zeros_like(st.k_sb)
+        ops.kv_quantize_mlx4(st.k[i], st.v[i], st.k4[i], st.v4[i], st.k_sb[i], st.v_sb[i], L)
 
     # ------------------------------------------------------------------ graph-replayed greedy decode step
     def _build_decode_graph(self, st):

@@ -300,6 +300,24 @@ def rope_kv_append(qkv, cos_t, sin_t, q_out, k_dst, v_dst, B, Lq, nh, nkv, hd, p
             "rope_kv_append")
 
 
+def gemm_qkv(a, w, cos_t, sin_t, q_out, k_dst, v_dst, B, Lq, nh, nkv, hd, past, dst_t, dst_off_is_past, tab_t=0, tab_div=1,
+             q_scale=1.0, bias=None):
+    """qkv projection + head split + _rotate_half + KVCache append in the GEMM's own launches (include/p3v.h: p3v_gemm_qkv) ==
+    gemm(a, w[, bias]) followed by rope_kv_append(...), bit for bit.  Returns False -- nothing launched -- when the library does not
+    take the shape (short prompts, unaligned append offsets, ...): the caller then runs the two calls."""
+    _chk(a, BF16, "a"), _chk(w, BF16, "w")
+    M, K = a.shape
+    g = L.GemmArgs(_p(a), _p(w), 0, _p(bias), 0, 0, M, w.shape[0], K, a.stride(0), w.stride(0), w.shape[0],
+                   EPI_BIAS if bias is not None else EPI_NONE, 0, 0, 0)
+    sp = L.QkvSplit(_p(cos_t), _p(sin_t), _p(q_out), _p(k_dst), _p(v_dst), B, Lq, nh, nkv, hd, int(past), dst_t, int(dst_off_is_past),
+                    tab_t, tab_div, float(q_scale))
+    rc = L.lib().p3v_gemm_qkv(C.byref(g), C.byref(sp), _stream())
+    if rc == L.ERR_UNSUPPORTED:
+        return False
+    L.check(rc, "gemm_qkv")
+    return True
+
+
 Q_PRESCALE = 1.4426950408889634          # log2(e): q_scale = Q_PRESCALE * softmax scale for q_prescaled attention
 
 
@@ -361,6 +379,19 @@ def kv_quantize(k, vt, k8, v8t, k_scale, v_scale, t0, n_tok):
     B, nkv, src_t, hd = k.shape
     L.check(L.lib().p3v_kv_quantize(_p(k), _p(vt), _p(k8), _p(v8t), _p(k_scale), _p(v_scale), B * nkv, hd, src_t,
                                     k8.shape[2], int(t0), int(n_tok), _stream()), "kv_quantize")
+
+
+def kv_quantize_mlx4(k, vt, k4, v4, k_sb, v_sb, n_tok):
+    """The reference's own prompt-cache format (phi.py:528-540: mx.quantize, group 32, 4 bits): tokens [0, n_tok) of bf16
+    K [B,nkv,T,hd] / V^T [B,nkv,hd,T] -> codes [B,nkv,n_tok,hd/32,4] int32 + (scale, bias) [B,nkv,n_tok,hd/32,2] fp32, and the
+    cache rows rewritten with the dequantised values."""
+    _chk(k, BF16, "k"), _chk(vt, BF16, "vt"), _chk(k4, I32, "k4"), _chk(v4, I32, "v4"), _chk(k_sb, F32, "k_sb"), _chk(v_sb, F32, "v_sb")
+    B, nkv, T, hd = k.shape
+    if tuple(vt.shape) != (B, nkv, hd, T) or tuple(k4.shape) != (B, nkv, n_tok, hd // 32, 4) or tuple(k_sb.shape) != (B, nkv, n_tok, hd // 32, 2) \
+            or k4.shape != v4.shape or k_sb.shape != v_sb.shape:
+        raise ValueError("kv_quantize_mlx4: shapes")
+    L.check(L.lib().p3v_kv_quantize_mlx4(_p(k), _p(vt), _p(k4), _p(v4), _p(k_sb), _p(v_sb), B * nkv, hd, T, int(n_tok), _stream()),
+            "kv_quantize_mlx4")
 
 
 def kv_dequantize(k8, v8t, k_scale, v_scale, k, vt, n_tok):

@@ -647,6 +647,89 @@ def test_attention_decode_with_fused_oproj_is_bit_identical_to_two_launches(ops,
     assert not torch.isnan(x1.float()).any() and (x1.float() - x0.float()).abs().max().item() > 0.01
 
 
+@pytest.mark.parametrize("B,L,nh,nkv,hd,K,past,rot,bias,big", [
+    (1, 2531, 32, 32, 96, 256, 0, True, False, -1),      # the bench prompt's shape (short K): big tiles + remainder rows, ragged end
+    (1, 2531, 32, 32, 96, 256, 0, True, False, 1000000),  # all rows on the 256 x 256 kernel
+    (1, 1300, 32, 32, 96, 128, 0, True, False, 0),        # all rows on the 128 x 128 kernel
+    (1, 1100, 8, 4, 96, 192, 64, True, False, 512),       # GQA regions of different widths, appended behind 64 cached keys
+    (2, 1024, 16, 16, 64, 128, 0, False, True, -1),       # plain head split with bias (CLIP-like), two batch rows, L % 8 == 0
+    (3, 680, 16, 16, 64, 128, 8, True, True, 512),
+])
+def test_gemm_qkv_fused(ops, B, L, nh, nkv, hd, K, past, rot, bias, big):
+    """p3v_gemm_qkv (qkv projection with head split + rotation + KV append in its epilogue) against the two calls it replaces --
+    p3v_gemm then p3v_rope_kv_append -- on the same inputs: rotated / scaled Q, the appended K rows and the appended V^T columns
+    BIT-IDENTICAL, everything else in the caches untouched."""
+    M, N = B * L, (nh + 2 * nkv) * hd
+    a = g((M, K), 400).cuda()
+    w = g((N, K), 401, 1.0 / math.sqrt(K)).cuda()
+    bq = g((N,), 402, 0.5).cuda() if bias else None
+    T = past + L + 5
+    Tp = (T + 127) // 128 * 128
+    half = hd // 2
+    cos = torch.rand((B, T, half), device="cuda") if rot else None
+    sin = torch.rand((B, T, half), device="cuda") if rot else None
+    qs = 1.3
+    k0, v0 = g((B, nkv, Tp, hd), 403).cuda(), g((B, nkv, hd, Tp), 404).cuda()
+    pinned = ops.set_tuning("gemm_big_rows", big)
+    try:
+        qkv = ops.gemm(a, w, ops.EPI_BIAS, bias=bq) if bias else ops.gemm(a, w)
+        q1, k1, v1 = torch.empty((B, nh, L, hd), dtype=BF16, device="cuda"), k0.clone(), v0.clone()
+        ops.rope_kv_append(qkv, cos, sin, q1, k1, v1, B, L, nh, nkv, hd, past, Tp, True, T, 1, q_scale=qs)
+        q2, k2, v2 = torch.full((B, nh, L, hd), 7.0, dtype=BF16, device="cuda"), k0.clone(), v0.clone()
+        assert ops.gemm_qkv(a, w, cos, sin, q2, k2, v2, B, L, nh, nkv, hd, past, Tp, True, T, 1, q_scale=qs, bias=bq), "shape not taken"
+        torch.cuda.synchronize()
+    finally:
+        ops.set_tuning("gemm_big_rows", pinned)
+    assert torch.equal(q2, q1), f"Q differs ({(q2 != q1).sum().item()} elements)"
+    assert torch.equal(k2, k1), f"K cache differs ({(k2 != k1).sum().item()} elements)"
+    assert torch.equal(v2, v1), f"V^T cache differs ({(v2 != v1).sum().item()} elements)"
+    assert not torch.equal(k1, k0) and not torch.equal(v1, v0)
+
+
+def test_gemm_qkv_declines_what_it_cannot_fuse(ops):
+    """Short prompts, unaligned append offsets and batch rows whose length is not a multiple of 8: P3V_ERR_UNSUPPORTED, nothing written."""
+    nh, hd, K = 16, 64, 128
+    N = 3 * nh * hd
+    w = g((N, K), 410).cuda()
+    for B, L, past in ((1, 300, 0), (1, 1200, 3), (2, 1001, 0)):
+        a = g((B * L, K), 411).cuda()
+        Tp = (past + L + 127) // 128 * 128
+        q = torch.zeros((B, nh, L, hd), dtype=BF16, device="cuda")
+        k, v = torch.zeros((B, nh, Tp, hd), dtype=BF16, device="cuda"), torch.zeros((B, nh, hd, Tp), dtype=BF16, device="cuda")
+        assert not ops.gemm_qkv(a, w, None, None, q, k, v, B, L, nh, nh, hd, past, Tp, True)
+        torch.cuda.synchronize()
+        assert not q.any() and not k.any() and not v.any()
+
+
+@pytest.mark.parametrize("B,nkv,T,n_tok", [(1, 32, 384, 300), (2, 4, 128, 128), (1, 2, 64, 5)])
+def test_kv_quantize_mlx4_is_mx_quantize(ops, B, nkv, T, n_tok):
+    """p3v_kv_quantize_mlx4 (the reference's own prompt-cache format, phi.py:528-540) against the MLX group quantiser
+    (weights.mlx_quantize: group 32, 4 bits, fp32 scales as for the reference's fp32 keys) on the same bf16 rows: codes, scales and
+    biases BIT-IDENTICAL for K (token-major) and V (stored transposed), the cache rows rewritten with scale * q + bias rounded to
+    bf16, rows beyond n_tok untouched."""
+    from phi_3_vision_mlx_amd.weights import mlx_dequantize, mlx_quantize
+    hd = 96
+    k = g((B, nkv, T, hd), 300, 1.5)
+    v = g((B, nkv, T, hd), 301, 0.7)
+    k[0, 0, 1] = 0.0                                        # an all-zero group (scale clamps to 1e-7, every code 0)
+    k[0, 0, 2, :32] = torch.linspace(-3, -1, 32).to(BF16)   # all negative: the minimum is the exact edge
+    k[0, 0, 3, :32] = torch.linspace(0.5, 2, 32).to(BF16)   # all positive: the maximum is
+    kc, vt = k.cuda(), v.transpose(2, 3).contiguous().cuda()
+    k4 = torch.zeros((B, nkv, n_tok, 3, 4), dtype=torch.int32, device="cuda")
+    v4 = torch.zeros_like(k4)
+    ksb = torch.zeros((B, nkv, n_tok, 3, 2), dtype=F32, device="cuda")
+    vsb = torch.zeros_like(ksb)
+    ops.kv_quantize_mlx4(kc, vt, k4, v4, ksb, vsb, n_tok)
+    for name, src, c4, sb, back in (("K", k, k4, ksb, kc), ("V", v, v4, vsb, vt.transpose(2, 3))):
+        flat = src[:, :, :n_tok].reshape(B * nkv, n_tok * hd).float()
+        pw, ps, pb = mlx_quantize(flat, 32, 4)
+        assert torch.equal(c4.cpu().reshape(B * nkv, -1), pw), f"{name}: codes differ from mx.quantize"
+        assert torch.equal(sb.cpu()[..., 0].reshape(B * nkv, -1), ps) and torch.equal(sb.cpu()[..., 1].reshape(B * nkv, -1), pb), f"{name}: scale / bias"
+        deq = mlx_dequantize(pw, ps, pb, 32, 4).to(BF16).reshape(B, nkv, n_tok, hd)
+        assert torch.equal(back.cpu()[:, :, :n_tok], deq), f"{name}: rows not rewritten with the dequantised values"
+        assert torch.equal(back.cpu()[:, :, n_tok:], src[:, :, n_tok:]), f"{name}: rows beyond n_tok touched"
+
+
 @pytest.mark.parametrize("seed", range(4))
 def test_attention_decode_random_shapes_merge_modes_agree(ops, seed):
     """Fuzz of the decode attention: random (B, L, past, heads, pads) on the 64-key, 128-key and streaming plans; the

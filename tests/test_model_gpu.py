@@ -253,6 +253,43 @@ def test_quantized_cache_close_to_bf16_cache():
     assert (lq.float() - lb.float()).abs().max().item() <= 3e-2 * lb.float().abs().max().item() + 1e-2
 
 
+def test_mlx4_prompt_cache_is_the_references_semantics():
+    """load(..., quantize_cache=True, cache_format="mlx4"): the reference's own quantised cache (phi.py:528-540).  (a) the prefill
+    attends on the EXACT keys: its logits equal the bf16-cache model's bit for bit; (b) from the second call on the prompt's K / V are
+    mx.dequantize(mx.quantize(., group 32, 4 bits)) and later tokens stay unquantised: the decode steps are bit-identical to a bf16-cache
+    model whose prompt rows were replaced, on the host, by that round trip (weights.mlx_quantize / mlx_dequantize); (c) beam reads of
+    the quantised cache raise as in the reference (phi.py:525)."""
+    from phi_3_vision_mlx_amd import ops
+    from phi_3_vision_mlx_amd.api import load_synthetic
+    from phi_3_vision_mlx_amd.weights import mlx_dequantize, mlx_quantize
+    plain, _ = load_synthetic(blind_model=True, tiny=True, seed=0, std_scale=4.0, device="cuda:0")
+    q4, _ = load_synthetic(blind_model=True, tiny=True, seed=0, std_scale=4.0, device="cuda:0", use_quantized_cache=True, cache_format="mlx4")
+    ids = rand_ids(70, 31)
+    la, ca = plain(input_ids=ids, max_tokens=8)
+    lb, cb = q4(input_ids=ids, max_tokens=8)
+    assert torch.equal(la, lb), "the prefill must attend on the exact keys"
+    sa, sb = ca[0].state, cb[0].state
+    assert sb.mlx4 and not sb.quantized and sb.mlx4_tokens == 70
+    S, hd = 70, plain.hd
+    for name, t, tr in (("k", sa.k, False), ("v", sa.v, True)):                      # host round trip on the bf16 model's prompt rows
+        rows = (t.transpose(3, 4) if tr else t)[:, :, :, :S].float().cpu()           # [nl, B, nkv, S, hd]
+        nl, B, nkv = rows.shape[:3]
+        deq = mlx_dequantize(*mlx_quantize(rows.reshape(nl * B * nkv, S * hd), 32, 4), 32, 4).to(BF16).reshape(nl, B, nkv, S, hd).cuda()
+        if tr:
+            t[:, :, :, :, :S] = deq.transpose(3, 4)
+        else:
+            t[:, :, :, :S] = deq
+    assert torch.equal(sa.k[:, :, :, :S], sb.k[:, :, :, :S]) and torch.equal(sa.v[..., :S], sb.v[..., :S])
+    tok = ops.argmax(la[:, -1, :].contiguous())[:, None]
+    ta, tb = tok, tok
+    for step in range(6):
+        la, ta = plain.greedy_step(ta, ca)
+        lb, tb = q4.greedy_step(tb, cb)
+        assert torch.equal(la, lb) and torch.equal(ta, tb), f"decode step {step} differs"
+    with pytest.raises(NotImplementedError):
+        q4(input_ids=np.asarray([[5, 6]]), cache=cb, n_beam=2, advance_offset=0)
+
+
 def test_fp8_weights_equal_bf16_model_on_dequantised_weights():
     """quantize_model=True: the fp8 model must equal a bf16 model that is handed the dequantised weights
     (isolates the kernels from the quantisation error itself), and stay close to the unquantised model."""
@@ -494,6 +531,7 @@ REF_CASES = {
     "visns": (False, "<|user|>\n<|image_1|>\nWhat is shown?<|end|>\n<|assistant|>\n", ["land"]),
     "vis2": (False, "<|user|>\n<|image_1|>\n<|image_2|>\nCompare the two.<|end|>\n<|assistant|>\n", ["sq", "land"]),
     "lora": (True, REF_PROMPTS[1], None),
+    "q4cache": (True, REF_PROMPTS[0], None),        # the reference's own quantised cache (phi.py:528-540) -> cache_format="mlx4"
 }
 
 
@@ -520,8 +558,9 @@ def test_reference_model_fixture(name, tmp_path):
         tensors = {k[len("lora_"):].replace("__", "."): torch.from_numpy(g[k]) for k in g.files if k.startswith("lora_model")}
         adapter = str(tmp_path / "ad")
         save_adapter(adapter, dict(meta["lora_adapter"], model_path="m", adapter_path=adapter), tensors)
+    extra = dict(use_quantized_cache=True, cache_format="mlx4") if name == "q4cache" else {}
     model, proc = api.load_synthetic(blind_model=blind, tiny=True, seed=0, std_scale=4.0, device="cuda:0", adapter_path=adapter,
-                                     lm_head_spread=float(g["spread"][0]), lm_head_seed=int(g[name + "_head_seed"][0]))
+                                     lm_head_spread=float(g["spread"][0]), lm_head_seed=int(g[name + "_head_seed"][0]), **extra)
     imgs = [make_image(*REF_IMAGES[i]) for i in images] if images else None
     inputs = proc(prompt, imgs) if imgs else proc(prompt)
     assert np.array_equal(np.asarray(inputs["input_ids"]), g[name + "_input_ids"])       # the reference processor's ids
@@ -722,7 +761,8 @@ def _walk_long_fixture(model, inp, g, prefix, rel_tol, what):
 
 def test_well_conditioned_reference_long_horizon():
     """Round 5: the end-to-end check on a network that does NOT amplify rounding noise.  Full-size text model
-    with its residual-branch output projections scaled by 1 / sqrt(2 * 32) (weights.synth_weights(residual_scale=True)); config 1's
+    with its residual-branch output projections scaled by 1 / 512 (weights.synth_weights(residual_scale=...), the fixture names the
+    value: the 64 branches then carry about half the amplitude of the embedding stream; gen_golden_refmodel.wc); config 1's
     128-token prompt; 128 greedy tokens produced by the REFERENCE'S OWN `_generate` over the functional MLX stand-in
     (tests/golden/gen_golden_refmodel.py wc -> ref_model_wc.npz) under two UNSEARCHED heads -- the plain N(0, 0.02) lm_head that
     bench.py times, and the peaked head of seed 0.  The HIP path, teacher-forced through the graph-replayed step: every recorded
@@ -734,7 +774,7 @@ def test_well_conditioned_reference_long_horizon():
     assert rel_tol <= 0.015 + 1e-9
     inp = {"input_ids": np.load(GOLDEN + "/c1_oracle.npz")["ids"]}
     for prefix, kw in (("plain_", {}), ("peaked0_", dict(lm_head_spread=float(g["spread"][0]), lm_head_seed=0))):
-        model, _ = load_synthetic(blind_model=True, tiny=False, seed=0, device="cuda:0", residual_scale=True, **kw)
+        model, _ = load_synthetic(blind_model=True, tiny=False, seed=0, device="cuda:0", residual_scale=float(g["residual_scale"][0]), **kw)
         exact, n_clear, _ = _walk_long_fixture(model, inp, g, prefix, rel_tol, f"well-conditioned C1, {prefix[:-1]} head vs the reference")
         assert exact == n_clear
         if prefix == "plain_":
