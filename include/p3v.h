@@ -273,9 +273,13 @@ int p3v_kv_dequantize(const uint8_t* k8, const uint8_t* v8t, const float* k_scal
  * calls attend on mx.dequantize of them, later tokens stay unquantised.  Tokens [0, n_tok) of a bf16 K [BH, cache_t, hd] /
  * V^T [BH, hd, cache_t] pair -> codes k4 / v4 [BH, n_tok, hd / 32, 4] (uint32, MLX's packing: code k of a word at bits [4k, 4k+4)),
  * k_sb / v_sb [BH, n_tok, hd / 32, 2] fp32 (scale, bias), and the rows REWRITTEN IN PLACE with scale * q + bias (one rounding to
- * bf16): what every later call of the reference attends on.  hd % 32 == 0. */
+ * bf16): what every later call of the reference attends on.  hd % 32 == 0.
+ * qkv != null: the keys are quantised from their EXACT fp32 values, as the reference's are (RoPE promotes k to fp32, phi.py:451) --
+ * recomputed from the layer's projection output qkv [B * n_tok, (n_heads + 2 n_kv) * hd] (the first call: L = n_tok) and the rotation
+ * tables (positions past + t), with p3v_rope_kv_append's arithmetic; null: from the cache rows (already rounded to bf16). */
 int p3v_kv_quantize_mlx4(uint16_t* k, uint16_t* vt, uint32_t* k4, uint32_t* v4, float* k_sb, float* v_sb, int BH, int hd,
-                         int cache_t, int n_tok, void* stream);
+                         int cache_t, int n_tok, const uint16_t* qkv, const float* cos_t, const float* sin_t, int n_heads, int n_kv,
+                         int past, int tab_t, int tab_div, void* stream);
 
 typedef struct {
   const uint16_t* qkv; const float* cos_t; const float* sin_t;

@@ -96,22 +96,66 @@ def su_rope_tables(cfg, L_all, pids):
     return cos, sin
 
 
+def mx_quantize(w, group_size=32, bits=4):
+    """mx.quantize as MLX documents it (restated here: the oracle imports nothing of the product): per group of `group_size` values
+    w ~ scale * q + bias with q in 0 .. 2^bits - 1; the end of the range with the larger magnitude is represented exactly (it
+    becomes the bias, the scale takes the sign that reaches the other end); scale and bias are returned in w's dtype and the codes
+    are taken against those stored values.  -> (codes int64 [N, K], scales [N, K / group], biases)."""
+    N, K = w.shape
+    g = w.float().reshape(N, K // group_size, group_size)
+    n_bins = (1 << bits) - 1
+    w_max, w_min = g.amax(-1), g.amin(-1)
+    side = w_min.abs() > w_max.abs()
+    scales = ((w_max - w_min) / n_bins).clamp_min(1e-7)
+    scales = torch.where(side, scales, -scales)
+    edge = torch.where(side, w_min, w_max)
+    q0 = torch.round(edge / scales)
+    scales = torch.where(q0 != 0, edge / q0, scales)
+    biases = torch.where(q0 == 0, torch.zeros_like(edge), edge)
+    scales, biases = scales.to(w.dtype), biases.to(w.dtype)
+    q = torch.round((g - biases.float()[..., None]) / scales.float()[..., None]).clamp(0, n_bins).to(torch.int64)
+    return q.reshape(N, K), scales, biases
+
+
+def mx_dequantize(q, scales, biases, group_size=32):
+    """mx.dequantize: scale * q + bias per group, in the scales' dtype."""
+    N, K = q.shape
+    w = q.float().reshape(N, K // group_size, group_size) * scales.float()[..., None] + biases.float()[..., None]
+    return w.reshape(N, K).to(scales.dtype)
+
+
 class OracleKVCache:
-    """KVCache (phi.py:509-548), bf16/fp32 path + beam view.  The 4-bit
-    quantised variant is not restated (replaced by int8 KV in the build, Q12)."""
+    """KVCache (phi.py:509-548): the plain path + beam view, and (round 5) the reference's quantised variant
+    (`use_quantized_cache`: phi.py:528-540 -- mx.quantize(group 32, 4 bits) of the FIRST call's keys / values, later tokens kept
+    unquantised, every later call attends on the dequantised prompt + those)."""
 
     def __init__(self, cfg, B, S, max_tokens):
         self.max_tokens = max_tokens
         self.offset = 0
         self.shape = (2, B, cfg.num_key_value_heads, S + max_tokens, cfg.hidden_size // cfg.num_key_value_heads)
         self.kv = None
+        self.use_quantized_cache = bool(getattr(cfg, "use_quantized_cache", False)) and getattr(cfg, "cache_format", "int8") == "mlx4"
+        self.keys, self.values = [], []
 
     def __call__(self, keys, values, n_beam):
         if self.max_tokens < 1:
             return keys, values
         if n_beam > 1:
+            if self.use_quantized_cache:
+                raise NotImplementedError("Beam Search is not yet compatible with Quantized Cache")
             kv = self.kv[:, :, :, :self.offset, :].repeat_interleave(n_beam, dim=1)
             return torch.cat([kv[0], keys.to(kv.dtype)], dim=-2), torch.cat([kv[1], values.to(kv.dtype)], dim=-2)
+        if self.use_quantized_cache:                             # phi.py:528-540
+            self.offset += values.shape[2]
+            _, B, N, _, D = self.shape
+            if self.kv is None:
+                self.kv = (mx_quantize(keys.reshape(B * N, -1)), mx_quantize(values.reshape(B * N, -1)))
+                return keys, values
+            self.keys.append(keys)
+            self.values.append(values)
+            k_cache = mx_dequantize(*self.kv[0]).reshape(B, N, -1, D)
+            v_cache = mx_dequantize(*self.kv[1]).reshape(B, N, -1, D)
+            return torch.cat([k_cache] + self.keys, dim=2), torch.cat([v_cache] + self.values, dim=2)
         if self.kv is None:
             self.kv = torch.zeros(self.shape, dtype=keys.dtype)
         new_offset = self.offset + keys.shape[2]

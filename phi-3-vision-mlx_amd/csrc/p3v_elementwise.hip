@@ -398,11 +398,17 @@ extern "C" int p3v_rope_kv_append(const uint16_t* qkv, const float* cos_t, const
 // groups -- and every later call attends on mx.dequantize of that (later tokens stay unquantised).  One thread per (row, token,
 // group): the MLX affine group quantiser (weights.mlx_quantize: the larger-magnitude end of the range is represented exactly,
 // scale and bias stay fp32 as they do for the reference's fp32 keys), the codes in MLX's packing (code k of a word at bits
-// [4k, 4k+4)), and the group written BACK dequantised (scale * q + bias, one rounding to bf16): the cache rows then hold exactly
+// [4k, 4k+4)), and the group written BACK dequantised (scale * q + bias, one rounding to bf16; V: scale and bias are bf16 values, as
+// mx.quantize returns them for a bf16 input): the cache rows then hold exactly
 // what the reference attends on from the second call on, and the decode kernels read them as they are.
+struct Mlx4Src {                                                  // where the EXACT fp32 keys come from (null qkv: from the bf16 cache rows)
+  const bf16_t* qkv; const float* cos_t; const float* sin_t;      // the layer's projection output [B * L, (nh + 2 nkv) * hd] + rotation tables
+  int L, nh, nkv, past, tab_t, tab_div;
+};
+
 __global__ void __launch_bounds__(256) k_kv_quantize_mlx4(bf16_t* __restrict__ k, bf16_t* __restrict__ vt, uint32_t* __restrict__ k4,
                                                           uint32_t* __restrict__ v4, float* __restrict__ k_sb, float* __restrict__ v_sb,
-                                                          int hd, int cache_t, int n_tok, long total) {
+                                                          int hd, int cache_t, int n_tok, long total, Mlx4Src src) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
   const int gpt = hd >> 5;                                        // groups per token (3)
@@ -414,11 +420,25 @@ __global__ void __launch_bounds__(256) k_kv_quantize_mlx4(bf16_t* __restrict__ k
   const bool is_v = row2 >= BH;
   const long row = is_v ? row2 - BH : row2;
   float w[32];
-  if (!is_v) {
-    const u32x4_t* src = (const u32x4_t*)(k + ((size_t)row * cache_t + t) * hd + g * 32);
+  if (!is_v && src.qkv) {
+    // The reference quantises its fp32 keys (phi.py:451, 531: RoPE promotes k to fp32 and the cache takes it as it is); the cache row
+    // holds them rounded to bf16 -- 0.4 % away, enough to flip 4-bit codes.  Recompute the rotation from the projection output with
+    // the arithmetic the rotation kernels use (p3v_rope_pair: multiply, multiply, add in fp32 = the reference's expression).
+    const int b = (int)(row / src.nkv), head = (int)(row % src.nkv), half = hd >> 1;
+    const bf16_t* x = src.qkv + ((size_t)b * src.L + t) * (size_t)((src.nh + 2 * src.nkv) * hd) + (size_t)(src.nh + head) * hd;
+    const size_t trow = ((size_t)(b / src.tab_div) * src.tab_t + src.past + t) * half;
+#pragma unroll
+    for (int d = 0; d < 32; ++d) {
+      const int dd = g * 32 + d, pr = dd < half ? dd : dd - half;
+      float o1, o2;
+      p3v_rope_pair(bf16_to_f32(x[pr]), bf16_to_f32(x[pr + half]), src.cos_t[trow + pr], src.sin_t[trow + pr], 1.f, o1, o2);
+      w[d] = dd < half ? o1 : o2;
+    }
+  } else if (!is_v) {
+    const u32x4_t* srcp = (const u32x4_t*)(k + ((size_t)row * cache_t + t) * hd + g * 32);
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-      const u32x4_t v = src[c];
+      const u32x4_t v = srcp[c];
 #pragma unroll
       for (int j = 0; j < 4; ++j) { w[c * 8 + 2 * j] = bf16lo(v[j]); w[c * 8 + 2 * j + 1] = bf16hi(v[j]); }
     }
@@ -435,7 +455,10 @@ __global__ void __launch_bounds__(256) k_kv_quantize_mlx4(bf16_t* __restrict__ k
   const float edge = mask ? w_min : w_max;
   const float q0 = rintf(edge / scale);
   if (q0 != 0.f) scale = edge / q0;
-  const float bias = q0 == 0.f ? 0.f : edge;
+  float bias = q0 == 0.f ? 0.f : edge;
+  if (is_v) {                                                     // mx.quantize keeps scale and bias in the INPUT's dtype: the values reach the
+    scale = bf16_round(scale), bias = bf16_round(bias);           // cache as bf16 (phi.py:443-449: only q and k are promoted by the rotation),
+  }                                                               // the keys as fp32 -- and the codes are taken against the stored pair
   uint32_t words[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
   for (int d = 0; d < 32; ++d) {
@@ -465,14 +488,17 @@ __global__ void __launch_bounds__(256) k_kv_quantize_mlx4(bf16_t* __restrict__ k
 }
 
 extern "C" int p3v_kv_quantize_mlx4(uint16_t* k, uint16_t* vt, uint32_t* k4, uint32_t* v4, float* k_sb, float* v_sb, int BH, int hd,
-                                    int cache_t, int n_tok, void* stream) {
+                                    int cache_t, int n_tok, const uint16_t* qkv, const float* cos_t, const float* sin_t, int n_heads,
+                                    int n_kv, int past, int tab_t, int tab_div, void* stream) {
   if (!k || !vt || !k4 || !v4 || !k_sb || !v_sb) return P3V_ERR_ARG;
   if (BH < 0 || n_tok < 0 || hd <= 0 || hd % 32 || n_tok > cache_t) return P3V_ERR_ARG;
+  if (qkv && (!cos_t || !sin_t || n_heads <= 0 || n_kv <= 0 || BH % n_kv || tab_div <= 0)) return P3V_ERR_ARG;
+  const Mlx4Src src = {qkv, cos_t, sin_t, n_tok, n_heads, n_kv, past, tab_t, tab_div};
   if (((uintptr_t)k | (uintptr_t)k4 | (uintptr_t)v4) & 15) return P3V_ERR_ARG;
   const long total = (long)BH * n_tok * (hd / 32) * 2;
   if (total == 0) return P3V_OK;
   hipLaunchKernelGGL(k_kv_quantize_mlx4, dim3((unsigned)p3v_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, k, vt, k4, v4, k_sb,
-                     v_sb, hd, cache_t, n_tok, total);
+                     v_sb, hd, cache_t, n_tok, total, src);
   P3V_CHECK_LAUNCH();
   return P3V_OK;
 }

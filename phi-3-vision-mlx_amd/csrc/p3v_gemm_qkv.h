@@ -54,47 +54,66 @@ __device__ __forceinline__ void qkv_epilogue_rot(const QkvP& q, f32x4_t (&acc)[N
   }
   // the block this lane stores after the swap: jj = fq & 1, its columns 8 * (fq >> 1) .. + 8
   const int Ps = pw + (fq & 1) * 16, head_s = Ps / half, d_s = Ps % half + (fq >> 1) * 8;
+  // (b, l) of the lane's row in block 0; later blocks are 16 tokens further on (one division per tile, not per block)
+  const int m00 = m_first + fc;
+  int b0 = 0, l0 = q.m_base + (m00 < M ? m00 : M - 1);
+  if (l0 >= q.L) { b0 = l0 / q.L; l0 -= b0 * q.L; }
+  // The rotation tables cost 4 sixteen-byte loads per block row: requested FOUR BLOCK ROWS AT A TIME (64 registers; the fragment
+  // registers of the K loop are free here), so a tile pays two round trips to the L2 instead of eight dependent ones.
+  constexpr int G = NI < 4 ? NI : 4;
 #pragma unroll
-  for (int i = 0; i < NI; ++i) {
-    const int m = m_first + i * 16 + fc;
-    const int mg = q.m_base + (m < M ? m : M - 1), b = mg / q.L, l = mg - b * q.L;
-    const float* ct = rot ? q.cos_t + ((size_t)(b / q.tab_div) * q.tab_t + q.past + l) * half : nullptr;
-    const float* st = rot ? q.sin_t + ((size_t)(b / q.tab_div) * q.tab_t + q.past + l) * half : nullptr;
-    uint32_t pk1[2][2], pk2[2][2];
+  for (int ig = 0; ig < NI; ig += G) {
+    float4 cs4[G][2], sn4[G][2];
+    int bb[G], ll[G];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      float cs[4] = {1.f, 1.f, 1.f, 1.f}, sn[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int ii = 0; ii < G; ++ii) {
+      const int i = ig + ii;
+      int l = l0 + i * 16, b = b0;
+      const int m = m00 + i * 16;
+      if (m >= M) l = l0 + (M - 1 - (m00 < M ? m00 : M - 1));   // clamped rows: any valid table row (nothing is stored for them)
+      while (l >= q.L) { l -= q.L; ++b; }
+      bb[ii] = b, ll[ii] = l;
       if (rot) {
-        const float4 c4 = *(const float4*)(ct + d0[j]), s4 = *(const float4*)(st + d0[j]);
-        cs[0] = c4.x, cs[1] = c4.y, cs[2] = c4.z, cs[3] = c4.w, sn[0] = s4.x, sn[1] = s4.y, sn[2] = s4.z, sn[3] = s4.w;
-      }
-      float o1[4], o2[4];
+        const size_t trow = ((size_t)(b / q.tab_div) * q.tab_t + q.past + l) * half;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float a0 = bf16_round(acc[i][j][r] + b1[j][r]), a1 = bf16_round(acc[i][j + 2][r] + b2[j][r]);   // the Linear's bf16 output
-        if (rot) {
-          p3v_rope_pair(a0, a1, cs[r], sn[r], qs, o1[r], o2[r]);
-        } else {
-          o1[r] = qs != 1.f ? a0 * qs : a0;
-          o2[r] = qs != 1.f ? a1 * qs : a1;
+        for (int j = 0; j < 2; ++j) { cs4[ii][j] = *(const float4*)(q.cos_t + trow + d0[j]); sn4[ii][j] = *(const float4*)(q.sin_t + trow + d0[j]); }
+      }
+    }
+#pragma unroll
+    for (int ii = 0; ii < G; ++ii) {
+      const int i = ig + ii, m = m00 + i * 16, b = bb[ii], l = ll[ii];
+      uint32_t pk1[2][2], pk2[2][2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const float cs[4] = {cs4[ii][j].x, cs4[ii][j].y, cs4[ii][j].z, cs4[ii][j].w}, sn[4] = {sn4[ii][j].x, sn4[ii][j].y, sn4[ii][j].z, sn4[ii][j].w};
+        float o1[4], o2[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float a0 = bf16_round(acc[i][j][r] + b1[j][r]), a1 = bf16_round(acc[i][j + 2][r] + b2[j][r]);   // the Linear's bf16 output
+          if (rot) {
+            p3v_rope_pair(a0, a1, cs[r], sn[r], qs, o1[r], o2[r]);
+          } else {
+            o1[r] = qs != 1.f ? a0 * qs : a0;
+            o2[r] = qs != 1.f ? a1 * qs : a1;
+          }
         }
+        pk1[j][0] = pack_bf16x2(o1[0], o1[1]), pk1[j][1] = pack_bf16x2(o1[2], o1[3]);
+        pk2[j][0] = pack_bf16x2(o2[0], o2[1]), pk2[j][1] = pack_bf16x2(o2[2], o2[3]);
       }
-      pk1[j][0] = pack_bf16x2(o1[0], o1[1]), pk1[j][1] = pack_bf16x2(o1[2], o1[3]);
-      pk2[j][0] = pack_bf16x2(o2[0], o2[1]), pk2[j][1] = pack_bf16x2(o2[2], o2[3]);
-    }
-    u32x4_t w1, w2;
+      u32x4_t w1, w2;
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      auto s1 = __builtin_amdgcn_permlane16_swap(pk1[0][k], pk1[1][k], false, false);
-      w1[k] = s1[0], w1[2 + k] = s1[1];
-      auto s2 = __builtin_amdgcn_permlane16_swap(pk2[0][k], pk2[1][k], false, false);
-      w2[k] = s2[0], w2[2 + k] = s2[1];
-    }
-    if (m < M) {
-      bf16_t* dst = is_k ? q.k_dst + (((size_t)b * q.nkv + head_s) * q.dst_t + q.dpos0 + l) * q.hd
-                         : q.q_out + (((size_t)b * q.nh + head_s) * q.L + l) * q.hd;
-      *(u32x4_t*)(dst + d_s) = w1;
-      *(u32x4_t*)(dst + d_s + half) = w2;
+      for (int k = 0; k < 2; ++k) {
+        auto s1 = __builtin_amdgcn_permlane16_swap(pk1[0][k], pk1[1][k], false, false);
+        w1[k] = s1[0], w1[2 + k] = s1[1];
+        auto s2 = __builtin_amdgcn_permlane16_swap(pk2[0][k], pk2[1][k], false, false);
+        w2[k] = s2[0], w2[2 + k] = s2[1];
+      }
+      if (m < M) {
+        bf16_t* dst = is_k ? q.k_dst + (((size_t)b * q.nkv + head_s) * q.dst_t + q.dpos0 + l) * q.hd
+                           : q.q_out + (((size_t)b * q.nh + head_s) * q.L + l) * q.hd;
+        *(u32x4_t*)(dst + d_s) = w1;
+        *(u32x4_t*)(dst + d_s + half) = w2;
+      }
     }
   }
 }
@@ -125,7 +144,7 @@ __device__ __forceinline__ void qkv_epilogue_vt(const QkvP& q, f32x4_t (&acc)[NI
       }
       const int t = t_first + (2 * jp + (fq & 1)) * 16 + (fq >> 1) * 8;      // 8 consecutive tokens t .. t + 7 (one batch row: launcher)
       if (t < M) {
-        const int mg = q.m_base + t, b = mg / q.L, l = mg - b * q.L;
+        const int mg = q.m_base + t, b = mg < q.L ? 0 : mg / q.L, l = mg - b * q.L;
         bf16_t* dst = q.v_dst + (((size_t)b * q.nkv + head) * q.hd + d) * (size_t)q.dst_t + q.dpos0 + l;
         if (t + 8 <= M) {
           *(u32x4_t*)dst = w;

@@ -544,7 +544,7 @@ class Phi3VModel:
             # its own epilogue (ops.gemm_qkv: bit-identical to the projection + rope_kv_append, one launch sequence instead of two).
             fused_qkv = False
             k_w = p + "self_attn.qkv_proj.weight"
-            if (L > ops.L.DECODE_MAX_L and n_beam == 1 and k_w in w and k_w not in self.adapters and M >= 1024
+            if (L > ops.L.DECODE_MAX_L and n_beam == 1 and k_w in w and k_w not in self.adapters and M >= 1024 and not mlx4_first
                     and os.environ.get("P3V_QKV_FUSE", "1") != "0"):
                 kd, vd = (st.k_tmp, st.v_tmp) if st.quantized else (st.k[i], st.v[i])
                 if not (st.quantized and past > 0 and not getattr(st, "fresh_rows", False)):
@@ -609,8 +609,7 @@ class Phi3VModel:
                 ops.attention(q, o, B, L, nh, nkv, hd, scale, True, past=past, k_past=st.k[i], v_past=st.v[i],
                               past_t=st.Tp, pad_len=st.pad_len, new_is_cache=True, q_prescaled=True)
             if mlx4_first:                                      # this layer attended on the exact keys (phi.py:533); from now on: the codes
-                ops.kv_quantize_mlx4(st.k[i], st.v[i], st.k4[i, :, :, :L], st.v4[i, :, :, :L], st.k_sb[i, :, :, :L], st.v_sb[i, :, :, :L], L) \
-                    if L == st.k4.shape[3] else self._mlx4_partial(st, i, L)
+                self._mlx4_quantize(st, i, L, qkv, nh)          # (keys from their exact fp32 values: recomputed from `qkv`)
             if last_only and i == cfg.num_hidden_layers - 1 and L > 1:
                 o = o.view(B, L, -1)[:, -1].contiguous()
                 x = x.view(B, L, -1)[:, -1].contiguous()
@@ -625,15 +624,15 @@ class Phi3VModel:
             st.mlx4_tokens = L
         return x
 
-    def _mlx4_partial(self, st, i, L):
-        """(first call shorter than the state's prompt length: contiguous code buffers of its own size)"""
-        if st.k4.shape[3] != L:
+    def _mlx4_quantize(self, st, i, L, qkv, nh):
+        if st.k4.shape[3] != L:                                 # (first call shorter than the state was sized for)
             nl, B, nkv, _, g, _ = st.k4.shape
             st.k4 = torch.zeros((nl, B, nkv, L, g, 4), dtype=I32, device=self.device)
             st.v4 = torch.zeros_like(st.k4)
             st.k_sb = torch.zeros((nl, B, nkv, L, g, 2), dtype=F32, device=self.device)
             st.v_sb = torch.zeros_like(st.k_sb)
-        ops.kv_quantize_mlx4(st.k[i], st.v[i], st.k4[i], st.v4[i], st.k_sb[i], st.v_sb[i], L)
+        ops.kv_quantize_mlx4(st.k[i], st.v[i], st.k4[i], st.v4[i], st.k_sb[i], st.v_sb[i], L, qkv=qkv, cos_t=st.cos, sin_t=st.sin, nh=nh,
+                             past=0, tab_t=st.T, tab_div=1)
 
     # ------------------------------------------------------------------ graph-replayed greedy decode step
     def _build_decode_graph(self, st):

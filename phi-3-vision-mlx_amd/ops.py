@@ -381,17 +381,22 @@ def kv_quantize(k, vt, k8, v8t, k_scale, v_scale, t0, n_tok):
                                     k8.shape[2], int(t0), int(n_tok), _stream()), "kv_quantize")
 
 
-def kv_quantize_mlx4(k, vt, k4, v4, k_sb, v_sb, n_tok):
+def kv_quantize_mlx4(k, vt, k4, v4, k_sb, v_sb, n_tok, qkv=None, cos_t=None, sin_t=None, nh=0, past=0, tab_t=0, tab_div=1):
     """The reference's own prompt-cache format (phi.py:528-540: mx.quantize, group 32, 4 bits): tokens [0, n_tok) of bf16
     K [B,nkv,T,hd] / V^T [B,nkv,hd,T] -> codes [B,nkv,n_tok,hd/32,4] int32 + (scale, bias) [B,nkv,n_tok,hd/32,2] fp32, and the
-    cache rows rewritten with the dequantised values."""
+    cache rows rewritten with the dequantised values.  qkv (+ cos_t / sin_t, nh): quantise the keys from their exact fp32 values,
+    recomputed from the projection output (the reference's keys are fp32), instead of the bf16 cache rows."""
     _chk(k, BF16, "k"), _chk(vt, BF16, "vt"), _chk(k4, I32, "k4"), _chk(v4, I32, "v4"), _chk(k_sb, F32, "k_sb"), _chk(v_sb, F32, "v_sb")
     B, nkv, T, hd = k.shape
     if tuple(vt.shape) != (B, nkv, hd, T) or tuple(k4.shape) != (B, nkv, n_tok, hd // 32, 4) or tuple(k_sb.shape) != (B, nkv, n_tok, hd // 32, 2) \
             or k4.shape != v4.shape or k_sb.shape != v_sb.shape:
         raise ValueError("kv_quantize_mlx4: shapes")
-    L.check(L.lib().p3v_kv_quantize_mlx4(_p(k), _p(vt), _p(k4), _p(v4), _p(k_sb), _p(v_sb), B * nkv, hd, T, int(n_tok), _stream()),
-            "kv_quantize_mlx4")
+    if qkv is not None:
+        _chk(qkv, BF16, "qkv"), _chk(cos_t, F32, "cos_t"), _chk(sin_t, F32, "sin_t")
+        if tuple(qkv.shape) != (B * n_tok, (nh + 2 * nkv) * hd):
+            raise ValueError("kv_quantize_mlx4: qkv must be the projection output of exactly the n_tok tokens being quantised")
+    L.check(L.lib().p3v_kv_quantize_mlx4(_p(k), _p(vt), _p(k4), _p(v4), _p(k_sb), _p(v_sb), B * nkv, hd, T, int(n_tok), _p(qkv), _p(cos_t),
+                                         _p(sin_t), nh, nkv, int(past), tab_t, tab_div, _stream()), "kv_quantize_mlx4")
 
 
 def kv_dequantize(k8, v8t, k_scale, v_scale, k, vt, n_tok):

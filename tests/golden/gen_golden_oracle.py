@@ -55,7 +55,7 @@ REL_TOL_SHORT = 0.09      # full size, short text prompts
 CKPT = os.environ.get("P3V_ORACLE_CKPT", "/tmp/p3v_oracle_ckpt_r4")     # prefilled requests are kept here between runs (GBs)
 SPREAD = 4.0                   # log2-sd of the lm_head row scales
 C1_STEPS = 6                   # prefill + 5 decode steps, all clear (each extra all-clear step costs ~4x more head seeds)
-REL_TOL_WC = 0.015             # full size, WELL-CONDITIONED checkpoint (residual branches x 1 / sqrt(2 * 32)): gen_golden_refmodel.py wc
+REL_TOL_WC = 0.012             # full size, WELL-CONDITIONED checkpoint (residual branches x 1 / 1024; measured HIP-vs-reference: 0.93 %): gen_golden_refmodel.py wc
 REL_TOL_C3 = 0.08              # full size, 5000-token text prompt (long RoPE factors): 7 % until RMSNorm rounded twice (round 4; measured 7.5 %)
 REL_TOL_C5 = 0.25              # config 5, W8A8 prefill + W8A16 decode + int8 KV: see c5()
 REL_TOL_C5W = 0.07             # config 5 with fp8_activations=False (weight-only fp8 + int8 KV)

@@ -463,12 +463,20 @@ def full():
     print("wrote ref_model_full.npz/.json")
 
 
+Q4CACHE_REL_TOL = 0.10
+
+
 def q4cache_case(out, meta):
     """Round 5: the reference's OWN quantised KV cache -- `_load(..., use_quantized_cache=True)` -> KVCache keeps
     mx.quantize(keys / values of the first call, group_size=32) and attends on mx.dequantize of them from the second call on, later
     tokens unquantised (phi.py:528-540) -- through `_generate` on the tiny text model.  The head seed is searched ON THE REFERENCE
-    (the oracle has no such cache) until every step is clear.  tests/test_model_gpu.py::test_reference_model_fixture[q4cache] runs
-    load(..., quantize_cache=True, cache_format="mlx4") against it."""
+    until every step is clear at Q4CACHE_REL_TOL = 10 % (the other tiny cases: 3 %).  Why so wide: the oracle (which restates this
+    cache too, phi3v_oracle.OracleKVCache, and reproduces this fixture BIT FOR BIT on the CPU) and the HIP path agree on layer 0's
+    codes, but from layer 1 on their inputs differ by the usual ~1 % of rounding noise, which flips ~10 % of the 4-bit codes -- each
+    flip moves a key or value by a full quantisation step (1/15 of its group's range).  Two correct implementations of a 4-bit cache
+    part at that level: 1.3 - 2.9 % of max |logit| against the oracle on this model (tools/scratch/q4cache_dbg.py), up to 6.5 % in
+    the tolerance's own unit under the peaked heads.  tests/test_model_gpu.py pins the mechanism exactly instead
+    (test_kv_quantize_mlx4_*: codes / scales / biases bit-identical to mx.quantize on equal inputs)."""
     d = tiny_config_dict(vision=False)
     cfg = make_config(d)
     w = synth_weights(cfg, seed=0, std_scale=4.0)
@@ -479,8 +487,8 @@ def q4cache_case(out, meta):
     mx, phi, loops = ref_env.load_reference()
     model, proc = ref_env.load_model(path, ByteTokenizer(), use_quantized_cache=True)
     assert model.config.use_quantized_cache if hasattr(model, "config") else True
-    prompt, n = TINY_PROMPTS[0], 6
-    for hs in range(400):
+    prompt, n = TINY_PROMPTS[0], 4
+    for hs in range(2000):
         head = peaked_lm_head(base, SPREAD, hs)
         model.lm_head.weight = mx.array(head)
         rec = ref_env.Recorder(model)
@@ -488,12 +496,13 @@ def q4cache_case(out, meta):
         lgs = torch.stack([c["logits"]._t[:, -1] for c in rec.calls], 1)
         if lgs.shape[1] != n:
             continue
-        mg = clearance(lgs, row_norms(head), REL_TOL)
+        mg = clearance(lgs, row_norms(head), Q4CACHE_REL_TOL)
         toks = torch.argmax(lgs.float(), dim=-1)
         if mg.min().item() > 1.0 and len(set(toks.reshape(-1).tolist())) >= 2:
             break
     else:
         raise RuntimeError("q4cache: no clear head seed")
+    out["q4cache_rel_tol"] = np.asarray([Q4CACHE_REL_TOL], dtype=np.float32)
     kv = rec.calls[0]  # noqa: F841
     ids = as_t(rec.calls[0]["input_ids"]).long()
     out["q4cache_head_seed"] = np.asarray([hs], dtype=np.int32)
@@ -506,13 +515,13 @@ def q4cache_case(out, meta):
     shutil.rmtree(path, ignore_errors=True)
 
 
-RESIDUAL_SCALE_WC = 1.0 / 512
+RESIDUAL_SCALE_WC = 1.0 / 1024
 
 
 def wc():
     """`ref_model_wc.npz` (round 5): the reference's own code at FULL size on a WELL-CONDITIONED checkpoint -- the seeded synthetic
-    text model with its residual-branch output projections (o_proj, down_proj) scaled by RESIDUAL_SCALE_WC = 1 / 512
-    (weights.synth_weights(residual_scale=...)), so that the 64 branches together carry about half the amplitude of the embedding
+    text model with its residual-branch output projections (o_proj, down_proj) scaled by RESIDUAL_SCALE_WC = 1 / 1024
+    (weights.synth_weights(residual_scale=...)), so that the 64 branches together carry about a quarter of the amplitude of the embedding
     stream instead of replacing it layer after layer (the depth-scaled initialisation 1 / sqrt(2 * 32) = 1 / 8 is not enough for
     that: the plain N(0, 0.02) gate_up / down pair alone has a gain of ~40; tools/scratch/wc_probe.py measured the decode-vs-prefill
     self-consistency at 5.8 / 5.4 / 4.2 / 2.6 / 1.1 % of max |logit| for scales 1, 1/8, 1/64, 1/256, 1/1024 -- 0.7 % of that is one
@@ -566,9 +575,32 @@ def wc():
     print("wrote ref_model_wc.npz/.json")
 
 
+def wc_retol():
+    """Re-state ref_model_wc.npz at the current REL_TOL_WC without re-running the reference (12 minutes of CPU per head): the clearance
+    of a step is (top-2 margin) / (sum of the two entries' tolerances), i.e. inversely proportional to rel_tol -- an exact rescale."""
+    from gen_golden_oracle import REL_TOL_WC
+    f = os.path.join(HERE, "ref_model_wc.npz")
+    g = dict(np.load(f))
+    old = float(g["rel_tol"][0])
+    for k in [k for k in g if k.endswith("margins")]:
+        g[k] = (g[k].astype(np.float64) * (old / REL_TOL_WC)).astype(np.float32)
+    g["rel_tol"] = np.asarray([REL_TOL_WC], dtype=np.float32)
+    np.savez_compressed(f, **g)
+    with open(os.path.join(HERE, "ref_model_wc.json")) as fh:
+        meta = json.load(fh)
+    meta["rel_tol"] = REL_TOL_WC
+    for k in ("plain", "peaked0"):
+        meta[k]["clear"] = int((g[k + "_margins"] > 1.0).sum())
+    with open(os.path.join(HERE, "ref_model_wc.json"), "w") as fh:
+        json.dump(meta, fh, indent=1)
+    print(f"ref_model_wc: rel_tol {old} -> {REL_TOL_WC}; clear steps plain {meta['plain']['clear']}, peaked0 {meta['peaked0']['clear']}")
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "wc":
         wc()
+    elif len(sys.argv) > 1 and sys.argv[1] == "wc_retol":
+        wc_retol()
     elif len(sys.argv) > 1 and sys.argv[1] in ("constrain", "q4cache"):   # one case, merged into the existing fixture
         out, meta = {}, {}
         if sys.argv[1] == "constrain":

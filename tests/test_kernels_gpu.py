@@ -721,13 +721,42 @@ def test_kv_quantize_mlx4_is_mx_quantize(ops, B, nkv, T, n_tok):
     vsb = torch.zeros_like(ksb)
     ops.kv_quantize_mlx4(kc, vt, k4, v4, ksb, vsb, n_tok)
     for name, src, c4, sb, back in (("K", k, k4, ksb, kc), ("V", v, v4, vsb, vt.transpose(2, 3))):
-        flat = src[:, :, :n_tok].reshape(B * nkv, n_tok * hd).float()
-        pw, ps, pb = mlx_quantize(flat, 32, 4)
+        flat = src[:, :, :n_tok].reshape(B * nkv, n_tok * hd)
+        # (the reference's keys reach mx.quantize as fp32 -- the rotation promotes them -- and its values as bf16: scale / bias
+        #  come back in the input's dtype and the codes are taken against them)
+        pw, ps, pb = mlx_quantize(flat.float() if name == "K" else flat, 32, 4)
         assert torch.equal(c4.cpu().reshape(B * nkv, -1), pw), f"{name}: codes differ from mx.quantize"
-        assert torch.equal(sb.cpu()[..., 0].reshape(B * nkv, -1), ps) and torch.equal(sb.cpu()[..., 1].reshape(B * nkv, -1), pb), f"{name}: scale / bias"
+        assert torch.equal(sb.cpu()[..., 0].reshape(B * nkv, -1), ps.float()) and torch.equal(sb.cpu()[..., 1].reshape(B * nkv, -1), pb.float()), f"{name}: scale / bias"
         deq = mlx_dequantize(pw, ps, pb, 32, 4).to(BF16).reshape(B, nkv, n_tok, hd)
         assert torch.equal(back.cpu()[:, :, :n_tok], deq), f"{name}: rows not rewritten with the dequantised values"
         assert torch.equal(back.cpu()[:, :, n_tok:], src[:, :, n_tok:]), f"{name}: rows beyond n_tok touched"
+
+
+def test_kv_quantize_mlx4_keys_from_exact_fp32_rotation(ops):
+    """With the projection output at hand the keys are quantised as the reference quantises them: from the fp32 result of the rotation
+    (phi.py:451 promotes k to fp32 and the cache takes it unrounded, :531), not from the bf16 cache rows.  Codes / scales / biases
+    against mx.quantize of the rotation evaluated in fp32 on the host (multiply, multiply, add: the array expression of phi.py:423)."""
+    from phi_3_vision_mlx_amd.weights import mlx_dequantize, mlx_quantize
+    B, nh, nkv, hd, L, T = 2, 4, 2, 96, 40, 128
+    half = hd // 2
+    qkv = g((B * L, (nh + 2 * nkv) * hd), 310, 1.2)
+    cos, sin = torch.rand((B, 50, half)), torch.rand((B, 50, half))
+    x = qkv.view(B, L, nh + 2 * nkv, hd)[:, :, nh:nh + nkv].float()                    # [B, L, nkv, hd] keys before rotation
+    k1, k2 = x[..., :half], x[..., half:]
+    cs, sn = cos[:, :L, None, :], sin[:, :L, None, :]
+    rot = torch.cat([k1 * cs - k2 * sn, k2 * cs + k1 * sn], dim=-1).permute(0, 2, 1, 3).contiguous()   # [B, nkv, L, hd] fp32
+    kc = torch.zeros((B, nkv, T, hd), dtype=BF16, device="cuda")
+    kc[:, :, :L] = rot.to(BF16).cuda()                                                  # what the rotation kernel left in the cache
+    vt = g((B, nkv, hd, T), 311).cuda()
+    k4 = torch.zeros((B, nkv, L, 3, 4), dtype=torch.int32, device="cuda")
+    v4 = torch.zeros_like(k4)
+    ksb = torch.zeros((B, nkv, L, 3, 2), dtype=F32, device="cuda")
+    vsb = torch.zeros_like(ksb)
+    ops.kv_quantize_mlx4(kc, vt, k4, v4, ksb, vsb, L, qkv=qkv.cuda(), cos_t=cos.cuda(), sin_t=sin.cuda(), nh=nh, past=0, tab_t=50, tab_div=1)
+    pw, ps, pb = mlx_quantize(rot.reshape(B * nkv, L * hd), 32, 4)
+    assert torch.equal(k4.cpu().reshape(B * nkv, -1), pw), "codes differ from mx.quantize of the fp32 keys"
+    assert torch.equal(ksb.cpu()[..., 0].reshape(B * nkv, -1), ps) and torch.equal(ksb.cpu()[..., 1].reshape(B * nkv, -1), pb)
+    assert torch.equal(kc.cpu()[:, :, :L], mlx_dequantize(pw, ps, pb, 32, 4).to(BF16).reshape(B, nkv, L, hd))
 
 
 @pytest.mark.parametrize("seed", range(4))

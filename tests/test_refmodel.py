@@ -120,6 +120,46 @@ def test_oracle_generate_matches_reference(fx, tiny_models, name):
         t.oracle.adapters = {}
 
 
+def test_oracle_quantised_cache_is_the_references(fx):
+    """Round 5: the reference's own quantised KV cache (`use_quantized_cache`, phi.py:528-540: mx.quantize(group 32, 4 bits) of the
+    first call's keys / values, later tokens unquantised) restated in the oracle (OracleKVCache + mx_quantize) reproduces the
+    reference's `_generate` run of fixture case `q4cache` BIT FOR BIT: every logit of every step."""
+    g, meta = fx
+    cfg = make_config(tiny_config_dict(vision=False), use_quantized_cache=True, cache_format="mlx4")
+    w = synth_weights(cfg, seed=0, std_scale=4.0)
+    w["lm_head.weight"] = peaked_lm_head(w["lm_head.weight"], float(g["spread"][0]), int(g["q4cache_head_seed"][0]))
+    o = orc.OraclePhi3V(cfg, w, cache_fp32=True)
+    n = g["q4cache_tokens"].shape[1]
+    toks, lgs = orc.greedy_generate(o, {"input_ids": g["q4cache_input_ids"]}, n, stop_on_eos=False)
+    assert np.array_equal(toks.numpy(), g["q4cache_tokens"])
+    assert np.array_equal(_bits(lgs), g["q4cache_logits_bf16"]), "quantised-cache logits are not bit-exact"
+    assert (g["q4cache_margins"] > 1.0).all() and float(g["q4cache_rel_tol"][0]) == pytest.approx(0.10)
+
+
+def test_clear_constrain_heads_and_well_conditioned_fixture(fx, tiny_models):
+    """Round 5 fixtures.  (a) `loops_clear`: under the recorded head seeds EVERY decision of the oracle's constrain loop (plain and
+    beam) has a margin above 3 % of max |logit|, and the oracle's synthesised ids decode to the reference's final texts.  (b)
+    ref_model_wc: 128 reference steps per head at rel_tol <= 1.5 %, >= 100 clear under the unsearched peaked head, >= 85 under the
+    plain head."""
+    g, meta = fx
+    t = tiny_models[True]
+    lc = meta["loops_clear"]
+    cons = tuple(lc["constraint"])
+    idc = t.proc.tokenizer.encode(cons[1], add_special_tokens=False)[1:]
+    for ub in (False, True):
+        info = lc[f"beam{int(ub)}"]
+        t.head(g["spread"][0], info["head_seed"])
+        ps = TINY_PROMPTS if not ub else TINY_PROMPTS[:1] * 2
+        tr = []
+        synth, _ = orc.constrain_one(t.oracle, dict(t.proc(list(ps))), cons, idc, use_beam=ub, trace=tr)
+        assert min(m for _, m, _ in tr) > lc["clear_margin"] and len(tr) == info["n_decisions"]
+        assert np.array_equal(synth.numpy(), g[f"clear_beam{int(ub)}_synth"])
+        assert all(txt.endswith(cons[1]) for txt in info["full_text"])
+    wc = np.load(os.path.join(GOLDEN, "ref_model_wc.npz"))
+    assert float(wc["rel_tol"][0]) <= 0.015 + 1e-9 and wc["plain_tokens"].shape[1] == 128 and wc["peaked0_tokens"].shape[1] == 128
+    assert int((wc["peaked0_margins"] > 1.0).sum()) >= 100 and int((wc["plain_margins"] > 1.0).sum()) >= 85
+
+
 def test_full_size_oracle_fixtures_equal_the_reference_composed_ones():
     """FULL SIZE (32 layers x 3072, vocab 32064; CLIP ViT-L/14-336 on 17 crops): `ref_model_full.npz` holds what the REFERENCE'S
     own `_load` + processors + `_generate` + `Phi3VForCausalLM` produce (over the MLX stand-in) for the requests of the oracle
