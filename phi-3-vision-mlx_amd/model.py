@@ -107,11 +107,15 @@ class CacheState:
         self.epoch = None                                       # model.epoch the graphs were captured under
 
 
+class _Lease:
+    """Held by the cache views of one captured-prefill call: while it lives, the entry's buffers belong to that caller."""
+
+
 class LayerCache:
     """`cache[i]` view with the reference's `.offset` attribute."""
 
-    def __init__(self, state, i):
-        self.state, self.i = state, i
+    def __init__(self, state, i, lease=None):
+        self.state, self.i, self.lease = state, i, lease
 
     @property
     def offset(self):
@@ -146,6 +150,8 @@ class Phi3VModel:
         # split-KV merge on grids larger than the machine) -- ADVICE r04.  One-shot generate() on an exclusive GPU keeps them.
         self.serving = os.environ.get("P3V_SHARED_GPU", "0") == "1"
         self.epoch = 0                               # bumped whenever captured decode graphs become stale
+        self._prefill_graphs = {}                    # (S, max_tokens) -> captured short-prompt prefill (see _prefill_captured)
+        self._prefill_seen = {}
         self._states = weakref.WeakSet()             # every live CacheState (their graphs bake pointers into this model)
         # quantize_model=True (fp8): prompt-sized projections run W8A8 on the fp8 MFMA unless fp8_activations=False
         # (then: dequantise to a bf16 scratch + bf16 MFMA, weight-only accuracy at bf16 prefill speed)
@@ -187,6 +193,7 @@ class Phi3VModel:
         for st in list(self._states):                # pointers in: drop them on EVERY live cache before the scratch goes
             st.graphs.clear()
         self._lora_tmp, self._lora_flat = {}, None
+        self._prefill_graphs.clear()
 
     def _quantize_decoder_q4(self):
         """Decoder projections + lm_head -> 4-bit group-64 (the reference's nn.quantize(model, 64, 4)): 7.4 GB -> 2.1 GB
@@ -737,10 +744,15 @@ class Phi3VModel:
         ids = ids.contiguous()
         B, L = ids.shape
         H = cfg.hidden_size
+        prefill = cache is None
+        if prefill and pixel_values is None and B == 1 and pids is None and mask is None and n_beam == 1 and not full_logits \
+                and advance_offset is None:
+            got = self._prefill_captured(ids, L, max_tokens)
+            if got is not None:
+                return got
         x = ops.embed_gather(ids.view(-1), w["model.embed_tokens.weight"])
         if pixel_values is not None and self.vision:
             self.vision_embed(x, pixel_values, image_sizes, positions, L)
-        prefill = cache is None
         if prefill:
             st = self._new_state(B, L, max_tokens, pids, mask)
             cache = [LayerCache(st, i) for i in range(cfg.num_hidden_layers)]
@@ -761,6 +773,74 @@ class Phi3VModel:
             x = x.view(B, L, H)[:, -1, :].contiguous()
         logits = self._proj(x, "lm_head.weight", norm_w=w["model.norm.weight"])
         return logits.view(B, -1, cfg.vocab_size), cache
+
+    # ------------------------------------------------------------------ captured prefill of short text prompts
+    PREFILL_GRAPH_MAX_S = 512
+    PREFILL_GRAPH_ENTRIES = 4
+
+    def _prefill_captured(self, ids, S, max_tokens):
+        """Short text prompts (B = 1, 17 .. 512 tokens) are launch-bound: ~390 launches of a few microseconds each, every one paid
+        for in Python + ctypes time (BASELINE config 1: 4.5 ms of wall time for 3.6 ms of kernels).  A (length, max_tokens) pair seen
+        for the SECOND time is captured as ONE hipGraph over buffers the entry owns -- ids, activations, rotation tables, the KV
+        cache itself -- and later prompts of that geometry cost one 0.5 KB copy + one graph launch.  The entry's cache is LEASED to
+        the caller: while any of the returned cache views is alive a new prompt of the same geometry takes the eager path, so a
+        caller that keeps two caches gets two caches (the reference's contract).  Bit-identical to the eager path (same kernels, same
+        order).  P3V_PREFILL_GRAPH=0 switches it off.  Returns None when not applicable."""
+        cfg = self.cfg
+        if (os.environ.get("P3V_PREFILL_GRAPH", "1") == "0" or S <= ops.L.DECODE_MAX_L or S > self.PREFILL_GRAPH_MAX_S or max_tokens < 1
+                or getattr(cfg, "use_quantized_cache", False) or self.adapters or self.hidden_hook is not None or self.w8 or self.w4):
+            return None
+        key = (S, max_tokens)
+        e = self._prefill_graphs.get(key)
+        if e is None:
+            if self._prefill_seen.get(key, 0) < 1:                # first sighting: eager (one-off lengths never pay for a capture)
+                if len(self._prefill_seen) > 64:
+                    self._prefill_seen.clear()
+                self._prefill_seen[key] = 1
+                return None
+            if len(self._prefill_graphs) >= self.PREFILL_GRAPH_ENTRIES:
+                self._prefill_graphs.pop(next(iter(self._prefill_graphs)))
+            e = self._prefill_graphs[key] = self._build_prefill_graph(S, max_tokens)
+        if e["lease"] is not None and e["lease"]() is not None:    # the previous caller still holds this entry's cache
+            return None
+        st = e["st"]
+        e["ids"].copy_(ids.view(-1), non_blocking=True)
+        st.offset = 0
+        g = st.graphs.get("greedy")
+        if g is not None:                                         # the decode graph of this cache geometry stays valid: same buffers
+            g["n_replays"], g["host_tok"], g["synced_offset"] = 0, None, None
+            g["d_step"].zero_()
+        e["graph"].launch()
+        st.offset = S
+        self._state = st
+        lease = _Lease()
+        e["lease"] = weakref.ref(lease)
+        return e["logits"].clone().view(1, 1, cfg.vocab_size), [LayerCache(st, i, lease) for i in range(cfg.num_hidden_layers)]
+
+    def _build_prefill_graph(self, S, max_tokens):
+        cfg, w, dev = self.cfg, self.w, self.device
+        st = self._new_state(1, S, max_tokens, None, None)
+        e = dict(st=st, lease=None, ids=torch.zeros((S,), dtype=I32, device=dev), x=torch.empty((S, cfg.hidden_size), dtype=BF16, device=dev),
+                 logits=torch.empty((1, cfg.vocab_size), dtype=BF16, device=dev), bufs=self._alloc_bufs(1, S), ws={})
+
+        def run():
+            st.offset = 0
+            ops.embed_gather(e["ids"], w["model.embed_tokens.weight"], out=e["x"])
+            xl = self._layers(e["x"], st, 1, S, 0, 1, bufs=e["bufs"], last_only=True)
+            self._proj(xl.view(1, -1), "lm_head.weight", norm_w=w["model.norm.weight"], out=e["logits"])
+        with ops.owned_gemm_workspace(e["ws"], frozen=False):
+            run()                                                # warm-up (sizes the split-K workspace the graph owns)
+        torch.cuda.synchronize()
+        graph = ops.Graph()
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side), ops.owned_gemm_workspace(e["ws"], frozen=True):
+            graph.begin()
+            run()
+            graph.end()
+        torch.cuda.current_stream().wait_stream(side)
+        e["graph"] = graph
+        return e
 
     @property
     def layers(self):

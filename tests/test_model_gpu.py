@@ -120,6 +120,57 @@ def test_graph_replayed_greedy_step_equals_eager(text):
         assert torch.equal(hist, torch.cat(eager_tok, dim=1).to(hist.dtype))
 
 
+def test_captured_short_prompt_prefill_equals_eager(text, monkeypatch):
+    """Round 5: a text prompt whose (length, max_tokens) was seen before is prefilled by ONE hipGraph over buffers the entry owns
+    (model._prefill_captured).  Same kernels in the same order: logits, cache contents and the greedy continuation are bit-identical to
+    the eager path; the entry's cache is leased -- while the caller keeps it, the next prompt of that geometry gets a state of its own
+    (eager), and once it is dropped the entry is reused."""
+    from phi_3_vision_mlx_amd import ops
+    model, _, _ = text
+    model._prefill_graphs.clear(), model._prefill_seen.clear()
+    ids_a, ids_b = rand_ids(57, 41), rand_ids(57, 42)
+    monkeypatch.setenv("P3V_PREFILL_GRAPH", "0")
+    ref = {}
+    for name, ids in (("a", ids_a), ("b", ids_b)):
+        lg, cache = model(input_ids=ids, max_tokens=6)
+        st = cache[0].state
+        toks, t = [], ops.argmax(lg[:, -1, :].contiguous())[:, None]
+        for _ in range(4):
+            _, t = model.greedy_step(t, cache)
+            toks.append(t.clone())
+        ref[name] = (lg.clone(), st.k[:, :, :, :57].clone(), st.v[..., :57].clone(), torch.cat(toks, 1).clone())
+        del cache, st
+    monkeypatch.setenv("P3V_PREFILL_GRAPH", "1")
+    l1, c1 = model(input_ids=ids_a, max_tokens=6)                # first sighting of (57, 6): eager
+    assert not model._prefill_graphs
+    del c1
+    l2, c2 = model(input_ids=ids_a, max_tokens=6)                # second: captured and replayed
+    assert (57, 6) in model._prefill_graphs
+    entry_state = model._prefill_graphs[(57, 6)]["st"]
+    assert c2[0].state is entry_state
+    assert torch.equal(l2, ref["a"][0]) and torch.equal(entry_state.k[:, :, :, :57], ref["a"][1]) and torch.equal(entry_state.v[..., :57], ref["a"][2])
+    l3, c3 = model(input_ids=ids_b, max_tokens=6)                # c2 still alive: the entry is leased -> a state of its own
+    assert c3[0].state is not entry_state and torch.equal(l3, ref["b"][0])
+    t = ops.argmax(l2[:, -1, :].contiguous())[:, None]           # the leased cache is intact and decodes as the eager one did
+    toks = []
+    for _ in range(4):
+        _, t = model.greedy_step(t, c2)
+        toks.append(t.clone())
+    assert torch.equal(torch.cat(toks, 1), ref["a"][3])
+    del c2, c3
+    l4, c4 = model(input_ids=ids_b, max_tokens=6)                # lease released: the entry again, other prompt, decode graph reused
+    assert c4[0].state is entry_state and torch.equal(l4, ref["b"][0])
+    t = ops.argmax(l4[:, -1, :].contiguous())[:, None]
+    toks = []
+    for _ in range(4):
+        _, t = model.greedy_step(t, c4)
+        toks.append(t.clone())
+    assert torch.equal(torch.cat(toks, 1), ref["b"][3])
+    l5, _ = model(input_ids=rand_ids(58, 43), max_tokens=6)      # another length: eager (first sighting), nothing captured for it
+    assert (58, 6) not in model._prefill_graphs and torch.isfinite(l5.float()).all()
+    model._prefill_graphs.clear(), model._prefill_seen.clear()
+
+
 def test_graph_decode_with_more_than_16_rows(text):
     """B = 20 rows: the decode projections are split-K GEMMs (M > 16), whose workspace the captured graph must own (ADVICE r03:
     no allocation under capture, no dangling pointer after a regrow).  Graph replays == eager steps, bit for bit, also after
