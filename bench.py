@@ -126,7 +126,7 @@ def cpu_baseline(model, n_decode=32, runs=3, warm_decode=2):
                       f"phi.py) on torch-CPU: 1 warm-up pass + {runs} timed pass(es); {n_decode} of the 128 decode steps per pass"}
 
 
-PMC_TRAFFIC_FILE = "r04_pmc_hbm_traffic.json"      # written by tools/pmc_round4.sh from separate rocprofv3 --pmc passes
+PMC_TRAFFIC_FILE = "r05_pmc_hbm_traffic.json"      # written by tools/pmc_round5.sh from separate rocprofv3 --pmc passes
 
 
 def kernel_source_sha16():

@@ -406,11 +406,29 @@ static int splitk_slices(int M, int N, int K, int epilogue) {
   return S;
 }
 
+int p3v_gemm_skinny_slices(int M, int N, int K, int epilogue);   // p3v_gemm_skinny.hip: 0 = not one of its shapes
+int p3v_gemm_skinny_try(const p3v_gemm_args_t* a, hipStream_t s);
+
 extern "C" int64_t p3v_gemm_ws_bytes(int M, int N, int K, int epilogue) {
   if (M <= 0 || N <= 0 || K <= 0) return 0;
-  const int S = splitk_slices(M, N, K, epilogue);
+  const int sk = p3v_gemm_skinny_slices(M, N, K, epilogue);
+  const int S = sk ? sk : splitk_slices(M, N, K, epilogue);
   if (S == 1) return 0;
   return (int64_t)S * M * (epilogue == P3V_EPI_SILU_MUL ? 2 * N : N) * 4;
+}
+
+// the second launch of a split: adds the S fp32 partials [S, M, W rows] in slice order and applies the epilogue
+int p3v_splitk_reduce(const float* part, const p3v_gemm_args_t* a, int S, hipStream_t s) {
+  const bool silu = a->epilogue == P3V_EPI_SILU_MUL;
+  const int w_rows = silu ? 2 * a->N : a->N;
+  const long items = (long)a->M * (a->N / 8);
+  const dim3 grid((unsigned)p3v_cdiv(items, 256));
+  if (silu) hipLaunchKernelGGL(k_splitk_reduce<P3V_EPI_SILU_MUL>, grid, dim3(256), 0, s, part, a->out, a->resid, a->M, a->N, w_rows, a->ldo, S);
+  else if (a->epilogue == P3V_EPI_RESID_BF16)
+    hipLaunchKernelGGL(k_splitk_reduce<P3V_EPI_RESID_BF16>, grid, dim3(256), 0, s, part, a->out, a->resid, a->M, a->N, w_rows, a->ldo, S);
+  else hipLaunchKernelGGL(k_splitk_reduce<P3V_EPI_NONE>, grid, dim3(256), 0, s, part, a->out, a->resid, a->M, a->N, w_rows, a->ldo, S);
+  P3V_CHECK_LAUNCH();
+  return P3V_OK;
 }
 
 // returns P3V_ERR_UNSUPPORTED when the shape is not one for split-K (or the caller gave no workspace for it)
@@ -425,14 +443,7 @@ static int gemm_splitk(const p3v_gemm_args_t* a, hipStream_t s) {
   GemmP p = {a->A, a->W, part, nullptr, nullptr, nullptr, a->M, w_rows, a->K, a->lda, a->ldw, w_rows, 0, a->K / S, {}};
   const int rc = launch_gemm<P3V_EPI_F32>(p, s);
   if (rc != P3V_OK) return rc;
-  const long items = (long)a->M * (a->N / 8);
-  const dim3 grid((unsigned)p3v_cdiv(items, 256));
-  if (silu) hipLaunchKernelGGL(k_splitk_reduce<P3V_EPI_SILU_MUL>, grid, dim3(256), 0, s, part, a->out, a->resid, a->M, a->N, w_rows, a->ldo, S);
-  else if (a->epilogue == P3V_EPI_RESID_BF16)
-    hipLaunchKernelGGL(k_splitk_reduce<P3V_EPI_RESID_BF16>, grid, dim3(256), 0, s, part, a->out, a->resid, a->M, a->N, w_rows, a->ldo, S);
-  else hipLaunchKernelGGL(k_splitk_reduce<P3V_EPI_NONE>, grid, dim3(256), 0, s, part, a->out, a->resid, a->M, a->N, w_rows, a->ldo, S);
-  P3V_CHECK_LAUNCH();
-  return P3V_OK;
+  return p3v_splitk_reduce(part, a, S, s);
 }
 
 extern "C" int p3v_gemm(const p3v_gemm_args_t* a, void* stream) {
@@ -450,6 +461,10 @@ extern "C" int p3v_gemm(const p3v_gemm_args_t* a, void* stream) {
     if ((size_t)a->M * a->lda * 2 >= (1ull << 32) || w_rows * a->ldw * 2 >= (1ull << 32)) return P3V_ERR_UNSUPPORTED;
   }
   hipStream_t s = (hipStream_t)stream;
+  if (!a->bias) {                                              // 17 .. 256 rows: the weight-streaming kernel (p3v_gemm_skinny.hip)
+    const int rc = p3v_gemm_skinny_try(a, s);
+    if (rc != P3V_ERR_UNSUPPORTED) return rc;
+  }
   {
     const int rc = gemm_splitk(a, s);
     if (rc != P3V_ERR_UNSUPPORTED) return rc;

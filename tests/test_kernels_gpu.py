@@ -168,7 +168,49 @@ def test_gemm_round_packing(ops, epi, M, N, K):
     if epi == "none": close(picked[:64], acc.to(BF16), rtol=2 ** -6, atol=2e-2)
 
 
-@pytest.mark.parametrize("epi,M,N,K", [("resid_bf16", 129, 3072, 8192), ("silu", 40, 8192, 3072), ("none", 300, 9216, 3072)])
+SKINNY_CASES = [("none", 128, 9216, 3072), ("none", 17, 9216, 3072), ("resid_bf16", 128, 3072, 3072), ("resid_bf16", 100, 3072, 8192),
+                ("silu", 128, 8192, 3072), ("silu", 33, 8192, 3072), ("silu", 256, 1024, 3072), ("none", 129, 3072, 3072),
+                ("resid_bf16", 250, 192, 768), ("silu", 64, 96, 384), ("none", 200, 64, 64)]
+
+
+@pytest.mark.parametrize("epi,M,N,K", SKINNY_CASES)
+def test_gemm_skinny_rows(ops, epi, M, N, K):
+    """17 .. 256 rows run on the 128 x 64-tile weight-streaming kernel (p3v_gemm_skinny.hip), in one pass or as K slices + the
+    reduction launch: against a float64 product of the same bf16 operands with the reference's roundings (Linear output to bf16,
+    then the elementwise ops), and against the 128 x 128-tile path the shape took before (same roundings, another fp32 summation
+    order: equal but for last-place flips of the bf16 rounding)."""
+    EPI = {"none": ops.EPI_NONE, "resid_bf16": ops.EPI_RESID_BF16, "silu": ops.EPI_SILU_MUL}[epi]
+    assert ops.L.lib().p3v_gemm_ws_bytes(M, N, K, EPI) >= 0
+    a = g((M, K), 60).cuda()
+    w = g(((2 * N if epi == "silu" else N), K), 61, 1.0 / math.sqrt(K)).cuda()
+    r = g((M, N), 62).cuda() if epi == "resid_bf16" else None
+    out = ops.gemm(a, w, EPI, resid=r)
+    old = ops.set_tuning("gemm_no_skinny", 1)
+    try:
+        other = ops.gemm(a, w, EPI, resid=r)
+    finally:
+        ops.set_tuning("gemm_no_skinny", old)
+    z = (a.double() @ w.double().t())
+    if epi == "silu":
+        gate, up = z[:, :N].to(BF16).double(), z[:, N:].to(BF16).double()
+        ref = (gate * torch.sigmoid(gate)).to(BF16).double() * up
+    elif epi == "resid_bf16":
+        ref = r.double() + z.to(BF16).double()
+    else:
+        ref = z
+    close(out, ref.to(BF16), rtol=2 ** -6, atol=2e-2)
+    close(out, other, rtol=2 ** -6, atol=2e-2)
+    assert (out == other).float().mean().item() > 0.99
+    for s_pin in (1, 2):                                        # the split pinned: one pass / two slices, same values up to summation order
+        if K % (s_pin * 64) == 0:
+            old = ops.set_tuning("gemm_skinny_s", s_pin)
+            try:
+                close(ops.gemm(a, w, EPI, resid=r), out, rtol=2 ** -6, atol=2e-2)
+            finally:
+                ops.set_tuning("gemm_skinny_s", old)
+
+
+@pytest.mark.parametrize("epi,M,N,K", [("resid_bf16", 129, 3072, 8192), ("silu", 40, 1024, 3072), ("none", 300, 9216, 3072)])
 def test_gemm_splitk_workspace_is_the_callers(ops, epi, M, N, K):
     """p3v_gemm never allocates: the split-K partials live in a workspace the caller sizes with p3v_gemm_ws_bytes.  With the
     workspace the call is capturable in a hipGraph (replay == eager, bit for bit); without one the same shape runs on the
