@@ -169,6 +169,14 @@ int p3v_rope_kv_append(const uint16_t* qkv, const float* cos_t, const float* sin
                        int past, const int32_t* d_past, int dst_t, int dst_off_is_past,
                        int tab_t, int tab_div, float q_scale, void* stream);
 
+/* ---- a residual projection whose consumer is an RMSNorm, as one launch sequence (round 5; phi.py:478-484: `r + o_proj(...)` followed
+ *      by `post_attention_layernorm`, `r + down_proj(...)` followed by the next layer's `input_layernorm`):
+ *      p3v_gemm_resid_norm(g, w, eps, normed) == p3v_gemm(g) with P3V_EPI_RESID_BF16 + p3v_rmsnorm(g->out, w, normed, M, N, eps), bit
+ *      for bit, where the projection runs as K slices (17 .. 256 rows and N small enough that the split pays: the fp32 partials are
+ *      summed, the residual added, the row normalised by the SAME launch).  P3V_ERR_UNSUPPORTED -- nothing launched, the caller runs the
+ *      two calls -- for every other shape, without a workspace of p3v_gemm_ws_bytes(), or N > 3072.  normed: bf16 [M, N] contiguous. */
+int p3v_gemm_resid_norm(const p3v_gemm_args_t* gemm /* host */, const uint16_t* norm_w, float eps, uint16_t* normed, void* stream);
+
 /* ---- the qkv projection with the split, the rotation and the KV append in its EPILOGUE (round 5):
  *      p3v_gemm_qkv(g, s) == p3v_gemm(g) into a scratch [M, N] + p3v_rope_kv_append(scratch, ...) with s's arguments, bit for bit, in the
  *      GEMM's launches alone (phi.py:437-452 / 140-147: `qkv_proj` + `split` + `_rotate_half` + KVCache append; CLIP: q/k/v projections

@@ -104,6 +104,7 @@ SIGNATURES = {
     "p3v_kv_quantize": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "p3v_kv_dequantize": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "p3v_gemm_qkv": (i32, [vp, vp, vp]),
+    "p3v_gemm_resid_norm": (i32, [C.POINTER(GemmArgs), vp, f32, vp, vp]),
     "p3v_kv_quantize_mlx4": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "p3v_attention_decode_q8": (i32, [C.POINTER(AttnDecQ8Args), vp]),
     "p3v_attention_decode_q8_can_fuse_oproj": (i32, [i32, i32, i32, i32, i32, i32, i32, i32]),

@@ -391,6 +391,61 @@ __global__ void __launch_bounds__(256) k_splitk_reduce(const float* __restrict__
   store8_bf16((bf16_t*)out + o, v);
 }
 
+// The reduction of a split whose consumer is an RMSNorm (o_proj / down_proj of a short prompt): adds the S partials in slice order,
+// out = resid + bf16(sum) exactly as k_splitk_reduce<P3V_EPI_RESID_BF16>, and writes RMSNorm(out) beside it with k_rmsnorm_r's
+// arithmetic (one wave per row, the lane's 6 chunks of 8 columns in registers, the same summation order) -- the residual stream and
+// the next projection's input from ONE launch instead of two.
+__global__ void __launch_bounds__(256) k_splitk_reduce_norm(const float* __restrict__ part, bf16_t* __restrict__ out, const bf16_t* __restrict__ resid,
+                                                            const u32x4_t* __restrict__ norm_w, u32x4_t* __restrict__ normed, int M, int N,
+                                                            int ldo, int S, float inv_h, float eps) {
+  constexpr int CH = 6;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63, chunks = N / 8;
+  if (row >= M) return;
+  u32x4_t v[CH], g[CH];
+#pragma unroll
+  for (int i = 0; i < CH; ++i) {
+    const int c = i * 64 + lane;
+    v[i] = g[i] = (u32x4_t){0u, 0u, 0u, 0u};
+    if (c < chunks) {
+      float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      for (int z = 0; z < S; ++z) {
+        const float* pr = part + ((size_t)z * M + row) * N + c * 8;
+        const float4 a0 = *(const float4*)pr, a1 = *(const float4*)(pr + 4);
+        acc[0] += a0.x; acc[1] += a0.y; acc[2] += a0.z; acc[3] += a0.w; acc[4] += a1.x; acc[5] += a1.y; acc[6] += a1.z; acc[7] += a1.w;
+      }
+      const size_t o = (size_t)row * ldo + c * 8;
+      float r[8];
+      load8_bf16(resid + o, r);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] = r[e] + bf16_round(acc[e]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[i][j] = pack_bf16x2(acc[2 * j], acc[2 * j + 1]);
+      *(u32x4_t*)(out + o) = v[i];
+      g[i] = norm_w[c];
+    }
+  }
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < CH; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float a = bf16lo(v[i][j]), b = bf16hi(v[i][j]);
+      ss += a * a + b * b;
+    }
+  const float r = rsqrtf(wave_sum(ss) * inv_h + eps);
+  u32x4_t* yr = normed + (size_t)row * chunks;
+#pragma unroll
+  for (int i = 0; i < CH; ++i) {
+    const int c = i * 64 + lane;
+    if (c < chunks) {
+      u32x4_t o4;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o4[j] = rms_pair(v[i][j], r, g[i][j]);
+      yr[c] = o4;
+    }
+  }
+}
+
 // number of K slices for a shape (1 = not a split-K shape)
 static int splitk_slices(int M, int N, int K, int epilogue) {
   const P3vTuning& t = p3v_tuning();
@@ -415,6 +470,25 @@ extern "C" int64_t p3v_gemm_ws_bytes(int M, int N, int K, int epilogue) {
   const int S = sk ? sk : splitk_slices(M, N, K, epilogue);
   if (S == 1) return 0;
   return (int64_t)S * M * (epilogue == P3V_EPI_SILU_MUL ? 2 * N : N) * 4;
+}
+
+// ---- out = resid + bf16(A W^T) and normed = RMSNorm(out) (include/p3v.h): only where the projection runs as K slices anyway
+int p3v_gemm_skinny_partials(const p3v_gemm_args_t* a, int* S_out, hipStream_t s);   // p3v_gemm_skinny.hip
+extern "C" int p3v_gemm_resid_norm(const p3v_gemm_args_t* a, const uint16_t* norm_w, float eps, uint16_t* normed, void* stream) {
+  if (!a || !a->A || !a->W || !a->out || !a->resid || !norm_w || !normed) return P3V_ERR_ARG;
+  if (a->epilogue != P3V_EPI_RESID_BF16 || a->M <= 0 || a->N <= 0 || a->K <= 0 || a->K % BK || a->N % 8 || a->ldo % 8 || a->ldo < a->N) return P3V_ERR_ARG;
+  if (a->lda < a->K || a->ldw < a->K || a->lda % 8 || a->ldw % 8) return P3V_ERR_ARG;
+  if (((uintptr_t)a->A | (uintptr_t)a->W | (uintptr_t)a->out | (uintptr_t)a->resid | (uintptr_t)norm_w | (uintptr_t)normed | (uintptr_t)a->ws) & 15)
+    return P3V_ERR_ARG;
+  if (a->N > 6 * 64 * 8 || a->bias || (size_t)a->N * a->ldw * 2 >= (1ull << 32)) return P3V_ERR_UNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream;
+  int S = 0;
+  const int rc = p3v_gemm_skinny_partials(a, &S, s);           // P3V_ERR_UNSUPPORTED (nothing launched) unless the shape splits
+  if (rc != P3V_OK) return rc;
+  hipLaunchKernelGGL(k_splitk_reduce_norm, dim3(p3v_cdiv(a->M, 4)), dim3(256), 0, s, (const float*)a->ws, (bf16_t*)a->out, (const bf16_t*)a->resid,
+                     (const u32x4_t*)norm_w, (u32x4_t*)normed, a->M, a->N, a->ldo, S, 1.0f / (float)a->N, eps);
+  P3V_CHECK_LAUNCH();
+  return P3V_OK;
 }
 
 // the second launch of a split: adds the S fp32 partials [S, M, W rows] in slice order and applies the epilogue

@@ -280,20 +280,31 @@ static int launch_skinny(const SkinnyP& p, int S, hipStream_t s) {
 
 int p3v_splitk_reduce(const float* part, const p3v_gemm_args_t* a, int S, hipStream_t s);   // p3v_gemm.hip
 
+// the K-slice launch alone (fp32 partials into a->ws; *S_out slices): P3V_ERR_UNSUPPORTED, nothing launched, unless the shape is
+// one this kernel splits and the workspace holds the partials
+int p3v_gemm_skinny_partials(const p3v_gemm_args_t* a, int* S_out, hipStream_t s) {
+  const int S = p3v_gemm_skinny_slices(a->M, a->N, a->K, a->epilogue);
+  const bool silu = a->epilogue == P3V_EPI_SILU_MUL;
+  const int w_rows = silu ? 2 * a->N : a->N;
+  if (S <= 1 || !a->ws || a->ws_bytes < (int64_t)S * a->M * w_rows * 4) return P3V_ERR_UNSUPPORTED;
+  if ((uintptr_t)a->ws & 15) return P3V_ERR_ARG;
+  *S_out = S;
+  const SkinnyP p = {a->A, a->W, a->ws, a->resid, a->M, a->N, a->K, a->lda, a->ldw, a->ldo, a->K / S};
+  if (silu) return launch_skinny<P3V_EPI_SILU_MUL>(p, S, s);
+  if (a->epilogue == P3V_EPI_RESID_BF16) return launch_skinny<P3V_EPI_RESID_BF16>(p, S, s);
+  return launch_skinny<P3V_EPI_NONE>(p, S, s);
+}
+
 // P3V_ERR_UNSUPPORTED: not a shape for this kernel (the caller goes on to the other GEMM paths).  A split that finds no workspace of
 // p3v_gemm_ws_bytes() runs as one pass.
 int p3v_gemm_skinny_try(const p3v_gemm_args_t* a, hipStream_t s) {
-  int S = p3v_gemm_skinny_slices(a->M, a->N, a->K, a->epilogue);
-  if (S == 0) return P3V_ERR_UNSUPPORTED;
-  const bool silu = a->epilogue == P3V_EPI_SILU_MUL;
-  const int w_rows = silu ? 2 * a->N : a->N;
-  if (S > 1 && (!a->ws || a->ws_bytes < (int64_t)S * a->M * w_rows * 4)) S = 1;
-  if (S > 1 && ((uintptr_t)a->ws & 15)) return P3V_ERR_ARG;
-  SkinnyP p = {a->A, a->W, S > 1 ? a->ws : a->out, a->resid, a->M, a->N, a->K, a->lda, a->ldw, a->ldo, S > 1 ? a->K / S : 0};
-  int rc;
-  if (silu) rc = launch_skinny<P3V_EPI_SILU_MUL>(p, S, s);
-  else if (a->epilogue == P3V_EPI_RESID_BF16) rc = launch_skinny<P3V_EPI_RESID_BF16>(p, S, s);
-  else rc = launch_skinny<P3V_EPI_NONE>(p, S, s);
-  if (rc != P3V_OK || S == 1) return rc;
-  return p3v_splitk_reduce((const float*)a->ws, a, S, s);
+  if (p3v_gemm_skinny_slices(a->M, a->N, a->K, a->epilogue) == 0) return P3V_ERR_UNSUPPORTED;
+  int S = 1;
+  const int rc = p3v_gemm_skinny_partials(a, &S, s);
+  if (rc == P3V_OK) return p3v_splitk_reduce((const float*)a->ws, a, S, s);
+  if (rc != P3V_ERR_UNSUPPORTED) return rc;
+  const SkinnyP p = {a->A, a->W, a->out, a->resid, a->M, a->N, a->K, a->lda, a->ldw, a->ldo, 0};
+  if (a->epilogue == P3V_EPI_SILU_MUL) return launch_skinny<P3V_EPI_SILU_MUL>(p, 1, s);
+  if (a->epilogue == P3V_EPI_RESID_BF16) return launch_skinny<P3V_EPI_RESID_BF16>(p, 1, s);
+  return launch_skinny<P3V_EPI_NONE>(p, 1, s);
 }

@@ -257,6 +257,15 @@ class Phi3VModel:
             x = ops.rmsnorm(x, norm_w, eps, out=h)
         return ops.gemm(x, w, epilogue, resid=resid, out=out)
 
+    def _proj_resid_norm(self, o, key, x, norm_w, h):
+        """x += bf16(o @ W^T) and h = RMSNorm(x) * norm_w from the projection's own launches (ops.gemm_resid_norm); False -- nothing
+        done -- where that does not apply (adapters, quantised weights, shapes the library does not run as K slices)."""
+        M = o.shape[0]
+        if (key in self.adapters or key not in self.w or M <= ops.GEMV_MAX_M or h.shape[0] < M
+                or os.environ.get("P3V_RESID_NORM_FUSE", "1") == "0"):
+            return False
+        return ops.gemm_resid_norm(o, self.w[key], x, norm_w, self.cfg.rms_norm_eps, h[:M], out=x)
+
     # ------------------------------------------------------------------ vision tower
     def _prep_vision(self):
         c = self.cfg.clip
@@ -545,6 +554,7 @@ class Phi3VModel:
             Lp = (L + 7) // 8 * 8
             k_new = torch.empty((B, nkv, Lp, hd), dtype=BF16, device=self.device)
             v_new = torch.zeros((B, nkv, hd, Lp), dtype=BF16, device=self.device)
+        normed_in = False                                       # `h` already holds the layer's normalised input
         for i in range(cfg.num_hidden_layers):
             p = f"model.layers.{i}."
             # Prompt-sized calls on bf16 weights: the qkv projection writes rotated Q, the K cache rows and the V^T cache columns from
@@ -559,7 +569,10 @@ class Phi3VModel:
                     fused_qkv = ops.gemm_qkv(hn, w[k_w], st.cos, st.sin, q, kd, vd, B, L, nh, nkv, hd, past, st.Tp, True, st.T, 1,
                                              q_scale=scale * ops.Q_PRESCALE)
             if not fused_qkv:
-                self._proj(x, p + "self_attn.qkv_proj.weight", norm_w=w[p + "input_layernorm.weight"], out=qkv, h=h)
+                if normed_in:                                   # `h` holds RMSNorm(x) already (the previous down_proj's reduction launch)
+                    self._proj(h, p + "self_attn.qkv_proj.weight", out=qkv)
+                else:
+                    self._proj(x, p + "self_attn.qkv_proj.weight", norm_w=w[p + "input_layernorm.weight"], out=qkv, h=h)
             if st.quantized:
                 if L <= ops.L.DECODE_MAX_L:
                     if d_past is not None:
@@ -621,10 +634,23 @@ class Phi3VModel:
                 o = o.view(B, L, -1)[:, -1].contiguous()
                 x = x.view(B, L, -1)[:, -1].contiguous()
                 a, h = a[:B], h[:B]
+            # Short prompts (17 .. 256 rows): o_proj and down_proj run as K slices, and the launch that adds the slices also writes the
+            # RMSNorm of the new residual stream into `h` -- the next projection's input (ops.gemm_resid_norm; bit-identical to the
+            # two launches it replaces).
+            normed = False
             if not (bufs.get("fuse_o", False) and L <= ops.L.DECODE_MAX_L and n_beam == 1):
-                self._proj(o, p + "self_attn.o_proj.weight", EPI_RESID_BF16, resid=x, out=x)
-            self._proj(x, p + "mlp.gate_up_proj.weight", EPI_SILU_MUL, norm_w=w[p + "post_attention_layernorm.weight"], out=a, h=h)
-            self._proj(a, p + "mlp.down_proj.weight", EPI_RESID_BF16, resid=x, out=x)
+                normed = self._proj_resid_norm(o, p + "self_attn.o_proj.weight", x, w[p + "post_attention_layernorm.weight"], h)
+                if not normed:
+                    self._proj(o, p + "self_attn.o_proj.weight", EPI_RESID_BF16, resid=x, out=x)
+            if normed:
+                self._proj(h, p + "mlp.gate_up_proj.weight", EPI_SILU_MUL, out=a)
+            else:
+                self._proj(x, p + "mlp.gate_up_proj.weight", EPI_SILU_MUL, norm_w=w[p + "post_attention_layernorm.weight"], out=a, h=h)
+            normed_in = False
+            if i + 1 < cfg.num_hidden_layers:
+                normed_in = self._proj_resid_norm(a, p + "mlp.down_proj.weight", x, w[f"model.layers.{i + 1}.input_layernorm.weight"], h)
+            if not normed_in:
+                self._proj(a, p + "mlp.down_proj.weight", EPI_RESID_BF16, resid=x, out=x)
             if self.hidden_hook is not None:                     # diagnostics only (tools/precision_decomp.py); never set
                 self.hidden_hook(i, x, B, x.shape[0] // B)       # while a decode graph is captured
         if mlx4_first:

@@ -131,6 +131,30 @@ def gemm(a, w, epilogue=EPI_NONE, bias=None, resid=None, out=None, n_out=None, p
     return out
 
 
+def gemm_resid_norm(a, w, resid, norm_w, eps, normed, out=None):
+    """out = resid + bf16(a @ w^T) and normed = RMSNorm(out) * norm_w from the projection's own launch sequence (the K-slice GEMM +
+    ONE reduction launch that also normalises).  Returns False, nothing launched, where the library does not split the shape
+    (P3V_ERR_UNSUPPORTED): the caller runs gemm(..., EPI_RESID_BF16) and rmsnorm."""
+    _chk(a, BF16, "a"), _chk(w, BF16, "w"), _chk(resid, BF16, "resid"), _chk(norm_w, BF16, "norm_w"), _chk(normed, BF16, "normed")
+    M, K = a.shape
+    N = w.shape[0]
+    if w.shape[1] != K or resid.shape != (M, N) or normed.shape != (M, N) or norm_w.numel() != N:
+        raise ValueError(f"gemm_resid_norm: shapes {a.shape} x {w.shape}, resid {resid.shape}, normed {normed.shape}")
+    if out is None:
+        out = torch.empty((M, N), dtype=BF16, device=a.device)
+    ws_bytes = L.lib().p3v_gemm_ws_bytes(M, N, K, EPI_RESID_BF16)
+    if not ws_bytes:
+        return False
+    ws = _gemm_workspace(a.device, ws_bytes)
+    args = L.GemmArgs(_p(a), _p(w), _p(out), None, _p(resid), None, M, N, K, a.stride(0), w.stride(0), out.stride(0), EPI_RESID_BF16, 0,
+                      _p(ws), ws.numel())
+    rc = L.lib().p3v_gemm_resid_norm(C.byref(args), _p(norm_w), float(eps), _p(normed), _stream())
+    if rc == L.ERR_UNSUPPORTED:
+        return False
+    L.check(rc, "gemm_resid_norm")
+    return True
+
+
 GEMV_MAX_M = 16
 
 

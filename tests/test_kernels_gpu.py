@@ -210,6 +210,28 @@ def test_gemm_skinny_rows(ops, epi, M, N, K):
                 ops.set_tuning("gemm_skinny_s", old)
 
 
+@pytest.mark.parametrize("M,N,K", [(128, 3072, 3072), (100, 3072, 8192), (17, 3072, 3072), (250, 192, 768), (129, 1024, 1024)])
+def test_gemm_resid_norm_is_the_two_calls(ops, M, N, K):
+    """p3v_gemm_resid_norm == p3v_gemm(P3V_EPI_RESID_BF16) + p3v_rmsnorm, bit for bit, from the projection's own launches (the K-slice
+    GEMM + one reduction that also normalises); shapes the library does not split report "unsupported" and launch nothing."""
+    a, w = g((M, K), 70).cuda(), g((N, K), 71, 1.0 / math.sqrt(K)).cuda()
+    r, nw = g((M, N), 72).cuda(), (g((N,), 73, 0.1) + 1).cuda()
+    two = ops.gemm(a, w, ops.EPI_RESID_BF16, resid=r)
+    two_n = ops.rmsnorm(two, nw, 1e-5)
+    out, normed = torch.full_like(two, 7.0), torch.full_like(two, 7.0)
+    assert ops.gemm_resid_norm(a, w, r, nw, 1e-5, normed, out=out)
+    assert torch.equal(out, two) and torch.equal(normed, two_n)
+    x = r.clone()                                               # in place on the residual stream, as the decoder layer calls it
+    assert ops.gemm_resid_norm(a, w, x, nw, 1e-5, normed, out=x)
+    assert torch.equal(x, two) and torch.equal(normed, two_n)
+    # not a split shape (too many rows; a wide N that runs in one pass): nothing is launched
+    big = g((300, K), 74).cuda()
+    sentinel = torch.full((300, N), 7.0, dtype=BF16, device="cuda")
+    assert not ops.gemm_resid_norm(big, w, g((300, N), 75).cuda(), nw, 1e-5, sentinel.clone(), out=sentinel)
+    torch.cuda.synchronize()
+    assert bool((sentinel == 7.0).all())
+
+
 @pytest.mark.parametrize("epi,M,N,K", [("resid_bf16", 129, 3072, 8192), ("silu", 40, 1024, 3072), ("none", 300, 9216, 3072)])
 def test_gemm_splitk_workspace_is_the_callers(ops, epi, M, N, K):
     """p3v_gemm never allocates: the split-K partials live in a workspace the caller sizes with p3v_gemm_ws_bytes.  With the

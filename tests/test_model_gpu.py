@@ -120,6 +120,24 @@ def test_graph_replayed_greedy_step_equals_eager(text):
         assert torch.equal(hist, torch.cat(eager_tok, dim=1).to(hist.dtype))
 
 
+def test_short_prompt_resid_norm_fusion_changes_nothing(monkeypatch):
+    """A 128-token prompt runs o_proj / down_proj as K slices whose reduction launch also writes the next RMSNorm
+    (model._proj_resid_norm): logits and cache equal the unfused launches bit for bit."""
+    from phi_3_vision_mlx_amd.api import load_synthetic
+    model, _ = load_synthetic(blind_model=True, tiny=False, seed=0, device="cuda:0", num_hidden_layers=3)
+    ids = torch.randint(3, 32000, (1, 128), dtype=torch.int64, generator=torch.Generator().manual_seed(5))
+    monkeypatch.setenv("P3V_PREFILL_GRAPH", "0")
+    outs = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("P3V_RESID_NORM_FUSE", flag)
+        logits, cache = model(input_ids=ids, max_tokens=4)
+        st = cache[0].state
+        outs.append((logits.clone(), st.k[:, :, :, :128].clone(), st.v[:, :, :, :, :128].clone()))
+    assert all(torch.equal(a, b) for a, b in zip(*outs))
+    del model
+    torch.cuda.empty_cache()
+
+
 def test_captured_short_prompt_prefill_equals_eager(text, monkeypatch):
     """Round 5: a text prompt whose (length, max_tokens) was seen before is prefilled by ONE hipGraph over buffers the entry owns
     (model._prefill_captured).  Same kernels in the same order: logits, cache contents and the greedy continuation are bit-identical to
