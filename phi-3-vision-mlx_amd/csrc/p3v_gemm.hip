@@ -392,57 +392,60 @@ __global__ void __launch_bounds__(256) k_splitk_reduce(const float* __restrict__
 }
 
 // The reduction of a split whose consumer is an RMSNorm (o_proj / down_proj of a short prompt): adds the S partials in slice order,
-// out = resid + bf16(sum) exactly as k_splitk_reduce<P3V_EPI_RESID_BF16>, and writes RMSNorm(out) beside it with k_rmsnorm_r's
-// arithmetic (one wave per row, the lane's 6 chunks of 8 columns in registers, the same summation order) -- the residual stream and
-// the next projection's input from ONE launch instead of two.
-__global__ void __launch_bounds__(256) k_splitk_reduce_norm(const float* __restrict__ part, bf16_t* __restrict__ out, const bf16_t* __restrict__ resid,
+// out = resid + bf16(sum) exactly as k_splitk_reduce<P3V_EPI_RESID_BF16>, and writes RMSNorm(out) beside it -- the residual stream
+// and the next projection's input from ONE launch instead of two.  A workgroup per row, a thread per 8 columns (every load of the
+// launch in flight at once: with k_rmsnorm_r's one wave per row, 128 rows keep 128 waves busy and the launch takes longer than the
+// two it replaces).  The sum of squares is k_rmsnorm_r's, bit for bit: that kernel's lane l adds p = lo*lo + fl(hi*hi) of its chunks
+// l, l + 64, ... one pair at a time; here every thread computes the four p of ITS chunk, and wave 0 adds them in that order.
+__global__ void __launch_bounds__(384) k_splitk_reduce_norm(const float* __restrict__ part, bf16_t* __restrict__ out, const bf16_t* __restrict__ resid,
                                                             const u32x4_t* __restrict__ norm_w, u32x4_t* __restrict__ normed, int M, int N,
                                                             int ldo, int S, float inv_h, float eps) {
-  constexpr int CH = 6;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63, chunks = N / 8;
-  if (row >= M) return;
-  u32x4_t v[CH], g[CH];
-#pragma unroll
-  for (int i = 0; i < CH; ++i) {
-    const int c = i * 64 + lane;
-    v[i] = g[i] = (u32x4_t){0u, 0u, 0u, 0u};
-    if (c < chunks) {
-      float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-      for (int z = 0; z < S; ++z) {
-        const float* pr = part + ((size_t)z * M + row) * N + c * 8;
-        const float4 a0 = *(const float4*)pr, a1 = *(const float4*)(pr + 4);
-        acc[0] += a0.x; acc[1] += a0.y; acc[2] += a0.z; acc[3] += a0.w; acc[4] += a1.x; acc[5] += a1.y; acc[6] += a1.z; acc[7] += a1.w;
-      }
-      const size_t o = (size_t)row * ldo + c * 8;
-      float r[8];
-      load8_bf16(resid + o, r);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) acc[e] = r[e] + bf16_round(acc[e]);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) v[i][j] = pack_bf16x2(acc[2 * j], acc[2 * j + 1]);
-      *(u32x4_t*)(out + o) = v[i];
-      g[i] = norm_w[c];
+  __shared__ float ps[6 * 4][64];
+  __shared__ float r_sh;
+  const int row = blockIdx.x, c = threadIdx.x, lane = c & 63, wv = c >> 6, chunks = N / 8;
+  u32x4_t v = {0u, 0u, 0u, 0u}, g = {0u, 0u, 0u, 0u};
+  if (c < chunks) {
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int z = 0; z < S; ++z) {
+      const float* pr = part + ((size_t)z * M + row) * N + c * 8;
+      const float4 a0 = *(const float4*)pr, a1 = *(const float4*)(pr + 4);
+      acc[0] += a0.x; acc[1] += a0.y; acc[2] += a0.z; acc[3] += a0.w; acc[4] += a1.x; acc[5] += a1.y; acc[6] += a1.z; acc[7] += a1.w;
     }
+    const size_t o = (size_t)row * ldo + c * 8;
+    float r[8];
+    load8_bf16(resid + o, r);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = r[e] + bf16_round(acc[e]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = pack_bf16x2(acc[2 * j], acc[2 * j + 1]);
+    *(u32x4_t*)(out + o) = v;
+    g = norm_w[c];
   }
-  float ss = 0.f;
 #pragma unroll
-  for (int i = 0; i < CH; ++i)
+  for (int j = 0; j < 4; ++j) {
+    const float lo = bf16lo(v[j]), hi = bf16hi(v[j]);
+    float hh = hi * hi;
+    asm volatile("" : "+v"(hh));                                // (one rounding of hi*hi, then ONE fma: k_rmsnorm_r's compiled form)
+    ps[wv * 4 + j][lane] = __builtin_fmaf(lo, lo, hh);
+  }
+  __syncthreads();
+  if (wv == 0) {
+    float ss = ps[0][lane];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const float a = bf16lo(v[i][j]), b = bf16hi(v[i][j]);
-      ss += a * a + b * b;
+    for (int k = 1; k < 24; ++k) {
+      ss += ps[k][lane];
+      asm volatile("" : "+v"(ss));
     }
-  const float r = rsqrtf(wave_sum(ss) * inv_h + eps);
-  u32x4_t* yr = normed + (size_t)row * chunks;
+    const float r = rsqrtf(wave_sum(ss) * inv_h + eps);
+    if (lane == 0) r_sh = r;
+  }
+  __syncthreads();
+  if (c < chunks) {
+    const float r = r_sh;
+    u32x4_t o4;
 #pragma unroll
-  for (int i = 0; i < CH; ++i) {
-    const int c = i * 64 + lane;
-    if (c < chunks) {
-      u32x4_t o4;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) o4[j] = rms_pair(v[i][j], r, g[i][j]);
-      yr[c] = o4;
-    }
+    for (int j = 0; j < 4; ++j) o4[j] = rms_pair(v[j], r, g[j]);
+    normed[(size_t)row * chunks + c] = o4;
   }
 }
 
@@ -485,7 +488,7 @@ extern "C" int p3v_gemm_resid_norm(const p3v_gemm_args_t* a, const uint16_t* nor
   int S = 0;
   const int rc = p3v_gemm_skinny_partials(a, &S, s);           // P3V_ERR_UNSUPPORTED (nothing launched) unless the shape splits
   if (rc != P3V_OK) return rc;
-  hipLaunchKernelGGL(k_splitk_reduce_norm, dim3(p3v_cdiv(a->M, 4)), dim3(256), 0, s, (const float*)a->ws, (bf16_t*)a->out, (const bf16_t*)a->resid,
+  hipLaunchKernelGGL(k_splitk_reduce_norm, dim3(a->M), dim3(384), 0, s, (const float*)a->ws, (bf16_t*)a->out, (const bf16_t*)a->resid,
                      (const u32x4_t*)norm_w, (u32x4_t*)normed, a->M, a->N, a->ldo, S, 1.0f / (float)a->N, eps);
   P3V_CHECK_LAUNCH();
   return P3V_OK;
