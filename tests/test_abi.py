@@ -24,7 +24,7 @@ def test_header_symbols_are_exported_and_bound():
     for s in syms:
         assert hasattr(lib, s), f"{s} declared in include/p3v.h but not exported by libp3v.so"
     assert sorted(_lib.SIGNATURES) == syms, set(_lib.SIGNATURES) ^ set(syms)
-    assert _lib.lib().p3v_version() == 400
+    assert _lib.lib().p3v_version() == 500
     assert _lib.lib().p3v_strerror(-22).decode().startswith("invalid argument")
 
 
@@ -89,9 +89,11 @@ def test_tuning_table_and_gemm_workspace_size():
     assert l.p3v_set_tuning(b"no_such_knob", 1) == -22
     assert l.p3v_set_tuning(b"combine_g", 4) == 0 and l.p3v_get_tuning(b"combine_g", ctypes.byref(v)) == 0 and v.value == 4
     assert l.p3v_set_tuning(b"combine_g", -1) == 0
-    # split-K shapes (17 <= M <= 1024, < 256 tiles): S slices of fp32 [M, N or 2N]; none elsewhere
-    assert l.p3v_gemm_ws_bytes(128, 3072, 8192, _lib.EPI_RESID_BF16) == 8 * 128 * 3072 * 4
-    assert l.p3v_gemm_ws_bytes(128, 8192, 3072, _lib.EPI_SILU_MUL) == 2 * 128 * 16384 * 4
+    # K-slice shapes: S slices of fp32 [M, N or 2N]; none elsewhere.  17 .. 256 rows: the 128 x 64-tile kernel (one workgroup per CU:
+    # 48 tiles x 4 slices for down_proj, gate_up's 256 tiles in one pass); up to 1024 rows with < 256 tiles: the 128 x 128 kernel's split
+    assert l.p3v_gemm_ws_bytes(128, 3072, 8192, _lib.EPI_RESID_BF16) == 4 * 128 * 3072 * 4
+    assert l.p3v_gemm_ws_bytes(128, 8192, 3072, _lib.EPI_SILU_MUL) == 0
+    assert l.p3v_gemm_ws_bytes(300, 3072, 8192, _lib.EPI_RESID_BF16) == 4 * 300 * 3072 * 4
     assert l.p3v_gemm_ws_bytes(2531, 3072, 8192, _lib.EPI_RESID_BF16) == 0
     assert l.p3v_gemm_ws_bytes(16, 3072, 8192, _lib.EPI_NONE) == 0
     assert l.p3v_gemm_ws_bytes(128, 3072, 8192, _lib.EPI_BIAS) == 0
