@@ -1421,9 +1421,14 @@ __device__ __forceinline__ void split_merge(float* base0, bf16_t* out0, size_t o
       const float mn = fmaxf(m, ms);
       const float mu = mn == -INFINITY ? 0.f : mn;
       const float ca = __builtin_amdgcn_exp2f(m - mu), cb = __builtin_amdgcn_exp2f(ms - mu);
-      l = l * ca + ls * cb;
-      a0 = a0 * ca + o0 * cb;
-      a1 = a1 * ca + o1 * cb;
+      // one rounded product + one fma per accumulator, written out: this function is inlined into several kernels (merge only,
+      // merge + o_proj, int8 KV) whose results are compared bit for bit, and hipcc contracts `x * a + y * b` differently from one
+      // instantiation to the next (tools/stress_fused_oproj.py: one bf16 ulp in one word of ~4 % of random inputs)
+      float lb = ls * cb, b0 = o0 * cb, b1 = o1 * cb;
+      asm volatile("" : "+v"(lb), "+v"(b0), "+v"(b1));
+      l = __builtin_fmaf(l, ca, lb);
+      a0 = __builtin_fmaf(a0, ca, b0);
+      a1 = __builtin_fmaf(a1, ca, b1);
       m = mn;
     };
     constexpr int UB = 6;                                      // partials per load round: 4 * UB loads in flight per lane
@@ -1472,9 +1477,9 @@ __device__ __forceinline__ void split_merge(float* base0, bf16_t* out0, size_t o
 #pragma unroll
           for (int k = 0; k < G; ++k) {
             const float c = __builtin_amdgcn_exp2f(pm[k] - Mu);
-            acc0 += c * part[k][2 * t];
-            acc1 += c * part[k][2 * t + 1];
-            lsum += c * pl[k];
+            acc0 = __builtin_fmaf(c, part[k][2 * t], acc0);
+            acc1 = __builtin_fmaf(c, part[k][2 * t + 1], acc1);
+            lsum = __builtin_fmaf(c, pl[k], lsum);
           }
           const uint32_t wv = poison ? 0x7fc07fc0u : pack_bf16x2(lsum > 0.f ? acc0 / lsum : 0.f, lsum > 0.f ? acc1 / lsum : 0.f);
           __hip_atomic_store((uint32_t*)(out0 + (size_t)q * out_qstride) + t, wv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1489,8 +1494,8 @@ __device__ __forceinline__ void split_merge(float* base0, bf16_t* out0, size_t o
 #pragma unroll
         for (int k = 0; k < G; ++k) {
           const float c = __builtin_amdgcn_exp2f(pm[k] - Mu);
-          acc += c * part[k][t];
-          lsum += c * pl[k];
+          acc = __builtin_fmaf(c, part[k][t], acc);
+          lsum = __builtin_fmaf(c, pl[k], lsum);
         }
         out0[(size_t)q * out_qstride + t] = poison ? (bf16_t)0x7fc0 : f32_to_bf16(lsum > 0.f ? acc / lsum : 0.f);
       }
