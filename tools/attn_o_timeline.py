@@ -58,3 +58,17 @@ if fuse:
     print("means: partial stored -> canary %.2f | canary -> vector %.2f | vector -> stored %.2f" % (
         (pw[:, 12] - pw[:, 3]).mean(), (pw[:, 13] - pw[:, 12]).mean(), (pw[:, 14] - pw[:, 13]).mean()))
     print("last merger out stored %.2f ; last projecting workgroup done %.2f" % (us[:, merger, 5].max(), pw[:, 14].max()))
+# ---- round 5: where do the late workgroups lose their time?
+row("worker: loads issued (7)", work[:, :, 7]); row("worker: Q staged (8)", work[:, :, 8])
+d = work[:, :, 2] - work[:, :, 1]
+row("worker: landed -> PV done", d)
+late = work[:, :, 2] > np.percentile(work[:, :, 2], 90)
+print("late (p90+) PV-done workgroups: entry %.2f  loads issued %.2f  landed %.2f  PV %.2f ; the others: %.2f %.2f %.2f %.2f" % (
+    work[:, :, 0][late].mean(), work[:, :, 7][late].mean(), work[:, :, 1][late].mean(), work[:, :, 2][late].mean(),
+    work[:, :, 0][~late].mean(), work[:, :, 7][~late].mean(), work[:, :, 1][~late].mean(), work[:, :, 2][~late].mean()))
+print("late ones by split index (share of each split that is late):", np.round(late.mean(axis=0), 2).tolist())
+print("late ones by head (share):", np.round(late.mean(axis=1), 2).tolist())
+if fuse:
+    proj = (rank < H // 8)[:, :work.shape[1]]
+    print("PV done: projecting workgroups mean %.2f max %.2f ; non-projecting mean %.2f max %.2f" % (
+        work[:, :, 2][proj].mean(), work[:, :, 2][proj].max(), work[:, :, 2][~proj].mean(), work[:, :, 2][~proj].max()))
