@@ -20,7 +20,7 @@ random text tokens.  Prints ONE JSON line on rank 0.
 
 `value` is the REFERENCE-DEFINED rate: (gen_len - 1) / gen_time over the K timed steps through `_generate`'s own loop
 (per-token D2H copy = the reference's mx.eval, Streamer, TokenStopper, detokenisation; phi_3_vision_mlx.py:390-403);
-`device_rate` is the same K steps as back-to-back graph replays between two syncs (what the kernels sustain).
+`device_rate` is K further steps as back-to-back graph replays between two syncs (what the kernels sustain), run AFTER that loop.
 At N = 1 the line also carries `configs`: BASELINE configs[0], [2], [3] (one GPU's share) and [4] measured in the same
 process with the same definitions, each with its own roofline fractions (`--no-configs` skips them).
 """
@@ -193,19 +193,18 @@ def measure_request_set(model, processor, reqs, steps, warmup, prefill_reps, kv_
     for _ in range(warmup):
         _, token = model.greedy_step(token, cache)
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        _, token = model.greedy_step(token, cache)
-    torch.cuda.synchronize()
-    dev_s = (time.perf_counter() - t0) / steps
-    streamer, stopper = api.Streamer(processor, False, True), api.TokenStopper(processor, B)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
+    streamer, stopper = api.Streamer(processor, False, True), api.TokenStopper(processor, B)   # the reference-defined loop first,
+    t0 = time.perf_counter()                                                                     # the bare replays after it (as main())
     streamer(api._rows(token))
     token = api.greedy_loop(model, token, cache, steps, streamer, stopper)
     _, gen_len = streamer.end()
     torch.cuda.synchronize()
     gen_s = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        _, token = model.greedy_step(token, cache)
+    torch.cuda.synchronize()
+    dev_s = (time.perf_counter() - t0) / steps
     lens = [int(np.asarray(r["input_ids"]).shape[-1]) for r in reqs]
     valid = sum(lens)
     nbytes = decode_bytes(model, cfg, valid, B, warmup + steps // 2, kv_elt)
@@ -358,18 +357,9 @@ def main():
     prefill = float(np.median(prefill_ms))
     print("prefill reps ms:", [round(v, 1) for v in prefill_ms], file=sys.stderr)
 
-    # ---- decode: W untimed + K timed graph-replayed greedy steps (device rate: no host work between replays)
-    for _ in range(args.warmup):
-        logits, token = model.greedy_step(token, cache)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        logits, token = model.greedy_step(token, cache)
-    barrier()
-    elapsed = time.perf_counter() - t0
-
-    # ---- the same K steps through `_generate`'s own loop (reference phi_3_vision_mlx.py:390-400): one D2H copy of the
-    #      token per step (the reference's mx.eval), Streamer, TokenStopper, detokenisation in Streamer.end() inside the span
+    # ---- decode, the reference-defined rate FIRST (the K steps that follow the prefill, as phi_3_vision_mlx.py:390-403 times them):
+    #      W untimed steps, then K steps through `_generate`'s own loop -- the step's tokens read per step (the reference's mx.eval),
+    #      Streamer, TokenStopper, detokenisation in Streamer.end() inside the span
     streamer = api.Streamer(processor, False, True)
     stopper = api.TokenStopper(processor, B)
     for _ in range(args.warmup):
@@ -382,6 +372,16 @@ def main():
     barrier()
     gen_elapsed = time.perf_counter() - t0
     gen_tps = (gen_len - 1) / gen_elapsed
+
+    # ---- the same number of steps as bare graph replays (device rate: no host work between replays; K keys further into the cache)
+    for _ in range(args.warmup):
+        logits, token = model.greedy_step(token, cache)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        logits, token = model.greedy_step(token, cache)
+    barrier()
+    elapsed = time.perf_counter() - t0
     local_elapsed = elapsed                                        # this rank's own span (the reported one is the max over ranks)
     if world > 1:
         t = torch.tensor([elapsed, prefill, gen_elapsed], device="cpu" if share else dev)
@@ -484,7 +484,7 @@ def main():
                             "so the figure is (B * (K + 1) - 1) / gen_time -- slightly above the device rate B * K / time by construction "
                             "(phi_3_vision_mlx.py:77,401-403), not a faster step",
         "device_rate": {"tokens_per_s": round(tokens_per_s, 2), "ms_per_step": round(step_s * 1e3, 4),
-                        "definition": "the same K steps as back-to-back graph replays between two syncs (no per-token host work)"},
+                        "definition": "K further steps as back-to-back graph replays between two syncs (no per-token host work; run after the reference-defined loop, K keys deeper into the cache)"},
         "rccl": rccl,
         "dtype": "fp8(e4m3)+int8kv" if args.config5 else "bf16", "data": "synthetic",
         "config": {"workload": workload, "parallelism": f"batch-sharded replicas x{world}", "batch_per_gpu": int(B), "tiny": bool(args.tiny)},
