@@ -279,6 +279,7 @@ def main():
     share = bool(os.environ.get("P3V_BENCH_SHARE_GPU"))           # debug only: all ranks on GPU 0 over gloo (1-GPU boxes)
     if share:
         local = 0
+        os.environ.setdefault("P3V_SHARED_GPU", "1")               # several processes on one GPU: no launch that needs the whole chip resident
     elif torch.cuda.device_count() <= local:
         raise SystemExit(f"rank {rank}: needs GPU {local}, {torch.cuda.device_count()} visible (one rank per GPU)")
     torch.cuda.set_device(local)

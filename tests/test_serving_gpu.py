@@ -411,6 +411,33 @@ def test_bench_two_gpus_reports_its_rccl_ranks():
     assert len(line["rccl"]["per_rank_tokens_per_s"]) == 2 and min(line["rccl"]["per_rank_tokens_per_s"]) > 0
 
 
+def test_bench_two_ranks_sharing_one_gpu():
+    """The driver's multi-GPU command line (`python -m torch.distributed.run ... bench.py --gpus 2`) on a 1-GPU box: bench.py's debug
+    switch P3V_BENCH_SHARE_GPU puts both ranks on GPU 0 over gloo (and plans every launch for a shared GPU).  One JSON line from rank 0,
+    whole-job aggregate over both ranks, both ranks counted."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, P3V_BENCH_SHARE_GPU="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--tiny", "--steps", "8", "--warmup", "2",
+                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["rccl"]["ranks"] == 2 and line["rccl"]["backend"] == "gloo"
+    per_rank = line["rccl"]["per_rank_tokens_per_s"]
+    assert len(per_rank) == 2 and min(per_rank) > 0
+    assert line["value"] > 0 and line["steps"] == 8 and line["scaling"] == "weak"
+
+
 def _fleet_worker(rank, world, port, out_dir):
     import os
     import sys
