@@ -586,6 +586,7 @@ static int gemm128(const p3v_gemm_args_t* a, hipStream_t s) {
 
 // ---- the qkv projection with the head split, the rotation and the KV append in its epilogue (p3v_gemm_qkv.h)
 int p3v_gemm256_qkv(const p3v_gemm_args_t* a, const QkvP& q, hipStream_t s);   // p3v_gemm256.hip
+int p3v_gemm_skinny_qkv(const p3v_gemm_args_t* a, const QkvP& q, hipStream_t s);   // p3v_gemm_skinny.hip
 
 extern "C" int p3v_gemm_qkv(const p3v_gemm_args_t* a, const p3v_qkv_split_t* sp, void* stream) {
   if (!a || !sp || !a->A || !a->W || !sp->q_out || !sp->k_dst || !sp->v_dst || (!sp->cos_t) != (!sp->sin_t)) return P3V_ERR_ARG;
@@ -601,13 +602,13 @@ extern "C" int p3v_gemm_qkv(const p3v_gemm_args_t* a, const p3v_qkv_split_t* sp,
   // prompt-sized M; rotation pairs in blocks of 16 inside a head; whole 128-column tiles per region; 8-token runs of V^T stores
   // that neither straddle a batch row nor start off a 16-byte boundary
   const int dpos0 = sp->dst_off_is_past ? sp->past : 0;
-  if (a->M < 1024 || hd % 32 || half % 16 || (nh * hd) % BN || (nkv * hd) % BN || dpos0 % 8 || sp->dst_t % 8 || (sp->B > 1 && sp->L % 8) ||
-      p3v_tuning().gemm_128 || p3v_tuning().gemm_no_qkv_fuse)
-    return P3V_ERR_UNSUPPORTED;
+  if (hd % 32 || half % 16 || dpos0 % 8 || sp->dst_t % 8 || (sp->B > 1 && sp->L % 8) || p3v_tuning().gemm_no_qkv_fuse) return P3V_ERR_UNSUPPORTED;
   if ((size_t)a->M * a->lda * 2 >= (1ull << 32) || (size_t)a->N * a->ldw * 2 >= (1ull << 32)) return P3V_ERR_UNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
   QkvP q = {sp->cos_t, sp->sin_t, sp->q_out, sp->k_dst, sp->v_dst, sp->L, nh, nkv, hd, sp->past, dpos0, sp->dst_t, sp->tab_t, sp->tab_div, 0,
             sp->q_scale};
+  if (a->M < 1024) return p3v_gemm_skinny_qkv(a, q, s);       // 17 .. 256 rows: the weight-streaming kernel (or "unsupported")
+  if ((nh * hd) % BN || (nkv * hd) % BN || p3v_tuning().gemm_128) return P3V_ERR_UNSUPPORTED;
   p3v_gemm_args_t plain = *a;
   plain.epilogue = P3V_EPI_NONE;                                // (the row packing below prices the plain bf16 epilogue)
   int rows_big = (nh * hd) % 256 || (nkv * hd) % 256 ? 0 : gemm_big_rows(&plain);

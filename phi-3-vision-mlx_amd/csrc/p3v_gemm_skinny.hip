@@ -60,7 +60,10 @@ struct SkinnyP {
   const bf16_t* A; const bf16_t* W; void* out; const void* resid;
   int M, N, K, lda, ldw, ldo;      // N = output columns (SiLU: W holds 2N rows, gate rows then up rows)
   int kslice;                      // 0: one pass with the epilogue; else K columns per slice, fp32 partials
+  QkvP q;                          // P3V_EPI_QKV only (p3v_gemm_qkv.h): head split + rotation + KV append in the epilogue
 };
+
+#define P3V_EPI_QKV 100            // internal, as in the other GEMM kernels
 
 template <int EPI, bool PART, int TN>
 __global__ void __launch_bounds__(512, 1) k_gemm_skinny(SkinnyP p) {
@@ -70,9 +73,35 @@ __global__ void __launch_bounds__(512, 1) k_gemm_skinny(SkinnyP p) {
   static_assert(NS - 2 <= 4 && (NS - 2) * C::PER < 64, "sk_wait_stages covers 4 stages in flight");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  constexpr bool QKV = EPI == P3V_EPI_QKV;
+  static_assert(!QKV || (TN == 64 && !PART), "the qkv epilogue: 64-column tiles, one pass");
   constexpr int n_out_tile = SILU ? TN / 2 : TN;
-  const int n0 = blockIdx.x * n_out_tile, m0 = blockIdx.y * SK_BM, kz = blockIdx.z;
+  int n0 = blockIdx.x * n_out_tile, m0 = blockIdx.y * SK_BM;
+  const int kz = blockIdx.z;
   const int nk = (PART ? p.kslice : p.K) / SK_BK, kt0 = kz * nk;
+  // P3V_EPI_QKV (p3v_gemm_qkv.h), a one-dimensional grid: first the Q and K tiles (128 tokens x 32 rotation pairs, W rows fetched in
+  // pair order), M-tile-major; then the V tiles with the operand roles swapped (128 V dimensions on the tile's A side, 64 tokens on
+  // its B side), so that a lane ends up with consecutive TOKENS of one dimension for the transposed cache.
+  bool swapped = false, is_k = false;
+  int row0 = 0;
+  if (QKV) {
+    const int nq_t = p.q.nh * p.q.hd / 64, nk_t = p.q.nkv * p.q.hd / 64, nqk = nq_t + nk_t, mt = (p.M + SK_BM - 1) / SK_BM;
+    int t = blockIdx.x;
+    if (t < nqk * mt) {
+      const int n_t = t % nqk;
+      m0 = (t / nqk) * SK_BM;
+      is_k = n_t >= nq_t;
+      row0 = is_k ? p.q.nh * p.q.hd : 0;
+      n0 = (n_t - (is_k ? nq_t : 0)) * 64;                     // first column INSIDE the region
+    } else {
+      t -= nqk * mt;
+      const int nv_t = p.q.nkv * p.q.hd / SK_BM;
+      swapped = true;
+      row0 = (p.q.nh + p.q.nkv) * p.q.hd;
+      n0 = (t % nv_t) * SK_BM;                                 // first V dimension of the tile (its A side)
+      m0 = (t / nv_t) * 64;                                    // first token (its B side)
+    }
+  }
 
   if (wave >= 4) {
     // ---- PRODUCERS: wave pw stages 4 A pieces and WQ W pieces per K-tile, a piece = 8 tile rows x 128 B (1 KiB), the 16-byte
@@ -80,19 +109,31 @@ __global__ void __launch_bounds__(512, 1) k_gemm_skinny(SkinnyP p) {
     // SiLU: a 64-column group of the tile = gate rows (blocks 0, 1) and the up rows (blocks 2, 3) of the same 32 output columns.
     const int srow = lane >> 3, schunk = lane & 7, pw = wave - 4;
     unsigned a_src[4], w_src[4];                                 // (fixed sizes: see the note in stage())
-    const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, 0xffffffff, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, 0xffffffff, 0x00020000);
+    __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, 0xffffffff, 0x00020000);
+    __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, 0xffffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_x = rs_a;
+    if (QKV && swapped) { rs_a = rs_w; rs_w = rs_x; }           // the tile's A side reads W rows, its B side token rows
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int r = (pw * 4 + q) * 8 + srow;
-      const int ar = min(m0 + r, p.M - 1);
-      a_src[q] = (unsigned)(((size_t)ar * p.lda + ((schunk ^ (r & 7)) * 8)) * 2);
+      if (QKV && swapped) {
+        a_src[q] = (unsigned)(((size_t)(row0 + n0 + r) * p.ldw + ((schunk ^ (r & 7)) * 8)) * 2);
+      } else {
+        const int ar = min(m0 + r, p.M - 1);
+        a_src[q] = (unsigned)(((size_t)ar * p.lda + ((schunk ^ (r & 7)) * 8)) * 2);
+      }
     }
 #pragma unroll
     for (int q = 0; q < C::WQ; ++q) {
       const int r = (pw * C::WQ + q) * 8 + srow;
+      if (QKV && swapped) {
+        const int ar = min(m0 + r, p.M - 1);
+        w_src[q] = (unsigned)(((size_t)ar * p.lda + ((schunk ^ (r & 7)) * 8)) * 2);
+        continue;
+      }
       int br;
       if (SILU) br = min(n0 + (r >> 6) * 32 + ((r >> 4) & 1) * 16 + (r & 15), p.N - 1) + ((r >> 5) & 1) * p.N;
+      else if (QKV) br = qkv_pair_row(p.q, row0, n0 >> 1, r);
       else br = min(n0 + r, p.N - 1);
       w_src[q] = (unsigned)(((size_t)br * p.ldw + ((schunk ^ (r & 7)) * 8)) * 2);
     }
@@ -170,6 +211,11 @@ __global__ void __launch_bounds__(512, 1) k_gemm_skinny(SkinnyP p) {
 
   // ---- epilogue, straight from the accumulators: lane (fc = lane & 15, fq = lane >> 4) holds columns 4 fq .. 4 fq + 3 of block
   //      row fc (see p3v_gemm256_epi.h)
+  if constexpr (QKV) {
+    if (!swapped) qkv_epilogue_rot<NI>(p.q, acc, nullptr, is_k, row0, n0 >> 1, m0 + wr * NI * 16, p.M, lane);
+    else qkv_epilogue_vt<NI>(p.q, acc, nullptr, n0 + wr * NI * 16, m0, p.M, lane);
+    return;
+  }
   const int fc = lane & 15, fq = lane >> 4;
   const int mrow0 = m0 + wr * NI * 16 + fc;
   if constexpr (PART) {
@@ -289,7 +335,7 @@ int p3v_gemm_skinny_partials(const p3v_gemm_args_t* a, int* S_out, hipStream_t s
   if (S <= 1 || !a->ws || a->ws_bytes < (int64_t)S * a->M * w_rows * 4) return P3V_ERR_UNSUPPORTED;
   if ((uintptr_t)a->ws & 15) return P3V_ERR_ARG;
   *S_out = S;
-  const SkinnyP p = {a->A, a->W, a->ws, a->resid, a->M, a->N, a->K, a->lda, a->ldw, a->ldo, a->K / S};
+  const SkinnyP p = {a->A, a->W, a->ws, a->resid, a->M, a->N, a->K, a->lda, a->ldw, a->ldo, a->K / S, {}};
   if (silu) return launch_skinny<P3V_EPI_SILU_MUL>(p, S, s);
   if (a->epilogue == P3V_EPI_RESID_BF16) return launch_skinny<P3V_EPI_RESID_BF16>(p, S, s);
   return launch_skinny<P3V_EPI_NONE>(p, S, s);
@@ -303,8 +349,28 @@ int p3v_gemm_skinny_try(const p3v_gemm_args_t* a, hipStream_t s) {
   const int rc = p3v_gemm_skinny_partials(a, &S, s);
   if (rc == P3V_OK) return p3v_splitk_reduce((const float*)a->ws, a, S, s);
   if (rc != P3V_ERR_UNSUPPORTED) return rc;
-  const SkinnyP p = {a->A, a->W, a->out, a->resid, a->M, a->N, a->K, a->lda, a->ldw, a->ldo, 0};
+  const SkinnyP p = {a->A, a->W, a->out, a->resid, a->M, a->N, a->K, a->lda, a->ldw, a->ldo, 0, {}};
   if (a->epilogue == P3V_EPI_SILU_MUL) return launch_skinny<P3V_EPI_SILU_MUL>(p, 1, s);
   if (a->epilogue == P3V_EPI_RESID_BF16) return launch_skinny<P3V_EPI_RESID_BF16>(p, 1, s);
   return launch_skinny<P3V_EPI_NONE>(p, 1, s);
+}
+
+// ---- the qkv projection of a short prompt with the head split, the rotation and the KV append in the epilogue (p3v_gemm_qkv's
+// 17 .. 256-row case): one pass (the epilogue needs whole sums), Q / K tiles + V tiles in a one-dimensional grid.
+// P3V_ERR_UNSUPPORTED (nothing launched) where the shape is not this kernel's.
+int p3v_gemm_skinny_qkv(const p3v_gemm_args_t* a, const QkvP& q, hipStream_t s) {
+  const P3vTuning& t = p3v_tuning();
+  if (t.gemm_no_skinny || a->M <= 16 || a->M > t.gemm_skinny_max_m || a->K % SK_BK || a->bias) return P3V_ERR_UNSUPPORTED;
+  if ((q.nh * q.hd) % 64 || (q.nkv * q.hd) % SK_BM) return P3V_ERR_UNSUPPORTED;   // whole Q / K tiles of 32 pairs, whole V tiles of 128 dims
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)k_gemm_skinny<P3V_EPI_QKV, false, SK_TN>, hipFuncAttributeMaxDynamicSharedMemorySize, SkCfg<SK_TN>::LDS) != hipSuccess)
+      return P3V_ERR_HIP;
+    attr_set = true;
+  }
+  const SkinnyP p = {a->A, a->W, nullptr, nullptr, a->M, a->N, a->K, a->lda, a->ldw, 0, 0, q};
+  const int mt = p3v_cdiv(a->M, SK_BM), tiles = ((q.nh + q.nkv) * q.hd / 64) * mt + (q.nkv * q.hd / SK_BM) * p3v_cdiv(a->M, 64);
+  hipLaunchKernelGGL((k_gemm_skinny<P3V_EPI_QKV, false, SK_TN>), dim3(tiles), dim3(512), SkCfg<SK_TN>::LDS, s, p);
+  P3V_CHECK_LAUNCH();
+  return P3V_OK;
 }

@@ -561,11 +561,12 @@ class Phi3VModel:
             # its own epilogue (ops.gemm_qkv: bit-identical to the projection + rope_kv_append, one launch sequence instead of two).
             fused_qkv = False
             k_w = p + "self_attn.qkv_proj.weight"
-            if (L > ops.L.DECODE_MAX_L and n_beam == 1 and k_w in w and k_w not in self.adapters and M >= 1024 and not mlx4_first
-                    and os.environ.get("P3V_QKV_FUSE", "1") != "0"):
+            if (L > ops.L.DECODE_MAX_L and n_beam == 1 and k_w in w and k_w not in self.adapters and not mlx4_first
+                    and (M >= 1024 or M <= 256) and os.environ.get("P3V_QKV_FUSE", "1") != "0"):
                 kd, vd = (st.k_tmp, st.v_tmp) if st.quantized else (st.k[i], st.v[i])
                 if not (st.quantized and past > 0 and not getattr(st, "fresh_rows", False)):
-                    hn = ops.rmsnorm(x, w[p + "input_layernorm.weight"], eps, out=h)
+                    hn = h if normed_in else ops.rmsnorm(x, w[p + "input_layernorm.weight"], eps, out=h)
+                    normed_in = True                            # (`h` holds the normalised input now, whatever the fused call answers)
                     fused_qkv = ops.gemm_qkv(hn, w[k_w], st.cos, st.sin, q, kd, vd, B, L, nh, nkv, hd, past, st.Tp, True, st.T, 1,
                                              q_scale=scale * ops.Q_PRESCALE)
             if not fused_qkv:

@@ -719,6 +719,9 @@ def test_attention_decode_with_fused_oproj_is_bit_identical_to_two_launches(ops,
     (1, 1100, 8, 4, 96, 192, 64, True, False, 512),       # GQA regions of different widths, appended behind 64 cached keys
     (2, 1024, 16, 16, 64, 128, 0, False, True, -1),       # plain head split with bias (CLIP-like), two batch rows, L % 8 == 0
     (3, 680, 16, 16, 64, 128, 8, True, True, 512),
+    # short prompts (17 .. 256 rows): the 128 x 64-tile weight-streaming kernel, Q / K tiles in pair order + V tiles with swapped roles
+    (1, 128, 32, 32, 96, 256, 0, True, False, -1), (1, 100, 32, 32, 96, 192, 0, True, False, -1), (1, 17, 32, 32, 96, 128, 64, True, False, -1),
+    (1, 250, 8, 4, 96, 192, 8, True, False, -1), (2, 64, 16, 16, 64, 128, 0, False, False, -1),
 ])
 def test_gemm_qkv_fused(ops, B, L, nh, nkv, hd, K, past, rot, bias, big):
     """p3v_gemm_qkv (qkv projection with head split + rotation + KV append in its epilogue) against the two calls it replaces --
