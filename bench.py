@@ -190,6 +190,7 @@ def measure_request_set(model, processor, reqs, steps, warmup, prefill_reps, kv_
         if rep < prefill_reps:
             del cache
     prefill = float(np.median(pms))
+    print(f"configs: prefill reps ms (B={B}, {len(reqs)} request(s)):", [round(v, 1) for v in pms], file=sys.stderr)
     for _ in range(warmup):
         _, token = model.greedy_step(token, cache)
     torch.cuda.synchronize()
@@ -244,7 +245,7 @@ def other_configs(model, processor, dev, args):
     # configs[2]: 32k-token long-context prefill + decode (long RoPE factors)
     S3 = 5000 if args.tiny else 32768
     ids = np.random.default_rng(4).integers(3, 32000, (1, S3)).astype(np.int64)
-    out["c3_long_32k"] = dict(measure_request_set(model, processor, [{"input_ids": ids}], K, W, 2),
+    out["c3_long_32k"] = dict(measure_request_set(model, processor, [{"input_ids": ids}], K, W, 3),    # (3 reps: one in ~4 takes 1.5x)
                               workload=f"BASELINE configs[2]: {S3}-token text prompt (Su/LongRoPE long factors), prefill + decode at that context, B=1")
     torch.cuda.empty_cache()
     # configs[3]: one GPU's share of the 64-request mixed batch: 4 single-image VQA + 4 text prompts as one B = 8 decode batch
