@@ -20,6 +20,7 @@ HF-hub download (`_setup`): a model directory must exist locally, or pass
 import json
 import math
 import os
+import sys
 import time
 from io import BytesIO
 from pathlib import Path
@@ -60,6 +61,10 @@ def _rows(token):
     if rows and min(rows) < 0:
         raise RuntimeError(f"device step failed: NaN logits (token ids {rows})")
     return rows
+
+
+class _StepFailed(RuntimeError):
+    """a decode step delivered a negative token id (NaN logits, or a poisoned row)"""
 
 
 class Streamer:
@@ -316,43 +321,78 @@ def greedy_loop(model, token, cache, n_steps, streamer, token_stopper, logit_sto
     pending = None                                                  # (event, pinned buffer) of the step the host has not read yet
 
     debug = os.environ.get("P3V_DEBUG_STEP") == "1"
+    fail_at = int(os.environ.get("P3V_DEBUG_FAIL_STEP", "-1"))      # tests: report this step's tokens as failed, once
     taken = []
+    n_done = 0                                                      # steps of this call whose tokens reached the streamer
 
     def take(p):
+        nonlocal n_done, fail_at
         p[0].synchronize()
         if debug and p[2] is not None:                              # the pinned-history read trusts n_replays == the device's step
             g_, k_ = p[2]                                           # counter; a direct graph.launch() or a d_step reset breaks that
             assert int(g_["d_step"].item()) >= k_ + 1, f"history column {k_} read, device step counter {int(g_['d_step'].item())}"
         rows = p[1].tolist()
+        if n_done == fail_at:                                       # (tests) what a poisoned step leaves: a negative token, NaN cache rows
+            rows, fail_at = [-1] * len(rows), -1
+            torch.cuda.synchronize()
+            if not st.quantized:
+                st.v[..., st.offset - (i - n_done):st.offset] = float("nan")
+                st.k[:, :, :, st.offset - (i - n_done):st.offset] = float("nan")
         if min(rows) < 0:
-            raise RuntimeError(f"device step failed: NaN logits (token ids {rows})")
+            raise _StepFailed(f"device step failed: NaN logits (token ids {rows})")
         taken[:] = rows
+        n_done += 1
         streamer(rows)
         return token_stopper(rows)
     st = cache[0].state
-    for i in range(n_steps):
-        _, token = graph_step(token, cache)                         # enqueue step i
-        g = st.graphs["greedy"]
-        k, hist = g["n_replays"] - 1, g["history"]
-        ev = torch.cuda.Event()
-        if k < hist.shape[1] and not hist.is_cuda:
-            # the step wrote its tokens into pinned host memory itself (history[:, k], model._build_decode_graph): nothing to copy,
-            # the replays run back to back (an in-line D2H copy node costs the step ~18 us of idle GPU: 550 -> 556 tok/s at config 2)
-            ev.record()
-            src, chk = hist[:, k], (g, k)
-        else:                                                       # (history full, or kept on the device by another model class)
-            if not host:
-                host = [torch.empty((B,), dtype=torch.int32).pin_memory() for _ in range(2)]
-            host[i & 1].copy_(token.reshape(-1), non_blocking=True) # stream-ordered copy, before the next replay overwrites the buffer
-            ev.record()
-            src, chk = host[i & 1], None
-        if pending is not None and take(pending):                   # host work of step i - 1 under the GPU's step i
-            st.offset -= 1                                          # drop the speculative step i: its K/V row lies beyond the offset
-            return torch.tensor(taken, dtype=torch.int32, device=token.device).view(-1, 1)
-        pending = (ev, src, chk)
-    if pending is not None:
-        take(pending)
-    return token
+    token0 = token.clone()                                          # (the caller's tensor may be the step's own output buffer)
+    degraded = False
+    i = 0
+    while True:
+        try:
+            while i < n_steps:
+                _, token = graph_step(token, cache)                 # enqueue step i
+                i += 1
+                g = st.graphs["greedy"]
+                k, hist = g["n_replays"] - 1, g["history"]
+                ev = torch.cuda.Event()
+                if k < hist.shape[1] and not hist.is_cuda:
+                    # the step wrote its tokens into pinned host memory itself (history[:, k], model._build_decode_graph): nothing to
+                    # copy, the replays run back to back (an in-line D2H copy node costs the step ~18 us of idle GPU: 550 -> 556 tok/s)
+                    ev.record()
+                    src, chk = hist[:, k], (g, k)
+                else:                                               # (history full, or kept on the device by another model class)
+                    if not host:
+                        host = [torch.empty((B,), dtype=torch.int32).pin_memory() for _ in range(2)]
+                    host[i & 1].copy_(token.reshape(-1), non_blocking=True)   # stream-ordered copy, before the next replay overwrites it
+                    ev.record()
+                    src, chk = host[i & 1], None
+                prev, pending = pending, (ev, src, chk)
+                if prev is not None and take(prev):                 # host work of step i - 2 under the GPU's step i - 1
+                    st.offset -= 1                                  # drop the speculative step: its K/V row lies beyond the offset
+                    return torch.tensor(taken, dtype=torch.int32, device=token.device).view(-1, 1)
+            if pending is not None:
+                last, pending = pending, None
+                take(last)
+            return token
+        except _StepFailed:
+            # A step delivered no token.  The one launch of the step that depends on the rest of the GPU is the fused attention +
+            # o_proj (every workgroup resident at once: another process on the same GPU can starve it until its bound runs out and
+            # the row is poisoned).  Once per call: plan without it (as a server-owned model does), rewind to the last good token,
+            # go on.  Anything else -- or a second failure -- is raised.
+            g = st.graphs.get("greedy")
+            if degraded or g is None or not g["bufs"].get("fuse_o", False):
+                raise
+            degraded = True
+            torch.cuda.synchronize()
+            model.serving = True
+            st.graphs.clear()
+            st.offset -= i - n_done                                 # the failed step and the speculative one behind it
+            st.scrub(st.offset, st.offset + i - n_done)             # (their cache rows hold NaN: 0 x NaN would poison every later step)
+            i, pending = n_done, None
+            token = torch.tensor(taken, dtype=torch.int32, device=token0.device).view(-1, 1) if n_done else token0
+            print("[phi3v] a decode step timed out in the fused attention + o_proj launch (is another process using this GPU?): "
+                  "continuing with separate launches", file=sys.stderr)
 
 
 def _generate(model, processor, prompt, images=None, max_tokens=512, verbose=True, return_tps=False, early_stop=False,

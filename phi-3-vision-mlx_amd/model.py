@@ -107,6 +107,22 @@ class CacheState:
         self.epoch = None                                       # model.epoch the graphs were captured under
 
 
+    def scrub(self, lo, hi):
+        """Forget cache positions [lo, hi) that a FAILED step wrote (api.greedy_loop's recovery): a poisoned step leaves NaN there,
+        and the decode attention multiplies every V^T column of a tile -- live or not -- by its (zero) probability."""
+        hi = min(hi, self.Tp)
+        if hi <= lo:
+            return
+        if self.quantized:
+            self.v8[..., lo:hi] = 128
+            self.k8[:, :, :, lo:hi] = 128
+            self.vs[..., lo:hi] = 1.0
+            self.ks[..., lo:hi] = 1.0
+        else:
+            self.v[..., lo:hi] = 0
+            self.k[:, :, :, lo:hi] = 0
+
+
 class _Lease:
     """Held by the cache views of one captured-prefill call: while it lives, the entry's buffers belong to that caller."""
 

@@ -120,6 +120,46 @@ def test_graph_replayed_greedy_step_equals_eager(text):
         assert torch.equal(hist, torch.cat(eager_tok, dim=1).to(hist.dtype))
 
 
+def test_generate_loop_survives_a_timed_out_fused_launch(monkeypatch, capsys):
+    """The fused attention + o_proj launch needs the GPU to itself; when another process starves it the step's row is poisoned and
+    the token comes back negative.  `_generate`'s loop then re-plans the step without that launch (as a server-owned model does),
+    rewinds to the last good token and goes on: same tokens, same cache offset (the failure is injected with P3V_DEBUG_FAIL_STEP)."""
+    from phi_3_vision_mlx_amd import api
+    from phi_3_vision_mlx_amd.api import load_synthetic
+    model, processor = load_synthetic(blind_model=True, tiny=False, seed=0, device="cuda:0", num_hidden_layers=2)
+    ids = torch.randint(3, 32000, (1, 1700), dtype=torch.int64, generator=torch.Generator().manual_seed(6))
+
+    class Keep:
+        def __init__(self): self.rows = []
+        def __call__(self, rows): self.rows.append(list(rows))
+
+    def run(fail):
+        if fail is None:
+            monkeypatch.delenv("P3V_DEBUG_FAIL_STEP", raising=False)
+        else:
+            monkeypatch.setenv("P3V_DEBUG_FAIL_STEP", str(fail))
+        logits, cache = model(input_ids=ids, max_tokens=40)
+        token = ops_mod.argmax(logits[:, -1].contiguous())[:, None]
+        keep = Keep()
+        out = api.greedy_loop(model, token, cache, 12, keep, lambda rows: False)
+        return keep.rows, out.reshape(-1).tolist(), cache[0].state.offset, cache[0].state.graphs["greedy"]["bufs"].get("fuse_o", False)
+
+    from phi_3_vision_mlx_amd import ops as ops_mod
+    model.serving = False
+    good, last, off, fused = run(None)
+    assert fused and len(good) == 12 and off == 1700 + 12
+    for fail in (0, 5, 11):
+        model.serving = False
+        rows, last2, off2, fused2 = run(fail)
+        assert rows == good and last2 == last and off2 == off and not fused2 and model.serving
+        assert "continuing with separate launches" in capsys.readouterr().err
+    model.serving = True                                          # already degraded: the same failure is raised
+    with pytest.raises(RuntimeError, match="device step failed"):
+        run(3)
+    del model
+    torch.cuda.empty_cache()
+
+
 def test_short_prompt_resid_norm_fusion_changes_nothing(monkeypatch):
     """A 128-token prompt runs o_proj / down_proj as K slices whose reduction launch also writes the next RMSNorm
     (model._proj_resid_norm): logits and cache equal the unfused launches bit for bit."""
