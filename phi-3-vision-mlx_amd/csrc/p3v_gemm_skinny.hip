@@ -10,6 +10,8 @@
 //             there) -- the kernel's bound; 128 x 128 tiles (W x 2 staged, half the workgroups) ran into the ~50 GB/s a single
 //             CU's DMA path takes instead and were not faster on any shape (the template keeps the variant).
 //   staging   LDS-DMA into a ring of 6 stages (A 16 KiB + W 8 KiB each), 5 in flight behind a counted vmcnt; one workgroup per CU
+//             (<= 64 rows: 64-row tiles, A 8 KiB per stage -- a third less staged per K-tile, the same sums bit for bit: 60 -> 53 us
+//             per decoder layer at 17 rows)
 //   waves     8: four CONSUMERS (stacked along M, 32 rows x 64 columns each: acc[2][4]; W fragment first
 //             in the MFMA, so the epilogue is the register-direct one of the other GEMM kernels, p3v_gemm256_epi.h) and four
 //             PRODUCERS that only issue the DMA and wait for it; one barrier per K-tile hands a landed stage over and a drained
@@ -30,12 +32,13 @@
 
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-template <int TN> struct SkCfg {
+template <int TN, int TM = SK_BM> struct SkCfg {
+  static_assert(TM == 128 || (TM == 64 && TN == 64), "64-row tiles: prompts / batches of <= 64 rows, 64-column tiles");
   static constexpr int NS = TN == 64 ? 6 : 4;                  // ring stages (NS - 1 ahead)
-  static constexpr int W_BYTES = TN * SK_BK * 2, STAGE = SK_A_BYTES + W_BYTES, LDS = NS * STAGE;
-  static constexpr int WQ = TN / 32;                           // W pieces (8 rows x 128 B) per producer wave and stage
-  static constexpr int PER = 4 + WQ;                           // DMA instructions per producer wave and stage
-  static constexpr int NI = TN == 64 ? 2 : 4;                  // 16-row blocks per consumer wave (its 64 columns: 4 blocks)
+  static constexpr int A_BYTES = TM * SK_BK * 2, W_BYTES = TN * SK_BK * 2, STAGE = A_BYTES + W_BYTES, LDS = NS * STAGE;
+  static constexpr int AQ = TM / 32, WQ = TN / 32;             // A / W pieces (8 rows x 128 B) per producer wave and stage
+  static constexpr int PER = AQ + WQ;                          // DMA instructions per producer wave and stage
+  static constexpr int NI = TN == 64 ? TM / 64 : 4;            // 16-row blocks per consumer wave (its 64 columns: 4 blocks)
 };
 
 // s_waitcnt vmcnt(PER * n) for a uniform run-time n = stages that may stay in flight (PER = 6 or 8 DMA instructions per stage)
@@ -47,8 +50,13 @@ __device__ __forceinline__ void sk_wait_stages(int n) {
       SK_WAIT_CASE(1, 6) SK_WAIT_CASE(2, 12) SK_WAIT_CASE(3, 18) SK_WAIT_CASE(4, 24)
       default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
+  } else if (PER == 4) {
+    switch (n) {
+      SK_WAIT_CASE(1, 4) SK_WAIT_CASE(2, 8) SK_WAIT_CASE(3, 12) SK_WAIT_CASE(4, 16)
+      default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
   } else {
-    static_assert(PER == 6 || PER == 8, "");
+    static_assert(PER == 4 || PER == 6 || PER == 8, "");
     switch (n) {
       SK_WAIT_CASE(1, 8) SK_WAIT_CASE(2, 16) SK_WAIT_CASE(3, 24) SK_WAIT_CASE(4, 32)
       default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -65,9 +73,10 @@ struct SkinnyP {
 
 #define P3V_EPI_QKV 100            // internal, as in the other GEMM kernels
 
-template <int EPI, bool PART, int TN>
+template <int EPI, bool PART, int TN, int TM = SK_BM>
 __global__ void __launch_bounds__(512, 1) k_gemm_skinny(SkinnyP p) {
-  typedef SkCfg<TN> C;
+  typedef SkCfg<TN, TM> C;
+  static_assert(TM == SK_BM || EPI != P3V_EPI_QKV, "the qkv epilogue's V tiles are 128 dimensions tall");
   constexpr bool SILU = EPI == P3V_EPI_SILU_MUL;
   constexpr int NS = C::NS, NI = C::NI;
   static_assert(NS - 2 <= 4 && (NS - 2) * C::PER < 64, "sk_wait_stages covers 4 stages in flight");
@@ -76,7 +85,7 @@ __global__ void __launch_bounds__(512, 1) k_gemm_skinny(SkinnyP p) {
   constexpr bool QKV = EPI == P3V_EPI_QKV;
   static_assert(!QKV || (TN == 64 && !PART), "the qkv epilogue: 64-column tiles, one pass");
   constexpr int n_out_tile = SILU ? TN / 2 : TN;
-  int n0 = blockIdx.x * n_out_tile, m0 = blockIdx.y * SK_BM;
+  int n0 = blockIdx.x * n_out_tile, m0 = blockIdx.y * TM;
   const int kz = blockIdx.z;
   const int nk = (PART ? p.kslice : p.K) / SK_BK, kt0 = kz * nk;
   // P3V_EPI_QKV (p3v_gemm_qkv.h), a one-dimensional grid: first the Q and K tiles (128 tokens x 32 rotation pairs, W rows fetched in
@@ -114,8 +123,8 @@ __global__ void __launch_bounds__(512, 1) k_gemm_skinny(SkinnyP p) {
     const __amdgpu_buffer_rsrc_t rs_x = rs_a;
     if (QKV && swapped) { rs_a = rs_w; rs_w = rs_x; }           // the tile's A side reads W rows, its B side token rows
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int r = (pw * 4 + q) * 8 + srow;
+    for (int q = 0; q < C::AQ; ++q) {
+      const int r = (pw * C::AQ + q) * 8 + srow;
       if (QKV && swapped) {
         a_src[q] = (unsigned)(((size_t)(row0 + n0 + r) * p.ldw + ((schunk ^ (r & 7)) * 8)) * 2);
       } else {
@@ -142,17 +151,19 @@ __global__ void __launch_bounds__(512, 1) k_gemm_skinny(SkinnyP p) {
       // where the HOST pass does not know the builtin and hipcc silently drops the kernel's host stub)
       unsigned char* base = smem + slot * (int)C::STAGE;
       const int koff = (kt0 + kt) * (SK_BK * 2), koff_a = SK_ABL == 1 ? 0 : koff, koff_w = SK_ABL == 2 ? 0 : koff;
-      const int wq = C::WQ;
+      const int wq = C::WQ, aq = C::AQ, a_bytes = C::A_BYTES;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        lptr_t dst = (lptr_t)(base + (pw * 4 + q) * 1024);
-        const unsigned vo = a_src[q];
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, dst, 16, vo, koff_a, 0, 0);
+        if (q < aq) {
+          lptr_t dst = (lptr_t)(base + (pw * aq + q) * 1024);
+          const unsigned vo = a_src[q];
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, dst, 16, vo, koff_a, 0, 0);
+        }
       }
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         if (q < wq) {
-          lptr_t dst = (lptr_t)(base + SK_A_BYTES + (pw * wq + q) * 1024);
+          lptr_t dst = (lptr_t)(base + a_bytes + (pw * wq + q) * 1024);
           const unsigned vo = SK_ABL == 2 ? a_src[q] : w_src[q];
           __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, dst, 16, vo, koff_w, 0, 0);
         }
@@ -182,7 +193,7 @@ __global__ void __launch_bounds__(512, 1) k_gemm_skinny(SkinnyP p) {
     for (int kt = 0; kt < nk; ++kt) {
       __builtin_amdgcn_s_barrier();                             // K-tile kt is in LDS (every producer waited for its pieces)
       const unsigned char* ta = smem + slot * C::STAGE;
-      const unsigned char* tb = ta + SK_A_BYTES;
+      const unsigned char* tb = ta + C::A_BYTES;
       bf16x8_t af[2][NI], bfr[2][4];
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
@@ -307,21 +318,27 @@ int p3v_gemm_skinny_slices(int M, int N, int K, int epilogue) {
   return best;
 }
 
-template <int EPI>
-static int launch_skinny(const SkinnyP& p, int S, hipStream_t s) {
+template <int EPI, int TM>
+static int launch_skinny_tm(const SkinnyP& p, int S, hipStream_t s) {
+  typedef SkCfg<SK_TN, TM> C;
   static bool attr_set[2] = {false, false};
   const bool part = S > 1;
   if (!attr_set[part]) {
-    const void* fn = part ? (const void*)k_gemm_skinny<EPI, true, SK_TN> : (const void*)k_gemm_skinny<EPI, false, SK_TN>;
-    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, SkCfg<SK_TN>::LDS) != hipSuccess) return P3V_ERR_HIP;
+    const void* fn = part ? (const void*)k_gemm_skinny<EPI, true, SK_TN, TM> : (const void*)k_gemm_skinny<EPI, false, SK_TN, TM>;
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS) != hipSuccess) return P3V_ERR_HIP;
     attr_set[part] = true;
   }
   const int n_tile = EPI == P3V_EPI_SILU_MUL ? SK_TN / 2 : SK_TN;
-  const dim3 grid(p.N / n_tile, p3v_cdiv(p.M, SK_BM), S);
-  if (part) hipLaunchKernelGGL((k_gemm_skinny<EPI, true, SK_TN>), grid, dim3(512), SkCfg<SK_TN>::LDS, s, p);
-  else hipLaunchKernelGGL((k_gemm_skinny<EPI, false, SK_TN>), grid, dim3(512), SkCfg<SK_TN>::LDS, s, p);
+  const dim3 grid(p.N / n_tile, p3v_cdiv(p.M, TM), S);
+  if (part) hipLaunchKernelGGL((k_gemm_skinny<EPI, true, SK_TN, TM>), grid, dim3(512), C::LDS, s, p);
+  else hipLaunchKernelGGL((k_gemm_skinny<EPI, false, SK_TN, TM>), grid, dim3(512), C::LDS, s, p);
   P3V_CHECK_LAUNCH();
   return P3V_OK;
+}
+// <= 64 rows: 64-row tiles (the A panel is two thirds of what a 128-row tile stages per K-tile; half of it would be clamped copies)
+template <int EPI>
+static int launch_skinny(const SkinnyP& p, int S, hipStream_t s) {
+  return p.M <= 64 && !p3v_tuning().gemm_skinny_tm128 ? launch_skinny_tm<EPI, 64>(p, S, s) : launch_skinny_tm<EPI, SK_BM>(p, S, s);
 }
 
 int p3v_splitk_reduce(const float* part, const p3v_gemm_args_t* a, int S, hipStream_t s);   // p3v_gemm.hip

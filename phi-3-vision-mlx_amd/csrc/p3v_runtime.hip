@@ -43,7 +43,7 @@ const Knob kKnobs[] = {
     {"gemv_f8_wpc", &P3vTuning::gemv_f8_wpc, 16},           {"gemv_q4_wpc", &P3vTuning::gemv_q4_wpc, 8},
     {"gemv_wpw", &P3vTuning::gemv_wpw, 0},
     {"gemm_no_skinny", &P3vTuning::gemm_no_skinny, 0},      {"gemm_skinny_max_m", &P3vTuning::gemm_skinny_max_m, 256},
-    {"gemm_skinny_s", &P3vTuning::gemm_skinny_s, 0},
+    {"gemm_skinny_s", &P3vTuning::gemm_skinny_s, 0},            {"gemm_skinny_tm128", &P3vTuning::gemm_skinny_tm128, 0},
 };
 P3vTuning g_tuning;
 std::once_flag g_tuning_once;

@@ -170,7 +170,7 @@ def test_gemm_round_packing(ops, epi, M, N, K):
 
 SKINNY_CASES = [("none", 128, 9216, 3072), ("none", 17, 9216, 3072), ("resid_bf16", 128, 3072, 3072), ("resid_bf16", 100, 3072, 8192),
                 ("silu", 128, 8192, 3072), ("silu", 33, 8192, 3072), ("silu", 256, 1024, 3072), ("none", 129, 3072, 3072),
-                ("resid_bf16", 250, 192, 768), ("silu", 64, 96, 384), ("none", 200, 64, 64)]
+                ("resid_bf16", 250, 192, 768), ("silu", 64, 96, 384), ("none", 200, 64, 64), ("resid_bf16", 40, 3072, 8192), ("none", 64, 9216, 3072)]
 
 
 @pytest.mark.parametrize("epi,M,N,K", SKINNY_CASES)
@@ -201,6 +201,12 @@ def test_gemm_skinny_rows(ops, epi, M, N, K):
     close(out, ref.to(BF16), rtol=2 ** -6, atol=2e-2)
     close(out, other, rtol=2 ** -6, atol=2e-2)
     assert (out == other).float().mean().item() > 0.99
+    if M <= 64:                                                 # <= 64 rows run on 64-row tiles: the same sums as the 128-row tiles, bit for bit
+        old = ops.set_tuning("gemm_skinny_tm128", 1)
+        try:
+            assert torch.equal(ops.gemm(a, w, EPI, resid=r), out)
+        finally:
+            ops.set_tuning("gemm_skinny_tm128", old)
     for s_pin in (1, 2):                                        # the split pinned: one pass / two slices, same values up to summation order
         if K % (s_pin * 64) == 0:
             old = ops.set_tuning("gemm_skinny_s", s_pin)

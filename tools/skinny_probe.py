@@ -37,12 +37,13 @@ for M in Ms:
         res = torch.randn(M, N, device="cuda").bfloat16()
         kw = {"resid": res} if epi == ops.EPI_RESID_BF16 else {}
         outs, t = {}, {}
-        for label, off in (("skinny", 0), ("split-K 128x128", 1)):
-            old = ops.set_tuning("gemm_no_skinny", off)
+        variants = [("skinny", 0, 0), ("split-K 128x128", 1, 0)] + ([("skinny, 128-row tiles", 0, 1)] if M <= 64 else [])
+        for label, off, tm128 in variants:
+            old, old2 = ops.set_tuning("gemm_no_skinny", off), ops.set_tuning("gemm_skinny_tm128", tm128)
             outs[label] = ops.gemm(A, Ws[0], epi, **kw).float()
             t[label] = sorted(timeit(lambda i: ops.gemm(A, Ws[i], epi, **kw), 4, iters=20) for _ in range(3))[1]
-            ops.set_tuning("gemm_no_skinny", old)
-            tot[label] += t[label]
+            ops.set_tuning("gemm_no_skinny", old), ops.set_tuning("gemm_skinny_tm128", old2)
+            tot[label] = tot.get(label, 0.0) + t[label]
         z = A.double() @ Ws[0].double().t()
         if epi == ops.EPI_SILU_MUL:
             g, u = z[:, :N].bfloat16().double(), z[:, N:].bfloat16().double()
