@@ -172,7 +172,7 @@ int p3v_rope_kv_append(const uint16_t* qkv, const float* cos_t, const float* sin
 /* ---- a residual projection whose consumer is an RMSNorm, as one launch sequence (round 5; phi.py:478-484: `r + o_proj(...)` followed
  *      by `post_attention_layernorm`, `r + down_proj(...)` followed by the next layer's `input_layernorm`):
  *      p3v_gemm_resid_norm(g, w, eps, normed) == p3v_gemm(g) with P3V_EPI_RESID_BF16 + p3v_rmsnorm(g->out, w, normed, M, N, eps), bit
- *      for bit, where the projection runs as K slices (17 .. 256 rows and N small enough that the split pays: the fp32 partials are
+ *      for bit, where the projection runs as K slices (9 .. 256 rows and N small enough that the split pays: the fp32 partials are
  *      summed, the residual added, the row normalised by the SAME launch).  P3V_ERR_UNSUPPORTED -- nothing launched, the caller runs the
  *      two calls -- for every other shape, without a workspace of p3v_gemm_ws_bytes(), or N > 3072.  normed: bf16 [M, N] contiguous. */
 int p3v_gemm_resid_norm(const p3v_gemm_args_t* gemm /* host */, const uint16_t* norm_w, float eps, uint16_t* normed, void* stream);
@@ -183,7 +183,7 @@ int p3v_gemm_resid_norm(const p3v_gemm_args_t* gemm /* host */, const uint16_t* 
  *      + head split).  g: A [B*L, K], W [(nh + 2 nkv) * hd, K] (q rows, k rows, v rows), epilogue P3V_EPI_NONE or P3V_EPI_BIAS; out /
  *      resid / ws unused.  P3V_ERR_UNSUPPORTED (nothing launched) unless hd % 32 == 0, (hd / 2) % 16 == 0, an 8-aligned append
  *      offset and dst_t, B == 1 or L % 8 == 0, and either M >= 1024 with whole 128-column tiles per region (the 256 x 256 /
- *      128 x 128-tile kernels) or 17 <= M <= 256 without bias, whole 64-column Q / K tiles and 128-row V tiles (the 128 x 64-tile
+ *      128 x 128-tile kernels) or 9 <= M <= 256 without bias, whole 64-column Q / K tiles and 128-row V tiles (the 128 x 64-tile
  *      weight-streaming kernel) -- callers then run the two calls. */
 typedef struct {
   const float* cos_t; const float* sin_t;          /* as p3v_rope_kv_append; both null: plain head split */

@@ -1,5 +1,5 @@
-// Prompt-sized-but-short projections  C[M, N] = A[M, K] * W[N, K]^T  for 17 .. 256 rows (round 5): a 128-token chat prompt, the text
-// group of a mixed batch, a 17..128-row decode batch.  At these M the GEMM is a WEIGHT STREAM (2 * 128 * N * K flops against N * K * 2
+// Prompt-sized-but-short projections  C[M, N] = A[M, K] * W[N, K]^T  for 9 .. 256 rows (round 5): a 128-token chat prompt, the text
+// group of a mixed batch, a 9..128-row decode batch.  At these M the GEMM is a WEIGHT STREAM (2 * 128 * N * K flops against N * K * 2
 // bytes: ~13 GFLOP for the 100 MB of gate_up, both worth ~10-17 us), and what decides its speed is how many K-tiles a workgroup
 // has on the wire: the 128 x 128-tile kernel (p3v_gemm.hip) holds ONE ahead and pays a DMA round trip (~1.3 us at this load) per
 // K-tile -- gate_up 34 us + 5 us for the reduction of the split it needs to reach 256 workgroups, 2.9 TB/s.  Here:
@@ -308,7 +308,7 @@ __global__ void __launch_bounds__(512, 1) k_gemm_skinny(SkinnyP p) {
 int p3v_gemm_skinny_slices(int M, int N, int K, int epilogue) {
   const P3vTuning& t = p3v_tuning();
   const bool silu = epilogue == P3V_EPI_SILU_MUL;
-  if (t.gemm_no_skinny || M <= 16 || M > t.gemm_skinny_max_m || K % SK_BK || N % (silu ? 32 : 64)) return 0;
+  if (t.gemm_no_skinny || M <= 8 || M > t.gemm_skinny_max_m || K % SK_BK || N % (silu ? 32 : 64)) return 0;
   if (epilogue != P3V_EPI_NONE && epilogue != P3V_EPI_RESID_BF16 && !silu) return 0;
   const int tiles = p3v_cdiv(M, SK_BM) * ((silu ? 2 * N : N) / SK_TN);
   if (t.gemm_skinny_s > 0) return K % (t.gemm_skinny_s * SK_BK) ? 1 : t.gemm_skinny_s;
@@ -377,7 +377,7 @@ int p3v_gemm_skinny_try(const p3v_gemm_args_t* a, hipStream_t s) {
 // P3V_ERR_UNSUPPORTED (nothing launched) where the shape is not this kernel's.
 int p3v_gemm_skinny_qkv(const p3v_gemm_args_t* a, const QkvP& q, hipStream_t s) {
   const P3vTuning& t = p3v_tuning();
-  if (t.gemm_no_skinny || a->M <= 16 || a->M > t.gemm_skinny_max_m || a->K % SK_BK || a->bias) return P3V_ERR_UNSUPPORTED;
+  if (t.gemm_no_skinny || a->M <= 8 || a->M > t.gemm_skinny_max_m || a->K % SK_BK || a->bias) return P3V_ERR_UNSUPPORTED;
   if ((q.nh * q.hd) % 64 || (q.nkv * q.hd) % SK_BM) return P3V_ERR_UNSUPPORTED;   // whole Q / K tiles of 32 pairs, whole V tiles of 128 dims
   static bool attr_set = false;
   if (!attr_set) {

@@ -253,6 +253,10 @@ class Phi3VModel:
         M, K = x.shape
         q, q4 = self.w8.get(key), self.w4.get(key)
         skinny = M <= 8 or (M <= ops.GEMV_MAX_M and K % 512 == 0)
+        if skinny and M > 8 and q is None and q4 is None and K % 64 == 0 and self.w[key].shape[0] % 64 == 0:
+            # 9 .. 16 rows on bf16 weights: the 64-row tiles of the weight-streaming GEMM (p3v_gemm_skinny.hip) beat the 16-row MFMA
+            # GEMV by a quarter of the step (B = 16 at 512 keys: 3.9 -> 3.1 ms); up to 8 rows k_gemv_mfma8 stays ahead
+            skinny = False
         if q4 is not None and M == 1 and K in (3072, 8192):
             return ops.gemv_q4(x, q4[0], q4[1], epilogue, resid=resid, norm_w=norm_w, norm_eps=eps, out=out)
         if q is not None and skinny and K in (3072, 8192):
@@ -714,7 +718,7 @@ class Phi3VModel:
             ops.step_begin(g["tok"], w["model.embed_tokens.weight"], g["x"], st.cos, st.sin, g["d_past"],
                            bufs["rope_cos"], bufs["rope_sin"])
             self._layers(g["x"], st, B, 1, 0, 1, bufs=bufs, d_past=g["d_past"])
-            self._proj(g["x"], "lm_head.weight", norm_w=w["model.norm.weight"], out=g["logits"])
+            self._proj(g["x"], "lm_head.weight", norm_w=w["model.norm.weight"], out=g["logits"], h=bufs["h"])   # (h: the norm's output
             ops.step_end(g["logits"], g["next_tok"], g["tok"], g["history"], g["d_step"], g["d_past"], g["ticket"])
         g["d_past"].fill_(st.offset)
         g["gemm_ws"] = {}                                        # B > 16 rows: the projections are split-K GEMMs; their workspace

@@ -95,7 +95,7 @@ def test_tuning_table_and_gemm_workspace_size():
     assert l.p3v_gemm_ws_bytes(128, 8192, 3072, _lib.EPI_SILU_MUL) == 0
     assert l.p3v_gemm_ws_bytes(300, 3072, 8192, _lib.EPI_RESID_BF16) == 4 * 300 * 3072 * 4
     assert l.p3v_gemm_ws_bytes(2531, 3072, 8192, _lib.EPI_RESID_BF16) == 0
-    assert l.p3v_gemm_ws_bytes(16, 3072, 8192, _lib.EPI_NONE) == 0
+    assert l.p3v_gemm_ws_bytes(8, 3072, 8192, _lib.EPI_NONE) == 0
     assert l.p3v_gemm_ws_bytes(128, 3072, 8192, _lib.EPI_BIAS) == 0
 
 
