@@ -281,7 +281,7 @@ class Phi3VModel:
         """x += bf16(o @ W^T) and h = RMSNorm(x) * norm_w from the projection's own launches (ops.gemm_resid_norm); False -- nothing
         done -- where that does not apply (adapters, quantised weights, shapes the library does not run as K slices)."""
         M = o.shape[0]
-        if (key in self.adapters or key not in self.w or M <= ops.GEMV_MAX_M or h.shape[0] < M
+        if (key in self.adapters or key not in self.w or M <= 8 or h.shape[0] < M
                 or os.environ.get("P3V_RESID_NORM_FUSE", "1") == "0"):
             return False
         return ops.gemm_resid_norm(o, self.w[key], x, norm_w, self.cfg.rms_norm_eps, h[:M], out=x)
