@@ -13,9 +13,10 @@ out, tag = sys.argv[1], sys.argv[2]
 f = glob.glob(out + "/**/*kernel_trace.csv", recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-# decode section = everything after the last k_gemm* (prefill) kernel
-last_pref = max(i for i, r in enumerate(rows) if "k_gemm" in r["Kernel_Name"])
-dec = rows[last_pref + 1:]
+# decode section = from the first step's k_step_begin on (batches of 9+ rows run k_gemm_skinny inside the step: the prefill's GEMM
+# kernels are no marker for where it ends)
+first_step = min(i for i, r in enumerate(rows) if "k_step_begin" in r["Kernel_Name"])
+dec = rows[first_step:]
 # drop the first step(s): eager warm-up + first replay
 names = [r["Kernel_Name"] for r in dec]
 per_step = None
