@@ -9,7 +9,7 @@ from phi_3_vision_mlx_amd.engine import ContinuousEngine
 n_req = int(sys.argv[1]) if len(sys.argv) > 1 else 120
 model, proc = load_synthetic(blind_model=True, device="cuda:0", lm_head_spread=4.0, lm_head_seed=2315)
 rng = np.random.default_rng(0)
-eng = ContinuousEngine(model, proc, slots=8, window=4096)
+eng = ContinuousEngine(model, proc, slots=int(os.environ.get("SOAK_SLOTS", "8")), window=4096)
 stop = threading.Event()
 th = threading.Thread(target=eng.serve_forever, args=(stop,), daemon=True)
 th.start()
