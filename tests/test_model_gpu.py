@@ -1121,6 +1121,33 @@ def test_full_size_decode_equals_prefill_property(full_text):
     assert_logits(b[:, -1], c[:, -1], "full-size decode vs prefill", rel_atol=6e-2)   # 32 layers: see _check_topk
 
 
+@pytest.mark.parametrize("B", [12, 20, 64])
+def test_full_width_batched_decode_rows_equal_their_solo_runs(B):
+    """Decode batches of 9+ rows run their projections on the weight-streaming GEMM (64-row tiles up to 64 rows; K slices + the
+    reduction that also normalises), B = 1 on the GEMV kernels: on a full-WIDTH 2-layer model every row of a graph-replayed batch
+    step must match that row decoded alone -- same arithmetic, another kernel family and summation order."""
+    from phi_3_vision_mlx_amd import ops
+    from phi_3_vision_mlx_amd.api import load_synthetic
+    model, _ = load_synthetic(blind_model=True, tiny=False, seed=0, device="cuda:0", num_hidden_layers=2)
+    ids = np.random.default_rng(B).integers(3, 32000, (B, 40)).astype(np.int64)
+    lg, cache = model(input_ids=ids, max_tokens=4)
+    tok = ops.argmax(lg[:, -1].contiguous())[:, None]
+    batch = [lg[:, -1].float().cpu()]
+    toks = [tok.cpu()]
+    for _ in range(3):
+        lg, tok = model.greedy_step(tok, cache)
+        batch.append(lg[:, -1].float().cpu())
+        toks.append(tok.cpu())
+    for r in sorted({0, B // 2, B - 1}):
+        lg1, c1 = model(input_ids=ids[r:r + 1], max_tokens=4)
+        assert_logits(batch[0][r:r + 1], lg1[:, -1], f"B={B} row {r} prefill")
+        for step in range(3):
+            lg1, _ = model.greedy_step(toks[step][r:r + 1].to("cuda:0"), c1)       # teacher-forced with the batch's tokens
+            assert_logits(batch[step + 1][r:r + 1], lg1[:, -1], f"B={B} row {r} step {step}")
+    del model
+    torch.cuda.empty_cache()
+
+
 @pytest.mark.parametrize("layers,serving", [(3, False), (2, False), (2, True)], ids=["odd-stack", "even-stack", "even-stack-server"])
 def test_fused_oproj_decode_needs_an_even_stack_and_an_exclusive_gpu(layers, serving, monkeypatch):
     """the fused attention + o_proj launch of layer i re-arms the OTHER parity's output buffer, so an odd number of
