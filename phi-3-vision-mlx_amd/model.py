@@ -655,7 +655,7 @@ class Phi3VModel:
                 o = o.view(B, L, -1)[:, -1].contiguous()
                 x = x.view(B, L, -1)[:, -1].contiguous()
                 a, h = a[:B], h[:B]
-            # Short prompts (17 .. 256 rows): o_proj and down_proj run as K slices, and the launch that adds the slices also writes the
+            # Short prompts and decode batches (9 .. 256 rows): o_proj and down_proj run as K slices, and the launch that adds the slices also writes the
             # RMSNorm of the new residual stream into `h` -- the next projection's input (ops.gemm_resid_norm; bit-identical to the
             # two launches it replaces).
             normed = False
