@@ -97,31 +97,36 @@ def su_rope_tables(cfg, L_all, pids):
 
 
 def mx_quantize(w, group_size=32, bits=4):
-    """mx.quantize as MLX documents it (restated here: the oracle imports nothing of the product): per group of `group_size` values
-    w ~ scale * q + bias with q in 0 .. 2^bits - 1; the end of the range with the larger magnitude is represented exactly (it
-    becomes the bias, the scale takes the sign that reaches the other end); scale and bias are returned in w's dtype and the codes
-    are taken against those stored values.  -> (codes int64 [N, K], scales [N, K / group], biases)."""
+    """mx.quantize of the pinned mlx 0.15.0 (restated here: the oracle imports nothing of the product): per group of `group_size`
+    values w ~ scale * q + bias with q in 0 .. 2^bits - 1; the end of the range with the larger magnitude is represented exactly
+    (it becomes the bias, the scale takes the sign that reaches the other end).  In that release the function is a composite of
+    array primitives in w's dtype, so for the reference's bf16 VALUES (phi.py:443-449: only q and k are promoted to fp32 by the
+    rotation) every intermediate rounds to bf16 -- `r` below -- while its fp32 KEYS see plain fp32 arithmetic.
+    -> (codes int64 [N, K], scales [N, K / group], biases) with scales / biases in w's dtype."""
     N, K = w.shape
+    dt = w.dtype
+    r = (lambda t: t) if dt == torch.float32 else (lambda t: t.to(dt).float())
     g = w.float().reshape(N, K // group_size, group_size)
-    n_bins = (1 << bits) - 1
+    n_bins = float((1 << bits) - 1)
     w_max, w_min = g.amax(-1), g.amin(-1)
     side = w_min.abs() > w_max.abs()
-    scales = ((w_max - w_min) / n_bins).clamp_min(1e-7)
+    scales = torch.maximum(r(r(w_max - w_min) / n_bins), r(torch.tensor(1e-7)))
     scales = torch.where(side, scales, -scales)
     edge = torch.where(side, w_min, w_max)
-    q0 = torch.round(edge / scales)
-    scales = torch.where(q0 != 0, edge / q0, scales)
+    q0 = torch.round(r(edge / scales))
+    scales = torch.where(q0 != 0, r(edge / q0), scales)
     biases = torch.where(q0 == 0, torch.zeros_like(edge), edge)
-    scales, biases = scales.to(w.dtype), biases.to(w.dtype)
-    q = torch.round((g - biases.float()[..., None]) / scales.float()[..., None]).clamp(0, n_bins).to(torch.int64)
-    return q.reshape(N, K), scales, biases
+    q = torch.round(r(r(g - biases[..., None]) / scales[..., None])).clamp(0, n_bins).to(torch.int64)
+    return q.reshape(N, K), scales.to(dt), biases.to(dt)
 
 
 def mx_dequantize(q, scales, biases, group_size=32):
-    """mx.dequantize: scale * q + bias per group, in the scales' dtype."""
+    """mx.dequantize of the same release: multiply(codes, scales) then add(., biases), two primitives that each round to the
+    scales' dtype."""
     N, K = q.shape
-    w = q.float().reshape(N, K // group_size, group_size) * scales.float()[..., None] + biases.float()[..., None]
-    return w.reshape(N, K).to(scales.dtype)
+    dt = scales.dtype
+    prod = (q.float().reshape(N, K // group_size, group_size) * scales.float()[..., None]).to(dt)
+    return (prod.float() + biases.float()[..., None]).to(dt).reshape(N, K)
 
 
 class OracleKVCache:

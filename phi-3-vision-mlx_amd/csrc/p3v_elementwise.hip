@@ -398,8 +398,8 @@ extern "C" int p3v_rope_kv_append(const uint16_t* qkv, const float* cos_t, const
 // groups -- and every later call attends on mx.dequantize of that (later tokens stay unquantised).  One thread per (row, token,
 // group): the MLX affine group quantiser (weights.mlx_quantize: the larger-magnitude end of the range is represented exactly,
 // scale and bias stay fp32 as they do for the reference's fp32 keys), the codes in MLX's packing (code k of a word at bits
-// [4k, 4k+4)), and the group written BACK dequantised (scale * q + bias, one rounding to bf16; V: scale and bias are bf16 values, as
-// mx.quantize returns them for a bf16 input): the cache rows then hold exactly
+// [4k, 4k+4)), and the group written BACK dequantised (scale * q, + bias, then the cache's bf16; V: every primitive of the composite
+// rounds to bf16, as mlx 0.15.0 computes it for a bf16 input): the cache rows then hold exactly
 // what the reference attends on from the second call on, and the decode kernels read them as they are.
 struct Mlx4Src {                                                  // where the EXACT fp32 keys come from (null qkv: from the bf16 cache rows)
   const bf16_t* qkv; const float* cos_t; const float* sin_t;      // the layer's projection output [B * L, (nh + 2 nkv) * hd] + rotation tables
@@ -446,28 +446,33 @@ __global__ void __launch_bounds__(256) k_kv_quantize_mlx4(bf16_t* __restrict__ k
 #pragma unroll
     for (int d = 0; d < 32; ++d) w[d] = bf16_to_f32(vt[((size_t)row * hd + g * 32 + d) * cache_t + t]);
   }
+  // mlx 0.15.0's mx.quantize / mx.dequantize are composites of array primitives in the INPUT's dtype (weights.mlx_quantize): the
+  // reference's values reach the cache as bf16 (phi.py:443-449: only q and k are promoted by the rotation), so for V every
+  // intermediate -- range, scale, edge / scale, edge / q0, w - bias, (w - bias) / scale, scale * q, + bias -- rounds to bf16 (R);
+  // its keys are fp32 arrays and see plain fp32 arithmetic.
+#define R(x) (is_v ? bf16_round(x) : (x))
   float w_max = w[0], w_min = w[0];
 #pragma unroll
   for (int d = 1; d < 32; ++d) { w_max = fmaxf(w_max, w[d]); w_min = fminf(w_min, w[d]); }
   const bool mask = fabsf(w_min) > fabsf(w_max);
-  float scale = fmaxf((w_max - w_min) / 15.f, 1e-7f);
+  float scale = fmaxf(R(R(w_max - w_min) / 15.f), R(1e-7f));
   scale = mask ? scale : -scale;
   const float edge = mask ? w_min : w_max;
-  const float q0 = rintf(edge / scale);
-  if (q0 != 0.f) scale = edge / q0;
-  float bias = q0 == 0.f ? 0.f : edge;
-  if (is_v) {                                                     // mx.quantize keeps scale and bias in the INPUT's dtype: the values reach the
-    scale = bf16_round(scale), bias = bf16_round(bias);           // cache as bf16 (phi.py:443-449: only q and k are promoted by the rotation),
-  }                                                               // the keys as fp32 -- and the codes are taken against the stored pair
+  const float q0 = rintf(R(edge / scale));
+  if (q0 != 0.f) scale = R(edge / q0);
+  const float bias = q0 == 0.f ? 0.f : edge;
   uint32_t words[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
   for (int d = 0; d < 32; ++d) {
-    const float q = fminf(fmaxf(rintf((w[d] - bias) / scale), 0.f), 15.f);
+    float diff = w[d] - bias;                             // (the empty asm statements keep hipcc, fp-contract=fast, from fusing two
+    asm volatile("" : "+v"(diff));                        // primitives into one fma or reassociating across a rounding)
+    const float q = fminf(fmaxf(rintf(R(R(diff) / scale)), 0.f), 15.f);
     words[d >> 3] |= (uint32_t)q << (4 * (d & 7));
-    float prod = scale * q;                               // two roundings, as mx.dequantize's multiply-then-add: the empty asm keeps
-    asm volatile("" : "+v"(prod));                        // hipcc (fp-contract=fast) from fusing them into one fma
-    w[d] = prod + bias;
+    float prod = scale * q;                               // two roundings, as mx.dequantize's multiply-then-add
+    asm volatile("" : "+v"(prod));
+    w[d] = R(prod) + bias;
   }
+#undef R
   uint32_t* c4 = (is_v ? v4 : k4) + (((size_t)row * n_tok + t) * gpt + g) * 4;
   *(u32x4_t*)c4 = (u32x4_t){words[0], words[1], words[2], words[3]};
   float* sb = (is_v ? v_sb : k_sb) + (((size_t)row * n_tok + t) * gpt + g) * 2;

@@ -236,7 +236,7 @@ def load_safetensors_dir(model_path, cfg, device="cpu"):
                 raise NotImplementedError(f"only {Q4_BITS}-bit group-{Q4_GROUP} MLX checkpoints are supported, got {quantized}")
             q = Q4Weight(t.view(torch.int32) if t.dtype != torch.int32 else t, raw[base + ".scales"], raw[base + ".biases"])
             fast = k == "lm_head.weight" or (k.startswith("model.layers.") and k.endswith("_proj.weight"))
-            out[k] = q if fast else mlx_dequantize(*q).to(torch.bfloat16).to(device)
+            out[k] = q if fast else mlx_dequantize(*q, dtype=torch.bfloat16).to(device)
             continue
         if "patch_embedding.weight" in k and getattr(cfg, "sanitized", False):
             t = t.permute(0, 3, 1, 2).contiguous()
@@ -327,29 +327,37 @@ class Q4Weight(tuple):
 
 
 def mlx_quantize(w, group_size=Q4_GROUP, bits=Q4_BITS):
-    """Affine group quantisation as mx.quantize documents it (the reference calls nn.quantize(model, 64, 4),
-    phi_3_vision_mlx.py:264,297-305): per group of `group_size` input columns  w ~ scale * q + bias,  q in 0..2^bits-1.
-    -> (packed uint32-as-int32 [N, K*bits/32] in MLX's order: weight k of a word at bits [4k, 4k+4), scales, biases
-    [N, K/group] in w.dtype).  The scale/edge selection follows MLX's kernel (the end of the range with the larger
-    magnitude is represented exactly); a checkpoint written by MLX only needs `mlx_dequantize` below."""
+    """Affine group quantisation as mlx 0.15.0's mx.quantize does it (the reference calls nn.quantize(model, 64, 4),
+    phi_3_vision_mlx.py:264,297-305, and mx.quantize(keys, group_size=32), phi.py:531): per group of `group_size` input columns
+    w ~ scale * q + bias,  q in 0..2^bits-1, the end of the range with the larger magnitude represented exactly.
+    In that release the function is a composite of array primitives, so EVERY intermediate is an array of w's dtype: for bf16
+    weights the range, the scale, edge / scale, edge / q0, w - bias and (w - bias) / scale each round to bf16 (`r` below); for
+    fp32 inputs `r` is the identity.  (Later releases compute the group statistics in fp32 inside one kernel; a checkpoint
+    written by either only needs `mlx_dequantize` below.)
+    -> (packed uint32-as-int32 [N, K*bits/32] in MLX's order: weight k of a word at bits [4k, 4k+4); scales, biases
+    [N, K/group] in w.dtype)."""
     N, K = w.shape
+    dt = w.dtype
+
+    def r(t):                                                  # one primitive's result: computed in fp32, stored in w's dtype
+        return t.to(dt).float()
     g = w.float().reshape(N, K // group_size, group_size)
-    n_bins = (1 << bits) - 1
+    n_bins = float((1 << bits) - 1)
     w_max, w_min = g.amax(-1), g.amin(-1)
     mask = w_min.abs() > w_max.abs()
-    scales = ((w_max - w_min) / n_bins).clamp_min(1e-7)
+    eps = r(torch.tensor(1e-7, dtype=torch.float32, device=w.device))
+    scales = torch.maximum(r(r(w_max - w_min) / n_bins), eps)
     scales = torch.where(mask, scales, -scales)
     edge = torch.where(mask, w_min, w_max)
-    q0 = torch.round(edge / scales)
-    scales = torch.where(q0 != 0, edge / q0, scales)
+    q0 = torch.round(r(edge / scales))
+    scales = torch.where(q0 != 0, r(edge / q0), scales)
     biases = torch.where(q0 == 0, torch.zeros_like(edge), edge)
-    scales, biases = scales.to(w.dtype), biases.to(w.dtype)                 # stored in the model dtype
-    q = torch.round((g - biases.float()[..., None]) / scales.float()[..., None]).clamp(0, n_bins).to(torch.int64).reshape(N, K)
+    q = torch.round(r(r(g - biases[..., None]) / scales[..., None])).clamp(0, n_bins).to(torch.int64).reshape(N, K)
     per = 32 // bits
     shifts = (torch.arange(per, dtype=torch.int64, device=w.device) * bits)
     packed = (q.reshape(N, K // per, per) << shifts).sum(-1)
     packed = torch.where(packed >= 2 ** 31, packed - 2 ** 32, packed).to(torch.int32)     # uint32 bit pattern in int32
-    return packed, scales, biases
+    return packed, scales.to(dt), biases.to(dt)
 
 
 def mlx_unpack(packed, bits=Q4_BITS):
@@ -360,11 +368,17 @@ def mlx_unpack(packed, bits=Q4_BITS):
     return ((u[..., None] >> shifts) & ((1 << bits) - 1)).reshape(packed.shape[0], -1)
 
 
-def mlx_dequantize(packed, scales, biases, group_size=Q4_GROUP, bits=Q4_BITS):
-    """mx.dequantize: scale * q + bias per group, in float32."""
+def mlx_dequantize(packed, scales, biases, group_size=Q4_GROUP, bits=Q4_BITS, dtype=None):
+    """scale * q + bias per group.  dtype=None: in float32 (what a fused quantised matmul computes on the fly: p3v_gemv_q4,
+    mx.quantized_matmul).  dtype given: as mlx 0.15.0's mx.dequantize ARRAY -- multiply then add, each rounding to `dtype` -- which
+    is what nn.QuantizedEmbedding returns for a looked-up row (the reference's 4-bit embedding table, phi_3_vision_mlx.py:297-305)."""
     q = mlx_unpack(packed, bits).float()
     N, K = q.shape
-    return (q.reshape(N, K // group_size, group_size) * scales.float()[..., None] + biases.float()[..., None]).reshape(N, K)
+    prod = q.reshape(N, K // group_size, group_size) * scales.float()[..., None]
+    if dtype is not None:
+        prod = prod.to(dtype).float()
+    out = (prod + biases.float()[..., None]).reshape(N, K)
+    return out if dtype is None else out.to(dtype)
 
 
 def q4_repack(packed, scales, biases):

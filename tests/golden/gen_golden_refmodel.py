@@ -281,8 +281,9 @@ def q4_case(out, meta):
     `quantized_model.safetensors` + config['quantized'] / ['sanitized']) writes the checkpoint from the tiny bf16 directory, its
     `_load` reads it back (`nn.quantize` BEFORE `load_weights`, :264) and `_generate` runs on `QuantizedLinear` /
     `QuantizedEmbedding`.  Recorded: which tensors the reference quantises (names, shapes, dtypes, sha256 of every tensor of the
-    file it wrote) and the greedy logits of a text and an image prompt.  The affine group format itself is `weights.mlx_quantize`'s
-    statement of mx.quantize (the stand-in reuses it): what this pins is everything AROUND it -- traversal, naming, file layout,
+    file it wrote) and the greedy logits of a text and an image prompt.  The affine group quantiser runs in the stand-in's OWN
+    statement of mlx 0.15.0's composite (mlx_shim.quantize; round 6: it no longer calls `weights.mlx_quantize`, and
+    tests/test_host_logic.py holds the two to bit equality): this pins the format AND everything around it -- traversal, naming, file layout,
     config keys, load order, which layers run quantised (every Linear incl. the ViT's and the projector's, both embeddings and the
     CLIP position table; not the patch convolution, not the norms)."""
     import gen_golden_oracle as ggo
@@ -309,9 +310,10 @@ def q4_case(out, meta):
                 continue
             base_k = k[:-len(".weight")] if k.endswith(".weight") else None
             if base_k is not None and base_k + ".scales" in t:
-                deq = mlx_dequantize(v, t[base_k + ".scales"], t[base_k + ".biases"])
-                ow[k] = deq.to(torch.bfloat16) if "embed" in k and "vision_embed_tokens.img_projection" not in k and "patch" not in k \
-                    and ("embed_tokens.weight" in k or "position_embedding" in k) else deq      # embeddings leave mx.dequantize as bf16
+                is_table = "vision_embed_tokens.img_projection" not in k and ("embed_tokens.weight" in k or "position_embedding" in k)
+                # embedding tables leave mx.dequantize as bf16 ARRAYS (nn.QuantizedEmbedding: multiply and add each round to bf16);
+                # the Linears run mx.quantized_matmul: scale * q + bias in fp32 on the fly
+                ow[k] = mlx_dequantize(v, t[base_k + ".scales"], t[base_k + ".biases"], dtype=torch.bfloat16 if is_table else None)
             elif "patch_embedding.weight" in k:
                 ow[k] = v.permute(0, 3, 1, 2).contiguous()            # sanitized file: OHWI -> the oracle's OIHW
             else:
@@ -328,26 +330,32 @@ def q4_case(out, meta):
         o = orc.OraclePhi3V(cfg, ow, cache_fp32=True)
         o_in = {k: (torch.from_numpy(np.asarray(v)) if k == "pixel_values" else v) for k, v in my_in.items()}
         plain = ggo.peaked_lm_head
-        ggo.peaked_lm_head = q4_head
-        try:
-            r = Prefilled(o, o_in, n)
-            r.rel_tol = 0.045
-            hs, _ = search_head([r], base, n, min_distinct=2)
-        finally:
-            ggo.peaked_lm_head = plain
-        # the reference on a checkpoint whose bf16 source carries that head
-        w2 = dict(w)
-        w2["lm_head.weight"] = peaked_lm_head(base, SPREAD, hs)
-        shutil.rmtree(src, ignore_errors=True), shutil.rmtree(dst, ignore_errors=True)
-        save_safetensors_dir(w2, d, src)
-        loops._quantize(from_path=src, to_path=dst)
-        tens, _ = oracle_weights(dst)
-        model, proc = ref_env.load_model(dst, ByteTokenizer(), clip_cfg=d["clip"])
-        rec = ref_env.Recorder(model)
-        loops._generate(rec, proc, prompt, imgs, max_tokens=n, verbose=False, stream=False, mute=True)
-        lgs = torch.stack([c["logits"]._t[:, -1] for c in rec.calls], 1)
-        toks = torch.argmax(lgs.float(), dim=-1)
-        mg = clearance(lgs, row_norms(q4_head(base, SPREAD, hs)), 0.045)
+        r = Prefilled(o, o_in, n)
+        r.rel_tol = 0.045
+        first = 0
+        for attempt in range(8):                                    # the oracle picks a candidate; the REFERENCE's own logits decide
+            ggo.peaked_lm_head = q4_head
+            try:
+                hs, _ = search_head([r], base, n, min_distinct=2, first_seed=first)
+            finally:
+                ggo.peaked_lm_head = plain
+            # the reference on a checkpoint whose bf16 source carries that head
+            w2 = dict(w)
+            w2["lm_head.weight"] = peaked_lm_head(base, SPREAD, hs)
+            shutil.rmtree(src, ignore_errors=True), shutil.rmtree(dst, ignore_errors=True)
+            save_safetensors_dir(w2, d, src)
+            loops._quantize(from_path=src, to_path=dst)
+            tens, _ = oracle_weights(dst)
+            model, proc = ref_env.load_model(dst, ByteTokenizer(), clip_cfg=d["clip"])
+            rec = ref_env.Recorder(model)
+            loops._generate(rec, proc, prompt, imgs, max_tokens=n, verbose=False, stream=False, mute=True)
+            lgs = torch.stack([c["logits"]._t[:, -1] for c in rec.calls], 1)
+            toks = torch.argmax(lgs.float(), dim=-1)
+            mg = clearance(lgs, row_norms(q4_head(base, SPREAD, hs)), 0.045)
+            if mg.min().item() > 1.0:
+                break
+            print(f"  {name}: head seed {hs} is clear for the oracle, not for the reference ({mg.min().item():.2f}); next", flush=True)
+            first = hs + 1
         assert mg.min().item() > 1.0, f"{name}: not clear under the reference's logits ({mg.tolist()})"
         out[name + "_head_seed"] = np.asarray([hs], dtype=np.int32)
         out[name + "_tokens"] = toks.numpy().astype(np.int32)

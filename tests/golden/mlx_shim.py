@@ -618,33 +618,78 @@ def _unsupported(name):
     return f
 
 
-def _q():
-    """MLX's affine group quantiser lives in the package as data-preparation code (`weights.mlx_quantize` restates mx.quantize's
-    kernel: per group of `group_size` inputs w ~ scale * q + bias, the range end of larger magnitude exact, 32 / bits codes per
-    uint32 with element k at bits [bits * k, bits * (k + 1))); the stand-in reuses it so that there is ONE statement of the format."""
-    import os
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    if root not in sys.path:
-        sys.path.insert(0, root)
-    from phi_3_vision_mlx_amd import weights
-    return weights
+def round(a, decimals=0):      # noqa: A001
+    """mx.round: to the nearest integer, halves to even (the backends' `rint`), in the array's dtype."""
+    t = _arr(a)._t
+    if decimals != 0:
+        raise NotImplementedError("mlx shim: round(decimals != 0) is off the pinned path")
+    return array(torch.round(t.to(torch.float32)).to(t.dtype) if t.is_floating_point() else t)
 
 
+def clip(a, a_min=None, a_max=None):
+    """mx.clip = minimum(maximum(a, a_min), a_max)."""
+    out = _arr(a)
+    if a_min is not None:
+        out = maximum(out, a_min)
+    if a_max is not None:
+        out = minimum(out, a_max)
+    return out
+
+
+# The affine group quantiser.  The reference pins mlx==0.15.0 (requirements.txt:1), where `mx.quantize` / `mx.dequantize` are not
+# kernels but COMPOSITES of array primitives (mlx/ops.cpp; the fused affine_quantize kernel arrived with 0.17), restated here
+# primitive by primitive over this file's own array ops -- so every intermediate is an array of w's dtype and rounds to it, exactly as
+# the composite's intermediates do.  Nothing of the product is imported: `phi_3_vision_mlx_amd.weights.mlx_quantize` is a SECOND
+# statement of the same algorithm and tests/test_host_logic.py cross-checks the two bit for bit on random inputs.
 def quantize(w, group_size=64, bits=4):
-    packed, scales, biases = _q().mlx_quantize(_arr(w)._t, group_size, bits)
-    return array(packed), array(scales), array(biases)          # (uint32 bit patterns carried in int32)
+    """w [N, K] -> (uint32 words [N, K * bits / 32] carried as int32 bit patterns, scales [N, K / group], biases [N, K / group]):
+    per group  w ~ scale * q + bias,  q in 0 .. 2^bits - 1, the range end of larger magnitude represented exactly;
+    element k of a word at bits [bits * k, bits * (k + 1))."""
+    w = _arr(w)
+    if w.ndim != 2 or w.shape[1] % group_size or group_size % (32 // bits):
+        raise ValueError(f"[quantize] the last dimension ({w.shape}) must be divisible by the group size {group_size}")
+    dt = w.dtype
+    n_bins = (1 << bits) - 1
+    el_per_int = 32 // bits
+    shifts = array(torch.tensor([1 << sh for sh in range(0, 32, bits)], dtype=torch.int64)).reshape(1, 1, -1)    # power(2, arange(0, 32, bits))
+    packed_w = reshape(w, (w.shape[0], w.shape[1] // group_size, group_size))
+    w_max = max(packed_w, axis=-1, keepdims=True)
+    w_min = min(packed_w, axis=-1, keepdims=True)
+    mask = abs(w_min) > abs(w_max)
+    scales = maximum((w_max - w_min) / array(n_bins, dt), array(1e-7, dt))
+    scales = where(mask, scales, -scales)
+    edge = where(mask, w_min, w_max)
+    q0 = round(edge / scales)
+    scales = where(q0 != array(0, dt), edge / q0, scales)
+    biases = where(q0 == array(0, dt), array(0, dt), edge)
+    packed_w = clip(round((packed_w - biases) / scales), array(0.0, dt), array(n_bins, dt)).astype(uint32)
+    packed_w = reshape(packed_w, (w.shape[0], -1, el_per_int))
+    words = sum(packed_w * shifts, axis=2)._t                              # uint32 arithmetic (carried in int64: no wrap below 2^32)
+    words = torch.where(words >= 2 ** 31, words - 2 ** 32, words).to(torch.int32)
+    return array(words), reshape(scales, (w.shape[0], -1)), reshape(biases, (w.shape[0], -1))
+
+
+def _unpack(w, bits):
+    """The composite's shift pairs: element k of every word = (word << (32 - bits * (k + 1))) >> (32 - bits), as uint32."""
+    u = _arr(w)._t.to(torch.int64) & 0xFFFFFFFF
+    parts = [(((u << (32 - (start + bits))) & 0xFFFFFFFF) >> (32 - bits)).unsqueeze(-1) for start in range(0, 32, bits)]
+    return torch.cat(parts, dim=-1)
 
 
 def dequantize(w, scales, biases, group_size=64, bits=4):
-    """scale * q + bias, in the scales' dtype (one rounding for bf16 scales)."""
-    out = _q().mlx_dequantize(_arr(w)._t, _arr(scales)._t, _arr(biases)._t, group_size, bits)
-    return array(out.to(_arr(scales)._t.dtype))
+    """multiply(codes, scales) then add(., biases): two primitives, each rounding to the scales' dtype."""
+    s, b = _arr(scales), _arr(biases)
+    w_full = array(_unpack(w, bits).reshape(s.shape[0], -1, group_size).to(s._t.dtype))       # 0 .. 15: exact in every float dtype
+    w_full = w_full * expand_dims(s, -1)
+    w_full = w_full + expand_dims(b, -1)
+    return reshape(w_full, (s.shape[0], -1))
 
 
 def quantized_matmul(x, w, scales, biases, transpose=True, group_size=64, bits=4):
-    """x @ dequantize(w).T with the dequantised values and the accumulation in fp32; result in x.dtype."""
-    wd = _q().mlx_dequantize(_arr(w)._t, _arr(scales)._t, _arr(biases)._t, group_size, bits)
+    """x @ dequantize(w).T (documented semantics of the fused kernel): scale * q + bias and the accumulation in fp32, result in
+    x.dtype."""
+    s, b = _arr(scales)._t.float(), _arr(biases)._t.float()
+    wd = (_unpack(w, bits).reshape(s.shape[0], -1, group_size).float() * s[..., None] + b[..., None]).reshape(s.shape[0], -1)
     xt = _arr(x)._t
     return array(torch.matmul(xt.float(), wd.t() if transpose else wd).to(xt.dtype))
 
@@ -1086,7 +1131,7 @@ def install():
                   "flatten", "reshape", "transpose", "swapaxes", "pad", "triu", "tril", "where", "sum", "mean", "max", "min", "all",
                   "any", "argmax", "argmin", "argsort", "argpartition", "sort", "exp", "log", "cos", "sin", "sqrt", "rsqrt", "tanh",
                   "erf", "sigmoid", "abs", "square", "maximum", "minimum", "isinf", "isnan", "stop_gradient", "logsumexp", "softmax",
-                  "take", "load", "save_safetensors", "quantize", "dequantize", "quantized_matmul"]
+                  "take", "load", "save_safetensors", "quantize", "dequantize", "quantized_matmul", "round", "clip"]
     for n in core_names:
         setattr(core, n, getattr(me, n))
     fast = mk("mlx.core.fast")

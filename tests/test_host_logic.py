@@ -228,8 +228,52 @@ def test_mlx_int4_format_round_trip_and_checkpoint_loading(tmp_path):
     got = load_safetensors_dir(str(tmp_path / "q"), cfg_q)
     assert isinstance(got["model.layers.0.self_attn.qkv_proj.weight"], Q4Weight) and isinstance(got["lm_head.weight"], Q4Weight)
     emb = got["model.embed_tokens.weight"]
-    assert emb.dtype == torch.bfloat16 and torch.equal(emb, mlx_dequantize(*mlx_quantize(ws["model.embed_tokens.weight"])).to(torch.bfloat16))
+    # (the embedding table is an mx.dequantize ARRAY in the reference -- nn.QuantizedEmbedding -- multiply and add each rounding to bf16)
+    assert emb.dtype == torch.bfloat16 and torch.equal(emb, mlx_dequantize(*mlx_quantize(ws["model.embed_tokens.weight"]), dtype=torch.bfloat16))
     assert torch.equal(got["model.norm.weight"], ws["model.norm.weight"])
+
+
+@pytest.mark.parametrize("dtype", ["float32", "bfloat16", "float16"])
+@pytest.mark.parametrize("group", [32, 64])
+def test_two_independent_statements_of_mx_quantize_agree_bit_for_bit(dtype, group):
+    """The MLX stand-in the reference runs over (tests/golden/mlx_shim.py: mx.quantize / mx.dequantize as mlx 0.15.0's composites,
+    written over the stand-in's own array primitives, importing nothing of the product) and the product's quantiser
+    (weights.mlx_quantize / mlx_dequantize, straight torch) are two separately written statements of one algorithm: codes, scales
+    and biases must agree BIT FOR BIT on random inputs of every dtype -- both branches of the edge selection, all-zero, constant,
+    one-sided, denormal-range and huge groups included -- and so must the dequantised arrays.  (Until round 5 the stand-in
+    called the product's function: the reference-composed q4 fixtures compared the quantiser with itself.)"""
+    import torch
+    import mlx_shim as mx
+    from phi_3_vision_mlx_amd.weights import mlx_dequantize, mlx_quantize
+    assert "phi_3_vision_mlx_amd" not in open(mx.__file__).read().replace("`phi_3_vision_mlx_amd.weights.mlx_quantize`", "")
+    dt = getattr(torch, dtype)
+    as_bits = (lambda t: t.view(torch.int32)) if dt == torch.float32 else (lambda t: t.view(torch.int16))
+    gen = torch.Generator().manual_seed(group)
+    sides = set()
+    for trial in range(24):
+        std = (0.02, 3.0, 1e-4, 300.0)[trial % 4]
+        w = (torch.randn(48, 4 * group, generator=gen) * std).to(dt)
+        if trial % 3 == 0:
+            w[0] = 0                                              # all-zero groups: the scale clamps to 1e-7 (in w's dtype)
+            w[1] = 0.37                                           # constant groups
+            w[2, :group] = -w[2, :group].abs() - 0.01             # one-sided negative: the minimum is the exact edge
+            w[3, :group] = w[3, :group].abs() + 0.01              # one-sided positive
+            w[4, :group] = 0
+            w[4, 5] = 1e-9                                        # a range below the clamp
+            w[5, :group] = torch.linspace(-1, 1, group).to(dt)    # symmetric: |min| == |max| takes the maximum's branch
+        a_w, a_s, a_b = mx.quantize(mx.array(w), group, 4)
+        b_w, b_s, b_b = mlx_quantize(w, group, 4)
+        assert a_s._t.dtype == dt and b_s.dtype == dt
+        assert torch.equal(a_w._t, b_w), f"trial {trial}: packed codes differ"
+        assert torch.equal(as_bits(a_s._t), as_bits(b_s)) and torch.equal(as_bits(a_b._t), as_bits(b_b)), f"trial {trial}: scales / biases differ"
+        d_a = mx.dequantize(a_w, a_s, a_b, group, 4)._t
+        assert d_a.dtype == dt and torch.equal(as_bits(d_a), as_bits(mlx_dequantize(b_w, b_s, b_b, group, 4, dtype=dt)))
+        sides |= set((b_s.float() > 0).unique().tolist())
+        g_ = w.float().reshape(48, 4, group)
+        step = (g_.amax(-1) - g_.amin(-1)) / 15
+        slack = 2.0 ** -7 * g_.abs().amax(-1) if dt != torch.float32 else 0.0    # narrow dtypes: each primitive's own rounding
+        assert ((d_a.float().reshape(48, 4, group) - g_).abs() <= (1.01 * step + 1e-6 + slack)[..., None]).all(), "not within a step"
+    assert sides == {False, True}                                 # both signs of the scale were exercised
 
 
 @pytest.mark.parametrize("name", ["mlx_quantize_doc_example.json", "mlx_quantize_doc_example2.json"])

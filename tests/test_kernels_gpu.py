@@ -778,9 +778,9 @@ def test_gemm_qkv_declines_what_it_cannot_fuse(ops):
 @pytest.mark.parametrize("B,nkv,T,n_tok", [(1, 32, 384, 300), (2, 4, 128, 128), (1, 2, 64, 5)])
 def test_kv_quantize_mlx4_is_mx_quantize(ops, B, nkv, T, n_tok):
     """p3v_kv_quantize_mlx4 (the reference's own prompt-cache format, phi.py:528-540) against the MLX group quantiser
-    (weights.mlx_quantize: group 32, 4 bits, fp32 scales as for the reference's fp32 keys) on the same bf16 rows: codes, scales and
-    biases BIT-IDENTICAL for K (token-major) and V (stored transposed), the cache rows rewritten with scale * q + bias rounded to
-    bf16, rows beyond n_tok untouched."""
+    (weights.mlx_quantize: group 32, 4 bits; fp32 arithmetic for the reference's fp32 keys, every primitive of mlx 0.15.0's composite
+    rounding to bf16 for its bf16 values) on the same bf16 rows: codes, scales and biases BIT-IDENTICAL for K (token-major) and V
+    (stored transposed), the cache rows rewritten with mx.dequantize's values, rows beyond n_tok untouched."""
     from phi_3_vision_mlx_amd.weights import mlx_dequantize, mlx_quantize
     hd = 96
     k = g((B, nkv, T, hd), 300, 1.5)
@@ -801,7 +801,8 @@ def test_kv_quantize_mlx4_is_mx_quantize(ops, B, nkv, T, n_tok):
         pw, ps, pb = mlx_quantize(flat.float() if name == "K" else flat, 32, 4)
         assert torch.equal(c4.cpu().reshape(B * nkv, -1), pw), f"{name}: codes differ from mx.quantize"
         assert torch.equal(sb.cpu()[..., 0].reshape(B * nkv, -1), ps.float()) and torch.equal(sb.cpu()[..., 1].reshape(B * nkv, -1), pb.float()), f"{name}: scale / bias"
-        deq = mlx_dequantize(pw, ps, pb, 32, 4).to(BF16).reshape(B, nkv, n_tok, hd)
+        # mx.dequantize: fp32 arrays for the keys (then the cache's bf16), bf16 arrays -- multiply and add each rounding -- for V
+        deq = (mlx_dequantize(pw, ps, pb, 32, 4).to(BF16) if name == "K" else mlx_dequantize(pw, ps, pb, 32, 4, dtype=BF16)).reshape(B, nkv, n_tok, hd)
         assert torch.equal(back.cpu()[:, :, :n_tok], deq), f"{name}: rows not rewritten with the dequantised values"
         assert torch.equal(back.cpu()[:, :, n_tok:], src[:, :, n_tok:]), f"{name}: rows beyond n_tok touched"
 

@@ -384,7 +384,7 @@ def test_mlx4_prompt_cache_is_the_references_semantics():
     S, hd = 70, plain.hd
     rows = sa.v.transpose(3, 4)[:, :, :, :S].float().cpu()                           # [nl, B, nkv, S, hd]
     nl, B, nkv = rows.shape[:3]
-    deq = mlx_dequantize(*mlx_quantize(rows.to(BF16).reshape(nl * B * nkv, S * hd), 32, 4), 32, 4).to(BF16).reshape(nl, B, nkv, S, hd).cuda()
+    deq = mlx_dequantize(*mlx_quantize(rows.to(BF16).reshape(nl * B * nkv, S * hd), 32, 4), 32, 4, dtype=BF16).reshape(nl, B, nkv, S, hd).cuda()
     assert torch.equal(sb.v[..., :S], deq.transpose(3, 4)), "V rows are not mx.dequantize(mx.quantize(V)) of the bf16 values"
     krt = sa.k[:, :, :, :S].float().cpu()
     kdq = mlx_dequantize(*mlx_quantize(krt.reshape(nl * B * nkv, S * hd), 32, 4), 32, 4).reshape(nl, B, nkv, S, hd)
