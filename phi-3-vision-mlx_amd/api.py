@@ -382,6 +382,7 @@ def greedy_loop(model, token, cache, n_steps, streamer, token_stopper, logit_sto
             # go on.  Anything else -- or a second failure -- is raised.
             g = st.graphs.get("greedy")
             if degraded or g is None or not g["bufs"].get("fuse_o", False):
+                st.mark_dirty() if hasattr(st, "mark_dirty") else None    # (a captured-prefill entry on these buffers is dropped)
                 raise
             degraded = True
             torch.cuda.synchronize()

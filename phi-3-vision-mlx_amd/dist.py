@@ -124,26 +124,60 @@ def _all_gather_ragged(t, group=None):
     return [b[:k].cpu() for b, k in zip(bufs, ns)]
 
 
+_K_TEXT, _K_INTS, _K_FLOATS, _K_INT, _K_FLOAT = 0, 1, 2, 3, 4
+
+
+def _encode_result(r):
+    """One result -> (kind, int32 words).  Texts (utf-8 bytes, one per word), integer sequences / scalars, float sequences / scalars
+    (float64 bit patterns, two words each: nothing is truncated); anything else raises instead of being coerced."""
+    import numbers
+    import struct
+    if isinstance(r, str):
+        return _K_TEXT, list(r.encode("utf-8"))
+    if torch.is_tensor(r):
+        r = r.tolist()
+    elif hasattr(r, "tolist") and not isinstance(r, (list, tuple)):
+        r = r.tolist()                                              # numpy arrays / scalars
+    scalar = not isinstance(r, (list, tuple))
+    vals = [r] if scalar else list(r)
+    if all(isinstance(v, numbers.Integral) and not isinstance(v, bool) for v in vals):
+        if any(not -2 ** 31 <= int(v) < 2 ** 31 for v in vals):
+            raise TypeError("gather_results: integer results must fit int32")
+        return (_K_INT if scalar else _K_INTS), [int(v) for v in vals]
+    if all(isinstance(v, numbers.Real) and not isinstance(v, bool) for v in vals):
+        words = []
+        for v in vals:
+            words += struct.unpack("<ii", struct.pack("<d", float(v)))
+        return (_K_FLOAT if scalar else _K_FLOATS), words
+    raise TypeError(f"gather_results carries texts, integer or real sequences and scalars, not {type(r).__name__} of "
+                    f"{sorted({type(v).__name__ for v in vals})}")
+
+
+def _decode_result(kind, words):
+    import struct
+    if kind == _K_TEXT:
+        return bytes(words).decode("utf-8")
+    if kind in (_K_INTS, _K_INT):
+        return words[0] if kind == _K_INT else words
+    vals = [struct.unpack("<d", struct.pack("<ii", words[i], words[i + 1]))[0] for i in range(0, len(words), 2)]
+    return vals[0] if kind == _K_FLOAT else vals
+
+
 def pack_results(local_idx, local_results):
-    """This rank's results as ONE int32 tensor: [n, kind | request ids | lengths | payload], kind 0 = texts (payload: utf-8 bytes,
-    one per word), 1 = token lists.  (Round 5: the result gather used to pickle Python objects through all_gather_object.)"""
-    res = list(local_results)
-    is_text = [isinstance(r, str) for r in res]
-    if res and any(is_text) != all(is_text):
-        raise TypeError("gather_results: a rank's results are all texts or all token lists")
-    kind = 0 if (not res or is_text[0]) else 1
-    seqs = [list(r.encode("utf-8")) if kind == 0 else [int(v) for v in r] for r in res]
-    flat = [len(res), kind] + [int(i) for i in local_idx] + [len(q) for q in seqs] + [v for q in seqs for v in q]
+    """This rank's results as ONE int32 tensor: [n | request ids | kinds | lengths | payload] (kinds: `_encode_result`).
+    (Round 5: the result gather used to pickle Python objects through all_gather_object; round 6: typed per result, so float
+    scores and scalar results survive a world > 1 gather unchanged instead of being truncated / raising.)"""
+    enc = [_encode_result(r) for r in local_results]
+    flat = [len(enc)] + [int(i) for i in local_idx] + [k for k, _ in enc] + [len(q) for _, q in enc] + [v for _, q in enc for v in q]
     return torch.tensor(flat, dtype=torch.int32)
 
 
 def unpack_results(t, out):
     v = t.tolist()
-    n, kind = v[0], v[1]
-    idx, lens, off = v[2:2 + n], v[2 + n:2 + 2 * n], 2 + 2 * n
-    for i, ln in zip(idx, lens):
-        seq = v[off:off + ln]
-        out[i] = bytes(seq).decode("utf-8") if kind == 0 else seq
+    n = v[0]
+    idx, kinds, lens, off = v[1:1 + n], v[1 + n:1 + 2 * n], v[1 + 2 * n:1 + 3 * n], 1 + 3 * n
+    for i, kind, ln in zip(idx, kinds, lens):
+        out[i] = _decode_result(kind, v[off:off + ln])
         off += ln
 
 
@@ -153,7 +187,7 @@ def gather_results(local_idx, local_results, n_total, group=None):
     out = [None] * n_total
     if world == 1:
         for i, r in zip(local_idx, local_results):
-            out[i] = r
+            out[i] = _decode_result(*_encode_result(r))           # (the same validation and value types as a world > 1 gather)
         return out
     for t in _all_gather_ragged(pack_results(local_idx, local_results), group):
         unpack_results(t, out)
@@ -181,7 +215,8 @@ def sync_weights(weights, src=0, group=None):
 
 
 def run_sharded(n_requests, worker, group=None):
-    """`worker(indices) -> list of results` on this rank's shard; returns the gathered, ordered list."""
+    """`worker(indices) -> list of results` on this rank's shard; returns the gathered, ordered list.  A result is a text, a sequence
+    of integers (int32) or reals, or an integer / real scalar (`pack_results`); anything else raises TypeError on every world size."""
     rank, world = _world(group)
     idx = shard_indices(n_requests, rank, world)
     local = worker(idx) if idx else []

@@ -22,6 +22,7 @@ Dtype flow differs from the reference only where stated in DESIGN.md
 tolerance the parity tests state.
 """
 import math
+import copy
 import os
 
 import numpy as np
@@ -105,7 +106,12 @@ class CacheState:
         self.cos = self.sin = self.pad_len = None
         self.graphs = {}
         self.epoch = None                                       # model.epoch the graphs were captured under
+        self.shared = {"dirty": False}                          # shared by the per-request views of a captured-prefill entry (copy.copy)
 
+    def mark_dirty(self):
+        """An unrecovered failed step may have left NaN rows beyond the offset and half-armed buffers in the decode graph: a
+        captured-prefill entry built on these buffers must not be reused (model._prefill_captured drops it)."""
+        self.shared["dirty"] = True
 
     def scrub(self, lo, hi):
         """Forget cache positions [lo, hi) that a FAILED step wrote (api.greedy_loop's recovery): a poisoned step leaves NaN there,
@@ -123,15 +129,11 @@ class CacheState:
             self.k[:, :, :, lo:hi] = 0
 
 
-class _Lease:
-    """Held by the cache views of one captured-prefill call: while it lives, the entry's buffers belong to that caller."""
-
-
 class LayerCache:
     """`cache[i]` view with the reference's `.offset` attribute."""
 
-    def __init__(self, state, i, lease=None):
-        self.state, self.i, self.lease = state, i, lease
+    def __init__(self, state, i):
+        self.state, self.i = state, i
 
     @property
     def offset(self):
@@ -155,7 +157,6 @@ class Phi3VModel:
         self.hd = head_dim(cfg)
         if self.hd != 96:
             raise ValueError(f"decoder head_dim must be 96 (got {self.hd})")
-        self._state = None
         self.hidden_hook = None                      # fn(layer, x [B*L, H], B, L) after every decoder layer (diagnostics)
         self.w8 = {}
         self.adapters = {}                           # weight key -> (lora_a, lora_b, scale), see set_adapters
@@ -803,7 +804,6 @@ class Phi3VModel:
         if prefill:
             st = self._new_state(B, L, max_tokens, pids, mask)
             cache = [LayerCache(st, i) for i in range(cfg.num_hidden_layers)]
-            self._state = st
         else:
             st = cache[0].state
         past = st.offset
@@ -824,18 +824,24 @@ class Phi3VModel:
     # ------------------------------------------------------------------ captured prefill of short text prompts
     PREFILL_GRAPH_MAX_S = 512
     PREFILL_GRAPH_ENTRIES = 4
+    PREFILL_GRAPH_MAX_CACHE_BYTES = 2 << 30                       # an entry pins its (S + max_tokens) KV cache: 393 KB per token at full size
 
     def _prefill_captured(self, ids, S, max_tokens):
         """Short text prompts (B = 1, 17 .. 512 tokens) are launch-bound: ~390 launches of a few microseconds each, every one paid
         for in Python + ctypes time (BASELINE config 1: 4.5 ms of wall time for 3.6 ms of kernels).  A (length, max_tokens) pair seen
         for the SECOND time is captured as ONE hipGraph over buffers the entry owns -- ids, activations, rotation tables, the KV
         cache itself -- and later prompts of that geometry cost one 0.5 KB copy + one graph launch.  The entry's cache is LEASED to
-        the caller: while any of the returned cache views is alive a new prompt of the same geometry takes the eager path, so a
-        caller that keeps two caches gets two caches (the reference's contract).  Bit-identical to the eager path (same kernels, same
-        order).  P3V_PREFILL_GRAPH=0 switches it off.  Returns None when not applicable."""
+        the caller: every call gets its own CacheState object (a shallow copy of the entry's: same tensors, same decode graphs, its
+        own offset) and the lease IS that object -- while it is alive, through the returned cache list or through a kept
+        `cache[i].state`, a new prompt of the same geometry takes the eager path, so a caller that keeps two caches gets two caches
+        (the reference's contract).  An entry whose caller died in an unrecovered failed step is dropped (`CacheState.mark_dirty`),
+        and entries whose cache would exceed PREFILL_GRAPH_MAX_CACHE_BYTES are not made.  Bit-identical to the eager path (same
+        kernels, same order).  P3V_PREFILL_GRAPH=0 switches it off.  Returns None when not applicable."""
         cfg = self.cfg
         if (os.environ.get("P3V_PREFILL_GRAPH", "1") == "0" or S <= ops.L.DECODE_MAX_L or S > self.PREFILL_GRAPH_MAX_S or max_tokens < 1
                 or getattr(cfg, "use_quantized_cache", False) or self.adapters or self.hidden_hook is not None or self.w8 or self.w4):
+            return None
+        if 4 * cfg.num_hidden_layers * cfg.num_key_value_heads * self.hd * (S + max_tokens + 256) > self.PREFILL_GRAPH_MAX_CACHE_BYTES:
             return None
         # the graph bakes in the rotation tables and the weight pointers: both are part of the key (tests mutate `cfg` and swap weight
         # tensors on a live model; in-place weight updates are seen by the graph as they are by every launch)
@@ -855,7 +861,12 @@ class Phi3VModel:
             e = self._prefill_graphs[key] = self._build_prefill_graph(S, max_tokens)
         if e["lease"] is not None and e["lease"]() is not None:    # the previous caller still holds this entry's cache
             return None
-        st = e["st"]
+        if e["st"].shared["dirty"]:                               # its last caller died in a failed step: NaN rows, half-armed buffers
+            del self._prefill_graphs[key]
+            self._prefill_seen[key] = 1                           # (the next prompt of this geometry captures afresh)
+            return None
+        st = copy.copy(e["st"])                                   # this call's state: the entry's tensors and graphs, its own offset
+        self._states.add(st)
         e["ids"].copy_(ids.view(-1), non_blocking=True)
         st.offset = 0
         g = st.graphs.get("greedy")
@@ -864,10 +875,8 @@ class Phi3VModel:
             g["d_step"].zero_()
         e["graph"].launch()
         st.offset = S
-        self._state = st
-        lease = _Lease()
-        e["lease"] = weakref.ref(lease)
-        return e["logits"].clone().view(1, 1, cfg.vocab_size), [LayerCache(st, i, lease) for i in range(cfg.num_hidden_layers)]
+        e["lease"] = weakref.ref(st)
+        return e["logits"].clone().view(1, 1, cfg.vocab_size), [LayerCache(st, i) for i in range(cfg.num_hidden_layers)]
 
     def _build_prefill_graph(self, S, max_tokens):
         cfg, w, dev = self.cfg, self.w, self.device

@@ -115,6 +115,17 @@ def _worker_generate(rank, world, port, out_dir):
     assert isinstance(texts, list) and len(texts) == 7 and all(isinstance(t, str) for t in texts)
     uni = pd.gather_results([rank], ["r\u00e9sum\u00e9 \u2713 %d" % rank], world)      # non-ASCII text survives the byte packing
     assert uni == ["r\u00e9sum\u00e9 \u2713 0", "r\u00e9sum\u00e9 \u2713 1"], uni
+    # typed results: float scores are not truncated, scalar results and mixed kinds survive a world-2 gather
+    assert pd.run_sharded(5, lambda idx: [i * i for i in idx]) == [0, 1, 4, 9, 16]
+    assert pd.run_sharded(4, lambda idx: [[0.1 * i, -1e-30, 3.0e300] for i in idx]) == [[0.1 * i, -1e-30, 3.0e300] for i in range(4)]
+    mixed = pd.gather_results([rank, rank + 2], [0.5 + rank, "t%d" % rank] if rank == 0 else [[1, -2, 3], 7], 4)
+    assert mixed == [0.5, [1, -2, 3], "t0", 7], mixed
+    for bad in ([object()], [[1, "a"]], [2 ** 40], [{"a": 1}]):
+        try:
+            pd.pack_results([0], bad)
+            raise AssertionError(f"pack_results accepted {bad!r}")
+        except TypeError:
+            pass
     dist.barrier()
     dist.destroy_process_group()
     open(os.path.join(out_dir, f"gen{rank}"), "w").write("ok")

@@ -205,10 +205,10 @@ def test_captured_short_prompt_prefill_equals_eager(text, monkeypatch):
     l2, c2 = model(input_ids=ids_a, max_tokens=6)                # second: captured and replayed
     assert len(model._prefill_graphs) == 1 and next(iter(model._prefill_graphs))[:2] == (57, 6)
     entry_state = next(iter(model._prefill_graphs.values()))["st"]
-    assert c2[0].state is entry_state
+    assert c2[0].state is not entry_state and c2[0].state.k.data_ptr() == entry_state.k.data_ptr()    # its own state object over the entry's buffers
     assert torch.equal(l2, ref["a"][0]) and torch.equal(entry_state.k[:, :, :, :57], ref["a"][1]) and torch.equal(entry_state.v[..., :57], ref["a"][2])
     l3, c3 = model(input_ids=ids_b, max_tokens=6)                # c2 still alive: the entry is leased -> a state of its own
-    assert c3[0].state is not entry_state and torch.equal(l3, ref["b"][0])
+    assert c3[0].state.k.data_ptr() != entry_state.k.data_ptr() and torch.equal(l3, ref["b"][0])
     t = ops.argmax(l2[:, -1, :].contiguous())[:, None]           # the leased cache is intact and decodes as the eager one did
     toks = []
     for _ in range(4):
@@ -217,13 +217,41 @@ def test_captured_short_prompt_prefill_equals_eager(text, monkeypatch):
     assert torch.equal(torch.cat(toks, 1), ref["a"][3])
     del c2, c3
     l4, c4 = model(input_ids=ids_b, max_tokens=6)                # lease released: the entry again, other prompt, decode graph reused
-    assert c4[0].state is entry_state and torch.equal(l4, ref["b"][0])
+    assert c4[0].state.k.data_ptr() == entry_state.k.data_ptr() and torch.equal(l4, ref["b"][0])
     t = ops.argmax(l4[:, -1, :].contiguous())[:, None]
     toks = []
     for _ in range(4):
         _, t = model.greedy_step(t, c4)
         toks.append(t.clone())
     assert torch.equal(torch.cat(toks, 1), ref["b"][3])
+    # the lease is the STATE, not the list: a caller that keeps `cache[0].state` and drops the list still owns the buffers
+    st4 = c4[0].state
+    del c4
+    l6, c6 = model(input_ids=ids_a, max_tokens=6)
+    assert c6[0].state.k.data_ptr() != entry_state.k.data_ptr() and torch.equal(l6, ref["a"][0])
+    assert torch.equal(st4.k[:, :, :, :57], ref["b"][1]) and torch.equal(st4.v[..., :57], ref["b"][2]) and st4.offset == 57 + 4
+    del st4, c6
+    # an entry whose caller died in an unrecovered failed step is dropped, and the geometry captures afresh
+    l7, c7 = model(input_ids=ids_a, max_tokens=6)
+    assert c7[0].state.k.data_ptr() == entry_state.k.data_ptr()
+    c7[0].state.mark_dirty()
+    del c7
+    l8, c8 = model(input_ids=ids_a, max_tokens=6)                # dirty: dropped, eager
+    assert not model._prefill_graphs and torch.equal(l8, ref["a"][0])
+    del c8
+    l9, c9 = model(input_ids=ids_b, max_tokens=6)                # captured again on fresh buffers
+    assert len(model._prefill_graphs) == 1 and torch.equal(l9, ref["b"][0])
+    del c9
+    big = model.PREFILL_GRAPH_MAX_CACHE_BYTES
+    try:                                                          # the entry's cache is capped
+        type(model).PREFILL_GRAPH_MAX_CACHE_BYTES = 1
+        model._prefill_graphs.clear(), model._prefill_seen.clear()
+        for _ in range(3):
+            lx, cx = model(input_ids=ids_a, max_tokens=6)
+            del cx
+        assert not model._prefill_graphs and not model._prefill_seen and torch.equal(lx, ref["a"][0])
+    finally:
+        type(model).PREFILL_GRAPH_MAX_CACHE_BYTES = big
     l5, _ = model(input_ids=rand_ids(58, 43), max_tokens=6)      # another length: eager (first sighting), nothing captured for it
     assert all(k[:2] != (58, 6) for k in model._prefill_graphs) and torch.isfinite(l5.float()).all()
     model._prefill_graphs.clear(), model._prefill_seen.clear()
@@ -1260,8 +1288,12 @@ def test_int4_weights_full_size_decode_matches_dequantised_model():
     torch.cuda.empty_cache()
 
 
-def test_int4_weights_vs_live_oracle_on_mlx_dequantised_weights():
-    """The reference's `quantize_model=True` format (4-bit group-64, `nn.quantize`, phi_3_vision_mlx.py:264,297-305) against
+@pytest.mark.parametrize("path,prefill_bound", [("tiles128", 0.045), ("default", 0.065)])
+def test_int4_weights_vs_live_oracle_on_mlx_dequantised_weights(path, prefill_bound):
+    """(the prefill bound went 0.045 -> 0.065 when the 160-row GEMMs moved to the 128 x 64 weight-streaming tiles; the old
+    bound is still asserted on the path it was measured on -- `gemm_no_skinny` pins the 128 x 128 tiles -- and the new one on the
+    launcher's own choice, with the measured values printed so drift is visible.)
+    The reference's `quantize_model=True` format (4-bit group-64, `nn.quantize`, phi_3_vision_mlx.py:264,297-305) against
     the ORACLE, not against the HIP path itself: a 2-layer model of the full width (H = 3072, I = 8192, V = 32064 -- the
     shapes `p3v_gemv_q4` takes) built from MLX-format tensors (`Q4Weight`: packed codes + bf16 scales / biases, the same
     objects an MLX `*_Q` checkpoint loads into), vs the oracle on `mx.dequantize`'s arithmetic -- scale * q + bias in fp32,
@@ -1288,24 +1320,30 @@ def test_int4_weights_vs_live_oracle_on_mlx_dequantised_weights():
     ids = np.random.default_rng(8).integers(3, 32000, (1, 160)).astype(np.int64)
     n = 5
     ref, oc = oracle(input_ids=ids, max_tokens=n)
-    got, cache = model(input_ids=ids, max_tokens=n)
+    from phi_3_vision_mlx_amd import ops
+    old = ops.set_tuning("gemm_no_skinny", int(path == "tiles128"))
+    try:
+        got, cache = model(input_ids=ids, max_tokens=n)
+        torch.cuda.synchronize()
+    finally:
+        ops.set_tuning("gemm_no_skinny", old)
     worst, n_tok = [], 0
     for step in range(n):
         r, gl = ref[:, -1].float(), got[:, -1].float().cpu()
         worst.append(((gl - r).abs().amax() / r.abs().amax()).item())
         v, i = r.topk(2, dim=-1)
-        if (v[0, 0] - v[0, 1]) > 2 * (0.065 if step == 0 else 0.03) * r.abs().amax():     # clear under the tolerance asserted below
+        if (v[0, 0] - v[0, 1]) > 2 * (prefill_bound if step == 0 else 0.03) * r.abs().amax():     # clear under the tolerance asserted below
             assert int(gl.argmax(-1)) == int(i[0, 0]), (step, int(gl.argmax(-1)), int(i[0, 0]))
             n_tok += 1
         if step + 1 < n:
             tok = torch.argmax(r, dim=-1)[:, None]
             ref, oc = oracle(input_ids=tok, cache=oc)
             got, _ = model.greedy_step(tok.to("cuda:0", torch.int32), cache)
-    print("int4 vs oracle: worst logit error per step (fraction of max|logit|):", [round(x, 4) for x in worst], "tokens pinned:", n_tok)
+    print(f"int4 vs oracle [{path}]: worst logit error per step (fraction of max|logit|):", [round(x, 4) for x in worst], "tokens pinned:", n_tok)
     # measured 0.032-0.053 (prefill: every weight rounded once more, to bf16; the worst of 32064 logits moves that much with the
     # fp32 summation order of the 160-row GEMMs alone: 0.041 on the 128 x 128 tiles, 0.050 / 0.053 on the 128 x 64 ones in one pass /
     # in K slices) and 0.011-0.024 (decode: exact 4-bit products)
-    assert worst[0] <= 0.065 and max(worst[1:]) <= 0.03 and n_tok >= 3, (worst, n_tok)
+    assert worst[0] <= prefill_bound and max(worst[1:]) <= 0.03 and n_tok >= 3, (path, worst, n_tok)
     del model, cache
     torch.cuda.empty_cache()
 
