@@ -260,6 +260,13 @@ typedef struct {
 int p3v_attention_decode(const p3v_attn_decode_args_t* args /* host */, void* stream);
 /* 1 when the fused attention + o_proj launch takes this shape on this device (host query, no launch) */
 int p3v_attention_decode_can_fuse_oproj(int B, int L, int n_heads, int hd, int n_split, int cache_t, int o_n, int merge_in_launch);
+/* Which role workgroup `wg` of the fused launch's 1-D grid (n_heads * n_split workgroups) plays under placement `map` (the
+ * attn_fo_map tuning knob: 2 = default, 1 = the round's first form): out[0] = key split, out[1] = head, out[2] / out[3] = its
+ * projection units (rows [8 u, 8 u + 8) of o_proj; -1 = none).  Split n_split - 1 of a head is its merging workgroup.  Workgroups
+ * L and L +- 256 share a CU on this part (round-robin dispatch), which is what the placement is built on: mergers sit alone with
+ * one tile-only workgroup, projection units ride on the last workgroup of every other CU.  Returns P3V_ERR_UNSUPPORTED for shapes
+ * the placement does not cover (the launch then uses the (split, head) grid).  Host-only, no GPU needed: tests/test_abi.py. */
+int p3v_attention_decode_fused_role(int wg, int n_heads, int n_split, int o_n, int map, int* out4);
 /* cos/sin rows of positions [past, past+L) of each batch row ([B, tab_t, half] tables) -> [B, L, half] */
 int p3v_stage_rope(const float* cos_t, const float* sin_t, int past, const int32_t* d_past,
                    float* cos_out, float* sin_out, int B, int L, int tab_t, int half_dim, void* stream);

@@ -101,6 +101,7 @@ SIGNATURES = {
     "p3v_attention": (i32, [C.POINTER(AttnArgs), vp]),
     "p3v_attention_decode": (i32, [C.POINTER(AttnDecArgs), vp]),
     "p3v_attention_decode_can_fuse_oproj": (i32, [i32, i32, i32, i32, i32, i32, i32, i32]),
+    "p3v_attention_decode_fused_role": (i32, [i32, i32, i32, i32, i32, C.POINTER(i32)]),
     "p3v_kv_quantize": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "p3v_kv_dequantize": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "p3v_gemm_qkv": (i32, [vp, vp, vp]),

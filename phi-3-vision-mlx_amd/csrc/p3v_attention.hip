@@ -1364,6 +1364,7 @@ struct AttnDecP {
   bf16_t* o_x;                 // residual stream row [o_n]: x += bf16(W_o . attention output), in place
   bf16_t* o_rearm;             // the OTHER attention-output buffer: set to the all-ones sentinel by this launch
   int o_n;
+  int fo_remap;                // fused launch: 1-D grid with the roles placed by virtual CU (fo_map) instead of the (split, head) grid
 };
 
 // ---- fused split-KV merge ("last workgroup merges") without flags.  `ws` holds the SENTINEL bit pattern (all ones: a
@@ -1393,6 +1394,13 @@ extern "C" int p3v_timing_read(long long* out, int n) {
 __device__ __forceinline__ void st_wt(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ float ld_wt(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ bool is_sentinel(float v) { return __builtin_bit_cast(uint32_t, v) == WS_SENTINEL; }
+// Round 6: 16- and 8-byte write-through stores for the sentinels a merge puts back (24 x 16 bytes + 8 per record instead of 98 dword
+// stores: a write-through `sc1` store leaves the CU as one fabric write per lane whatever its width, MI355X_MICROARCH.md).  The same
+// widening of the partial records and of the merged row was built and measured SLOWER (+25 us per decode step: the wide stores of a
+// record become visible to the polling merger ~0.5 us later; profiles/r06_attn_oproj_placement.txt), so those stay dword stores.
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void st_wt4(void* p, f32x4_t v) { asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory"); }
+__device__ __forceinline__ void st_wt2(void* p, f32x2_t v) { asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory"); }
 
 // merge of the n_split partials of one (b, head) by the calling workgroup (NT threads = G groups of 64 lanes).
 // own: the calling workgroup's partial (split n_split - 1) in LDS, [16][HD + 2] like a `ws` record, or nullptr when it
@@ -1506,9 +1514,14 @@ __device__ __forceinline__ void split_merge(float* base0, bf16_t* out0, size_t o
     }
     TMARK(5);
     for (int s = grp; s < n_glob; s += G) {                    // sentinel back (after the output: off its path): ready for the next launch
-      st_wt(base + s * sstr + d0, sentinel);
-      if (two) st_wt(base + s * sstr + d0 + 64, sentinel);
-      if (d0 == 0) { st_wt(base + s * sstr + HD, sentinel); st_wt(base + s * sstr + HD + 1, sentinel); }
+      if ((q & 1) == 0) {                                      // (even rows of a record are 16-byte aligned: 24 x 16 bytes + 8)
+        if (d0 < 24) st_wt4(base + s * sstr + 4 * d0, (f32x4_t){sentinel, sentinel, sentinel, sentinel});
+        else if (d0 == 24) st_wt2(base + s * sstr + HD, (f32x2_t){sentinel, sentinel});
+      } else {
+        st_wt(base + s * sstr + d0, sentinel);
+        if (two) st_wt(base + s * sstr + d0 + 64, sentinel);
+        if (d0 == 0) { st_wt(base + s * sstr + HD, sentinel); st_wt(base + s * sstr + HD + 1, sentinel); }
+      }
     }
   }
 }
@@ -1851,6 +1864,42 @@ __device__ __forceinline__ void attn_decode_body(const AttnDecP& p, const int bx
 // arithmetic (lane l holds chunks l, l + 64, ..; dot8 in chunk order; DPP wave sum; resid + bf16 round), so the step's results do
 // not depend on whether the projection was fused.  One launch (~5 us) and its boundary leave the layer.  The attention output
 // lives in two buffers used by alternate layers: a launch re-arms the one it does not use.
+// Round 6: WHERE the roles of the fused launch sit.  Measured (tools/scratch/wg_census_r6.hip): workgroup L of a launch whose
+// workgroups are all resident runs on XCD L % 8 and shares its CU with workgroups L +- 256 -- the dispatcher deals them round
+// robin over the 256 CUs -- so "virtual CU" v = L % 256, slot = L / 256 says who is co-resident with whom (for speed only: nothing
+// below is needed for correctness).  With the (split, head) grid of rounds 4-5 the 32 merging workgroups shared their CUs with
+// workgroups streaming 48 KB of W_o each, whose loads sit in the same per-CU memory queue as the merger's polls (a hand-over costs
+// 1.1 us into a quiet CU, 2.5-2.9 us into a streaming one: MI355X_MICROARCH.md, handoff-1to1), and W_o requests of a CU's first
+// workgroup got ahead of its last workgroup's tile DMA.  Now: G = heads x splits workgroups as a 1-D grid; CUs v < r = G % 256
+// carry G / 256 + 1 workgroups, the others G / 256; the mergers are the LAST workgroup of CUs 224 .. 255 (always light CUs: r is
+// a multiple of 32 <= 224 with 32 heads), nobody on those CUs streams W_o; the 384 projection units (4 row pairs each) go to the
+// last workgroup of every other CU (224 units: their tile is the last of the CU to land, so their W_o requests never precede a
+// tile); the remaining 160 units ride on the same workgroups of the least loaded CUs as a second row pair per wave (two_on_last)
+// or, the first form of this round, on the second-to-last workgroups (attn_fo_map = 1: their requests precede the CU's last tile
+// unless held back ~7.75 us after entry, a gate that would have to follow the cache length; profiles/r06_attn_oproj_placement.txt).
+struct FoMap { int bx, by, o_unit, o_unit2; };
+__host__ __device__ __forceinline__ bool fo_map_ok(int n_split, int nh, int o_n) { return nh == 32 && o_n == 3072 && n_split >= 13 && n_split * nh <= 768; }
+__host__ __device__ __forceinline__ FoMap fo_map(int L, int n_split, int nh, int n_units, bool two_on_last) {
+  const int G = n_split * nh, base = G >> 8, r = G & 255;
+  const int v = L & 255, slot = L >> 8, ns = base + (v < r ? 1 : 0);
+  const int m0 = (base - 1) * 256 + 224;                       // the mergers: ids m0 .. m0 + 31
+  FoMap m;
+  m.o_unit = m.o_unit2 = -1;
+  if (L >= m0 && L < m0 + 32) { m.by = L - m0; m.bx = n_split - 1; return m; }
+  const int before = L - m0 < 0 ? 0 : (L - m0 > 32 ? 32 : L - m0);
+  const int u = L - before;                                    // rank among the non-merging workgroups: (head, split) head-major
+  m.by = u / (n_split - 1);
+  m.bx = u - m.by * (n_split - 1);
+  if (v < 224) {
+    const int from_last = ns - 1 - slot;
+    const int idx = base >= 2 || two_on_last ? (v >= r ? v - r : (224 - r) + v) : v;   // second units: light CUs first (one workgroup per light CU and
+    const int second = 224 + idx < n_units ? 224 + idx : -1;                             // second-to-last placement: only heavy CUs have a second workgroup)
+    if (from_last == 0) { m.o_unit = v; if (two_on_last) m.o_unit2 = second; }
+    else if (from_last == 1 && !two_on_last) m.o_unit = second;
+  }
+  return m;
+}
+
 #ifndef P3V_FO_SLEEP
 #define P3V_FO_SLEEP 4
 #endif
@@ -1861,36 +1910,45 @@ __device__ __forceinline__ void attn_decode_body(const AttnDecP& p, const int bx
 // else uses any more.
 enum { FO_NONE = 0, FO_BF16 = 1, FO_F8 = 2, FO_Q4 = 3 };
 struct FoP { const void* o_w; const void* o_scale; bf16_t* o_x; const bf16_t* out; int nh; };
-template <int KIND>
-__device__ __forceinline__ void fo_project(const FoP f, const int o_wl, unsigned char* lds) {
+template <int KIND, int NU = 1>                                // NU = 2: the workgroup may carry a SECOND unit (o_wl2 >= 0): two row pairs per wave
+__device__ __forceinline__ void fo_project(const FoP f, const int o_wl, unsigned char* lds, const int o_wl2 = -1) {
   constexpr bool F8 = KIND == FO_F8, Q4 = KIND == FO_Q4;
   constexpr int HD = 96, NJ = KIND == FO_BF16 ? 6 : 3;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int o_u = o_wl * 4 + wave;                             // row pair (2 o_u, 2 o_u + 1)
   const int Kd = f.nh * HD;
   const size_t row_bytes = (size_t)Kd * (Q4 ? 1 : F8 ? 2 : 4) / 2;
-  u32x4_t ow[2][Q4 ? 1 : NJ];                                  // bf16 / e4m3: 16-byte chunks
-  u32x2_t oq[2][Q4 ? 3 : 1];                                   // 4-bit: 16-weight pieces (8 bytes) + their scale | bias words
-  uint32_t osb[2][Q4 ? 3 : 1];
-  const unsigned char* r0p = (const unsigned char*)f.o_w + (size_t)(2 * o_u) * row_bytes;
-  if (Q4) {
-    const uint32_t* s0 = (const uint32_t*)f.o_scale + (size_t)(2 * o_u) * (Kd / 64) + (lane >> 2);
+  const bool two = NU > 1 && o_wl2 >= 0;                       // workgroup-uniform
+  int o_u[NU];                                                 // row pair (2 o_u, 2 o_u + 1) of unit k
+  u32x4_t ow[NU][2][Q4 ? 1 : NJ];                              // bf16 / e4m3: 16-byte chunks
+  u32x2_t oq[NU][2][Q4 ? 3 : 1];                               // 4-bit: 16-weight pieces (8 bytes) + their scale | bias words
+  uint32_t osb[NU][2][Q4 ? 3 : 1];
+  uint32_t ores[NU];
+  float osc[NU][2];
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      oq[0][j] = __builtin_nontemporal_load((const u32x2_t*)r0p + j * 64 + lane);
-      oq[1][j] = __builtin_nontemporal_load((const u32x2_t*)(r0p + row_bytes) + j * 64 + lane);
-      osb[0][j] = s0[j * 16];
-      osb[1][j] = s0[Kd / 64 + j * 16];
-    }
-  } else {
+  for (int k = 0; k < NU; ++k) {
+    o_u[k] = (k == 0 ? o_wl : o_wl2) * 4 + wave;
+    if (k == 1 && !two) continue;
+    const unsigned char* r0p = (const unsigned char*)f.o_w + (size_t)(2 * o_u[k]) * row_bytes;
+    if (Q4) {
+      const uint32_t* s0 = (const uint32_t*)f.o_scale + (size_t)(2 * o_u[k]) * (Kd / 64) + (lane >> 2);
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-      ow[0][j] = __builtin_nontemporal_load((const u32x4_t*)r0p + j * 64 + lane);
-      ow[1][j] = __builtin_nontemporal_load((const u32x4_t*)(r0p + row_bytes) + j * 64 + lane);
+      for (int j = 0; j < 3; ++j) {
+        oq[k][0][j] = __builtin_nontemporal_load((const u32x2_t*)r0p + j * 64 + lane);
+        oq[k][1][j] = __builtin_nontemporal_load((const u32x2_t*)(r0p + row_bytes) + j * 64 + lane);
+        osb[k][0][j] = s0[j * 16];
+        osb[k][1][j] = s0[Kd / 64 + j * 16];
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        ow[k][0][j] = __builtin_nontemporal_load((const u32x4_t*)r0p + j * 64 + lane);
+        ow[k][1][j] = __builtin_nontemporal_load((const u32x4_t*)(r0p + row_bytes) + j * 64 + lane);
+      }
     }
+    ores[k] = *(const uint32_t*)(f.o_x + 2 * o_u[k]);
+    osc[k][0] = F8 ? ((const float*)f.o_scale)[2 * o_u[k]] : 1.f;
+    osc[k][1] = F8 ? ((const float*)f.o_scale)[2 * o_u[k] + 1] : 1.f;
   }
-  const uint32_t ores = *(const uint32_t*)(f.o_x + 2 * o_u);
-  const float osc0 = F8 ? ((const float*)f.o_scale)[2 * o_u] : 1.f, osc1 = F8 ? ((const float*)f.o_scale)[2 * o_u + 1] : 1.f;
   {
     // Wait for the merged attention output.  1536 waves polling all 1536 words would flood the memory side with uncached
     // 4-byte loads and starve the very workgroups that produce them (measured: every wave timed out); so ONE wave per
@@ -1933,9 +1991,8 @@ __device__ __forceinline__ void fo_project(const FoP f, const int o_wl, unsigned
     }
     __syncthreads();
     timeout = o_timeout != 0;
-    float a0 = 0.f, a1 = 0.f;
-    if (Q4) {                                                  // k_gemv3_q4<1, 3>: piece pc = 64 j + lane, X = sum of its 16 activations
-      float* xsum = (float*)(lds + 6144);
+    float* xsum = (float*)(lds + 6144);
+    if (Q4) {                                                  // k_gemv3_q4<1, 3>: X = sum of a piece's 16 activations
       if (tid < 192) {
         const u32x4_t a = ((const u32x4_t*)xs)[2 * tid], b = ((const u32x4_t*)xs)[2 * tid + 1];
         float t = 0.f;
@@ -1944,52 +2001,60 @@ __device__ __forceinline__ void fo_project(const FoP f, const int o_wl, unsigned
         xsum[tid] = t;
       }
       __syncthreads();
-#pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        const int pc = j * 64 + lane;
-        const u32x4_t xa = ((const u32x4_t*)xs)[2 * pc], xb = ((const u32x4_t*)xs)[2 * pc + 1];
-        const float X = xsum[pc], X128 = 128.f * X;
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const float D = dot8_q4(oq[h][j][1], xb, dot8_q4(oq[h][j][0], xa, 0.f));
-          const float c = bf16lo(osb[h][j]) * (D - X128) + bf16hi(osb[h][j]) * X;
-          if (h == 0) a0 += c; else a1 += c;
-        }
-      }
-      TMARK(13);
-      a0 = wave_sum(a0);
-      a1 = wave_sum(a1);
-    } else if (F8) {                                           // k_gemv3_f8<1, 3>: weight chunk c = 64 j + lane meets x chunks 2c, 2c + 1
-#pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        const u32x4_t xa = ((const u32x4_t*)xs)[2 * (j * 64 + lane)], xb = ((const u32x4_t*)xs)[2 * (j * 64 + lane) + 1];
-        a0 = dot16_f8(ow[0][j], xa, xb, a0);
-        a1 = dot16_f8(ow[1][j], xa, xb, a1);
-      }
-      TMARK(13);
-      a0 = wave_sum(a0) * osc0;
-      a1 = wave_sum(a1) * osc1;
-    } else {                                                   // k_gemv3<1, 1, 6>: chunk 64 j + lane
-#pragma unroll
-      for (int j = 0; j < 6; ++j) {
-        const u32x4_t xa = ((const u32x4_t*)xs)[j * 64 + lane];
-        a0 = dot8(ow[0][j], xa, a0);
-        a1 = dot8(ow[1][j], xa, a1);
-      }
-      TMARK(13);
-      a0 = wave_sum(a0);
-      a1 = wave_sum(a1);
     }
-    if (lane == 0) {
-      const float v0 = bf16lo(ores) + bf16_round(a0), v1 = bf16hi(ores) + bf16_round(a1);
-      *(uint32_t*)(f.o_x + 2 * o_u) = timeout ? 0x7fc07fc0u : pack_bf16x2(v0, v1);     // NaN: loud (api._rows raises)
+#pragma unroll
+    for (int k = 0; k < NU; ++k) {
+      if (k == 1 && !two) continue;
+      float a0 = 0.f, a1 = 0.f;
+      if (Q4) {                                                // piece pc = 64 j + lane
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          const int pc = j * 64 + lane;
+          const u32x4_t xa = ((const u32x4_t*)xs)[2 * pc], xb = ((const u32x4_t*)xs)[2 * pc + 1];
+          const float X = xsum[pc], X128 = 128.f * X;
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const float D = dot8_q4(oq[k][h][j][1], xb, dot8_q4(oq[k][h][j][0], xa, 0.f));
+            const float c = bf16lo(osb[k][h][j]) * (D - X128) + bf16hi(osb[k][h][j]) * X;
+            if (h == 0) a0 += c; else a1 += c;
+          }
+        }
+        if (k == 0) TMARK(13);
+        a0 = wave_sum(a0);
+        a1 = wave_sum(a1);
+      } else if (F8) {                                         // k_gemv3_f8<1, 3>: weight chunk c = 64 j + lane meets x chunks 2c, 2c + 1
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          const u32x4_t xa = ((const u32x4_t*)xs)[2 * (j * 64 + lane)], xb = ((const u32x4_t*)xs)[2 * (j * 64 + lane) + 1];
+          a0 = dot16_f8(ow[k][0][j], xa, xb, a0);
+          a1 = dot16_f8(ow[k][1][j], xa, xb, a1);
+        }
+        if (k == 0) TMARK(13);
+        a0 = wave_sum(a0) * osc[k][0];
+        a1 = wave_sum(a1) * osc[k][1];
+      } else {                                                 // k_gemv3<1, 1, 6>: chunk 64 j + lane
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+          const u32x4_t xa = ((const u32x4_t*)xs)[j * 64 + lane];
+          a0 = dot8(ow[k][0][j], xa, a0);
+          a1 = dot8(ow[k][1][j], xa, a1);
+        }
+        if (k == 0) TMARK(13);
+        a0 = wave_sum(a0);
+        a1 = wave_sum(a1);
+      }
+      if (lane == 0) {
+        const float v0 = bf16lo(ores[k]) + bf16_round(a0), v1 = bf16hi(ores[k]) + bf16_round(a1);
+        *(uint32_t*)(f.o_x + 2 * o_u[k]) = timeout ? 0x7fc07fc0u : pack_bf16x2(v0, v1);     // NaN: loud (api._rows raises)
+      }
     }
     TMARK(14);
   }
 }
 
 template <int FO = 0>                                          // FO_NONE, FO_BF16 or FO_Q4: the o_proj weights' format
-__device__ __forceinline__ void attn_decode_body128(const AttnDecP& p, const int bx, const int by, const int bz, unsigned char* KV) {
+__device__ __forceinline__ void attn_decode_body128(const AttnDecP& p, const int bx, const int by, const int bz, unsigned char* KV,
+                                                    const int o_unit = -2, const int o_unit2 = -1) {   // -2: projection units by (head, split) rank (rounds 4-5)
   constexpr int TK = 128, WK = 32, HD = 96, KROW = HD * 2, VROWB = TK * 2, NKS = 3, NDT = 6, CPR = 12;
   constexpr int KS_BYTES = WK * KROW;                          // 6 KiB per wave = 16 x 96 fp32: the wave's O partial parks here
   static_assert(KS_BYTES >= 16 * HD * 4, "a wave's O partial reuses its K slice");
@@ -2003,6 +2068,14 @@ __device__ __forceinline__ void attn_decode_body128(const AttnDecP& p, const int
   unsigned char* vtile = KV + 4 * KS_BYTES;
 
   TMARK(0);
+#ifdef P3V_ATTN_TIMING
+  {                                                            // physical CU of this workgroup (is `L % 256` the co-residency class?)
+    unsigned hw, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    TVAL(15, (long long)(((xcc & 15) << 8) | (((hw >> 13) & 7) << 5) | (((hw >> 12) & 1) << 4) | ((hw >> 8) & 15)));
+  }
+#endif
   int past = p.past, pad = 0;
   // With d_past, p.past is a LOWER BOUND of the cache length (the prompt length when the graph was captured; negative = no
   // bound known: every tile is requested at once, as in round 3): a
@@ -2210,8 +2283,8 @@ __device__ __forceinline__ void attn_decode_body128(const AttnDecP& p, const int
   TMARK(2);
   // fused o_proj: this wave's row pair is requested once the partial is stored (below): requested here, 18.9 MB of weight
   // loads compete with the other workgroups' K/V tiles and the whole attention phase runs 0.6 us later (tools/attn_o_timeline.py)
-  const int o_wl = by * (p.n_split - 1) + bx;                  // rank among the non-merging workgroups
-  const bool o_worker = FO && !merger && bx < p.n_split - 1 && o_wl * 8 < p.o_n;
+  const int o_wl = o_unit != -2 ? o_unit : by * (p.n_split - 1) + bx;      // projection unit: rows [8 o_wl, 8 o_wl + 8)
+  const bool o_worker = FO && !merger && bx < p.n_split - 1 && o_wl >= 0 && o_wl * 8 < p.o_n;
   if (FO) {
     if (bx == 0 && by == 0) {                                  // re-arm the other layer parity's buffer (nobody reads it in this launch)
       uint32_t* ra = (uint32_t*)p.o_rearm;
@@ -2252,7 +2325,9 @@ __device__ __forceinline__ void attn_decode_body128(const AttnDecP& p, const int
   if (merger)
     split_merge<256>(p.ws + ((size_t)b * p.nh + head) * p.n_split * 16 * (HD + 2), p.out + (size_t)b * p.L * (p.nh * HD) + head * HD,
                      (size_t)p.nh * HD, p.L, p.n_split, own, (float*)vtile, FO != 0);
-  if (FO && o_worker) fo_project<FO>(FoP{p.o_w, p.o_sb, p.o_x, p.out, p.nh}, o_wl, KV);
+  if (FO && o_worker) {
+    fo_project<FO, 2>(FoP{p.o_w, p.o_sb, p.o_x, p.out, p.nh}, o_wl, KV, o_unit2);
+  }
 }
 
 __global__ void __launch_bounds__(256) k_attn_decode128(AttnDecP p) {
@@ -2262,12 +2337,22 @@ __global__ void __launch_bounds__(256) k_attn_decode128(AttnDecP p) {
 
 __global__ void __launch_bounds__(256) k_attn_decode128_o(AttnDecP p) {            // + the layer's o_proj + residual (body128<true>)
   __shared__ __attribute__((aligned(1024))) unsigned char KV[4 * 6144 + 96 * 256];
-  attn_decode_body128<FO_BF16>(p, blockIdx.x, blockIdx.y, blockIdx.z, KV);
+  int bx = blockIdx.x, by = blockIdx.y, o_unit = -2, o_unit2 = -1;
+  if (p.fo_remap) {                                            // 1-D grid, roles placed by virtual CU (fo_map)
+    const FoMap m = fo_map((int)blockIdx.x, p.n_split, p.nh, p.o_n / 8, p.fo_remap == 2);
+    bx = m.bx, by = m.by, o_unit = m.o_unit, o_unit2 = m.o_unit2;
+  }
+  attn_decode_body128<FO_BF16>(p, bx, by, blockIdx.z, KV, o_unit, o_unit2);
 }
 
 __global__ void __launch_bounds__(256) k_attn_decode128_o4(AttnDecP p) {           // the same on MLX 4-bit group-64 o_proj weights
   __shared__ __attribute__((aligned(1024))) unsigned char KV[4 * 6144 + 96 * 256];
-  attn_decode_body128<FO_Q4>(p, blockIdx.x, blockIdx.y, blockIdx.z, KV);
+  int bx = blockIdx.x, by = blockIdx.y, o_unit = -2, o_unit2 = -1;
+  if (p.fo_remap) {                                            // 1-D grid, roles placed by virtual CU (fo_map)
+    const FoMap m = fo_map((int)blockIdx.x, p.n_split, p.nh, p.o_n / 8, p.fo_remap == 2);
+    bx = m.bx, by = m.by, o_unit = m.o_unit, o_unit2 = m.o_unit2;
+  }
+  attn_decode_body128<FO_Q4>(p, bx, by, blockIdx.z, KV, o_unit, o_unit2);
 }
 
 __global__ void __launch_bounds__(256) k_attn_decode(AttnDecP p) {
@@ -2563,22 +2648,35 @@ extern "C" int p3v_attention_decode_can_fuse_oproj(int B, int L, int n_heads, in
   return (long)B * n_heads * n_split <= capacity;
 }
 
+extern "C" int p3v_attention_decode_fused_role(int wg, int n_heads, int n_split, int o_n, int map, int* out4) {
+  if (!out4 || wg < 0 || n_split < 2 || n_heads < 1 || wg >= n_heads * n_split || (map != 1 && map != 2)) return P3V_ERR_ARG;
+  if (!fo_map_ok(n_split, n_heads, o_n)) return P3V_ERR_UNSUPPORTED;
+  const FoMap m = fo_map(wg, n_split, n_heads, o_n / 8, map == 2);
+  out4[0] = m.bx, out4[1] = m.by, out4[2] = m.o_unit, out4[3] = m.o_unit2;
+  return P3V_OK;
+}
+
 extern "C" int p3v_attention_decode(const p3v_attn_decode_args_t* a, void* stream) {
   if (!a || !a->qkv || !a->cos_t || !a->sin_t || !a->k_cache || !a->v_cache || !a->out || !a->ws) return P3V_ERR_ARG;
   if (a->hd != 96) return P3V_ERR_UNSUPPORTED;
   if (a->B <= 0 || a->L <= 0 || a->L > P3V_DECODE_MAX_L || a->n_heads % a->n_kv) return P3V_ERR_ARG;
   if (a->n_split < 1 || a->n_split > 128 || a->cache_t % 64) return P3V_ERR_ARG;
+  if (((uintptr_t)a->ws | (uintptr_t)a->out) & 15) return P3V_ERR_ARG;      // 16-byte write-through stores of the partial records / merged rows
   const int grp = a->n_heads / a->n_kv;
   const int chunk = ((a->cache_t + a->n_split - 1) / a->n_split + 63) & ~63;
   AttnDecP p = {a->qkv, a->cos_t, a->sin_t, a->k_cache, a->v_cache, a->pad_len, a->d_past, a->ws,
                 a->B, a->L, a->n_heads, a->n_kv, a->past, a->cache_t, a->rope_bstride, a->n_split, a->scale,
                 chunk, grp, (65536 + grp - 1) / grp, a->merge_in_launch, (bf16_t*)a->out,
-                a->o_proj_w, a->o_proj_sb, (bf16_t*)a->o_proj_x, (bf16_t*)a->o_rearm, a->o_n};
+                a->o_proj_w, a->o_proj_sb, (bf16_t*)a->o_proj_x, (bf16_t*)a->o_rearm, a->o_n, 0};
   hipStream_t s = (hipStream_t)stream;
-  const dim3 grid(a->n_split, a->n_heads, a->B);
+  dim3 grid(a->n_split, a->n_heads, a->B);
   if (a->o_proj_w) {                                           // attention + o_proj + residual in one launch
     if (!p3v_attention_decode_can_fuse_oproj(a->B, a->L, a->n_heads, a->hd, a->n_split, a->cache_t, a->o_n, a->merge_in_launch)) return P3V_ERR_UNSUPPORTED;
     if (!a->o_proj_x || !a->o_rearm || ((uintptr_t)a->o_proj_w | (uintptr_t)a->o_proj_x | (uintptr_t)a->o_rearm) & 15) return P3V_ERR_ARG;
+    if (p3v_tuning().attn_fo_map && fo_map_ok(a->n_split, a->n_heads, a->o_n)) {
+      p.fo_remap = p3v_tuning().attn_fo_map;                    // 1: second units on the second-to-last workgroups, 2: on the last ones
+      grid = dim3(a->n_split * a->n_heads, 1, 1);
+    }
     if (a->o_proj_sb) {                                        // 4-bit group-64 o_proj weights
       if ((uintptr_t)a->o_proj_sb & 3) return P3V_ERR_ARG;
       hipLaunchKernelGGL(k_attn_decode128_o4, grid, dim3(256), 0, s, p);
@@ -2789,6 +2887,7 @@ struct AttnDecQ8P {
   bf16_t* out;                 // [B, L, nh * 96] (fused merge only)
   // fused o_proj + residual on e4m3 weights (k_attn_decode128_q8<true> only), as AttnDecP's
   const uint8_t* o_w; const float* o_scale; bf16_t* o_x; bf16_t* o_rearm; int o_n;
+  int fo_remap;                // as AttnDecP's (fo_map)
 };
 
 // 16 offset-binary bytes -> 16 FP16 values 1024 + byte: a byte dropped into the mantissa of 0x6400 (= 1024.0) is exactly
@@ -3266,7 +3365,12 @@ __global__ void __launch_bounds__(256) k_attn_decode128_q8(AttnDecQ8P p) {
   __shared__ float Ml[4][16][2];
   const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, qi = lane & 15;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int b = blockIdx.z, head = blockIdx.y, kvh = (head * p.grp_magic) >> 16;
+  int bx = blockIdx.x, by = blockIdx.y, o_unit = -2, o_unit2 = -1;
+  if (FO && p.fo_remap) {                                      // 1-D grid, roles placed by virtual CU (fo_map)
+    const FoMap fm = fo_map((int)blockIdx.x, p.n_split, p.nh, p.o_n / 8, p.fo_remap == 2);
+    bx = fm.bx, by = fm.by, o_unit = fm.o_unit, o_unit2 = fm.o_unit2;
+  }
+  const int b = blockIdx.z, head = by, kvh = (head * p.grp_magic) >> 16;
   const bool kv_writer = head == kvh * p.grp;
   unsigned char* kslice = KV + wave * KS_BYTES;
   unsigned char* vtile = KV + 4 * KS_BYTES;
@@ -3280,7 +3384,7 @@ __global__ void __launch_bounds__(256) k_attn_decode128_q8(AttnDecQ8P p) {
   if (p.d_past) asm volatile("s_load_dword %0, %1, 0x0" : "=s"(past) : "s"(p.d_past) : "memory");
   if (p.pad_len) asm volatile("s_load_dword %0, %1, 0x0" : "=s"(pad) : "s"(p.pad_len + b) : "memory");
 
-  const int kv_lo = blockIdx.x * TK, kv_hi = min(p.cache_t, kv_lo + TK);
+  const int kv_lo = bx * TK, kv_hi = min(p.cache_t, kv_lo + TK);
   const int kvd = min(kv_lo, p.cache_t - TK);                  // tile actually fetched (an empty split fetches one it never uses)
   // ---- small loads first: the tile's scales, and the L new rows (Q / K raw for the rotation, V)
   const int row_w = (p.nh + 2 * p.nkv) * HD;
@@ -3484,7 +3588,7 @@ __global__ void __launch_bounds__(256) k_attn_decode128_q8(AttnDecQ8P p) {
     if (g == 0) { Ml[wave][qi][0] = m_run; Ml[wave][qi][1] = l_run; }
   }
   __syncthreads();
-  const bool merger = p.merge && blockIdx.x == p.n_split - 1;  // the highest split of a (b, head) merges in-launch
+  const bool merger = p.merge && bx == p.n_split - 1;  // the highest split of a (b, head) merges in-launch
   float* own = (float*)(Aux + 2176);                           // its partial: [16][HD + 2] in the (dead) aux block, after the merge scratch
 #pragma unroll 1
   for (int idx = tid; idx < n_vnew; idx += 256) {
@@ -3504,7 +3608,7 @@ __global__ void __launch_bounds__(256) k_attn_decode128_q8(AttnDecQ8P p) {
       own[q * (HD + 2) + d] = acc;
       if (d == 0) { own[q * (HD + 2) + HD] = M; own[q * (HD + 2) + HD + 1] = lsum; }
     } else {
-      float* w = p.ws + ((((size_t)b * p.nh + head) * p.n_split + blockIdx.x) * 16 + q) * (HD + 2);
+      float* w = p.ws + ((((size_t)b * p.nh + head) * p.n_split + bx) * 16 + q) * (HD + 2);
       st_wt(w + d, acc);
       if (d == 0) { st_wt(w + HD, M); st_wt(w + HD + 1, lsum); }
     }
@@ -3513,13 +3617,13 @@ __global__ void __launch_bounds__(256) k_attn_decode128_q8(AttnDecQ8P p) {
     split_merge<256>(p.ws + ((size_t)b * p.nh + head) * p.n_split * 16 * (HD + 2), p.out + (size_t)b * p.L * (p.nh * HD) + head * HD,
                      (size_t)p.nh * HD, p.L, p.n_split, own, (float*)Aux, FO);
   if (FO) {
-    if (blockIdx.x == 0 && blockIdx.y == 0) {                  // re-arm the other layer parity's buffer (nobody reads it in this launch)
+    if (bx == 0 && by == 0) {                  // re-arm the other layer parity's buffer (nobody reads it in this launch)
       uint32_t* ra = (uint32_t*)p.o_rearm;
       for (int i = tid; i < p.nh * HD / 2; i += 256) ra[i] = 0xffffffffu;
     }
-    const int o_wl = blockIdx.y * (p.n_split - 1) + blockIdx.x;   // rank among the non-merging workgroups
-    if (!merger && (int)blockIdx.x < p.n_split - 1 && o_wl * 8 < p.o_n)
-      fo_project<FO_F8>(FoP{p.o_w, p.o_scale, p.o_x, p.out, p.nh}, o_wl, KV);
+    const int o_wl = o_unit != -2 ? o_unit : by * (p.n_split - 1) + bx;   // projection unit (fo_map), or the rank among the non-merging workgroups
+    if (!merger && bx < p.n_split - 1 && o_wl >= 0 && o_wl * 8 < p.o_n)
+      fo_project<FO_F8, 2>(FoP{p.o_w, p.o_scale, p.o_x, p.out, p.nh}, o_wl, KV, o_unit2);
   }
 }
 
@@ -3547,6 +3651,7 @@ extern "C" int p3v_attention_decode_q8(const p3v_attn_decode_q8_args_t* a, void*
   if (a->hd != 96) return P3V_ERR_UNSUPPORTED;
   if (a->B <= 0 || a->L <= 0 || a->L > P3V_DECODE_MAX_L || a->n_heads % a->n_kv) return P3V_ERR_ARG;
   if (a->n_split < 1 || a->n_split > 128 || a->cache_t % 64) return P3V_ERR_ARG;
+  if (((uintptr_t)a->ws | (uintptr_t)a->out) & 15) return P3V_ERR_ARG;      // (16-byte write-through stores, as p3v_attention_decode)
   const int grp = a->n_heads / a->n_kv;
   AttnDecQ8P p = {a->qkv, a->cos_t, a->sin_t, a->k8, a->v8t, a->k_scale, a->v_scale, a->pad_len, a->d_past, a->ws,
                   a->B, a->L, a->n_heads, a->n_kv, a->past, a->cache_t, a->rope_bstride, a->n_split, a->scale,
@@ -3566,6 +3671,14 @@ extern "C" int p3v_attention_decode_q8(const p3v_attn_decode_q8_args_t* a, void*
       if (!a->o_proj_scale || !a->o_proj_x || !a->o_rearm || ((uintptr_t)a->o_proj_w8 | (uintptr_t)a->o_proj_x | (uintptr_t)a->o_rearm) & 15)
         return P3V_ERR_ARG;
       p.o_w = a->o_proj_w8; p.o_scale = a->o_proj_scale; p.o_x = (bf16_t*)a->o_proj_x; p.o_rearm = (bf16_t*)a->o_rearm; p.o_n = a->o_n;
+      // (the virtual-CU placement of k_attn_decode128_o, off by default here: with 24 KB tiles and 9.4 MB of e4m3 W_o the (split, head)
+      //  grid measured 0.3 - 0.8 % FASTER on config 5 -- 1.197 vs 1.203 ms per step, profiles/r06_attn_oproj_placement.txt)
+      if (p3v_tuning().attn_fo_map_q8 && fo_map_ok(a->n_split, a->n_heads, a->o_n)) {
+        p.fo_remap = p3v_tuning().attn_fo_map_q8;
+        hipLaunchKernelGGL(k_attn_decode128_q8<true>, dim3(a->n_split * a->n_heads, 1, 1), dim3(256), 0, s, p);
+        P3V_CHECK_LAUNCH();
+        return P3V_OK;
+      }
       hipLaunchKernelGGL(k_attn_decode128_q8<true>, grid, dim3(256), 0, s, p);
       P3V_CHECK_LAUNCH();
       return P3V_OK;

@@ -158,6 +158,8 @@ struct P3vTuning {
   int gemm_no_qkv_fuse;     // 1: p3v_gemm_qkv reports P3V_ERR_UNSUPPORTED (callers then run p3v_gemm + p3v_rope_kv_append)
   int gemm_f8_narrow;       // -1: by shape, 0 / 1: pin the fp8 tile width
   int attn_no_dma, attn_old, attn_pp, attn_il, attn_il_waves, combine_g, kvq_old, q8_old;
+  int attn_fo_map_q8;       // the same placement for the int8-KV twin (k_attn_decode128_q8<true>): 0 = off (measured slower there)
+  int attn_fo_map;          // fused decode attention + o_proj: 2 / 1 = roles placed by virtual CU (fo_map, round 6), 0 = the (split, head) grid
   int gemv_no_mfma, gemv_no_mfma8, gemv_wpc, gemv8_wgs, gemv_variant, gemv_rows, gemv8_min, gemv_mfma8, gemv_f8_wpc, gemv_q4_wpc, gemv_wpw;
 };
 const P3vTuning& p3v_tuning();

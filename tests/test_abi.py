@@ -99,6 +99,45 @@ def test_tuning_table_and_gemm_workspace_size():
     assert l.p3v_gemm_ws_bytes(128, 3072, 8192, _lib.EPI_BIAS) == 0
 
 
+@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("n_split", list(range(13, 25)))
+def test_fused_decode_attention_role_placement_is_a_bijection(n_split, mode):
+    """p3v_attention_decode_fused_role (round 6): the 1-D grid of the fused attention + o_proj launch.  For every cache capacity
+    the fused form takes (13 .. 24 tiles of 128 keys, 32 heads, o_n = 3072): every (head, split) is played by exactly one
+    workgroup, every projection unit 0 .. 383 by exactly one, the 32 merging workgroups are the LAST workgroups of virtual CUs
+    224 .. 255 (workgroups L, L + 256, L + 512 share a CU) and nobody on those CUs carries a projection unit; every other CU's
+    last workgroup carries one (placement 2: also the second ones; placement 1: those sit on second-to-last workgroups)."""
+    from phi_3_vision_mlx_amd import _lib
+    l = _lib.lib()
+    nh, o_n = 32, 3072
+    G = nh * n_split
+    out = (ctypes.c_int * 4)()
+    roles = []
+    for wg in range(G):
+        assert l.p3v_attention_decode_fused_role(wg, nh, n_split, o_n, mode, out) == 0
+        roles.append(tuple(out))
+    assert sorted((r[1], r[0]) for r in roles) == [(h, s) for h in range(nh) for s in range(n_split)]
+    units = [u for r in roles for u in r[2:] if u >= 0]
+    assert sorted(units) == list(range(o_n // 8))
+    n_on = [sum(1 for wg in range(v, G, 256)) for v in range(256)]
+    for wg, (split, head, u1, u2) in enumerate(roles):
+        v, slot = wg % 256, wg // 256
+        last = slot == n_on[v] - 1
+        if split == n_split - 1:
+            assert v == 224 + head and last and u1 < 0 and u2 < 0
+        if v >= 224:
+            assert u1 < 0 and u2 < 0
+        elif last:
+            assert u1 == v
+        if mode == 2:
+            assert (u1 >= 0) == (last and v < 224) and (u2 < 0 or u1 >= 0)
+        else:
+            assert u2 < 0 and (u1 < 0 or slot >= n_on[v] - 2)
+    assert l.p3v_attention_decode_fused_role(0, 32, 12, o_n, mode, out) == _lib.ERR_UNSUPPORTED      # too few workgroups for 384 units
+    assert l.p3v_attention_decode_fused_role(0, 8, 16, o_n, mode, out) == _lib.ERR_UNSUPPORTED       # not the 32-head geometry
+    assert l.p3v_attention_decode_fused_role(G, nh, n_split, o_n, mode, out) == -22
+
+
 def test_product_never_imports_the_oracle():
     pkg = os.path.join(ROOT, "phi-3-vision-mlx_amd")
     for dirpath, _, files in os.walk(pkg):
