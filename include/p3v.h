@@ -389,6 +389,27 @@ int p3v_step_begin(const int32_t* tok, const uint16_t* table, uint16_t* x_out, c
 int p3v_step_end(const uint16_t* logits, int32_t* next_tok, int32_t* tok, int32_t* history, int32_t* d_step,
                  int32_t* d_past, int32_t* ticket, int B, int n, int max_steps, void* stream);
 
+/* Round 6: the same two stages WITHOUT launches of their own -- folded into the step's first projection (layer 0's RMSNorm + qkv)
+ * and its last (final norm + lm_head, phi.py:597-608, phi_3_vision_mlx.py:386-393): p3v_gemv with
+ *   begin (tok != NULL):      x row b = embed_table[clamp(tok[b])] instead of args->x; the rows are also written to x_out (the residual
+ *                             stream) and the rotation rows of position *d_past staged into cos_out / sin_out, as p3v_step_begin does;
+ *   end (next_tok != NULL):   next_tok[b] = tok_out[b] = argmax(out[b]) (first maximum of the bf16 values; a NaN row reports -1),
+ *                             history[b, *d_step] = it, then *d_step += 1, *d_past += 1 -- by the last workgroup to finish (every
+ *                             workgroup publishes its candidates into amax_ws and takes a ticket; `ticket`: one zeroed int32, left zero;
+ *                             amax_ws: P3V_GEMV_STEP_WS_BYTES bytes, 8-byte aligned, contents irrelevant).
+ * Exactly one of the two.  M = 1 row (the kernel p3v_gemv runs there), bf16 weights, K = 3072 or 8192, P3V_EPI_NONE: otherwise
+ * P3V_ERR_UNSUPPORTED and the caller
+ * keeps p3v_step_begin / p3v_step_end.  Bit-identical to the separate launches. */
+#define P3V_GEMV_STEP_MAX_WG 1024
+#define P3V_GEMV_STEP_WS_BYTES (P3V_GEMV_STEP_MAX_WG * 8)
+typedef struct {
+  const int32_t* tok; const uint16_t* embed_table; int vocab; uint16_t* x_out;
+  const float* cos_t; const float* sin_t; float* cos_out; float* sin_out; int tab_t, half_dim;
+  int32_t* next_tok; int32_t* tok_out; int32_t* history; int32_t* d_step; int32_t* ticket; float* amax_ws; int max_steps;
+  int32_t* d_past;            /* begin: read (position of the rows to stage); end: incremented */
+} p3v_gemv_step_t;
+int p3v_gemv_step(const p3v_gemv_args_t* args /* host */, const p3v_gemv_step_t* step /* host */, void* stream);
+
 /* ---- hipGraph helpers: capture a sequence of the launches above and replay it */
 int p3v_graph_begin(void* stream);
 int p3v_graph_end(void* stream, void** graph_exec_out /* host */);

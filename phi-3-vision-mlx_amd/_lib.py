@@ -39,6 +39,16 @@ class GemvArgs(C.Structure):
                 ("M", i32), ("N", i32), ("K", i32), ("epilogue", i32)]
 
 
+class GemvStep(C.Structure):
+    _fields_ = [("tok", vp), ("embed_table", vp), ("vocab", i32), ("x_out", vp),
+                ("cos_t", vp), ("sin_t", vp), ("cos_out", vp), ("sin_out", vp), ("tab_t", i32), ("half_dim", i32),
+                ("next_tok", vp), ("tok_out", vp), ("history", vp), ("d_step", vp), ("ticket", vp), ("amax_ws", vp), ("max_steps", i32),
+                ("d_past", vp)]
+
+
+GEMV_STEP_WS_BYTES = 1024 * 8               # P3V_GEMV_STEP_WS_BYTES
+
+
 class GemvF8Args(C.Structure):
     _fields_ = [("x", vp), ("W", vp), ("w_scale", vp), ("out", vp), ("resid", vp), ("norm_w", vp), ("norm_eps", f32),
                 ("M", i32), ("N", i32), ("K", i32), ("epilogue", i32)]
@@ -92,6 +102,7 @@ SIGNATURES = {
     "p3v_gemm": (i32, [C.POINTER(GemmArgs), vp]),
     "p3v_gemm_ws_bytes": (i64, [i32, i32, i32, i32]),
     "p3v_gemv": (i32, [C.POINTER(GemvArgs), vp]),
+    "p3v_gemv_step": (i32, [C.POINTER(GemvArgs), C.POINTER(GemvStep), vp]),
     "p3v_gemv_fp8": (i32, [C.POINTER(GemvF8Args), vp]),
     "p3v_dequant_fp8": (i32, [vp, vp, vp, i32, i32, vp]),
     "p3v_gemm_fp8": (i32, [C.POINTER(GemmF8Args), vp]),

@@ -157,8 +157,15 @@ __global__ void __launch_bounds__(256) k_gemv3(GemvP p, int units_per_wave, int 
   GMARK(1);
 }
 
-template <int MT, int NST, int CH>
-static int launch_gemv3(const GemvP& p, hipStream_t s) {
+template <int MT, int NST, int CH, int STEP>
+__global__ void __launch_bounds__(256) k_gemv3_step(GemvP p, int units_per_wave, int wpw, GemvStepP sp) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ float red[8];
+  gemv3_body<MT, NST, CH, STEP>(p, units_per_wave, blockIdx.x, smem, red, wpw, &sp);
+}
+
+template <int MT, int NST, int CH, int STEP = STEP_NONE>
+static int launch_gemv3(const GemvP& p, hipStream_t s, const GemvStepP* sp = nullptr) {
   static int n_cu = 0;
   if (!n_cu) {
     int dev = 0;
@@ -178,7 +185,12 @@ static int launch_gemv3(const GemvP& p, hipStream_t s) {
       return P3V_ERR_HIP;
     attr_set = true;
   }
-  hipLaunchKernelGGL((k_gemv3<MT, NST, CH>), dim3(p3v_cdiv(waves, wpw_)), dim3(256), lds, s, p, upw, wpw_);
+  if constexpr (STEP != STEP_NONE) {
+    if (p3v_cdiv(waves, wpw_) > P3V_GEMV_STEP_MAX_WG) return P3V_ERR_UNSUPPORTED;      // (amax_ws holds one candidate per workgroup and row)
+    hipLaunchKernelGGL((k_gemv3_step<MT, NST, CH, STEP>), dim3(p3v_cdiv(waves, wpw_)), dim3(256), lds, s, p, upw, wpw_, *sp);
+  } else {
+    hipLaunchKernelGGL((k_gemv3<MT, NST, CH>), dim3(p3v_cdiv(waves, wpw_)), dim3(256), lds, s, p, upw, wpw_);
+  }
   P3V_CHECK_LAUNCH();
   return P3V_OK;
 }
@@ -524,6 +536,33 @@ static int launch_gemv_mfma(const GemvP& p, hipStream_t s) {
   else hipLaunchKernelGGL(k_gemv_mfma<false>, grid, dim3(256), 0, s, p);
   P3V_CHECK_LAUNCH();
   return P3V_OK;
+}
+
+// The first / last projection of a replayed greedy step with p3v_step_begin / p3v_step_end folded in (gemv3_body<.., STEP>): only on
+// the M = 1 streaming kernel (bf16 weights, K = 3072 or 8192); anything else reports P3V_ERR_UNSUPPORTED and the caller keeps the
+// separate launches.
+extern "C" int p3v_gemv_step(const p3v_gemv_args_t* a, const p3v_gemv_step_t* st, void* stream) {
+  if (!a || !st || !a->W || !a->out) return P3V_ERR_ARG;
+  const bool begin = st->tok != nullptr, end = st->next_tok != nullptr;
+  if (begin == end) return P3V_ERR_ARG;                        // exactly one of the two ends
+  if (a->M <= 0 || a->N <= 0 || a->K <= 0) return P3V_ERR_ARG;
+  // one row only: that is where p3v_gemv itself runs this kernel (2 .. 8 rows go to k_gemv_mfma8, whose sums associate differently --
+  // a folded step must stay bit-identical to the eager one)
+  if (a->M != 1 || a->N % 2 || (a->K != 3072 && a->K != 8192) || p3v_tuning().gemv_variant != 3) return P3V_ERR_UNSUPPORTED;
+  if (a->epilogue != P3V_EPI_NONE) return P3V_ERR_UNSUPPORTED;
+  if (begin) {
+    if (!st->embed_table || !st->x_out || !st->cos_t || !st->sin_t || !st->d_past || !st->cos_out || !st->sin_out || st->vocab <= 0) return P3V_ERR_ARG;
+    if (((uintptr_t)st->embed_table | (uintptr_t)st->x_out) & 15) return P3V_ERR_ARG;
+  } else {
+    if (!a->x || !st->tok_out || !st->history || !st->d_step || !st->d_past || !st->ticket || !st->amax_ws) return P3V_ERR_ARG;
+    if ((uintptr_t)st->amax_ws & 7) return P3V_ERR_ARG;
+  }
+  GemvP p = {a->x, a->W, a->out, a->resid, a->norm_w, a->norm_eps, a->M, a->N, a->K, a->epilogue, (a->N + 1) / 2};
+  const GemvStepP sp = {st->tok, st->embed_table, st->vocab, st->x_out, st->cos_t, st->sin_t, st->d_past, st->cos_out, st->sin_out, st->tab_t,
+                        st->half_dim, st->next_tok, st->tok_out, st->history, st->d_step, st->d_past, st->ticket, st->amax_ws, st->max_steps};
+  hipStream_t s = (hipStream_t)stream;
+  if (a->K == 3072) return begin ? launch_gemv3<1, 1, 6, STEP_BEGIN>(p, s, &sp) : launch_gemv3<1, 1, 6, STEP_END>(p, s, &sp);
+  return begin ? launch_gemv3<1, 4, 4, STEP_BEGIN>(p, s, &sp) : launch_gemv3<1, 4, 4, STEP_END>(p, s, &sp);
 }
 
 extern "C" int p3v_gemv(const p3v_gemv_args_t* a, void* stream) {

@@ -31,11 +31,32 @@ __device__ __forceinline__ float dot8(u32x4_t w, u32x4_t x, float acc) {
 typedef std::integral_constant<int, 0> IC0;
 typedef std::integral_constant<int, 1> IC1;
 
+// Round 6: the two ends of a replayed greedy decode step ride in the step's first and last projection (p3v_gemv_step):
+//  STEP_BEGIN  x row m = embed_table[clamp(tok[m])] (what p3v_step_begin gathered into x_out); workgroup 0 also writes the rows to
+//              x_out -- the residual stream the later launches update in place -- and stages the rotation rows of position *d_past.
+//  STEP_END    arg-max of the output rows (first maximum of the bf16 values; a NaN row reports -1) + p3v_step_end's bookkeeping:
+//              every workgroup publishes its (value, index) candidates write-through and takes a ticket, the LAST one reduces them.
+enum { STEP_NONE = 0, STEP_BEGIN = 1, STEP_END = 2 };
+struct GemvStepP {
+  const int32_t* tok; const bf16_t* table; int vocab; bf16_t* x_out;
+  const float* cos_t; const float* sin_t; const int32_t* d_past_in; float* cos_o; float* sin_o; int tab_t, half;
+  int32_t* next_tok; int32_t* tok_out; int32_t* hist; int32_t* d_step; int32_t* d_past; int32_t* ticket; float* amax_ws; int max_steps;
+};
+struct ArgMaxVI { float v; int i; };
+__device__ __forceinline__ ArgMaxVI amax_better(ArgMaxVI a, ArgMaxVI b) {   // larger value, then smaller index (k_argmax's order)
+  return (b.v > a.v || (b.v == a.v && b.i < a.i)) ? b : a;
+}
+__device__ __forceinline__ void amax_take(ArgMaxVI& m, float v, int i) {
+  if (v != v) { v = INFINITY; i = -1; }                         // a NaN logit: (+inf, -1) beats every real entry (api._rows raises)
+  if (v > m.v || (v == m.v && i < m.i) || m.i == 0x7fffffff) { m.v = v; m.i = i; }
+}
+
 // wpw: waves of the 4-wave workgroup that take rows (4, or 3: wave 3 then only helps with the prologue).  1536 streaming waves
 // (qkv, o_proj, down) as 384 four-wave workgroups put two workgroups on half of the CUs and one on the others, and the launch
 // lasts as long as the doubly loaded CUs; 512 workgroups x 3 waves load every CU alike (tools/gemv_timeline.py).
-template <int MT, int NST, int CH>
-__device__ __forceinline__ void gemv3_body(const GemvP& p, int units_per_wave, int bx, unsigned char* smem, float* red, int wpw = 4) {
+template <int MT, int NST, int CH, int STEP = STEP_NONE>
+__device__ __forceinline__ void gemv3_body(const GemvP& p, int units_per_wave, int bx, unsigned char* smem, float* red, int wpw = 4,
+                                           const GemvStepP* sp = nullptr) {
   constexpr int CHUNKS = NST * CH * 64;                 // 16-byte chunks per row (K = 8 * CHUNKS)
   constexpr int XC = (CHUNKS + 255) / 256;              // x chunks per thread
   u32x4_t* xs = (u32x4_t*)smem;                         // [MT][CHUNKS] bf16 x (normalised)
@@ -48,11 +69,22 @@ __device__ __forceinline__ void gemv3_body(const GemvP& p, int units_per_wave, i
 
   // ---- 1. x / norm-weight loads (oldest in the queue)
   u32x4_t xv[MT][XC], gv[XC];
+  const bf16_t* xrow[MT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    if (STEP == STEP_BEGIN) {
+      int id = sp->tok[min(m, p.M - 1)];                       // (uniform: a scalar load)
+      id = id < 0 ? 0 : (id >= sp->vocab ? sp->vocab - 1 : id);
+      xrow[m] = sp->table + (size_t)id * (CHUNKS * 8);
+    } else {
+      xrow[m] = p.x + (size_t)min(m, p.M - 1) * (CHUNKS * 8);
+    }
+  }
 #pragma unroll
   for (int k = 0; k < XC; ++k) {
     const int c = min(tid + k * 256, CHUNKS - 1);
 #pragma unroll
-    for (int m = 0; m < MT; ++m) xv[m][k] = ((const u32x4_t*)(p.x + (size_t)min(m, p.M - 1) * (CHUNKS * 8)))[c];
+    for (int m = 0; m < MT; ++m) xv[m][k] = ((const u32x4_t*)xrow[m])[c];
     gv[k] = p.norm_w ? ((const u32x4_t*)p.norm_w)[c] : (u32x4_t){0, 0, 0, 0};
   }
 
@@ -120,6 +152,9 @@ __device__ __forceinline__ void gemv3_body(const GemvP& p, int units_per_wave, i
   float a0[MT], a1[MT];
 #pragma unroll
   for (int m = 0; m < MT; ++m) a0[m] = a1[m] = 0.f;
+  ArgMaxVI best[MT];                                         // STEP_END: this wave's arg-max candidates (lane 0's copy counts)
+#pragma unroll
+  for (int m = 0; m < MT; ++m) best[m] = ArgMaxVI{-INFINITY, 0x7fffffff};
   auto compute = [&](int gs, auto bufc) {
     constexpr int buf = decltype(bufc)::value;
     const int s = gs % NST;
@@ -153,6 +188,10 @@ __device__ __forceinline__ void gemv3_body(const GemvP& p, int units_per_wave, i
               if (has_res) { v0 = bf16lo(rbuf[buf][m]) + bf16_round(v0); v1 = bf16hi(rbuf[buf][m]) + bf16_round(v1); }
               uint32_t* dst = (uint32_t*)((bf16_t*)p.out + (size_t)m * p.N + 2 * u);
               *dst = pack_bf16x2(v0, v1);
+              if (STEP == STEP_END) {                          // on the values just stored (bf16)
+                amax_take(best[m], bf16_round(v0), 2 * u);
+                if (2 * u + 1 < p.N) amax_take(best[m], bf16_round(v1), 2 * u + 1);
+              }
             }
           }
         }
@@ -175,5 +214,82 @@ __device__ __forceinline__ void gemv3_body(const GemvP& p, int units_per_wave, i
     compute(gs + 1, IC1{});
   } else if (gs < n_st) {
     compute(gs, IC0{});
+  }
+  if (STEP == STEP_BEGIN && bx == 0) {
+    // ---- 5a. the gathered rows become the residual stream the later launches update in place (re-read from the table: L2-hot, and
+    // nothing above has to keep them in registers), and the rotation rows of position *d_past are staged for the attention launches
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+      if (m < p.M)
+        for (int c = tid; c < CHUNKS; c += 256) ((u32x4_t*)(sp->x_out + (size_t)m * (CHUNKS * 8)))[c] = ((const u32x4_t*)xrow[m])[c];
+    const int past = *sp->d_past_in;
+    for (int i = tid; i < p.M * sp->half; i += 256) {
+      const int b = i / sp->half, d = i - b * sp->half;
+      sp->cos_o[i] = sp->cos_t[((size_t)b * sp->tab_t + past) * sp->half + d];
+      sp->sin_o[i] = sp->sin_t[((size_t)b * sp->tab_t + past) * sp->half + d];
+    }
+  }
+  if (STEP == STEP_END) {
+    // ---- 5b. arg-max + loop bookkeeping (p3v_step_end) without a launch of their own
+    __shared__ ArgMaxVI wbest[4][MT];
+    __shared__ int s_last;
+    if (lane == 0) {
+#pragma unroll
+      for (int m = 0; m < MT; ++m) wbest[wave][m] = best[m];
+    }
+    __syncthreads();
+    const int n_wg = gridDim.x;
+    if (tid == 0) {
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        ArgMaxVI r = wbest[0][m];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) r = amax_better(r, wbest[w][m]);
+        // one 8-byte write-through store per row: a (value, index) pair is never seen half-written by the reducer below
+        const unsigned long long rec = (unsigned long long)__builtin_bit_cast(uint32_t, r.v) | ((unsigned long long)(uint32_t)r.i << 32);
+        __hip_atomic_store((unsigned long long*)sp->amax_ws + ((size_t)bx * MT + m), rec, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the candidates are out before the ticket is taken
+      const int t = __hip_atomic_fetch_add(sp->ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s_last = t == n_wg - 1;
+    }
+    __syncthreads();
+    if (s_last) {                                              // the last workgroup to finish: every other candidate is visible
+      __shared__ ArgMaxVI fin[4][MT];
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        ArgMaxVI r = ArgMaxVI{-INFINITY, 0x7fffffff};
+        for (int g = tid; g < n_wg; g += 256) {
+          const unsigned long long rec = __hip_atomic_load((const unsigned long long*)sp->amax_ws + ((size_t)g * MT + m), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          r = amax_better(r, ArgMaxVI{__builtin_bit_cast(float, (uint32_t)rec), (int)(uint32_t)(rec >> 32)});
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+          ArgMaxVI o;
+          o.v = __shfl_xor(r.v, off, 64);
+          o.i = __shfl_xor(r.i, off, 64);
+          r = amax_better(r, o);
+        }
+        if (lane == 0) fin[wave][m] = r;
+      }
+      __syncthreads();
+      if (tid == 0) {
+        const int step = *sp->d_step, past_now = *sp->d_past;
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+          if (m < p.M) {
+            ArgMaxVI r = fin[0][m];
+#pragma unroll
+            for (int w = 1; w < 4; ++w) r = amax_better(r, fin[w][m]);
+            const int idx = r.i == 0x7fffffff ? 0 : r.i;
+            sp->next_tok[m] = idx;
+            sp->tok_out[m] = idx;
+            if (step < sp->max_steps) sp->hist[(size_t)m * sp->max_steps + step] = idx;
+          }
+        *sp->d_step = step + 1;
+        *sp->d_past = past_now + 1;
+        __hip_atomic_store(sp->ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // re-armed for the next replay
+      }
+    }
   }
 }

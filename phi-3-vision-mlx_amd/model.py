@@ -549,7 +549,7 @@ class Phi3VModel:
                 fused = B * nh * n_split <= per_cu * ops.device_props(torch.device(self.device).index or 0)["cu_count"]
             bufs["attn_merge"] = bool(fused)
 
-    def _layers(self, x, st, B, L, past, n_beam, bufs=None, d_past=None, last_only=False):
+    def _layers(self, x, st, B, L, past, n_beam, bufs=None, d_past=None, last_only=False, step_begin=None):
         """Phi3DecoderLayer stack (phi.py:473-485).  `d_past` (device int32) makes every
         position-dependent kernel read the cache length from HBM -> graph-replayable.
         last_only: the caller reads the LAST position only (prefill of generate / choose, Q8): the final layer still builds
@@ -590,7 +590,14 @@ class Phi3VModel:
                     normed_in = True                            # (`h` holds the normalised input now, whatever the fused call answers)
                     fused_qkv = ops.gemm_qkv(hn, w[k_w], st.cos, st.sin, q, kd, vd, B, L, nh, nkv, hd, past, st.Tp, True, st.T, 1,
                                              q_scale=scale * ops.Q_PRESCALE)
-            if not fused_qkv:
+            if i == 0 and step_begin is not None:               # replayed greedy step: the embedding gather + rotation-row staging
+                sb = step_begin                                 # ride in this projection's prologue when the library takes the shape
+                if not (k_w in w and k_w not in self.adapters and os.environ.get("P3V_STEP_FOLD", "1") != "0"
+                        and ops.gemv_step_begin(sb["tok"], sb["table"], x, st.cos, st.sin, d_past, sb["cos_o"], sb["sin_o"],
+                                                w[k_w], w[p + "input_layernorm.weight"], eps, qkv)):
+                    ops.step_begin(sb["tok"], sb["table"], x, st.cos, st.sin, d_past, sb["cos_o"], sb["sin_o"])
+                    self._proj(x, k_w, norm_w=w[p + "input_layernorm.weight"], out=qkv, h=h)
+            elif not fused_qkv:
                 if normed_in:                                   # `h` holds RMSNorm(x) already (the previous down_proj's reduction launch)
                     self._proj(h, p + "self_attn.qkv_proj.weight", out=qkv)
                 else:
@@ -715,12 +722,19 @@ class Phi3VModel:
         bufs["rope_sin"] = torch.empty_like(bufs["rope_cos"])
         g["bufs"] = bufs
 
+        g["amax_ws"] = torch.empty((ops.L.GEMV_STEP_WS_BYTES // 4,), dtype=F32, device=dev)
+
         def step():
-            ops.step_begin(g["tok"], w["model.embed_tokens.weight"], g["x"], st.cos, st.sin, g["d_past"],
-                           bufs["rope_cos"], bufs["rope_sin"])
-            self._layers(g["x"], st, B, 1, 0, 1, bufs=bufs, d_past=g["d_past"])
-            self._proj(g["x"], "lm_head.weight", norm_w=w["model.norm.weight"], out=g["logits"], h=bufs["h"])   # (h: the norm's output
-            ops.step_end(g["logits"], g["next_tok"], g["tok"], g["history"], g["d_step"], g["d_past"], g["ticket"])
+            # (round 6) the step's two ends have no launch of their own where the library folds them into the first / last projection
+            # (B = 1 on bf16 weights: ops.gemv_step_begin / gemv_step_end; 129 launches per step instead of 131)
+            self._layers(g["x"], st, B, 1, 0, 1, bufs=bufs, d_past=g["d_past"],
+                         step_begin=dict(tok=g["tok"], table=w["model.embed_tokens.weight"], cos_o=bufs["rope_cos"], sin_o=bufs["rope_sin"]))
+            head = "lm_head.weight"
+            if not (head in w and head not in self.adapters and os.environ.get("P3V_STEP_FOLD", "1") != "0"
+                    and ops.gemv_step_end(g["x"], w[head], w["model.norm.weight"], cfg.rms_norm_eps, g["logits"], g["next_tok"], g["tok"],
+                                          g["history"], g["d_step"], g["d_past"], g["ticket"], g["amax_ws"])):
+                self._proj(g["x"], head, norm_w=w["model.norm.weight"], out=g["logits"], h=bufs["h"])   # (h: the norm's output
+                ops.step_end(g["logits"], g["next_tok"], g["tok"], g["history"], g["d_step"], g["d_past"], g["ticket"])
         g["d_past"].fill_(st.offset)
         g["gemm_ws"] = {}                                        # B > 16 rows: the projections are split-K GEMMs; their workspace
         with ops.owned_gemm_workspace(g["gemm_ws"], frozen=False):   # belongs to the graph (sized here, baked in below)

@@ -1152,6 +1152,60 @@ def test_step_begin_end_match_separate_kernels(ops, B):
     assert torch.equal(hist, torch.stack(want[:steps], dim=1))
 
 
+@pytest.mark.parametrize("K", [3072, 8192])
+def test_gemv_step_folds_are_the_separate_launches(ops, K, B=1):
+    """p3v_gemv_step (round 6): the replayed step's first projection with step_begin in its prologue, and its last with step_end in
+    its epilogue, against the launches they replace -- projection outputs, residual rows, staged rotation rows, arg-max tokens
+    (ties: first maximum; NaN rows: -1), history and both counters BIT-IDENTICAL over several steps, the ticket left at zero;
+    shapes the fold does not take answer False and launch nothing."""
+    V, T, half, steps = 32064, 40, 48, 5
+    N1 = 1024                                                     # the "qkv" of this test
+    table = g((V, K), 70).cuda()
+    cos, sin = torch.rand((B, T, half), dtype=F32).cuda(), torch.rand((B, T, half), dtype=F32).cuda()
+    w1, nw1 = (g((N1, K), 71) * 0.05).cuda(), (1 + 0.1 * g((K,), 72)).cuda()
+    tok = torch.tensor([V + 5 if K == 8192 else 7004], dtype=torch.int32).cuda()   # (out of range: clamped, as p3v_step_begin clamps)
+    d_past = torch.tensor([11], dtype=torch.int32).cuda()
+    x_a, x_b = torch.empty((B, K), dtype=BF16).cuda(), torch.full((B, K), 7.0, dtype=BF16).cuda()
+    ca, sa = torch.empty((B, 1, half), dtype=F32).cuda(), torch.empty((B, 1, half), dtype=F32).cuda()
+    cb, sb = torch.zeros_like(ca), torch.zeros_like(sa)
+    ops.step_begin(tok, table, x_a, cos, sin, d_past, ca, sa)
+    out_a = ops.gemv(x_a, w1, norm_w=nw1, norm_eps=1e-5)
+    out_b = torch.full((B, N1), float("nan"), dtype=BF16).cuda()
+    assert ops.gemv_step_begin(tok, table, x_b, cos, sin, d_past, cb, sb, w1, nw1, 1e-5, out_b)
+    assert torch.equal(out_a.view(torch.int16), out_b.view(torch.int16)) and torch.equal(x_a, x_b)
+    assert torch.equal(ca, cb) and torch.equal(sa, sb) and torch.equal(cb[:, 0], cos[:, 11])
+    # the tail: final norm + lm_head + arg-max + bookkeeping
+    wl, nwl = (g((V, K), 73) * 0.05).cuda(), (1 + 0.1 * g((K,), 74)).cuda()
+    amax_ws = torch.empty((ops.L.GEMV_STEP_WS_BYTES // 4,), dtype=F32).cuda()
+    hist_a, hist_b = torch.zeros((B, steps), dtype=torch.int32).cuda(), torch.zeros((B, steps), dtype=torch.int32).cuda()
+    st_a, st_b = torch.zeros(1, dtype=torch.int32).cuda(), torch.zeros(1, dtype=torch.int32).cuda()
+    pa, pb = d_past.clone(), d_past.clone()
+    tk_a, tk_b = torch.zeros(1, dtype=torch.int32).cuda(), torch.zeros(1, dtype=torch.int32).cuda()
+    nx_a, nx_b, to_a, to_b = (torch.zeros(B, dtype=torch.int32).cuda() for _ in range(4))
+    for s in range(steps + 1):                                    # one step past the history capacity: must not write
+        x = g((B, K), 90 + s).cuda()
+        if s == 2:                                                # a tie between two vocabulary rows: the first one wins
+            wl[20000] = wl[300]
+        if s == 3:                                                # a poisoned row reports -1, the others their arg-max
+            x[0, 5] = float("nan")
+        lg_a = ops.gemv(x, wl, norm_w=nwl, norm_eps=1e-5)
+        ops.step_end(lg_a, nx_a, to_a, hist_a, st_a, pa, tk_a)
+        lg_b = torch.empty((B, V), dtype=BF16).cuda()
+        assert ops.gemv_step_end(x, wl, nwl, 1e-5, lg_b, nx_b, to_b, hist_b, st_b, pb, tk_b, amax_ws)
+        assert torch.equal(lg_a.view(torch.int16), lg_b.view(torch.int16))
+        assert torch.equal(nx_a, nx_b) and torch.equal(to_a, to_b), (s, nx_a.tolist(), nx_b.tolist())
+        assert st_b.item() == s + 1 and pb.item() == 12 + s and tk_b.item() == 0 and st_a.item() == st_b.item() and pa.item() == pb.item()
+        if s == 3:
+            assert nx_b[0].item() == -1
+    assert torch.equal(hist_a, hist_b)
+    # not on the fold's path: more than one row (p3v_gemv runs another kernel there), a hidden size the streaming kernel does not take
+    assert not ops.gemv_step_end(g((2, K), 1).cuda(), wl, nwl, 1e-5, torch.empty((2, V), dtype=BF16).cuda(), nx_b, to_b, hist_b, st_b, pb, tk_b, amax_ws)
+    small = g((64, 192), 2).cuda()
+    assert not ops.gemv_step_begin(tok[:1], g((V, 192), 3).cuda(), torch.empty((1, 192), dtype=BF16).cuda(), cos, sin, d_past, cb, sb, small,
+                                   torch.ones(192, dtype=BF16).cuda(), 1e-5, torch.empty((1, 64), dtype=BF16).cuda())
+    assert st_b.item() == steps + 1                               # (nothing was launched)
+
+
 @pytest.mark.parametrize("M,K,N,r", [(1, 3072, 9216, 1), (5, 192, 576, 8), (300, 256, 512, 20)])
 def test_lora_down_up(ops, M, K, N, r):
     """p3v_lora_down / p3v_lora_up vs LoRALinear.__call__ (phi.py:129-133) in fp32, all three fused epilogues."""
