@@ -1958,11 +1958,16 @@ __device__ __forceinline__ void fo_project(const FoP f, const int o_wl, unsigned
     __shared__ int o_timeout;
     const uint32_t* src = (const uint32_t*)f.out;
     if (wave == 0) {
+      // bounded by WALL TIME (100 MHz counter), 5 ms: the launch itself lasts ~15 us, and a run whose workgroups are not all resident
+      // (a profiler that masks CUs or serialises workgroups, a co-tenant process) must fail FAST and loudly -- NaN row, negative token,
+      // api.greedy_loop re-plans with separate launches -- not after 65536 polls per workgroup (rounds 4-5: ~65 ms each, 32 launches per
+      // step: whole-graph rocprofv3 --pmc passes did not finish).  P3V_PROFILING=1 plans the separate launches from the start.
       bool to = false;
+      const long long t_wait = wall_clock64();
       for (unsigned tries = 0;; ++tries) {
         const uint32_t c = lane < f.nh ? __hip_atomic_load(src + lane * (HD / 2) + HD / 2 - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
         if (!__any((c & 0xffffu) == 0xffffu || (c >> 16) == 0xffffu)) break;
-        if (tries >= (1u << 16)) { to = true; break; }
+        if ((tries & 15u) == 15u && wall_clock64() - t_wait > 500000) { to = true; break; }
         __builtin_amdgcn_s_sleep(P3V_FO_SLEEP);
       }
       if (lane == 0) o_timeout = to;

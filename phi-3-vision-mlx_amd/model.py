@@ -498,7 +498,10 @@ class Phi3VModel:
         # The launch of layer i re-arms the OTHER buffer, so the two alternate cleanly only over an EVEN number of layers (an odd
         # stack would hand layer 0 of the next step the buffer the last layer just filled: stale words read as "written").
         # It also needs the GPU to itself (every workgroup resident at once): not for a server-owned model.
-        ok = (os.environ.get("P3V_ATTN_FUSE_OPROJ", "1") != "0" and B == 1 and L == 1 and bufs.get("attn_merge", False)
+        # P3V_PROFILING=1: no launch of the step may wait for another workgroup of its own grid (whole-graph rocprofv3 --pmc passes
+        # serialise / mask what they profile): separate o_proj launch here, separate merge launch in _split_plan
+        ok = (os.environ.get("P3V_ATTN_FUSE_OPROJ", "1") != "0" and os.environ.get("P3V_PROFILING") != "1"
+              and B == 1 and L == 1 and bufs.get("attn_merge", False)
               and cfg.num_hidden_layers % 2 == 0 and not self.serving
               and not self.adapters and (o_key in self.w8) == bool(quantized) and not (quantized and o_key in self.w4)
               and can(B, L, cfg.num_attention_heads, self.hd, bufs["n_split"], T, cfg.hidden_size, True))
@@ -547,6 +550,8 @@ class Phi3VModel:
             if serving and fused and mode != "2":
                 per_cu = 3 if n_split == tiles128 else 5
                 fused = B * nh * n_split <= per_cu * ops.device_props(torch.device(self.device).index or 0)["cu_count"]
+            if os.environ.get("P3V_PROFILING") == "1":           # (see _plan_fused_oproj)
+                fused = False
             bufs["attn_merge"] = bool(fused)
 
     def _layers(self, x, st, B, L, past, n_beam, bufs=None, d_past=None, last_only=False, step_begin=None):
