@@ -98,6 +98,11 @@ typedef struct {
  * own.  Graph-capturable. */
 int p3v_gemm(const p3v_gemm_args_t* args /* host */, void* stream);
 int64_t p3v_gemm_ws_bytes(int M, int N, int K, int epilogue);
+/* Round 6: 9 .. 32 rows of A on bf16 weights with K = 3072 or 8192 (a 9 .. 32-sequence decode batch; the reference's batched benchmark
+ * runs 15, phi_3_vision_mlx.py:1226-1243) take a register-streaming kernel inside p3v_gemm / p3v_gemm_resid_norm (weights HBM ->
+ * registers in whole lines, A resident as MFMA fragments): this query says how -- 0 = not that kernel's shape, 1 = one pass,
+ * S > 1 = S K slices through the `ws` partials + the reduction launch.  Host-only. */
+int p3v_gemm_rows_slices(int M, int N, int K, int epilogue);
 
 /* ---- skinny projection for decode: y[M,N] = x[M,K] * W[N,K]^T, M <= 16, weight-streaming
  * (M == 1: VALU dot products; 2 <= M <= 16: the weight rows go straight from HBM into MFMA fragments).

@@ -101,6 +101,7 @@ SIGNATURES = {
     "p3v_layernorm": (i32, [vp, vp, vp, vp, i32, i32, i32, f32, vp]),
     "p3v_gemm": (i32, [C.POINTER(GemmArgs), vp]),
     "p3v_gemm_ws_bytes": (i64, [i32, i32, i32, i32]),
+    "p3v_gemm_rows_slices": (i32, [i32, i32, i32, i32]),
     "p3v_gemv": (i32, [C.POINTER(GemvArgs), vp]),
     "p3v_gemv_step": (i32, [C.POINTER(GemvArgs), C.POINTER(GemvStep), vp]),
     "p3v_gemv_fp8": (i32, [C.POINTER(GemvF8Args), vp]),

@@ -154,6 +154,7 @@ static inline int p3v_gemv_wpw(int waves, int n_cu, int forced) {
 struct P3vTuning {
   int gemm_big_rows;        // rows given to the 256x256-tile GEMM (-1: cost model)
   int gemm_no_splitk, gemm_splitk_max_m, gemm_splitk_max_s, gemm_splitk_wgs, gemm_128, gemm_persistent;
+  int gemm_rows;            // 1: 9 .. 32 rows on the register-streaming kernel (p3v_gemm_rows.hip), 0: on the 64-row tiles of p3v_gemm_skinny.hip
   int gemm_no_skinny, gemm_skinny_max_m, gemm_skinny_s, gemm_skinny_tm128;   // the 128 x 64-tile weight-streaming kernel for 17 .. max_m rows (p3v_gemm_skinny.hip)
   int gemm_no_qkv_fuse;     // 1: p3v_gemm_qkv reports P3V_ERR_UNSUPPORTED (callers then run p3v_gemm + p3v_rope_kv_append)
   int gemm_f8_narrow;       // -1: by shape, 0 / 1: pin the fp8 tile width

@@ -305,7 +305,14 @@ __global__ void __launch_bounds__(512, 1) k_gemm_skinny(SkinnyP p) {
 
 // K slices for a shape on this kernel: 0 = not one of its shapes; 1 = one pass; S > 1 = S slices + the reduction launch.
 // One workgroup per CU: the largest S <= 8 whose tiles * S still fit one round of the chip (slices of >= 6 K-tiles).
+extern "C" int p3v_gemm_rows_slices(int M, int N, int K, int epilogue);            // p3v_gemm_rows.hip: 9 .. 32 rows, weights straight to registers
+int p3v_gemm_rows_launch(const p3v_gemm_args_t* a, float* part, hipStream_t s);
+static int sk_slices(int M, int N, int K, int epilogue);
 int p3v_gemm_skinny_slices(int M, int N, int K, int epilogue) {
+  const int rs = p3v_gemm_rows_slices(M, N, K, epilogue);
+  return rs ? rs : sk_slices(M, N, K, epilogue);
+}
+static int sk_slices(int M, int N, int K, int epilogue) {
   const P3vTuning& t = p3v_tuning();
   const bool silu = epilogue == P3V_EPI_SILU_MUL;
   if (t.gemm_no_skinny || M <= 8 || M > t.gemm_skinny_max_m || K % SK_BK || N % (silu ? 32 : 64)) return 0;
@@ -346,9 +353,16 @@ int p3v_splitk_reduce(const float* part, const p3v_gemm_args_t* a, int S, hipStr
 // the K-slice launch alone (fp32 partials into a->ws; *S_out slices): P3V_ERR_UNSUPPORTED, nothing launched, unless the shape is
 // one this kernel splits and the workspace holds the partials
 int p3v_gemm_skinny_partials(const p3v_gemm_args_t* a, int* S_out, hipStream_t s) {
-  const int S = p3v_gemm_skinny_slices(a->M, a->N, a->K, a->epilogue);
   const bool silu = a->epilogue == P3V_EPI_SILU_MUL;
   const int w_rows = silu ? 2 * a->N : a->N;
+  const int RS = a->bias ? 0 : p3v_gemm_rows_slices(a->M, a->N, a->K, a->epilogue);
+  if (RS > 1 && a->ws && a->ws_bytes >= (int64_t)RS * a->M * w_rows * 4) {        // 9 .. 32 rows: the register-streaming kernel's K slices
+    if ((uintptr_t)a->ws & 15) return P3V_ERR_ARG;
+    *S_out = RS;
+    return p3v_gemm_rows_launch(a, (float*)a->ws, s);
+  }
+  if (RS == 1) return P3V_ERR_UNSUPPORTED;                       // (runs in one pass: no partials)
+  const int S = sk_slices(a->M, a->N, a->K, a->epilogue);
   if (S <= 1 || !a->ws || a->ws_bytes < (int64_t)S * a->M * w_rows * 4) return P3V_ERR_UNSUPPORTED;
   if ((uintptr_t)a->ws & 15) return P3V_ERR_ARG;
   *S_out = S;
@@ -362,10 +376,15 @@ int p3v_gemm_skinny_partials(const p3v_gemm_args_t* a, int* S_out, hipStream_t s
 // p3v_gemm_ws_bytes() runs as one pass.
 int p3v_gemm_skinny_try(const p3v_gemm_args_t* a, hipStream_t s) {
   if (p3v_gemm_skinny_slices(a->M, a->N, a->K, a->epilogue) == 0) return P3V_ERR_UNSUPPORTED;
+  if (p3v_gemm_rows_slices(a->M, a->N, a->K, a->epilogue) == 1) {                  // 9 .. 32 rows, one pass
+    const int rr = p3v_gemm_rows_launch(a, nullptr, s);
+    if (rr != P3V_ERR_UNSUPPORTED) return rr;
+  }
   int S = 1;
   const int rc = p3v_gemm_skinny_partials(a, &S, s);
   if (rc == P3V_OK) return p3v_splitk_reduce((const float*)a->ws, a, S, s);
   if (rc != P3V_ERR_UNSUPPORTED) return rc;
+  if (sk_slices(a->M, a->N, a->K, a->epilogue) == 0) return P3V_ERR_UNSUPPORTED;   // (a rows shape whose slices found no workspace and that the tile kernel does not take)
   const SkinnyP p = {a->A, a->W, a->out, a->resid, a->M, a->N, a->K, a->lda, a->ldw, a->ldo, 0, {}};
   if (a->epilogue == P3V_EPI_SILU_MUL) return launch_skinny<P3V_EPI_SILU_MUL>(p, 1, s);
   if (a->epilogue == P3V_EPI_RESID_BF16) return launch_skinny<P3V_EPI_RESID_BF16>(p, 1, s);

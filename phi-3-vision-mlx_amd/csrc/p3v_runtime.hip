@@ -44,6 +44,7 @@ const Knob kKnobs[] = {
     {"gemv_wpw", &P3vTuning::gemv_wpw, 0},
     {"gemm_no_skinny", &P3vTuning::gemm_no_skinny, 0},      {"gemm_skinny_max_m", &P3vTuning::gemm_skinny_max_m, 256},
     {"gemm_skinny_s", &P3vTuning::gemm_skinny_s, 0},            {"gemm_skinny_tm128", &P3vTuning::gemm_skinny_tm128, 0},
+    {"gemm_rows", &P3vTuning::gemm_rows, 1},
     {"attn_fo_map", &P3vTuning::attn_fo_map, 2},              {"attn_fo_map_q8", &P3vTuning::attn_fo_map_q8, 0},
 };
 P3vTuning g_tuning;

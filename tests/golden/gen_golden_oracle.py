@@ -309,11 +309,11 @@ def tiny_serve():
     print("wrote tiny_serve_oracle.npz")
 
 
-def _full_oracle(transform=None, outliers=None):
+def _full_oracle(transform=None, outliers=None, residual_scale=None):
     torch.set_num_threads(8)
     cfg = make_config(phi3v_config_dict(vision=True))
     t0 = time.time()
-    w = synth_weights(cfg, seed=0, outliers=outliers)
+    w = synth_weights(cfg, seed=0, outliers=outliers, residual_scale=residual_scale)
     print(f"weights {time.time() - t0:.0f}s", flush=True)
     base = w["lm_head.weight"]
     if transform is not None:
@@ -472,6 +472,46 @@ def c5(act8=True):
     print("wrote", name)
 
 
+REL_TOL_C5_WC = 0.08            # config 5 W8A8 on the well-conditioned checkpoint, <= 8 %
+REL_TOL_C5W_WC = 0.03           # ... and weight-only fp8 (W8A16)
+
+
+def c5_wc(act8=True):
+    """`c5_wc_oracle.npz` / `c5w_wc_oracle.npz` (round 6): config 5's three quantisers (e4m3 weights, e4m3 prompt activations when
+    act8, int8 KV) applied to the oracle on the WELL-CONDITIONED checkpoint (decoder residual branches x 1 / 1024, as
+    gen_golden_refmodel.wc) for BASELINE config 2's request, 8 greedy steps under two UNSEARCHED heads (plain, peaked seed 0; the
+    peaked one through the weight quantiser, as the build quantises its lm_head).  The reference has no fp8 path: this fixture is
+    the oracle's, like every c5 fixture.  On this net a flipped e4m3 code is not amplified by the 32 layers behind it, so what two
+    correct implementations of the SAME quantised arithmetic differ by is visible at its own size (c5_oracle.npz on the plain
+    checkpoint needs 25 %)."""
+    from phi_3_vision_mlx_amd.ops import quantize_fp8_rows
+    n_steps = 8
+    rel_tol = REL_TOL_C5_WC if act8 else REL_TOL_C5W_WC
+    cfg, o, base = _full_oracle(c5_quantisers, residual_scale=1.0 / 1024)
+    o.proj = c5_proj(o, act8)
+    orig = orc.OracleKVCache
+    orc.OracleKVCache = QuantKVCache
+    try:
+        ip = Phi3VProcessor(None).img_processor
+        inp = vqa_request(ip, 0)
+        r = Prefilled(o, {k: (torch.from_numpy(v) if k == "pixel_values" else v) for k, v in inp.items()}, n_steps, tag="c5wc" if act8 else "c5wwc")
+        r.rel_tol = rel_tol
+
+        def q(h):                                                    # the build quantises its lm_head rows too
+            w8, sc = quantize_fp8_rows(h.to(BF16))
+            return w8.view(torch.float8_e4m3fn).to(F32) * sc[:, None]
+        out = dict(COMMON, rel_tol=np.asarray([rel_tol], dtype=np.float32), n_ids=np.asarray([r.S], dtype=np.int32),
+                   residual_scale=np.asarray([1.0 / 1024], dtype=np.float32))
+        for prefix, head in (("plain_", q(base)), ("peaked0_", q(peaked_lm_head(base.to(F32), SPREAD, 0)))):
+            res = r.greedy(head, n_steps)
+            pack_long(prefix, head, res, out, rel_tol)
+    finally:
+        orc.OracleKVCache = orig
+    name = "c5_wc_oracle.npz" if act8 else "c5w_wc_oracle.npz"
+    np.savez_compressed(os.path.join(HERE, name), **out)
+    print("wrote", name)
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # Heavy-tailed activations (weights.add_outliers: 6 residual-stream channels x 64, 2 key / value dimensions per head x 8).
 # Three arithmetic variants of config 2's request at FULL size, each against an oracle with the same weights / quantisers:
@@ -576,3 +616,7 @@ if __name__ == "__main__":
         c5(True)
     if which in ("c5w", "all"):
         c5(False)
+    if which == "c5_wc":
+        c5_wc(True)
+    if which == "c5w_wc":
+        c5_wc(False)

@@ -583,6 +583,65 @@ def wc():
     print("wrote ref_model_wc.npz/.json")
 
 
+REL_TOL_WC_C2 = 0.02            # <= 2 % on the image path of a well-conditioned checkpoint
+
+
+def wc_c2():
+    """`ref_model_wc_c2.npz` (round 6): the REFERENCE'S OWN code at full size on the WELL-CONDITIONED vision checkpoint (decoder
+    residual branches x 1 / 1024, as `wc`; the CLIP tower and the projector as they are) for BASELINE config 2's request -- bench.py's
+    seeded 336 x 336 image -> 17 crops -> 2509 image tokens + 22 text tokens -- over 16 greedy steps through `_generate`, under two
+    UNSEARCHED heads (plain N(0, 0.02) and the peaked head of seed 0).  The image path (ViT + HD merge + projector + scatter) feeds a
+    decoder that does not amplify: what differs between two correct programs there (fp32 tower association, bf16 GEMM inputs of the
+    build) reaches the logits at its own size.  pack_long records per step; tests/test_model_gpu.py holds the HIP path to
+    REL_TOL_WC_C2."""
+    from gen_golden_oracle import pack_long
+    from golden_inputs import vqa_request
+    from phi_3_vision_mlx_amd.config import phi3v_config_dict
+    torch.set_num_threads(8)
+    n_steps = 16
+    out = dict(spread=np.asarray([SPREAD], dtype=np.float32), rel_tol=np.asarray([REL_TOL_WC_C2], dtype=np.float32),
+               residual_scale=np.asarray([RESIDUAL_SCALE_WC], dtype=np.float32))
+    meta = {"generator": "tests/golden/gen_golden_refmodel.py wc_c2", "residual_scale": RESIDUAL_SCALE_WC, "steps": n_steps}
+    d = phi3v_config_dict(vision=True)
+    cfg = make_config(d)
+    t0 = time.time()
+    w = synth_weights(cfg, seed=0, residual_scale=RESIDUAL_SCALE_WC)
+    base = w["lm_head.weight"]
+    path = os.path.join(TMP, "wc_vision")
+    shutil.rmtree(path, ignore_errors=True)
+    save_safetensors_dir(w, d, path)
+    print(f"weights written {time.time() - t0:.0f}s", flush=True)
+    inp2 = vqa_request(Phi3VProcessor(None).img_processor, 0)
+    ids2 = np.asarray(inp2["input_ids"])[0]
+    n_img = int((ids2 < 0).sum())
+    first_neg = int(np.argmax(ids2 < 0))
+    table = {"A": [int(t) for t in ids2[:first_neg]], "B": [int(t) for t in ids2[first_neg + n_img:]]}
+    mx, phi, loops = ref_env.load_reference()
+    model, proc = ref_env.load_model(path, TableTokenizer(table), clip_cfg=d["clip"])
+    del w
+    from PIL import Image
+    img = Image.fromarray(np.random.default_rng(0).integers(0, 256, (336, 336, 3), dtype=np.uint8))      # vqa_request's image (seed 0)
+    out["n_ids"] = np.asarray([ids2.shape[0]], dtype=np.int32)
+    for prefix, head in (("plain_", base), ("peaked0_", peaked_lm_head(base, SPREAD, 0))):
+        model.lm_head.weight = mx.array(head)
+        rec = ref_env.Recorder(model)
+        t0 = time.time()
+        loops._generate(rec, proc, "A<|image_1|>B", [img], max_tokens=n_steps, verbose=False, stream=False, mute=True)
+        ids = as_t(rec.calls[0]["input_ids"]).long()
+        assert np.array_equal(ids.numpy(), ids2[None]), "the reference's processor built other ids than bench.py's request"
+        lgs = torch.stack([c["logits"]._t[:, -1] for c in rec.calls], 1)
+        toks = torch.argmax(lgs.float(), dim=-1)
+        mg = clearance(lgs, row_norms(head), REL_TOL_WC_C2)
+        pack_long(prefix, head, (toks, lgs, mg), out, REL_TOL_WC_C2)
+        meta[prefix[:-1]] = {"steps": int(lgs.shape[1]), "clear": int((mg > 1.0).sum()), "seconds": round(time.time() - t0)}
+        print(f"  {prefix[:-1]}: {lgs.shape[1]} steps, {int((mg > 1.0).sum())} clear at rel_tol {REL_TOL_WC_C2} ({time.time() - t0:.0f}s)", flush=True)
+    np.savez_compressed(os.path.join(HERE, "ref_model_wc_c2.npz"), **out)
+    with open(os.path.join(HERE, "ref_model_wc_c2.json"), "w") as f:
+        json.dump(meta, f, indent=1)
+    shutil.rmtree(path, ignore_errors=True)
+    print("wrote ref_model_wc_c2.npz/.json")
+
+
 def wc_retol():
     """Re-state ref_model_wc.npz at the current REL_TOL_WC without re-running the reference (12 minutes of CPU per head): the clearance
     of a step is (top-2 margin) / (sum of the two entries' tolerances), i.e. inversely proportional to rel_tol -- an exact rescale."""
@@ -609,6 +668,8 @@ if __name__ == "__main__":
         wc()
     elif len(sys.argv) > 1 and sys.argv[1] == "wc_retol":
         wc_retol()
+    elif len(sys.argv) > 1 and sys.argv[1] == "wc_c2":
+        wc_c2()
     elif len(sys.argv) > 1 and sys.argv[1] in ("constrain", "q4cache"):   # one case, merged into the existing fixture
         out, meta = {}, {}
         if sys.argv[1] == "constrain":

@@ -216,7 +216,55 @@ def test_gemm_skinny_rows(ops, epi, M, N, K):
                 ops.set_tuning("gemm_skinny_s", old)
 
 
-@pytest.mark.parametrize("M,N,K", [(128, 3072, 3072), (100, 3072, 8192), (17, 3072, 3072), (250, 192, 768), (129, 1024, 1024)])
+ROWS_SHAPES = [("none", 9216, 3072), ("resid_bf16", 3072, 3072), ("silu", 8192, 3072), ("resid_bf16", 3072, 8192), ("none", 32064, 3072)]
+
+
+@pytest.mark.parametrize("M", [9, 15, 16, 17, 24, 32])
+@pytest.mark.parametrize("epi,N,K", ROWS_SHAPES)
+def test_gemm_rows_9_to_32(ops, epi, N, K, M):
+    """9 .. 32 rows on the register-streaming kernel (p3v_gemm_rows.hip, round 6: weights HBM -> registers in full lines, x as resident
+    MFMA B fragments, K quarters per wave; qkv / gate_up / lm_head in one pass, o_proj / down as 4 K slices + the reduction launch)
+    on the decoder's own shapes: against a float64 product with the reference's roundings, against the 64-row-tile kernel the shape
+    took before (same roundings, another summation order), three launches bit-identical, rows beyond M untouched."""
+    EPI = {"none": ops.EPI_NONE, "resid_bf16": ops.EPI_RESID_BF16, "silu": ops.EPI_SILU_MUL}[epi]
+    assert ops.L.lib().p3v_gemm_rows_slices(M, N, K, EPI) in (1, 4)
+    a = g((M, K), 160 + M).cuda()
+    w = g(((2 * N if epi == "silu" else N), K), 161, 1.0 / math.sqrt(K)).cuda()
+    r = g((M, N), 162).cuda() if epi == "resid_bf16" else None
+    buf = torch.full((M + 3, N), 7.0, dtype=BF16, device="cuda")            # three guard rows behind the output
+    out = ops.gemm(a, w, EPI, resid=r, out=buf[:M])
+    assert bool((buf[M:] == 7.0).all())
+    for _ in range(2):
+        assert torch.equal(ops.gemm(a, w, EPI, resid=r), out)
+    old = ops.set_tuning("gemm_rows", 0)
+    try:
+        other = ops.gemm(a, w, EPI, resid=r)
+    finally:
+        ops.set_tuning("gemm_rows", old)
+    z = (a.double() @ w.double().t())
+    if epi == "silu":
+        gate, up = z[:, :N].to(BF16).double(), z[:, N:].to(BF16).double()
+        ref = (gate * torch.sigmoid(gate)).to(BF16).double() * up
+    elif epi == "resid_bf16":
+        ref = r.double() + z.to(BF16).double()
+    else:
+        ref = z
+    close(out, ref.to(BF16), rtol=2 ** -6, atol=2e-2)
+    close(out, other, rtol=2 ** -6, atol=2e-2)
+    assert (out == other).float().mean().item() > 0.99
+
+
+def test_gemm_rows_declines_other_shapes(ops):
+    """Not this kernel's: 8 rows and fewer (k_gemv_mfma8), more than 32, a K it has no slicing for, a bias epilogue; those keep their
+    previous kernels and results."""
+    lib = ops.L.lib()
+    assert lib.p3v_gemm_rows_slices(8, 9216, 3072, ops.EPI_NONE) == 0 and lib.p3v_gemm_rows_slices(33, 9216, 3072, ops.EPI_NONE) == 0
+    assert lib.p3v_gemm_rows_slices(16, 9216, 1024, ops.EPI_NONE) == 0 and lib.p3v_gemm_rows_slices(16, 1024, 3072, ops.EPI_BIAS) == 0
+    a, w = g((16, 1024), 170).cuda(), g((512, 1024), 171, 1 / 32).cuda()
+    close(ops.gemm(a, w), (a.double() @ w.double().t()).to(BF16), rtol=2 ** -6, atol=2e-2)
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 3072, 3072), (100, 3072, 8192), (17, 3072, 3072), (250, 192, 768), (129, 1024, 1024), (16, 3072, 8192), (32, 3072, 3072)])
 def test_gemm_resid_norm_is_the_two_calls(ops, M, N, K):
     """p3v_gemm_resid_norm == p3v_gemm(P3V_EPI_RESID_BF16) + p3v_rmsnorm, bit for bit, from the projection's own launches (the K-slice
     GEMM + one reduction that also normalises); shapes the library does not split report "unsupported" and launch nothing."""
