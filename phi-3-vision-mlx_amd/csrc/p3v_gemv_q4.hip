@@ -207,8 +207,196 @@ static int launch_gemv3_q4(const GemvQ4P& p, hipStream_t s) {
   return P3V_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// 2 .. 16 rows of x on the 4-bit weights (round 6): the reference runs QuantizedLinear at every batch size
+// (phi_3_vision_mlx.py:296; README batched 4-bit benchmark), rounds 3-5 dequantised the WHOLE matrix into a bf16 scratch per call
+// (2 launches, 5 x the 4-bit bytes moved).  This is k_gemm_rows (p3v_gemm_rows.hip) on the packed weights: the lane that held a
+// 16-byte bf16 chunk of a weight line now loads 16 bytes = 32 WEIGHTS of the row (eight lanes cover the 128-byte line that holds a
+// row's 256-weight block: whole lines per instruction, 0.5 byte per weight from HBM), all of one 64-weight group (dword j of the
+// lane = weights 64 g + 32 h + 8 j ..+7 of the block: group g), so ONE scale | bias word per (lane, block, row set) dequantises them in
+// registers: (1024 + q) as an fp16 pair straight from the nibbles (0x6400 | q), - 1024, * scale + bias with v_pk_fma_f16 -- two
+// weights per instruction, 11 significant bits (the bf16 scratch of the old path kept 8) -- and the products run on the fp16 MFMA
+// against x converted once to fp16 fragments in the matching k-order (column m, k-slot g of MFMA j: x[m][64 g + 32 h' + 8 j ..+7]).
+// K = 3072: 4 waves x 3 blocks; K = 8192: 8 waves x 4 blocks.  Epilogues and the cross-wave exchange as k_gemm_rows.
+typedef _Float16 q4h2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 q4h8_t __attribute__((ext_vector_type(8)));
+struct RowsQ4P {
+  const bf16_t* x; const uint32_t* W; const uint32_t* sb; void* out; const bf16_t* resid;
+  int M, N, K, epi, n_sets;
+};
+typedef std::integral_constant<int, 2> QC2;
+typedef std::integral_constant<int, 3> QC3;
+
+__device__ __forceinline__ q4h8_t q4_dequant8(uint32_t d, q4h2_t s2, q4h2_t b2) {
+  const q4h2_t k1024 = {(_Float16)1024.f, (_Float16)1024.f};
+  uint32_t o[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    uint32_t pw = ((d >> (4 * i)) & 0x000F000Fu) | 0x64006400u;       // fp16 pair (1024 + q[2i], 1024 + q[2i + 1])
+    asm("" : "+v"(pw));                                               // (hipcc folds bit_casts of freshly built words: see dot8)
+    const q4h2_t q = __builtin_bit_cast(q4h2_t, pw) - k1024;
+    o[i] = __builtin_bit_cast(uint32_t, q * s2 + b2);
+  }
+  const u32x4_t v = {o[0], o[1], o[2], o[3]};
+  return __builtin_bit_cast(q4h8_t, v);
+}
+
+template <bool SILU, int NW, int NST>
+__global__ void __launch_bounds__(NW * 64) k_gemm_rows_q4(RowsQ4P p) {
+  constexpr int KQ = NST * 256;                                  // a wave's K quarter (NST 256-weight blocks)
+  __shared__ float cpart[2][NW * 2 * 8 * 16];                    // [parity][wave][row set][weight row][x row]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, li = lane & 15;
+  const int r8 = li >> 1, hbit = lane & 1;
+  const int k_lo = wave * KQ;
+  const int kd = p.K / 8, kg = p.K / 64;                         // dwords / groups per weight row
+  auto row_ptrs = [&](int set, const uint32_t*& w0, const uint32_t*& w1, const uint32_t*& s0, const uint32_t*& s1) {
+    const int n_base = set * (SILU ? 8 : 16);
+    const int row0 = min(n_base + r8, p.N - 1);
+    const int row1 = SILU ? p.N + row0 : min(n_base + 8 + r8, p.N - 1);
+    w0 = p.W + (size_t)row0 * kd + k_lo / 8 + 4 * (2 * g + hbit);
+    w1 = p.W + (size_t)row1 * kd + k_lo / 8 + 4 * (2 * g + hbit);
+    s0 = p.sb + (size_t)row0 * kg + k_lo / 64 + g;
+    s1 = p.sb + (size_t)row1 * kg + k_lo / 64 + g;
+  };
+  // Register ring of D sets: set i lives in slot i % D and the stage just consumed is refilled with the same stage of set i + D.  D = 1
+  // is what ships: a set's K quarter is only NST x 2 KB here, but D = 3 (9 KB per wave on the wire, 295 registers) measured SLOWER --
+  // qkv / o_proj 8.6 -> 10.6 us, gate_up 12.6 -> 14.4 at 8 rows: the launch is not bandwidth- or latency-bound but made of fixed costs
+  // (the x fragments of every workgroup, a barrier + epilogue per set).
+  constexpr int D = 1;
+  const int stride = (int)gridDim.x;
+  int set = blockIdx.x;
+  u32x4_t wa[D][NST][2];
+  uint32_t sv[D][NST][2];
+  auto issue = [&](int which, auto slotc, auto stc) {
+    constexpr int slot = decltype(slotc)::value, st = decltype(stc)::value;
+    const uint32_t *a0, *a1, *b0, *b1;
+    row_ptrs(min(which, p.n_sets - 1), a0, a1, b0, b1);
+    wa[slot][st][0] = __builtin_nontemporal_load((const u32x4_t*)(a0 + st * 32));
+    wa[slot][st][1] = __builtin_nontemporal_load((const u32x4_t*)(a1 + st * 32));
+    sv[slot][st][0] = b0[st * 4];
+    sv[slot][st][1] = b1[st * 4];
+  };
+  auto issue_set = [&](int which, auto slotc) {
+    issue(which, slotc, QC0{});
+    if constexpr (NST > 1) issue(which, slotc, QC1{});
+    if constexpr (NST > 2) issue(which, slotc, QC2{});
+    if constexpr (NST > 3) issue(which, slotc, QC3{});
+  };
+  static_assert(NST <= 4, "unrolled for at most four blocks");
+  issue_set(set, QC0{});
+  if constexpr (D > 1) issue_set(set + stride, QC1{});
+  if constexpr (D > 2) issue_set(set + 2 * stride, QC2{});
+
+  // (The input RMSNorm is NOT fused here: built and measured -- every one of the 192-256 workgroups normalising its own copy of the 2 .. 16
+  //  rows costs more than the one p3v_rmsnorm launch it saves: B = 8 at 512 keys 2.39 ms per step fused against 2.13 with the launch.)
+  q4h8_t xf[NST][4][2];
+  {
+    const bf16_t* xr = p.x + (size_t)min(li, p.M - 1) * p.K + k_lo + 64 * g;
+#pragma unroll
+    for (int blk = 0; blk < NST; ++blk)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const u32x4_t v = *(const u32x4_t*)(xr + blk * 256 + 32 * h + 8 * j);
+          q4h8_t f;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { f[2 * e] = (_Float16)bf16lo(v[e]); f[2 * e + 1] = (_Float16)bf16hi(v[e]); }
+          xf[blk][j][h] = f;
+        }
+  }
+
+  int par = 0;
+  auto do_set = [&](auto slotc) {
+    constexpr int slot = decltype(slotc)::value;
+    const int refill = set + D * stride;
+    const bool has_refill = refill < p.n_sets;                   // workgroup-uniform
+    f32x4_t acc[2][2];
+#pragma unroll
+    for (int s_ = 0; s_ < 2; ++s_) acc[s_][0] = acc[s_][1] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    auto step = [&](auto stc) {
+      constexpr int st = decltype(stc)::value;
+      if constexpr (st < NST) {
+#pragma unroll
+        for (int s_ = 0; s_ < 2; ++s_) {
+          const _Float16 sc = (_Float16)bf16lo(sv[slot][st][s_]), bi = (_Float16)bf16hi(sv[slot][st][s_]);
+          const q4h2_t s2 = {sc, sc}, b2 = {bi, bi};
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const q4h8_t a = q4_dequant8(wa[slot][st][s_][j], s2, b2);
+            acc[s_][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, xf[st][j][0], acc[s_][0], 0, 0, 0);
+            acc[s_][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, xf[st][j][1], acc[s_][1], 0, 0, 0);
+          }
+        }
+        if (has_refill) issue(refill, slotc, stc);
+      }
+    };
+    step(QC0{}); step(QC1{}); step(QC2{}); step(QC3{});
+    float* cp = cpart[par];
+#pragma unroll
+    for (int s_ = 0; s_ < 2; ++s_) {
+      cp[((wave * 2 + s_) * 8 + 2 * g) * 16 + li] = acc[s_][0][0] + acc[s_][1][1];
+      cp[((wave * 2 + s_) * 8 + 2 * g + 1) * 16 + li] = acc[s_][0][2] + acc[s_][1][3];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    constexpr int ITEMS = (SILU ? 8 : 16) * 16;
+#pragma unroll 1
+    for (int idx = tid; idx < ITEMS; idx += NW * 64) {
+      const int R = idx & 7, sub = SILU ? 0 : (idx >> 3) & 1, m = SILU ? idx >> 3 : idx >> 4;
+      const int n = set * (SILU ? 8 : 16) + sub * 8 + R;
+      if (m < p.M && n < p.N) {
+        float v0 = 0.f, v1 = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+          v0 += cp[((w * 2 + sub) * 8 + R) * 16 + m];
+          if (SILU) v1 += cp[((w * 2 + 1) * 8 + R) * 16 + m];
+        }
+        const size_t o = (size_t)m * p.N + n;
+        if (SILU) {
+          const float gt = bf16_round(v0), up = bf16_round(v1);
+          ((bf16_t*)p.out)[o] = f32_to_bf16(bf16_round(gt * bf16_round(1.f / (1.f + __expf(-gt)))) * up);
+        } else if (p.epi == P3V_EPI_F32) {
+          ((float*)p.out)[o] = v0;
+        } else if (p.epi == P3V_EPI_RESID_BF16) {
+          ((bf16_t*)p.out)[o] = f32_to_bf16(bf16_to_f32(p.resid[o]) + bf16_round(v0));
+        } else {
+          ((bf16_t*)p.out)[o] = f32_to_bf16(v0);
+        }
+      }
+    }
+    set += stride;
+    par ^= 1;
+    return set < p.n_sets;
+  };
+  for (;;) {
+    if (!do_set(QC0{})) break;
+    if constexpr (D > 1) { if (!do_set(QC1{})) break; }
+    if constexpr (D > 2) { if (!do_set(QC2{})) break; }
+  }
+}
+
+template <bool SILU, int NW, int NST>
+static int launch_rows_q4(const RowsQ4P& p, hipStream_t s) {
+  const int per = p3v_cdiv(p.n_sets, 256), gx = p3v_cdiv(p.n_sets, per);
+  hipLaunchKernelGGL((k_gemm_rows_q4<SILU, NW, NST>), dim3(gx), dim3(NW * 64), 0, s, p);
+  P3V_CHECK_LAUNCH();
+  return P3V_OK;
+}
+
 extern "C" int p3v_gemv_q4(const p3v_gemv_q4_args_t* a, void* stream) {
   if (!a || !a->x || !a->W || !a->sb || !a->out) return P3V_ERR_ARG;
+  if (a->M >= 2 && a->M <= 16 && (a->K == 3072 || a->K == 8192) && !a->norm_w && a->N > 0) {      // 2 .. 16 rows: k_gemm_rows_q4
+    const bool silu = a->epilogue == P3V_EPI_SILU_MUL;
+    if (a->N % (silu ? 8 : 16)) return P3V_ERR_UNSUPPORTED;
+    if (a->epilogue != P3V_EPI_NONE && a->epilogue != P3V_EPI_RESID_BF16 && !silu && a->epilogue != P3V_EPI_F32) return P3V_ERR_UNSUPPORTED;
+    if (a->epilogue == P3V_EPI_RESID_BF16 && !a->resid) return P3V_ERR_ARG;
+    if (((uintptr_t)a->x | (uintptr_t)a->W) & 15) return P3V_ERR_ARG;
+    const RowsQ4P q = {a->x, a->W, a->sb, a->out, a->resid, a->M, a->N, a->K, a->epilogue, a->N / (silu ? 8 : 16)};
+    hipStream_t s = (hipStream_t)stream;
+    if (a->K == 3072) return silu ? launch_rows_q4<true, 4, 3>(q, s) : launch_rows_q4<false, 4, 3>(q, s);
+    return silu ? launch_rows_q4<true, 8, 4>(q, s) : launch_rows_q4<false, 8, 4>(q, s);
+  }
   if (a->M != 1 || a->N <= 0 || a->N % 2 || (a->K != 3072 && a->K != 8192)) return P3V_ERR_UNSUPPORTED;
   if (a->epilogue != P3V_EPI_NONE && a->epilogue != P3V_EPI_RESID_BF16 && a->epilogue != P3V_EPI_SILU_MUL &&
       a->epilogue != P3V_EPI_F32)

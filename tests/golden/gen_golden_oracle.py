@@ -472,8 +472,8 @@ def c5(act8=True):
     print("wrote", name)
 
 
-REL_TOL_C5_WC = 0.08            # config 5 W8A8 on the well-conditioned checkpoint, <= 8 %
-REL_TOL_C5W_WC = 0.03           # ... and weight-only fp8 (W8A16)
+REL_TOL_C5_WC = 0.03            # VERDICT r05 item 1c asked for <= 8 % (config 5 W8A8 on the well-conditioned checkpoint); measured HIP-vs-oracle 1.6 %
+REL_TOL_C5W_WC = 0.02           # ... and weight-only fp8 (W8A16): measured 1.0 %
 
 
 def c5_wc(act8=True):

@@ -583,7 +583,7 @@ def wc():
     print("wrote ref_model_wc.npz/.json")
 
 
-REL_TOL_WC_C2 = 0.02            # <= 2 % on the image path of a well-conditioned checkpoint
+REL_TOL_WC_C2 = 0.012           # VERDICT r05 item 1c asked for <= 2 % on the image path of a well-conditioned checkpoint; measured HIP-vs-reference 0.76 %
 
 
 def wc_c2():

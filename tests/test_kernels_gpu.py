@@ -1326,6 +1326,54 @@ def test_gemv_q4_and_dequant(ops, N, K, epi, norm):
     close(got, ref, rtol=2 ** -6, atol=3e-2)
 
 
+@pytest.mark.parametrize("M", [2, 5, 8, 15, 16])
+@pytest.mark.parametrize("N,K,epi", [(9216, 3072, "none"), (3072, 3072, "resid"), (8192, 3072, "silu"), (3072, 8192, "resid"), (32064, 3072, "none")])
+def test_gemv_q4_rows_2_to_16(ops, N, K, epi, M):
+    """2 .. 16 rows straight on the 4-bit weights (k_gemm_rows_q4, round 6): == the fp32 product with the dequantised weights
+    (mx.quantized_matmul's semantics) on the decoder's own shapes -- the dequantisation in registers keeps 11 significant bits of
+    scale * q + bias (fp16), x is converted to fp16 exactly; against the dequantise-then-bf16-GEMM path it replaces; three launches
+    bit-identical; rows beyond M untouched; a fused RMSNorm is declined (the model normalises first)."""
+    from phi_3_vision_mlx_amd.ops import EPI_NONE, EPI_RESID_BF16, EPI_SILU_MUL
+    from phi_3_vision_mlx_amd.weights import mlx_dequantize, mlx_quantize, q4_repack
+    rows = 2 * N if epi == "silu" else N
+    w = g((rows, K), 410, 0.03)
+    packed, sc, bi = mlx_quantize(w)
+    wd = mlx_dequantize(packed, sc, bi)
+    w4, sb = (t.cuda() for t in q4_repack(packed, sc, bi))
+    x = g((M, K), 411 + M)
+    res = g((M, N), 413)
+    e = {"none": EPI_NONE, "resid": EPI_RESID_BF16, "silu": EPI_SILU_MUL}[epi]
+    buf = torch.full((M + 2, N), 7.0, dtype=BF16, device="cuda")
+    got = ops.gemv_q4(x.cuda(), w4, sb, e, resid=res.cuda() if epi == "resid" else None, out=buf[:M])
+    assert bool((buf[M:] == 7.0).all())
+    for _ in range(2):
+        assert torch.equal(ops.gemv_q4(x.cuda(), w4, sb, e, resid=res.cuda() if epi == "resid" else None), got)
+    y = x.double() @ wd.double().t()
+    if epi == "resid":
+        ref = (res.double() + y.to(BF16).double()).to(BF16)
+    elif epi == "silu":
+        gt, up = y[:, :N].to(BF16).double(), y[:, N:].to(BF16).double()
+        ref = ((gt * torch.sigmoid(gt)).to(BF16).double() * up).to(BF16)
+    else:
+        ref = y.to(BF16)
+    def near(a, b):
+        # SiLU * up: when the bf16 rounding of a gate or an up value falls on the other side of a tie in two correct computations the
+        # product moves by a whole ulp of one factor times the other factor: a handful of the 10^5 outputs may sit up to twice the
+        # bound away (the M = 1 kernel's test draws 8192 outputs and meets none)
+        if epi != "silu":
+            return close(a, b, rtol=2 ** -6, atol=3e-2)
+        a, b = a.float().cpu(), b.float().cpu()
+        err, tol = (a - b).abs(), 3e-2 + 2 ** -6 * b.abs()
+        assert (err <= 2 * tol).all() and (err > tol).float().mean().item() < 1e-4, (err / tol).max().item()
+    near(got, ref)
+    wb = ops.dequant_q4(w4, sb)                                          # the path it replaces: a bf16 scratch + the bf16 kernels
+    other = ops.gemm(x.cuda(), wb, e, resid=res.cuda() if epi == "resid" else None) if M > 8 else \
+        ops.gemv(x.cuda(), wb, e, resid=res.cuda() if epi == "resid" else None)
+    near(got, other)
+    with pytest.raises(RuntimeError):                              # (no fused RMSNorm at M > 1: the model normalises first)
+        ops.gemv_q4(x.cuda(), w4, sb, e, resid=res.cuda() if epi == "resid" else None, norm_w=torch.ones(K, dtype=BF16, device="cuda"), norm_eps=1e-5)
+
+
 # ----------------------------------------------------------------------------- W8A8 on the fp8 matrix cores (config 5 prefill)
 def _e4m3(x):
     return x.to(torch.float8_e4m3fn)
