@@ -15,15 +15,16 @@ rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 # decode section = from the first step's k_step_begin on (batches of 9+ rows run k_gemm_skinny inside the step: the prefill's GEMM
 # kernels are no marker for where it ends)
-first_step = min(i for i, r in enumerate(rows) if "k_step_begin" in r["Kernel_Name"])
+import re
+# the step's two ends: the launches p3v_step_begin / p3v_step_end, or -- round 6, B = 1 on bf16 weights -- the first / last projection
+# that carries them (k_gemv3_step<.., 1> / <.., 2>)
+def is_begin(n): return "k_step_begin" in n or re.search(r"k_gemv3_step<[^>]*, 1>", n) is not None
+def is_end(n): return "k_step_end" in n or "k_store_token" in n or re.search(r"k_gemv3_step<[^>]*, 2>", n) is not None
+first_step = min(i for i, r in enumerate(rows) if is_begin(r["Kernel_Name"]))
 dec = rows[first_step:]
 # drop the first step(s): eager warm-up + first replay
 names = [r["Kernel_Name"] for r in dec]
-per_step = None
-for i, n in enumerate(names):
-    if "k_step_end" in n or "k_store_token" in n:
-        idx = [j for j, m in enumerate(names) if "k_step_end" in m or "k_store_token" in m]
-        break
+idx = [j for j, m in enumerate(names) if is_end(m)]
 steps = [(idx[k] + 1, idx[k + 1] + 1) for k in range(len(idx) - 1)]
 steps = steps[4:]          # skip warm-up + early replays
 agg = collections.OrderedDict(); gaps = []
