@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define P3V_VERSION 500
+#define P3V_VERSION 600
 #define P3V_OK 0
 #define P3V_ERR_ARG (-22)         /* bad shape / null pointer / unsupported size */
 #define P3V_ERR_LAUNCH (-5)       /* hipGetLastError() != hipSuccess after launch */

@@ -24,7 +24,7 @@ def test_header_symbols_are_exported_and_bound():
     for s in syms:
         assert hasattr(lib, s), f"{s} declared in include/p3v.h but not exported by libp3v.so"
     assert sorted(_lib.SIGNATURES) == syms, set(_lib.SIGNATURES) ^ set(syms)
-    assert _lib.lib().p3v_version() == 500
+    assert _lib.lib().p3v_version() == 600
     assert _lib.lib().p3v_strerror(-22).decode().startswith("invalid argument")
 
 
