@@ -342,9 +342,11 @@ int p3v_topk(const uint16_t* x, int32_t* idx_out, int rows, int n, int k, int64_
  * W [N or 2N, K/8] u32 in the DEVICE nibble order (weights 8d..8d+7 at bits 0,16,4,20,8,24,12,28 of dword d;
  * weights.q4_repack converts MLX's sequential order), sb [N or 2N, K/64] u32 = scale bf16 | bias bf16 << 16.
  * p3v_gemv_q4: decode projection, K = 3072 or 8192.  M = 1: same norm / epilogue options as p3v_gemv.  2 <= M <= 16 (round 6: a
- *   decode batch, a constrained-decoding step; norm_w must be NULL, N % 16 == 0 (SiLU: % 8)): the packed weights are dequantised in
- *   registers (fp16 scale * q + bias, two weights per instruction) in front of the fp16 MFMA -- 0.5 byte per weight from HBM at every
- *   batch size, as the reference's QuantizedLinear (phi_3_vision_mlx.py:296).
+ *   decode batch, a constrained-decoding step; N % 16 == 0 (SiLU: % 8)): the packed weights are dequantised in registers (fp16
+ *   scale * q + bias, two weights per instruction) in front of the fp16 MFMA -- 0.5 byte per weight from HBM at every batch size, as
+ *   the reference's QuantizedLinear (phi_3_vision_mlx.py:296).  norm_w: up to 8 rows the input RMSNorm may ride along (the rows are
+ *   normalised to the bf16 values p3v_rmsnorm writes while the first weights are in flight); 9 .. 16 rows: must be NULL
+ *   (P3V_ERR_UNSUPPORTED otherwise -- the caller runs p3v_rmsnorm first).
  * p3v_dequant_q4: -> bf16 [rows, K] (prefill / batched decode run the bf16 kernels on a dequantised scratch). */
 typedef struct {
   const uint16_t* x; const uint32_t* W; const uint32_t* sb; void* out;

@@ -161,6 +161,6 @@ struct P3vTuning {
   int attn_no_dma, attn_old, attn_pp, attn_il, attn_il_waves, combine_g, kvq_old, q8_old;
   int attn_fo_map_q8;       // the same placement for the int8-KV twin (k_attn_decode128_q8<true>): 0 = off (measured slower there)
   int attn_fo_map;          // fused decode attention + o_proj: 2 / 1 = roles placed by virtual CU (fo_map, round 6), 0 = the (split, head) grid
-  int gemv_no_mfma, gemv_no_mfma8, gemv_wpc, gemv8_wgs, gemv_variant, gemv_rows, gemv8_min, gemv_mfma8, gemv_f8_wpc, gemv_q4_wpc, gemv_wpw;
+  int gemv_no_mfma, gemv_no_mfma8, gemv_wpc, gemv8_wgs, gemv_variant, gemv_rows, gemv8_min, gemv_mfma8, gemv_f8_wpc, gemv_q4_wpc, gemv_wpw, gemv_q4_rows_wgs, gemv_q4_rows8;
 };
 const P3vTuning& p3v_tuning();

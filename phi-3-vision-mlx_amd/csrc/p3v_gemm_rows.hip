@@ -82,11 +82,13 @@ __global__ void __launch_bounds__(NW * 64, 1) k_gemm_rows(RowsP p) {
   static_assert(NST <= 4, "unrolled for at most four stages");
 
   int par = 0;
-  for (;;) {
+  // two straight-line copies of the set body (as k_gemv_mfma8): with a further set to request, and the last one -- a branch around the
+  // refills makes the compiler's counted vmcnt ignore them, and the last stage of every set then waits for loads issued a moment before
+  auto do_set = [&](auto refillc) {
+    constexpr bool REFILL = decltype(refillc)::value;
     const int nset = set + (int)gridDim.x;
-    const bool has_next = nset < p.n_sets;                       // workgroup-uniform
     const bf16_t *w0n = nullptr, *w1n = nullptr;
-    if (has_next) row_ptrs(nset, w0n, w1n);
+    if constexpr (REFILL) row_ptrs(nset, w0n, w1n);
     f32x4_t acc[2][MT][2];
 #pragma unroll
     for (int s = 0; s < 2; ++s)
@@ -107,7 +109,7 @@ __global__ void __launch_bounds__(NW * 64, 1) k_gemm_rows(RowsP p) {
             }
           }
         }
-        if (has_next) issue(w0n, w1n, stc);
+        if constexpr (REFILL) { issue(w0n, w1n, stc); __builtin_amdgcn_sched_barrier(0); }   // (pinned behind this stage's MFMAs)
       }
     };
     step(RIC0{}); step(RIC1{}); step(RIC2{}); step(RIC3{});
@@ -153,8 +155,9 @@ __global__ void __launch_bounds__(NW * 64, 1) k_gemm_rows(RowsP p) {
     }
     set = nset;
     par ^= 1;
-    if (!has_next) break;
-  }
+  };
+  while (set + (int)gridDim.x < p.n_sets) do_set(std::true_type{});
+  do_set(std::false_type{});
 }
 
 // ---- shapes: K slices S and the (waves, stages) of a workgroup's slice.  0 = not this kernel's.

@@ -433,12 +433,23 @@ __global__ void __launch_bounds__(NW * 64) k_gemv_mfma8(GemvP p, int n_sets) {
   const bool odd = lane & 1;
   int par = 0;
   // one row set out of register slot `slot`; its registers are refilled stage by stage with the set one stride ahead
-  auto do_set = [&](auto slotc) {
+  // Two straight-line copies of the set body: REFILL (a further set follows: its stages are requested as this one's are consumed) and the
+  // last set (nothing requested).  One body with `if (has_next) issue(..)` makes the compiler count vmcnt as if the refills did not
+  // exist: the last stage of every set then waited for the refills issued a moment before (vmcnt(0)), one memory round trip per set.
+  // Same reason for fetching the epilogue's residual element at the top, ahead of the refills, instead of in the epilogue (where it
+  // would be the youngest load in flight).
+  auto do_set = [&](auto slotc, auto refillc) {
     constexpr int slot = decltype(slotc)::value;
+    constexpr bool REFILL = decltype(refillc)::value;
     const int nset = set + (int)gridDim.x;
-    const bool has_next = nset < n_sets;                                         // workgroup-uniform
     const bf16_t *w0n = nullptr, *w1n = nullptr;
-    if (has_next) row_ptrs(nset, w0n, w1n);
+    if constexpr (REFILL) row_ptrs(nset, w0n, w1n);
+    const int e_R = tid & 7, e_m = (tid >> 3) & 7, e_sub = tid >> 6;
+    const int e_n = set * ROWS + e_sub * 8 + e_R;
+    const bool e_live = tid < (SILU ? 64 : 128) && e_m < p.M && e_n < p.N;
+    const size_t e_o = (size_t)e_m * p.N + e_n;
+    const bool e_has = !SILU && p.epi == P3V_EPI_RESID_BF16;
+    uint32_t e_res = (e_has ? p.resid : p.x)[e_has && e_live ? e_o : 0];
     f32x4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
     auto step = [&](auto stc) {
       constexpr int st = decltype(stc)::value;
@@ -449,7 +460,7 @@ __global__ void __launch_bounds__(NW * 64) k_gemv_mfma8(GemvP p, int n_sets) {
           acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wa[slot][st][2 * q]), xb, acc0, 0, 0, 0);
           acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wa[slot][st][2 * q + 1]), xb, acc1, 0, 0, 0);
         }
-        if (has_next) issue(w0n, w1n, stc, slotc);
+        if constexpr (REFILL) { issue(w0n, w1n, stc, slotc); __builtin_amdgcn_sched_barrier(0); }   // (pinned behind this stage's MFMAs)
       }
     };
     step(IC0{}); step(IC1{}); step(IC2{}); step(IC3{});
@@ -473,10 +484,9 @@ __global__ void __launch_bounds__(NW * 64) k_gemv_mfma8(GemvP p, int n_sets) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                                                // (the weight loads of the sets ahead stay in flight across it)
     GMARK(6);
-    if (tid < (SILU ? 64 : 128)) {
-      const int R = tid & 7, m = (tid >> 3) & 7, sub = tid >> 6;
-      const int n = set * ROWS + sub * 8 + R;
-      if (m < p.M && n < p.N) {
+    if (e_live) {
+      const int R = e_R, m = e_m, sub = e_sub;
+      {
         float v0 = 0.f, v1 = 0.f, t = 0.f;
 #pragma unroll
         for (int w = 0; w < NW; ++w) {
@@ -489,14 +499,15 @@ __global__ void __launch_bounds__(NW * 64) k_gemv_mfma8(GemvP p, int n_sets) {
           v0 *= r;
           v1 *= r;
         }
-        const size_t o = (size_t)m * p.N + n;
+        const size_t o = e_o;
         if (SILU) {
           const float gt = bf16_round(v0), up = bf16_round(v1);
           ((bf16_t*)p.out)[o] = f32_to_bf16(bf16_round(gt * bf16_round(1.f / (1.f + __expf(-gt)))) * up);
         } else if (p.epi == P3V_EPI_F32) {
           ((float*)p.out)[o] = v0;
         } else if (p.epi == P3V_EPI_RESID_BF16) {
-          ((bf16_t*)p.out)[o] = f32_to_bf16(bf16_to_f32(p.resid[o]) + bf16_round(v0));
+          asm volatile("" : "+v"(e_res));                                        // (first looked at here: no wait for it above)
+          ((bf16_t*)p.out)[o] = f32_to_bf16(bf16_to_f32((bf16_t)e_res) + bf16_round(v0));
         } else {
           ((bf16_t*)p.out)[o] = f32_to_bf16(v0);
         }
@@ -504,11 +515,9 @@ __global__ void __launch_bounds__(NW * 64) k_gemv_mfma8(GemvP p, int n_sets) {
     }
     set += (int)gridDim.x;
     par ^= 1;
-    return set < n_sets;
   };
-  for (;;) {
-    if (!do_set(IC0{})) break;
-  }
+  while (set + (int)gridDim.x < n_sets) do_set(IC0{}, std::true_type{});
+  do_set(IC0{}, std::false_type{});
 }
 
 template <bool SILU, int NW, int NST>

@@ -258,10 +258,8 @@ __global__ void __launch_bounds__(NW * 64) k_gemm_rows_q4(RowsQ4P p) {
     s0 = p.sb + (size_t)row0 * kg + k_lo / 64 + g;
     s1 = p.sb + (size_t)row1 * kg + k_lo / 64 + g;
   };
-  // Register ring of D sets: set i lives in slot i % D and the stage just consumed is refilled with the same stage of set i + D.  D = 1
-  // is what ships: a set's K quarter is only NST x 2 KB here, but D = 3 (9 KB per wave on the wire, 295 registers) measured SLOWER --
-  // qkv / o_proj 8.6 -> 10.6 us, gate_up 12.6 -> 14.4 at 8 rows: the launch is not bandwidth- or latency-bound but made of fixed costs
-  // (the x fragments of every workgroup, a barrier + epilogue per set).
+  // One set of weight registers, each stage refilled with the same stage of the NEXT set as it is consumed.  (A ring of 2 - 3 sets was
+  // built and measured slower; the register budget is x's: 96 VGPRs of fragments in both k-orders.)
   constexpr int D = 1;
   const int stride = (int)gridDim.x;
   int set = blockIdx.x;
@@ -270,7 +268,7 @@ __global__ void __launch_bounds__(NW * 64) k_gemm_rows_q4(RowsQ4P p) {
   auto issue = [&](int which, auto slotc, auto stc) {
     constexpr int slot = decltype(slotc)::value, st = decltype(stc)::value;
     const uint32_t *a0, *a1, *b0, *b1;
-    row_ptrs(min(which, p.n_sets - 1), a0, a1, b0, b1);
+    row_ptrs(which, a0, a1, b0, b1);
     wa[slot][st][0] = __builtin_nontemporal_load((const u32x4_t*)(a0 + st * 32));
     wa[slot][st][1] = __builtin_nontemporal_load((const u32x4_t*)(a1 + st * 32));
     sv[slot][st][0] = b0[st * 4];
@@ -284,8 +282,6 @@ __global__ void __launch_bounds__(NW * 64) k_gemm_rows_q4(RowsQ4P p) {
   };
   static_assert(NST <= 4, "unrolled for at most four blocks");
   issue_set(set, QC0{});
-  if constexpr (D > 1) issue_set(set + stride, QC1{});
-  if constexpr (D > 2) issue_set(set + 2 * stride, QC2{});
 
   // (The input RMSNorm is NOT fused here: built and measured -- every one of the 192-256 workgroups normalising its own copy of the 2 .. 16
   //  rows costs more than the one p3v_rmsnorm launch it saves: B = 8 at 512 keys 2.39 ms per step fused against 2.13 with the launch.)
@@ -307,10 +303,20 @@ __global__ void __launch_bounds__(NW * 64) k_gemm_rows_q4(RowsQ4P p) {
   }
 
   int par = 0;
-  auto do_set = [&](auto slotc) {
-    constexpr int slot = decltype(slotc)::value;
-    const int refill = set + D * stride;
-    const bool has_refill = refill < p.n_sets;                   // workgroup-uniform
+  // (two straight-line copies: with a further set to request, and the last one -- see k_gemv_mfma8, p3v_gemv.hip)
+  auto do_set = [&](auto refillc) {
+    constexpr int slot = 0;
+    constexpr bool REFILL = decltype(refillc)::value;
+    const auto slotc = QC0{};
+    const int refill = set + stride;
+    constexpr int ITEMS = (SILU ? 8 : 16) * 16;                  // (output column, x row) pairs of a set: at most one per thread
+    static_assert(ITEMS <= NW * 64, "one epilogue item per thread");
+    const int e_R = tid & 7, e_sub = SILU ? 0 : (tid >> 3) & 1, e_m = SILU ? tid >> 3 : tid >> 4;
+    const int e_n = set * (SILU ? 8 : 16) + e_sub * 8 + e_R;
+    const bool e_live = tid < ITEMS && e_m < p.M && e_n < p.N;
+    const size_t e_o = (size_t)e_m * p.N + e_n;
+    const bool e_has = !SILU && p.epi == P3V_EPI_RESID_BF16;      // the residual element goes out ahead of the refills (see k_gemv8_q4)
+    uint32_t e_res = (e_has ? p.resid : p.x)[e_has && e_live ? e_o : 0];
     f32x4_t acc[2][2];
 #pragma unroll
     for (int s_ = 0; s_ < 2; ++s_) acc[s_][0] = acc[s_][1] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
@@ -328,7 +334,7 @@ __global__ void __launch_bounds__(NW * 64) k_gemm_rows_q4(RowsQ4P p) {
             acc[s_][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, xf[st][j][1], acc[s_][1], 0, 0, 0);
           }
         }
-        if (has_refill) issue(refill, slotc, stc);
+        if constexpr (REFILL) { issue(refill, slotc, stc); __builtin_amdgcn_sched_barrier(0); }   // (pinned: the scheduler otherwise sinks the refills to the end of the set)
       }
     };
     step(QC0{}); step(QC1{}); step(QC2{}); step(QC3{});
@@ -340,45 +346,242 @@ __global__ void __launch_bounds__(NW * 64) k_gemm_rows_q4(RowsQ4P p) {
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    constexpr int ITEMS = (SILU ? 8 : 16) * 16;
-#pragma unroll 1
-    for (int idx = tid; idx < ITEMS; idx += NW * 64) {
-      const int R = idx & 7, sub = SILU ? 0 : (idx >> 3) & 1, m = SILU ? idx >> 3 : idx >> 4;
-      const int n = set * (SILU ? 8 : 16) + sub * 8 + R;
-      if (m < p.M && n < p.N) {
-        float v0 = 0.f, v1 = 0.f;
+    if (e_live) {
+      const int R = e_R, sub = e_sub, m = e_m;
+      float v0 = 0.f, v1 = 0.f;
 #pragma unroll
-        for (int w = 0; w < NW; ++w) {
-          v0 += cp[((w * 2 + sub) * 8 + R) * 16 + m];
-          if (SILU) v1 += cp[((w * 2 + 1) * 8 + R) * 16 + m];
-        }
-        const size_t o = (size_t)m * p.N + n;
-        if (SILU) {
-          const float gt = bf16_round(v0), up = bf16_round(v1);
-          ((bf16_t*)p.out)[o] = f32_to_bf16(bf16_round(gt * bf16_round(1.f / (1.f + __expf(-gt)))) * up);
-        } else if (p.epi == P3V_EPI_F32) {
-          ((float*)p.out)[o] = v0;
-        } else if (p.epi == P3V_EPI_RESID_BF16) {
-          ((bf16_t*)p.out)[o] = f32_to_bf16(bf16_to_f32(p.resid[o]) + bf16_round(v0));
-        } else {
-          ((bf16_t*)p.out)[o] = f32_to_bf16(v0);
-        }
+      for (int w = 0; w < NW; ++w) {
+        v0 += cp[((w * 2 + sub) * 8 + R) * 16 + m];
+        if (SILU) v1 += cp[((w * 2 + 1) * 8 + R) * 16 + m];
+      }
+      const size_t o = e_o;
+      if (SILU) {
+        const float gt = bf16_round(v0), up = bf16_round(v1);
+        ((bf16_t*)p.out)[o] = f32_to_bf16(bf16_round(gt * bf16_round(1.f / (1.f + __expf(-gt)))) * up);
+      } else if (p.epi == P3V_EPI_F32) {
+        ((float*)p.out)[o] = v0;
+      } else if (p.epi == P3V_EPI_RESID_BF16) {
+        asm volatile("" : "+v"(e_res));
+        ((bf16_t*)p.out)[o] = f32_to_bf16(bf16_to_f32((bf16_t)e_res) + bf16_round(v0));
+      } else {
+        ((bf16_t*)p.out)[o] = f32_to_bf16(v0);
       }
     }
     set += stride;
     par ^= 1;
-    return set < p.n_sets;
   };
-  for (;;) {
-    if (!do_set(QC0{})) break;
-    if constexpr (D > 1) { if (!do_set(QC1{})) break; }
-    if constexpr (D > 2) { if (!do_set(QC2{})) break; }
+  while (set + stride < p.n_sets) do_set(std::true_type{});
+  do_set(std::false_type{});
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// 2 .. 8 rows of x on the 4-bit weights: k_gemv_mfma8 (p3v_gemv.hip) with the packed weights dequantised in front of the fp16 MFMA.
+// What k_gemm_rows_q4 above pays per workgroup -- every lane fetching its own 16-byte pieces of 16 x rows (64 scattered requests per
+// load instruction, ~2.5 us of L1 request time per workgroup) and both k-orders of x in registers (96 VGPRs: no room for a deeper weight
+// ring) -- this one does not: the wave's K quarter of x is read in whole 1 KB runs, normalised (the input RMSNorm rides along: sums of
+// squares per wave -> LDS -> one barrier -> bf16(bf16(x r) g), the value p3v_rmsnorm writes, exact in fp16), parked in LDS as fp16 in
+// fragment order, and each MFMA reads its B operand from there with one ds_read_b128; with at most 8 rows the 16 MFMA columns are
+// (x row m, k-half h') pairs, so ONE product per weight fragment carries both k-orders (column 2 m + h', as k_gemv_mfma8).
+template <bool SILU, int NW, int NST>
+__global__ void __launch_bounds__(NW * 64) k_gemv8_q4(RowsQ4P p, const bf16_t* norm_w, float eps) {
+  constexpr int KQ = NST * 256, K = KQ * NW, XS = K * 2 + 32, NCH = KQ / 8;     // wave's K quarter, LDS row stride (bytes: 2 x 16 B mod 256), its 8-element chunks
+  constexpr int ROWS = SILU ? 8 : 16;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ float red[NW][8];
+  __shared__ float cpart[2][NW * 2 * 8 * 8];                     // [parity][wave][row set][weight row][x row]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4;
+  const int r8 = (lane & 15) >> 1, hbit = lane & 1;
+  const int k_lo = wave * KQ;
+  const int kd = K / 8, kg = K / 64;
+  auto row_ptrs = [&](int set, const uint32_t*& w0, const uint32_t*& w1, const uint32_t*& s0, const uint32_t*& s1) {
+    const int n_base = set * ROWS;
+    const int row0 = min(n_base + r8, p.N - 1);
+    const int row1 = SILU ? p.N + row0 : min(n_base + 8 + r8, p.N - 1);
+    w0 = p.W + (size_t)row0 * kd + k_lo / 8 + 4 * (2 * g + hbit);
+    w1 = p.W + (size_t)row1 * kd + k_lo / 8 + 4 * (2 * g + hbit);
+    s0 = p.sb + (size_t)row0 * kg + k_lo / 64 + g;
+    s1 = p.sb + (size_t)row1 * kg + k_lo / 64 + g;
+  };
+  const int stride = (int)gridDim.x;
+  int set = blockIdx.x;
+  constexpr int D = 1;                                           // (rings of 2 .. 4 sets were built and measured: no faster)
+  u32x4_t wa[D][NST][2];
+  uint32_t sv[D][NST][2];
+  auto issue = [&](int which, auto slotc, auto stc) {
+    constexpr int slot = decltype(slotc)::value, st = decltype(stc)::value;
+    const uint32_t *a0, *a1, *b0, *b1;
+    row_ptrs(which, a0, a1, b0, b1);
+    wa[slot][st][0] = __builtin_nontemporal_load((const u32x4_t*)(a0 + st * 32));
+    wa[slot][st][1] = __builtin_nontemporal_load((const u32x4_t*)(a1 + st * 32));
+    sv[slot][st][0] = b0[st * 4];
+    sv[slot][st][1] = b1[st * 4];
+  };
+  auto issue_set = [&](int which, auto slotc) {
+    issue(which, slotc, QC0{});
+    if constexpr (NST > 1) issue(which, slotc, QC1{});
+    if constexpr (NST > 2) issue(which, slotc, QC2{});
+    if constexpr (NST > 3) issue(which, slotc, QC3{});
+  };
+  static_assert(NST <= 4, "unrolled for at most four blocks");
+
+  // ---- x quarter (8 rows x NCH chunks, lanes over chunks: 1 KB runs), then the ring's weights
+  unsigned char* xslice = smem + k_lo * 2;
+  {
+    u32x4_t xv[8][2], gv[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int c = min(lane + 64 * k, NCH - 1);
+#pragma unroll
+      for (int m = 0; m < 8; ++m) xv[m][k] = *(const u32x4_t*)(p.x + (size_t)min(m, p.M - 1) * K + k_lo + 8 * c);
+      gv[k] = norm_w ? *(const u32x4_t*)(norm_w + k_lo + 8 * c) : (u32x4_t){0, 0, 0, 0};
+    }
+    issue_set(set, QC0{});
+    float r[8];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) r[m] = 1.f;
+    if (norm_w) {                                                // workgroup-uniform
+#pragma unroll
+      for (int m = 0; m < 8; ++m) {
+        float ss = 0.f;
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+          if (lane + 64 * k < NCH) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const float a = bf16lo(xv[m][k][j]), b = bf16hi(xv[m][k][j]); ss += a * a + b * b; }
+          }
+        ss = wave_sum(ss);
+        if (lane == 0) red[wave][m] = ss;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+#pragma unroll
+      for (int m = 0; m < 8; ++m) {
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) t += red[w][m];
+        r[m] = rsqrtf(t / (float)K + eps);
+      }
+    }
+    // fragment order inside a 256-element block: the 16-byte piece of elements 64 g + 32 h + 8 j ..+7 sits at slot 8 j + 2 g + h, so
+    // that the 16 lanes of an MFMA row group (x row r8 = 0..7, h) read 16 different 16-byte slots (row stride = 2 slots mod 16)
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int c = lane + 64 * k;
+      if (c < NCH) {
+        const int blk = c >> 5, w = c & 31, slot = 8 * (w & 3) + 2 * (w >> 3) + ((w >> 2) & 1);
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+          u32x4_t o;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const uint32_t hw = norm_w ? rms_pair(xv[m][k][j], r[m], gv[k][j]) : xv[m][k][j];
+            const q4h2_t f = {(_Float16)bf16lo(hw), (_Float16)bf16hi(hw)};
+            o[j] = m < p.M ? __builtin_bit_cast(uint32_t, f) : 0u;
+          }
+          *(u32x4_t*)(xslice + m * XS + blk * 512 + slot * 16) = o;
+        }
+      }
+    }
   }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             // the slice is wave-private: no barrier
+
+  const unsigned char* xrow = xslice + r8 * XS + (2 * g + hbit) * 16;
+  const bool odd = lane & 1;
+  int par = 0;
+  // Two straight-line copies of the set body (as k_gemv_mfma8, p3v_gemv.hip): with a further set to request stage by stage, and the
+  // last one.  A branch around the refills makes the compiler's counted vmcnt ignore them -- every stage then waits for loads issued a
+  // moment ago (measured: 2 us per set instead of 1.5).
+  auto do_set = [&](auto refillc) {
+    constexpr int slot = 0;
+    constexpr bool REFILL = decltype(refillc)::value;
+    const auto slotc = QC0{};
+    const int refill = set + stride;
+    // the residual element of this thread's output goes out BEFORE this set's refills: read in the epilogue it would be the youngest
+    // load in flight and its wait (vmcnt(0)) would drain the whole ring at every set
+    const int e_R = tid & 7, e_m = (tid >> 3) & 7, e_sub = tid >> 6;
+    const int e_n = set * ROWS + e_sub * 8 + e_R;
+    const bool e_live = tid < (SILU ? 64 : 128) && e_m < p.M && e_n < p.N;
+    const size_t e_o = (size_t)e_m * p.N + e_n;
+    const bool e_has = !SILU && p.epi == P3V_EPI_RESID_BF16;    // (an unconditional load: element 0 of x where there is no residual)
+    uint32_t e_res = (e_has ? p.resid : p.x)[e_has && e_live ? e_o : 0];
+    f32x4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    auto step = [&](auto stc) {
+      constexpr int st = decltype(stc)::value;
+      if constexpr (st < NST) {
+        const _Float16 sc0 = (_Float16)bf16lo(sv[slot][st][0]), bi0 = (_Float16)bf16hi(sv[slot][st][0]);
+        const _Float16 sc1 = (_Float16)bf16lo(sv[slot][st][1]), bi1 = (_Float16)bf16hi(sv[slot][st][1]);
+        const q4h2_t s20 = {sc0, sc0}, b20 = {bi0, bi0}, s21 = {sc1, sc1}, b21 = {bi1, bi1};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const q4h8_t xb = *(const q4h8_t*)(xrow + st * 512 + j * 128);
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(q4_dequant8(wa[slot][st][0][j], s20, b20), xb, acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(q4_dequant8(wa[slot][st][1][j], s21, b21), xb, acc1, 0, 0, 0);
+        }
+        if constexpr (REFILL) { issue(refill, slotc, stc); __builtin_amdgcn_sched_barrier(0); }   // (pinned: the scheduler otherwise sinks the refills to the end of the set)
+      }
+    };
+    step(QC0{}); step(QC1{}); step(QC2{}); step(QC3{});
+    // C[4 (lane >> 4) + e][column 2 m + h']: e = h' and h' + 2 are weight rows 2 (lane >> 4), + 1 over k-half h'; the halves meet by DPP
+    float e[2][2] = {{odd ? acc0[1] : acc0[0], odd ? acc0[3] : acc0[2]}, {odd ? acc1[1] : acc1[0], odd ? acc1[3] : acc1[2]}};
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) e[t][u] += P3V_DPP_F32(e[t][u], 0xB1);        // quad_perm [1,0,3,2]
+    float* cp = cpart[par];
+    if (!odd) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) cp[((wave * 2 + t) * 8 + 2 * g + u) * 8 + r8] = e[t][u];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                                // (the weight loads of the sets ahead stay in flight across it)
+    if (e_live) {
+      const int R = e_R, m = e_m, sub = e_sub;
+      float v0 = 0.f, v1 = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) {
+        v0 += cp[((w * 2 + sub) * 8 + R) * 8 + m];
+        if (SILU) v1 += cp[((w * 2 + 1) * 8 + R) * 8 + m];
+      }
+      const size_t o = e_o;
+      if (SILU) {
+        const float gt = bf16_round(v0), up = bf16_round(v1);
+        ((bf16_t*)p.out)[o] = f32_to_bf16(bf16_round(gt * bf16_round(1.f / (1.f + __expf(-gt)))) * up);
+      } else if (p.epi == P3V_EPI_F32) {
+        ((float*)p.out)[o] = v0;
+      } else if (p.epi == P3V_EPI_RESID_BF16) {
+        asm volatile("" : "+v"(e_res));                          // (the value is first looked at HERE: no wait for it at the top of the set)
+        ((bf16_t*)p.out)[o] = f32_to_bf16(bf16_to_f32((bf16_t)e_res) + bf16_round(v0));
+      } else {
+        ((bf16_t*)p.out)[o] = f32_to_bf16(v0);
+      }
+    }
+    set += stride;
+    par ^= 1;
+  };
+  while (set + stride < p.n_sets) do_set(std::true_type{});
+  do_set(std::false_type{});
+}
+
+template <bool SILU, int NW, int NST>
+static int launch_gemv8_q4(const RowsQ4P& p, const bf16_t* norm_w, float eps, hipStream_t s) {
+  const size_t lds = (size_t)8 * (p.K * 2 + 32);
+  static bool attr_set = false;
+  if (!attr_set && lds > 40 * 1024) {
+    if (hipFuncSetAttribute((const void*)k_gemv8_q4<SILU, NW, NST>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 8704) != hipSuccess)
+      return P3V_ERR_HIP;
+    attr_set = true;
+  }
+  const int per = p3v_cdiv(p.n_sets, p3v_tuning().gemv_q4_rows_wgs), gx = p3v_cdiv(p.n_sets, per);
+  hipLaunchKernelGGL((k_gemv8_q4<SILU, NW, NST>), dim3(gx), dim3(NW * 64), lds, s, p, norm_w, eps);
+  P3V_CHECK_LAUNCH();
+  return P3V_OK;
 }
 
 template <bool SILU, int NW, int NST>
 static int launch_rows_q4(const RowsQ4P& p, hipStream_t s) {
-  const int per = p3v_cdiv(p.n_sets, 256), gx = p3v_cdiv(p.n_sets, per);
+  const int per = p3v_cdiv(p.n_sets, p3v_tuning().gemv_q4_rows_wgs), gx = p3v_cdiv(p.n_sets, per);
   hipLaunchKernelGGL((k_gemm_rows_q4<SILU, NW, NST>), dim3(gx), dim3(NW * 64), 0, s, p);
   P3V_CHECK_LAUNCH();
   return P3V_OK;
@@ -386,7 +589,8 @@ static int launch_rows_q4(const RowsQ4P& p, hipStream_t s) {
 
 extern "C" int p3v_gemv_q4(const p3v_gemv_q4_args_t* a, void* stream) {
   if (!a || !a->x || !a->W || !a->sb || !a->out) return P3V_ERR_ARG;
-  if (a->M >= 2 && a->M <= 16 && (a->K == 3072 || a->K == 8192) && !a->norm_w && a->N > 0) {      // 2 .. 16 rows: k_gemm_rows_q4
+  if (a->M >= 2 && a->M <= 16 && (a->K == 3072 || a->K == 8192) && (!a->norm_w || a->M <= 8) && a->N > 0) {
+    // 2 .. 8 rows: k_gemv8_q4 (input RMSNorm optional); 9 .. 16: k_gemm_rows_q4 (the caller normalises)
     const bool silu = a->epilogue == P3V_EPI_SILU_MUL;
     if (a->N % (silu ? 8 : 16)) return P3V_ERR_UNSUPPORTED;
     if (a->epilogue != P3V_EPI_NONE && a->epilogue != P3V_EPI_RESID_BF16 && !silu && a->epilogue != P3V_EPI_F32) return P3V_ERR_UNSUPPORTED;
@@ -394,6 +598,12 @@ extern "C" int p3v_gemv_q4(const p3v_gemv_q4_args_t* a, void* stream) {
     if (((uintptr_t)a->x | (uintptr_t)a->W) & 15) return P3V_ERR_ARG;
     const RowsQ4P q = {a->x, a->W, a->sb, a->out, a->resid, a->M, a->N, a->K, a->epilogue, a->N / (silu ? 8 : 16)};
     hipStream_t s = (hipStream_t)stream;
+    if (a->M <= 8 && p3v_tuning().gemv_q4_rows8) {
+      if (a->norm_w && ((uintptr_t)a->norm_w & 15)) return P3V_ERR_ARG;
+if (a->K == 3072) return silu ? launch_gemv8_q4<true, 4, 3>(q, a->norm_w, a->norm_eps, s) : launch_gemv8_q4<false, 4, 3>(q, a->norm_w, a->norm_eps, s);
+      return silu ? launch_gemv8_q4<true, 8, 4>(q, a->norm_w, a->norm_eps, s) : launch_gemv8_q4<false, 8, 4>(q, a->norm_w, a->norm_eps, s);
+    }
+    if (a->norm_w) return P3V_ERR_UNSUPPORTED;
     if (a->K == 3072) return silu ? launch_rows_q4<true, 4, 3>(q, s) : launch_rows_q4<false, 4, 3>(q, s);
     return silu ? launch_rows_q4<true, 8, 4>(q, s) : launch_rows_q4<false, 8, 4>(q, s);
   }

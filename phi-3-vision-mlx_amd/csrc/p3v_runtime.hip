@@ -41,7 +41,8 @@ const Knob kKnobs[] = {
     {"gemv_variant", &P3vTuning::gemv_variant, 3},          {"gemv_rows", &P3vTuning::gemv_rows, 1},
     {"gemv8_min", &P3vTuning::gemv8_min, 2},                {"gemv_mfma8", &P3vTuning::gemv_mfma8, 1},
     {"gemv_f8_wpc", &P3vTuning::gemv_f8_wpc, 16},           {"gemv_q4_wpc", &P3vTuning::gemv_q4_wpc, 8},
-    {"gemv_wpw", &P3vTuning::gemv_wpw, 0},
+    {"gemv_wpw", &P3vTuning::gemv_wpw, 0},                  {"gemv_q4_rows_wgs", &P3vTuning::gemv_q4_rows_wgs, 256},
+    {"gemv_q4_rows8", &P3vTuning::gemv_q4_rows8, 1},
     {"gemm_no_skinny", &P3vTuning::gemm_no_skinny, 0},      {"gemm_skinny_max_m", &P3vTuning::gemm_skinny_max_m, 256},
     {"gemm_skinny_s", &P3vTuning::gemm_skinny_s, 0},            {"gemm_skinny_tm128", &P3vTuning::gemm_skinny_tm128, 0},
     {"gemm_rows", &P3vTuning::gemm_rows, 1},

@@ -262,11 +262,11 @@ class Phi3VModel:
             return ops.gemv_q4(x, q4[0], q4[1], epilogue, resid=resid, norm_w=norm_w, norm_eps=eps, out=out)
         if (q4 is not None and 2 <= M <= 16 and K in (3072, 8192) and os.environ.get("P3V_Q4_ROWS", "1") != "0"
                 and (q4[0].shape[0] // (2 if epilogue == EPI_SILU_MUL else 1)) % 16 == 0):
-            # 2 .. 16 rows straight on the 4-bit weights (round 6: k_gemm_rows_q4; the reference runs QuantizedLinear at every batch
-            # size, phi_3_vision_mlx.py:296) instead of dequantising the whole matrix into the bf16 scratch per call
-            if norm_w is not None:                              # (one p3v_rmsnorm launch: fusing it into every workgroup's x load measured slower)
-                x = ops.rmsnorm(x, norm_w, eps, out=h)
-            return ops.gemv_q4(x, q4[0], q4[1], epilogue, resid=resid, out=out)
+            # 2 .. 16 rows straight on the 4-bit weights (round 6: k_gemv8_q4 / k_gemm_rows_q4; the reference runs QuantizedLinear at
+            # every batch size, phi_3_vision_mlx.py:296) instead of dequantising the whole matrix into the bf16 scratch per call
+            if norm_w is not None and (M > 8 or os.environ.get("P3V_Q4_ROWS8_NORM", "1") == "0"):
+                x, norm_w = ops.rmsnorm(x, norm_w, eps, out=h), None       # 9 .. 16 rows: one p3v_rmsnorm launch in front
+            return ops.gemv_q4(x, q4[0], q4[1], epilogue, resid=resid, norm_w=norm_w, norm_eps=eps, out=out)
         if q is not None and skinny and K in (3072, 8192):
             return ops.gemv_fp8(x, q[0], q[1], epilogue, resid=resid, norm_w=norm_w, norm_eps=eps, out=out)
         if q is not None and not skinny and self.fp8_act and ops.gemm_fp8_ok(M, q[0].shape[0], K, epilogue):

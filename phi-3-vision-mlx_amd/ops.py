@@ -219,7 +219,8 @@ def lora_up(y, t, lora_b, scale, epilogue=EPI_NONE, resid=None, out=None):
 
 def gemv_q4(x, w4, sb, epilogue=EPI_NONE, resid=None, norm_w=None, norm_eps=0.0, out=None):
     """`gemv` on 4-bit group-64 weights (device layout of weights.q4_repack): x [M,K] bf16, w4 [N,K/8] i32, sb [N,K/64] i32.
-    M = 1: the streaming GEMV (fused RMSNorm allowed); 2 <= M <= 16: the register-streaming MFMA kernel (no fused norm)."""
+    M = 1: the streaming GEMV (fused RMSNorm allowed); 2 <= M <= 8: k_gemv8_q4 (fused RMSNorm allowed); 9 <= M <= 16: k_gemm_rows_q4
+    (no fused norm)."""
     _chk(x, BF16, "x"), _chk(w4, I32, "w4"), _chk(sb, I32, "sb")
     M, K = x.shape
     N = w4.shape[0] // 2 if epilogue == EPI_SILU_MUL else w4.shape[0]

@@ -1370,8 +1370,24 @@ def test_gemv_q4_rows_2_to_16(ops, N, K, epi, M):
     other = ops.gemm(x.cuda(), wb, e, resid=res.cuda() if epi == "resid" else None) if M > 8 else \
         ops.gemv(x.cuda(), wb, e, resid=res.cuda() if epi == "resid" else None)
     near(got, other)
-    with pytest.raises(RuntimeError):                              # (no fused RMSNorm at M > 1: the model normalises first)
-        ops.gemv_q4(x.cuda(), w4, sb, e, resid=res.cuda() if epi == "resid" else None, norm_w=torch.ones(K, dtype=BF16, device="cuda"), norm_eps=1e-5)
+    nw = (1 + 0.1 * g((K,), 415)).cuda()
+    if M > 8:                                                      # (no fused RMSNorm at 9 .. 16 rows: the model normalises first)
+        with pytest.raises(RuntimeError):
+            ops.gemv_q4(x.cuda(), w4, sb, e, resid=res.cuda() if epi == "resid" else None, norm_w=nw, norm_eps=1e-5)
+        return
+    # 2 .. 8 rows (k_gemv8_q4): the input RMSNorm rides along -- the value p3v_rmsnorm writes (bf16, exact in fp16), so the fused call
+    # equals the two calls up to the summation order of the squares (a last-bit difference of r on a handful of elements)
+    ops.set_tuning("gemv_q4_rows8", 0)                             # k_gemm_rows_q4 (also what 9 .. 16 rows run): same product, other order
+    try:
+        near(ops.gemv_q4(x.cuda(), w4, sb, e, resid=res.cuda() if epi == "resid" else None), ref)
+    finally:
+        ops.set_tuning("gemv_q4_rows8", 1)
+    xs = (x * 3.0).to(BF16)
+    h = ops.rmsnorm(xs.cuda(), nw, 1e-5)
+    two = ops.gemv_q4(h, w4, sb, e, resid=res.cuda() if epi == "resid" else None)
+    one = ops.gemv_q4(xs.cuda(), w4, sb, e, resid=res.cuda() if epi == "resid" else None, norm_w=nw, norm_eps=1e-5)
+    near(one, two)
+    assert (one.float() != two.float()).float().mean().item() < 0.02
 
 
 # ----------------------------------------------------------------------------- W8A8 on the fp8 matrix cores (config 5 prefill)
