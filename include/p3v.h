@@ -419,6 +419,8 @@ typedef struct {
   int32_t* d_past;            /* begin: read (position of the rows to stage); end: incremented */
 } p3v_gemv_step_t;
 int p3v_gemv_step(const p3v_gemv_args_t* args /* host */, const p3v_gemv_step_t* step /* host */, void* stream);
+/* the same on e4m3 weights (config 5: `args` as for p3v_gemv_fp8, one row, no epilogue) */
+int p3v_gemv_fp8_step(const p3v_gemv_fp8_args_t* args /* host */, const p3v_gemv_step_t* step /* host */, void* stream);
 
 /* ---- hipGraph helpers: capture a sequence of the launches above and replay it */
 int p3v_graph_begin(void* stream);

@@ -104,6 +104,7 @@ SIGNATURES = {
     "p3v_gemm_rows_slices": (i32, [i32, i32, i32, i32]),
     "p3v_gemv": (i32, [C.POINTER(GemvArgs), vp]),
     "p3v_gemv_step": (i32, [C.POINTER(GemvArgs), C.POINTER(GemvStep), vp]),
+    "p3v_gemv_fp8_step": (i32, [C.POINTER(GemvF8Args), C.POINTER(GemvStep), vp]),
     "p3v_gemv_fp8": (i32, [C.POINTER(GemvF8Args), vp]),
     "p3v_dequant_fp8": (i32, [vp, vp, vp, i32, i32, vp]),
     "p3v_gemm_fp8": (i32, [C.POINTER(GemmF8Args), vp]),

@@ -51,6 +51,91 @@ __device__ __forceinline__ void amax_take(ArgMaxVI& m, float v, int i) {
   if (v > m.v || (v == m.v && i < m.i) || m.i == 0x7fffffff) { m.v = v; m.i = i; }
 }
 
+// ---- the two ends of a replayed greedy step, carried by its first / last projection (p3v_gemv_step, p3v_gemv_fp8_step):
+// 5a. (workgroup 0 of the first qkv launch) the gathered embedding rows become the residual stream the later launches update in place
+// (re-read from the table: L2-hot, and nothing has to keep them in registers), and the rotation rows of position *d_past are staged for
+// the attention launches -- what p3v_step_begin did
+template <int MT>
+__device__ __forceinline__ void gemv_step_begin_tail(const GemvStepP* sp, const bf16_t* const* xrow, int M, int chunks, int tid) {
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+    if (m < M)
+      for (int c = tid; c < chunks; c += 256) ((u32x4_t*)(sp->x_out + (size_t)m * (chunks * 8)))[c] = ((const u32x4_t*)xrow[m])[c];
+  const int past = *sp->d_past_in;
+  for (int i = tid; i < M * sp->half; i += 256) {
+    const int b = i / sp->half, d = i - b * sp->half;
+    sp->cos_o[i] = sp->cos_t[((size_t)b * sp->tab_t + past) * sp->half + d];
+    sp->sin_o[i] = sp->sin_t[((size_t)b * sp->tab_t + past) * sp->half + d];
+  }
+}
+
+// 5b. (every workgroup of the vocabulary head) arg-max + loop bookkeeping without a launch of their own -- what p3v_argmax +
+// p3v_step_end did: `best` = each wave's candidates (lane 0's copy counts); the last workgroup to finish reduces all of them
+template <int MT>
+__device__ __forceinline__ void gemv_step_end_tail(const GemvStepP* sp, const ArgMaxVI (&best)[MT], int M, int bx, int tid) {
+  const int lane = tid & 63, wave = tid >> 6;
+  __shared__ ArgMaxVI wbest[4][MT];
+  __shared__ int s_last;
+  if (lane == 0) {
+#pragma unroll
+    for (int m = 0; m < MT; ++m) wbest[wave][m] = best[m];
+  }
+  __syncthreads();
+  const int n_wg = gridDim.x;
+  if (tid == 0) {
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      ArgMaxVI r = wbest[0][m];
+#pragma unroll
+      for (int w = 1; w < 4; ++w) r = amax_better(r, wbest[w][m]);
+      // one 8-byte write-through store per row: a (value, index) pair is never seen half-written by the reducer below
+      const unsigned long long rec = (unsigned long long)__builtin_bit_cast(uint32_t, r.v) | ((unsigned long long)(uint32_t)r.i << 32);
+      __hip_atomic_store((unsigned long long*)sp->amax_ws + ((size_t)bx * MT + m), rec, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the candidates are out before the ticket is taken
+    const int t = __hip_atomic_fetch_add(sp->ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = t == n_wg - 1;
+  }
+  __syncthreads();
+  if (s_last) {                                              // the last workgroup to finish: every other candidate is visible
+    __shared__ ArgMaxVI fin[4][MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      ArgMaxVI r = ArgMaxVI{-INFINITY, 0x7fffffff};
+      for (int g = tid; g < n_wg; g += 256) {
+        const unsigned long long rec = __hip_atomic_load((const unsigned long long*)sp->amax_ws + ((size_t)g * MT + m), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        r = amax_better(r, ArgMaxVI{__builtin_bit_cast(float, (uint32_t)rec), (int)(uint32_t)(rec >> 32)});
+      }
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        ArgMaxVI o;
+        o.v = __shfl_xor(r.v, off, 64);
+        o.i = __shfl_xor(r.i, off, 64);
+        r = amax_better(r, o);
+      }
+      if (lane == 0) fin[wave][m] = r;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      const int step = *sp->d_step, past_now = *sp->d_past;
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+        if (m < M) {
+          ArgMaxVI r = fin[0][m];
+#pragma unroll
+          for (int w = 1; w < 4; ++w) r = amax_better(r, fin[w][m]);
+          const int idx = r.i == 0x7fffffff ? 0 : r.i;
+          sp->next_tok[m] = idx;
+          sp->tok_out[m] = idx;
+          if (step < sp->max_steps) sp->hist[(size_t)m * sp->max_steps + step] = idx;
+        }
+      *sp->d_step = step + 1;
+      *sp->d_past = past_now + 1;
+      __hip_atomic_store(sp->ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // re-armed for the next replay
+    }
+  }
+}
+
 // wpw: waves of the 4-wave workgroup that take rows (4, or 3: wave 3 then only helps with the prologue).  1536 streaming waves
 // (qkv, o_proj, down) as 384 four-wave workgroups put two workgroups on half of the CUs and one on the others, and the launch
 // lasts as long as the doubly loaded CUs; 512 workgroups x 3 waves load every CU alike (tools/gemv_timeline.py).
@@ -215,81 +300,6 @@ __device__ __forceinline__ void gemv3_body(const GemvP& p, int units_per_wave, i
   } else if (gs < n_st) {
     compute(gs, IC0{});
   }
-  if (STEP == STEP_BEGIN && bx == 0) {
-    // ---- 5a. the gathered rows become the residual stream the later launches update in place (re-read from the table: L2-hot, and
-    // nothing above has to keep them in registers), and the rotation rows of position *d_past are staged for the attention launches
-#pragma unroll
-    for (int m = 0; m < MT; ++m)
-      if (m < p.M)
-        for (int c = tid; c < CHUNKS; c += 256) ((u32x4_t*)(sp->x_out + (size_t)m * (CHUNKS * 8)))[c] = ((const u32x4_t*)xrow[m])[c];
-    const int past = *sp->d_past_in;
-    for (int i = tid; i < p.M * sp->half; i += 256) {
-      const int b = i / sp->half, d = i - b * sp->half;
-      sp->cos_o[i] = sp->cos_t[((size_t)b * sp->tab_t + past) * sp->half + d];
-      sp->sin_o[i] = sp->sin_t[((size_t)b * sp->tab_t + past) * sp->half + d];
-    }
-  }
-  if (STEP == STEP_END) {
-    // ---- 5b. arg-max + loop bookkeeping (p3v_step_end) without a launch of their own
-    __shared__ ArgMaxVI wbest[4][MT];
-    __shared__ int s_last;
-    if (lane == 0) {
-#pragma unroll
-      for (int m = 0; m < MT; ++m) wbest[wave][m] = best[m];
-    }
-    __syncthreads();
-    const int n_wg = gridDim.x;
-    if (tid == 0) {
-#pragma unroll
-      for (int m = 0; m < MT; ++m) {
-        ArgMaxVI r = wbest[0][m];
-#pragma unroll
-        for (int w = 1; w < 4; ++w) r = amax_better(r, wbest[w][m]);
-        // one 8-byte write-through store per row: a (value, index) pair is never seen half-written by the reducer below
-        const unsigned long long rec = (unsigned long long)__builtin_bit_cast(uint32_t, r.v) | ((unsigned long long)(uint32_t)r.i << 32);
-        __hip_atomic_store((unsigned long long*)sp->amax_ws + ((size_t)bx * MT + m), rec, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the candidates are out before the ticket is taken
-      const int t = __hip_atomic_fetch_add(sp->ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      s_last = t == n_wg - 1;
-    }
-    __syncthreads();
-    if (s_last) {                                              // the last workgroup to finish: every other candidate is visible
-      __shared__ ArgMaxVI fin[4][MT];
-#pragma unroll
-      for (int m = 0; m < MT; ++m) {
-        ArgMaxVI r = ArgMaxVI{-INFINITY, 0x7fffffff};
-        for (int g = tid; g < n_wg; g += 256) {
-          const unsigned long long rec = __hip_atomic_load((const unsigned long long*)sp->amax_ws + ((size_t)g * MT + m), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          r = amax_better(r, ArgMaxVI{__builtin_bit_cast(float, (uint32_t)rec), (int)(uint32_t)(rec >> 32)});
-        }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-          ArgMaxVI o;
-          o.v = __shfl_xor(r.v, off, 64);
-          o.i = __shfl_xor(r.i, off, 64);
-          r = amax_better(r, o);
-        }
-        if (lane == 0) fin[wave][m] = r;
-      }
-      __syncthreads();
-      if (tid == 0) {
-        const int step = *sp->d_step, past_now = *sp->d_past;
-#pragma unroll
-        for (int m = 0; m < MT; ++m)
-          if (m < p.M) {
-            ArgMaxVI r = fin[0][m];
-#pragma unroll
-            for (int w = 1; w < 4; ++w) r = amax_better(r, fin[w][m]);
-            const int idx = r.i == 0x7fffffff ? 0 : r.i;
-            sp->next_tok[m] = idx;
-            sp->tok_out[m] = idx;
-            if (step < sp->max_steps) sp->hist[(size_t)m * sp->max_steps + step] = idx;
-          }
-        *sp->d_step = step + 1;
-        *sp->d_past = past_now + 1;
-        __hip_atomic_store(sp->ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // re-armed for the next replay
-      }
-    }
-  }
+  if (STEP == STEP_BEGIN && bx == 0) gemv_step_begin_tail<MT>(sp, xrow, p.M, CHUNKS, tid);
+  if (STEP == STEP_END) gemv_step_end_tail<MT>(sp, best, p.M, bx, tid);
 }

@@ -519,12 +519,19 @@ def topk(x2d, k):
 def gemv_step_begin(tok, table, x_out, cos_t, sin_t, d_past, cos_out, sin_out, w, norm_w, norm_eps, out):
     """The step's FIRST projection with `step_begin` in its prologue (include/p3v.h: p3v_gemv_step): out = W . RMSNorm(table[tok]),
     x_out = table[tok], rotation rows of *d_past staged.  False (nothing launched) where the library keeps the separate launch."""
-    _chk(w, BF16, "w"), _chk(table, BF16, "table"), _chk(x_out, BF16, "x_out"), _chk(tok, I32, "tok")
+    _chk(table, BF16, "table"), _chk(x_out, BF16, "x_out"), _chk(tok, I32, "tok")
     B, tab_t, half = tok.numel(), cos_t.shape[-2], cos_t.shape[-1]
-    args = L.GemvArgs(None, _p(w), _p(out), None, _p(norm_w), float(norm_eps), B, w.shape[0], w.shape[1], EPI_NONE)
     st = L.GemvStep(_p(tok), _p(table), table.shape[0], _p(x_out), _p(cos_t), _p(sin_t), _p(cos_out), _p(sin_out), tab_t, half,
                     None, None, None, None, None, None, 0, _p(d_past))
-    rc = L.lib().p3v_gemv_step(C.byref(args), C.byref(st), _stream())
+    if isinstance(w, tuple):                                    # (e4m3 weights, fp32 row scales): p3v_gemv_fp8_step
+        w8, ws = w
+        _chk(w8, torch.uint8, "w8"), _chk(ws, F32, "w_scale")
+        args = L.GemvF8Args(None, _p(w8), _p(ws), _p(out), None, _p(norm_w), float(norm_eps), B, w8.shape[0], w8.shape[1], EPI_NONE)
+        rc = L.lib().p3v_gemv_fp8_step(C.byref(args), C.byref(st), _stream())
+    else:
+        _chk(w, BF16, "w")
+        args = L.GemvArgs(None, _p(w), _p(out), None, _p(norm_w), float(norm_eps), B, w.shape[0], w.shape[1], EPI_NONE)
+        rc = L.lib().p3v_gemv_step(C.byref(args), C.byref(st), _stream())
     if rc == L.ERR_UNSUPPORTED:
         return False
     L.check(rc, "gemv_step(begin)")
@@ -534,14 +541,21 @@ def gemv_step_begin(tok, table, x_out, cos_t, sin_t, d_past, cos_out, sin_out, w
 def gemv_step_end(x, w, norm_w, norm_eps, out, next_tok, tok, history, d_step, d_past, ticket, amax_ws):
     """The step's LAST projection (final norm + lm_head) with `step_end` in its epilogue: logits -> out, their arg-max -> next_tok /
     tok / history[:, *d_step], counters bumped -- by the last workgroup to finish.  False where the library keeps the separate launch."""
-    _chk(x, BF16, "x"), _chk(w, BF16, "w"), _chk(out, BF16, "out")
+    _chk(x, BF16, "x"), _chk(out, BF16, "out")
     if amax_ws.numel() * amax_ws.element_size() < L.GEMV_STEP_WS_BYTES:
         raise ValueError("gemv_step_end: amax_ws smaller than P3V_GEMV_STEP_WS_BYTES")
     M, K = x.shape
-    args = L.GemvArgs(_p(x), _p(w), _p(out), None, _p(norm_w), float(norm_eps), M, w.shape[0], K, EPI_NONE)
     st = L.GemvStep(None, None, 0, None, None, None, None, None, 0, 0,
                     _p(next_tok), _p(tok), _p(history), _p(d_step), _p(ticket), _p(amax_ws), history.shape[1], _p(d_past))
-    rc = L.lib().p3v_gemv_step(C.byref(args), C.byref(st), _stream())
+    if isinstance(w, tuple):                                    # (e4m3 weights, fp32 row scales)
+        w8, ws = w
+        _chk(w8, torch.uint8, "w8"), _chk(ws, F32, "w_scale")
+        args = L.GemvF8Args(_p(x), _p(w8), _p(ws), _p(out), None, _p(norm_w), float(norm_eps), M, w8.shape[0], K, EPI_NONE)
+        rc = L.lib().p3v_gemv_fp8_step(C.byref(args), C.byref(st), _stream())
+    else:
+        _chk(w, BF16, "w")
+        args = L.GemvArgs(_p(x), _p(w), _p(out), None, _p(norm_w), float(norm_eps), M, w.shape[0], K, EPI_NONE)
+        rc = L.lib().p3v_gemv_step(C.byref(args), C.byref(st), _stream())
     if rc == L.ERR_UNSUPPORTED:
         return False
     L.check(rc, "gemv_step(end)")

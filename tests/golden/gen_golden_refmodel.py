@@ -273,7 +273,8 @@ def lora_case(out, meta):
     generate_case(r, "lora", out, meta)
 
 
-Q4_CASES = {"q4text": (TINY_PROMPTS[1], None, 4), "q4vis": (VIS_PROMPT, ["sq"], 3)}
+# (q4batch, round 6: the two prompts as ONE left-padded batch -- QuantizedLinear at B = 2 under the reference's Mask4D / position ids)
+Q4_CASES = {"q4text": (TINY_PROMPTS[1], None, 4), "q4vis": (VIS_PROMPT, ["sq"], 3), "q4batch": (TINY_PROMPTS, None, 4)}
 
 
 def q4_case(out, meta):

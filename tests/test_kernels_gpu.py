@@ -1461,3 +1461,52 @@ def test_gemm_fp8_asymmetric_identity(ops):
     w8 = _e4m3(wv).view(torch.uint8)
     out = ops.gemm_fp8(a8.cuda(), torch.ones(K).cuda(), w8.cuda(), torch.ones(N).cuda())
     assert torch.equal(out.float().cpu(), wv.t().contiguous())
+
+
+@pytest.mark.parametrize("K", [3072, 8192])
+def test_gemv_fp8_step_folds_are_the_separate_launches(ops, K):
+    """p3v_gemv_fp8_step (round 6, config 5): the replayed step's two ends inside the e4m3 projections next to them, against
+    p3v_step_begin + p3v_gemv_fp8 and p3v_gemv_fp8 + p3v_step_end -- projection outputs, residual row, staged rotation rows, tokens
+    (a tie: the first maximum; a NaN row: -1), history, both counters BIT-IDENTICAL over several steps, the ticket left at zero."""
+    V, T, half, steps, B = 32064, 40, 48, 4, 1
+    table = g((V, K), 170).cuda()
+    cos, sin = torch.rand((B, T, half), dtype=F32).cuda(), torch.rand((B, T, half), dtype=F32).cuda()
+    w1 = ops.quantize_fp8_rows((g((1024, K), 171) * 0.05).cuda())
+    nw1 = (1 + 0.1 * g((K,), 172)).cuda()
+    tok = torch.tensor([9001], dtype=torch.int32).cuda()
+    d_past = torch.tensor([11], dtype=torch.int32).cuda()
+    x_a, x_b = torch.empty((B, K), dtype=BF16).cuda(), torch.full((B, K), 7.0, dtype=BF16).cuda()
+    ca, sa = torch.empty((B, 1, half), dtype=F32).cuda(), torch.empty((B, 1, half), dtype=F32).cuda()
+    cb, sb = torch.zeros_like(ca), torch.zeros_like(sa)
+    ops.step_begin(tok, table, x_a, cos, sin, d_past, ca, sa)
+    out_a = ops.gemv_fp8(x_a, w1[0], w1[1], norm_w=nw1, norm_eps=1e-5)
+    out_b = torch.full((B, 1024), float("nan"), dtype=BF16).cuda()
+    assert ops.gemv_step_begin(tok, table, x_b, cos, sin, d_past, cb, sb, tuple(w1), nw1, 1e-5, out_b)
+    assert torch.equal(out_a.view(torch.int16), out_b.view(torch.int16)) and torch.equal(x_a, x_b)
+    assert torch.equal(ca, cb) and torch.equal(sa, sb) and torch.equal(cb[:, 0], cos[:, 11])
+    wl_bf = (g((V, K), 173) * 0.05).cuda()
+    nwl = (1 + 0.1 * g((K,), 174)).cuda()
+    amax_ws = torch.empty((ops.L.GEMV_STEP_WS_BYTES // 4,), dtype=F32).cuda()
+    hist_a, hist_b = torch.zeros((B, steps), dtype=torch.int32).cuda(), torch.zeros((B, steps), dtype=torch.int32).cuda()
+    st_a, st_b = torch.zeros(1, dtype=torch.int32).cuda(), torch.zeros(1, dtype=torch.int32).cuda()
+    pa, pb = d_past.clone(), d_past.clone()
+    tk_a, tk_b = torch.zeros(1, dtype=torch.int32).cuda(), torch.zeros(1, dtype=torch.int32).cuda()
+    nx_a, nx_b, to_a, to_b = (torch.zeros(B, dtype=torch.int32).cuda() for _ in range(4))
+    for s in range(steps + 1):
+        x = g((B, K), 190 + s).cuda()
+        if s == 2:
+            wl_bf[20000] = wl_bf[300]                             # a tie between two vocabulary rows: the first one wins
+        if s == 3:
+            x[0, 5] = float("nan")
+        wl = ops.quantize_fp8_rows(wl_bf)
+        lg_a = ops.gemv_fp8(x, wl[0], wl[1], norm_w=nwl, norm_eps=1e-5)
+        ops.step_end(lg_a, nx_a, to_a, hist_a, st_a, pa, tk_a)
+        lg_b = torch.empty((B, V), dtype=BF16).cuda()
+        assert ops.gemv_step_end(x, tuple(wl), nwl, 1e-5, lg_b, nx_b, to_b, hist_b, st_b, pb, tk_b, amax_ws)
+        assert torch.equal(lg_a.view(torch.int16), lg_b.view(torch.int16))
+        assert torch.equal(nx_a, nx_b) and torch.equal(to_a, to_b), (s, nx_a.tolist(), nx_b.tolist())
+        assert st_b.item() == s + 1 and pb.item() == 12 + s and tk_b.item() == 0
+        if s == 3:
+            assert nx_b[0].item() == -1
+    assert torch.equal(hist_a, hist_b)
+    assert not ops.gemv_step_end(g((2, K), 1).cuda(), tuple(wl), nwl, 1e-5, torch.empty((2, V), dtype=BF16).cuda(), nx_b, to_b, hist_b, st_b, pb, tk_b, amax_ws)

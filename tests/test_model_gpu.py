@@ -736,12 +736,13 @@ def test_reference_model_fixture_full_size(name):
     torch.cuda.empty_cache()
 
 
-@pytest.mark.parametrize("name", ["q4text", "q4vis"])
+@pytest.mark.parametrize("name", ["q4text", "q4vis", "q4batch"])
 def test_reference_written_4bit_checkpoint(name, tmp_path):
     """Row f4 on the GPU against the reference's own 4-bit writer / reader: the checkpoint `_quantize` wrote (rebuilt here bit for
     bit, every tensor's sha256 checked: tests/golden/q4_ckpt.py) is loaded by `api._load` -- decoder projections and lm_head stay
     4-bit (`p3v_gemv_q4` / `p3v_dequant_q4`), embeddings, ViT and projector are dequantised -- and must reproduce what the
-    reference's `_load` + `_generate` computed on `QuantizedLinear` / `QuantizedEmbedding`: logits inside 4.5 %, tokens exact."""
+    reference's `_load` + `_generate` computed on `QuantizedLinear` / `QuantizedEmbedding`: logits inside 4.5 %, tokens exact.
+    q4batch (round 6): the two prompts as one left-padded B = 2 batch, as the reference ran them."""
     import q4_ckpt
     from golden_inputs import make_image
     from phi_3_vision_mlx_amd import api
@@ -751,6 +752,8 @@ def test_reference_written_4bit_checkpoint(name, tmp_path):
     assert len(model.w4) == 2 * 4 + 1 and "lm_head.weight" not in model.w
     if name == "q4text":
         inputs = proc(REF_PROMPTS[1])
+    elif name == "q4batch":
+        inputs = proc(REF_PROMPTS)
     else:
         inputs = proc(REF_CASES["vis"][1], [make_image(*REF_IMAGES["sq"])])
     view = {"rel_tol": g[name + "_rel_tol"], "tokens": g[name + "_tokens"], "logits_bf16": g[name + "_logits_bf16"], "margins": g[name + "_margins"]}

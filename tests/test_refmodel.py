@@ -204,7 +204,7 @@ def test_full_size_oracle_fixtures_equal_the_reference_composed_ones():
         assert (g[name + "_margins"][:, :n] > 1.0).all()
 
 
-@pytest.mark.parametrize("name", ["q4text", "q4vis"])
+@pytest.mark.parametrize("name", ["q4text", "q4vis", "q4batch"])
 def test_reference_written_4bit_checkpoint_loader_and_oracle(fx, tmp_path, name):
     """Row f4 against the reference's own writer and reader: `_quantize` (phi_3_vision_mlx.py:291-305) wrote the checkpoint, `_load`
     (`nn.quantize` before `load_weights`, :264) read it back and `_generate` ran on it (fixture).  Here: (1) the same bytes come out
@@ -212,7 +212,9 @@ def test_reference_written_4bit_checkpoint_loader_and_oracle(fx, tmp_path, name)
     takes the directory: decoder projections + lm_head stay 4-bit (`Q4Weight`), both embeddings, the CLIP position table, the ViT's
     and the projector's Linears are dequantised, the sanitised patch convolution is permuted back; (3) the oracle on the
     dequantised values (fp32 scale * q + bias, what MLX's quantised matmul accumulates; bf16 for embedding rows) reproduces the
-    reference's logits -- bit for bit on the text prompt, to 2^-5 of the row's largest logit on the image prompt (fp32 tower)."""
+    reference's logits -- bit for bit on the text prompt and on the two prompts as ONE left-padded batch (q4batch, round 6:
+    QuantizedLinear at B = 2 under the reference's Mask4D / position ids), to 2^-5 of the row's largest logit on the image prompt
+    (fp32 tower)."""
     import q4_ckpt
     from phi_3_vision_mlx_amd.weights import Q4Weight, load_safetensors_dir, mlx_dequantize
     g, meta = fx
@@ -235,11 +237,11 @@ def test_reference_written_4bit_checkpoint_loader_and_oracle(fx, tmp_path, name)
         else:
             ow[k] = v
     oracle = orc.OraclePhi3V(cfg, ow, cache_fp32=True)
-    blind, prompt, images = (None, TINY_PROMPTS[1], None) if name == "q4text" else (None, VIS_PROMPT, ["sq"])
+    blind, prompt, images = {"q4text": (None, TINY_PROMPTS[1], None), "q4batch": (None, TINY_PROMPTS, None)}.get(name, (None, VIS_PROMPT, ["sq"]))
     proc = Phi3VProcessor(None)
     imgs = [make_image(*IMAGES[i]) for i in images] if images else None
     inp = proc(prompt, imgs) if imgs else proc(prompt)
-    n = g[name + "_tokens"].shape[1]
+    n = g[name + "_tokens"].shape[-1]
     o_in = {k: (torch.from_numpy(np.asarray(v)) if k == "pixel_values" else v) for k, v in inp.items()}
     toks, lgs = orc.greedy_generate(oracle, o_in, n, stop_on_eos=False)
     assert np.array_equal(toks.numpy(), g[name + "_tokens"])
