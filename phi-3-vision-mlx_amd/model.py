@@ -159,6 +159,7 @@ class Phi3VModel:
             raise ValueError(f"decoder head_dim must be 96 (got {self.hd})")
         self.hidden_hook = None                      # fn(layer, x [B*L, H], B, L) after every decoder layer (diagnostics)
         self.w8 = {}
+        self._rope_tables = {}                                   # (B, T, factors, ..) -> (cos, sin): shared read-only (see _new_state)
         self.adapters = {}                           # weight key -> (lora_a, lora_b, scale), see set_adapters
         self._lora_tmp = {}                          # decode-sized (M <= 16) adapter scratch: captured graphs point at it
         self._lora_flat = None                       # ONE grow-only scratch for prefill-sized calls (not graph-captured)
@@ -367,7 +368,10 @@ class Phi3VModel:
         sizes = (np.asarray(image_sizes) // 336).tolist()
         positions = np.asarray(positions).tolist()
         live = [h * ww + 1 for h, ww in sizes]
-        pix = torch.cat([pv[i, :n] for i, n in enumerate(live)], dim=0).contiguous().to(self.device)
+        if len(live) == 1 and pv.is_contiguous():                          # one image: its live crops are a view, nothing to gather
+            pix = pv[0, :live[0]].to(self.device)
+        else:
+            pix = torch.cat([pv[i, :n] for i, n in enumerate(live)], dim=0).contiguous().to(self.device)
         feats = self.clip_forward(pix)
         C_ = self.cfg.img_processor["image_dim_out"]
         G = self.cfg.clip["image_size"] // self.cfg.clip["patch_size"]
@@ -385,13 +389,24 @@ class Phi3VModel:
         return x
 
     # ------------------------------------------------------------------ per-prompt state
-    def _new_state(self, B, S, max_tokens, pids, mask):
+    ROPE_TABLE_ENTRIES = 8
+
+    def _new_state(self, B, S, max_tokens, pids, mask, shared_tables=True):
         cfg = self.cfg
         st = CacheState(cfg, B, S, max_tokens, self.device)
         self._states.add(st)
         L_all = S + max_tokens                                  # reference sizes tables with max_tokens as given
         half = self.hd // 2
         su = cfg.rope_scaling["long_factor"] if L_all > cfg.original_max_position_embeddings else cfg.rope_scaling["short_factor"]
+        # Prompts without explicit position ids (every unpadded request) of one geometry rotate by the same table: it is built once
+        # and shared read-only between their states (a server's requests repeat a few geometries; building it costs three small host ->
+        # device copies and a launch in front of every prefill).  Slot states write per-row tables: they get their own.
+        tkey = (B, st.T, tuple(float(v) for v in su), float(cfg.rope_theta), rope_scaling_factor(cfg), self.hd) if pids is None and shared_tables else None
+        if tkey is not None and tkey in self._rope_tables:
+            st.cos, st.sin = self._rope_tables[tkey]
+            if mask is not None:
+                st.pad_len = torch.as_tensor((np.asarray(mask) == 0).sum(axis=1).astype(np.int32)).to(self.device)
+            return st
         inv_freq = 1.0 / (torch.tensor(su, dtype=F32) * (torch.tensor(float(cfg.rope_theta), dtype=F32)
                                                         ** (torch.arange(0, self.hd, 2, dtype=F32) / self.hd)))
         T = st.T
@@ -404,6 +419,10 @@ class Phi3VModel:
         pos = pos.contiguous().to(self.device)
         cos, sin = ops.rope_table(pos.view(-1), inv_freq.to(self.device), rope_scaling_factor(cfg))
         st.cos, st.sin = cos.view(B, T, half), sin.view(B, T, half)
+        if tkey is not None:
+            if len(self._rope_tables) >= self.ROPE_TABLE_ENTRIES:
+                self._rope_tables.pop(next(iter(self._rope_tables)))
+            self._rope_tables[tkey] = (st.cos, st.sin)
         if mask is not None:
             m = np.asarray(mask)
             st.pad_len = torch.as_tensor((m == 0).sum(axis=1).astype(np.int32)).to(self.device)
@@ -418,7 +437,7 @@ class Phi3VModel:
         of every row (phi.py:492: one choice per call from prompt + max_tokens): window <= 4096 -> short factors, beyond
         -> long factors; the engine admits only requests that would pick the same factors alone.  With
         `quantize_cache=True` the rows keep the int8 KV cache (BASELINE config 5)."""
-        st = self._new_state(slots, 0, window, None, None)
+        st = self._new_state(slots, 0, window, None, None, shared_tables=False)
         st.pad_len = torch.full((slots,), window, dtype=I32, device=self.device)
         st.slots = True
         return st
@@ -827,14 +846,16 @@ class Phi3VModel:
             got = self._prefill_captured(ids, L, max_tokens)
             if got is not None:
                 return got
-        x = ops.embed_gather(ids.view(-1), w["model.embed_tokens.weight"])
-        if pixel_values is not None and self.vision:
-            self.vision_embed(x, pixel_values, image_sizes, positions, L)
         if prefill:
+            # (before the vision tower is enqueued: the host is launch-bound through the ViT's ~280 launches, so whatever it does between
+            #  the tower and the decoder -- cache allocation, its zero fill, the rotation tables -- would show as idle GPU time there)
             st = self._new_state(B, L, max_tokens, pids, mask)
             cache = [LayerCache(st, i) for i in range(cfg.num_hidden_layers)]
         else:
             st = cache[0].state
+        x = ops.embed_gather(ids.view(-1), w["model.embed_tokens.weight"])
+        if pixel_values is not None and self.vision:
+            self.vision_embed(x, pixel_values, image_sizes, positions, L)
         past = st.offset
         if n_beam == 1 and past + L > st.T:
             raise ValueError(f"KV cache overflow: {past}+{L} > {st.T} (prompt + max_tokens)")
