@@ -405,13 +405,16 @@ int p3v_step_end(const uint16_t* logits, int32_t* next_tok, int32_t* tok, int32_
  *                             stream) and the rotation rows of position *d_past staged into cos_out / sin_out, as p3v_step_begin does;
  *   end (next_tok != NULL):   next_tok[b] = tok_out[b] = argmax(out[b]) (first maximum of the bf16 values; a NaN row reports -1),
  *                             history[b, *d_step] = it, then *d_step += 1, *d_past += 1 -- by the last workgroup to finish (every
- *                             workgroup publishes its candidates into amax_ws and takes a ticket; `ticket`: one zeroed int32, left zero;
- *                             amax_ws: P3V_GEMV_STEP_WS_BYTES bytes, 8-byte aligned, contents irrelevant).
+ *                             workgroup publishes its candidates into amax_ws and counts itself in: one arrival counter per XCD, then
+ *                             one for the eight group-last workgroups -- a thousand workgroups finishing together on ONE counter
+ *                             serialise for ~10 us; amax_ws: P3V_GEMV_STEP_WS_BYTES bytes, 8-byte aligned: P3V_GEMV_STEP_MAX_WG
+ *                             candidate records (contents irrelevant) + nine counters, 128 bytes apart, that must be ZERO before
+ *                             the first launch and are left zero by every launch; `ticket` is not touched).
  * Exactly one of the two.  M = 1 row (the kernel p3v_gemv runs there), bf16 weights, K = 3072 or 8192, P3V_EPI_NONE: otherwise
  * P3V_ERR_UNSUPPORTED and the caller
  * keeps p3v_step_begin / p3v_step_end.  Bit-identical to the separate launches. */
 #define P3V_GEMV_STEP_MAX_WG 1024
-#define P3V_GEMV_STEP_WS_BYTES (P3V_GEMV_STEP_MAX_WG * 8)
+#define P3V_GEMV_STEP_WS_BYTES (P3V_GEMV_STEP_MAX_WG * 8 + 9 * 128)
 typedef struct {
   const int32_t* tok; const uint16_t* embed_table; int vocab; uint16_t* x_out;
   const float* cos_t; const float* sin_t; float* cos_out; float* sin_out; int tab_t, half_dim;
@@ -421,6 +424,8 @@ typedef struct {
 int p3v_gemv_step(const p3v_gemv_args_t* args /* host */, const p3v_gemv_step_t* step /* host */, void* stream);
 /* the same on e4m3 weights (config 5: `args` as for p3v_gemv_fp8, one row, no epilogue) */
 int p3v_gemv_fp8_step(const p3v_gemv_fp8_args_t* args /* host */, const p3v_gemv_step_t* step /* host */, void* stream);
+/* and on MLX 4-bit group-64 weights (`args` as for p3v_gemv_q4, one row, no epilogue) */
+int p3v_gemv_q4_step(const p3v_gemv_q4_args_t* args /* host */, const p3v_gemv_step_t* step /* host */, void* stream);
 
 /* ---- hipGraph helpers: capture a sequence of the launches above and replay it */
 int p3v_graph_begin(void* stream);

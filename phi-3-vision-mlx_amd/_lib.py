@@ -46,7 +46,7 @@ class GemvStep(C.Structure):
                 ("d_past", vp)]
 
 
-GEMV_STEP_WS_BYTES = 1024 * 8               # P3V_GEMV_STEP_WS_BYTES
+GEMV_STEP_WS_BYTES = 1024 * 8 + 9 * 128     # P3V_GEMV_STEP_WS_BYTES (candidate records + nine arrival counters, zero-initialised)
 
 
 class GemvF8Args(C.Structure):
@@ -105,6 +105,7 @@ SIGNATURES = {
     "p3v_gemv": (i32, [C.POINTER(GemvArgs), vp]),
     "p3v_gemv_step": (i32, [C.POINTER(GemvArgs), C.POINTER(GemvStep), vp]),
     "p3v_gemv_fp8_step": (i32, [C.POINTER(GemvF8Args), C.POINTER(GemvStep), vp]),
+    "p3v_gemv_q4_step": (i32, [C.POINTER(GemvQ4Args), C.POINTER(GemvStep), vp]),
     "p3v_gemv_fp8": (i32, [C.POINTER(GemvF8Args), vp]),
     "p3v_dequant_fp8": (i32, [vp, vp, vp, i32, i32, vp]),
     "p3v_gemm_fp8": (i32, [C.POINTER(GemmF8Args), vp]),

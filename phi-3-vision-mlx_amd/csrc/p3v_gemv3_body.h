@@ -92,9 +92,16 @@ __device__ __forceinline__ void gemv_step_end_tail(const GemvStepP* sp, const Ar
       const unsigned long long rec = (unsigned long long)__builtin_bit_cast(uint32_t, r.v) | ((unsigned long long)(uint32_t)r.i << 32);
       __hip_atomic_store((unsigned long long*)sp->amax_ws + ((size_t)bx * MT + m), rec, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the candidates are out before the ticket is taken
-    const int t = __hip_atomic_fetch_add(sp->ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    s_last = t == n_wg - 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the candidates are out before this workgroup counts itself in
+    // Arrival in two levels (MI355X_MICROARCH.md, fanin: ~12 ns per atomic on one word -- the 1002 workgroups of the e4m3 vocabulary head
+    // finish together and queued for ~10 us on a single ticket): workgroup b counts on counter b % 8 (b % 8 is also its XCD), the last of
+    // each group on the top counter; the last of those has seen everything.  Counters: behind the records, 128 bytes apart, left zero.
+    int* ctr = (int*)((unsigned long long*)sp->amax_ws + P3V_GEMV_STEP_MAX_WG * MT);
+    const int grp = bx & 7, n_grp = min(8, n_wg), in_grp = (n_wg - grp + 7) >> 3;
+    int last = 0;
+    if (__hip_atomic_fetch_add(ctr + 32 * grp, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == in_grp - 1)
+      last = __hip_atomic_fetch_add(ctr + 32 * 8, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == n_grp - 1;
+    s_last = last;
   }
   __syncthreads();
   if (s_last) {                                              // the last workgroup to finish: every other candidate is visible
@@ -131,7 +138,8 @@ __device__ __forceinline__ void gemv_step_end_tail(const GemvStepP* sp, const Ar
         }
       *sp->d_step = step + 1;
       *sp->d_past = past_now + 1;
-      __hip_atomic_store(sp->ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // re-armed for the next replay
+      int* ctr = (int*)((unsigned long long*)sp->amax_ws + P3V_GEMV_STEP_MAX_WG * MT);
+      for (int c = 0; c < 9; ++c) __hip_atomic_store(ctr + 32 * c, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-armed for the next replay
     }
   }
 }

@@ -18,6 +18,7 @@
 
 #include "p3v_common.h"
 #include "p3v_dot_q4.h"
+#include "p3v_gemv3_body.h"      // GemvStepP + the step-end helpers shared with the bf16 / e4m3 kernels
 
 struct GemvQ4P {
   const bf16_t* x; const uint32_t* W; const uint32_t* sb; void* out; const bf16_t* resid; const bf16_t* norm_w;
@@ -27,13 +28,12 @@ struct GemvQ4P {
 typedef std::integral_constant<int, 0> QC0;
 typedef std::integral_constant<int, 1> QC1;
 // NST stages x NP 16-weight pieces per lane per row: K = NST * NP * 64 * 16
-template <int NST, int NP>
-__global__ void __launch_bounds__(256) k_gemv3_q4(GemvQ4P p, int units_per_wave, int wpw) {
+// STEP (p3v_gemv3_body.h): STEP_BEGIN / STEP_END carry the replayed greedy step's two ends, as gemv3_body does for bf16 weights
+template <int NST, int NP, int STEP>
+__device__ __forceinline__ void gemv3_q4_body(const GemvQ4P& p, int units_per_wave, int wpw, unsigned char* smem, float* red, const GemvStepP* sp) {
   constexpr int PIECES = NST * NP * 64;                 // 16-weight pieces per row
   constexpr int K = PIECES * 16, XCH = K / 8;           // 16-byte x chunks
   constexpr int XC = (XCH + 255) / 256;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  __shared__ float red[4];
   u32x4_t* xs = (u32x4_t*)smem;                         // [K] bf16 x (normalised)
   float* xsum = (float*)(smem + K * 2);                 // [PIECES] sum of the 16 activations of a piece
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -43,10 +43,16 @@ __global__ void __launch_bounds__(256) k_gemv3_q4(GemvQ4P p, int units_per_wave,
   const int n_st = (u_end - u_begin) * NST;
 
   u32x4_t xv[XC], gv[XC];
+  const bf16_t* xrow[1] = {p.x};
+  if (STEP == STEP_BEGIN) {
+    int id = sp->tok[0];                                // (uniform: a scalar load)
+    id = id < 0 ? 0 : (id >= sp->vocab ? sp->vocab - 1 : id);
+    xrow[0] = sp->table + (size_t)id * K;
+  }
 #pragma unroll
   for (int k = 0; k < XC; ++k) {
     const int c = min(tid + k * 256, XCH - 1);
-    xv[k] = ((const u32x4_t*)p.x)[c];
+    xv[k] = ((const u32x4_t*)xrow[0])[c];
     gv[k] = p.norm_w ? ((const u32x4_t*)p.norm_w)[c] : (u32x4_t){0, 0, 0, 0};
   }
   u32x2_t wbuf[2][2][NP];
@@ -112,6 +118,7 @@ __global__ void __launch_bounds__(256) k_gemv3_q4(GemvQ4P p, int units_per_wave,
   __builtin_amdgcn_s_barrier();
 
   float a0 = 0.f, a1 = 0.f;
+  ArgMaxVI best[1] = {ArgMaxVI{-INFINITY, 0x7fffffff}};      // STEP_END: this wave's arg-max candidate (lane 0's copy counts)
   auto compute = [&](int gs, auto bufc) {
     constexpr int buf = decltype(bufc)::value;
     const int s = gs % NST;
@@ -144,6 +151,10 @@ __global__ void __launch_bounds__(256) k_gemv3_q4(GemvQ4P p, int units_per_wave,
           float v0 = a0, v1 = a1;
           if (has_res) { v0 = bf16lo(rbuf[buf]) + bf16_round(v0); v1 = bf16hi(rbuf[buf]) + bf16_round(v1); }
           *(uint32_t*)((bf16_t*)p.out + 2 * u) = pack_bf16x2(v0, v1);
+          if (STEP == STEP_END) {                              // on the values just stored (bf16)
+            amax_take(best[0], bf16_round(v0), 2 * u);
+            if (2 * u + 1 < p.N) amax_take(best[0], bf16_round(v1), 2 * u + 1);
+          }
         }
       }
       a0 = a1 = 0.f;
@@ -160,6 +171,22 @@ __global__ void __launch_bounds__(256) k_gemv3_q4(GemvQ4P p, int units_per_wave,
   } else if (gs < n_st) {
     compute(gs, QC0{});
   }
+  if (STEP == STEP_BEGIN && blockIdx.x == 0) gemv_step_begin_tail<1>(sp, xrow, 1, XCH, tid);
+  if (STEP == STEP_END) gemv_step_end_tail<1>(sp, best, 1, (int)blockIdx.x, tid);
+}
+
+template <int NST, int NP>
+__global__ void __launch_bounds__(256) k_gemv3_q4(GemvQ4P p, int units_per_wave, int wpw) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ float red[4];
+  gemv3_q4_body<NST, NP, STEP_NONE>(p, units_per_wave, wpw, smem, red, nullptr);
+}
+
+template <int NST, int NP, int STEP>
+__global__ void __launch_bounds__(256) k_gemv3_q4_step(GemvQ4P p, int units_per_wave, int wpw, GemvStepP sp) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ float red[4];
+  gemv3_q4_body<NST, NP, STEP>(p, units_per_wave, wpw, smem, red, &sp);
 }
 
 // W4 / SB -> bf16 [rows, K] (prefill and batched decode run the bf16 kernels on a dequantised scratch copy)
@@ -188,8 +215,8 @@ extern "C" int p3v_dequant_q4(const uint32_t* w4, const uint32_t* sb, uint16_t* 
   return P3V_OK;
 }
 
-template <int NST, int NP>
-static int launch_gemv3_q4(const GemvQ4P& p, hipStream_t s) {
+template <int NST, int NP, int STEP = STEP_NONE>
+static int launch_gemv3_q4(const GemvQ4P& p, hipStream_t s, const GemvStepP* sp = nullptr) {
   static int n_cu = 0;
   if (!n_cu) {
     int dev = 0;
@@ -202,9 +229,37 @@ static int launch_gemv3_q4(const GemvQ4P& p, hipStream_t s) {
   if (upw < 1) upw = 1;
   const int waves = p3v_cdiv(p.units, upw);
   const int wpw = p3v_gemv_wpw(waves, n_cu, p3v_tuning().gemv_wpw);
-  hipLaunchKernelGGL((k_gemv3_q4<NST, NP>), dim3(p3v_cdiv(waves, wpw)), dim3(256), (size_t)p.K * 2 + (size_t)p.K / 4, s, p, upw, wpw);
+  if constexpr (STEP != STEP_NONE) {
+    if (p3v_cdiv(waves, wpw) > P3V_GEMV_STEP_MAX_WG) return P3V_ERR_UNSUPPORTED;        // (amax_ws holds one candidate per workgroup)
+    hipLaunchKernelGGL((k_gemv3_q4_step<NST, NP, STEP>), dim3(p3v_cdiv(waves, wpw)), dim3(256), (size_t)p.K * 2 + (size_t)p.K / 4, s, p, upw, wpw, *sp);
+  } else {
+    hipLaunchKernelGGL((k_gemv3_q4<NST, NP>), dim3(p3v_cdiv(waves, wpw)), dim3(256), (size_t)p.K * 2 + (size_t)p.K / 4, s, p, upw, wpw);
+  }
   P3V_CHECK_LAUNCH();
   return P3V_OK;
+}
+
+// p3v_gemv_step on MLX 4-bit weights: the first / last projection of a replayed greedy step with p3v_step_begin / p3v_step_end folded in
+// (one row, K = 3072 or 8192, no epilogue); anything else reports P3V_ERR_UNSUPPORTED and the caller keeps the separate launches.
+extern "C" int p3v_gemv_q4_step(const p3v_gemv_q4_args_t* a, const p3v_gemv_step_t* st, void* stream) {
+  if (!a || !st || !a->W || !a->sb || !a->out) return P3V_ERR_ARG;
+  const bool begin = st->tok != nullptr, end = st->next_tok != nullptr;
+  if (begin == end) return P3V_ERR_ARG;                        // exactly one of the two ends
+  if (a->M <= 0 || a->N <= 0 || a->K <= 0) return P3V_ERR_ARG;
+  if (a->M != 1 || a->N % 2 || (a->K != 3072 && a->K != 8192) || a->epilogue != P3V_EPI_NONE) return P3V_ERR_UNSUPPORTED;
+  if (begin) {
+    if (!st->embed_table || !st->x_out || !st->cos_t || !st->sin_t || !st->d_past || !st->cos_out || !st->sin_out || st->vocab <= 0) return P3V_ERR_ARG;
+    if (((uintptr_t)st->embed_table | (uintptr_t)st->x_out) & 15) return P3V_ERR_ARG;
+  } else {
+    if (!a->x || !st->tok_out || !st->history || !st->d_step || !st->d_past || !st->ticket || !st->amax_ws) return P3V_ERR_ARG;
+    if ((uintptr_t)st->amax_ws & 7) return P3V_ERR_ARG;
+  }
+  const GemvQ4P p = {a->x, a->W, a->sb, a->out, a->resid, a->norm_w, a->norm_eps, a->M, a->N, a->K, a->epilogue, a->N / 2};
+  const GemvStepP sp = {st->tok, st->embed_table, st->vocab, st->x_out, st->cos_t, st->sin_t, st->d_past, st->cos_out, st->sin_out, st->tab_t,
+                        st->half_dim, st->next_tok, st->tok_out, st->history, st->d_step, st->d_past, st->ticket, st->amax_ws, st->max_steps};
+  hipStream_t s = (hipStream_t)stream;
+  if (a->K == 3072) return begin ? launch_gemv3_q4<1, 3, STEP_BEGIN>(p, s, &sp) : launch_gemv3_q4<1, 3, STEP_END>(p, s, &sp);
+  return begin ? launch_gemv3_q4<2, 4, STEP_BEGIN>(p, s, &sp) : launch_gemv3_q4<2, 4, STEP_END>(p, s, &sp);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

@@ -624,7 +624,7 @@ class Phi3VModel:
                                              q_scale=scale * ops.Q_PRESCALE)
             if i == 0 and step_begin is not None:               # replayed greedy step: the embedding gather + rotation-row staging
                 sb = step_begin                                 # ride in this projection's prologue when the library takes the shape
-                w_fold = w.get(k_w) if k_w in w else self.w8.get(k_w)       # bf16 weights, or (e4m3, row scales)
+                w_fold = w.get(k_w) if k_w in w else (self.w8.get(k_w) or self.w4.get(k_w))   # bf16, (e4m3, row scales) or (4-bit, scale | bias)
                 if not (w_fold is not None and k_w not in self.adapters and os.environ.get("P3V_STEP_FOLD", "1") != "0"
                         and ops.gemv_step_begin(sb["tok"], sb["table"], x, st.cos, st.sin, d_past, sb["cos_o"], sb["sin_o"],
                                                 w_fold, w[p + "input_layernorm.weight"], eps, qkv)):
@@ -755,15 +755,15 @@ class Phi3VModel:
         bufs["rope_sin"] = torch.empty_like(bufs["rope_cos"])
         g["bufs"] = bufs
 
-        g["amax_ws"] = torch.empty((ops.L.GEMV_STEP_WS_BYTES // 4,), dtype=F32, device=dev)
+        g["amax_ws"] = torch.zeros((ops.L.GEMV_STEP_WS_BYTES // 4,), dtype=F32, device=dev)   # (its arrival counters start at zero)
 
         def step():
             # (round 6) the step's two ends have no launch of their own where the library folds them into the first / last projection
-            # (B = 1 on bf16 or e4m3 weights: ops.gemv_step_begin / gemv_step_end; 129 launches per step instead of 131)
+            # (B = 1 on bf16, e4m3 or 4-bit weights: ops.gemv_step_begin / gemv_step_end; 129 launches per step instead of 131)
             self._layers(g["x"], st, B, 1, 0, 1, bufs=bufs, d_past=g["d_past"],
                          step_begin=dict(tok=g["tok"], table=w["model.embed_tokens.weight"], cos_o=bufs["rope_cos"], sin_o=bufs["rope_sin"]))
             head = "lm_head.weight"
-            w_fold = w.get(head) if head in w else self.w8.get(head)          # bf16 weights, or (e4m3, row scales)
+            w_fold = w.get(head) if head in w else (self.w8.get(head) or self.w4.get(head))   # bf16, (e4m3, row scales) or (4-bit, scale | bias)
             if not (w_fold is not None and head not in self.adapters and os.environ.get("P3V_STEP_FOLD", "1") != "0"
                     and ops.gemv_step_end(g["x"], w_fold, w["model.norm.weight"], cfg.rms_norm_eps, g["logits"], g["next_tok"], g["tok"],
                                           g["history"], g["d_step"], g["d_past"], g["ticket"], g["amax_ws"])):

@@ -523,7 +523,12 @@ def gemv_step_begin(tok, table, x_out, cos_t, sin_t, d_past, cos_out, sin_out, w
     B, tab_t, half = tok.numel(), cos_t.shape[-2], cos_t.shape[-1]
     st = L.GemvStep(_p(tok), _p(table), table.shape[0], _p(x_out), _p(cos_t), _p(sin_t), _p(cos_out), _p(sin_out), tab_t, half,
                     None, None, None, None, None, None, 0, _p(d_past))
-    if isinstance(w, tuple):                                    # (e4m3 weights, fp32 row scales): p3v_gemv_fp8_step
+    if isinstance(w, tuple) and w[0].dtype == I32:              # (4-bit weights, scale | bias words): p3v_gemv_q4_step
+        w4, sb = w
+        _chk(sb, I32, "sb")
+        args = L.GemvQ4Args(None, _p(w4), _p(sb), _p(out), None, _p(norm_w), float(norm_eps), B, w4.shape[0], w4.shape[1] * 8, EPI_NONE)
+        rc = L.lib().p3v_gemv_q4_step(C.byref(args), C.byref(st), _stream())
+    elif isinstance(w, tuple):                                  # (e4m3 weights, fp32 row scales): p3v_gemv_fp8_step
         w8, ws = w
         _chk(w8, torch.uint8, "w8"), _chk(ws, F32, "w_scale")
         args = L.GemvF8Args(None, _p(w8), _p(ws), _p(out), None, _p(norm_w), float(norm_eps), B, w8.shape[0], w8.shape[1], EPI_NONE)
@@ -547,7 +552,12 @@ def gemv_step_end(x, w, norm_w, norm_eps, out, next_tok, tok, history, d_step, d
     M, K = x.shape
     st = L.GemvStep(None, None, 0, None, None, None, None, None, 0, 0,
                     _p(next_tok), _p(tok), _p(history), _p(d_step), _p(ticket), _p(amax_ws), history.shape[1], _p(d_past))
-    if isinstance(w, tuple):                                    # (e4m3 weights, fp32 row scales)
+    if isinstance(w, tuple) and w[0].dtype == I32:              # (4-bit weights, scale | bias words)
+        w4, sb = w
+        _chk(sb, I32, "sb")
+        args = L.GemvQ4Args(_p(x), _p(w4), _p(sb), _p(out), None, _p(norm_w), float(norm_eps), M, w4.shape[0], K, EPI_NONE)
+        rc = L.lib().p3v_gemv_q4_step(C.byref(args), C.byref(st), _stream())
+    elif isinstance(w, tuple):                                  # (e4m3 weights, fp32 row scales)
         w8, ws = w
         _chk(w8, torch.uint8, "w8"), _chk(ws, F32, "w_scale")
         args = L.GemvF8Args(_p(x), _p(w8), _p(ws), _p(out), None, _p(norm_w), float(norm_eps), M, w8.shape[0], K, EPI_NONE)

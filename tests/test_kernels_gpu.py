@@ -1224,7 +1224,7 @@ def test_gemv_step_folds_are_the_separate_launches(ops, K, B=1):
     assert torch.equal(ca, cb) and torch.equal(sa, sb) and torch.equal(cb[:, 0], cos[:, 11])
     # the tail: final norm + lm_head + arg-max + bookkeeping
     wl, nwl = (g((V, K), 73) * 0.05).cuda(), (1 + 0.1 * g((K,), 74)).cuda()
-    amax_ws = torch.empty((ops.L.GEMV_STEP_WS_BYTES // 4,), dtype=F32).cuda()
+    amax_ws = torch.zeros((ops.L.GEMV_STEP_WS_BYTES // 4,), dtype=F32).cuda()      # (candidate records + arrival counters: zero once)
     hist_a, hist_b = torch.zeros((B, steps), dtype=torch.int32).cuda(), torch.zeros((B, steps), dtype=torch.int32).cuda()
     st_a, st_b = torch.zeros(1, dtype=torch.int32).cuda(), torch.zeros(1, dtype=torch.int32).cuda()
     pa, pb = d_past.clone(), d_past.clone()
@@ -1486,7 +1486,7 @@ def test_gemv_fp8_step_folds_are_the_separate_launches(ops, K):
     assert torch.equal(ca, cb) and torch.equal(sa, sb) and torch.equal(cb[:, 0], cos[:, 11])
     wl_bf = (g((V, K), 173) * 0.05).cuda()
     nwl = (1 + 0.1 * g((K,), 174)).cuda()
-    amax_ws = torch.empty((ops.L.GEMV_STEP_WS_BYTES // 4,), dtype=F32).cuda()
+    amax_ws = torch.zeros((ops.L.GEMV_STEP_WS_BYTES // 4,), dtype=F32).cuda()      # (candidate records + arrival counters: zero once)
     hist_a, hist_b = torch.zeros((B, steps), dtype=torch.int32).cuda(), torch.zeros((B, steps), dtype=torch.int32).cuda()
     st_a, st_b = torch.zeros(1, dtype=torch.int32).cuda(), torch.zeros(1, dtype=torch.int32).cuda()
     pa, pb = d_past.clone(), d_past.clone()
@@ -1510,3 +1510,42 @@ def test_gemv_fp8_step_folds_are_the_separate_launches(ops, K):
             assert nx_b[0].item() == -1
     assert torch.equal(hist_a, hist_b)
     assert not ops.gemv_step_end(g((2, K), 1).cuda(), tuple(wl), nwl, 1e-5, torch.empty((2, V), dtype=BF16).cuda(), nx_b, to_b, hist_b, st_b, pb, tk_b, amax_ws)
+
+
+def test_gemv_q4_step_folds_are_the_separate_launches(ops, K=3072):
+    """p3v_gemv_q4_step (round 6): the replayed step's two ends inside the MLX 4-bit projections next to them, against p3v_step_begin +
+    p3v_gemv_q4 and p3v_gemv_q4 + p3v_step_end: outputs, residual row, rotation rows, tokens, history and counters BIT-IDENTICAL."""
+    from phi_3_vision_mlx_amd.weights import mlx_quantize, q4_repack
+    V, T, half, steps, B = 32064, 40, 48, 3, 1
+    table = g((V, K), 270).cuda()
+    cos, sin = torch.rand((B, T, half), dtype=F32).cuda(), torch.rand((B, T, half), dtype=F32).cuda()
+    w1 = tuple(t.cuda() for t in q4_repack(*mlx_quantize(g((1024, K), 271, 0.03))))
+    nw1 = (1 + 0.1 * g((K,), 272)).cuda()
+    tok = torch.tensor([1234], dtype=torch.int32).cuda()
+    d_past = torch.tensor([11], dtype=torch.int32).cuda()
+    x_a, x_b = torch.empty((B, K), dtype=BF16).cuda(), torch.full((B, K), 7.0, dtype=BF16).cuda()
+    ca, sa = torch.empty((B, 1, half), dtype=F32).cuda(), torch.empty((B, 1, half), dtype=F32).cuda()
+    cb, sb = torch.zeros_like(ca), torch.zeros_like(sa)
+    ops.step_begin(tok, table, x_a, cos, sin, d_past, ca, sa)
+    out_a = ops.gemv_q4(x_a, w1[0], w1[1], norm_w=nw1, norm_eps=1e-5)
+    out_b = torch.full((B, 1024), float("nan"), dtype=BF16).cuda()
+    assert ops.gemv_step_begin(tok, table, x_b, cos, sin, d_past, cb, sb, w1, nw1, 1e-5, out_b)
+    assert torch.equal(out_a.view(torch.int16), out_b.view(torch.int16)) and torch.equal(x_a, x_b)
+    assert torch.equal(ca, cb) and torch.equal(sa, sb)
+    wl = tuple(t.cuda() for t in q4_repack(*mlx_quantize(g((V, K), 273, 0.03))))
+    nwl = (1 + 0.1 * g((K,), 274)).cuda()
+    amax_ws = torch.zeros((ops.L.GEMV_STEP_WS_BYTES // 4,), dtype=F32).cuda()      # (candidate records + arrival counters: zero once)
+    hist_a, hist_b = torch.zeros((B, steps), dtype=torch.int32).cuda(), torch.zeros((B, steps), dtype=torch.int32).cuda()
+    st_a, st_b = torch.zeros(1, dtype=torch.int32).cuda(), torch.zeros(1, dtype=torch.int32).cuda()
+    pa, pb = d_past.clone(), d_past.clone()
+    tk_a, tk_b = torch.zeros(1, dtype=torch.int32).cuda(), torch.zeros(1, dtype=torch.int32).cuda()
+    nx_a, nx_b, to_a, to_b = (torch.zeros(B, dtype=torch.int32).cuda() for _ in range(4))
+    for s in range(steps):
+        x = g((B, K), 290 + s).cuda()
+        lg_a = ops.gemv_q4(x, wl[0], wl[1], norm_w=nwl, norm_eps=1e-5)
+        ops.step_end(lg_a, nx_a, to_a, hist_a, st_a, pa, tk_a)
+        lg_b = torch.empty((B, V), dtype=BF16).cuda()
+        assert ops.gemv_step_end(x, wl, nwl, 1e-5, lg_b, nx_b, to_b, hist_b, st_b, pb, tk_b, amax_ws)
+        assert torch.equal(lg_a.view(torch.int16), lg_b.view(torch.int16))
+        assert torch.equal(nx_a, nx_b) and torch.equal(to_a, to_b) and st_b.item() == s + 1 and pb.item() == 12 + s and tk_b.item() == 0
+    assert torch.equal(hist_a, hist_b)

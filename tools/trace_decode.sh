@@ -17,9 +17,9 @@ rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 # kernels are no marker for where it ends)
 import re
 # the step's two ends: the launches p3v_step_begin / p3v_step_end, or -- round 6, B = 1 on bf16 weights -- the first / last projection
-# that carries them (k_gemv3_step<.., 1> / <.., 2>)
-def is_begin(n): return "k_step_begin" in n or re.search(r"k_gemv3_step<[^>]*, 1>", n) is not None
-def is_end(n): return "k_step_end" in n or "k_store_token" in n or re.search(r"k_gemv3_step<[^>]*, 2>", n) is not None
+# that carries them (k_gemv3_step<.., 1> / <.., 2>, and their _f8 / _q4 twins)
+def is_begin(n): return "k_step_begin" in n or re.search(r"k_gemv3(_f8|_q4)?_step<[^>]*, 1>", n) is not None
+def is_end(n): return "k_step_end" in n or "k_store_token" in n or re.search(r"k_gemv3(_f8|_q4)?_step<[^>]*, 2>", n) is not None
 first_step = min(i for i, r in enumerate(rows) if is_begin(r["Kernel_Name"]))
 dec = rows[first_step:]
 # drop the first step(s): eager warm-up + first replay
