@@ -263,7 +263,9 @@ typedef struct {
   const uint32_t* o_proj_sb;
 } p3v_attn_decode_args_t;
 int p3v_attention_decode(const p3v_attn_decode_args_t* args /* host */, void* stream);
-/* 1 when the fused attention + o_proj launch takes this shape on this device (host query, no launch) */
+/* Does p3v_attention_decode take `o_proj_w` for this shape on this device (host query, no launch)?  0 = no; 1 = attention + o_proj +
+ * residual in ONE launch (merge_in_launch = 1, the 128-key one-tile plan); 2 (round 6) = merge_in_launch = 0: the launch that merges
+ * the split-KV partials also carries the o_proj + residual (long contexts, 64-key plans) -- same arguments, same bits. */
 int p3v_attention_decode_can_fuse_oproj(int B, int L, int n_heads, int hd, int n_split, int cache_t, int o_n, int merge_in_launch);
 /* Which role workgroup `wg` of the fused launch's 1-D grid (n_heads * n_split workgroups) plays under placement `map` (the
  * attn_fo_map tuning knob: 2 = default, 1 = the round's first form): out[0] = key split, out[1] = head, out[2] / out[3] = its

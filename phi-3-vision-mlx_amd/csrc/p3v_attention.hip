@@ -2546,11 +2546,13 @@ __global__ void __launch_bounds__(64) k_attn_decode_stream(AttnDecP p) {
 // merge split-KV partials: one block of G = 4 or 8 64-lane groups per (b, head, query): thread (grp, d) loads
 // (m, l, o[d]) of its share of the splits (batches of 4 independent loads), reduces them against its own
 // running max, and the groups are merged through LDS.
-__global__ void __launch_bounds__(64 * CMB_G) k_attn_combine2(const float* __restrict__ ws, bf16_t* __restrict__ out, int L,
-                                                              int nh, int hd, int n_split) {
+// (the body is shared with k_attn_combine_o below: WT = the row goes out as 48 packed words with write-through stores, for
+//  consumers polling them in the same launch; the value of every element is computed by the same expression either way)
+template <bool WT>
+__device__ __forceinline__ void combine_rows(const float* __restrict__ ws, bf16_t* __restrict__ out, int L, int nh, int hd, int n_split, int block) {
   __shared__ float pm[CMB_G], pl[CMB_G];
   __shared__ float part[CMB_G][128];
-  const int qi = blockIdx.x % L, head = (blockIdx.x / L) % nh, b = blockIdx.x / (L * nh);
+  const int qi = block % L, head = (block / L) % nh, b = block / (L * nh);
   const float* base = ws + (((size_t)b * nh + head) * n_split * 16 + qi) * (hd + 2);
   const size_t sstr = (size_t)16 * (hd + 2);
   const int t = threadIdx.x, grp = t >> 6, d0 = t & 63;       // G groups x 64 lanes; lane handles d0 and d0+64
@@ -2583,7 +2585,7 @@ __global__ void __launch_bounds__(64 * CMB_G) k_attn_combine2(const float* __res
   part[grp][d0] = a0;
   if (two) part[grp][d0 + 64] = a1;
   __syncthreads();
-  if (t < hd) {
+  auto elem = [&](int e) {
     float M = pm[0];
     for (int k = 1; k < G; ++k) M = fmaxf(M, pm[k]);
     const float Mu = M == -INFINITY ? 0.f : M;
@@ -2591,11 +2593,64 @@ __global__ void __launch_bounds__(64 * CMB_G) k_attn_combine2(const float* __res
 #pragma unroll 4
     for (int k = 0; k < G; ++k) {
       const float c = __builtin_amdgcn_exp2f(pm[k] - Mu);
-      acc += c * part[k][t];
+      acc += c * part[k][e];
       lsum += c * pl[k];
     }
-    out[((size_t)b * L + qi) * (size_t)(nh * hd) + head * hd + t] = f32_to_bf16(lsum > 0.f ? acc / lsum : 0.f);
+    return lsum > 0.f ? acc / lsum : 0.f;
+  };
+  bf16_t* row = out + ((size_t)b * L + qi) * (size_t)(nh * hd) + head * hd;
+  if (WT) {
+    if (t < hd / 2) __hip_atomic_store((uint32_t*)row + t, pack_bf16x2(elem(2 * t), elem(2 * t + 1)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  } else if (t < hd) {
+    row[t] = f32_to_bf16(elem(t));
   }
+}
+
+__global__ void __launch_bounds__(64 * CMB_G) k_attn_combine2(const float* __restrict__ ws, bf16_t* __restrict__ out, int L,
+                                                              int nh, int hd, int n_split) {
+  combine_rows<false>(ws, out, L, nh, hd, n_split, (int)blockIdx.x);
+}
+
+// Round 6, long contexts (the split-KV plans whose partials are merged by a launch of their own: more than 48 tiles of 128 keys, i.e.
+// every context beyond ~6k tokens up to the model's 128k): the merge launch also carries the layer's o_proj + residual (B = L = 1),
+// as k_attn_decode128_o does for the one-tile plans.  Workgroups 0 .. nh - 1 merge one head each (k_attn_combine2's arithmetic, the row
+// published as 48 write-through words); the others are fo_project units (two row-pair quartets each): their W_o rows are requested at
+// once and the dot products start when the 32 rows have been seen.  224 workgroups: every one resident (one per CU).
+// 32k keys: combine 4.9 us + o_proj 5.0 us -> one launch.
+template <int KIND>
+__global__ void __launch_bounds__(512) k_attn_combine_o(const float* __restrict__ ws, bf16_t* __restrict__ out, bf16_t* __restrict__ o_rearm,
+                                                        const void* o_w, const void* o_sb, bf16_t* o_x, int nh, int n_split, int n_units) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[7 * 1024 + 768];
+  if ((int)blockIdx.x < nh) {
+    if (blockIdx.x == 0) {                                     // re-arm the other layer parity's buffer (nobody reads it in this launch)
+      uint32_t* ra = (uint32_t*)o_rearm;
+      for (int i = threadIdx.x; i < nh * 96 / 2; i += blockDim.x) ra[i] = 0xffffffffu;
+    }
+    combine_rows<true>(ws, out, 1, nh, 96, n_split, (int)blockIdx.x);
+    return;
+  }
+  if (threadIdx.x >= 256) return;                              // (the merging workgroups use all 64 x G threads, a unit four waves)
+  const int n_uw = (int)gridDim.x - nh, u = (int)blockIdx.x - nh;
+  fo_project<KIND, 2>(FoP{o_w, o_sb, o_x, out, nh}, u, lds, u + n_uw < n_units ? u + n_uw : -1);
+}
+
+// B = L = 1, 32 x 96: one workgroup per head + one per two row-pair quartets, all resident at once (one per CU, 8 CUs of head-room)
+static bool combine_o_ok(int B, int L, int n_heads, int hd, int n_split, int o_n) {
+  if (B != 1 || L != 1 || hd != 96 || n_heads * hd != 3072 || o_n <= 0 || o_n % 8) return false;
+  if (n_split < 1 || n_split > 128 || combine_threads(n_split) > 512) return false;
+  int dev = 0;
+  hipDeviceProp_t pr;
+  if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess) return false;
+  return n_heads + (o_n / 8 + 1) / 2 <= pr.multiProcessorCount - 8;
+}
+template <int KIND>
+static int launch_combine_o(const float* ws, void* out, void* o_rearm, const void* o_w, const void* o_sb, void* o_x, int n_heads, int n_split,
+                            int o_n, hipStream_t s) {
+  const int n_units = o_n / 8, grid_o = n_heads + (n_units + 1) / 2;
+  hipLaunchKernelGGL(k_attn_combine_o<KIND>, dim3(grid_o), dim3(combine_threads(n_split)), 0, s, ws, (bf16_t*)out, (bf16_t*)o_rearm, o_w, o_sb,
+                     (bf16_t*)o_x, n_heads, n_split, n_units);
+  P3V_CHECK_LAUNCH();
+  return P3V_OK;
 }
 
 // cos/sin rows of the L positions [past, past+L) of every batch row -> compact [B, L, half] buffers, so that
@@ -2629,7 +2684,9 @@ extern "C" int p3v_debug_read(unsigned long long* out) {
 // in-launch merge, enough non-merging workgroups for the o_n / 8 row-pair quartets, and EVERY workgroup of the launch resident at
 // once (3 per CU) -- the polling workgroups then cannot keep a producer from being scheduled.
 extern "C" int p3v_attention_decode_can_fuse_oproj(int B, int L, int n_heads, int hd, int n_split, int cache_t, int o_n, int merge_in_launch) {
-  if (B != 1 || L != 1 || hd != 96 || n_heads * hd != 3072 || o_n <= 0 || o_n % 8 || !merge_in_launch) return 0;
+  if (B != 1 || L != 1 || hd != 96 || n_heads * hd != 3072 || o_n <= 0 || o_n % 8) return 0;
+  if (!merge_in_launch)      // the partials are merged by a launch of their own: that launch takes the o_proj (k_attn_combine_o) -- answer 2
+    return combine_o_ok(B, L, n_heads, hd, n_split, o_n) ? 2 : 0;
   if (!(n_split * 128 >= cache_t && cache_t % 128 == 0 && n_split * 64 < cache_t) || n_split < 2) return 0;
   if ((long)(n_split - 1) * n_heads * 8 < o_n) return 0;
   // every workgroup of the launch must be resident at once (the projecting ones wait for the merging ones): ask the runtime how
@@ -2675,9 +2732,11 @@ extern "C" int p3v_attention_decode(const p3v_attn_decode_args_t* a, void* strea
                 a->o_proj_w, a->o_proj_sb, (bf16_t*)a->o_proj_x, (bf16_t*)a->o_rearm, a->o_n, 0};
   hipStream_t s = (hipStream_t)stream;
   dim3 grid(a->n_split, a->n_heads, a->B);
-  if (a->o_proj_w) {                                           // attention + o_proj + residual in one launch
-    if (!p3v_attention_decode_can_fuse_oproj(a->B, a->L, a->n_heads, a->hd, a->n_split, a->cache_t, a->o_n, a->merge_in_launch)) return P3V_ERR_UNSUPPORTED;
-    if (!a->o_proj_x || !a->o_rearm || ((uintptr_t)a->o_proj_w | (uintptr_t)a->o_proj_x | (uintptr_t)a->o_rearm) & 15) return P3V_ERR_ARG;
+  const int fuse_form = a->o_proj_w ? p3v_attention_decode_can_fuse_oproj(a->B, a->L, a->n_heads, a->hd, a->n_split, a->cache_t, a->o_n, a->merge_in_launch) : 0;
+  if (a->o_proj_w && !fuse_form) return P3V_ERR_UNSUPPORTED;
+  if (a->o_proj_w && (!a->o_proj_x || !a->o_rearm || ((uintptr_t)a->o_proj_w | (uintptr_t)a->o_proj_x | (uintptr_t)a->o_rearm) & 15)) return P3V_ERR_ARG;
+  if (a->o_proj_w && a->o_proj_sb && ((uintptr_t)a->o_proj_sb & 3)) return P3V_ERR_ARG;
+  if (fuse_form == 1) {                                        // attention + o_proj + residual in one launch
     if (p3v_tuning().attn_fo_map && fo_map_ok(a->n_split, a->n_heads, a->o_n)) {
       p.fo_remap = p3v_tuning().attn_fo_map;                    // 1: second units on the second-to-last workgroups, 2: on the last ones
       grid = dim3(a->n_split * a->n_heads, 1, 1);
@@ -2696,6 +2755,9 @@ extern "C" int p3v_attention_decode(const p3v_attn_decode_args_t* a, void* strea
   else hipLaunchKernelGGL(k_attn_decode_stream<64>, grid, dim3(64), 0, s, p);
   P3V_CHECK_LAUNCH();
   if (a->merge_in_launch) return P3V_OK;                       // the last workgroup of every (b, head) merged in-kernel
+  if (fuse_form == 2)                                          // the merge launch carries the o_proj + residual
+    return a->o_proj_sb ? launch_combine_o<FO_Q4>(a->ws, a->out, a->o_rearm, a->o_proj_w, a->o_proj_sb, a->o_proj_x, a->n_heads, a->n_split, a->o_n, s)
+                        : launch_combine_o<FO_BF16>(a->ws, a->out, a->o_rearm, a->o_proj_w, nullptr, a->o_proj_x, a->n_heads, a->n_split, a->o_n, s);
   hipLaunchKernelGGL(k_attn_combine2, dim3(a->B * a->n_heads * a->L), dim3(combine_threads(a->n_split)), 0, s, a->ws, a->out, a->L, a->n_heads,
                      a->hd, a->n_split);
   P3V_CHECK_LAUNCH();
@@ -3633,7 +3695,8 @@ __global__ void __launch_bounds__(256) k_attn_decode128_q8(AttnDecQ8P p) {
 }
 
 extern "C" int p3v_attention_decode_q8_can_fuse_oproj(int B, int L, int n_heads, int hd, int n_split, int cache_t, int o_n, int merge_in_launch) {
-  if (B != 1 || L != 1 || hd != 96 || n_heads * hd != 3072 || o_n <= 0 || o_n % 8 || !merge_in_launch) return 0;
+  if (!merge_in_launch) return combine_o_ok(B, L, n_heads, hd, n_split, o_n) ? 2 : 0;      // the merge launch carries the e4m3 o_proj (k_attn_combine_o)
+  if (B != 1 || L != 1 || hd != 96 || n_heads * hd != 3072 || o_n <= 0 || o_n % 8) return 0;
   if (!(n_split * 128 >= cache_t && cache_t % 128 == 0 && n_split * 64 < cache_t) || n_split < 2) return 0;
   if ((long)(n_split - 1) * n_heads * 8 < o_n || p3v_tuning().q8_old) return 0;
   static long capacity_of[P3V_MAX_DEVICES] = {0};              // every workgroup resident at once: see p3v_attention_decode_can_fuse_oproj
@@ -3664,13 +3727,31 @@ extern "C" int p3v_attention_decode_q8(const p3v_attn_decode_q8_args_t* a, void*
   hipStream_t s = (hipStream_t)stream;
   const dim3 grid(a->n_split, a->n_heads, a->B);
   const bool old_only = p3v_tuning().q8_old != 0;   // A/B knob
+  // the o_proj rides either in the one-tile attention launch (in-launch merge) or in the merge launch (k_attn_combine_o, round 6)
+  const bool merge_o = a->o_proj_w8 && !a->merge_in_launch;
+  if (merge_o) {
+    if (!combine_o_ok(a->B, a->L, a->n_heads, a->hd, a->n_split, a->o_n)) return P3V_ERR_UNSUPPORTED;
+    if (!a->o_proj_scale || !a->o_proj_x || !a->o_rearm || ((uintptr_t)a->o_proj_w8 | (uintptr_t)a->o_proj_x | (uintptr_t)a->o_rearm) & 15)
+      return P3V_ERR_ARG;
+  }
+  auto merge = [&]() -> int {                                    // the launch that merges the partials
+    if (merge_o)
+      return launch_combine_o<FO_F8>(a->ws, a->out, a->o_rearm, a->o_proj_w8, a->o_proj_scale, a->o_proj_x, a->n_heads, a->n_split, a->o_n, s);
+    hipLaunchKernelGGL(k_attn_combine2, dim3(a->B * a->n_heads * a->L), dim3(combine_threads(a->n_split)), 0, s, a->ws, a->out, a->L, a->n_heads,
+                       a->hd, a->n_split);
+    P3V_CHECK_LAUNCH();
+    return P3V_OK;
+  };
+  if (a->o_proj_w8 && a->merge_in_launch &&
+      !(!old_only && a->cache_t % 128 == 0 && a->n_split * 128 >= a->cache_t && a->n_split * 64 < a->cache_t))
+    return P3V_ERR_UNSUPPORTED;                                 // (the in-launch form exists for the 128-key plan only)
   // one tile per workgroup and at most 16 of them (contexts up to 1k): the 4-wave kernel, which with `merge_in_launch` also
   // merges the splits inside the launch.  Beyond that the single-wave kernel + merge launch is as fast or faster
   // (measured at 42 tiles, config 5 decode: 1.543 ms/step against 1.560 with the 4-wave kernel + fused merge: its
   // bytes go through registers and a ds_write pass into the fp16 images, where the bf16 kernel uses LDS-DMA).
   if (!old_only && a->cache_t % 128 == 0 && a->n_split * 128 >= a->cache_t && a->n_split * 64 < a->cache_t) {   // 128-key tiles
     p.merge = a->merge_in_launch;
-    if (a->o_proj_w8) {                                        // attention + o_proj (e4m3) + residual in one launch
+    if (a->o_proj_w8 && a->merge_in_launch) {                  // attention + o_proj (e4m3) + residual in one launch
       if (!p3v_attention_decode_q8_can_fuse_oproj(a->B, a->L, a->n_heads, a->hd, a->n_split, a->cache_t, a->o_n, a->merge_in_launch))
         return P3V_ERR_UNSUPPORTED;
       if (!a->o_proj_scale || !a->o_proj_x || !a->o_rearm || ((uintptr_t)a->o_proj_w8 | (uintptr_t)a->o_proj_x | (uintptr_t)a->o_rearm) & 15)
@@ -3691,10 +3772,7 @@ extern "C" int p3v_attention_decode_q8(const p3v_attn_decode_q8_args_t* a, void*
     hipLaunchKernelGGL(k_attn_decode128_q8<false>, grid, dim3(256), 0, s, p);
     P3V_CHECK_LAUNCH();
     if (a->merge_in_launch) return P3V_OK;
-    hipLaunchKernelGGL(k_attn_combine2, dim3(a->B * a->n_heads * a->L), dim3(combine_threads(a->n_split)), 0, s, a->ws, a->out, a->L, a->n_heads,
-                       a->hd, a->n_split);
-    P3V_CHECK_LAUNCH();
-    return P3V_OK;
+    return merge();
   }
   const bool single_tile = !old_only && a->n_split * 64 >= a->cache_t && a->n_split <= 16;
   if (single_tile && a->merge_in_launch) {
@@ -3706,8 +3784,5 @@ extern "C" int p3v_attention_decode_q8(const p3v_attn_decode_q8_args_t* a, void*
   if (single_tile) hipLaunchKernelGGL(k_attn_decode_q8s, grid, dim3(256), 0, s, p);
   else hipLaunchKernelGGL(k_attn_decode_q8, grid, dim3(64), 0, s, p);
   P3V_CHECK_LAUNCH();
-  hipLaunchKernelGGL(k_attn_combine2, dim3(a->B * a->n_heads * a->L), dim3(combine_threads(a->n_split)), 0, s, a->ws, a->out, a->L, a->n_heads,
-                     a->hd, a->n_split);
-  P3V_CHECK_LAUNCH();
-  return P3V_OK;
+  return merge();
 }

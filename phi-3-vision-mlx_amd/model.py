@@ -517,7 +517,8 @@ class Phi3VModel:
     def _plan_fused_oproj(self, bufs, B, L, T, quantized=False):
         """B = L = 1 decode: attention + o_proj + residual as ONE launch per layer where the library takes the shape -- on bf16 or
         MLX 4-bit weights and a bf16 cache (k_attn_decode128_o / _o4), or on e4m3 weights and the int8 cache (config 5:
-        k_attn_decode128_q8<true>); p3v_attention.hip.  The attention output then lives in two buffers that alternate layers use, both all-ones (= "not written
+        k_attn_decode128_q8<true>); p3v_attention.hip.  Long contexts (round 6), whose partials are merged by a launch of their own:
+        that launch carries the o_proj (k_attn_combine_o).  The attention output then lives in two buffers that alternate layers use, both all-ones (= "not written
         yet") between launches; P3V_ATTN_FUSE_OPROJ=0 switches it off."""
         cfg = self.cfg
         can = ops.attention_decode_q8_can_fuse_oproj if quantized else ops.attention_decode_can_fuse_oproj
@@ -528,10 +529,20 @@ class Phi3VModel:
         # P3V_PROFILING=1: no launch of the step may wait for another workgroup of its own grid (whole-graph rocprofv3 --pmc passes
         # serialise / mask what they profile): separate o_proj launch here, separate merge launch in _split_plan
         ok = (os.environ.get("P3V_ATTN_FUSE_OPROJ", "1") != "0" and os.environ.get("P3V_PROFILING") != "1"
-              and B == 1 and L == 1 and bufs.get("attn_merge", False)
+              and B == 1 and L == 1
               and cfg.num_hidden_layers % 2 == 0 and not self.serving
               and not self.adapters and (o_key in self.w8) == bool(quantized) and not (quantized and o_key in self.w4)
-              and can(B, L, cfg.num_attention_heads, self.hd, bufs["n_split"], T, cfg.hidden_size, True))
+              # (without the in-launch merge -- long contexts: the MERGE launch carries the o_proj, k_attn_combine_o, round 6)
+              and can(B, L, cfg.num_attention_heads, self.hd, bufs["n_split"], T, cfg.hidden_size, bool(bufs.get("attn_merge", False))))
+        if not ok and bufs.get("attn_merge", False) and B == 1 and L == 1 and not quantized:
+            # Short contexts (64-key one-tile plans: the in-launch form above is for 128-key tiles): attention that only writes its partials
+            # + the merge launch carrying the o_proj beats attention with the in-launch merge + an o_proj launch (1.587 -> 1.570 ms per
+            # step at 128 keys, 1.662 -> 1.652 at 1000; with the int8 cache it loses: 1.165 -> 1.179 at 128 keys, so not there)
+            bufs["attn_merge"] = False
+            self._plan_fused_oproj(bufs, B, L, T, quantized)
+            if not bufs["fuse_o"]:
+                bufs["attn_merge"] = True
+            return
         bufs["fuse_o"] = bool(ok)
         if ok:
             for k in ("o_f", "o_f2"):                            # all-ones = "not written yet"
@@ -677,7 +688,8 @@ class Phi3VModel:
                     kw_o = dict(o_proj_w=q4o[0], o_proj_sb=q4o[1]) if q4o is not None else dict(o_proj_w=w[p + "self_attn.o_proj.weight"])
                     ops.attention_decode(qkv, rc, rs, rb, st.k[i], st.v[i], o_i, B, L, nh, nkv, hd, scale,
                                          past if d_past is None else bufs.get("past_lb", -1), st.Tp, ws, n_split,
-                                         pad_len=st.pad_len, d_past=d_past, merge_in_launch=True, o_proj_x=x, o_rearm=o_other, **kw_o)
+                                         pad_len=st.pad_len, d_past=d_past, merge_in_launch=bufs.get("attn_merge", False), o_proj_x=x,
+                                         o_rearm=o_other, **kw_o)
                 else:
                     ops.attention_decode(qkv, rc, rs, rb, st.k[i], st.v[i], o, B, L, nh, nkv, hd, scale,
                                          past if d_past is None else bufs.get("past_lb", -1), st.Tp, ws, n_split,

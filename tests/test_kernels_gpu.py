@@ -737,7 +737,7 @@ def test_attention_decode_with_fused_oproj_is_bit_identical_to_two_launches(ops,
     T, n_split = cap, cap // 128
     assert ops.attention_decode_can_fuse_oproj(B, L, nh, hd, n_split, T, H, True)
     assert not ops.attention_decode_can_fuse_oproj(2, L, nh, hd, n_split, T, H, True)        # B = 1 only
-    assert not ops.attention_decode_can_fuse_oproj(B, L, nh, hd, n_split, T, H, False)       # needs the in-launch merge
+    assert ops.attention_decode_can_fuse_oproj(B, L, nh, hd, n_split, T, H, False)           # (round 6: then the merge launch carries the o_proj)
     qkv = g((1, 3 * nh * hd), 145).cuda()
     kc0, vc0 = g((B, nh, T, hd), 146).cuda(), g((B, nh, hd, T), 147).cuda()
     wo = (g((H, nh * hd), 148) * 0.05).cuda()
@@ -761,6 +761,51 @@ def test_attention_decode_with_fused_oproj_is_bit_identical_to_two_launches(ops,
                              o_proj_w=wo, o_proj_x=x2, o_rearm=other)
         assert torch.equal(o2.view(torch.int16), o1.view(torch.int16)), f"rep {rep}: attention output differs"
         assert torch.equal(x2.view(torch.int16), x1.view(torch.int16)), f"rep {rep}: residual row differs from attention + gemv"
+        assert torch.equal(k2, k1) and torch.equal(v2, v1)
+        assert (other.view(torch.int16) == -1).all() and (ws.view(torch.int32) == -1).all()
+    assert not torch.isnan(x1.float()).any() and (x1.float() - x0.float()).abs().max().item() > 0.01
+
+
+@pytest.mark.parametrize("q4", [False, True], ids=["bf16", "q4"])
+@pytest.mark.parametrize("past,cap,n_split,dev_past", [(7000, 7168, 112, False), (9000, 9216, 24, True), (300, 384, 3, False), (33000, 33280, 24, True)])
+def test_merge_launch_with_fused_oproj_is_bit_identical_to_three_launches(ops, past, cap, n_split, dev_past, q4):
+    """k_attn_combine_o (round 6): plans whose split-KV partials are merged by a launch of their own (long contexts; 64-key tiles or
+    the multi-tile streaming kernel) -- the merge launch also carries o_proj + residual (B = L = 1).  Against attention + merge + GEMV:
+    attention output, residual row and caches BIT-IDENTICAL, ten launches alike, the other output buffer re-armed, the workspace
+    left all-ones."""
+    from phi_3_vision_mlx_amd.weights import mlx_quantize, q4_repack
+    B, L, nh, hd, H = 1, 1, 32, 96, 3072
+    T = cap
+    assert ops.attention_decode_can_fuse_oproj(B, L, nh, hd, n_split, T, H, False)
+    qkv = g((1, 3 * nh * hd), 245).cuda()
+    kc0, vc0 = g((B, nh, T, hd), 246).cuda(), g((B, nh, hd, T), 247).cuda()
+    wo = (g((H, nh * hd), 248) * 0.05)
+    if q4:
+        w4, sb = (t.cuda() for t in q4_repack(*mlx_quantize(wo)))
+        kw_o = dict(o_proj_w=w4, o_proj_sb=sb)
+    else:
+        wo = wo.cuda()
+        kw_o = dict(o_proj_w=wo)
+    x0 = g((1, H), 249).cuda()
+    gen = torch.Generator(device="cuda").manual_seed(250)
+    cos, sin = torch.rand((B, 1, hd // 2), device="cuda", generator=gen), torch.rand((B, 1, hd // 2), device="cuda", generator=gen)
+    d_past = torch.tensor([past], dtype=torch.int32).cuda()
+    ws = ops.attention_ws(B, L, nh, hd, n_split, "cuda")
+    kw = dict(d_past=d_past if dev_past else None, merge_in_launch=False)
+    hp = past - 40 if dev_past else past
+    k1, v1, o1, x1 = kc0.clone(), vc0.clone(), torch.empty((1, 1, H), dtype=BF16, device="cuda"), x0.clone()
+    ops.attention_decode(qkv, cos, sin, 1, k1, v1, o1, B, L, nh, nh, hd, hd ** -0.5, hp, T, ws, n_split, **kw)
+    if q4:
+        ops.gemv_q4(o1.view(1, H), w4, sb, ops.EPI_RESID_BF16, resid=x1, out=x1)
+    else:
+        ops.gemv(o1.view(1, H), wo, ops.EPI_RESID_BF16, resid=x1, out=x1)
+    for rep in range(10):
+        k2, v2, x2 = kc0.clone(), vc0.clone(), x0.clone()
+        o2 = torch.full((1, 1, H), -1, dtype=torch.int16, device="cuda").view(BF16)
+        other = torch.zeros((1, 1, H), dtype=BF16, device="cuda")
+        ops.attention_decode(qkv, cos, sin, 1, k2, v2, o2, B, L, nh, nh, hd, hd ** -0.5, hp, T, ws, n_split, **kw, o_proj_x=x2, o_rearm=other, **kw_o)
+        assert torch.equal(o2.view(torch.int16), o1.view(torch.int16)), f"rep {rep}: attention output differs"
+        assert torch.equal(x2.view(torch.int16), x1.view(torch.int16)), f"rep {rep}: residual row differs from attention + merge + gemv"
         assert torch.equal(k2, k1) and torch.equal(v2, v1)
         assert (other.view(torch.int16) == -1).all() and (ws.view(torch.int32) == -1).all()
     assert not torch.isnan(x1.float()).any() and (x1.float() - x0.float()).abs().max().item() > 0.01
@@ -1076,6 +1121,48 @@ def test_q8_attention_decode_with_fused_fp8_oproj_is_bit_identical_to_two_launch
                                 o_proj_w8=w8, o_proj_scale=wsc, o_proj_x=x2, o_rearm=other)
         assert torch.equal(o2.view(torch.int16), o1.view(torch.int16)), f"rep {rep}: attention output differs"
         assert torch.equal(x2.view(torch.int16), x1.view(torch.int16)), f"rep {rep}: residual row differs from attention + gemv_fp8"
+        assert torch.equal(k2, k1) and torch.equal(v2, v1) and torch.equal(ks2, ks1) and torch.equal(vs2, vs1)
+        assert (other.view(torch.int16) == -1).all() and (ws.view(torch.int32) == -1).all()
+    assert not torch.isnan(x1.float()).any() and (x1.float() - x0.float()).abs().max().item() > 0.01
+
+
+@pytest.mark.parametrize("past,cap,n_split,dev_past", [(7000, 7168, 56, False), (9000, 9216, 40, True), (600, 640, 5, False), (600, 640, 10, True)])
+def test_q8_merge_launch_with_fused_fp8_oproj_is_bit_identical_to_three_launches(ops, past, cap, n_split, dev_past):
+    """k_attn_combine_o<e4m3> (round 6, config 5 at long contexts): the int8-KV plans whose partials are merged by a launch of their own
+    (128-key tiles without the in-launch merge, the multi-tile single-wave kernel, the 64-key one-tile kernel) -- the merge launch also
+    carries the e4m3 o_proj + residual.  Against attention + merge + p3v_gemv_fp8: everything BIT-IDENTICAL, ten launches alike."""
+    B, L, nh, hd, H = 1, 1, 32, 96, 3072
+    T = cap
+    assert ops.attention_decode_q8_can_fuse_oproj(B, L, nh, hd, n_split, T, H, False)
+    assert not ops.attention_decode_q8_can_fuse_oproj(2, L, nh, hd, n_split, T, H, False)
+    qkv = g((1, 3 * nh * hd), 355).cuda()
+    k, v = g((B, nh, T, hd), 356).cuda(), g((B, nh, hd, T), 357).cuda()
+    k8_0 = torch.full((B, nh, T, hd), 128, dtype=torch.uint8).cuda()
+    v8_0 = torch.full((B, nh, hd, T), 128, dtype=torch.uint8).cuda()
+    ks0, vs0 = torch.ones((B, nh, T)).cuda(), torch.ones((B, nh, T)).cuda()
+    ops.kv_quantize(k, v, k8_0, v8_0, ks0, vs0, 0, past)
+    w8, wsc = ops.quantize_fp8_rows((g((H, nh * hd), 358) * 0.05).cuda())
+    x0 = g((1, H), 359).cuda()
+    gen = torch.Generator(device="cuda").manual_seed(360)
+    cos, sin = torch.rand((B, 1, hd // 2), device="cuda", generator=gen), torch.rand((B, 1, hd // 2), device="cuda", generator=gen)
+    d_past = torch.tensor([past], dtype=torch.int32).cuda()
+    ws = ops.attention_ws(B, L, nh, hd, n_split, "cuda")
+    kw = dict(d_past=d_past if dev_past else None, merge_in_launch=False)
+    def fresh():
+        return k8_0.clone(), v8_0.clone(), ks0.clone(), vs0.clone()
+    k1, v1, ks1, vs1 = fresh()
+    o1, x1 = torch.empty((1, 1, H), dtype=BF16, device="cuda"), x0.clone()
+    ops.attention_decode_q8(qkv, cos, sin, 1, k1, v1, ks1, vs1, o1, B, L, nh, nh, hd, hd ** -0.5, past, T, ws, n_split, **kw)
+    ops.gemv_fp8(o1.view(1, H), w8, wsc, ops.EPI_RESID_BF16, resid=x1, out=x1)
+    for rep in range(10):
+        k2, v2, ks2, vs2 = fresh()
+        x2 = x0.clone()
+        o2 = torch.full((1, 1, H), -1, dtype=torch.int16, device="cuda").view(BF16)
+        other = torch.zeros((1, 1, H), dtype=BF16, device="cuda")
+        ops.attention_decode_q8(qkv, cos, sin, 1, k2, v2, ks2, vs2, o2, B, L, nh, nh, hd, hd ** -0.5, past, T, ws, n_split, **kw,
+                                o_proj_w8=w8, o_proj_scale=wsc, o_proj_x=x2, o_rearm=other)
+        assert torch.equal(o2.view(torch.int16), o1.view(torch.int16)), f"rep {rep}: attention output differs"
+        assert torch.equal(x2.view(torch.int16), x1.view(torch.int16)), f"rep {rep}: residual row differs from attention + merge + gemv_fp8"
         assert torch.equal(k2, k1) and torch.equal(v2, v1) and torch.equal(ks2, ks1) and torch.equal(vs2, vs1)
         assert (other.view(torch.int16) == -1).all() and (ws.view(torch.int32) == -1).all()
     assert not torch.isnan(x1.float()).any() and (x1.float() - x0.float()).abs().max().item() > 0.01
