@@ -8,7 +8,7 @@ ctx = int(sys.argv[1]) if len(sys.argv) > 1 else 2531
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 model, _ = load_synthetic(blind_model=True, device="cuda:0", use_quantized_cache=bool(os.environ.get("P3V_QCACHE")), quantized_fp8=bool(os.environ.get("P3V_FP8")), quantized_int4=bool(os.environ.get("P3V_INT4")))
 ids = np.random.default_rng(0).integers(3, 32000, (B, ctx))
-lg, cache = model(input_ids=ids, max_tokens=80)
+lg, cache = model(input_ids=ids, max_tokens=int(sys.argv[3]) if len(sys.argv) > 3 else 80)
 t = ops.argmax(lg[:, -1].contiguous())[:, None]
 for _ in range(8): lg, t = model.greedy_step(t, cache)
 torch.cuda.synchronize(); res = []
