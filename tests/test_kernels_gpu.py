@@ -768,7 +768,7 @@ def test_attention_decode_with_fused_oproj_is_bit_identical_to_two_launches(ops,
 
 @pytest.mark.parametrize("q4", [False, True], ids=["bf16", "q4"])
 @pytest.mark.parametrize("past,cap,n_split,dev_past", [(7000, 7168, 112, False), (9000, 9216, 24, True), (300, 384, 3, False), (33000, 33280, 24, True)])
-def test_merge_launch_with_fused_oproj_is_bit_identical_to_three_launches(ops, past, cap, n_split, dev_past, q4):
+def test_merge_launch_with_fused_oproj_is_bit_identical_to_three_launches(ops, past, cap, n_split, dev_past, q4, nkv=32):
     """k_attn_combine_o (round 6): plans whose split-KV partials are merged by a launch of their own (long contexts; 64-key tiles or
     the multi-tile streaming kernel) -- the merge launch also carries o_proj + residual (B = L = 1).  Against attention + merge + GEMV:
     attention output, residual row and caches BIT-IDENTICAL, ten launches alike, the other output buffer re-armed, the workspace
@@ -777,8 +777,8 @@ def test_merge_launch_with_fused_oproj_is_bit_identical_to_three_launches(ops, p
     B, L, nh, hd, H = 1, 1, 32, 96, 3072
     T = cap
     assert ops.attention_decode_can_fuse_oproj(B, L, nh, hd, n_split, T, H, False)
-    qkv = g((1, 3 * nh * hd), 245).cuda()
-    kc0, vc0 = g((B, nh, T, hd), 246).cuda(), g((B, nh, hd, T), 247).cuda()
+    qkv = g((1, (nh + 2 * nkv) * hd), 245).cuda()
+    kc0, vc0 = g((B, nkv, T, hd), 246).cuda(), g((B, nkv, hd, T), 247).cuda()
     wo = (g((H, nh * hd), 248) * 0.05)
     if q4:
         w4, sb = (t.cuda() for t in q4_repack(*mlx_quantize(wo)))
@@ -794,7 +794,7 @@ def test_merge_launch_with_fused_oproj_is_bit_identical_to_three_launches(ops, p
     kw = dict(d_past=d_past if dev_past else None, merge_in_launch=False)
     hp = past - 40 if dev_past else past
     k1, v1, o1, x1 = kc0.clone(), vc0.clone(), torch.empty((1, 1, H), dtype=BF16, device="cuda"), x0.clone()
-    ops.attention_decode(qkv, cos, sin, 1, k1, v1, o1, B, L, nh, nh, hd, hd ** -0.5, hp, T, ws, n_split, **kw)
+    ops.attention_decode(qkv, cos, sin, 1, k1, v1, o1, B, L, nh, nkv, hd, hd ** -0.5, hp, T, ws, n_split, **kw)
     if q4:
         ops.gemv_q4(o1.view(1, H), w4, sb, ops.EPI_RESID_BF16, resid=x1, out=x1)
     else:
@@ -803,12 +803,18 @@ def test_merge_launch_with_fused_oproj_is_bit_identical_to_three_launches(ops, p
         k2, v2, x2 = kc0.clone(), vc0.clone(), x0.clone()
         o2 = torch.full((1, 1, H), -1, dtype=torch.int16, device="cuda").view(BF16)
         other = torch.zeros((1, 1, H), dtype=BF16, device="cuda")
-        ops.attention_decode(qkv, cos, sin, 1, k2, v2, o2, B, L, nh, nh, hd, hd ** -0.5, hp, T, ws, n_split, **kw, o_proj_x=x2, o_rearm=other, **kw_o)
+        ops.attention_decode(qkv, cos, sin, 1, k2, v2, o2, B, L, nh, nkv, hd, hd ** -0.5, hp, T, ws, n_split, **kw, o_proj_x=x2, o_rearm=other, **kw_o)
         assert torch.equal(o2.view(torch.int16), o1.view(torch.int16)), f"rep {rep}: attention output differs"
         assert torch.equal(x2.view(torch.int16), x1.view(torch.int16)), f"rep {rep}: residual row differs from attention + merge + gemv"
         assert torch.equal(k2, k1) and torch.equal(v2, v1)
         assert (other.view(torch.int16) == -1).all() and (ws.view(torch.int32) == -1).all()
     assert not torch.isnan(x1.float()).any() and (x1.float() - x0.float()).abs().max().item() > 0.01
+
+
+def test_merge_launch_with_fused_oproj_under_grouped_queries(ops):
+    """... and with 8 key / value heads for the 32 query heads (the merge launch itself never sees the grouping)."""
+    test_merge_launch_with_fused_oproj_is_bit_identical_to_three_launches(ops, 7000, 7168, 112, True, False, nkv=8)
+    test_merge_launch_with_fused_oproj_is_bit_identical_to_three_launches(ops, 300, 384, 3, False, True, nkv=8)
 
 
 @pytest.mark.parametrize("B,L,nh,nkv,hd,K,past,rot,bias,big", [
