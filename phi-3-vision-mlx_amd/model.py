@@ -160,6 +160,7 @@ class Phi3VModel:
         self.hidden_hook = None                      # fn(layer, x [B*L, H], B, L) after every decoder layer (diagnostics)
         self.w8 = {}
         self._rope_tables = {}                                   # (B, T, factors, ..) -> (cos, sin): shared read-only (see _new_state)
+        self._vit_graphs, self._vit_seen = {}, {}                # captured vision tower per crop count (clip_forward)
         self.adapters = {}                           # weight key -> (lora_a, lora_b, scale), see set_adapters
         self._lora_tmp = {}                          # decode-sized (M <= 16) adapter scratch: captured graphs point at it
         self._lora_flat = None                       # ONE grow-only scratch for prefill-sized calls (not graph-captured)
@@ -313,30 +314,87 @@ class Phi3VModel:
             bq = torch.cat([self.w[q + f"{n}_proj.bias"] for n in "qkv"], dim=0).contiguous()
             self.clip_qkv.append((wq, bq))
 
+    VIT_GRAPH_ENTRIES = 2
+
+    def _clip_bufs(self, n):
+        """Every intermediate of the tower for n crops (one allocation set per call on the eager path; owned by the graph entry otherwise)."""
+        c, dev = self.cfg.clip, self.device
+        D, P, I_ = c["hidden_size"], c["patch_size"], c["intermediate_size"]
+        G = c["image_size"] // P
+        T, nh = G * G + 1, c["num_attention_heads"]
+        Tp = (T + 63) // 64 * 64
+        return dict(
+            patches=torch.empty((n * G * G, self.kpad), dtype=BF16, device=dev), x=torch.empty((n, T, D), dtype=F32, device=dev),
+            q=torch.empty((n, nh, T, 64), dtype=BF16, device=dev), k=torch.empty((n, nh, Tp, 64), dtype=BF16, device=dev),
+            v=torch.zeros((n, nh, 64, Tp), dtype=BF16, device=dev),              # V^T, zero tail
+            o=torch.empty((n * T, D), dtype=BF16, device=dev), h=torch.empty((n * T, D), dtype=BF16, device=dev),
+            qkv=torch.empty((n * T, 3 * D), dtype=BF16, device=dev), f=torch.empty((n * T, I_), dtype=BF16, device=dev))
+
     @_on_device
     def clip_forward(self, pix):
         """ClipModel.__call__ (phi.py:216-221) on live crops; pix f32 [n,3,336,336] -> f32 [n,577,D]
-        (row 0 = CLS, which the caller skips)."""
+        (row 0 = CLS, which the caller skips).
+        Round 6: the tower's ~280 launches cost the host as long to enqueue (25 - 30 us each in Python + ctypes) as the GPU to run, so a
+        crop count seen for the SECOND time is captured as one hipGraph over buffers the entry owns (as the short-prompt prefill,
+        _prefill_captured) and later images of that geometry cost one copy + one graph launch; the returned features are the
+        entry's buffer -- the caller consumes them on the same stream before the next image can overwrite them.  Same kernels in
+        the same order: bit-identical.  P3V_VIT_GRAPH=0 keeps eager launches."""
+        n = pix.shape[0]
+        w = self.w
+        key = (n, w[V_PREFIX + "embeddings.position_embedding.weight"].data_ptr(), w[V_PREFIX + "encoder.layers.0.mlp.fc1.weight"].data_ptr())
+        if os.environ.get("P3V_VIT_GRAPH", "1") == "0" or self.hidden_hook is not None:
+            return self._clip_body(pix, self._clip_bufs(n))
+        e = self._vit_graphs.get(key)
+        if e is None:
+            if self._vit_seen.get(key, 0) < 1:                    # first sight of this crop count: eager, remember it
+                if len(self._vit_seen) > 64:
+                    self._vit_seen.clear()
+                self._vit_seen[key] = 1
+                return self._clip_body(pix, self._clip_bufs(n))
+            e = self._build_vit_graph(pix)
+            if len(self._vit_graphs) >= self.VIT_GRAPH_ENTRIES:
+                self._vit_graphs.pop(next(iter(self._vit_graphs)))
+            self._vit_graphs[key] = e
+        e["pix"].copy_(pix, non_blocking=True)
+        e["graph"].launch()
+        return e["bufs"]["x"]
+
+    def _build_vit_graph(self, pix):
+        dev = self.device
+        e = dict(pix=torch.empty_like(pix), bufs=self._clip_bufs(pix.shape[0]), ws={})
+        e["pix"].copy_(pix)
+        with ops.owned_gemm_workspace(e["ws"], frozen=False):
+            self._clip_body(e["pix"], e["bufs"])                 # warm-up (sizes whatever workspace the graph owns)
+        torch.cuda.synchronize()
+        graph = ops.Graph()
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side), ops.owned_gemm_workspace(e["ws"], frozen=True):
+            graph.begin()
+            self._clip_body(e["pix"], e["bufs"])
+            graph.end()
+        torch.cuda.current_stream().wait_stream(side)
+        e["graph"] = graph
+        return e
+
+    def _clip_body(self, pix, B_):
         c, w = self.cfg.clip, self.w
         n, D, P = pix.shape[0], c["hidden_size"], c["patch_size"]
         G = c["image_size"] // P
         T, nh, eps = G * G + 1, c["num_attention_heads"], c["layer_norm_eps"]
         e = V_PREFIX + "embeddings."
-        patches = ops.im2col_patches(pix, P, self.kpad)
-        x = torch.empty((n, T, D), dtype=F32, device=self.device)
+        patches = ops.im2col_patches(pix, P, self.kpad, out=B_["patches"])
+        x = B_["x"]
         pos = w[e + "position_embedding.weight"]
         ops.gemm(patches, self.w_patch, EPI_PATCH, out=x, n_out=D, pos=pos, patches_per_img=G * G, ldo=D)
         ops.clip_cls_rows(x, w[e + "class_embedding"], pos)
         x2 = x.view(n * T, D)
         ops.layernorm(x2, w[V_PREFIX + "pre_layrnorm.weight"], w[V_PREFIX + "pre_layrnorm.bias"], 1e-5, out_f32=True, out=x2)
         Tp = (T + 63) // 64 * 64
-        q = torch.empty((n, nh, T, 64), dtype=BF16, device=self.device)
-        k = torch.empty((n, nh, Tp, 64), dtype=BF16, device=self.device)
-        v = torch.zeros((n, nh, 64, Tp), dtype=BF16, device=self.device)                 # V^T, zero tail
-        o = torch.empty((n * T, D), dtype=BF16, device=self.device)
+        q, k, v, o, h, qkv, f = (B_[t] for t in ("q", "k", "v", "o", "h", "qkv", "f"))
         for j in range(c["num_hidden_layers"] - 1):
             lp = V_PREFIX + f"encoder.layers.{j}."
-            h = ops.layernorm(x2, w[lp + "layer_norm1.weight"], w[lp + "layer_norm1.bias"], eps)
+            ops.layernorm(x2, w[lp + "layer_norm1.weight"], w[lp + "layer_norm1.bias"], eps, out=h)
             wq, bq = self.clip_qkv[j]
             # head split; the queries leave it multiplied by scale * log2(e) like the decoder's (the attention's softmax is then the
             # bare exp2: k_attn_prefill_dma<64, PRE> 59 -> 49 us per layer at 17 crops, tools/clip_attn_probe.py).  The split stays a
@@ -346,13 +404,13 @@ class Phi3VModel:
             # merge and a separate key count in the attention to follow -- priced at 0.4 ms of a 28 ms prefill, not done.
             pre = os.environ.get("P3V_VIT_PLAIN_Q") != "1"
             qs = 64 ** -0.5 * ops.Q_PRESCALE if pre else 1.0
-            qkv = ops.gemm(h, wq, EPI_BIAS, bias=bq)
+            ops.gemm(h, wq, EPI_BIAS, bias=bq, out=qkv)
             ops.rope_kv_append(qkv, None, None, q, k, v, n, T, nh, nh, 64, 0, Tp, False, q_scale=qs)
             ops.attention(q, o, n, T, nh, nh, 64, 64 ** -0.5, False, k_past=k, v_past=v, past_t=Tp, new_is_cache=True, q_prescaled=pre)
             ops.gemm(o, w[lp + "self_attn.out_proj.weight"], EPI_BIAS_RESID_F32, bias=w[lp + "self_attn.out_proj.bias"],
                      resid=x2, out=x2)
-            h = ops.layernorm(x2, w[lp + "layer_norm2.weight"], w[lp + "layer_norm2.bias"], eps)
-            f = ops.gemm(h, w[lp + "mlp.fc1.weight"], EPI_BIAS_QGELU, bias=w[lp + "mlp.fc1.bias"])
+            ops.layernorm(x2, w[lp + "layer_norm2.weight"], w[lp + "layer_norm2.bias"], eps, out=h)
+            ops.gemm(h, w[lp + "mlp.fc1.weight"], EPI_BIAS_QGELU, bias=w[lp + "mlp.fc1.bias"], out=f)
             ops.gemm(f, w[lp + "mlp.fc2.weight"], EPI_BIAS_RESID_F32, bias=w[lp + "mlp.fc2.bias"], resid=x2, out=x2)
         return x
 

@@ -466,10 +466,11 @@ def attention_ws(B, Lq, nh, hd, n_split, device):
     return torch.full((attention_ws_bytes(B, Lq, nh, hd, n_split) // 4,), -1, dtype=torch.int32, device=device).view(F32)
 
 
-def im2col_patches(pix, patch, kpad):
+def im2col_patches(pix, patch, kpad, out=None):
     _chk(pix, F32, "pix")
     n, _, S, _ = pix.shape
-    out = torch.empty((n * (S // patch) ** 2, kpad), dtype=BF16, device=pix.device)
+    if out is None:
+        out = torch.empty((n * (S // patch) ** 2, kpad), dtype=BF16, device=pix.device)
     L.check(L.lib().p3v_im2col_patches(_p(pix), _p(out), n, S, patch, kpad, _stream()), "im2col")
     return out
 
