@@ -187,7 +187,7 @@ int p3v_gemm_resid_norm(const p3v_gemm_args_t* gemm /* host */, const uint16_t* 
  *      GEMM's launches alone (phi.py:437-452 / 140-147: `qkv_proj` + `split` + `_rotate_half` + KVCache append; CLIP: q/k/v projections
  *      + head split).  g: A [B*L, K], W [(nh + 2 nkv) * hd, K] (q rows, k rows, v rows), epilogue P3V_EPI_NONE or P3V_EPI_BIAS; out /
  *      resid / ws unused.  P3V_ERR_UNSUPPORTED (nothing launched) unless hd % 32 == 0, (hd / 2) % 16 == 0, an 8-aligned append
- *      offset and dst_t, B == 1 or L % 8 == 0, and either M >= 1024 with whole 128-column tiles per region (the 256 x 256 /
+ *      offset and dst_t (round 6: batch rows of any length L -- CLIP's 577-token crops), and either M >= 1024 with whole 128-column tiles per region (the 256 x 256 /
  *      128 x 128-tile kernels) or 9 <= M <= 256 without bias, whole 64-column Q / K tiles and 128-row V tiles (the 128 x 64-tile
  *      weight-streaming kernel) -- callers then run the two calls. */
 typedef struct {

@@ -599,10 +599,10 @@ extern "C" int p3v_gemm_qkv(const p3v_gemm_args_t* a, const p3v_qkv_split_t* sp,
        (uintptr_t)sp->cos_t | (uintptr_t)sp->sin_t) & 15)
     return P3V_ERR_ARG;
   // what the fused epilogue needs (anything else: P3V_ERR_UNSUPPORTED, the caller runs p3v_gemm + p3v_rope_kv_append):
-  // prompt-sized M; rotation pairs in blocks of 16 inside a head; whole 128-column tiles per region; 8-token runs of V^T stores
-  // that neither straddle a batch row nor start off a 16-byte boundary
+  // prompt-sized M; rotation pairs in blocks of 16 inside a head; whole 128-column tiles per region; an 8-aligned append offset
   const int dpos0 = sp->dst_off_is_past ? sp->past : 0;
-  if (hd % 32 || half % 16 || dpos0 % 8 || sp->dst_t % 8 || (sp->B > 1 && sp->L % 8) || p3v_tuning().gemm_no_qkv_fuse) return P3V_ERR_UNSUPPORTED;
+  // (round 6: batch rows of any length -- the V^T runs are then stored at whatever offset they fall on, qkv_epilogue_vt)
+  if (hd % 32 || half % 16 || dpos0 % 8 || sp->dst_t % 8 || p3v_tuning().gemm_no_qkv_fuse) return P3V_ERR_UNSUPPORTED;
   if ((size_t)a->M * a->lda * 2 >= (1ull << 32) || (size_t)a->N * a->ldw * 2 >= (1ull << 32)) return P3V_ERR_UNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
   QkvP q = {sp->cos_t, sp->sin_t, sp->q_out, sp->k_dst, sp->v_dst, sp->L, nh, nkv, hd, sp->past, dpos0, sp->dst_t, sp->tab_t, sp->tab_div, 0,

@@ -8,7 +8,8 @@
 //     (acc[i][j][r] and acc[i][j + 2][r]) and the rotation is lane-local.  16 pairs never straddle a head (hd/2 = 48 or 32).
 //   * V tiles: the cache keeps V TRANSPOSED ([.., hd, t]).  These tiles are computed with the operand roles swapped -- W rows fill the
 //     tile's A side, the tokens its B side (the tile is square and the K loop does not care) -- so a lane holds 4 consecutive TOKENS of
-//     one V dimension, and 8 after the v_permlane16_swap: one 16-byte store into a V^T row.
+//     one V dimension, and 8 after the v_permlane16_swap: one 16-byte store into a V^T row (rows whose length is not a multiple of 8
+//     -- CLIP's 577-token crops -- shift the run inside the row: still one dwordx4 store at even offsets, three stores at odd ones).
 // Arithmetic: exactly p3v_gemm's + p3v_rope_kv_append's (the Linear output rounded to bf16, rotation in fp32 on those values,
 // q_scale before the one rounding): bit-identical to the two launches (tests/test_kernels_gpu.py::test_gemm_qkv_fused).
 #pragma once
@@ -142,14 +143,30 @@ __device__ __forceinline__ void qkv_epilogue_vt(const QkvP& q, f32x4_t (&acc)[NI
         auto sw = __builtin_amdgcn_permlane16_swap(pk[0][k], pk[1][k], false, false);
         w[k] = sw[0], w[2 + k] = sw[1];
       }
-      const int t = t_first + (2 * jp + (fq & 1)) * 16 + (fq >> 1) * 8;      // 8 consecutive tokens t .. t + 7 (one batch row: launcher)
+      const int t = t_first + (2 * jp + (fq & 1)) * 16 + (fq >> 1) * 8;      // 8 consecutive tokens t .. t + 7
       if (t < M) {
         const int mg = q.m_base + t, b = mg < q.L ? 0 : mg / q.L, l = mg - b * q.L;
         bf16_t* dst = q.v_dst + (((size_t)b * q.nkv + head) * q.hd + d) * (size_t)q.dst_t + q.dpos0 + l;
-        if (t + 8 <= M) {
-          *(u32x4_t*)dst = w;
-        } else {                                               // the ragged end of the prompt
-          for (int e = 0; e < M - t; ++e) dst[e] = (bf16_t)(w[e >> 1] >> (16 * (e & 1)));
+        if (t + 8 <= M && l + 8 <= q.L) {                      // the run lies in one batch row
+          if (!(l & 1)) {
+            // even token offset: the run is dword-aligned (16-byte aligned for one batch row, or rows of L % 8 == 0 tokens; round 6:
+            // any row length -- CLIP's 577-token crops start one token later in every crop) -- one dwordx4 store either way
+            typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+            *(u32x4_a4*)dst = w;
+          } else {                                             // odd offset: first token, three dwords of token pairs, last token
+            typedef uint32_t u32x3_a4 __attribute__((ext_vector_type(3), aligned(4)));
+            dst[0] = (bf16_t)w[0];
+            const u32x3_a4 mid = {__builtin_amdgcn_alignbyte(w[1], w[0], 2), __builtin_amdgcn_alignbyte(w[2], w[1], 2),
+                                  __builtin_amdgcn_alignbyte(w[3], w[2], 2)};
+            *(u32x3_a4*)(dst + 1) = mid;
+            dst[7] = (bf16_t)(w[3] >> 16);
+          }
+        } else {                                               // the ragged end of the prompt, or a run across two batch rows
+          for (int e = 0; e < 8 && t + e < M; ++e) {
+            int le = l + e, be = b;
+            if (le >= q.L) { le -= q.L; ++be; }
+            q.v_dst[(((size_t)be * q.nkv + head) * q.hd + d) * (size_t)q.dst_t + q.dpos0 + le] = (bf16_t)(w[e >> 1] >> (16 * (e & 1)));
+          }
         }
       }
     }

@@ -397,15 +397,16 @@ class Phi3VModel:
             ops.layernorm(x2, w[lp + "layer_norm1.weight"], w[lp + "layer_norm1.bias"], eps, out=h)
             wq, bq = self.clip_qkv[j]
             # head split; the queries leave it multiplied by scale * log2(e) like the decoder's (the attention's softmax is then the
-            # bare exp2: k_attn_prefill_dma<64, PRE> 59 -> 49 us per layer at 17 crops, tools/clip_attn_probe.py).  The split stays a
-            # launch of its own here: the projection's fused epilogue (ops.gemm_qkv) stores V^T as 16-byte runs of 8 tokens, which a
-            # crop of 577 tokens misaligns for every crop but the first (p3v_gemm_qkv declines B > 1 with L % 8 != 0; ADVICE r05: the
-            # call that could never apply is gone).  A padded 584-token layout would need the patch epilogue, the CLS rows, the HD
-            # merge and a separate key count in the attention to follow -- priced at 0.4 ms of a 28 ms prefill, not done.
+            # bare exp2: k_attn_prefill_dma<64, PRE> 59 -> 49 us per layer at 17 crops, tools/clip_attn_probe.py).  Round 6: the split
+            # rides in the projection's epilogue here too (ops.gemm_qkv: Q, K rows and V^T columns straight from the accumulators) --
+            # a crop is 577 tokens, so the 8-token V^T runs start one token later in every crop; the epilogue now stores them at
+            # whatever offset they fall on (one dwordx4 at even offsets, three stores at odd ones, element-wise across a crop end).
             pre = os.environ.get("P3V_VIT_PLAIN_Q") != "1"
             qs = 64 ** -0.5 * ops.Q_PRESCALE if pre else 1.0
-            ops.gemm(h, wq, EPI_BIAS, bias=bq, out=qkv)
-            ops.rope_kv_append(qkv, None, None, q, k, v, n, T, nh, nh, 64, 0, Tp, False, q_scale=qs)
+            if not (os.environ.get("P3V_QKV_FUSE", "1") != "0"
+                    and ops.gemm_qkv(h, wq, None, None, q, k, v, n, T, nh, nh, 64, 0, Tp, False, q_scale=qs, bias=bq)):
+                ops.gemm(h, wq, EPI_BIAS, bias=bq, out=qkv)
+                ops.rope_kv_append(qkv, None, None, q, k, v, n, T, nh, nh, 64, 0, Tp, False, q_scale=qs)
             ops.attention(q, o, n, T, nh, nh, 64, 64 ** -0.5, False, k_past=k, v_past=v, past_t=Tp, new_is_cache=True, q_prescaled=pre)
             ops.gemm(o, w[lp + "self_attn.out_proj.weight"], EPI_BIAS_RESID_F32, bias=w[lp + "self_attn.out_proj.bias"],
                      resid=x2, out=x2)

@@ -827,6 +827,10 @@ def test_merge_launch_with_fused_oproj_under_grouped_queries(ops):
     # short prompts (17 .. 256 rows): the 128 x 64-tile weight-streaming kernel, Q / K tiles in pair order + V tiles with swapped roles
     (1, 128, 32, 32, 96, 256, 0, True, False, -1), (1, 100, 32, 32, 96, 192, 0, True, False, -1), (1, 17, 32, 32, 96, 128, 64, True, False, -1),
     (1, 250, 8, 4, 96, 192, 8, True, False, -1), (2, 64, 16, 16, 64, 128, 0, False, False, -1),
+    # round 6: batch rows whose length is not a multiple of 8 (CLIP: 577-token crops) -- the V^T runs fall on even and odd offsets and
+    # across row ends
+    (17, 577, 16, 16, 64, 1024, 0, False, True, -1), (5, 577, 16, 16, 64, 128, 0, False, True, 0), (3, 1001, 8, 4, 96, 128, 0, True, False, -1),
+    (4, 61, 16, 16, 64, 128, 0, False, False, -1), (3, 85, 8, 4, 96, 192, 0, True, False, -1),
 ])
 def test_gemm_qkv_fused(ops, B, L, nh, nkv, hd, K, past, rot, bias, big):
     """p3v_gemm_qkv (qkv projection with head split + rotation + KV append in its epilogue) against the two calls it replaces --
@@ -860,11 +864,11 @@ def test_gemm_qkv_fused(ops, B, L, nh, nkv, hd, K, past, rot, bias, big):
 
 
 def test_gemm_qkv_declines_what_it_cannot_fuse(ops):
-    """Short prompts, unaligned append offsets and batch rows whose length is not a multiple of 8: P3V_ERR_UNSUPPORTED, nothing written."""
+    """Decode-sized inputs (<= 8 rows) and unaligned append offsets: P3V_ERR_UNSUPPORTED, nothing written."""
     nh, hd, K = 16, 64, 128
     N = 3 * nh * hd
     w = g((N, K), 410).cuda()
-    for B, L, past in ((1, 300, 0), (1, 1200, 3), (2, 1001, 0)):
+    for B, L, past in ((1, 8, 0), (1, 1200, 3), (2, 1001, 5)):
         a = g((B * L, K), 411).cuda()
         Tp = (past + L + 127) // 128 * 128
         q = torch.zeros((B, nh, L, hd), dtype=BF16, device="cuda")
