@@ -512,6 +512,45 @@ def c5_wc(act8=True):
     print("wrote", name)
 
 
+REL_TOL_Q4_WC = 0.02            # round 6: MLX 4-bit weights on the well-conditioned checkpoint (measured HIP-vs-oracle: see the test's output)
+
+
+def q4_quantisers(cfg, w):
+    """`quantize_model=True, quantize_format="int4"` applied to the oracle's weights: decoder projections + lm_head through the MLX
+    group quantiser (weights.mlx_quantize: group 64, 4 bits), kept as the exact fp32 values scale * q + bias -- what
+    mx.quantized_matmul multiplies by (phi_3_vision_mlx.py:264,296)."""
+    from phi_3_vision_mlx_amd.weights import mlx_dequantize, mlx_quantize
+    out = dict(w)
+    for k in w:
+        if k.startswith("model.layers.") and k.endswith("_proj.weight"):
+            out[k] = mlx_dequantize(*mlx_quantize(w[k])).float()
+    return out
+
+
+def q4_wc():
+    """`q4_wc_oracle.npz` (round 6): MLX 4-bit group-64 decoder weights on the WELL-CONDITIONED full-size checkpoint, BASELINE config
+    1's 128-token text prompt, 16 greedy steps under two unsearched heads (plain, peaked seed 0; both through the quantiser, as the
+    build quantises its lm_head).  Pins the round's 4-bit decode kernels at full size -- k_gemv3_q4 with the folded step ends
+    (p3v_gemv_q4_step), the merge launch with the 4-bit o_proj (k_attn_combine_o) -- and the dequantise + GEMM prefill against an
+    oracle that multiplies by the exact dequantised values."""
+    from phi_3_vision_mlx_amd.weights import mlx_dequantize, mlx_quantize
+    n_steps = 16
+    cfg, o, base = _full_oracle(q4_quantisers, residual_scale=1.0 / 1024)
+    ids = np.load(os.path.join(HERE, "c1_oracle.npz"))["ids"]
+    r = Prefilled(o, {"input_ids": ids}, n_steps, tag="q4wc")
+    r.rel_tol = REL_TOL_Q4_WC
+
+    def q(h):
+        return mlx_dequantize(*mlx_quantize(h.to(BF16))).float()
+    out = dict(COMMON, rel_tol=np.asarray([REL_TOL_Q4_WC], dtype=np.float32), n_ids=np.asarray([r.S], dtype=np.int32),
+               residual_scale=np.asarray([1.0 / 1024], dtype=np.float32), ids=ids)
+    for prefix, head in (("plain_", q(base)), ("peaked0_", q(peaked_lm_head(base.to(F32), SPREAD, 0)))):
+        res = r.greedy(head, n_steps)
+        pack_long(prefix, head, res, out, REL_TOL_Q4_WC)
+    np.savez_compressed(os.path.join(HERE, "q4_wc_oracle.npz"), **out)
+    print("wrote q4_wc_oracle.npz")
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # Heavy-tailed activations (weights.add_outliers: 6 residual-stream channels x 64, 2 key / value dimensions per head x 8).
 # Three arithmetic variants of config 2's request at FULL size, each against an oracle with the same weights / quantisers:
@@ -620,3 +659,5 @@ if __name__ == "__main__":
         c5_wc(True)
     if which == "c5w_wc":
         c5_wc(False)
+    if which == "q4_wc":
+        q4_wc()

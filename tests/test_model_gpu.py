@@ -986,6 +986,29 @@ def test_well_conditioned_config5_fixtures(name, kw5):
         torch.cuda.empty_cache()
 
 
+def test_well_conditioned_4bit_fixture():
+    """Round 6: MLX 4-bit group-64 decoder weights (`quantize_model=True, quantize_format="int4"`) at FULL size on the well-conditioned
+    checkpoint against the oracle on the exact dequantised values (gen_golden_oracle.q4_wc), BASELINE config 1's 128-token prompt, 16
+    greedy steps under two unsearched heads: every recorded logit within 2 % of max |z|, the token exact on every clear step.  The
+    steps run what round 6 built for this format: k_gemv3_q4 with the step's two ends folded in (p3v_gemv_q4_step) and the merge
+    launch that carries the 4-bit o_proj (k_attn_combine_o); the prefill dequantises per projection."""
+    from phi_3_vision_mlx_amd.api import load_synthetic
+    g = np.load(GOLDEN + "/q4_wc_oracle.npz")
+    rel_tol = float(g["rel_tol"][0])
+    assert rel_tol <= 0.02 + 1e-9
+    for prefix, kw in (("plain_", {}), ("peaked0_", dict(lm_head_spread=float(g["spread"][0]), lm_head_seed=0))):
+        model, proc = load_synthetic(blind_model=True, tiny=False, seed=0, device="cuda:0", residual_scale=float(g["residual_scale"][0]),
+                                     quantized_int4=True, **kw)
+        assert len(model.w4) == 32 * 4 + 1
+        inp = {"input_ids": g["ids"]}
+        assert np.asarray(inp["input_ids"]).shape[1] == int(g["n_ids"][0])
+        exact, n_clear, _ = _walk_long_fixture(model, inp, g, prefix, rel_tol, f"well-conditioned 4-bit weights, {prefix[:-1]} head vs the oracle")
+        assert exact == n_clear and n_clear >= 8
+        st = None
+        del model
+        torch.cuda.empty_cache()
+
+
 @pytest.mark.parametrize("name", ["c1", "c2"])
 def test_long_horizon_fixtures_full_size(name):
     """Token-level parity over the BENCHMARK'S horizon: the oracle's own greedy run of BASELINE config 1 over 128

@@ -176,6 +176,10 @@ def test_round6_well_conditioned_fixtures_are_what_the_gpu_tests_assume():
         assert float(g5["rel_tol"][0]) <= cap + 1e-9 and int(g5["n_ids"][0]) == 2531 and abs(float(g5["residual_scale"][0]) - 1 / 1024) < 1e-9
         assert g5["plain_tokens"].shape[1] == 8 and g5["peaked0_tokens"].shape[1] == 8
         assert int((g5["plain_margins"] > 1.0).sum()) + int((g5["peaked0_margins"] > 1.0).sum()) >= 3
+    q4 = np.load(os.path.join(GOLDEN, "q4_wc_oracle.npz"))          # MLX 4-bit weights, config 1's prompt, 16 steps
+    assert float(q4["rel_tol"][0]) <= 0.02 + 1e-9 and int(q4["n_ids"][0]) == 128 and abs(float(q4["residual_scale"][0]) - 1 / 1024) < 1e-9
+    assert q4["plain_tokens"].shape[1] == 16 and np.array_equal(q4["ids"], np.load(os.path.join(GOLDEN, "c1_oracle.npz"))["ids"])
+    assert int((q4["plain_margins"] > 1.0).sum()) >= 8 and int((q4["peaked0_margins"] > 1.0).sum()) >= 8
 
 
 def test_full_size_oracle_fixtures_equal_the_reference_composed_ones():
