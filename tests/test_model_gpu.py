@@ -1004,7 +1004,6 @@ def test_well_conditioned_4bit_fixture():
         assert np.asarray(inp["input_ids"]).shape[1] == int(g["n_ids"][0])
         exact, n_clear, _ = _walk_long_fixture(model, inp, g, prefix, rel_tol, f"well-conditioned 4-bit weights, {prefix[:-1]} head vs the oracle")
         assert exact == n_clear and n_clear >= 8
-        st = None
         del model
         torch.cuda.empty_cache()
 
