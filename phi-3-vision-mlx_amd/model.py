@@ -960,16 +960,19 @@ class Phi3VModel:
         kernels, same order).  P3V_PREFILL_GRAPH=0 switches it off.  Returns None when not applicable."""
         cfg = self.cfg
         if (os.environ.get("P3V_PREFILL_GRAPH", "1") == "0" or S <= ops.L.DECODE_MAX_L or S > self.PREFILL_GRAPH_MAX_S or max_tokens < 1
-                or getattr(cfg, "use_quantized_cache", False) or self.adapters or self.hidden_hook is not None or self.w8 or self.w4):
-            return None
+                or getattr(cfg, "use_quantized_cache", False) or self.adapters or self.hidden_hook is not None or self.w8):
+            return None                                           # (4-bit weights are captured too, round 6: their prefill is the bf16 one + a
+                                                                  #  dequantise launch per projection into the model's own scratch)
         if 4 * cfg.num_hidden_layers * cfg.num_key_value_heads * self.hd * (S + max_tokens + 256) > self.PREFILL_GRAPH_MAX_CACHE_BYTES:
             return None
         # the graph bakes in the rotation tables and the weight pointers: both are part of the key (tests mutate `cfg` and swap weight
         # tensors on a live model; in-place weight updates are seen by the graph as they are by every launch)
         nl = cfg.num_hidden_layers - 1
+        def wptr(k):
+            return self.w[k].data_ptr() if k in self.w else self.w4[k][0].data_ptr()
         key = (S, max_tokens, rope_scaling_factor(cfg), float(cfg.rope_theta), cfg.original_max_position_embeddings,
-               self.w["model.embed_tokens.weight"].data_ptr(), self.w["lm_head.weight"].data_ptr(),
-               self.w["model.layers.0.self_attn.qkv_proj.weight"].data_ptr(), self.w[f"model.layers.{nl}.mlp.down_proj.weight"].data_ptr())
+               self.w["model.embed_tokens.weight"].data_ptr(), wptr("lm_head.weight"),
+               wptr("model.layers.0.self_attn.qkv_proj.weight"), wptr(f"model.layers.{nl}.mlp.down_proj.weight"))
         e = self._prefill_graphs.get(key)
         if e is None:
             if self._prefill_seen.get(key, 0) < 1:                # first sighting: eager (one-off lengths never pay for a capture)

@@ -257,6 +257,31 @@ def test_captured_short_prompt_prefill_equals_eager(text, monkeypatch):
     model._prefill_graphs.clear(), model._prefill_seen.clear()
 
 
+def test_captured_short_prompt_prefill_with_4bit_weights_equals_eager(monkeypatch):
+    """Round 6: the captured short-prompt prefill also takes MLX 4-bit checkpoints (each projection = a dequantise launch into the model's
+    own scratch + the bf16 GEMM: the same launches, captured): logits and greedy continuation bit-identical to the eager path."""
+    from phi_3_vision_mlx_amd import ops
+    from phi_3_vision_mlx_amd.api import load_synthetic
+    model, _ = load_synthetic(blind_model=True, tiny=False, seed=0, device="cuda:0", num_hidden_layers=2, quantized_int4=True)
+    ids = rand_ids(57, 43)
+    out = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("P3V_PREFILL_GRAPH", mode)
+        for rep in range(3):                                     # (mode 1: eager, capture, replay)
+            lg, cache = model(input_ids=ids, max_tokens=6)
+            t = ops.argmax(lg[:, -1, :].contiguous())[:, None]
+            toks = []
+            for _ in range(3):
+                _, t = model.greedy_step(t, cache)
+                toks.append(t.clone())
+            got = (lg.clone(), torch.cat(toks, 1).clone())
+            if mode == "0" and rep == 0:
+                out["ref"] = got
+            assert torch.equal(got[0], out["ref"][0]) and torch.equal(got[1], out["ref"][1]), (mode, rep)
+            del cache
+    assert len(model._prefill_graphs) == 1
+
+
 def test_graph_decode_with_more_than_16_rows(text):
     """B = 20 rows: the decode projections are split-K GEMMs (M > 16), whose workspace the captured graph must own (ADVICE r03:
     no allocation under capture, no dangling pointer after a regrow).  Graph replays == eager steps, bit for bit, also after
